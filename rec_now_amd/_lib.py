@@ -1,0 +1,100 @@
+"""ctypes binding of librecnow_hip.so (the C ABI declared in include/recnow.h).
+
+There is deliberately NO CPU fallback: if the shared library is missing, or a tensor is not on the GPU, the call
+raises.  torch is used only for device memory, streams and autograd plumbing.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librecnow_hip.so')
+
+_c = ctypes
+_P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); kept in the order of include/recnow.h
+SIGNATURES = {
+    'recnow_abi_version': (_I, []),
+    'recnow_key_words': (_I, [_I]),
+    'recnow_group_keys': (_I, [_P, _I, _L, _P, _P, _P]),
+    'recnow_group_segments_workspace_bytes': (_Z, [_L, _I]),
+    'recnow_group_segments': (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    'recnow_pairwise_workspace_bytes': (_Z, [_L]),
+    'recnow_pair_count': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _Z, _P]),
+    'recnow_pair_offsets': (_I, [_P, _L, _P, _P, _Z, _P]),
+    'recnow_pair_emit': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _L, _P, _Z, _P]),
+    'recnow_pair_bpr_fwdbwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _P, _P, _P, _Z, _P]),
+    'recnow_bpr_loss_fwdbwd': (_I, [_P, _P, _P, _L, _F, _I, _P, _P, _P, _Z, _P]),
+    'recnow_pair_mask_dense': (_I, [_P, _P, _P, _L, _I, _P, _P]),
+    'recnow_occurance_power_weight': (_I, [_P, _P, _P, _L, _F, _P, _P]),
+    'recnow_fm_fwd': (_I, [_P, _I, _L, _I, _P, _P, _P]),
+    'recnow_fm_bwd': (_I, [_P, _P, _I, _L, _I, _P, _P, _P]),
+}
+
+_ERR = {-1: 'RECNOW_EINVAL', -2: 'RECNOW_EWORKSPACE', -3: 'RECNOW_EUNSUPPORTED'}
+_lib = None
+
+
+def load():
+    """Load librecnow_hip.so once.  torch must already be imported (it is, above) so that both share one HIP runtime."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'rec_now_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = symbol missing from the .so
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed: %s' % (what, _ERR.get(rc, 'hipError_t %d' % rc)))
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    check(rc, name)
+
+
+def require_gpu(t, what='tensor'):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %s' % (what, type(t)))
+    if not t.is_cuda:
+        raise RuntimeError('rec_now_amd computes only on the GPU (hand-written gfx950 kernels); %s is on %s. '
+                           'Move it with .cuda(); there is no CPU fallback.' % (what, t.device))
+    return t
+
+
+def f32c(t, what='tensor'):
+    """contiguous fp32 CUDA tensor (no copy when already so)."""
+    require_gpu(t, what)
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return _P(t.data_ptr())
+
+
+def stream():
+    return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def ptr_array(tensors, device):
+    """Device array of base pointers (int64) for list-of-tensor kernels."""
+    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(device, non_blocking=True)

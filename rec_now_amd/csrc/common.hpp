@@ -1,0 +1,94 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of librecnow_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/recnow.h"
+
+#define RN_WAVE 64
+
+// Forward a HIP error (positive hipError_t) across the C ABI; no exceptions.
+#define RN_HIP(expr)                                   \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return (int)_e;          \
+    } while (0)
+
+#define RN_LAUNCH_CHECK() RN_HIP(hipGetLastError())
+
+static inline size_t rn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int rn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Workspace carving: every carve is 256-B aligned so vector accesses stay aligned.
+struct RnCarver {
+    char* base;
+    size_t off;
+    size_t cap;
+    RnCarver(void* p, size_t c) : base((char*)p), off(0), cap(c) {}
+    template <typename T>
+    T* take(size_t n) {
+        T* r = (T*)(base + off);
+        off += rn_align(n * sizeof(T));
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// ---- wave64 reductions -------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). `red` = >= 16 elements of LDS.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    T r = (T)0;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+
+// ---- activations (enum recnow_act) -------------------------------------------------------------
+__device__ __forceinline__ float rn_sigmoid(float x) {
+    // stable logistic
+    if (x >= 0.f) {
+        float e = __expf(-x);
+        return 1.f / (1.f + e);
+    }
+    float e = __expf(x);
+    return e / (1.f + e);
+}
+__device__ __forceinline__ float rn_tanh(float x) { return tanhf(x); }
+
+__device__ __forceinline__ float rn_act(float x, int act) {
+    switch (act) {
+        case RECNOW_ACT_RELU: return x > 0.f ? x : 0.f;
+        case RECNOW_ACT_TANH: return tanhf(x);
+        case RECNOW_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        default: return x;
+    }
+}
+// derivative expressed through the OUTPUT y = act(z)
+__device__ __forceinline__ float rn_act_grad_from_out(float y, int act) {
+    switch (act) {
+        case RECNOW_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case RECNOW_ACT_TANH: return 1.f - y * y;
+        case RECNOW_ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}

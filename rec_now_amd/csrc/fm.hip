@@ -1,0 +1,148 @@
+// FM second-order interaction, /root/reference/rec_now/layers/fm_layer.py:24-42:
+//   y[b] = 0.5 * sum_d [ (sum_f x[f][b][d])^2 - sum_f x[f][b][d]^2 ]          dx[f][b][d] = g[b] * (S[b][d] - x[f][b][d])
+//
+// HBM-bound: algorithmic traffic 4*B*F*D (fwd) + 8*B*F*D (bwd) bytes.  The reference takes a LIST of F (B,D) tensors;
+// the kernel takes a device array of F base pointers, so no stacking copy is made.  Every field tensor is a flat
+// contiguous array of B*D floats; a thread owns one 16-byte chunk q of that flat index space for all F fields, so each
+// load instruction of a wave is 1 KiB contiguous (coalesced) and the loop over fields keeps 8 loads in flight.
+// S (the per-row field sum, B*D floats = 1/F of the input) is saved by forward so backward reads x exactly once.
+#include "common.hpp"
+
+#define FM_UNROLL 8
+
+template <bool SAVE_S>
+__global__ void __launch_bounds__(256)
+k_fm_fwd_vec4(const float* const* __restrict__ fields, int F, int64_t nchunk /* B*D/4 */, int lanes_per_row /* D/4, pow2 <= 64 */,
+              float* __restrict__ y, float* __restrict__ S) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // grid-stride in units that keep all lanes of a row inside one wave: blockDim (256) is a multiple of lanes_per_row
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x; q0 < nchunk; q0 += stride) {
+        const int64_t q = q0 + threadIdx.x;
+        const bool ok = q < nchunk;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(0.f, 0.f, 0.f, 0.f);
+        int f = 0;
+        for (; f + FM_UNROLL <= F; f += FM_UNROLL) {
+            float4 v[FM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FM_UNROLL; ++u)
+                v[u] = ok ? reinterpret_cast<const float4*>(fields[f + u])[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < FM_UNROLL; ++u) {
+                s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+                sq.x += v[u].x * v[u].x; sq.y += v[u].y * v[u].y; sq.z += v[u].z * v[u].z; sq.w += v[u].w * v[u].w;
+            }
+        }
+        for (; f < F; ++f) {
+            const float4 v = ok ? reinterpret_cast<const float4*>(fields[f])[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+        }
+        if (SAVE_S && ok) reinterpret_cast<float4*>(S)[q] = s;
+        float r = (s.x * s.x - sq.x) + (s.y * s.y - sq.y) + (s.z * s.z - sq.z) + (s.w * s.w - sq.w);
+        for (int o = lanes_per_row >> 1; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+        if (ok && (q % lanes_per_row) == 0) y[q / lanes_per_row] = 0.5f * r;
+    }
+}
+
+// generic shapes (D not a multiple of 4 or D/4 not a power of two <= 64): one thread per row
+template <bool SAVE_S>
+__global__ void __launch_bounds__(256)
+k_fm_fwd_generic(const float* const* __restrict__ fields, int F, int64_t B, int D, float* __restrict__ y, float* __restrict__ S) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float r = 0.f;
+    for (int d = 0; d < D; ++d) {
+        float s = 0.f, sq = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float v = fields[f][b * D + d];
+            s += v;
+            sq += v * v;
+        }
+        if (SAVE_S) S[b * D + d] = s;
+        r += s * s - sq;
+    }
+    y[b] = 0.5f * r;
+}
+
+__global__ void __launch_bounds__(256)
+k_fm_bwd_vec4(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int64_t nchunk,
+              int lanes_per_row, const float* __restrict__ S, const float* __restrict__ gy) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nchunk; q += stride) {
+        const float g = gy[q / lanes_per_row];
+        const float4 s = reinterpret_cast<const float4*>(S)[q];
+        int f = 0;
+        for (; f + FM_UNROLL <= F; f += FM_UNROLL) {
+            float4 v[FM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FM_UNROLL; ++u) v[u] = reinterpret_cast<const float4*>(fields[f + u])[q];
+#pragma unroll
+            for (int u = 0; u < FM_UNROLL; ++u)
+                reinterpret_cast<float4*>(dfields[f + u])[q] =
+                    make_float4(g * (s.x - v[u].x), g * (s.y - v[u].y), g * (s.z - v[u].z), g * (s.w - v[u].w));
+        }
+        for (; f < F; ++f) {
+            const float4 v = reinterpret_cast<const float4*>(fields[f])[q];
+            reinterpret_cast<float4*>(dfields[f])[q] =
+                make_float4(g * (s.x - v.x), g * (s.y - v.y), g * (s.z - v.z), g * (s.w - v.w));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_fm_bwd_generic(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int64_t B, int D,
+                 const float* __restrict__ S, const float* __restrict__ gy) {
+    const int64_t n = B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = gy[i / D], s = S[i];
+        for (int f = 0; f < F; ++f) dfields[f][i] = g * (s - fields[f][i]);
+    }
+}
+
+static inline bool fm_vec_ok(int D) {
+    if (D % 4) return false;
+    const int l = D / 4;
+    return l >= 1 && l <= 64 && (l & (l - 1)) == 0;
+}
+
+static inline int fm_grid(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    const int64_t cap = 256 * 8;          // 256 CUs x 8 blocks of 4 waves
+    return (int)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+// fields: device array of F pointers, each to a contiguous (B,D) fp32 tensor (16-byte aligned when D % 4 == 0).
+// y: [B];  S: [B*D] saved for backward (may be NULL: forward only).
+extern "C" int recnow_fm_fwd(const float* const* fields, int F, int64_t B, int D, float* y, float* S, void* stream) {
+    if (F < 1 || B < 0 || D < 1) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!fields || !y) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (fm_vec_ok(D)) {
+        const int64_t nchunk = B * D / 4;
+        if (S) hipLaunchKernelGGL(k_fm_fwd_vec4<true>, fm_grid(nchunk), 256, 0, st, fields, F, nchunk, D / 4, y, S);
+        else hipLaunchKernelGGL(k_fm_fwd_vec4<false>, fm_grid(nchunk), 256, 0, st, fields, F, nchunk, D / 4, y, S);
+    } else {
+        if (S) hipLaunchKernelGGL(k_fm_fwd_generic<true>, rn_cdiv(B, 256), 256, 0, st, fields, F, B, D, y, S);
+        else hipLaunchKernelGGL(k_fm_fwd_generic<false>, rn_cdiv(B, 256), 256, 0, st, fields, F, B, D, y, S);
+    }
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+// dfields: device array of F pointers to (B,D) gradient buffers; gy: [B] upstream gradient of y.
+extern "C" int recnow_fm_bwd(const float* const* fields, float* const* dfields, int F, int64_t B, int D, const float* S,
+                             const float* gy, void* stream) {
+    if (F < 1 || B < 0 || D < 1) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!fields || !dfields || !S || !gy) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (fm_vec_ok(D)) {
+        const int64_t nchunk = B * D / 4;
+        hipLaunchKernelGGL(k_fm_bwd_vec4, fm_grid(nchunk), 256, 0, st, fields, dfields, F, nchunk, D / 4, S, gy);
+    } else {
+        hipLaunchKernelGGL(k_fm_bwd_generic, fm_grid(B * D), 256, 0, st, fields, dfields, F, B, D, S, gy);
+    }
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}

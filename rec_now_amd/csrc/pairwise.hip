@@ -1,0 +1,343 @@
+// In-batch pairwise loss on sorted segments.  Replaces the (B,B) mask algebra, tile/transpose and boolean_mask
+// passes of /root/reference/rec_now/rec_block/pairwise_loss_from_batch.py:228-291 by one thread per row walking its
+// own segment.  Members of a segment are contiguous in sorted order and ascending in original row index (stable
+// sort), so "ascending sorted position" == "ascending j": the pair order of tf.boolean_mask over the row-major
+// flattened mask (:217, :272-273) is reproduced exactly.
+//
+// Integer/latency-bound: the member records (16 B each) of a segment are read by every lane of the segment at the
+// same time (wave-uniform broadcast loads served by L1), work is sum_g n_g^2 candidate compares.
+#include "common.hpp"
+#include "scan.hpp"
+
+struct __attribute__((aligned(16))) Member {   // one sorted row
+    float label;
+    float score;
+    int32_t row;      // original row index
+    int32_t valid;    // sample mask (1 = takes part)
+};
+
+__device__ __forceinline__ Member load_member(const float* __restrict__ scores, const float* __restrict__ labels,
+                                              const uint8_t* __restrict__ mask, const int32_t* __restrict__ order, int64_t k) {
+    Member m;
+    m.row = order[k];
+    m.label = labels[m.row];
+    m.score = scores[m.row];
+    m.valid = mask ? (mask[m.row] != 0) : 1;
+    return m;
+}
+
+__global__ void k_pack_members(const float* __restrict__ scores, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+                               const int32_t* __restrict__ order, int64_t B, Member* __restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < B) out[k] = load_member(scores, labels, mask, order, k);
+}
+
+template <int FLAGS>
+__device__ __forceinline__ bool pair_ok(const Member& a, const Member& b) {   // a = positive candidate, b = negative
+    bool ok = a.valid && b.valid;
+    if (FLAGS & RECNOW_PAIR_LABEL_GT) ok = ok && (a.label > b.label);
+    if (FLAGS & RECNOW_PAIR_WRONG_ORDER) ok = ok && (a.score < b.score);
+    return ok;
+}
+
+// ---- count ---------------------------------------------------------------------------------------
+template <int FLAGS>
+__global__ void __launch_bounds__(256)
+k_pair_count(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
+             const int32_t* __restrict__ super_id, int64_t B, int32_t* __restrict__ cnt_row,
+             unsigned long long* __restrict__ cnt_super, unsigned long long* __restrict__ n_pair) {
+    __shared__ long long red[16];
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long c = 0;
+    if (k < B) {
+        const Member me = mem[k];
+        const int g = seg_id[k];
+        const int s = seg_first[g], e = seg_first[g + 1];
+        int cc = 0;
+        for (int j = s; j < e; ++j) {
+            const Member o = mem[j];
+            cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
+        }
+        cnt_row[me.row] = cc;
+        if (cc) atomicAdd(&cnt_super[super_id[k]], (unsigned long long)cc);   // integer atomics: order-independent
+        c = cc;
+    }
+    c = block_sum<long long>(c, red);
+    if (threadIdx.x == 0 && c) atomicAdd(n_pair, (unsigned long long)c);
+}
+
+// ---- emit ----------------------------------------------------------------------------------------
+template <int FLAGS>
+__global__ void __launch_bounds__(256)
+k_pair_emit(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
+            int64_t B, const int64_t* __restrict__ offsets, int32_t* __restrict__ pos_idx, int32_t* __restrict__ neg_idx,
+            int64_t capacity) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const Member me = mem[k];
+    const int g = seg_id[k];
+    const int s = seg_first[g], e = seg_first[g + 1];
+    int64_t o = offsets[me.row];
+    for (int j = s; j < e; ++j) {
+        const Member ot = mem[j];
+        if (j != (int)k && pair_ok<FLAGS>(me, ot)) {
+            if (o < capacity) {
+                pos_idx[o] = me.row;
+                neg_idx[o] = ot.row;
+            }
+            ++o;
+        }
+    }
+}
+
+// ---- fused BPR forward + backward ------------------------------------------------------------------
+// softplus(-x) = max(-x,0) + log1p(exp(-|x|))  ==  TF's max(x,0) - x + log1p(exp(-|x|)) for labels = 1
+__device__ __forceinline__ float softplus_neg(float x) { return fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid_neg(float x) {   // sigma(-x), stable
+    const float e = expf(-fabsf(x));
+    return x >= 0.f ? e / (1.f + e) : 1.f / (1.f + e);
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(256)
+k_pair_bpr(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
+           const int32_t* __restrict__ super_id, const unsigned long long* __restrict__ cnt_super,
+           const unsigned long long* __restrict__ n_pair, int64_t B, float factor, float power, int reduce_mean,
+           double* __restrict__ block_loss, float* __restrict__ dscores) {
+    __shared__ double red[16];
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double lsum = 0.0;
+    if (k < B) {
+        const Member me = mem[k];
+        const int g = seg_id[k];
+        const int s = seg_first[g], e = seg_first[g + 1];
+        float w = 1.f;
+        if (power != 0.f) {
+            const float cnt = (float)cnt_super[super_id[k]];
+            w = (power == 1.f) ? cnt : powf(cnt, power);
+        }
+        float la = 0.f, ga = 0.f;
+        for (int j = s; j < e; ++j) {
+            if (j == (int)k) continue;
+            const Member o = mem[j];
+            if (pair_ok<FLAGS>(me, o)) {          // me is the positive of (me, o)
+                const float x = factor * (me.score - o.score);
+                la += softplus_neg(x);
+                ga -= sigmoid_neg(x);
+            }
+            if (pair_ok<FLAGS>(o, me)) {          // me is the negative of (o, me)
+                const float x = factor * (o.score - me.score);
+                ga += sigmoid_neg(x);
+            }
+        }
+        const float denom = reduce_mean ? ((float)(*n_pair) + 1.0e-10f) : 1.f;
+        dscores[me.row] = w * factor * ga / denom;
+        lsum = (double)(w * la);
+    }
+    lsum = block_sum<double>(lsum, red);
+    if (threadIdx.x == 0) block_loss[blockIdx.x] = lsum;
+}
+
+__global__ void __launch_bounds__(1024)
+k_loss_finalize(const double* __restrict__ part, int n, const unsigned long long* __restrict__ n_pair, int64_t p_host,
+                int reduce_mean, float* __restrict__ loss) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];     // fixed order per thread, fixed tree
+    s = block_sum<double>(s, red);
+    if (threadIdx.x == 0) {
+        float v = (float)s;
+        if (reduce_mean) {
+            const float P = n_pair ? (float)(*n_pair) : (float)p_host;
+            v = v / (P + 1.0e-10f);
+        }
+        *loss = v;
+    }
+}
+
+// ---- explicit-vector bpr_loss_func -----------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_bpr_vec(const float* __restrict__ pos, const float* __restrict__ neg, const float* __restrict__ weights, int64_t P,
+          float factor, int reduce_mean, double* __restrict__ block_loss, float* __restrict__ dpos) {
+    __shared__ double red[16];
+    double lsum = 0.0;
+    const float denom = reduce_mean ? ((float)P + 1.0e-10f) : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = factor * (pos[i] - neg[i]);
+        const float w = weights ? weights[i] : 1.f;
+        lsum += (double)(w * softplus_neg(x));
+        dpos[i] = -w * factor * sigmoid_neg(x) / denom;
+    }
+    lsum = block_sum<double>(lsum, red);
+    if (threadIdx.x == 0) block_loss[blockIdx.x] = lsum;
+}
+
+// ---- dense mask / occurrence weights (API parity helpers) ---------------------------------------------
+__global__ void k_pair_mask_dense(const int32_t* __restrict__ order, const int32_t* __restrict__ seg_id,
+                                  const int32_t* __restrict__ seg_first, int64_t B, int only_upper_band, uint8_t* __restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const int i = order[k];
+    const int g = seg_id[k];
+    for (int j = seg_first[g]; j < seg_first[g + 1]; ++j) {
+        const int r = order[j];
+        if (r == i) continue;
+        if (only_upper_band && r != i + 1) continue;
+        out[(int64_t)i * B + r] = 1;
+    }
+}
+
+__global__ void k_occ_weight(const int32_t* __restrict__ order, const int32_t* __restrict__ seg_id,
+                             const int32_t* __restrict__ seg_first, int64_t B, float power, float* __restrict__ w) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const int g = seg_id[k];
+    const float c = (float)(seg_first[g + 1] - seg_first[g]);
+    w[order[k]] = (power == 1.f) ? c : powf(c, power);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+#define RN_PW_T 256
+#define RN_VEC_BLOCKS 1024
+
+extern "C" size_t recnow_pairwise_workspace_bytes(int64_t B) {
+    if (B < 0) return 0;
+    size_t s = rn_align((size_t)(B + 1) * sizeof(Member));
+    size_t nb = (size_t)rn_cdiv(B > 0 ? B : 1, RN_PW_T);
+    if (nb < RN_VEC_BLOCKS) nb = RN_VEC_BLOCKS;
+    s += rn_align(nb * sizeof(double));
+    s += rn_scan_ws_bytes(B);
+    return s;
+}
+
+#define RN_DISPATCH_FLAGS(KERNEL, ...)                                                          \
+    switch (flags & 3) {                                                                        \
+        case 0: hipLaunchKernelGGL(KERNEL<0>, G, RN_PW_T, 0, st, __VA_ARGS__); break;           \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, G, RN_PW_T, 0, st, __VA_ARGS__); break;           \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, G, RN_PW_T, 0, st, __VA_ARGS__); break;           \
+        default: hipLaunchKernelGGL(KERNEL<3>, G, RN_PW_T, 0, st, __VA_ARGS__); break;          \
+    }
+
+// The Member array lives at the start of the pairwise workspace; every entry point re-packs it (B x 16 B).
+static int pack_members(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order, int64_t B,
+                        Member* mem, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_members, rn_cdiv(B, 256), 256, 0, st, scores, labels, mask, order, B, mem);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_pair_count(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
+                                 const int32_t* seg_id, const int32_t* seg_first, const int32_t* super_id, int64_t B,
+                                 int flags, int32_t* cnt_row, int64_t* cnt_super, int64_t* n_pair, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (B < 0 || !n_pair) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    RN_HIP(hipMemsetAsync(n_pair, 0, sizeof(int64_t), st));
+    if (B == 0) return RECNOW_OK;
+    if (!scores || !labels || !order || !seg_id || !seg_first || !super_id || !cnt_row || !cnt_super || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
+    Member* mem = (Member*)ws;
+    RN_HIP(hipMemsetAsync(cnt_super, 0, (size_t)B * sizeof(int64_t), st));
+    int rc = pack_members(scores, labels, mask, order, B, mem, st);
+    if (rc) return rc;
+    const int G = rn_cdiv(B, RN_PW_T);
+    RN_DISPATCH_FLAGS(k_pair_count, mem, seg_id, seg_first, super_id, B, cnt_row, (unsigned long long*)cnt_super,
+                      (unsigned long long*)n_pair);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_pair_offsets(const int32_t* cnt_row, int64_t B, int64_t* offsets, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || !offsets) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        RN_HIP(hipMemsetAsync(offsets, 0, sizeof(int64_t), st));
+        return RECNOW_OK;
+    }
+    if (!cnt_row || !ws) return RECNOW_EINVAL;
+    return rn_exclusive_scan_i32_i64(cnt_row, offsets, B, ws, ws_bytes, st);
+}
+
+extern "C" int recnow_pair_emit(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
+                                const int32_t* seg_id, const int32_t* seg_first, int64_t B, int flags, const int64_t* offsets,
+                                int32_t* pos_idx, int32_t* neg_idx, int64_t capacity, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || capacity < 0) return RECNOW_EINVAL;
+    if (B == 0 || capacity == 0) return RECNOW_OK;
+    if (!scores || !labels || !order || !seg_id || !seg_first || !offsets || !pos_idx || !neg_idx || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Member* mem = (Member*)ws;
+    int rc = pack_members(scores, labels, mask, order, B, mem, st);
+    if (rc) return rc;
+    const int G = rn_cdiv(B, RN_PW_T);
+    RN_DISPATCH_FLAGS(k_pair_emit, mem, seg_id, seg_first, B, offsets, pos_idx, neg_idx, capacity);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
+                                      const int32_t* seg_id, const int32_t* seg_first, const int32_t* super_id,
+                                      const int64_t* cnt_super, const int64_t* n_pair, int64_t B, int flags, float factor,
+                                      float power, int reduce_mean, float* loss, float* dscores, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    if (B < 0 || !loss) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        RN_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+        return RECNOW_OK;
+    }
+    if (!scores || !labels || !order || !seg_id || !seg_first || !super_id || !n_pair || !dscores || !ws) return RECNOW_EINVAL;
+    if (power != 0.f && !cnt_super) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
+    RnCarver c(ws, ws_bytes);
+    Member* mem = c.take<Member>(B + 1);
+    const int G = rn_cdiv(B, RN_PW_T);
+    double* part = c.take<double>(G > RN_VEC_BLOCKS ? G : RN_VEC_BLOCKS);
+    int rc = pack_members(scores, labels, mask, order, B, mem, st);
+    if (rc) return rc;
+    RN_DISPATCH_FLAGS(k_pair_bpr, mem, seg_id, seg_first, super_id, (const unsigned long long*)cnt_super,
+                      (const unsigned long long*)n_pair, B, factor, power, reduce_mean, part, dscores);
+    hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, part, G, (const unsigned long long*)n_pair, (int64_t)0, reduce_mean, loss);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_bpr_loss_fwdbwd(const float* pos, const float* neg, const float* weights, int64_t P, float factor,
+                                      int reduce_mean, float* loss, float* dpos, void* ws, size_t ws_bytes, void* stream) {
+    if (P < 0 || !loss) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (P == 0) {
+        RN_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+        return RECNOW_OK;
+    }
+    if (!pos || !neg || !dpos || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < rn_align(RN_VEC_BLOCKS * sizeof(double))) return RECNOW_EWORKSPACE;
+    double* part = (double*)ws;
+    int G = rn_cdiv(P, 256);
+    if (G > RN_VEC_BLOCKS) G = RN_VEC_BLOCKS;
+    hipLaunchKernelGGL(k_bpr_vec, G, 256, 0, st, pos, neg, weights, P, factor, reduce_mean, part, dpos);
+    hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, part, G, (const unsigned long long*)nullptr, P, reduce_mean, loss);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_pair_mask_dense(const int32_t* order, const int32_t* seg_id, const int32_t* seg_first, int64_t B,
+                                      int only_upper_band, uint8_t* mask_out, void* stream) {
+    if (B < 0) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!order || !seg_id || !seg_first || !mask_out) return RECNOW_EINVAL;
+    hipLaunchKernelGGL(k_pair_mask_dense, rn_cdiv(B, 256), 256, 0, (hipStream_t)stream, order, seg_id, seg_first, B,
+                       only_upper_band, mask_out);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_occurance_power_weight(const int32_t* order, const int32_t* seg_id, const int32_t* seg_first, int64_t B,
+                                             float power, float* w_out, void* stream) {
+    if (B < 0) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!order || !seg_id || !seg_first || !w_out) return RECNOW_EINVAL;
+    hipLaunchKernelGGL(k_occ_weight, rn_cdiv(B, 256), 256, 0, (hipStream_t)stream, order, seg_id, seg_first, B, power, w_out);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}

@@ -1,0 +1,345 @@
+// Grouping machinery (integer path): canonical keys, stable LSD radix sort of row indices, device-wide scans,
+// segment detection.  Replaces the reference's dense (B,B) same-group mask
+// (/root/reference/rec_now/rec_block/pairwise_loss_from_batch.py:16-40,43-74) and tf.unique_with_counts
+// (/root/reference/rec_now/rec_block/listwise_loss_from_batch.py:109).
+//
+// HBM-bound integer work on <= a few MB: everything here is about few launches, coalesced 4-B streams and
+// LDS-resident counters, not MFMA.
+#include "common.hpp"
+#include "scan.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// keys
+// ------------------------------------------------------------------------------------------------
+__global__ void k_keys_f32(const float* __restrict__ g, int64_t B, uint32_t* __restrict__ w0, uint8_t* __restrict__ solo) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float v = g[i];
+    uint32_t u = __float_as_uint(v);
+    if (v == 0.0f) u = 0u;                       // -0.0 == +0.0
+    if (!(fabsf(v) < INFINITY)) solo[i] = 1;      // NaN, +-inf: v - v is NaN -> equals nothing
+    w0[i] = u;
+}
+__global__ void k_keys_f64(const double* __restrict__ g, int64_t B, uint32_t* __restrict__ w, uint8_t* __restrict__ solo) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    double v = g[i];
+    uint64_t u = (uint64_t)__double_as_longlong(v);
+    if (v == 0.0) u = 0ull;
+    if (!(fabs(v) < (double)INFINITY)) solo[i] = 1;
+    w[i] = (uint32_t)(u >> 32);
+    w[B + i] = (uint32_t)u;
+}
+__global__ void k_keys_i32(const int32_t* __restrict__ g, int64_t B, uint32_t* __restrict__ w0) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) w0[i] = (uint32_t)g[i];
+}
+__global__ void k_keys_i64(const int64_t* __restrict__ g, int64_t B, uint32_t* __restrict__ w) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    uint64_t u = (uint64_t)g[i];
+    w[i] = (uint32_t)(u >> 32);
+    w[B + i] = (uint32_t)u;
+}
+
+extern "C" int recnow_key_words(int dtype) {
+    switch (dtype) {
+        case RECNOW_KEY_F32: case RECNOW_KEY_I32: return 1;
+        case RECNOW_KEY_F64: case RECNOW_KEY_I64: return 2;
+        default: return RECNOW_EINVAL;
+    }
+}
+
+extern "C" int recnow_group_keys(const void* group, int dtype, int64_t B, uint32_t* words, uint8_t* solo, void* stream) {
+    if (B < 0 || recnow_key_words(dtype) < 0) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!group || !words || !solo) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = 256, G = rn_cdiv(B, T);
+    switch (dtype) {
+        case RECNOW_KEY_F32: hipLaunchKernelGGL(k_keys_f32, G, T, 0, st, (const float*)group, B, words, solo); break;
+        case RECNOW_KEY_F64: hipLaunchKernelGGL(k_keys_f64, G, T, 0, st, (const double*)group, B, words, solo); break;
+        case RECNOW_KEY_I32: hipLaunchKernelGGL(k_keys_i32, G, T, 0, st, (const int32_t*)group, B, words); break;
+        case RECNOW_KEY_I64: hipLaunchKernelGGL(k_keys_i64, G, T, 0, st, (const int64_t*)group, B, words); break;
+    }
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix sort of row indices by n_words x 32-bit keys, 8-bit digits, LSD, stable.
+// Only the index array is permuted; a pass gathers its digit through the index (arrays are <= a few MB -> L2).
+// Passes whose digit is constant over all rows are skipped on the device (plan), so float-encoded small ids
+// cost 2-3 passes instead of 4.
+// ------------------------------------------------------------------------------------------------
+#define RN_MAX_WORDS 8
+#define RN_MAX_PASS (4 * RN_MAX_WORDS)
+#define RN_TILE 2048          // keys per block per pass (256 threads x 8)
+
+struct SortPlan {
+    int trivial[RN_MAX_PASS];
+    int src[RN_MAX_PASS];     // which index buffer (0/1) pass p reads
+    int final_buf;            // buffer holding the sorted order after the last pass
+    int pad[3];
+};
+
+// global histograms of every digit of every word (permutation invariant -> computed once, on the input order)
+__global__ void k_sort_ghist(const uint32_t* __restrict__ words, int64_t B, int n_words, unsigned* __restrict__ ghist) {
+    extern __shared__ unsigned sh[];           // [n_words*4][256]
+    const int nb = n_words * 4 * 256;
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) sh[t] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        for (int w = 0; w < n_words; ++w) {
+            uint32_t k = words[(int64_t)w * B + i];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) atomicAdd(&sh[(w * 4 + d) * 256 + ((k >> (8 * d)) & 255u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nb; t += blockDim.x)
+        if (sh[t]) atomicAdd(&ghist[t], sh[t]);
+}
+
+// pass p sorts by word w = n_words-1 - p/4, digit d = p%4 (LSD overall)
+__global__ void k_sort_plan(const unsigned* __restrict__ ghist, int64_t B, int n_words, SortPlan* plan) {
+    __shared__ int triv[RN_MAX_PASS];
+    const int np = n_words * 4;
+    if (threadIdx.x < RN_MAX_PASS) triv[threadIdx.x] = 0;
+    __syncthreads();
+    for (int p = 0; p < np; ++p) {
+        const int w = n_words - 1 - p / 4, d = p % 4;
+        if (ghist[(w * 4 + d) * 256 + threadIdx.x] == (unsigned)B) triv[p] = 1;   // one bin holds every row
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int cur = 0;
+        for (int p = 0; p < np; ++p) {
+            plan->trivial[p] = triv[p];
+            plan->src[p] = cur;
+            if (!triv[p]) cur ^= 1;
+        }
+        plan->final_buf = cur;
+    }
+}
+
+__global__ void k_iota(int32_t* a, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (int32_t)i;
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_blockhist(const uint32_t* __restrict__ words, int64_t B, int n_words, int pass, const SortPlan* __restrict__ plan,
+                 const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1, unsigned* __restrict__ blockhist, int nblk) {
+    if (plan->trivial[pass]) return;
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t* src = plan->src[pass] ? idx1 : idx0;
+    const uint32_t* wk = words + (int64_t)(n_words - 1 - pass / 4) * B;
+    const int shift = 8 * (pass % 4);
+    const int64_t base = (int64_t)blockIdx.x * RN_TILE;
+#pragma unroll
+    for (int r = 0; r < RN_TILE / 256; ++r) {
+        int64_t e = base + r * 256 + threadIdx.x;
+        if (e < B) atomicAdd(&h[(wk[src[e]] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    blockhist[(int64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];   // digit-major
+}
+
+// exclusive scan of blockhist[256*nblk] in place, single block of 1024 threads
+__global__ void __launch_bounds__(1024)
+k_sort_scan(unsigned* __restrict__ blockhist, int n, int pass, const SortPlan* __restrict__ plan) {
+    if (plan->trivial[pass]) return;
+    __shared__ unsigned wsum[16];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    unsigned s = 0;
+    for (int i = lo; i < hi; ++i) s += blockhist[i];
+    // block exclusive scan of s
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned woff = 0;
+    for (int i = 0; i < w; ++i) woff += wsum[i];
+    unsigned run = woff + inc - s;
+    for (int i = lo; i < hi; ++i) {
+        unsigned v = blockhist[i];
+        blockhist[i] = run;
+        run += v;
+    }
+}
+
+// stable scatter: wave w of the block owns RN_TILE/4 consecutive keys, 8 rounds of 64 consecutive keys.
+__global__ void __launch_bounds__(256)
+k_sort_scatter(const uint32_t* __restrict__ words, int64_t B, int n_words, int pass, const SortPlan* __restrict__ plan,
+               int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, const unsigned* __restrict__ blockoff, int nblk) {
+    if (plan->trivial[pass]) return;
+    __shared__ unsigned wcnt[4][256];
+    for (int t = threadIdx.x; t < 1024; t += 256) (&wcnt[0][0])[t] = 0;
+    __syncthreads();
+    const int sb = plan->src[pass];
+    const int32_t* src = sb ? idx1 : idx0;
+    int32_t* dst = sb ? idx0 : idx1;
+    const uint32_t* wk = words + (int64_t)(n_words - 1 - pass / 4) * B;
+    const int shift = 8 * (pass % 4);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wbase = (int64_t)blockIdx.x * RN_TILE + w * (RN_TILE / 4);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int32_t my_idx[RN_TILE / 256];
+    unsigned my_dr[RN_TILE / 256];        // digit | (rank_in_wave << 8)
+#pragma unroll
+    for (int r = 0; r < RN_TILE / 256; ++r) {
+        const int64_t e = wbase + r * 64 + lane;
+        const bool ok = e < B;
+        int32_t id = ok ? src[e] : 0;
+        unsigned d = ok ? ((wk[id] >> shift) & 255u) : 0u;
+        unsigned long long peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        unsigned prior = ok ? wcnt[w][d] : 0u;                 // every lane reads before any leader adds
+        const unsigned rank = prior + (unsigned)__popcll(peers & lt);
+        if (ok && (peers & lt) == 0ull) wcnt[w][d] = prior + (unsigned)__popcll(peers);   // leader = lowest peer
+        my_idx[r] = id;
+        my_dr[r] = d | (rank << 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RN_TILE / 256; ++r) {
+        const int64_t e = wbase + r * 64 + lane;
+        if (e < B) {
+            const unsigned d = my_dr[r] & 255u, rank = my_dr[r] >> 8;
+            unsigned off = blockoff[(int64_t)d * nblk + blockIdx.x] + rank;
+            for (int pw = 0; pw < w; ++pw) off += wcnt[pw][d];
+            dst[off] = my_idx[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// segments
+// ------------------------------------------------------------------------------------------------
+__global__ void k_seg_heads(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int64_t B, int n_words,
+                            int n_words_first, const SortPlan* __restrict__ plan, const int32_t* __restrict__ idx0,
+                            const int32_t* __restrict__ idx1, int32_t* __restrict__ order, int32_t* __restrict__ head,
+                            int32_t* __restrict__ shead) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const int32_t* fin = plan->final_buf ? idx1 : idx0;
+    const int32_t i = fin[k];
+    order[k] = i;
+    int h = 1, sh = 1;
+    if (k > 0) {
+        const int32_t j = fin[k - 1];
+        const bool s = solo[i] | solo[j];
+        bool diff_first = false, diff_any = false;
+        for (int w = 0; w < n_words; ++w) {
+            const bool d = words[(int64_t)w * B + i] != words[(int64_t)w * B + j];
+            diff_any |= d;
+            if (w < n_words_first) diff_first |= d;
+        }
+        h = (s || diff_any) ? 1 : 0;
+        sh = (s || diff_first) ? 1 : 0;
+    }
+    head[k] = h;
+    shead[k] = sh;
+}
+
+__global__ void k_seg_finish(const int32_t* __restrict__ head, const int32_t* __restrict__ seg_incl,
+                             const int32_t* __restrict__ super_incl, int64_t B, int32_t* __restrict__ seg_id,
+                             int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const int32_t g = seg_incl[k] - 1;
+    seg_id[k] = g;
+    super_id[k] = super_incl[k] - 1;
+    if (head[k]) seg_first[g] = (int32_t)k;
+    if (k == B - 1) {
+        seg_first[g + 1] = (int32_t)B;
+        n_seg[0] = g + 1;
+        n_seg[1] = super_incl[k];
+    }
+}
+
+__global__ void k_seg_empty(int32_t* seg_first, int32_t* n_seg) {
+    seg_first[0] = 0;
+    n_seg[0] = 0;
+    n_seg[1] = 0;
+}
+
+extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) {
+    if (B < 0 || n_words < 1 || n_words > RN_MAX_WORDS) return 0;
+    const int nblk = rn_cdiv(B > 0 ? B : 1, RN_TILE);
+    size_t s = 0;
+    s += rn_align(sizeof(SortPlan));
+    s += rn_align((size_t)n_words * 4 * 256 * sizeof(unsigned));    // ghist
+    s += 2 * rn_align((size_t)(B + 1) * sizeof(int32_t));           // idx0, idx1
+    s += rn_align((size_t)256 * nblk * sizeof(unsigned));           // blockhist
+    s += 4 * rn_align((size_t)(B + 1) * sizeof(int32_t));           // head, shead, seg_incl, super_incl
+    s += rn_scan_ws_bytes(B);
+    return s;
+}
+
+extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo, int64_t B, int n_words, int n_words_first,
+                                     int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id, int32_t* n_seg,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || B > 0x7fffff00ll || n_words < 1 || n_words > RN_MAX_WORDS || n_words_first < 1 || n_words_first > n_words)
+        return RECNOW_EINVAL;
+    if (!seg_first || !n_seg) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        hipLaunchKernelGGL(k_seg_empty, 1, 1, 0, st, seg_first, n_seg);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
+    if (!words || !solo || !order || !seg_id || !super_id || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_group_segments_workspace_bytes(B, n_words)) return RECNOW_EWORKSPACE;
+    const int nblk = rn_cdiv(B, RN_TILE);
+    RnCarver c(ws, ws_bytes);
+    SortPlan* plan = c.take<SortPlan>(1);
+    unsigned* ghist = c.take<unsigned>((size_t)n_words * 4 * 256);
+    int32_t* idx0 = c.take<int32_t>(B + 1);
+    int32_t* idx1 = c.take<int32_t>(B + 1);
+    unsigned* blockhist = c.take<unsigned>((size_t)256 * nblk);
+    int32_t* head = c.take<int32_t>(B + 1);
+    int32_t* shead = c.take<int32_t>(B + 1);
+    int32_t* seg_incl = c.take<int32_t>(B + 1);
+    int32_t* super_incl = c.take<int32_t>(B + 1);
+    void* scan_ws = (void*)(c.base + c.off);
+    size_t scan_ws_bytes = ws_bytes - c.off;
+
+    RN_HIP(hipMemsetAsync(ghist, 0, (size_t)n_words * 4 * 256 * sizeof(unsigned), st));
+    const int T = 256, G = rn_cdiv(B, T);
+    hipLaunchKernelGGL(k_iota, G, T, 0, st, idx0, B);
+    {
+        int gh = rn_cdiv(B, 256 * 8);
+        if (gh > 512) gh = 512;
+        hipLaunchKernelGGL(k_sort_ghist, gh, 256, (size_t)n_words * 4 * 256 * sizeof(unsigned), st, words, B, n_words, ghist);
+    }
+    hipLaunchKernelGGL(k_sort_plan, 1, 256, 0, st, ghist, B, n_words, plan);
+    for (int p = 0; p < n_words * 4; ++p) {
+        hipLaunchKernelGGL(k_sort_blockhist, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, blockhist, nblk);
+        hipLaunchKernelGGL(k_sort_scan, 1, 1024, 0, st, blockhist, 256 * nblk, p, plan);
+        hipLaunchKernelGGL(k_sort_scatter, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, blockhist, nblk);
+    }
+    hipLaunchKernelGGL(k_seg_heads, G, T, 0, st, words, solo, B, n_words, n_words_first, plan, idx0, idx1, order, head, shead);
+    RN_LAUNCH_CHECK();
+    int rc = rn_inclusive_scan_i32(head, seg_incl, B, scan_ws, scan_ws_bytes, st);
+    if (rc) return rc;
+    rc = rn_inclusive_scan_i32(shead, super_incl, B, scan_ws, scan_ws_bytes, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_seg_finish, G, T, 0, st, head, seg_incl, super_incl, B, seg_id, seg_first, super_id, n_seg);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}

@@ -1,0 +1,33 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/recnow.h declares; the ctypes table binds
+every one of them.  No compute call is made (no GPU here)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'recnow.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(recnow_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from rec_now_amd import _lib
+    names = _declared()
+    assert len(names) >= 10
+    lib = _lib.load()
+    for n in names:
+        assert hasattr(lib, n), 'librecnow_hip.so does not export %s' % n
+        assert n in _lib.SIGNATURES, '%s is not bound in rec_now_amd/_lib.py' % n
+    for n in _lib.SIGNATURES:
+        assert n in names, '%s is bound but not declared in include/recnow.h' % n
+    assert lib.recnow_abi_version() >= 1
+
+
+def test_cpu_tensor_is_refused_loudly():
+    import pytest
+    import torch
+    from rec_now_amd.layers.fm_layer import FMLayer
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        FMLayer()([torch.zeros(2, 4), torch.zeros(2, 4)])

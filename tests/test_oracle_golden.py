@@ -1,0 +1,125 @@
+"""CPU: the oracle (oracle/dense_ref.py) against every golden the reference's own hot-path tests hold
+(SURVEY.md section 4).  This is what pins the oracle; the GPU parity tests then compare HIP vs oracle."""
+import numpy as np
+import torch
+
+import dense_ref as R
+
+T = torch.from_numpy
+TOL = 1e-5   # reference tolerance: sum|diff| < 1e-5 (util/numpy_tools.py metric)
+
+
+def test_fm(golden):
+    g = golden('fm')
+    out = R.fm_layer([T(x) for x in g['inputs']])
+    assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+
+
+def test_dcn(golden):
+    g = golden('dcn')
+    out = R.dcn_layer(T(g['inputs']), [T(g['kernel_%d' % i]) for i in range(3)], [T(g['bias_%d' % i]) for i in range(3)])
+    assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+
+
+def test_multi_dense(golden):
+    for name in ('multi_dense_2d', 'multi_dense_3d'):
+        g = golden(name)
+        out = R.multi_dense_layer(T(g['inputs']), T(g['kernel']), T(g['bias']))
+        assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+
+
+def test_multi_dense_wrong_leading_dim_raises():
+    # tests/layers/test_multi_dense_layer.py:57-73
+    try:
+        R.multi_dense_layer(torch.zeros(4, 2, 4), torch.zeros(3, 4, 1))
+    except ValueError:
+        return
+    raise AssertionError('expected an error')
+
+
+def test_mmoe(golden):
+    g = golden('mmoe')
+    out = R.mmoe_layer(T(g['inputs']), [T(g['expert_kernel_0']), T(g['expert_kernel_1'])],
+                       [T(g['expert_bias_0']), T(g['expert_bias_1'])], T(g['gate_kernel']), T(g['gate_bias']))
+    assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+
+
+def test_dcn_mix(golden):
+    g = golden('dcn_mix')
+    L = 2
+    pick = lambda fmt: [T(g[fmt % l]) for l in range(L)]   # noqa: E731
+    out = R.dcn_mix_layer(T(g['inputs']), pick('origin_to_sub_kernels_of_layer%d'), pick('sub_to_sub_kernels_of_layer%d'),
+                          pick('sub_to_origin_kernels_of_layer%d'), pick('bias_of_layer%d'), pick('gate_of_layer%d'))
+    assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+
+
+def test_cin(golden):
+    g = golden('cin')
+    out = R.cin_layer([T(x) for x in g['inputs']], [T(g['weight_of_layer1']), T(g['weight_of_layer2'])], 10, 3)
+    assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+
+
+def ple_layers_from_fixture(g, to=T):
+    layers = []
+    for li in range(3):
+        layer = {'dnn': [], 'gate': []}
+        for gi in range(3):
+            layer['dnn'].append([(to(g['l%d_g%d_dnn%d_kernel' % (li, gi, di)]), to(g['l%d_g%d_dnn%d_bias' % (li, gi, di)]))
+                                 for di in range(2)])
+            key = 'l%d_g%d_gate_kernel' % (li, gi)
+            layer['gate'].append((to(g[key]), to(g['l%d_g%d_gate_bias' % (li, gi)])) if key in g else None)
+        layers.append(layer)
+    return layers
+
+
+def test_ple(golden):
+    g = golden('ple')
+    out = R.ple_layer(T(g['inputs']), ple_layers_from_fixture(g), [True, False, False])
+    assert R.calc_sum_of_abs_diff(out[0].numpy(), g['golden_task1']) < TOL
+    assert R.calc_sum_of_abs_diff(out[1].numpy(), g['golden_task2']) < TOL
+
+
+# ---- literal-input goldens (no RNG) -------------------------------------------------------------------
+def _pairwise_case():
+    g = torch.tensor([1, 1, 2, 2, 2.]).reshape(-1, 1)
+    s = torch.tensor([0, 1, 2, 3, 4.]).reshape(-1, 1)
+    y = torch.tensor([1.1, 0, 0, 1, 1]).reshape(-1, 1)
+    return g, s, y
+
+
+def test_occurance_power_weight():
+    # tests/rec_block/test_pairwise_loss_from_batch.py:19-31
+    ids = [1, 1, 2, 4, 4, 4]
+    np.testing.assert_allclose(R.occurance_power_weight(ids, -1).numpy(), [.5, .5, 1, 1 / 3, 1 / 3, 1 / 3], atol=1e-4)
+    np.testing.assert_allclose(R.occurance_power_weight(ids, 2).numpy(), [4, 4, 1, 9, 9, 9], atol=1e-4)
+
+
+def test_pairwise_goldens():
+    # tests/rec_block/test_pairwise_loss_from_batch.py:33-74
+    g, s, y = _pairwise_case()
+    f = lambda p, n, w: R.bpr_loss_func(p, n, w, 1.0)   # noqa: E731
+    assert abs(R.pairwise_loss(s, y, g, f, click_occurance_power=-0.5).item() - 0.5415076) < 1e-4
+    wf = lambda a, b, **k: (a > b).float()              # noqa: E731
+    assert abs(R.pairwise_loss(s, y, g, f, click_occurance_power=-0.5, label_pair_to_weight_func=wf).item() - 0.5415076) < 1e-4
+    m = torch.tensor([True, True, False, False, False]).reshape(-1, 1)
+    assert abs(R.pairwise_loss(s, y, g, f, click_occurance_power=-0.5, mask=m).item() - 1.3132617) < 1e-4
+
+
+def test_listwise_goldens():
+    # tests/rec_block/test_listwise_loss_from_batch.py:18-51
+    g = torch.tensor([1, 1, 2, 1, 2, 2, 3, 4.])
+    y = torch.tensor([1, 1, 1, 0, 0, 0, 1, 0.])
+    s = torch.tensor([.1, .01, .2, .001, .02, .002, .3, .4])
+    m, lab, lg = R.to_listwise_sample(g, y, s)
+    assert lab.shape[0] == 2
+    assert abs(R.listwise_loss_via_softmax_cross_entropy_with_logits(lab, lg).item() - 1.0291535) < 1e-4
+    m, lab, lg = R.to_listwise_sample(torch.tensor([3., 4.]), torch.tensor([1., 0.]), torch.tensor([.3, .4]))
+    assert lab.shape[0] == 0
+    assert abs(R.listwise_loss_via_softmax_cross_entropy_with_logits(lab, lg).item()) < 1e-4
+
+
+def test_pair_order_is_row_major():
+    g = torch.tensor([7., 3., 7., 3., 7.])
+    y = torch.tensor([1., 0., 0., 1., 2.])
+    pos, neg = R.pair_indices(y, g)
+    assert pos.tolist() == [0, 3, 4, 4] and neg.tolist() == [2, 1, 0, 2]

@@ -1,0 +1,228 @@
+"""GPU parity: rec_now_amd.rec_block.pairwise_loss_from_batch (HIP, through the C ABI) vs the oracle.
+Reads like the reference's tests/rec_block/test_pairwise_loss_from_batch.py, plus randomized / edge cases.
+Integer outputs (pair indices, counts) must be bit-exact; floats within 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+import dense_ref as R
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _mod():
+    from rec_now_amd.rec_block import pairwise_loss_from_batch as M
+    return M
+
+
+def _case(dev):
+    g = torch.tensor([[1, 1, 2, 2, 2.]], device=dev).t()
+    s = torch.tensor([[0, 1, 2, 3, 4.]], device=dev).t()
+    y = torch.tensor([[1.1, 0, 0, 1, 1]], device=dev).t()
+    return g, s, y
+
+
+def test_occurance_power_weight(dev):
+    M = _mod()
+    ids = [1, 1, 2, 4, 4, 4]
+    for e, r in zip([0.5, 0.5, 1., 0.33333334, 0.33333334, 0.33333334], M.occurance_power_weight(ids, power=-1).cpu().numpy()):
+        assert abs(e - r) < 1e-4
+    for e, r in zip([4., 4., 1., 9., 9., 9.], M.occurance_power_weight(ids, power=2).cpu().numpy()):
+        assert abs(e - r) < 1e-4
+
+
+def test_pairwise_loss_reference_goldens(dev):
+    # /root/reference/tests/rec_block/test_pairwise_loss_from_batch.py:33-74
+    M = _mod()
+    g, s, y = _case(dev)
+
+    def pairwise_loss_func(outputs_pos, outputs_neg, weights):
+        return M.bpr_loss_func(outputs_pos, outputs_neg, weights, 1.0)
+
+    loss = M.pairwise_loss(s, y, g, pairwise_loss_func, only_use_wrong_order_pair=False, click_occurance_power=-0.5)
+    assert abs(loss.item() - 0.5415076) < 1e-4
+
+    def _label_pair_to_weight_func(label_matrix, label_matrix_transpose, **kwargs):
+        return (label_matrix > label_matrix_transpose).to(torch.float32)
+
+    loss = M.pairwise_loss(s, y, g, pairwise_loss_func, only_use_wrong_order_pair=False, click_occurance_power=-0.5,
+                           label_pair_to_weight_func=_label_pair_to_weight_func)
+    assert abs(loss.item() - 0.5415076) < 1e-4
+    mask = torch.tensor([[True, True, False, False, False]], device=dev).t()
+    loss = M.pairwise_loss(s, y, g, pairwise_loss_func, only_use_wrong_order_pair=False, click_occurance_power=-0.5, mask=mask)
+    assert abs(loss.item() - 1.3132617) < 1e-4
+    # fused path (default pairloss_func) gives the same three numbers
+    assert abs(M.pairwise_loss(s, y, g, click_occurance_power=-0.5).item() - 0.5415076) < 1e-4
+    assert abs(M.pairwise_loss(s, y, g, click_occurance_power=-0.5, mask=mask).item() - 1.3132617) < 1e-4
+
+
+def _random_case(B, n_groups, seed, label_levels=2, float_scores=True):
+    rng = np.random.default_rng(seed)
+    groups = rng.integers(0, n_groups, B).astype(np.float32)
+    scores = rng.normal(size=B).astype(np.float32)
+    if label_levels == 2:
+        labels = (rng.random(B) < 0.25).astype(np.float32)
+    else:
+        labels = rng.integers(0, label_levels, B).astype(np.float32)
+    return groups, scores, labels
+
+
+@pytest.mark.parametrize('B,G,seed', [(1, 1, 0), (2, 1, 1), (64, 4, 2), (257, 7, 3), (2048, 32, 4), (4096, 1, 5), (3000, 3000, 6)])
+def test_pair_indices_bit_exact(dev, B, G, seed):
+    M = _mod()
+    g, s, y = _random_case(B, G, seed, label_levels=3)
+    for wrong in (False, True):
+        pos, neg = M.pair_indices(torch.from_numpy(s).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(g).to(dev),
+                                  only_use_wrong_order_pair=wrong)
+        rpos, rneg = R.pair_indices(torch.from_numpy(y), torch.from_numpy(g), wrong, torch.from_numpy(s))
+        assert pos.dtype == torch.int32
+        assert np.array_equal(pos.cpu().numpy(), rpos.numpy().astype(np.int32))
+        assert np.array_equal(neg.cpu().numpy(), rneg.numpy().astype(np.int32))
+
+
+@pytest.mark.parametrize('B,G,seed', [(64, 4, 10), (1000, 17, 11), (2048, 32, 12), (4096, 2, 13)])
+@pytest.mark.parametrize('power', [0.0, -0.5, 1.0])
+@pytest.mark.parametrize('wrong', [False, True])
+def test_fused_loss_and_grad_vs_oracle(dev, B, G, seed, power, wrong):
+    M = _mod()
+    g, s, y = _random_case(B, G, seed)
+    rng = np.random.default_rng(seed + 100)
+    mask = rng.random(B) < 0.8
+    sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+    loss, n_pair = M.pairwise_loss(sd, torch.from_numpy(y).to(dev), torch.from_numpy(g).to(dev), only_use_wrong_order_pair=wrong,
+                                   return_num_pair=True, click_occurance_power=power, mask=torch.from_numpy(mask).to(dev))
+    loss.backward()
+    s64 = torch.from_numpy(s).double().requires_grad_(True)
+    rloss, rn = R.pairwise_loss(s64, torch.from_numpy(y).double(), torch.from_numpy(g), only_use_wrong_order_pair=wrong,
+                                return_num_pair=True, click_occurance_power=power, mask=torch.from_numpy(mask))
+    rloss.backward()
+    assert n_pair.item() == rn                                        # integer path: exact
+    assert abs(loss.item() - rloss.item()) <= RTOL * max(1.0, abs(rloss.item()))
+    gr = s64.grad.numpy()
+    scale = max(np.abs(gr).max(), 1e-12)
+    assert np.abs(sd.grad.cpu().numpy() - gr).max() <= RTOL * scale
+
+
+def test_general_path_custom_callables_vs_oracle(dev):
+    M = _mod()
+    g, s, y = _random_case(777, 13, 21, label_levels=4)
+    wf = lambda a, b, **k: torch.clamp(a - b, min=0.0) * k.get('scale', 1.0)   # noqa: E731
+    sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+    lf = lambda p, n, w: M.bpr_loss_func(p, n, w, 0.7)                       # noqa: E731
+    loss = M.pairwise_loss(sd, torch.from_numpy(y).to(dev), torch.from_numpy(g).to(dev), lf, click_occurance_power=-1.0,
+                           label_pair_to_weight_func=wf, scale=2.0)
+    loss.backward()
+    s64 = torch.from_numpy(s).double().requires_grad_(True)
+    rlf = lambda p, n, w: R.bpr_loss_func(p, n, w, 0.7)                      # noqa: E731
+    rloss = R.pairwise_loss(s64, torch.from_numpy(y).double(), torch.from_numpy(g), rlf, click_occurance_power=-1.0,
+                            label_pair_to_weight_func=wf, scale=2.0)
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) <= RTOL * max(1.0, abs(rloss.item()))
+    gr = s64.grad.numpy()
+    assert np.abs(sd.grad.cpu().numpy() - gr).max() <= RTOL * max(np.abs(gr).max(), 1e-12)
+
+
+def test_group_list_and_int_ids(dev):
+    M = _mod()
+    rng = np.random.default_rng(5)
+    B = 1500
+    g0 = rng.integers(0, 9, B)
+    g1 = rng.integers(0, 3, B)
+    s = rng.normal(size=B).astype(np.float32)
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    sd = torch.from_numpy(s).to(dev)
+    # list of groups (AND), groups[0] drives the occurrence weights
+    loss = M.pairwise_loss(sd, torch.from_numpy(y).to(dev), [torch.from_numpy(g0.astype(np.float32)).to(dev),
+                                                            torch.from_numpy(g1.astype(np.float32)).to(dev)],
+                           click_occurance_power=-0.5)
+    rloss = R.pairwise_loss(torch.from_numpy(s).double(), torch.from_numpy(y).double(),
+                            [torch.from_numpy(g0.astype(np.float32)), torch.from_numpy(g1.astype(np.float32))],
+                            click_occurance_power=-0.5)
+    assert abs(loss.item() - rloss.item()) <= RTOL * max(1.0, abs(rloss.item()))
+    # int64 ids beyond 2^24 compare exactly (floats would collide); int32 too
+    big = (g0.astype(np.int64) + (1 << 40))
+    pos, neg = M.pair_indices(sd, torch.from_numpy(y).to(dev), torch.from_numpy(big).to(dev))
+    rpos, rneg = R.pair_indices(torch.from_numpy(y), torch.from_numpy(g0.astype(np.float32)))
+    assert np.array_equal(pos.cpu().numpy(), rpos.numpy()) and np.array_equal(neg.cpu().numpy(), rneg.numpy())
+
+
+def test_float_group_semantics_B1(dev):
+    # -0.0 == +0.0, NaN/inf pair with nobody (g_i - g_j == 0.0 in float)
+    M = _mod()
+    g = torch.tensor([0.0, -0.0, float('nan'), float('nan'), float('inf'), float('inf'), 5.0, 5.0])
+    y = torch.tensor([1., 0., 1., 0., 1., 0., 1., 0.])
+    s = torch.zeros(8)
+    pos, neg = M.pair_indices(s.to(dev), y.to(dev), g.to(dev))
+    rpos, rneg = R.pair_indices(y, g)
+    assert pos.cpu().tolist() == rpos.tolist() == [0, 6] and neg.cpu().tolist() == rneg.tolist() == [1, 7]
+
+
+def test_no_pairs_gives_zero_loss_and_grad(dev):
+    M = _mod()
+    s = torch.randn(16, device=dev, requires_grad=True)
+    y = torch.ones(16, device=dev)
+    g = torch.arange(16, device=dev, dtype=torch.float32) // 4
+    loss, n = M.pairwise_loss(s, y, g, return_num_pair=True)
+    loss.backward()
+    assert loss.item() == 0.0 and n.item() == 0.0 and float(s.grad.abs().max()) == 0.0
+
+
+def test_generate_pair_mask_and_vec_to_matrix_pair(dev):
+    M = _mod()
+    g = torch.tensor([1, 1, 2, 2, 2.], device=dev)
+    m = M.generate_pair_mask(g)
+    assert np.array_equal(m.cpu().numpy(), R.generate_pair_mask(g.cpu()).numpy())
+    mb = M.generate_pair_mask([g, g], only_upper_band=True)
+    assert np.array_equal(mb.cpu().numpy(), R.generate_pair_mask([g.cpu(), g.cpu()], True).numpy())
+    a, at = M.vec_to_matrix_pair(g.reshape(1, -1))
+    ra, rat = R.vec_to_matrix_pair(g.cpu())
+    assert np.array_equal(a.cpu().numpy(), ra.numpy()) and np.array_equal(at.cpu().numpy(), rat.numpy())
+
+
+def test_bpr_loss_func_options(dev):
+    M = _mod()
+    rng = np.random.default_rng(0)
+    p, n, w = (rng.normal(size=333).astype(np.float32) for _ in range(3))
+    w = np.abs(w)
+    for factor in (1.0, 2.5):
+        for rm in (True, False):
+            pd = torch.from_numpy(p).to(dev).requires_grad_(True)
+            nd = torch.from_numpy(n).to(dev).requires_grad_(True)
+            out = M.bpr_loss_func(pd, nd, torch.from_numpy(w).to(dev), factor, rm)
+            out.backward()
+            p64 = torch.from_numpy(p).double().requires_grad_(True)
+            n64 = torch.from_numpy(n).double().requires_grad_(True)
+            ref = R.bpr_loss_func(p64, n64, torch.from_numpy(w).double(), factor, rm)
+            ref.backward()
+            assert abs(out.item() - ref.item()) <= RTOL * max(1.0, abs(ref.item()))
+            assert np.abs(pd.grad.cpu().numpy() - p64.grad.numpy()).max() <= RTOL * np.abs(p64.grad.numpy()).max()
+            assert np.abs(nd.grad.cpu().numpy() - n64.grad.numpy()).max() <= RTOL * np.abs(n64.grad.numpy()).max()
+
+
+def test_full_size_properties_config3(dev):
+    """B=65536 (BASELINE config 3 size): size-independent properties instead of the O(B^2) oracle:
+    n_pair == sum_g pos_g*neg_g, sum of gradients == 0 (each pair contributes +-sigma), loss invariant under a
+    row permutation, and bitwise run-to-run determinism."""
+    M = _mod()
+    B = 65536
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 1024, B)
+    s = rng.normal(size=B).astype(np.float32)
+    y = (rng.random(B) < 0.25).astype(np.float32)
+    gd, yd = torch.from_numpy(g.astype(np.float32)).to(dev), torch.from_numpy(y).to(dev)
+    sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+    loss, n_pair = M.pairwise_loss(sd, yd, gd, return_num_pair=True)
+    loss.backward()
+    pos_g = np.bincount(g, weights=y, minlength=1024)
+    cnt_g = np.bincount(g, minlength=1024)
+    assert int(n_pair.item()) == int((pos_g * (cnt_g - pos_g)).sum())
+    grad = sd.grad.double().cpu().numpy()
+    assert abs(grad.sum()) < 1e-6
+    perm = rng.permutation(B)
+    loss_p = M.pairwise_loss(torch.from_numpy(s[perm]).to(dev), torch.from_numpy(y[perm]).to(dev),
+                             torch.from_numpy(g[perm].astype(np.float32)).to(dev))
+    assert abs(loss_p.item() - loss.item()) <= 1e-5 * abs(loss.item())
+    loss2 = M.pairwise_loss(sd.detach(), yd, gd)
+    assert loss2.item() == loss.item()
