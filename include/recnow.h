@@ -140,6 +140,105 @@ int recnow_fm_fwd(const float* const* fields, int F, int64_t B, int D, float* y,
 int recnow_fm_bwd(const float* const* fields, float* const* dfields, int F, int64_t B, int D, const float* S,
                   const float* gy, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32: every product/accumulate is an fp32 fma, no reduced precision),
+ * the dense contraction under MultiDenseLayer (multi_dense_layer.py:90), DCNMixLayer (dcn_mix_layer.py:135-141),
+ * MMOELayer / PLELayer experts and gates.  Bound: fp32 MFMA peak (157 TFLOP/s), not HBM.
+ *     C[b] = epilogue( opA(A[b]) x opB(B[b]) ),   b = 0 .. batch-1
+ *     epilogue(v) = act(v + bias[n]) * emul[m][n]  (+ C[m][n] when accumulate)
+ * Operand modes fuse the elementwise producer of a gradient GEMM into the operand load:
+ *     MUL:      operand[i] * second[i]                       ACTGRAD:  operand[i] * act'(second[i]), act' through the
+ *                                                                      activation OUTPUT (1-y^2, y(1-y), y>0)
+ * A batch stride of 0 broadcasts that operand.  K-splitting (deterministic slab reduce) is chosen internally when
+ * M*N is small and K is large (weight gradients, K = batch rows).
+ * ---------------------------------------------------------------------------------------------------------- */
+#define RECNOW_OPMODE_NONE 0
+#define RECNOW_OPMODE_MUL 1
+#define RECNOW_OPMODE_ACTGRAD 2
+
+typedef struct recnow_gemm_desc {
+    const float* A;  const float* A2; int64_t lda; int64_t a_batch_stride; int a_trans; int a_mode; int a_act; int a_pad;
+    const float* B;  const float* B2; int64_t ldb; int64_t b_batch_stride; int b_trans; int b_mode; int b_act; int b_pad;
+    float* C; int64_t ldc; int64_t c_batch_stride;
+    int M, N, K, batch;               /* logical A: (M,K), B: (K,N), C: (M,N) */
+    const float* bias; int64_t bias_batch_stride;
+    const float* emul; int64_t lde; int64_t e_batch_stride;
+    int act;                          /* RECNOW_ACT_* applied to columns < act_cols (act_cols <= 0: all columns) */
+    int act_cols;
+    int e_mode; int e_act;            /* e_mode 0/MUL: v *= emul[m][n];  ACTGRAD: v *= act'(emul[m][n]) (e_act) */
+    int accumulate;
+    /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
+     * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
+} recnow_gemm_desc;
+
+size_t recnow_gemm_workspace_bytes(const recnow_gemm_desc* desc_host);
+int recnow_gemm(const recnow_gemm_desc* desc_host, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * MultiDenseLayer: rec_now/layers/multi_dense_layer.py:80-94.   y[n] = act(x[n] @ kernel[n] + bias[n])
+ *   x: (B,D) when x_batched == 0 (broadcast to every n, :88-89) else (N,B,D); kernel (N,D,U); bias (N,1,U) or NULL;
+ *   y: (N,B,U).  act must be a RECNOW_ACT_* code (other activations are applied by the caller on the linear output).
+ * Backward (derived from the forward lines; the reference leaves it to TF autodiff):
+ *   dZ = dy * act'(y);  dkernel[n] = x[n]^T dZ[n];  dbias[n] = colsum dZ[n];  dx[n] = dZ[n] kernel[n]^T (summed over n
+ *   when x was broadcast).  Any of dx / dkernel / dbias may be NULL (not needed).
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t recnow_multi_dense_workspace_bytes(int64_t B, int D, int U, int N);
+int recnow_multi_dense_fwd(const float* x, int x_batched, const float* kernel, const float* bias, int64_t B, int D, int U,
+                           int N, int act, float* y, void* ws, size_t ws_bytes, void* stream);
+int recnow_multi_dense_bwd(const float* x, int x_batched, const float* kernel, const float* y, const float* dy, int64_t B,
+                           int D, int U, int N, int act, float* dx, float* dkernel, float* dbias, void* ws, size_t ws_bytes,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Gate mixing of MMOELayer (mmoe_layer.py:109-117) and PLELayer (ple_layer.py:274-293):
+ *   g[t][b][:] = softmax(logits[t][b][:]);   out[t][b][:] = sum_n g[t][b][n] * E_n[b][:]
+ * experts: DEVICE array of N device pointers, expert n is a contiguous (B,U) matrix (so PLE's "own + shared" expert
+ * subsets need no concat copy).  logits, gates: (T,B,N); out: (T,B,U).  HBM-bound.
+ * Backward: dexperts[n] (+)= sum_t g*dout;  dlogits = g * (dg - sum_n g*dg), dg[t][b][n] = dout[t][b][:] . E_n[b][:].
+ * accumulate_dexperts != 0 adds into dexperts (an expert feeding several gates).
+ * ---------------------------------------------------------------------------------------------------------- */
+int recnow_moe_mix_fwd(const float* logits, const float* const* experts, int T, int64_t B, int N, int U, float* gates,
+                       float* out, void* stream);
+int recnow_moe_mix_bwd(const float* gates, const float* const* experts, const float* dout, int T, int64_t B, int N, int U,
+                       float* dlogits, float* const* dexperts, int accumulate_dexperts, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * DCNLayer (DCN-v1 cross, reference variant without residual): rec_now/layers/dcn_layer.py:79-103
+ *   x_{l+1} = act(x0 * (x_l . w_l) + b_l),  l = 0..L-1;  all L layers fused in one pass over x0 (HBM-bound: 8*B*D
+ *   bytes forward, 20*B*D backward incl. the recompute read).
+ *   kernels: (L,D) (row l = kernel_l[:,0]); biases: (L,D) or NULL (use_bias=False); y: (B,D).
+ * Backward recomputes the forward per row from x0 (nothing saved): dx (B,D), dkernels (L,D), dbiases (L,D) or NULL.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t recnow_dcn_workspace_bytes(int64_t B, int D, int L);
+int recnow_dcn_fwd(const float* x, const float* kernels, const float* biases, int64_t B, int D, int L, int act, float* y,
+                   void* stream);
+int recnow_dcn_bwd(const float* x, const float* kernels, const float* biases, const float* dy, int64_t B, int D, int L,
+                   int act, float* dx, float* dkernels, float* dbiases, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * DCNMixLayer (DCN-v2 mixture of low-rank experts, reference variant without residual):
+ * rec_now/layers/dcn_mix_layer.py:114-151.  Per layer l (x_0 = x):
+ *   A = x_l U_n -> act_inner -> (. V_n) -> act_outer -> (. W_n + b_n) -> * x   ;   gates = softmax(x_l K)
+ *   x_{l+1} = sum_n gates[:,n] * (...)_n
+ * Weight pointer arrays are HOST arrays of L DEVICE pointers:
+ *   U[l]: (N,D,S) origin_to_sub_kernels_of_layer{l};  V[l]: (N,S,S) sub_to_sub_...;  W[l]: (N,S,D) sub_to_origin_...;
+ *   bias[l]: (1,N,D) bias_of_layer{l};  gate[l]: (D,N) gate_of_layer{l} kernel (Dense, use_bias=False).
+ * The two D-sized contractions per layer run on the exact-fp32 MFMA GEMM with the gate logits folded in as extra
+ * columns and the gate-weighted bias folded in as extra K rows; `saved` keeps the small (B x ~(N*S+N)) activations
+ * and the layer inputs for backward.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int L);
+size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N, int L);
+int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, const float* const* V_host, const float* const* W_host,
+                       const float* const* bias_host, const float* const* gate_host, int64_t B, int D, int S, int N, int L,
+                       int act_inner, int act_outer, float* y, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                       void* stream);
+int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* const* V_host, const float* const* W_host,
+                       const float* const* bias_host, const float* const* gate_host, const float* dy, const void* saved,
+                       size_t saved_bytes, int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* dx,
+                       float* const* dU_host, float* const* dV_host, float* const* dW_host, float* const* dbias_host,
+                       float* const* dgate_host, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,35 @@ SIGNATURES = {
     'recnow_occurance_power_weight': (_I, [_P, _P, _P, _L, _F, _P, _P]),
     'recnow_fm_fwd': (_I, [_P, _I, _L, _I, _P, _P, _P]),
     'recnow_fm_bwd': (_I, [_P, _P, _I, _L, _I, _P, _P, _P]),
+    'recnow_gemm_workspace_bytes': (_Z, [_P]),
+    'recnow_gemm': (_I, [_P, _P, _Z, _P]),
+    'recnow_multi_dense_workspace_bytes': (_Z, [_L, _I, _I, _I]),
+    'recnow_multi_dense_fwd': (_I, [_P, _I, _P, _P, _L, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    'recnow_multi_dense_bwd': (_I, [_P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    'recnow_moe_mix_fwd': (_I, [_P, _P, _I, _L, _I, _I, _P, _P, _P]),
+    'recnow_moe_mix_bwd': (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _I, _P]),
+    'recnow_dcn_workspace_bytes': (_Z, [_L, _I, _I]),
+    'recnow_dcn_fwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    'recnow_dcn_bwd': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    'recnow_dcn_mix_saved_bytes': (_Z, [_L, _I, _I, _I, _I]),
+    'recnow_dcn_mix_workspace_bytes': (_Z, [_L, _I, _I, _I, _I]),
+    'recnow_dcn_mix_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P]),
+    'recnow_dcn_mix_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
+                                 _Z, _P]),
 }
+
+
+class GemmDesc(ctypes.Structure):
+    """recnow_gemm_desc of include/recnow.h (host struct of device pointers and sizes)."""
+    _fields_ = [
+        ('A', _P), ('A2', _P), ('lda', _L), ('a_batch_stride', _L), ('a_trans', _I), ('a_mode', _I), ('a_act', _I), ('a_pad', _I),
+        ('B', _P), ('B2', _P), ('ldb', _L), ('b_batch_stride', _L), ('b_trans', _I), ('b_mode', _I), ('b_act', _I), ('b_pad', _I),
+        ('C', _P), ('ldc', _L), ('c_batch_stride', _L),
+        ('M', _I), ('N', _I), ('K', _I), ('batch', _I),
+        ('bias', _P), ('bias_batch_stride', _L),
+        ('emul', _P), ('lde', _L), ('e_batch_stride', _L),
+        ('act', _I), ('act_cols', _I), ('e_mode', _I), ('e_act', _I), ('accumulate', _I),
+    ]
 
 _ERR = {-1: 'RECNOW_EINVAL', -2: 'RECNOW_EWORKSPACE', -3: 'RECNOW_EUNSUPPORTED'}
 _lib = None

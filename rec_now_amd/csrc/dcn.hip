@@ -1,0 +1,275 @@
+// DCNLayer (DCN-v1 cross network, reference variant WITHOUT residual), /root/reference/rec_now/layers/dcn_layer.py:79-103:
+//     x_{l+1} = act( x0 * (x_l . w_l) + b_l ),   l = 0 .. L-1
+// HBM-bound.  All L layers are fused: a row of x0 lives in the registers of TPR threads (one wave, or one 256-thread
+// workgroup for wide rows), every layer is a dot-reduce + elementwise update on registers, so forward moves 8*B*D
+// bytes (read x0, write y) and backward 16*B*D (read x0, dy; write dx) + tiny weight-gradient slabs.
+// Backward saves nothing: it recomputes x_l from x0 for each layer (O(L^2) dot-reduces on registers, L <= 4).
+// Weight/bias gradients accumulate in registers over the rows a thread group owns, are combined per workgroup through
+// LDS and finally summed over workgroups by the deterministic column-sum (no float atomics).
+#include "gemm.hpp"
+
+#define DCN_MAX_L 4
+
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v, float* red /* [rows_per_block][4] */) {
+    v = wave_sum(v);
+    if (TPR == 64) return v;
+    // 256 threads = 4 waves share one row
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <int TPR, int VEC, int NV>
+struct RowRegs {
+    float v[NV][VEC];
+};
+
+template <int TPR, int VEC, int NV>
+__device__ __forceinline__ void row_load(float (&r)[NV][VEC], const float* __restrict__ p, int D, int t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = (i * TPR + t) * VEC;
+        if (VEC == 4) {
+            float4 q = (d < D) ? *reinterpret_cast<const float4*>(p + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r[i][0] = q.x; r[i][1 % VEC] = q.y; r[i][2 % VEC] = q.z; r[i][3 % VEC] = q.w;
+        } else {
+            r[i][0] = (d < D) ? p[d] : 0.f;
+        }
+    }
+}
+template <int TPR, int VEC, int NV>
+__device__ __forceinline__ void row_store(const float (&r)[NV][VEC], float* __restrict__ p, int D, int t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int d = (i * TPR + t) * VEC;
+        if (d < D) {
+            if (VEC == 4) *reinterpret_cast<float4*>(p + d) = make_float4(r[i][0], r[i][1 % VEC], r[i][2 % VEC], r[i][3 % VEC]);
+            else p[d] = r[i][0];
+        }
+    }
+}
+template <int VEC, int NV>
+__device__ __forceinline__ float row_dot(const float (&a)[NV][VEC], const float (&b)[NV][VEC]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += a[i][e] * b[i][e];
+    return s;
+}
+
+template <int TPR, int VEC, int NV>
+__global__ void __launch_bounds__(256)
+k_dcn_fwd(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases, int64_t B, int D, int L,
+          int act, float* __restrict__ y) {
+    __shared__ float red[4];
+    constexpr int RPB = 256 / TPR;
+    const int t = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
+    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += (int64_t)gridDim.x * RPB) {
+        const int64_t row = row0 + rsub;
+        const bool ok = row < B;
+        float x0[NV][VEC], xl[NV][VEC], w[NV][VEC], bb[NV][VEC];
+        row_load<TPR, VEC, NV>(x0, x + (ok ? row : 0) * D, ok ? D : 0, t);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) xl[i][e] = x0[i][e];
+        for (int l = 0; l < L; ++l) {
+            row_load<TPR, VEC, NV>(w, kernels + (int64_t)l * D, D, t);
+            const float c = row_sum<TPR>(row_dot<VEC, NV>(xl, w), red);
+            if (biases) row_load<TPR, VEC, NV>(bb, biases + (int64_t)l * D, D, t);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) xl[i][e] = rn_act(x0[i][e] * c + (biases ? bb[i][e] : 0.f), act);
+        }
+        if (ok) row_store<TPR, VEC, NV>(xl, y + row * D, D, t);
+    }
+}
+
+// part: [gridDim.x][2*L][D]  (dkernel rows 0..L-1, dbias rows L..2L-1) per workgroup
+template <int TPR, int VEC, int NV>
+__global__ void __launch_bounds__(256)
+k_dcn_bwd(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases,
+          const float* __restrict__ dy, int64_t B, int D, int L, int act, float* __restrict__ dx, float* __restrict__ part) {
+    __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) float comb[];   // [256/TPR][D] when TPR == 64 (cross-wave combine)
+    constexpr int RPB = 256 / TPR;
+    const int t = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
+    float dw[DCN_MAX_L][NV][VEC], db[DCN_MAX_L][NV][VEC];
+#pragma unroll
+    for (int l = 0; l < DCN_MAX_L; ++l)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dw[l][i][e] = db[l][i][e] = 0.f;
+
+    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += (int64_t)gridDim.x * RPB) {
+        const int64_t row = row0 + rsub;
+        const bool ok = row < B;
+        float x0[NV][VEC], g[NV][VEC], dx0[NV][VEC], xl[NV][VEC], w[NV][VEC], bb[NV][VEC];
+        row_load<TPR, VEC, NV>(x0, x + (ok ? row : 0) * D, ok ? D : 0, t);
+        row_load<TPR, VEC, NV>(g, dy + (ok ? row : 0) * D, ok ? D : 0, t);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dx0[i][e] = 0.f;
+#pragma unroll
+        for (int li = 0; li < DCN_MAX_L; ++li) {
+            const int l = L - 1 - li;           // walk layers L-1 .. 0 with a compile-time accumulator index
+            if (l < 0) continue;
+            // recompute x_l from x0
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) xl[i][e] = x0[i][e];
+            for (int m = 0; m < l; ++m) {
+                row_load<TPR, VEC, NV>(w, kernels + (int64_t)m * D, D, t);
+                const float cm = row_sum<TPR>(row_dot<VEC, NV>(xl, w), red);
+                if (biases) row_load<TPR, VEC, NV>(bb, biases + (int64_t)m * D, D, t);
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) xl[i][e] = rn_act(x0[i][e] * cm + (biases ? bb[i][e] : 0.f), act);
+            }
+            row_load<TPR, VEC, NV>(w, kernels + (int64_t)l * D, D, t);
+            const float c = row_sum<TPR>(row_dot<VEC, NV>(xl, w), red);
+            if (biases) row_load<TPR, VEC, NV>(bb, biases + (int64_t)l * D, D, t);
+            float dz[NV][VEC];
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float out = rn_act(x0[i][e] * c + (biases ? bb[i][e] : 0.f), act);
+                    dz[i][e] = g[i][e] * rn_act_grad_from_out(out, act);
+                }
+            const float dc = row_sum<TPR>(row_dot<VEC, NV>(dz, x0), red);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    db[li][i][e] += dz[i][e];
+                    dx0[i][e] += dz[i][e] * c;
+                    dw[li][i][e] += xl[i][e] * dc;
+                    g[i][e] = dc * w[i][e];         // gradient w.r.t. x_l
+                }
+        }
+        // x_0 is x0 itself: the remaining g is the gradient through the first layer's input
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dx0[i][e] += g[i][e];
+        if (ok) row_store<TPR, VEC, NV>(dx0, dx + row * D, D, t);
+    }
+
+    // per-workgroup combine, then one slab per workgroup
+    float* slab = part + (int64_t)blockIdx.x * 2 * L * D;
+#pragma unroll
+    for (int li = 0; li < DCN_MAX_L; ++li) {
+        const int l = L - 1 - li;
+        if (l < 0) continue;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float* dst = slab + (int64_t)(which * L + l) * D;
+            if (TPR == 256) {
+                row_store<TPR, VEC, NV>(which ? db[li] : dw[li], dst, D, t);
+            } else {
+                __syncthreads();
+                row_store<TPR, VEC, NV>(which ? db[li] : dw[li], comb + rsub * D, D, t);
+                __syncthreads();
+                for (int d = threadIdx.x; d < D; d += 256) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RPB; ++r) s += comb[r * D + d];
+                    dst[d] = s;
+                }
+            }
+        }
+    }
+}
+
+struct DcnCfg {
+    int tpr, vec, nv;
+};
+static bool dcn_pick(int D, const void* a, const void* b, const void* c, DcnCfg* cfg) {
+    const bool aligned = (D % 4 == 0) && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0);
+    if (aligned) {
+        if (D <= 256) { *cfg = {64, 4, 1}; return true; }
+        if (D <= 1024) { *cfg = {64, 4, 4}; return true; }
+        if (D <= 4096) { *cfg = {256, 4, 4}; return true; }
+        return false;
+    }
+    if (D <= 256) { *cfg = {256, 1, 1}; return true; }
+    if (D <= 1024) { *cfg = {256, 1, 4}; return true; }
+    return false;
+}
+
+static inline int dcn_grid(int64_t B, int tpr) {
+    const int64_t rpb = 256 / tpr;
+    int64_t g = (B + rpb - 1) / rpb;
+    if (g > 1024) g = 1024;            // 256 CUs x 4 workgroups; rows are grid-strided
+    return (int)(g > 0 ? g : 1);
+}
+
+extern "C" size_t recnow_dcn_workspace_bytes(int64_t B, int D, int L) {
+    if (B <= 0 || D <= 0 || L <= 0) return 256;
+    const size_t slabs = rn_align((size_t)1024 * 2 * L * D * sizeof(float));
+    return slabs + rn_colsum_ws_bytes(1024, (int64_t)2 * L * D) + rn_align((size_t)2 * L * D * sizeof(float));
+}
+
+#define DCN_DISPATCH(KERNEL, SHMEM, ...)                                                                              \
+    do {                                                                                                              \
+        if (cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 1) hipLaunchKernelGGL((KERNEL<64, 4, 1>), G, 256, SHMEM, st, __VA_ARGS__);      \
+        else if (cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4) hipLaunchKernelGGL((KERNEL<64, 4, 4>), G, 256, SHMEM, st, __VA_ARGS__); \
+        else if (cfg.tpr == 256 && cfg.vec == 4) hipLaunchKernelGGL((KERNEL<256, 4, 4>), G, 256, SHMEM, st, __VA_ARGS__);              \
+        else if (cfg.tpr == 256 && cfg.vec == 1 && cfg.nv == 1) hipLaunchKernelGGL((KERNEL<256, 1, 1>), G, 256, SHMEM, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<256, 1, 4>), G, 256, SHMEM, st, __VA_ARGS__);                                                  \
+    } while (0)
+
+extern "C" int recnow_dcn_fwd(const float* x, const float* kernels, const float* biases, int64_t B, int D, int L, int act, float* y,
+                              void* stream) {
+    if (B < 0 || D < 1 || L < 1) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!x || !kernels || !y) return RECNOW_EINVAL;
+    DcnCfg cfg;
+    if (!dcn_pick(D, x, y, kernels, &cfg) || (biases && (((uintptr_t)biases & 15) != 0) && cfg.vec == 4)) return RECNOW_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dcn_grid(B, cfg.tpr);
+    DCN_DISPATCH(k_dcn_fwd, 0, x, kernels, biases, B, D, L, act, y);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float* biases, const float* dy, int64_t B, int D, int L,
+                              int act, float* dx, float* dkernels, float* dbiases, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || D < 1 || L < 1) return RECNOW_EINVAL;
+    if (L > DCN_MAX_L) return RECNOW_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        if (dkernels) RN_HIP(hipMemsetAsync(dkernels, 0, (size_t)L * D * sizeof(float), st));
+        if (dbiases) RN_HIP(hipMemsetAsync(dbiases, 0, (size_t)L * D * sizeof(float), st));
+        return RECNOW_OK;
+    }
+    if (!x || !kernels || !dy || !dx || !dkernels || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_dcn_workspace_bytes(B, D, L)) return RECNOW_EWORKSPACE;
+    DcnCfg cfg;
+    if (!dcn_pick(D, x, dy, dx, &cfg) || (cfg.vec == 4 && ((((uintptr_t)kernels | (uintptr_t)biases) & 15) != 0)))
+        return RECNOW_EUNSUPPORTED;
+    const int G = dcn_grid(B, cfg.tpr);
+    RnCarver c(ws, ws_bytes);
+    float* part = c.take<float>((size_t)1024 * 2 * L * D);
+    float* sums = c.take<float>((size_t)2 * L * D);
+    void* cs_ws = c.base + c.off;
+    const size_t cs_bytes = ws_bytes - c.off;
+    const size_t shmem = cfg.tpr == 64 ? (size_t)4 * D * sizeof(float) : 0;
+    DCN_DISPATCH(k_dcn_bwd, shmem, x, kernels, biases, dy, B, D, L, act, dx, part);
+    RN_LAUNCH_CHECK();
+    int rc = rn_colsum(part, nullptr, 0, 0, G, (int64_t)2 * L * D, (int64_t)2 * L * D, sums, 0, cs_ws, cs_bytes, st);
+    if (rc) return rc;
+    RN_HIP(hipMemcpyAsync(dkernels, sums, (size_t)L * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (dbiases) RN_HIP(hipMemcpyAsync(dbiases, sums + (size_t)L * D, (size_t)L * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return RECNOW_OK;
+}

@@ -1,0 +1,347 @@
+// DCNMixLayer (DCN-v2 mixture of low-rank experts, reference variant WITHOUT residual):
+// /root/reference/rec_now/layers/dcn_mix_layer.py:114-151.  Per layer (x_l = layer input, x = first input):
+//     A_n  = x_l U_n            (B,S)   :135      H1 = act_inner(A)        :136
+//     C_n  = H1_n V_n           (B,S)   :137      H2 = act_outer(C)        :138
+//     O_n  = H2_n W_n + b_n     (B,D)   :141-142  Q_n = x * O_n            :143
+//     G    = softmax(x_l K)     (B,N)   :146-147  y   = sum_n G_n Q_n      :149
+//
+// Mapping onto the exact-fp32 MFMA GEMM (gemm.hip), chosen so that x_l / x / y are each streamed once per GEMM:
+//   GEMM1:  T1 = x_l [U_0 | .. | U_{N-1} | K]          (B,D)x(D,NS+N): act_inner on the first NS columns, the last N
+//           columns are the gate logits (no separate pass over x_l for the gate).
+//   GEMM2:  H2_n = act_outer(H1_n V_n)                  batched over n, K = S.
+//   gate :  G = softmax(logits);  T2g = [G_n * H2_n | G]   (elementwise, B x (NS+N))
+//   GEMM3:  y = x * (T2g [W_0; ..; W_{N-1}; b])        (B,NS+N)x(NS+N,D) with the x-multiply as epilogue; the
+//           gate-weighted bias sum_n G_n b_n rides along as N extra K rows.
+// Backward mirrors this with the producers of each gradient GEMM fused into operand loads (x*dy) or epilogues
+// (act' multiply), split-K slab reduction for the K = B weight gradients, and O recomputed for dx (dy * O).
+// Leading dimension of the small activations: LDT = roundup(NS+N, 4) floats so rows stay 16-byte aligned.
+#include "gemm.hpp"
+
+static inline int ldt_of(int S, int N) { return (N * S + N + 3) / 4 * 4; }
+
+// Wc1[d][n*S+s] = U[n][d][s];  Wc1[d][NS+n] = K[d][n];  pad columns = 0
+__global__ void k_pack_w1(const float* __restrict__ U, const float* __restrict__ K, int D, int S, int N, int LDT, float* __restrict__ Wc1) {
+    const int64_t total = (int64_t)D * LDT;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i / LDT), c = (int)(i % LDT);
+        float v = 0.f;
+        if (c < N * S) v = U[((int64_t)(c / S) * D + d) * S + (c % S)];
+        else if (c < N * S + N) v = K[(int64_t)d * N + (c - N * S)];
+        Wc1[i] = v;
+    }
+}
+// dU[n][d][s] = dWc1[d][n*S+s];  dK[d][n] = dWc1[d][NS+n]
+__global__ void k_unpack_w1(const float* __restrict__ dWc1, int D, int S, int N, int LDT, float* __restrict__ dU, float* __restrict__ dK) {
+    const int64_t total = (int64_t)D * (N * S + N);
+    const int NS = N * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i / (NS + N)), c = (int)(i % (NS + N));
+        const float v = dWc1[(int64_t)d * LDT + c];
+        if (c < NS) dU[((int64_t)(c / S) * D + d) * S + (c % S)] = v;
+        else dK[(int64_t)d * N + (c - NS)] = v;
+    }
+}
+
+// one wave per row: G = softmax(T1[:, NS:NS+N]);  T2[:, NS+n] = G_n;  T2g = [G_n * H2_n | G]
+__global__ void __launch_bounds__(256)
+k_dcnmix_gate_fwd(const float* __restrict__ T1, float* __restrict__ T2, float* __restrict__ T2g, int64_t B, int S, int N, int LDT) {
+    const int lane = threadIdx.x & 63;
+    const int NS = N * S;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
+        const float lg = lane < N ? T1[b * LDT + NS + lane] : -INFINITY;
+        const float mx = wave_max(lg);
+        const float e = lane < N ? expf(lg - mx) : 0.f;
+        const float g = e / wave_sum(e);
+        if (lane < N) {
+            T2[b * LDT + NS + lane] = g;
+            T2g[b * LDT + NS + lane] = g;
+        }
+        for (int c0 = 0; c0 < NS; c0 += 64) {          // wave-uniform trip count (shuffle sources must be active)
+            const int c = c0 + lane;
+            const float gn = __shfl(g, (c < NS ? c : 0) / S, 64);
+            if (c < NS) T2g[b * LDT + c] = gn * T2[b * LDT + c];
+        }
+        for (int c = NS + N + lane; c < LDT; c += 64) { T2[b * LDT + c] = 0.f; T2g[b * LDT + c] = 0.f; }
+    }
+}
+
+// one wave per row.  in: dT2g (B,LDT), T2 = [H2 | G].  out: dC[:, n*S+s] = G_n * dT2g * act_outer'(H2);
+//                    dT1[:, NS+n] = dlogits_n = G_n * (dG_n - sum_m G_m dG_m),  dG_n = sum_s dT2g*H2 + dT2g[:, NS+n]
+__global__ void __launch_bounds__(256)
+k_dcnmix_gate_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, float* __restrict__ dC, float* __restrict__ dT1,
+                  int64_t B, int S, int N, int LDT, int act_outer) {
+    const int lane = threadIdx.x & 63;
+    const int NS = N * S;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
+        const float g = lane < N ? T2[b * LDT + NS + lane] : 0.f;
+        float dg_mine = lane < N ? dT2g[b * LDT + NS + lane] : 0.f;
+        for (int n = 0; n < N; ++n) {
+            float p = 0.f;
+            const float gn = __shfl(g, n, 64);
+            for (int s = lane; s < S; s += 64) {
+                const int c = n * S + s;
+                const float h2 = T2[b * LDT + c], d = dT2g[b * LDT + c];
+                p += d * h2;
+                dC[b * LDT + c] = gn * d * rn_act_grad_from_out(h2, act_outer);
+            }
+            p = wave_sum(p);
+            if (lane == n) dg_mine += p;
+        }
+        const float dot = wave_sum(g * dg_mine);
+        if (lane < N) dT1[b * LDT + NS + lane] = g * (dg_mine - dot);
+        for (int c = NS + N + lane; c < LDT; c += 64) { dT1[b * LDT + c] = 0.f; dC[b * LDT + c] = 0.f; }
+        for (int c = NS + lane; c < NS + N; c += 64) dC[b * LDT + c] = 0.f;
+    }
+}
+
+struct MixDims {
+    int64_t B;
+    int D, S, N, L, NS, KC, LDT;   // KC = NS + N
+};
+static inline MixDims mix_dims(int64_t B, int D, int S, int N, int L) {
+    MixDims m;
+    m.B = B; m.D = D; m.S = S; m.N = N; m.L = L; m.NS = N * S; m.KC = N * S + N; m.LDT = ldt_of(S, N);
+    return m;
+}
+static inline size_t act_block(const MixDims& m) { return rn_align((size_t)m.B * m.LDT * sizeof(float)); }
+static inline size_t xbuf(const MixDims& m) { return rn_align((size_t)m.B * m.D * sizeof(float)); }
+
+// saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D)
+extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int L) {
+    if (B <= 0 || D <= 0 || S <= 0 || N <= 0 || L <= 0) return 256;
+    const MixDims m = mix_dims(B, D, S, N, L);
+    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + 256;
+}
+
+static size_t mix_gemm_ws(const MixDims& m) {
+    size_t best = 0;
+    recnow_gemm_desc d = rn_gemm_desc_zero();
+    const int shapes[6][3] = {{(int)m.B, m.KC, m.D}, {(int)m.B, m.D, m.KC}, {m.KC, m.D, (int)m.B}, {m.D, m.KC, (int)m.B},
+                              {m.S, m.S, (int)m.B}, {(int)m.B, m.S, m.S}};
+    for (int i = 0; i < 6; ++i) {
+        d.M = shapes[i][0]; d.N = shapes[i][1]; d.K = shapes[i][2]; d.batch = (i >= 4) ? m.N : 1;
+        const size_t s = rn_gemm_ws_bytes(&d);
+        if (s > best) best = s;
+    }
+    return best;
+}
+
+extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N, int L) {
+    if (B <= 0 || D <= 0 || S <= 0 || N <= 0 || L <= 0) return 256;
+    const MixDims m = mix_dims(B, D, S, N, L);
+    size_t s = 0;
+    s += rn_align((size_t)D * m.LDT * sizeof(float));        // Wc1
+    s += rn_align((size_t)m.KC * D * sizeof(float));         // Wc2
+    s += rn_align((size_t)D * m.LDT * sizeof(float));        // dWc1
+    s += rn_align((size_t)m.KC * D * sizeof(float));         // dWc2
+    s += 3 * act_block(m);                                   // dT2g, dC, dT1
+    s += 2 * xbuf(m);                                        // inter-layer gradient ping-pong
+    s += mix_gemm_ws(m);
+    return s + 256;
+}
+
+static int pack_weights(const MixDims& m, const float* U, const float* V, const float* W, const float* bias, const float* K,
+                        float* Wc1, float* Wc2, hipStream_t st) {
+    (void)V;
+    int g = rn_cdiv((int64_t)m.D * m.LDT, 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_pack_w1, g, 256, 0, st, U, K, m.D, m.S, m.N, m.LDT, Wc1);
+    RN_LAUNCH_CHECK();
+    // Wc2 = [W (NS x D); bias (N x D)] -- both already row-major contiguous
+    RN_HIP(hipMemcpyAsync(Wc2, W, (size_t)m.NS * m.D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RN_HIP(hipMemcpyAsync(Wc2 + (size_t)m.NS * m.D, bias, (size_t)m.N * m.D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return RECNOW_OK;
+}
+
+static inline int gate_grid(int64_t B) {
+    int64_t g = (B + 3) / 4;
+    if (g > 4096) g = 4096;
+    return (int)(g > 0 ? g : 1);
+}
+
+extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, const float* const* V_host,
+                                  const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
+                                  int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* y, void* saved,
+                                  size_t saved_bytes, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || D < 1 || S < 1 || N < 1 || L < 1 || B > 0x7fffffffll) return RECNOW_EINVAL;
+    if (N > 64) return RECNOW_EUNSUPPORTED;
+    if (B == 0) return RECNOW_OK;
+    if (!x || !U_host || !V_host || !W_host || !bias_host || !gate_host || !y || !saved || !ws) return RECNOW_EINVAL;
+    if (saved_bytes < recnow_dcn_mix_saved_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
+    if (ws_bytes < recnow_dcn_mix_workspace_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const MixDims m = mix_dims(B, D, S, N, L);
+    RnCarver c(ws, ws_bytes);
+    float* Wc1 = c.take<float>((size_t)D * m.LDT);
+    float* Wc2 = c.take<float>((size_t)m.KC * D);
+    c.take<float>((size_t)D * m.LDT);
+    c.take<float>((size_t)m.KC * D);
+    c.take<float>(3 * act_block(m) / sizeof(float));
+    c.take<float>(2 * xbuf(m) / sizeof(float));
+    void* gws = c.base + c.off;
+    const size_t gws_bytes = ws_bytes - c.off;
+    char* sv = (char*)saved;
+    float* xmid = (float*)(sv + (size_t)L * 3 * act_block(m));
+    int rc;
+    const float* xl = x;
+    for (int l = 0; l < L; ++l) {
+        float* T1 = (float*)(sv + (size_t)(3 * l) * act_block(m));
+        float* T2 = (float*)(sv + (size_t)(3 * l + 1) * act_block(m));
+        float* T2g = (float*)(sv + (size_t)(3 * l + 2) * act_block(m));
+        float* out = (l == L - 1) ? y : xmid + (size_t)l * (xbuf(m) / sizeof(float));
+        if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
+        {   // GEMM1: T1 = [act_inner(x_l U) | x_l K]
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = xl; d.lda = D; d.a_trans = 0;
+            d.B = Wc1; d.ldb = m.LDT; d.b_trans = 0;
+            d.C = T1; d.ldc = m.LDT;
+            d.M = (int)B; d.N = m.KC; d.K = D;
+            d.act = act_inner; d.act_cols = m.NS;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+        }
+        {   // GEMM2: H2_n = act_outer(H1_n V_n), batched over the N experts
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
+            d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 0;
+            d.C = T2; d.ldc = m.LDT; d.c_batch_stride = S;
+            d.M = (int)B; d.N = S; d.K = S; d.batch = N;
+            d.act = act_outer;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+        }
+        hipLaunchKernelGGL(k_dcnmix_gate_fwd, gate_grid(B), 256, 0, st, T1, T2, T2g, B, S, N, m.LDT);
+        RN_LAUNCH_CHECK();
+        {   // GEMM3: out = x * (T2g [W; b])
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
+            d.B = Wc2; d.ldb = D; d.b_trans = 0;
+            d.C = out; d.ldc = D;
+            d.M = (int)B; d.N = D; d.K = m.KC;
+            d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+        }
+        xl = out;
+    }
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* const* V_host,
+                                  const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
+                                  const float* dy, const void* saved, size_t saved_bytes, int64_t B, int D, int S, int N, int L,
+                                  int act_inner, int act_outer, float* dx, float* const* dU_host, float* const* dV_host,
+                                  float* const* dW_host, float* const* dbias_host, float* const* dgate_host, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    if (B < 0 || D < 1 || S < 1 || N < 1 || L < 1 || B > 0x7fffffffll) return RECNOW_EINVAL;
+    if (N > 64) return RECNOW_EUNSUPPORTED;
+    if (!dU_host || !dV_host || !dW_host || !dbias_host || !dgate_host) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        for (int l = 0; l < L; ++l) {
+            RN_HIP(hipMemsetAsync(dU_host[l], 0, (size_t)N * D * S * sizeof(float), st));
+            RN_HIP(hipMemsetAsync(dV_host[l], 0, (size_t)N * S * S * sizeof(float), st));
+            RN_HIP(hipMemsetAsync(dW_host[l], 0, (size_t)N * S * D * sizeof(float), st));
+            RN_HIP(hipMemsetAsync(dbias_host[l], 0, (size_t)N * D * sizeof(float), st));
+            RN_HIP(hipMemsetAsync(dgate_host[l], 0, (size_t)D * N * sizeof(float), st));
+        }
+        return RECNOW_OK;
+    }
+    if (!x || !U_host || !V_host || !W_host || !bias_host || !gate_host || !dy || !saved || !dx || !ws) return RECNOW_EINVAL;
+    if (saved_bytes < recnow_dcn_mix_saved_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
+    if (ws_bytes < recnow_dcn_mix_workspace_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
+    const MixDims m = mix_dims(B, D, S, N, L);
+    RnCarver c(ws, ws_bytes);
+    float* Wc1 = c.take<float>((size_t)D * m.LDT);
+    float* Wc2 = c.take<float>((size_t)m.KC * D);
+    float* dWc1 = c.take<float>((size_t)D * m.LDT);
+    float* dWc2 = c.take<float>((size_t)m.KC * D);
+    float* dT2g = c.take<float>(act_block(m) / sizeof(float));
+    float* dC = c.take<float>(act_block(m) / sizeof(float));
+    float* dT1 = c.take<float>(act_block(m) / sizeof(float));
+    float* gbuf0 = c.take<float>(xbuf(m) / sizeof(float));
+    float* gbuf1 = c.take<float>(xbuf(m) / sizeof(float));
+    void* gws = c.base + c.off;
+    const size_t gws_bytes = ws_bytes - c.off;
+    const char* sv = (const char*)saved;
+    const float* xmid = (const float*)(sv + (size_t)L * 3 * act_block(m));
+    int rc;
+    const float* g = dy;                     // gradient w.r.t. the current layer's output
+    bool dx_started = false;                 // dx accumulates the x (= x0) contributions of every layer
+    for (int l = L - 1; l >= 0; --l) {
+        const float* T1 = (const float*)(sv + (size_t)(3 * l) * act_block(m));
+        const float* T2 = (const float*)(sv + (size_t)(3 * l + 1) * act_block(m));
+        const float* T2g = (const float*)(sv + (size_t)(3 * l + 2) * act_block(m));
+        const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));
+        float* gprev = (l == 0) ? nullptr : ((l & 1) ? gbuf0 : gbuf1);
+        if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
+        {   // dT2g = (x * g) Wc2^T
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 0;
+            d.B = Wc2; d.ldb = D; d.b_trans = 1;
+            d.C = dT2g; d.ldc = m.LDT;
+            d.M = (int)B; d.N = m.KC; d.K = D;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+        }
+        {   // dWc2 = T2g^T (x * g)          -> dW (NS x D) and dbias (N x D)
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = T2g; d.lda = m.LDT; d.a_trans = 1;
+            d.B = g; d.B2 = x; d.b_mode = RECNOW_OPMODE_MUL; d.ldb = D; d.b_trans = 0;
+            d.C = dWc2; d.ldc = D;
+            d.M = m.KC; d.N = D; d.K = (int)B;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            RN_HIP(hipMemcpyAsync(dW_host[l], dWc2, (size_t)m.NS * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+            RN_HIP(hipMemcpyAsync(dbias_host[l], dWc2 + (size_t)m.NS * D, (size_t)N * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        {   // dx (+)= g * O,  O = T2g Wc2 recomputed
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
+            d.B = Wc2; d.ldb = D; d.b_trans = 0;
+            d.C = dx; d.ldc = D;
+            d.M = (int)B; d.N = D; d.K = m.KC;
+            d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
+            d.accumulate = dx_started ? 1 : 0;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            dx_started = true;
+        }
+        hipLaunchKernelGGL(k_dcnmix_gate_bwd, gate_grid(B), 256, 0, st, dT2g, T2, dC, dT1, B, S, N, m.LDT, act_outer);
+        RN_LAUNCH_CHECK();
+        {   // dV_n = H1_n^T dC_n            (S x S), K = B
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 1;
+            d.B = dC; d.ldb = m.LDT; d.b_batch_stride = S; d.b_trans = 0;
+            d.C = dV_host[l]; d.ldc = S; d.c_batch_stride = (int64_t)S * S;
+            d.M = S; d.N = S; d.K = (int)B; d.batch = N;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+        }
+        {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n)  -> first NS columns of dT1
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = dC; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
+            d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 1;
+            d.C = dT1; d.ldc = m.LDT; d.c_batch_stride = S;
+            d.M = (int)B; d.N = S; d.K = S; d.batch = N;
+            d.emul = T1; d.lde = m.LDT; d.e_batch_stride = S; d.e_mode = RECNOW_OPMODE_ACTGRAD; d.e_act = act_inner;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+        }
+        {   // dWc1 = x_l^T dT1              -> dU, dgate
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = xl; d.lda = D; d.a_trans = 1;
+            d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
+            d.C = dWc1; d.ldc = m.LDT;
+            d.M = D; d.N = m.KC; d.K = (int)B;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            int gg = rn_cdiv((int64_t)D * m.KC, 256);
+            if (gg > 2048) gg = 2048;
+            hipLaunchKernelGGL(k_unpack_w1, gg, 256, 0, st, dWc1, D, S, N, m.LDT, dU_host[l], dgate_host[l]);
+            RN_LAUNCH_CHECK();
+        }
+        {   // gradient w.r.t. x_l:  dT1 Wc1^T.  Layer 0's x_l is x itself -> accumulate into dx.
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
+            d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
+            d.C = (l == 0) ? dx : gprev; d.ldc = D;
+            d.M = (int)B; d.N = D; d.K = m.KC;
+            d.accumulate = (l == 0) ? 1 : 0;
+            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+        }
+        g = gprev;
+    }
+    return RECNOW_OK;
+}

@@ -1,0 +1,390 @@
+// Exact-fp32 MFMA GEMM for gfx950: C = epilogue(opA(A) x opB(B)), batched, optional split-K.
+//
+// Why this shape: the reference's contractions (multi_dense_layer.py:90, dcn_mix_layer.py:135-141, MMoE/PLE experts)
+// must match TF's fp32 matmul to 1e-5 relative, so bf16 MFMA is out; gfx950's v_mfma_f32_32x32x2_f32 is an exact fp32
+// fma chain at 64 FLOP/clk/SIMD (157 TFLOP/s).  At that rate a 128x128x32 block tile needs 16 KB + 16 KB of LDS per
+// 4096 MFMA-cycles per wave, so LDS bandwidth and even ds_read_b32 fragment loads are far from binding; what matters
+// is (1) fragment reads that are bank-conflict-free, (2) global loads of the next k-tile in flight under the MFMAs of
+// the current one (register-staged double buffering, one barrier per k-tile), (3) enough workgroups (split-K for the
+// K = batch-rows weight-gradient GEMMs, reduced deterministically from slabs -- no float atomics).
+//
+// LDS images are k-major: As[k][m], Bs[k][n].  A wave64 MFMA 32x32x2 fragment read is then 32 consecutive floats for
+// lanes 0-31 (k) and 32 consecutive floats for lanes 32-63 (k+1): conflict-free ds_read_b32 with no padding tricks.
+// An operand that is k-contiguous in memory ([m][k]) is loaded as float4 along k (coalesced 128-B rows) and transposed
+// on the LDS write; its row stride is ROWS+1 floats so those 4-B writes are conflict-free too.
+#include "gemm.hpp"
+#include <string.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GEMM_BK 32
+#define GEMM_THREADS 256
+
+struct GemmK {
+    const float *A, *A2, *B, *B2, *bias, *emul;
+    float *C, *partial;
+    int64_t lda, ldb, ldc, lde, sA, sB, sC, sBias, sE;
+    int M, N, K, batch;
+    int a_mode, a_act, b_mode, b_act, act, act_cols, e_mode, e_act, accumulate, splitk, kchunk;
+};
+
+__device__ __forceinline__ float4 gemm_load4(const float* __restrict__ q, int rem) {
+    if (rem >= 4 && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) return *reinterpret_cast<const float4*>(q);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rem > 0) r.x = q[0];
+    if (rem > 1) r.y = q[1];
+    if (rem > 2) r.z = q[2];
+    if (rem > 3) r.w = q[3];
+    return r;
+}
+
+__device__ __forceinline__ float4 gemm_combine(float4 x, float4 y, int mode, int act) {
+    if (mode == RECNOW_OPMODE_MUL) return make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+    return make_float4(x.x * rn_act_grad_from_out(y.x, act), x.y * rn_act_grad_from_out(y.y, act),
+                       x.z * rn_act_grad_from_out(y.z, act), x.w * rn_act_grad_from_out(y.w, act));
+}
+
+// ROWS = BM (A) or BN (B).  KC: operand is k-contiguous in memory ([row][k]); else [k][row].
+template <int ROWS, bool KC>
+struct Tile {
+    static constexpr int NV = ROWS * GEMM_BK / 4 / GEMM_THREADS;
+    static constexpr int LD = KC ? ROWS + 1 : ROWS;
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2, int mode, int act,
+                                         int64_t ld, int r0, int k0, int R, int Kend) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * GEMM_THREADS;
+            int64_t off;
+            int rem;
+            if (KC) {
+                const int kq = idx % (GEMM_BK / 4), r = idx / (GEMM_BK / 4);
+                const int gr = r0 + r, gk = k0 + kq * 4;
+                off = (int64_t)gr * ld + gk;
+                rem = (gr < R) ? (Kend - gk) : 0;
+            } else {
+                const int rq = idx % (ROWS / 4), k = idx / (ROWS / 4);
+                const int gk = k0 + k, gr = r0 + rq * 4;
+                off = (int64_t)gk * ld + gr;
+                rem = (gk < Kend) ? (R - gr) : 0;
+            }
+            float4 x = gemm_load4(p + off, rem);
+            if (mode != RECNOW_OPMODE_NONE) x = gemm_combine(x, gemm_load4(p2 + off, rem), mode, act);
+            v[i] = x;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ S) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * GEMM_THREADS;
+            if (KC) {
+                const int kq = idx % (GEMM_BK / 4), r = idx / (GEMM_BK / 4);
+                float* s = S + (kq * 4) * LD + r;
+                s[0] = v[i].x;
+                s[LD] = v[i].y;
+                s[2 * LD] = v[i].z;
+                s[3 * LD] = v[i].w;
+            } else {
+                const int rq = idx % (ROWS / 4), k = idx / (ROWS / 4);
+                *reinterpret_cast<float4*>(S + k * LD + rq * 4) = v[i];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(GEMM_THREADS)
+k_gemm(const GemmK p) {
+    constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+    using TA = Tile<BM, A_KC>;
+    using TB = Tile<BN, B_KC>;
+    constexpr int A_SZ = GEMM_BK * TA::LD, B_SZ = GEMM_BK * TB::LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                 // two buffers of A_SZ floats, then two of B_SZ
+    float* const Bs = smem + 2 * A_SZ;
+
+    const int z = blockIdx.z, bidx = z / p.splitk, ks = z % p.splitk;
+    const int k_begin = ks * p.kchunk;
+    const int k_end = min(p.K, k_begin + p.kchunk);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const float* Ab = p.A + (int64_t)bidx * p.sA;
+    const float* A2b = p.A2 ? p.A2 + (int64_t)bidx * p.sA : nullptr;
+    const float* Bb = p.B + (int64_t)bidx * p.sB;
+    const float* B2b = p.B2 ? p.B2 + (int64_t)bidx * p.sB : nullptr;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int a_off = (lane >> 5) * TA::LD + wm * TM * 32 + (lane & 31);
+    const int b_off = (lane >> 5) * TB::LD + wn * TN * 32 + (lane & 31);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TA ta;
+    TB tb;
+    const int ntile = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+    if (ntile > 0) {
+        ta.load(Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end);
+        tb.load(Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end);
+        ta.store(As);
+        tb.store(Bs);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
+            const int k0 = k_begin + (t + 1) * GEMM_BK;
+            ta.load(Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end);
+            tb.load(Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end);
+        }
+        const float* as = As + cur * A_SZ + a_off;
+        const float* bs = Bs + cur * B_SZ + b_off;
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[kk * TA::LD + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[kk * TB::LD + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < ntile) {
+            ta.store(As + (cur ^ 1) * A_SZ);
+            tb.store(Bs + (cur ^ 1) * B_SZ);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    if (p.splitk > 1) {
+        float* P = p.partial + ((int64_t)z * p.M) * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * TN * 32 + j * 32 + col_l;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                    if (row < p.M && col < p.N) P[(int64_t)row * p.N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    float* Cb = p.C + (int64_t)bidx * p.sC;
+    const float* biasb = p.bias ? p.bias + (int64_t)bidx * p.sBias : nullptr;
+    const float* Eb = p.emul ? p.emul + (int64_t)bidx * p.sE : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + col_l;
+            const float bv = (biasb && col < p.N) ? biasb[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                if (row < p.M && col < p.N) {
+                    float v = acc[i][j][r] + bv;
+                    if (col < p.act_cols) v = rn_act(v, p.act);
+                    if (Eb) {
+                        const float e = Eb[(int64_t)row * p.lde + col];
+                        v *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(e, p.e_act) : e;
+                    }
+                    float* c = Cb + (int64_t)row * p.ldc + col;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
+// sum the split-K slabs in slice order (deterministic) and apply the epilogue
+__global__ void __launch_bounds__(256)
+k_gemm_splitk_reduce(const GemmK p) {
+    const int64_t MN = (int64_t)p.M * p.N;
+    const int64_t total = MN * p.batch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / MN);
+        const int64_t mn = i % MN;
+        const int row = (int)(mn / p.N), col = (int)(mn % p.N);
+        const float* P = p.partial + ((int64_t)b * p.splitk) * MN + mn;
+        float s = 0.f;
+        for (int k = 0; k < p.splitk; ++k) s += P[(int64_t)k * MN];
+        if (p.bias) s += p.bias[(int64_t)b * p.sBias + col];
+        if (col < p.act_cols) s = rn_act(s, p.act);
+        if (p.emul) {
+            const float e = p.emul[(int64_t)b * p.sE + (int64_t)row * p.lde + col];
+            s *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(e, p.e_act) : e;
+        }
+        float* c = p.C + (int64_t)b * p.sC + (int64_t)row * p.ldc + col;
+        if (p.accumulate) s += *c;
+        *c = s;
+    }
+}
+
+// ---- host dispatch -------------------------------------------------------------------------------------
+struct GemmCfg {
+    int BM, BN;
+};
+
+static inline GemmCfg pick_cfg(int N) {
+    if (N <= 32) return {256, 32};
+    if (N <= 64) return {256, 64};
+    if (N > 128 && N <= 160) return {128, 160};
+    return {128, 128};
+}
+
+static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* splitk, int* kchunk) {
+    const long long tiles = (long long)rn_cdiv(d->M, c.BM) * rn_cdiv(d->N, c.BN) * d->batch;
+    int s = 1;
+    if (tiles < 256) {
+        s = (int)(512 / tiles);
+        const int maxs = d->K / (8 * GEMM_BK);      // at least 8 k-tiles per slice
+        if (s > maxs) s = maxs;
+        if (s < 1) s = 1;
+    }
+    int kc = rn_cdiv(rn_cdiv(d->K, s), GEMM_BK) * GEMM_BK;
+    if (kc < GEMM_BK) kc = GEMM_BK;
+    s = rn_cdiv(d->K, kc);
+    if (s < 1) s = 1;
+    *splitk = s;
+    *kchunk = kc;
+}
+
+size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return 0;
+    const GemmCfg c = pick_cfg(d->N);
+    int s, kc;
+    pick_split(d, c, &s, &kc);
+    return s > 1 ? rn_align((size_t)s * d->batch * d->M * d->N * sizeof(float)) : 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmK& k, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
+    // LDS bytes for the worst-case (padded) strides of this instantiation
+#define RN_GEMM_LAUNCH(AKC, BKC)                                                                                  \
+    do {                                                                                                          \
+        constexpr size_t lds = 2 * GEMM_BK * (size_t)(Tile<BM, AKC>::LD + Tile<BN, BKC>::LD) * sizeof(float);     \
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, AKC, BKC>), grid, GEMM_THREADS, lds, st, k);                   \
+    } while (0)
+    if (a_kc && b_kc) RN_GEMM_LAUNCH(true, true);
+    else if (a_kc && !b_kc) RN_GEMM_LAUNCH(true, false);
+    else if (!a_kc && b_kc) RN_GEMM_LAUNCH(false, true);
+    else RN_GEMM_LAUNCH(false, false);
+#undef RN_GEMM_LAUNCH
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!d || d->M < 0 || d->N < 0 || d->K < 0 || d->batch < 0) return RECNOW_EINVAL;
+    if (d->M == 0 || d->N == 0 || d->batch == 0) return RECNOW_OK;
+    if (!d->A || !d->B || !d->C) return RECNOW_EINVAL;
+    if ((d->a_mode != RECNOW_OPMODE_NONE && !d->A2) || (d->b_mode != RECNOW_OPMODE_NONE && !d->B2)) return RECNOW_EINVAL;
+    if (d->K == 0) return RECNOW_EUNSUPPORTED;
+    const GemmCfg c = pick_cfg(d->N);
+    GemmK k;
+    k.A = d->A; k.A2 = d->a_mode ? d->A2 : nullptr; k.B = d->B; k.B2 = d->b_mode ? d->B2 : nullptr;
+    k.bias = d->bias; k.emul = d->emul; k.C = d->C; k.partial = nullptr;
+    k.lda = d->lda; k.ldb = d->ldb; k.ldc = d->ldc; k.lde = d->lde;
+    k.sA = d->a_batch_stride; k.sB = d->b_batch_stride; k.sC = d->c_batch_stride;
+    k.sBias = d->bias_batch_stride; k.sE = d->e_batch_stride;
+    k.M = d->M; k.N = d->N; k.K = d->K; k.batch = d->batch;
+    k.a_mode = d->a_mode; k.a_act = d->a_act; k.b_mode = d->b_mode; k.b_act = d->b_act;
+    k.act = d->act; k.act_cols = d->act_cols > 0 ? d->act_cols : d->N; k.e_mode = d->e_mode; k.e_act = d->e_act;
+    k.accumulate = d->accumulate;
+    pick_split(d, c, &k.splitk, &k.kchunk);
+    if (k.splitk > 1) {
+        const size_t need = rn_align((size_t)k.splitk * d->batch * d->M * d->N * sizeof(float));
+        if (!ws || ws_bytes < need) return RECNOW_EWORKSPACE;
+        k.partial = (float*)ws;
+    }
+    const long long gz = (long long)d->batch * k.splitk;
+    if (gz > 65535) return RECNOW_EUNSUPPORTED;
+    dim3 grid(rn_cdiv(d->M, c.BM), rn_cdiv(d->N, c.BN), (unsigned)gz);
+    const bool a_kc = d->a_trans == 0, b_kc = d->b_trans != 0;
+    int rc;
+    if (c.BM == 256 && c.BN == 32) rc = launch_cfg<256, 32, 4, 1>(k, a_kc, b_kc, grid, st);
+    else if (c.BM == 256 && c.BN == 64) rc = launch_cfg<256, 64, 4, 1>(k, a_kc, b_kc, grid, st);
+    else if (c.BN == 160) rc = launch_cfg<128, 160, 4, 1>(k, a_kc, b_kc, grid, st);
+    else rc = launch_cfg<128, 128, 2, 2>(k, a_kc, b_kc, grid, st);
+    if (rc) return rc;
+    if (k.splitk > 1) {
+        const int64_t total = (int64_t)d->M * d->N * d->batch;
+        int g = rn_cdiv(total, 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(k_gemm_splitk_reduce, g, 256, 0, st, k);
+        RN_LAUNCH_CHECK();
+    }
+    return RECNOW_OK;
+}
+
+// ---- deterministic column sum (bias gradients) -----------------------------------------------------------
+#define CS_ROWS_PER_BLOCK 512
+__global__ void __launch_bounds__(256)
+k_colsum_partial(const float* __restrict__ X, const float* __restrict__ X2, int mode, int act, int64_t M, int64_t N, int64_t ld,
+                 float* __restrict__ part) {
+    // block (bx, by): columns bx*256 + tid, rows by*CS_ROWS_PER_BLOCK ..
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS_PER_BLOCK;
+    const int64_t r1 = min(M, r0 + CS_ROWS_PER_BLOCK);
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        float v = X[r * ld + col];
+        if (mode == RECNOW_OPMODE_MUL) v *= X2[r * ld + col];
+        else if (mode == RECNOW_OPMODE_ACTGRAD) v *= rn_act_grad_from_out(X2[r * ld + col], act);
+        s += v;
+    }
+    part[(int64_t)blockIdx.y * N + col] = s;
+}
+__global__ void __launch_bounds__(256)
+k_colsum_final(const float* __restrict__ part, int nslab, int64_t N, float* __restrict__ out, int accumulate) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < nslab; ++i) s += part[(int64_t)i * N + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+
+size_t rn_colsum_ws_bytes(int64_t M, int64_t N) {
+    return rn_align((size_t)rn_cdiv(M > 0 ? M : 1, CS_ROWS_PER_BLOCK) * (size_t)(N > 0 ? N : 1) * sizeof(float));
+}
+
+int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int64_t N, int64_t ld, float* out,
+              int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (M < 0 || N < 0) return RECNOW_EINVAL;
+    if (N == 0) return RECNOW_OK;
+    if (!out) return RECNOW_EINVAL;
+    if (M == 0) {
+        if (!accumulate) RN_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st));
+        return RECNOW_OK;
+    }
+    if (!X || (mode && !X2) || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < rn_colsum_ws_bytes(M, N)) return RECNOW_EWORKSPACE;
+    const int nslab = rn_cdiv(M, CS_ROWS_PER_BLOCK);
+    dim3 g1(rn_cdiv(N, 256), nslab);
+    hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws);
+    hipLaunchKernelGGL(k_colsum_final, rn_cdiv(N, 256), 256, 0, st, (const float*)ws, nslab, N, out, accumulate);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" size_t recnow_gemm_workspace_bytes(const recnow_gemm_desc* desc_host) {
+    return desc_host ? rn_gemm_ws_bytes(desc_host) : 0;
+}
+extern "C" int recnow_gemm(const recnow_gemm_desc* desc_host, void* ws, size_t ws_bytes, void* stream) {
+    return rn_gemm(desc_host, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -114,7 +114,8 @@ k_pair_bpr(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, c
         float w = 1.f;
         if (power != 0.f) {
             const float cnt = (float)cnt_super[super_id[k]];
-            w = (power == 1.f) ? cnt : powf(cnt, power);
+            // cnt == 0: this row takes part in no pair, its weight is never used (avoid 0**negative = inf -> inf*0)
+            w = (cnt == 0.f) ? 1.f : ((power == 1.f) ? cnt : powf(cnt, power));
         }
         float la = 0.f, ga = 0.f;
         for (int j = s; j < e; ++j) {

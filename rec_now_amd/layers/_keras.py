@@ -123,9 +123,13 @@ class Layer(nn.Module):
         out = {}
         for name, attr in self._weight_names.items():
             out[prefix + name] = getattr(self, attr)
-        for child_name, child in self.named_children():
-            if isinstance(child, Layer):
-                out.update(child.named_weights(prefix + child.name + '/'))
+        def walk(module, pre):
+            for _, child in module.named_children():
+                if isinstance(child, Layer):
+                    out.update(child.named_weights(pre + child.name + '/'))
+                else:                      # nn.ModuleList and other plain containers are transparent
+                    walk(child, pre)
+        walk(self, prefix)
         return out
 
     def set_weights_by_name(self, values):

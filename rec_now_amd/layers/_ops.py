@@ -1,0 +1,178 @@
+"""torch.autograd.Function wrappers over the C ABI for the layer kernels (host plumbing only: shapes, buffers, streams)."""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+def _host_ptr_array(tensors):
+    """HOST array of device pointers (the `*_host` parameters of include/recnow.h)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+# ---- MultiDense ----------------------------------------------------------------------------------------------
+class MultiDenseFunction(torch.autograd.Function):
+    """y[n] = act(x[n] @ kernel[n] + bias[n]); x (B,D) broadcast or (N,B,D); kernel (N,D,U); bias (N,1,U) or None."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, act_code):
+        x = _lib.f32c(x, 'inputs')
+        kernel = _lib.f32c(kernel, 'kernel')
+        N, D, U = kernel.shape
+        batched = x.dim() == 3
+        B = x.shape[-2]
+        if bias is not None:
+            bias = _lib.f32c(bias, 'bias')
+        y = torch.empty((N, B, U), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        ws = _lib.workspace(lib.recnow_multi_dense_workspace_bytes(B, D, U, N), x.device)
+        _lib.call('recnow_multi_dense_fwd', _lib.ptr(x), 1 if batched else 0, _lib.ptr(kernel), _lib.ptr(bias), B, D, U, N,
+                  act_code, _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctx.save_for_backward(x, kernel, y)
+        ctx.meta = (batched, B, D, U, N, act_code, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, kernel, y = ctx.saved_tensors
+        batched, B, D, U, N, act_code, has_bias = ctx.meta
+        dy = _lib.f32c(dy, 'grad')
+        need_x, need_k, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_x else None
+        dk = torch.empty_like(kernel) if need_k else None
+        db = torch.empty((N, 1, U), dtype=torch.float32, device=x.device) if need_b else None
+        lib = _lib.load()
+        ws = _lib.workspace(lib.recnow_multi_dense_workspace_bytes(B, D, U, N), x.device)
+        _lib.call('recnow_multi_dense_bwd', _lib.ptr(x), 1 if batched else 0, _lib.ptr(kernel), _lib.ptr(y), _lib.ptr(dy), B, D,
+                  U, N, act_code, _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.stream())
+        return dx, dk, db, None
+
+
+def multi_dense(x, kernel, bias, act_code):
+    return MultiDenseFunction.apply(x, kernel, bias, act_code)
+
+
+# ---- gate softmax + expert mixing ------------------------------------------------------------------------------
+class MoeMixFunction(torch.autograd.Function):
+    """out[t] = sum_n softmax(logits[t])[:, n, None] * experts[n];  logits (T,B,N); experts: N tensors (B,U)."""
+
+    @staticmethod
+    def forward(ctx, logits, *experts):
+        logits = _lib.f32c(logits, 'gate logits')
+        T, B, N = logits.shape
+        es = [_lib.f32c(e, 'expert output') for e in experts]
+        if len(es) != N:
+            raise ValueError('gate has %d outputs but %d experts were given' % (N, len(es)))
+        U = es[0].shape[-1]
+        dev = logits.device
+        gates = torch.empty((T, B, N), dtype=torch.float32, device=dev)
+        out = torch.empty((T, B, U), dtype=torch.float32, device=dev)
+        ptrs = _lib.ptr_array(es, dev)
+        _lib.call('recnow_moe_mix_fwd', _lib.ptr(logits), _lib.ptr(ptrs), T, B, N, U, _lib.ptr(gates), _lib.ptr(out), _lib.stream())
+        ctx.save_for_backward(gates, *es)
+        ctx.meta = (T, B, N, U)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        gates, *es = ctx.saved_tensors
+        T, B, N, U = ctx.meta
+        dev = gates.device
+        dout = _lib.f32c(dout, 'grad')
+        dlogits = torch.empty_like(gates)
+        des = torch.empty((N, B, U), dtype=torch.float32, device=dev)
+        ptrs = _lib.ptr_array(es, dev)
+        dptrs = _lib.ptr_array([des[n] for n in range(N)], dev)
+        _lib.call('recnow_moe_mix_bwd', _lib.ptr(gates), _lib.ptr(ptrs), _lib.ptr(dout), T, B, N, U, _lib.ptr(dlogits),
+                  _lib.ptr(dptrs), 0, _lib.stream())
+        return (dlogits,) + tuple(des.unbind(0))
+
+
+def moe_mix(logits, experts):
+    """logits (T,B,N) or (B,N); experts: list of N (B,U) tensors.  Returns (T,B,U) or (B,U)."""
+    squeeze = logits.dim() == 2
+    if squeeze:
+        logits = logits.unsqueeze(0)
+    out = MoeMixFunction.apply(logits, *experts)
+    return out[0] if squeeze else out
+
+
+# ---- DCN-v1 ----------------------------------------------------------------------------------------------------
+class DCNFunction(torch.autograd.Function):
+    """All L cross layers fused.  kernels (L,D), biases (L,D) or None."""
+
+    @staticmethod
+    def forward(ctx, x, kernels, biases, act_code):
+        x = _lib.f32c(x, 'inputs')
+        kernels = _lib.f32c(kernels, 'kernels')
+        if biases is not None:
+            biases = _lib.f32c(biases, 'biases')
+        B, D = x.shape
+        L = kernels.shape[0]
+        y = torch.empty_like(x)
+        rc = getattr(_lib.load(), 'recnow_dcn_fwd')(_lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases), B, D, L, act_code,
+                                                     _lib.ptr(y), _lib.stream())
+        if rc == -3:
+            raise NotImplementedError('DCNLayer kernels support input_dim <= 4096 (multiple of 4) or <= 1024 otherwise; got %d' % D)
+        _lib.check(rc, 'recnow_dcn_fwd')
+        ctx.save_for_backward(x, kernels, biases if biases is not None else x.new_empty(0))
+        ctx.meta = (B, D, L, act_code, biases is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, kernels, biases = ctx.saved_tensors
+        B, D, L, act_code, has_bias = ctx.meta
+        dy = _lib.f32c(dy, 'grad')
+        dx = torch.empty_like(x)
+        dk = torch.empty_like(kernels)
+        db = torch.empty_like(kernels) if has_bias else None
+        lib = _lib.load()
+        ws = _lib.workspace(lib.recnow_dcn_workspace_bytes(B, D, L), x.device)
+        rc = lib.recnow_dcn_bwd(_lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases) if has_bias else None, _lib.ptr(dy), B, D, L,
+                                act_code, _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.stream())
+        if rc == -3:
+            raise NotImplementedError('DCNLayer backward supports degree_of_cross <= 4')
+        _lib.check(rc, 'recnow_dcn_bwd')
+        return dx, dk, db, None
+
+
+# ---- DCN-v2 mix ---------------------------------------------------------------------------------------------------
+class DCNMixFunction(torch.autograd.Function):
+    """All L layers of DCNMixLayer.  params = U_0..U_{L-1}, V_0.., W_0.., bias_0.., gate_0.. (5*L tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, L, act_inner, act_outer, *params):
+        x = _lib.f32c(x, 'inputs')
+        ps = [_lib.f32c(p, 'weight') for p in params]
+        U, V, W, bias, gate = (ps[i * L:(i + 1) * L] for i in range(5))
+        N, D, S = U[0].shape
+        B = x.shape[0]
+        lib = _lib.load()
+        saved = _lib.workspace(lib.recnow_dcn_mix_saved_bytes(B, D, S, N, L), x.device)
+        ws = _lib.workspace(lib.recnow_dcn_mix_workspace_bytes(B, D, S, N, L), x.device)
+        y = torch.empty_like(x)
+        _lib.call('recnow_dcn_mix_fwd', _lib.ptr(x), _host_ptr_array(U), _host_ptr_array(V), _host_ptr_array(W),
+                  _host_ptr_array(bias), _host_ptr_array(gate), B, D, S, N, L, act_inner, act_outer, _lib.ptr(y),
+                  _lib.ptr(saved), saved.numel(), _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctx.save_for_backward(x, saved, *ps)
+        ctx.meta = (B, D, S, N, L, act_inner, act_outer)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, saved, *ps = ctx.saved_tensors
+        B, D, S, N, L, act_inner, act_outer = ctx.meta
+        U, V, W, bias, gate = (ps[i * L:(i + 1) * L] for i in range(5))
+        dy = _lib.f32c(dy, 'grad')
+        dx = torch.empty_like(x)
+        grads = [torch.empty_like(p) for p in ps]
+        dU, dV, dW, dbias, dgate = (grads[i * L:(i + 1) * L] for i in range(5))
+        lib = _lib.load()
+        ws = _lib.workspace(lib.recnow_dcn_mix_workspace_bytes(B, D, S, N, L), x.device)
+        _lib.call('recnow_dcn_mix_bwd', _lib.ptr(x), _host_ptr_array(U), _host_ptr_array(V), _host_ptr_array(W),
+                  _host_ptr_array(bias), _host_ptr_array(gate), _lib.ptr(dy), _lib.ptr(saved), saved.numel(), B, D, S, N, L,
+                  act_inner, act_outer, _lib.ptr(dx), _host_ptr_array(dU), _host_ptr_array(dV), _host_ptr_array(dW),
+                  _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(ws), ws.numel(), _lib.stream())
+        return (dx, None, None, None) + tuple(grads)

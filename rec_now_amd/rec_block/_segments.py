@@ -45,8 +45,8 @@ def build_segments(groups):
     """groups: tensor or list of tensors, each with B elements ((B,), (B,1) or (1,B)).  A list means "same group in
     EVERY tensor" (logical AND of the masks, pairwise_loss_from_batch.py:65-73); groups[0] is the main group used for
     the occurrence weights (:285)."""
-    if not isinstance(groups, (list, tuple)):
-        groups = [groups]
+    if not (isinstance(groups, (list, tuple)) and len(groups) > 0 and all(isinstance(g, torch.Tensor) for g in groups)):
+        groups = [groups]          # one tensor, or one array-like of ids (e.g. a python list of numbers)
     if len(groups) == 0:
         raise ValueError('groups must not be empty')
     keyed = [_as_key_tensor(g) for g in groups]

@@ -33,7 +33,10 @@ def test_fm_fwd_bwd_vs_oracle(dev, B, F, D):
     x64 = [torch.from_numpy(x).double().requires_grad_(True) for x in xs]
     ry = R.fm_layer(x64)
     ry.backward(torch.from_numpy(gy).double())
-    scale = max(np.abs(ry.detach().numpy()).max(), 1e-12)
+    # tolerance is relative to the magnitude of the terms being subtracted (S^2 and sum x^2), not to a result
+    # that cancels to ~0 (e.g. F == 1)
+    xs64 = np.stack(xs).astype(np.float64)
+    scale = max(np.abs(ry.detach().numpy()).max(), 0.5 * ((xs64.sum(0) ** 2).sum(1) + (xs64 ** 2).sum((0, 2))).max())
     assert np.abs(y.detach().cpu().numpy() - ry.detach().numpy()).max() <= RTOL * scale
     for a, b in zip(xd, x64):
         gs = max(np.abs(b.grad.numpy()).max(), 1e-12)

@@ -1,0 +1,325 @@
+"""GPU parity for the GEMM-backed layers: MultiDense, MMoE, PLE, DCN, DCNMix and the raw GEMM entry point.
+Each layer is checked (a) against the reference's own golden (fixtures regenerated from the reference tests' seeds),
+(b) forward + backward against the oracle (fp64 autograd of the dense restatement) on seeded random inputs.
+Tolerance: 1e-5 relative to the largest magnitude of the compared tensor (north_star: 1e-5 rel fp32)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import dense_ref as R
+from test_oracle_golden import ple_layers_from_fixture
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def close(a, b, rtol=RTOL):
+    a = a.detach().cpu().double().numpy() if hasattr(a, 'detach') else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if hasattr(b, 'detach') else np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max()
+    assert err <= rtol * scale, 'max err %.3g vs scale %.3g (rel %.3g)' % (err, scale, err / scale)
+
+
+# ---- raw GEMM ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K,ta,tb', [(1, 1, 1, 0, 0), (5, 3, 7, 0, 0), (130, 33, 70, 0, 1), (257, 129, 65, 1, 0),
+                                         (300, 144, 1024, 0, 0), (64, 64, 5000, 1, 0), (1000, 160, 130, 0, 1),
+                                         (130, 1024, 3000, 1, 0)])
+def test_gemm_vs_fp64(dev, M, N, K, ta, tb):
+    from rec_now_amd import _lib
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.uniform(-1, 1, (K, M) if ta else (M, K)).astype(np.float32)
+    Bm = rng.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.uniform(-1, 1, N).astype(np.float32)
+    Ad, Bd, bd = (torch.from_numpy(v).to(dev) for v in (A, Bm, bias))
+    C = torch.empty((M, N), device=dev)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.a_trans = Ad.data_ptr(), A.shape[1], ta
+    d.B, d.ldb, d.b_trans = Bd.data_ptr(), Bm.shape[1], tb
+    d.C, d.ldc = C.data_ptr(), N
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    d.bias, d.act = bd.data_ptr(), 2     # tanh epilogue
+    lib = _lib.load()
+    ws = _lib.workspace(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)), dev)
+    _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.stream())
+    A64 = A.astype(np.float64).T if ta else A.astype(np.float64)
+    B64 = Bm.astype(np.float64).T if tb else Bm.astype(np.float64)
+    pre = A64 @ B64 + bias
+    ref = np.tanh(pre)
+    # error budget: fp32 accumulation error of the pre-activation (~1e-7 * sum|a*b|) through tanh' <= 1
+    bound = 2e-7 * (np.abs(A64) @ np.abs(B64)).max() + 1e-6
+    assert np.abs(C.cpu().numpy() - ref).max() <= bound
+
+
+# ---- MultiDense ------------------------------------------------------------------------------------------------
+def test_multi_dense_reference_goldens(dev, golden):
+    # /root/reference/tests/layers/test_multi_dense_layer.py:19-55
+    from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+    from rec_now_amd.util.numpy_tools import calc_sum_of_abs_diff
+    for name in ('multi_dense_2d', 'multi_dense_3d'):
+        g = golden(name)
+        x = torch.from_numpy(g['inputs']).to(dev)
+        dense_layer = MultiDenseLayer(1, 3)
+        dense_layer(x)                                  # builds
+        dense_layer.set_weights_by_name({'kernel': g['kernel'], 'bias': g['bias']})
+        result = dense_layer(x)
+        assert calc_sum_of_abs_diff(result, g['golden']) < 1e-5
+
+
+def test_multi_dense_wrong_3d_raises(dev):
+    # /root/reference/tests/layers/test_multi_dense_layer.py:57-73 (InvalidArgumentError there)
+    from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+    with pytest.raises(ValueError, match=r'\[4, 2, 4\] vs. \[3, 4, 1\]'):
+        MultiDenseLayer(1, 3)(torch.zeros(4, 2, 4, device=dev))
+
+
+@pytest.mark.parametrize('B,D,U,N,batched,act', [(7, 5, 3, 2, False, None), (300, 64, 48, 3, True, 'relu'),
+                                                  (1000, 130, 1, 1, False, 'tanh'), (513, 256, 200, 4, False, 'sigmoid'),
+                                                  (2048, 1024, 1, 1, False, None)])
+def test_multi_dense_fwd_bwd_vs_oracle(dev, B, D, U, N, batched, act):
+    from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+    rng = np.random.default_rng(B + D + U)
+    x = rng.normal(0, 0.5, (N, B, D) if batched else (B, D)).astype(np.float32)
+    k = rng.uniform(-0.3, 0.3, (N, D, U)).astype(np.float32)
+    b = rng.uniform(-0.3, 0.3, (N, 1, U)).astype(np.float32)
+    gy = rng.normal(size=(N, B, U)).astype(np.float32)
+    layer = MultiDenseLayer(U, N, activation=act)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    layer(xd)
+    layer.set_weights_by_name({'kernel': k, 'bias': b})
+    y = layer(xd)
+    y.backward(torch.from_numpy(gy).to(dev))
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    k64 = torch.from_numpy(k).double().requires_grad_(True)
+    b64 = torch.from_numpy(b).double().requires_grad_(True)
+    ry = R.multi_dense_layer(x64, k64, b64, act)
+    ry.backward(torch.from_numpy(gy).double())
+    close(y, ry)
+    close(xd.grad, x64.grad)
+    close(layer.kernel.grad, k64.grad)
+    close(layer.bias.grad, b64.grad)
+
+
+# ---- MMoE --------------------------------------------------------------------------------------------------------
+def _mmoe_weights(g):
+    return {'MMoE/experts/MultiDenseLayer_0/kernel': g['expert_kernel_0'], 'MMoE/experts/MultiDenseLayer_0/bias': g['expert_bias_0'],
+            'MMoE/experts/MultiDenseLayer_1/kernel': g['expert_kernel_1'], 'MMoE/experts/MultiDenseLayer_1/bias': g['expert_bias_1'],
+            'MMoE/gates/MultiDenseLayer/kernel': g['gate_kernel'], 'MMoE/gates/MultiDenseLayer/bias': g['gate_bias']}
+
+
+def test_mmoe_reference_golden(dev, golden):
+    # /root/reference/tests/layers/test_mmoe_layer.py:18-38
+    from rec_now_amd.layers.mmoe_layer import MMOELayer
+    from rec_now_amd.util.numpy_tools import calc_sum_of_abs_diff
+    g = golden('mmoe')
+    inputs = torch.from_numpy(g['inputs']).to(dev)
+    mmoe_layer = MMOELayer(2, 4, [8, 3], name="MMoE")
+    mmoe_layer(inputs, False)
+    mmoe_layer.set_weights_by_name(_mmoe_weights(g))
+    result = mmoe_layer(inputs, False)
+    assert isinstance(result, list) and len(result) == 2
+    assert calc_sum_of_abs_diff(torch.stack(result), g['golden']) < 1e-5
+    merged = mmoe_layer(inputs)                 # merge_output=True
+    assert merged.shape == (2, 3, 3)
+
+
+@pytest.mark.parametrize('act', [None, 'relu'])
+def test_mmoe_fwd_bwd_vs_oracle(dev, act):
+    from rec_now_amd.layers.mmoe_layer import MMOELayer
+    rng = np.random.default_rng(11)
+    B, D, T, N, dims = 700, 96, 3, 5, [64, 32]
+    x = rng.normal(0, 1, (B, D)).astype(np.float32)
+    layer = MMOELayer(T, N, dims, activation=act, name='m')
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    layer(xd)
+    w = {k: rng.uniform(-0.2, 0.2, tuple(v.shape)).astype(np.float32) for k, v in layer.named_weights().items()}
+    layer.set_weights_by_name(w)
+    gy = rng.normal(size=(T, B, dims[-1])).astype(np.float32)
+    y = layer(xd)
+    y.backward(torch.from_numpy(gy).to(dev))
+    w64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in w.items()}
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    ry = R.mmoe_layer(x64, [w64['m/experts/MultiDenseLayer_%d/kernel' % i] for i in range(2)],
+                      [w64['m/experts/MultiDenseLayer_%d/bias' % i] for i in range(2)],
+                      w64['m/gates/MultiDenseLayer/kernel'], w64['m/gates/MultiDenseLayer/bias'], activation=act)
+    ry.backward(torch.from_numpy(gy).double())
+    close(y, ry)
+    close(xd.grad, x64.grad)
+    for k, p in layer.named_weights().items():
+        close(p.grad, w64[k].grad)
+
+
+# ---- PLE ---------------------------------------------------------------------------------------------------------
+def _ple_names(li, gi, names=('shared_0', 'special_0', 'special_1')):
+    # the reference names groups shared_0.., special_0.. but assigns them through zip() -> group gi gets task_names[gi]
+    task_names = ['shared_0', 'shared_1', 'special_0', 'special_1']     # reference :108-111 with num_task = 2
+    return task_names[gi]
+
+
+def _load_ple(layer, g):
+    vals = {}
+    for li in range(3):
+        for gi in range(3):
+            tn = _ple_names(li, gi)
+            for di in range(2):
+                base = 'PLE/ple_layer_%d/task_%s/PLE/ple_layer_%d/task_%s/MultiDenseLayer_%d/' % (li, tn, li, tn, di)
+                vals[base + 'kernel'] = g['l%d_g%d_dnn%d_kernel' % (li, gi, di)]
+                vals[base + 'bias'] = g['l%d_g%d_dnn%d_bias' % (li, gi, di)]
+            key = 'l%d_g%d_gate_kernel' % (li, gi)
+            if key in g:
+                base = 'PLE/ple_gate_%d/task_%s/dense/' % (li, tn)
+                vals[base + 'kernel'] = g[key]
+                vals[base + 'bias'] = g['l%d_g%d_gate_bias' % (li, gi)]
+    layer.set_weights_by_name(vals)
+
+
+def test_ple_reference_golden(dev, golden):
+    # /root/reference/tests/layers/test_ple_layer.py:18-38
+    from rec_now_amd.layers.ple_layer import PLELayer
+    from rec_now_amd.util.numpy_tools import calc_sum_of_abs_diff
+    g = golden('ple')
+    inputs = torch.from_numpy(g['inputs']).to(dev)
+    ple_layer = PLELayer(2, [[2, 3], [2, 3], [3, 2]], [4, 3, 2], 1, name="PLE")
+    ple_layer(inputs)
+    _load_ple(ple_layer, g)
+    task1_output, task2_output = ple_layer(inputs)
+    assert calc_sum_of_abs_diff(task1_output, g['golden_task1']) < 1e-5
+    assert calc_sum_of_abs_diff(task2_output, g['golden_task2']) < 1e-5
+
+
+def test_ple_fwd_bwd_vs_oracle(dev, golden):
+    from rec_now_amd.layers.ple_layer import PLELayer
+    g = golden('ple')
+    rng = np.random.default_rng(3)
+    B = 333
+    x = rng.normal(0, 1, (B, 4)).astype(np.float32)
+    layer = PLELayer(2, [[2, 3], [2, 3], [3, 2]], [4, 3, 2], 1, name="PLE", activation='tanh')
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    layer(xd)
+    _load_ple(layer, g)
+    outs = layer(xd)
+    gy = [rng.normal(size=(B, 2)).astype(np.float32) for _ in range(2)]
+    (outs[0] * torch.from_numpy(gy[0]).to(dev)).sum().add((outs[1] * torch.from_numpy(gy[1]).to(dev)).sum()).backward()
+    g64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in g.items() if k.startswith('l')}
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    routs = R.ple_layer(x64, ple_layers_from_fixture(g64, to=lambda v: v), [True, False, False], activation='tanh')
+    ((routs[0] * torch.from_numpy(gy[0]).double()).sum() + (routs[1] * torch.from_numpy(gy[1]).double()).sum()).backward()
+    close(outs[0], routs[0])
+    close(outs[1], routs[1])
+    close(xd.grad, x64.grad)
+    tn = _ple_names(0, 1)
+    p = layer.named_weights()['PLE/ple_layer_0/task_%s/PLE/ple_layer_0/task_%s/MultiDenseLayer_0/kernel' % (tn, tn)]
+    close(p.grad, g64['l0_g1_dnn0_kernel'].grad)
+    p = layer.named_weights()['PLE/ple_gate_1/task_shared_0/dense/kernel']
+    close(p.grad, g64['l1_g0_gate_kernel'].grad)
+
+
+def test_ple_param_errors():
+    from rec_now_amd.layers.ple_layer import PLELayer
+    with pytest.raises(TypeError):
+        PLELayer(2, 3, 2)                      # ple_layer.py:42-43
+    with pytest.raises(ValueError):
+        PLELayer._extend_int_list([], 3)       # ple_layer.py:73-74
+    with pytest.raises(TypeError):
+        PLELayer._extend_int_list('a', 3)      # ple_layer.py:66-68
+
+
+# ---- DCN-v1 ------------------------------------------------------------------------------------------------------
+def test_dcn_reference_golden(dev, golden):
+    # /root/reference/tests/layers/test_dcn_layer.py:18-30
+    from rec_now_amd.layers.dcn_layer import DCNLayer
+    from rec_now_amd.util.numpy_tools import calc_sum_of_abs_diff
+    g = golden('dcn')
+    inputs = torch.from_numpy(g['inputs']).to(dev)
+    dcn_layer = DCNLayer(3)
+    dcn_layer(inputs)
+    dcn_layer.set_weights_by_name({k: v for k, v in g.items() if k.startswith(('kernel_', 'bias_'))})
+    result = dcn_layer(inputs)
+    assert calc_sum_of_abs_diff(result, g['golden']) < 1e-5
+
+
+@pytest.mark.parametrize('B,D,L,act,use_bias', [(5, 3, 3, None, True), (1000, 64, 2, 'tanh', True), (777, 1024, 3, None, True),
+                                                (300, 2048, 4, 'relu', False), (129, 130, 1, 'sigmoid', True),
+                                                (64, 1000, 3, None, True)])
+def test_dcn_fwd_bwd_vs_oracle(dev, B, D, L, act, use_bias):
+    from rec_now_amd.layers.dcn_layer import DCNLayer
+    rng = np.random.default_rng(B + D + L)
+    x = rng.normal(0, 1, (B, D)).astype(np.float32)
+    ks = [rng.uniform(-1, 1, (D, 1)).astype(np.float32) / np.sqrt(D) for _ in range(L)]
+    bs = [rng.uniform(-0.5, 0.5, (1, D)).astype(np.float32) for _ in range(L)]
+    gy = rng.normal(size=(B, D)).astype(np.float32)
+    layer = DCNLayer(L, activation=act, use_bias=use_bias)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    layer(xd)
+    vals = {'kernel_%d' % i: ks[i] for i in range(L)}
+    if use_bias:
+        vals.update({'bias_%d' % i: bs[i] for i in range(L)})
+    layer.set_weights_by_name(vals)
+    y = layer(xd)
+    y.backward(torch.from_numpy(gy).to(dev))
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    k64 = [torch.from_numpy(k).double().requires_grad_(True) for k in ks]
+    b64 = [torch.from_numpy(b).double().requires_grad_(True) for b in bs] if use_bias else None
+    ry = R.dcn_layer(x64, k64, b64, act)
+    ry.backward(torch.from_numpy(gy).double())
+    close(y, ry)
+    close(xd.grad, x64.grad)
+    for i in range(L):
+        close(layer.kernels[i].grad, k64[i].grad)
+        if use_bias:
+            close(layer.biases[i].grad, b64[i].grad)
+
+
+# ---- DCN-v2 mix -----------------------------------------------------------------------------------------------------
+def _mix_weights(g, L):
+    vals = {}
+    for l in range(L):
+        for n in ('origin_to_sub_kernels_of_layer%d', 'sub_to_sub_kernels_of_layer%d', 'sub_to_origin_kernels_of_layer%d',
+                  'bias_of_layer%d'):
+            vals[n % l] = g[n % l]
+        vals['gate_of_layer%d/kernel' % l] = g['gate_of_layer%d' % l]
+    return vals
+
+
+def test_dcn_mix_reference_golden(dev, golden):
+    # /root/reference/tests/layers/test_dcn_mix_layer.py:18-31
+    from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
+    from rec_now_amd.util.numpy_tools import calc_sum_of_abs_diff
+    g = golden('dcn_mix')
+    input = torch.from_numpy(g['inputs']).to(dev)
+    dcn_mix_layer = DCNMixLayer(dim_sub_space=3, num_layer=2, num_expert=4)
+    dcn_mix_layer(input)
+    dcn_mix_layer.set_weights_by_name(_mix_weights(g, 2))
+    dcn_mix_output = dcn_mix_layer(input)
+    assert calc_sum_of_abs_diff(dcn_mix_output, g['golden']) < 1e-5
+
+
+@pytest.mark.parametrize('B,D,S,N,L,ai,ao', [(9, 5, 3, 4, 2, 'tanh', 'tanh'), (500, 64, 16, 2, 3, 'tanh', 'tanh'),
+                                              (1000, 256, 64, 2, 2, 'relu', 'sigmoid'), (300, 1024, 64, 2, 3, 'tanh', 'tanh'),
+                                              (257, 130, 7, 3, 1, None, 'tanh')])
+def test_dcn_mix_fwd_bwd_vs_oracle(dev, B, D, S, N, L, ai, ao):
+    from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
+    rng = np.random.default_rng(B + D + S)
+    x = rng.normal(0, 0.5, (B, D)).astype(np.float32)
+    gy = rng.normal(size=(B, D)).astype(np.float32)
+    layer = DCNMixLayer(S, num_layer=L, num_expert=N, activation_inner=ai, activation_outer=ao)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    layer(xd)
+    w = {k: rng.uniform(-1, 1, tuple(v.shape)).astype(np.float32) * (0.3 if 'bias' in k else 1.5 / np.sqrt(v.shape[-2]))
+         for k, v in layer.named_weights().items()}
+    layer.set_weights_by_name(w)
+    y = layer(xd)
+    y.backward(torch.from_numpy(gy).to(dev))
+    w64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in w.items()}
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    pick = lambda fmt: [w64[fmt % l] for l in range(L)]     # noqa: E731
+    ry = R.dcn_mix_layer(x64, pick('origin_to_sub_kernels_of_layer%d'), pick('sub_to_sub_kernels_of_layer%d'),
+                         pick('sub_to_origin_kernels_of_layer%d'), pick('bias_of_layer%d'), pick('gate_of_layer%d/kernel'), ai, ao)
+    ry.backward(torch.from_numpy(gy).double())
+    close(y, ry)
+    close(xd.grad, x64.grad)
+    for k, p in layer.named_weights().items():
+        close(p.grad, w64[k].grad)
