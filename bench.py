@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): samples/sec, forward+backward, in-batch pairwise loss + 3-layer DCN-v2
+(DCNMixLayer, low-rank 64, 2 experts), B = 65536 rows per GPU, 64 fields x 16-dim = 1024 features, on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A step = one forward + backward pass of the hot path over one resident batch (inputs already in HBM):
+    x (B,1024) -> DCNMixLayer(dim_sub_space=64, num_layer=3, num_expert=2) -> MultiDenseLayer(1,1) head -> (B,) scores
+      -> pairwise_loss(scores, labels, group_id) -> backward to every weight (+ SUM all-reduce of weight grads, N > 1).
+Data-parallel (weak scaling): every rank owns whole groups, the loss is combined with one 2-float all-reduce
+(rec_now_amd/dp.py).  Prints ONE JSON line on rank 0.
+
+roofline:     the dominant kernel is the exact-fp32 MFMA GEMM; `achieved` = algorithmic flops (2*M*N*K per launch)
+              / HIP-event time of every launch of the busiest GEMM tile family during the timed steps, measured by
+              the library's own event hook on the launch stream (recnow_prof_*).
+cpu_baseline: the oracle (dense O(B^2) reference formulation, torch CPU, oracle/dense_ref.py) timed on this host on a
+              bounded sample of the same workload (B_s rows with the same 64 rows/group), rank 0, N = 1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 65536
+N_FIELD, EMB_DIM = 64, 16
+D = N_FIELD * EMB_DIM
+SUB, LAYERS, EXPERTS = 64, 3, 2
+ROWS_PER_GROUP = 64
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>'}
+
+
+def synth_batch(B, seed, rank=0):
+    rng = np.random.default_rng(seed + 1000 * rank)
+    x = rng.normal(0.0, 0.05, (B, D)).astype(np.float32)
+    groups = rng.integers(0, B // ROWS_PER_GROUP, B).astype(np.float32)      # ids are rank-local -> whole groups per rank
+    labels = (rng.random(B) < 0.25).astype(np.float32)
+    return x, groups, labels
+
+
+class Model(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
+        from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+        self.cross = DCNMixLayer(dim_sub_space=SUB, num_layer=LAYERS, num_expert=EXPERTS)
+        self.head = MultiDenseLayer(1, 1)
+
+    def forward(self, x):
+        return self.head(self.cross(x)).reshape(-1)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Reference formulation (dense (B,B) masks) on the host CPU, fwd+bwd, on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import dense_ref as R
+    Bs = 8192
+    x, groups, labels = synth_batch(Bs, 3)
+    g = torch.Generator().manual_seed(3)
+    lim = lambda *s: float(np.sqrt(6.0 / (s[-2] + s[-1])))     # noqa: E731
+    U = [((torch.rand(EXPERTS, D, SUB, generator=g) * 2 - 1) * lim(D, SUB)).requires_grad_(True) for _ in range(LAYERS)]
+    V = [((torch.rand(EXPERTS, SUB, SUB, generator=g) * 2 - 1) * lim(SUB, SUB)).requires_grad_(True) for _ in range(LAYERS)]
+    W = [((torch.rand(EXPERTS, SUB, D, generator=g) * 2 - 1) * lim(SUB, D)).requires_grad_(True) for _ in range(LAYERS)]
+    b = [torch.zeros(1, EXPERTS, D, requires_grad=True) for _ in range(LAYERS)]
+    K = [((torch.rand(D, EXPERTS, generator=g) * 2 - 1) * lim(D, EXPERTS)).requires_grad_(True) for _ in range(LAYERS)]
+    hk = ((torch.rand(1, D, 1, generator=g) * 2 - 1) * lim(D, 1)).requires_grad_(True)
+    hb = torch.zeros(1, 1, 1, requires_grad=True)
+    xt, gt, yt = torch.from_numpy(x), torch.from_numpy(groups), torch.from_numpy(labels)
+    params = U + V + W + b + K + [hk, hb]
+
+    def step():
+        for p in params:
+            p.grad = None
+        s = R.multi_dense_layer(R.dcn_mix_layer(xt, U, V, W, b, K), hk, hb).reshape(-1)
+        loss = R.pairwise_loss(s, yt, gt)
+        loss.backward()
+        return float(loss)
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 50:
+            break
+    return {'value': Bs * n / el, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d steps of fwd+bwd at B=%d (1/8 of the batch, same %d rows/group, same model): dense O(B^2) reference '
+                      'formulation restated on torch-CPU fp32 (oracle/dense_ref.py); TF2 itself is not installable here'
+                      % (n, Bs, ROWS_PER_GROUP)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events in the timed region')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from rec_now_amd import _lib, dp
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss_fused
+    lib = _lib.load()
+
+    torch.manual_seed(3)                      # identical replicated weights on every rank
+    model = Model()
+    x, groups, labels = synth_batch(B_PER_GPU, 3, rank)
+    xd, gd, yd = (torch.from_numpy(v).to(dev) for v in (x, groups, labels))
+    model(xd[:256])                           # lazy build on the device
+    params = [p for p in model.parameters()]
+    reducer = dp.GradientAllReducer(params)
+
+    def step():
+        for p in params:
+            p.grad = None
+        scores = model(xd)
+        local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False)
+        loss_bw, loss_val, _ = dp.global_pairwise_loss(local_sum, n_pair)
+        loss_bw.backward()
+        reducer.all_reduce()
+        return loss_val
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = not args.no_prof
+    if prof:
+        _lib.check(lib.recnow_prof_enable(64 * (args.steps + 1)), 'recnow_prof_enable')
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    roofline = None
+    if prof:
+        cnt = (ctypes.c_int * 8)()
+        ms = (ctypes.c_double * 8)()
+        fl = (ctypes.c_double * 8)()
+        _lib.check(lib.recnow_prof_collect(cnt, ms, fl), 'recnow_prof_collect')
+        lib.recnow_prof_enable(0)
+        tag = max(GEMM_TAGS, key=lambda t: ms[t])
+        if cnt[tag] > 0:
+            achieved = fl[tag] / (ms[tag] * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'kernel': GEMM_TAGS[tag],
+                        'launches': cnt[tag], 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
+                        'algorithmic_flops_per_launch': fl[tag] / cnt[tag],
+                        'all_gemm': {GEMM_TAGS[t]: {'launches': cnt[t], 'ms': ms[t],
+                                                    'tflops': (fl[t] / (ms[t] * 1e-3) / 1e12) if ms[t] > 0 else None}
+                                     for t in GEMM_TAGS if cnt[t] > 0}}
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        out = {
+            'metric': 'samples/sec fwd+bwd, in-batch pairwise + DCN-v2, B=65536 at 1/2/4/8 GPUs',
+            'value': B_PER_GPU * world * args.steps / elapsed,
+            'unit': 'samples/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed * 1e3 / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
+                                   'in-batch pairwise (logistic), B=65536 rows per GPU, 64 fields x 16-dim, ~64 rows/group',
+                       'global_batch': B_PER_GPU * world, 'parallelism': 'dp%d' % world,
+                       'loss': float(loss.item())},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

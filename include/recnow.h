@@ -167,6 +167,7 @@ typedef struct recnow_gemm_desc {
     int act_cols;
     int e_mode; int e_act;            /* e_mode 0/MUL: v *= emul[m][n];  ACTGRAD: v *= act'(emul[m][n]) (e_act) */
     int accumulate;
+    int c_trans;                      /* 1: store the result transposed, C[n][m] (ldc = row stride of that layout) */
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;
@@ -238,6 +239,15 @@ int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* 
                        size_t saved_bytes, int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* dx,
                        float* const* dU_host, float* const* dV_host, float* const* dW_host, float* const* dbias_host,
                        float* const* dgate_host, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py): per-launch HIP-event timing of the GEMM kernels on the launch stream.
+ * recnow_prof_enable(capacity > 0) arms `capacity` launch slots, (0) disables.  recnow_prof_collect synchronises and
+ * returns per-kernel-family totals in HOST arrays of 8 entries indexed by tag: 1 = k_gemm<128,128>, 2 = k_gemm<128,160>,
+ * 3 = k_gemm<256,64>, 4 = k_gemm<256,32>: launches, total milliseconds, total algorithmic flops (2*M*N*K*batch).
+ * ---------------------------------------------------------------------------------------------------------- */
+int recnow_prof_enable(int capacity);
+int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host);
 
 #ifdef __cplusplus
 }

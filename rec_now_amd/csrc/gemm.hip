@@ -13,6 +13,7 @@
 // An operand that is k-contiguous in memory ([m][k]) is loaded as float4 along k (coalesced 128-B rows) and transposed
 // on the LDS write; its row stride is ROWS+1 floats so those 4-B writes are conflict-free too.
 #include "gemm.hpp"
+#include "prof.hpp"
 #include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,18 +26,8 @@ struct GemmK {
     float *C, *partial;
     int64_t lda, ldb, ldc, lde, sA, sB, sC, sBias, sE;
     int M, N, K, batch;
-    int a_mode, a_act, b_mode, b_act, act, act_cols, e_mode, e_act, accumulate, splitk, kchunk;
+    int a_mode, a_act, b_mode, b_act, act, act_cols, e_mode, e_act, accumulate, c_trans, splitk, kchunk;
 };
-
-__device__ __forceinline__ float4 gemm_load4(const float* __restrict__ q, int rem) {
-    if (rem >= 4 && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) return *reinterpret_cast<const float4*>(q);
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rem > 0) r.x = q[0];
-    if (rem > 1) r.y = q[1];
-    if (rem > 2) r.z = q[2];
-    if (rem > 3) r.w = q[3];
-    return r;
-}
 
 __device__ __forceinline__ float4 gemm_combine(float4 x, float4 y, int mode, int act) {
     if (mode == RECNOW_OPMODE_MUL) return make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
@@ -45,63 +36,115 @@ __device__ __forceinline__ float4 gemm_combine(float4 x, float4 y, int mode, int
 }
 
 // ROWS = BM (A) or BN (B).  KC: operand is k-contiguous in memory ([row][k]); else [k][row].
-template <int ROWS, bool KC>
+// Two loaders, chosen per k-tile by a BLOCK-UNIFORM condition so that no load ever sits under a per-lane branch
+// (a branch around each load makes hipcc drain vmcnt at every merge and serialises the tile's loads):
+//   load_fast: whole tile in bounds and 16-B aligned -> unconditional float4 loads, all in flight together;
+//   load_safe: edge tiles -> unconditional scalar loads from CLAMPED (always valid) addresses + select to zero.
+template <int ROWS, int BK, bool KC>
 struct Tile {
-    static constexpr int NV = ROWS * GEMM_BK / 4 / GEMM_THREADS;
+    static constexpr int NF4 = ROWS * BK / 4;                                   // float4 slots in the tile
+    static constexpr int NV = (NF4 + GEMM_THREADS - 1) / GEMM_THREADS;
+    static constexpr bool RAGGED = (NF4 % GEMM_THREADS) != 0;                   // last slot only for some threads
     static constexpr int LD = KC ? ROWS + 1 : ROWS;
     float4 v[NV];
 
-    __device__ __forceinline__ void load(const float* __restrict__ p, const float* __restrict__ p2, int mode, int act,
-                                         int64_t ld, int r0, int k0, int R, int Kend) {
+    __device__ __forceinline__ static void coords(int idx, int& r, int& k) {   // first element of this thread's float4
+        if (KC) { k = (idx % (BK / 4)) * 4; r = idx / (BK / 4); }
+        else { r = (idx % (ROWS / 4)) * 4; k = idx / (ROWS / 4); }
+    }
+    __device__ __forceinline__ static bool has(int i) {
+        return !RAGGED || i + 1 < NV || (int)threadIdx.x + i * GEMM_THREADS < NF4;
+    }
+
+    template <bool SECOND>
+    __device__ __forceinline__ void load_fast(const float* __restrict__ p, const float* __restrict__ p2, int mode, int act,
+                                              int64_t ld, int r0, int k0) {
+        float4 y[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * GEMM_THREADS;
-            int64_t off;
-            int rem;
-            if (KC) {
-                const int kq = idx % (GEMM_BK / 4), r = idx / (GEMM_BK / 4);
-                const int gr = r0 + r, gk = k0 + kq * 4;
-                off = (int64_t)gr * ld + gk;
-                rem = (gr < R) ? (Kend - gk) : 0;
-            } else {
-                const int rq = idx % (ROWS / 4), k = idx / (ROWS / 4);
-                const int gk = k0 + k, gr = r0 + rq * 4;
-                off = (int64_t)gk * ld + gr;
-                rem = (gk < Kend) ? (R - gr) : 0;
+            int r, k;
+            coords(threadIdx.x + i * GEMM_THREADS, r, k);
+            const int64_t off = KC ? (int64_t)(r0 + r) * ld + (k0 + k) : (int64_t)(k0 + k) * ld + (r0 + r);
+            if (has(i)) {
+                v[i] = *reinterpret_cast<const float4*>(p + off);
+                if (SECOND) y[i] = *reinterpret_cast<const float4*>(p2 + off);
             }
-            float4 x = gemm_load4(p + off, rem);
-            if (mode != RECNOW_OPMODE_NONE) x = gemm_combine(x, gemm_load4(p2 + off, rem), mode, act);
-            v[i] = x;
+        }
+        if (SECOND) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = gemm_combine(v[i], y[i], mode, act);
+        }
+    }
+
+    template <bool SECOND>
+    __device__ __forceinline__ void load_safe(const float* __restrict__ p, const float* __restrict__ p2, int mode, int act,
+                                              int64_t ld, int r0, int k0, int R, int Kend) {
+        float y[NV][4];
+        float x[NV][4];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int r, k;
+            coords(threadIdx.x + i * GEMM_THREADS, r, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gr = r0 + r + (KC ? 0 : e), gk = k0 + k + (KC ? e : 0);
+                const bool ok = gr < R && gk < Kend;
+                const int cr = min(gr, R - 1), ck = min(gk, Kend - 1);          // always a valid address
+                const int64_t off = KC ? (int64_t)cr * ld + ck : (int64_t)ck * ld + cr;
+                const float a = p[off];
+                x[i][e] = ok ? a : 0.f;
+                if (SECOND) { const float b = p2[off]; y[i][e] = ok ? b : 0.f; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
+            if (SECOND) v[i] = gemm_combine(v[i], make_float4(y[i][0], y[i][1], y[i][2], y[i][3]), mode, act);
+        }
+    }
+
+    __device__ __forceinline__ void load(bool fast, const float* __restrict__ p, const float* __restrict__ p2, int mode,
+                                         int act, int64_t ld, int r0, int k0, int R, int Kend) {
+        if (mode == RECNOW_OPMODE_NONE) {
+            if (fast) load_fast<false>(p, p2, mode, act, ld, r0, k0);
+            else load_safe<false>(p, p2, mode, act, ld, r0, k0, R, Kend);
+        } else {
+            if (fast) load_fast<true>(p, p2, mode, act, ld, r0, k0);
+            else load_safe<true>(p, p2, mode, act, ld, r0, k0, R, Kend);
         }
     }
 
     __device__ __forceinline__ void store(float* __restrict__ S) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * GEMM_THREADS;
+            int r, k;
+            coords(threadIdx.x + i * GEMM_THREADS, r, k);
+            if (!has(i)) continue;
             if (KC) {
-                const int kq = idx % (GEMM_BK / 4), r = idx / (GEMM_BK / 4);
-                float* s = S + (kq * 4) * LD + r;
+                float* s = S + k * LD + r;
                 s[0] = v[i].x;
                 s[LD] = v[i].y;
                 s[2 * LD] = v[i].z;
                 s[3 * LD] = v[i].w;
             } else {
-                const int rq = idx % (ROWS / 4), k = idx / (ROWS / 4);
-                *reinterpret_cast<float4*>(S + k * LD + rq * 4) = v[i];
+                *reinterpret_cast<float4*>(S + k * LD + r) = v[i];
             }
         }
     }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(GEMM_THREADS)
+__device__ __forceinline__ bool gemm_aligned(const void* p, int64_t ld, int64_t sb) {
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0) && (sb % 4 == 0);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(GEMM_THREADS, 2)      // >= 2 waves/SIMD: VGPR+AGPR <= 256, two workgroups per CU
 k_gemm(const GemmK p) {
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
-    using TA = Tile<BM, A_KC>;
-    using TB = Tile<BN, B_KC>;
-    constexpr int A_SZ = GEMM_BK * TA::LD, B_SZ = GEMM_BK * TB::LD;
+    using TA = Tile<BM, BK, A_KC>;
+    using TB = Tile<BN, BK, B_KC>;
+    constexpr int A_SZ = BK * TA::LD, B_SZ = BK * TB::LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                 // two buffers of A_SZ floats, then two of B_SZ
     float* const Bs = smem + 2 * A_SZ;
@@ -114,6 +157,9 @@ k_gemm(const GemmK p) {
     const float* A2b = p.A2 ? p.A2 + (int64_t)bidx * p.sA : nullptr;
     const float* Bb = p.B + (int64_t)bidx * p.sB;
     const float* B2b = p.B2 ? p.B2 + (int64_t)bidx * p.sB : nullptr;
+    // block-uniform: rows of this tile all in bounds and every float4 16-byte aligned
+    const bool a_fast = (m0 + BM <= p.M) && gemm_aligned(p.A, p.lda, p.sA) && (!p.A2 || gemm_aligned(p.A2, p.lda, p.sA));
+    const bool b_fast = (n0 + BN <= p.N) && gemm_aligned(p.B, p.ldb, p.sB) && (!p.B2 || gemm_aligned(p.B2, p.ldb, p.sB));
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -130,10 +176,11 @@ k_gemm(const GemmK p) {
 
     TA ta;
     TB tb;
-    const int ntile = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+    const int ntile = (k_end - k_begin + BK - 1) / BK;
     if (ntile > 0) {
-        ta.load(Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end);
-        tb.load(Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end);
+        const bool kf = k_begin + BK <= k_end;
+        ta.load(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end);
+        tb.load(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end);
         ta.store(As);
         tb.store(Bs);
     }
@@ -141,23 +188,46 @@ k_gemm(const GemmK p) {
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
-            const int k0 = k_begin + (t + 1) * GEMM_BK;
-            ta.load(Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end);
-            tb.load(Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end);
+            const int k0 = k_begin + (t + 1) * BK;
+            const bool kf = k0 + BK <= k_end;
+            ta.load(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end);
+            tb.load(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end);
         }
         const float* as = As + cur * A_SZ + a_off;
         const float* bs = Bs + cur * B_SZ + b_off;
+        // ONE loop form for full and tail tiles (two forms make the compiler shuffle every accumulator between them):
+        // kv = valid k of this tile; rows beyond it are zero in LDS, so the (at most one) surplus k-step adds zeros.
+        const int kv = min(BK, k_end - (k_begin + t * BK));
+        float a0[TM], b0[TN], a1[TM], b1[TN];      // explicit fragment double buffer: step kk+2 loads under step kk's MFMAs
 #pragma unroll
-        for (int kk = 0; kk < GEMM_BK; kk += 2) {
-            float a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) a0[i] = as[i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[kk * TA::LD + i * 32];
+        for (int j = 0; j < TN; ++j) b0[j] = bs[j * 32];
+        // sched_barrier(0) pins "issue the NEXT step's ds_reads, then this step's MFMAs": without it hipcc sinks the
+        // reads below the MFMAs and waits lgkmcnt(0) right in front of their first use (seen in the .s).  An fp32
+        // 32x32x2 MFMA group is >= 256 cycles, far longer than the LDS latency, so nothing finer is needed.
+        for (int kk = 0; kk < kv; kk += 4) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[kk * TB::LD + j * 32];
+            for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = min(kk + 4, BK - 2);     // stays inside this buffer on the last iteration (value unused then)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a0[i] = as[kn * TA::LD + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b0[j] = bs[kn * TB::LD + j * 32];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (t + 1 < ntile) {
             ta.store(As + (cur ^ 1) * A_SZ);
@@ -168,6 +238,7 @@ k_gemm(const GemmK p) {
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);          // block-uniform
     if (p.splitk > 1) {
         float* P = p.partial + ((int64_t)z * p.M) * p.N;
 #pragma unroll
@@ -178,7 +249,7 @@ k_gemm(const GemmK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-                    if (row < p.M && col < p.N) P[(int64_t)row * p.N + col] = acc[i][j][r];
+                    if (interior || (row < p.M && col < p.N)) P[(int64_t)row * p.N + col] = acc[i][j][r];
                 }
             }
         return;
@@ -186,26 +257,44 @@ k_gemm(const GemmK p) {
     float* Cb = p.C + (int64_t)bidx * p.sC;
     const float* biasb = p.bias ? p.bias + (int64_t)bidx * p.sBias : nullptr;
     const float* Eb = p.emul ? p.emul + (int64_t)bidx * p.sE : nullptr;
+    const int64_t c_rs = p.c_trans ? 1 : p.ldc, c_cs = p.c_trans ? p.ldc : 1;     // C[row*c_rs + col*c_cs]
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * TN * 32 + j * 32 + col_l;
-            const float bv = (biasb && col < p.N) ? biasb[col] : 0.f;
+            const int colc = min(col, p.N - 1);
+            const float bv = biasb ? biasb[colc] : 0.f;
+            const int rbase = m0 + wm * TM * 32 + i * 32 + row_l;
+            float e[16], cprev[16];
+            // operands of the epilogue are loaded unconditionally from clamped addresses, 16 at a time
+            if (Eb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    e[r] = Eb[(int64_t)row * p.lde + colc];
+                }
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    cprev[r] = Cb[(int64_t)row * c_rs + (int64_t)colc * c_cs];
+                }
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+            if (p.act != RECNOW_ACT_LINEAR && col < p.act_cols) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = rn_act(v[r], p.act);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-                if (row < p.M && col < p.N) {
-                    float v = acc[i][j][r] + bv;
-                    if (col < p.act_cols) v = rn_act(v, p.act);
-                    if (Eb) {
-                        const float e = Eb[(int64_t)row * p.lde + col];
-                        v *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(e, p.e_act) : e;
-                    }
-                    float* c = Cb + (int64_t)row * p.ldc + col;
-                    if (p.accumulate) v += *c;
-                    *c = v;
-                }
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (Eb) v[r] *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(e[r], p.e_act) : e[r];
+                if (p.accumulate) v[r] += cprev[r];
+                if (interior || (row < p.M && col < p.N)) Cb[(int64_t)row * c_rs + (int64_t)col * c_cs] = v[r];
             }
         }
 }
@@ -228,7 +317,7 @@ k_gemm_splitk_reduce(const GemmK p) {
             const float e = p.emul[(int64_t)b * p.sE + (int64_t)row * p.lde + col];
             s *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(e, p.e_act) : e;
         }
-        float* c = p.C + (int64_t)b * p.sC + (int64_t)row * p.ldc + col;
+        float* c = p.C + (int64_t)b * p.sC + (p.c_trans ? ((int64_t)col * p.ldc + row) : ((int64_t)row * p.ldc + col));
         if (p.accumulate) s += *c;
         *c = s;
     }
@@ -271,13 +360,12 @@ size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     return s > 1 ? rn_align((size_t)s * d->batch * d->M * d->N * sizeof(float)) : 0;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 static int launch_cfg(const GemmK& k, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
-    // LDS bytes for the worst-case (padded) strides of this instantiation
-#define RN_GEMM_LAUNCH(AKC, BKC)                                                                                  \
-    do {                                                                                                          \
-        constexpr size_t lds = 2 * GEMM_BK * (size_t)(Tile<BM, AKC>::LD + Tile<BN, BKC>::LD) * sizeof(float);     \
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, AKC, BKC>), grid, GEMM_THREADS, lds, st, k);                   \
+#define RN_GEMM_LAUNCH(AKC, BKC)                                                                                        \
+    do {                                                                                                                \
+        constexpr size_t lds = 2 * BK * (size_t)(Tile<BM, BK, AKC>::LD + Tile<BN, BK, BKC>::LD) * sizeof(float);        \
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC>), grid, GEMM_THREADS, lds, st, k);                     \
     } while (0)
     if (a_kc && b_kc) RN_GEMM_LAUNCH(true, true);
     else if (a_kc && !b_kc) RN_GEMM_LAUNCH(true, false);
@@ -304,7 +392,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     k.M = d->M; k.N = d->N; k.K = d->K; k.batch = d->batch;
     k.a_mode = d->a_mode; k.a_act = d->a_act; k.b_mode = d->b_mode; k.b_act = d->b_act;
     k.act = d->act; k.act_cols = d->act_cols > 0 ? d->act_cols : d->N; k.e_mode = d->e_mode; k.e_act = d->e_act;
-    k.accumulate = d->accumulate;
+    k.accumulate = d->accumulate; k.c_trans = d->c_trans;
     pick_split(d, c, &k.splitk, &k.kchunk);
     if (k.splitk > 1) {
         const size_t need = rn_align((size_t)k.splitk * d->batch * d->M * d->N * sizeof(float));
@@ -316,10 +404,19 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     dim3 grid(rn_cdiv(d->M, c.BM), rn_cdiv(d->N, c.BN), (unsigned)gz);
     const bool a_kc = d->a_trans == 0, b_kc = d->b_trans != 0;
     int rc;
-    if (c.BM == 256 && c.BN == 32) rc = launch_cfg<256, 32, 4, 1>(k, a_kc, b_kc, grid, st);
-    else if (c.BM == 256 && c.BN == 64) rc = launch_cfg<256, 64, 4, 1>(k, a_kc, b_kc, grid, st);
-    else if (c.BN == 160) rc = launch_cfg<128, 160, 4, 1>(k, a_kc, b_kc, grid, st);
-    else rc = launch_cfg<128, 128, 2, 2>(k, a_kc, b_kc, grid, st);
+    const int tag = (c.BM == 256 && c.BN == 32) ? RN_TAG_GEMM_256x32 : (c.BM == 256) ? RN_TAG_GEMM_256x64
+                  : (c.BN == 160) ? RN_TAG_GEMM_128x160 : RN_TAG_GEMM_128x128;
+    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(tag, 2.0 * d->M * d->N * (double)d->K * d->batch, st) : nullptr;
+    // short-K products (K <= 256, e.g. the K = N*S+N = 130 contractions of DCN-v2) are prologue/epilogue dominated:
+    // BK = 16 halves the LDS footprint so 4 workgroups per CU overlap each other's load/store phases.
+    const bool short_k = d->K <= 256;
+    if (c.BM == 256 && c.BN == 32) rc = launch_cfg<256, 32, 4, 1, 32>(k, a_kc, b_kc, grid, st);
+    else if (c.BM == 256 && c.BN == 64) rc = launch_cfg<256, 64, 4, 1, 32>(k, a_kc, b_kc, grid, st);
+    else if (c.BN == 160) rc = short_k ? launch_cfg<128, 160, 4, 1, 16>(k, a_kc, b_kc, grid, st)
+                                      : launch_cfg<128, 160, 4, 1, 32>(k, a_kc, b_kc, grid, st);
+    else rc = short_k ? launch_cfg<128, 128, 2, 2, 16>(k, a_kc, b_kc, grid, st)
+                      : launch_cfg<128, 128, 2, 2, 32>(k, a_kc, b_kc, grid, st);
+    rn_prof_end(pr, st);
     if (rc) return rc;
     if (k.splitk > 1) {
         const int64_t total = (int64_t)d->M * d->N * d->batch;

@@ -1,0 +1,62 @@
+#include "prof.hpp"
+#include <vector>
+
+static bool g_on = false;
+static std::vector<RnProfRecord> g_pool;
+static size_t g_used = 0;
+
+bool rn_prof_on() { return g_on; }
+
+RnProfRecord* rn_prof_begin(int tag, double flops, hipStream_t st) {
+    if (!g_on || g_used >= g_pool.size()) return nullptr;
+    RnProfRecord* r = &g_pool[g_used++];
+    r->tag = tag;
+    r->flops = flops;
+    (void)hipEventRecord(r->e0, st);
+    return r;
+}
+void rn_prof_end(RnProfRecord* r, hipStream_t st) {
+    if (r) (void)hipEventRecord(r->e1, st);
+}
+
+// capacity > 0: (re)arm with that many launch slots; capacity == 0: disable and free.
+extern "C" int recnow_prof_enable(int capacity) {
+    for (auto& r : g_pool) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_pool.clear();
+    g_used = 0;
+    g_on = false;
+    if (capacity <= 0) return RECNOW_OK;
+    g_pool.resize((size_t)capacity);
+    for (auto& r : g_pool) {
+        RN_HIP(hipEventCreate(&r.e0));
+        RN_HIP(hipEventCreate(&r.e1));
+    }
+    g_on = true;
+    return RECNOW_OK;
+}
+
+// Synchronises, then fills per-tag totals (arrays of RN_TAG_MAX entries, HOST memory) and rewinds the pool.
+extern "C" int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host) {
+    if (!count_host || !ms_host || !flops_host) return RECNOW_EINVAL;
+    for (int t = 0; t < RN_TAG_MAX; ++t) {
+        count_host[t] = 0;
+        ms_host[t] = 0.0;
+        flops_host[t] = 0.0;
+    }
+    for (size_t i = 0; i < g_used; ++i) {
+        RnProfRecord& r = g_pool[i];
+        RN_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        RN_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        if (r.tag >= 0 && r.tag < RN_TAG_MAX) {
+            count_host[r.tag] += 1;
+            ms_host[r.tag] += ms;
+            flops_host[r.tag] += r.flops;
+        }
+    }
+    g_used = 0;
+    return RECNOW_OK;
+}

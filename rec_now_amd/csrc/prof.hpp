@@ -1,0 +1,20 @@
+// Optional per-launch HIP-event timing of the GEMM kernels (bench.py's roofline figure).  Off by default: no events
+// are recorded and nothing is allocated.  Not thread-safe by design (one process per GPU, one launching thread).
+#pragma once
+#include "common.hpp"
+
+struct RnProfRecord {
+    int tag;            // kernel family (RN_TAG_*)
+    double flops;       // algorithmic flops of the launch
+    hipEvent_t e0, e1;
+};
+#define RN_TAG_GEMM_128x128 1
+#define RN_TAG_GEMM_128x160 2
+#define RN_TAG_GEMM_256x64 3
+#define RN_TAG_GEMM_256x32 4
+#define RN_TAG_MAX 8
+
+bool rn_prof_on();
+// returns a slot (or nullptr when profiling is off / the pool is full) and records e0 on st
+RnProfRecord* rn_prof_begin(int tag, double flops, hipStream_t st);
+void rn_prof_end(RnProfRecord* r, hipStream_t st);

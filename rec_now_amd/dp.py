@@ -1,0 +1,108 @@
+"""Batch data-parallelism for the hot path: one process per GPU, torch.distributed ('nccl' = RCCL over xGMI on ROCm;
+'gloo' in the CPU tests).  The reference has no distributed code at all; this is the only strategy
+the path needs:
+
+  * the layers are row-independent (weights replicated)            -> shard rows, SUM-all-reduce weight gradients;
+  * the losses couple only rows of the same group                  -> every group must live on ONE rank
+    (`shard_rows_by_group`), then the global loss is  all_reduce(sum_p w_p l_p) / (all_reduce(P) + 1e-10)
+    and each rank's local gradient only needs the global pair count (one 2-float all-reduce, no data-path exchange).
+
+With that sharding the N-GPU loss and gradients equal the 1-GPU ones at the global batch.
+"""
+import torch
+import torch.distributed as dist
+
+SMALL_POSIVITE_FLOAT = 1.0e-10
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_rows_by_group(group_ids, world_size):
+    """Owner rank of every row: all rows of a group go to one rank (hash of the id).  group_ids: integer tensor/array.
+    Returns an int64 tensor of ranks; rank r keeps rows where result == r."""
+    g = torch.as_tensor(group_ids).to(torch.int64)
+    h = (g * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF     # Fibonacci hashing, wraps in int64
+    return (h >> 17) % world_size
+
+
+def global_pairwise_loss(local_loss_sum, local_n_pair):
+    """Combine per-rank pair-loss SUMS into the global mean loss.
+
+    local_loss_sum: 0-dim tensor = sum_p w_p*l_p over THIS rank's pairs (e.g. `pairwise_loss_fused(..., reduce_mean=
+    False)`), attached to the autograd graph; local_n_pair: 0-dim float tensor.
+    Returns (loss_for_backward, global_loss_value, global_n_pair):
+      loss_for_backward = local_loss_sum / (P_global + 1e-10)   -- backward gives exactly this rank's share of dL/ds
+      global_loss_value = all_reduce(local sums) / (P_global + 1e-10) (detached; identical on every rank)."""
+    stats = torch.stack([local_loss_sum.detach().to(torch.float32), local_n_pair.detach().to(torch.float32)])
+    if is_dist():
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    denom = stats[1] + SMALL_POSIVITE_FLOAT
+    return local_loss_sum / denom, stats[0] / denom, stats[1]
+
+
+def global_listwise_loss(local_loss_sum, local_n_valid):
+    """Same for the listwise loss: mean over ALL valid lists of all ranks; 0 when there is none (nan_to_zero)."""
+    stats = torch.stack([local_loss_sum.detach().to(torch.float32), local_n_valid.detach().to(torch.float32)])
+    if is_dist():
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    denom = torch.clamp(stats[1], min=1.0)
+    return local_loss_sum / denom, stats[0] / denom, stats[1]
+
+
+class GradientAllReducer(object):
+    """SUM-all-reduce of the weight gradients in a few large flat buckets (xGMI is point-to-point: 7 links x ~153 GB/s
+    per GPU, ring collectives are per-link bound, so fewer/larger messages win; the hot path's gradients are 3-80 MB)."""
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for p in self.params:
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self._flat = [None] * len(self.buckets)
+
+    def all_reduce(self, async_op=False):
+        """Call after backward.  Gradients missing on this rank count as zero."""
+        if not is_dist():
+            return []
+        works = []
+        for i, bucket in enumerate(self.buckets):
+            n = sum(p.numel() for p in bucket)
+            flat = self._flat[i]
+            if flat is None or flat.numel() != n or flat.device != bucket[0].device:
+                flat = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
+                self._flat[i] = flat
+            off = 0
+            for p in bucket:
+                k = p.numel()
+                if p.grad is None:
+                    flat[off:off + k].zero_()
+                else:
+                    flat[off:off + k].copy_(p.grad.reshape(-1))
+                off += k
+            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), i))
+        if async_op:
+            return works
+        self.finish(works)
+        return []
+
+    def finish(self, works):
+        for work, i in works:
+            work.wait()
+            flat, off = self._flat[i], 0
+            for p in self.buckets[i]:
+                k = p.numel()
+                if p.grad is None:
+                    p.grad = flat[off:off + k].reshape(p.shape).clone()
+                else:
+                    p.grad.copy_(flat[off:off + k].reshape(p.shape))
+                off += k

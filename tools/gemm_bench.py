@@ -1,0 +1,63 @@
+"""Microbenchmark of recnow_gemm on the shapes the DCN-v2 step uses (+ a square reference).  GPU only.
+usage: python tools/gemm_bench.py [reps]"""
+import ctypes
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rec_now_amd import _lib
+
+dev = torch.device('cuda:0')
+lib = _lib.load()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+B, D, KC, LDT = 65536, 1024, 130, 132
+
+SHAPES = [
+    # name, M, N, K, a_trans, b_trans, lda, ldb, ldc, a_mode, emul, c_trans
+    ('GEMM1  x[U|K]        (B,D)x(D,130)', B, KC, D, 0, 0, D, LDT, LDT, 0, 0, 0),
+    ('GEMM3  x*(T2g[W;b])  (B,130)x(130,D)', B, D, KC, 0, 0, LDT, D, D, 0, 1, 0),
+    ('dT2g   (x*g)Wc2^T    (B,D)x(D,130)', B, KC, D, 0, 1, D, D, LDT, 1, 0, 0),
+    ('dxl    dT1 Wc1^T     (B,130)x(130,D)', B, D, KC, 0, 1, LDT, LDT, D, 0, 0, 0),
+    ('dWc1   xl^T dT1      (D,B)x(B,130)', D, KC, B, 1, 0, D, LDT, LDT, 0, 0, 0),
+    ('dWc2^T (x*g)^T T2g   (D,B)x(B,130)', D, KC, B, 1, 0, D, LDT, D, 1, 0, 1),
+    ('square 4096^3 NN', 4096, 4096, 4096, 0, 0, 4096, 4096, 4096, 0, 0, 0),
+    ('square 4096^3 NT', 4096, 4096, 4096, 0, 1, 4096, 4096, 4096, 0, 0, 0),
+]
+
+
+def run(name, M, N, K, ta, tb, lda, ldb, ldc, a_mode, emul, c_trans):
+    rows_a = K if ta else M
+    rows_b = N if tb else K
+    A = torch.randn(rows_a, lda, device=dev) * 0.1
+    A2 = torch.randn(rows_a, lda, device=dev) if a_mode else None
+    Bm = torch.randn(rows_b, ldb, device=dev) * 0.1
+    C = torch.empty((N if c_trans else M), ldc, device=dev)
+    E = torch.randn(M, N, device=dev) if emul else None
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.a_trans = A.data_ptr(), lda, ta
+    if a_mode:
+        d.A2, d.a_mode = A2.data_ptr(), 1
+    d.B, d.ldb, d.b_trans = Bm.data_ptr(), ldb, tb
+    d.C, d.ldc, d.c_trans = C.data_ptr(), ldc, c_trans
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    if emul:
+        d.emul, d.lde, d.e_mode = E.data_ptr(), N, 1
+    ws = _lib.workspace(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)), dev)
+    st = _lib.stream()
+    for _ in range(2):
+        _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), st)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    print('%-40s %9.1f us  %6.1f TFLOP/s' % (name, us, 2.0 * M * N * K / us / 1e6), flush=True)
+
+
+for s in SHAPES:
+    run(*s)
