@@ -130,6 +130,41 @@ int recnow_occurance_power_weight(const int32_t* order, const int32_t* seg_id, c
                                   float power, float* w_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * In-batch listwise loss: rec_now/rec_block/listwise_loss_from_batch.py:89-173 on sorted segments (no (G,B) matrix).
+ *   valid group g: has a label > th and a (label - th) < 0 (:135-137);  p_i = y_i / sum_g y (:144)
+ *   row g of the reference's dense logits = members' logits + (B - n_g) entries equal to pad_logit
+ *       (pad_logit = value_of_masked_logit when do_mask_logits, else 0; :139-140)
+ *   l_g = lse(row g) * sum_i p_i - sum_i p_i s_i (:167);  loss = mean over valid groups of w_g l_g, NaN -> 0 (:168-172)
+ * Segment arrays are sized B and indexed by segment; valid_rank[g] = index of g among the valid groups in
+ * FIRST-OCCURRENCE order (the row order of the reference's outputs, tf.unique :109) or -1.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t recnow_listwise_workspace_bytes(int64_t B);
+int recnow_listwise_segments(const float* labels, const float* logits, const int32_t* order, const int32_t* seg_first,
+                             const int32_t* n_seg, int64_t B, float pos_neg_th, float pad_logit, int32_t* seg_valid,
+                             float* seg_lse, float* seg_ysum, float* seg_psum, float* seg_pdot, int32_t* valid_rank,
+                             int32_t* n_valid, void* ws, size_t ws_bytes, void* stream);
+/* loss [1]; dbase[i] = w_g * (softmax_i * psum_g - p_i) (0 outside valid groups): d loss/d logits = dbase / n_valid
+ * (do_reduce) or dbase * upstream[row_rank] (per-list losses);  row_rank[i] = valid rank of i's group or -1;
+ * group_loss[r] = weighted loss of the r-th valid list.  weights: [n_valid] or NULL. */
+int recnow_listwise_loss_fwdbwd(const float* labels, const float* logits, const int32_t* order, const int32_t* seg_id,
+                                const int32_t* seg_first, const int32_t* seg_valid, const float* seg_lse,
+                                const float* seg_ysum, const float* seg_psum, const float* seg_pdot,
+                                const int32_t* valid_rank, const int32_t* n_valid, const float* weights, int64_t B,
+                                float* loss, float* dbase, int32_t* row_rank, float* group_loss, void* stream);
+/* Dense (n_valid,B) outputs of to_listwise_sample (:131-148) for API parity.  The caller pre-fills mask_out = 0,
+ * labels_out = 0, logits_out = pad_logit; members of valid groups are scattered in. */
+int recnow_listwise_dense(const float* labels, const float* logits, const int32_t* order, const int32_t* seg_id,
+                          const float* seg_ysum, const int32_t* valid_rank, int64_t B, uint8_t* mask_out,
+                          float* labels_out, float* logits_out, void* stream);
+int recnow_listwise_dense_bwd(const float* ddense, const int32_t* row_rank, int64_t B, float* dlogits, void* stream);
+/* tf.nn.softmax_cross_entropy_with_logits over the rows of dense (G,N) matrices (:167): row_loss = lse*sum(p) - p.s;
+ * backward dlogits[g][j] = grow[g] * (exp(s - lse_g) * psum_g - p).  HBM-bound streaming over G*N. */
+int recnow_softmax_ce_rows_fwd(const float* labels, const float* logits, int64_t G, int64_t N, float* row_loss,
+                               float* row_lse, float* row_psum, void* stream);
+int recnow_softmax_ce_rows_bwd(const float* labels, const float* logits, const float* row_lse, const float* row_psum,
+                               const float* grow, int64_t G, int64_t N, float* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * FMLayer: rec_now/layers/fm_layer.py:24-42.   HBM-bound (12*B*F*D bytes fwd+bwd).
  *   y[b] = 0.5 * sum_d [ (sum_f x_f[b][d])^2 - sum_f x_f[b][d]^2 ]
  * fields: DEVICE array of F device pointers, each a contiguous (B,D) fp32 tensor (the reference's list input);

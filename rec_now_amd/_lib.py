@@ -29,6 +29,13 @@ SIGNATURES = {
     'recnow_bpr_loss_fwdbwd': (_I, [_P, _P, _P, _L, _F, _I, _P, _P, _P, _Z, _P]),
     'recnow_pair_mask_dense': (_I, [_P, _P, _P, _L, _I, _P, _P]),
     'recnow_occurance_power_weight': (_I, [_P, _P, _P, _L, _F, _P, _P]),
+    'recnow_listwise_workspace_bytes': (_Z, [_L]),
+    'recnow_listwise_segments': (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    'recnow_listwise_loss_fwdbwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
+    'recnow_listwise_dense': (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P]),
+    'recnow_listwise_dense_bwd': (_I, [_P, _P, _L, _P, _P]),
+    'recnow_softmax_ce_rows_fwd': (_I, [_P, _P, _L, _L, _P, _P, _P, _P]),
+    'recnow_softmax_ce_rows_bwd': (_I, [_P, _P, _P, _P, _P, _L, _L, _P, _P]),
     'recnow_fm_fwd': (_I, [_P, _I, _L, _I, _P, _P, _P]),
     'recnow_fm_bwd': (_I, [_P, _P, _I, _L, _I, _P, _P, _P]),
     'recnow_gemm_workspace_bytes': (_Z, [_P]),
