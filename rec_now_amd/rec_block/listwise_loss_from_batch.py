@@ -95,6 +95,8 @@ class _DenseLogits(torch.autograd.Function):
     def backward(ctx, g):
         (row_rank,) = ctx.saved_tensors
         B = ctx.B
+        if g.numel() == 0:                 # no valid list: nothing flows back
+            return torch.zeros(ctx.shape, dtype=torch.float32, device=g.device), None, None, None
         g = _lib.f32c(g, 'grad')
         d = torch.empty(max(B, 1), dtype=torch.float32, device=g.device)
         _lib.call('recnow_listwise_dense_bwd', _lib.ptr(g), _lib.ptr(row_rank), B, _lib.ptr(d), _lib.stream())
