@@ -190,6 +190,9 @@ int recnow_fm_bwd(const float* const* fields, float* const* dfields, int F, int6
 #define RECNOW_OPMODE_NONE 0
 #define RECNOW_OPMODE_MUL 1
 #define RECNOW_OPMODE_ACTGRAD 2
+#define RECNOW_OPMODE_OUTER 3   /* operand(row,col) = second[row][col / hq] * first[row][col % hq]: CIN's outer product
+                                 (cin_layer.py:103) generated in the operand load; row = the operand's non-k index for A
+                                 in [M][K] storage / B in [N][K] storage, and the k index for [K][M] / [K][N] storage */
 
 typedef struct recnow_gemm_desc {
     const float* A;  const float* A2; int64_t lda; int64_t a_batch_stride; int a_trans; int a_mode; int a_act; int a_pad;
@@ -202,6 +205,8 @@ typedef struct recnow_gemm_desc {
     int act_cols;
     int e_mode; int e_act;            /* e_mode 0/MUL: v *= emul[m][n];  ACTGRAD: v *= act'(emul[m][n]) (e_act) */
     int accumulate;
+    int a_hq; int b_hq;               /* OUTER mode: inner width hq (A2/B2 hold the [row][col / hq] factor) */
+    int64_t a_ld2; int64_t b_ld2;     /* OUTER mode: row stride of A2 / B2 */
     int c_trans;                      /* 1: store the result transposed, C[n][m] (ldc = row stride of that layout) */
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
@@ -274,6 +279,25 @@ int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* 
                        size_t saved_bytes, int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* dx,
                        float* const* dU_host, float* const* dV_host, float* const* dW_host, float* const* dbias_host,
                        float* const* dgate_host, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CINLayer (xDeepFM Compressed Interaction Network): rec_now/layers/cin_layer.py:72-122
+ *   X_k[b,d,c] = sum_{f,h} W_k[c, f*H_{k-1}+h] * x0[b,d,f] * X_{k-1}[b,d,h]   (X_0 = x0, H_0 = F)          (:103-109)
+ *   out = sum over the channels of all kept layers -> (B,D)            (sum_channel, :116-117)
+ *       | concat of the kept layers' channels, transposed -> (B, ctot*D) (:119-121); kept = [x0,] X_1..X_L (:112-113)
+ * emb: (B, F*D) (concat of the field embeddings, :88-91); weights_host: HOST array of L DEVICE pointers, W_k stored
+ * (H_k, F*H_{k-1}) = weight_of_layer{k}[0,0]; hidden_host: HOST int[L].  An implicit GEMM over M = B*D rows on the
+ * exact-fp32 MFMA kernel; the (B,D,F,H) outer product is generated in the operand load and never stored.
+ * `saved` keeps x0 transposed and X_1..X_L for backward.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t recnow_cin_saved_bytes(int64_t B, int D, int F, const int* hidden_host, int L);
+size_t recnow_cin_workspace_bytes(int64_t B, int D, int F, const int* hidden_host, int L);
+int recnow_cin_fwd(const float* emb, const float* const* weights_host, int64_t B, int D, int F, const int* hidden_host, int L,
+                   int output_input, int sum_channel, float* out, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                   void* stream);
+int recnow_cin_bwd(const float* const* weights_host, const float* dout, const void* saved, size_t saved_bytes, int64_t B, int D,
+                   int F, const int* hidden_host, int L, int output_input, int sum_channel, float* demb,
+                   float* const* dweights_host, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the GEMM kernels on the launch stream.

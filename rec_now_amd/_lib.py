@@ -53,6 +53,10 @@ SIGNATURES = {
     'recnow_dcn_mix_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P]),
     'recnow_dcn_mix_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                                  _Z, _P]),
+    'recnow_cin_saved_bytes': (_Z, [_L, _I, _I, _P, _I]),
+    'recnow_cin_workspace_bytes': (_Z, [_L, _I, _I, _P, _I]),
+    'recnow_cin_fwd': (_I, [_P, _P, _L, _I, _I, _P, _I, _I, _I, _P, _P, _Z, _P, _Z, _P]),
+    'recnow_cin_bwd': (_I, [_P, _P, _P, _Z, _L, _I, _I, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     'recnow_prof_enable': (_I, [_I]),
     'recnow_prof_collect': (_I, [_P, _P, _P]),
 }
@@ -67,7 +71,7 @@ class GemmDesc(ctypes.Structure):
         ('M', _I), ('N', _I), ('K', _I), ('batch', _I),
         ('bias', _P), ('bias_batch_stride', _L),
         ('emul', _P), ('lde', _L), ('e_batch_stride', _L),
-        ('act', _I), ('act_cols', _I), ('e_mode', _I), ('e_act', _I), ('accumulate', _I), ('c_trans', _I),
+        ('act', _I), ('act_cols', _I), ('e_mode', _I), ('e_act', _I), ('accumulate', _I), ('a_hq', _I), ('b_hq', _I), ('a_ld2', _L), ('b_ld2', _L), ('c_trans', _I),
     ]
 
 _ERR = {-1: 'RECNOW_EINVAL', -2: 'RECNOW_EWORKSPACE', -3: 'RECNOW_EUNSUPPORTED'}

@@ -27,6 +27,8 @@ struct GemmK {
     int64_t lda, ldb, ldc, lde, sA, sB, sC, sBias, sE;
     int M, N, K, batch;
     int a_mode, a_act, b_mode, b_act, act, act_cols, e_mode, e_act, accumulate, c_trans, splitk, kchunk;
+    int a_hq, b_hq;            // OUTER mode: operand(row, col) = second[row][col / hq] * first[row][col % hq]
+    int64_t a_ld2, b_ld2;      // row stride of `second` in OUTER mode
 };
 
 __device__ __forceinline__ float4 gemm_combine(float4 x, float4 y, int mode, int act) {
@@ -103,9 +105,54 @@ struct Tile {
         }
     }
 
+    // OUTER mode (CIN's on-the-fly outer product): element (row, col) = p2[row*ld2 + col/hq] * p[row*ld + col%hq], where
+    // (row, col) = (tile row, k) for k-contiguous tiles and (k, tile row) otherwise.  hq % 4 == 0 on the fast path, so
+    // the four elements of a float4 share one p2 value.
+    __device__ __forceinline__ void load_outer_fast(const float* __restrict__ p, const float* __restrict__ p2, int64_t ld,
+                                                    int64_t ld2, int hq, int r0, int k0) {
+        float s2[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int r, k;
+            coords(threadIdx.x + i * GEMM_THREADS, r, k);
+            const int row = KC ? r0 + r : k0 + k, col = KC ? k0 + k : r0 + r;
+            if (has(i)) {
+                v[i] = *reinterpret_cast<const float4*>(p + (int64_t)row * ld + (col % hq));
+                s2[i] = p2[(int64_t)row * ld2 + (col / hq)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = make_float4(v[i].x * s2[i], v[i].y * s2[i], v[i].z * s2[i], v[i].w * s2[i]);
+    }
+    __device__ __forceinline__ void load_outer_safe(const float* __restrict__ p, const float* __restrict__ p2, int64_t ld,
+                                                    int64_t ld2, int hq, int r0, int k0, int R, int Kend) {
+        float x[NV][4], y[NV][4];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int r, k;
+            coords(threadIdx.x + i * GEMM_THREADS, r, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gr = r0 + r + (KC ? 0 : e), gk = k0 + k + (KC ? e : 0);
+                const bool ok = gr < R && gk < Kend;
+                const int cr = min(gr, R - 1), ck = min(gk, Kend - 1);
+                const int row = KC ? cr : ck, col = KC ? ck : cr;
+                const float a = p[(int64_t)row * ld + (col % hq)];
+                const float b = p2[(int64_t)row * ld2 + (col / hq)];
+                x[i][e] = ok ? a : 0.f;
+                y[i][e] = b;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = make_float4(x[i][0] * y[i][0], x[i][1] * y[i][1], x[i][2] * y[i][2], x[i][3] * y[i][3]);
+    }
+
     __device__ __forceinline__ void load(bool fast, const float* __restrict__ p, const float* __restrict__ p2, int mode,
-                                         int act, int64_t ld, int r0, int k0, int R, int Kend) {
-        if (mode == RECNOW_OPMODE_NONE) {
+                                         int act, int64_t ld, int r0, int k0, int R, int Kend, int64_t ld2 = 0, int hq = 1) {
+        if (mode == RECNOW_OPMODE_OUTER) {
+            if (fast) load_outer_fast(p, p2, ld, ld2, hq, r0, k0);
+            else load_outer_safe(p, p2, ld, ld2, hq, r0, k0, R, Kend);
+        } else if (mode == RECNOW_OPMODE_NONE) {
             if (fast) load_fast<false>(p, p2, mode, act, ld, r0, k0);
             else load_safe<false>(p, p2, mode, act, ld, r0, k0, R, Kend);
         } else {
@@ -154,12 +201,15 @@ k_gemm(const GemmK p) {
     const int k_end = min(p.K, k_begin + p.kchunk);
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const float* Ab = p.A + (int64_t)bidx * p.sA;
-    const float* A2b = p.A2 ? p.A2 + (int64_t)bidx * p.sA : nullptr;
+    const float* A2b = p.A2 ? p.A2 + (p.a_mode == RECNOW_OPMODE_OUTER ? 0 : (int64_t)bidx * p.sA) : nullptr;
     const float* Bb = p.B + (int64_t)bidx * p.sB;
-    const float* B2b = p.B2 ? p.B2 + (int64_t)bidx * p.sB : nullptr;
+    const float* B2b = p.B2 ? p.B2 + (p.b_mode == RECNOW_OPMODE_OUTER ? 0 : (int64_t)bidx * p.sB) : nullptr;
     // block-uniform: rows of this tile all in bounds and every float4 16-byte aligned
-    const bool a_fast = (m0 + BM <= p.M) && gemm_aligned(p.A, p.lda, p.sA) && (!p.A2 || gemm_aligned(p.A2, p.lda, p.sA));
-    const bool b_fast = (n0 + BN <= p.N) && gemm_aligned(p.B, p.ldb, p.sB) && (!p.B2 || gemm_aligned(p.B2, p.ldb, p.sB));
+    const bool a_outer = p.a_mode == RECNOW_OPMODE_OUTER, b_outer = p.b_mode == RECNOW_OPMODE_OUTER;
+    const bool a_fast = (m0 + BM <= p.M) && gemm_aligned(p.A, p.lda, p.sA) &&
+                        (a_outer ? (p.a_hq % 4 == 0) : (!p.A2 || gemm_aligned(p.A2, p.lda, p.sA)));
+    const bool b_fast = (n0 + BN <= p.N) && gemm_aligned(p.B, p.ldb, p.sB) &&
+                        (b_outer ? (p.b_hq % 4 == 0) : (!p.B2 || gemm_aligned(p.B2, p.ldb, p.sB)));
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -179,8 +229,8 @@ k_gemm(const GemmK p) {
     const int ntile = (k_end - k_begin + BK - 1) / BK;
     if (ntile > 0) {
         const bool kf = k_begin + BK <= k_end;
-        ta.load(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end);
-        tb.load(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end);
+        ta.load(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end, p.a_ld2, p.a_hq);
+        tb.load(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end, p.b_ld2, p.b_hq);
         ta.store(As);
         tb.store(Bs);
     }
@@ -190,8 +240,8 @@ k_gemm(const GemmK p) {
         if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
             const int k0 = k_begin + (t + 1) * BK;
             const bool kf = k0 + BK <= k_end;
-            ta.load(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end);
-            tb.load(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end);
+            ta.load(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
+            tb.load(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
         }
         const float* as = As + cur * A_SZ + a_off;
         const float* bs = Bs + cur * B_SZ + b_off;
@@ -393,6 +443,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     k.a_mode = d->a_mode; k.a_act = d->a_act; k.b_mode = d->b_mode; k.b_act = d->b_act;
     k.act = d->act; k.act_cols = d->act_cols > 0 ? d->act_cols : d->N; k.e_mode = d->e_mode; k.e_act = d->e_act;
     k.accumulate = d->accumulate; k.c_trans = d->c_trans;
+    k.a_hq = d->a_hq > 0 ? d->a_hq : 1; k.b_hq = d->b_hq > 0 ? d->b_hq : 1; k.a_ld2 = d->a_ld2; k.b_ld2 = d->b_ld2;
     pick_split(d, c, &k.splitk, &k.kchunk);
     if (k.splitk > 1) {
         const size_t need = rn_align((size_t)k.splitk * d->batch * d->M * d->N * sizeof(float));

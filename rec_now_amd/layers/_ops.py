@@ -176,3 +176,42 @@ class DCNMixFunction(torch.autograd.Function):
                   act_inner, act_outer, _lib.ptr(dx), _host_ptr_array(dU), _host_ptr_array(dV), _host_ptr_array(dW),
                   _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(ws), ws.numel(), _lib.stream())
         return (dx, None, None, None) + tuple(grads)
+
+
+# ---- CIN --------------------------------------------------------------------------------------------------------------
+class CINFunction(torch.autograd.Function):
+    """emb (B, F*D); weights: L tensors, W_k viewed (H_k, F*H_{k-1})."""
+
+    @staticmethod
+    def forward(ctx, emb, D, F, hidden, output_input, sum_channel, *weights):
+        emb = _lib.f32c(emb, 'inputs')
+        ws_ = [_lib.f32c(w, 'weight') for w in weights]
+        B = emb.shape[0]
+        L = len(hidden)
+        hid = (ctypes.c_int * L)(*hidden)
+        lib = _lib.load()
+        saved = _lib.workspace(lib.recnow_cin_saved_bytes(B, D, F, hid, L), emb.device)
+        ws = _lib.workspace(lib.recnow_cin_workspace_bytes(B, D, F, hid, L), emb.device)
+        ctot = (F if output_input else 0) + sum(hidden)
+        out = torch.empty((B, D if sum_channel else ctot * D), dtype=torch.float32, device=emb.device)
+        _lib.call('recnow_cin_fwd', _lib.ptr(emb), _host_ptr_array(ws_), B, D, F, hid, L, 1 if output_input else 0,
+                  1 if sum_channel else 0, _lib.ptr(out), _lib.ptr(saved), saved.numel(), _lib.ptr(ws), ws.numel(), _lib.stream())
+        ctx.save_for_backward(saved, *ws_)
+        ctx.meta = (B, D, F, tuple(hidden), output_input, sum_channel)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved, *ws_ = ctx.saved_tensors
+        B, D, F, hidden, output_input, sum_channel = ctx.meta
+        L = len(hidden)
+        hid = (ctypes.c_int * L)(*hidden)
+        dout = _lib.f32c(dout, 'grad')
+        demb = torch.empty((B, F * D), dtype=torch.float32, device=dout.device)
+        dws = [torch.empty_like(w) for w in ws_]
+        lib = _lib.load()
+        ws = _lib.workspace(lib.recnow_cin_workspace_bytes(B, D, F, hid, L), dout.device)
+        _lib.call('recnow_cin_bwd', _host_ptr_array(ws_), _lib.ptr(dout), _lib.ptr(saved), saved.numel(), B, D, F, hid, L,
+                  1 if output_input else 0, 1 if sum_channel else 0, _lib.ptr(demb), _host_ptr_array(dws), _lib.ptr(ws),
+                  ws.numel(), _lib.stream())
+        return (demb, None, None, None, None, None) + tuple(dws)

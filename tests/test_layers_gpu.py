@@ -323,3 +323,51 @@ def test_dcn_mix_fwd_bwd_vs_oracle(dev, B, D, S, N, L, ai, ao):
     close(xd.grad, x64.grad)
     for k, p in layer.named_weights().items():
         close(p.grad, w64[k].grad)
+
+
+# ---- CIN ---------------------------------------------------------------------------------------------------------------
+def test_cin_reference_golden(dev, golden):
+    # /root/reference/tests/layers/test_cin_layer.py:18-42
+    from rec_now_amd.layers.cin_layer import CINLayer
+    from rec_now_amd.util.numpy_tools import calc_sum_of_abs_diff
+    g = golden('cin')
+    embeddings = [torch.from_numpy(x).to(dev) for x in g['inputs']]
+    cin = CINLayer([2, 1], name="CIN")
+    cin(embeddings, output_input=True, sum_channel=True)
+    cin.set_weights_by_name({'weight_of_layer1': g['weight_of_layer1'], 'weight_of_layer2': g['weight_of_layer2']})
+    cin_output = cin(embeddings, output_input=True, sum_channel=True)
+    assert calc_sum_of_abs_diff(cin_output, g['golden']) < 1e-5
+
+
+def test_cin_tensor_input_needs_embedding_dim(dev):
+    from rec_now_amd.layers.cin_layer import CINLayer
+    with pytest.raises(ValueError):
+        CINLayer([4])(torch.zeros(2, 12, device=dev))          # cin_layer.py:52-54
+
+
+@pytest.mark.parametrize('B,F,D,Hs,oi,sc,as_list', [(3, 4, 2, [3], True, True, True), (50, 10, 3, [2, 1], True, True, True),
+                                                     (64, 8, 4, [16, 8], False, True, False), (40, 6, 4, [5, 7], True, False, True),
+                                                     (33, 5, 8, [12], False, False, False), (128, 16, 8, [32, 32, 16], True, True, True)])
+def test_cin_fwd_bwd_vs_oracle(dev, B, F, D, Hs, oi, sc, as_list):
+    from rec_now_amd.layers.cin_layer import CINLayer
+    rng = np.random.default_rng(B + F + D)
+    xs = [rng.normal(0, 0.5, (B, D)).astype(np.float32) for _ in range(F)]
+    layer = CINLayer(Hs, embedding_dim=D)
+    xd = [torch.from_numpy(x).to(dev).requires_grad_(True) for x in xs]
+    inp = xd if as_list else torch.cat(xd, dim=1)
+    layer(inp, oi, sc)
+    ext = [F] + Hs
+    w = {'weight_of_layer%d' % k: rng.uniform(-0.5, 0.5, (1, 1, ext[k], ext[k - 1] * F)).astype(np.float32) for k in range(1, len(ext))}
+    layer.set_weights_by_name(w)
+    y = layer(inp, oi, sc)
+    gy = rng.normal(size=tuple(y.shape)).astype(np.float32)
+    y.backward(torch.from_numpy(gy).to(dev))
+    x64 = [torch.from_numpy(x).double().requires_grad_(True) for x in xs]
+    w64 = [torch.from_numpy(w['weight_of_layer%d' % k]).double().requires_grad_(True) for k in range(1, len(ext))]
+    ry = R.cin_layer(x64, w64, F, D, oi, sc)
+    ry.backward(torch.from_numpy(gy).double())
+    close(y, ry)
+    for a, b in zip(xd, x64):
+        close(a.grad, b.grad)
+    for k in range(1, len(ext)):
+        close(layer.idx2weight[k].grad, w64[k - 1].grad)
