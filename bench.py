@@ -171,8 +171,14 @@ def main():
         tag = max(GEMM_TAGS, key=lambda t: ms[t])
         if cnt[tag] > 0:
             achieved = fl[tag] / (ms[tag] * 1e-3) / 1e12
+            traffic = None                # HBM bytes per launch from the committed PMC passes (profiles/traffic.json)
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as fh:
+                    traffic = json.load(fh)['hbm_bytes_per_launch'].get(GEMM_TAGS[tag])
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'kernel': GEMM_TAGS[tag],
+                        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'kernel': GEMM_TAGS[tag],
                         'launches': cnt[tag], 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
                         'algorithmic_flops_per_launch': fl[tag] / cnt[tag],
                         'all_gemm': {GEMM_TAGS[t]: {'launches': cnt[t], 'ms': ms[t],
