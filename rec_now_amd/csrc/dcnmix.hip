@@ -14,10 +14,23 @@
 //           gate-weighted bias sum_n G_n b_n rides along as N extra K rows.
 // Backward mirrors this with the producers of each gradient GEMM fused into operand loads (x*dy) or epilogues
 // (act' multiply), split-K slab reduction for the K = B weight gradients, and O recomputed for dx (dy * O).
-// Leading dimension of the small activations: LDT = roundup(NS+N, 4) floats so rows stay 16-byte aligned.
+// Leading dimension of the small activations: LDT = N*S+N rounded up to the GEMM's column-tile width (32/64/128/160/
+// multiples of 128) and K of the (N*S+N)-deep products rounded up to 16/32, all zero padded, so every GEMM of the layer
+// takes the lean interior kernel (no bounds code) whenever B is a multiple of 256.  Zero columns/rows are inert.
 #include "gemm.hpp"
 
-static inline int ldt_of(int S, int N) { return (N * S + N + 3) / 4 * 4; }
+static inline int ldt_of(int S, int N) {
+    const int kc = N * S + N;
+    if (kc <= 32) return 32;
+    if (kc <= 64) return 64;
+    if (kc <= 128) return 128;
+    if (kc <= 160) return 160;
+    return (kc + 127) / 128 * 128;
+}
+static inline int kp_of(int S, int N) {            // padded depth of the K = N*S+N products
+    const int kc = N * S + N;
+    return kc <= 256 ? (kc + 15) / 16 * 16 : (kc + 31) / 32 * 32;
+}
 
 // Wc1[d][n*S+s] = U[n][d][s];  Wc1[d][NS+n] = K[d][n];  pad columns = 0
 __global__ void k_pack_w1(const float* __restrict__ U, const float* __restrict__ K, int D, int S, int N, int LDT, float* __restrict__ Wc1) {
@@ -96,11 +109,11 @@ k_dcnmix_gate_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, 
 
 struct MixDims {
     int64_t B;
-    int D, S, N, L, NS, KC, LDT;   // KC = NS + N
+    int D, S, N, L, NS, KC, LDT, KP;   // KC = NS + N; LDT/KP = padded width / depth
 };
 static inline MixDims mix_dims(int64_t B, int D, int S, int N, int L) {
     MixDims m;
-    m.B = B; m.D = D; m.S = S; m.N = N; m.L = L; m.NS = N * S; m.KC = N * S + N; m.LDT = ldt_of(S, N);
+    m.B = B; m.D = D; m.S = S; m.N = N; m.L = L; m.NS = N * S; m.KC = N * S + N; m.LDT = ldt_of(S, N); m.KP = kp_of(S, N);
     return m;
 }
 static inline size_t act_block(const MixDims& m) { return rn_align((size_t)m.B * m.LDT * sizeof(float)); }
@@ -116,7 +129,7 @@ extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int
 static size_t mix_gemm_ws(const MixDims& m) {
     size_t best = 0;
     recnow_gemm_desc d = rn_gemm_desc_zero();
-    const int shapes[6][3] = {{(int)m.B, m.KC, m.D}, {(int)m.B, m.D, m.KC}, {m.KC, m.D, (int)m.B}, {m.D, m.KC, (int)m.B},
+    const int shapes[6][3] = {{(int)m.B, m.LDT, m.D}, {(int)m.B, m.D, m.KP}, {m.LDT, m.D, (int)m.B}, {m.D, m.LDT, (int)m.B},
                               {m.S, m.S, (int)m.B}, {(int)m.B, m.S, m.S}};
     for (int i = 0; i < 6; ++i) {
         d.M = shapes[i][0]; d.N = shapes[i][1]; d.K = shapes[i][2]; d.batch = (i >= 4) ? m.N : 1;
@@ -131,9 +144,9 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
     const MixDims m = mix_dims(B, D, S, N, L);
     size_t s = 0;
     s += rn_align((size_t)D * m.LDT * sizeof(float));        // Wc1
-    s += rn_align((size_t)m.KC * D * sizeof(float));         // Wc2
+    s += rn_align((size_t)m.LDT * D * sizeof(float));        // Wc2 (rows >= KC are zero)
     s += rn_align((size_t)D * m.LDT * sizeof(float));        // dWc1
-    s += rn_align((size_t)m.KC * D * sizeof(float));         // dWc2
+    s += rn_align((size_t)m.LDT * D * sizeof(float));        // dWc2
     s += 3 * act_block(m);                                   // dT2g, dC, dT1
     s += 2 * xbuf(m);                                        // inter-layer gradient ping-pong
     s += mix_gemm_ws(m);
@@ -147,7 +160,8 @@ static int pack_weights(const MixDims& m, const float* U, const float* V, const 
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(k_pack_w1, g, 256, 0, st, U, K, m.D, m.S, m.N, m.LDT, Wc1);
     RN_LAUNCH_CHECK();
-    // Wc2 = [W (NS x D); bias (N x D)] -- both already row-major contiguous
+    // Wc2 = [W (NS x D); bias (N x D); zero rows up to LDT] -- W and bias are already row-major contiguous
+    RN_HIP(hipMemsetAsync(Wc2 + (size_t)m.KC * m.D, 0, (size_t)(m.LDT - m.KC) * m.D * sizeof(float), st));
     RN_HIP(hipMemcpyAsync(Wc2, W, (size_t)m.NS * m.D * sizeof(float), hipMemcpyDeviceToDevice, st));
     RN_HIP(hipMemcpyAsync(Wc2 + (size_t)m.NS * m.D, bias, (size_t)m.N * m.D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return RECNOW_OK;
@@ -173,9 +187,9 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
     const MixDims m = mix_dims(B, D, S, N, L);
     RnCarver c(ws, ws_bytes);
     float* Wc1 = c.take<float>((size_t)D * m.LDT);
-    float* Wc2 = c.take<float>((size_t)m.KC * D);
+    float* Wc2 = c.take<float>((size_t)m.LDT * D);
     c.take<float>((size_t)D * m.LDT);
-    c.take<float>((size_t)m.KC * D);
+    c.take<float>((size_t)m.LDT * D);
     c.take<float>(3 * act_block(m) / sizeof(float));
     c.take<float>(2 * xbuf(m) / sizeof(float));
     void* gws = c.base + c.off;
@@ -195,7 +209,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
             d.A = xl; d.lda = D; d.a_trans = 0;
             d.B = Wc1; d.ldb = m.LDT; d.b_trans = 0;
             d.C = T1; d.ldc = m.LDT;
-            d.M = (int)B; d.N = m.KC; d.K = D;
+            d.M = (int)B; d.N = m.LDT; d.K = D;
             d.act = act_inner; d.act_cols = m.NS;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
         }
@@ -215,7 +229,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
             d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc2; d.ldb = D; d.b_trans = 0;
             d.C = out; d.ldc = D;
-            d.M = (int)B; d.N = D; d.K = m.KC;
+            d.M = (int)B; d.N = D; d.K = m.KP;
             d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
         }
@@ -250,9 +264,9 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
     const MixDims m = mix_dims(B, D, S, N, L);
     RnCarver c(ws, ws_bytes);
     float* Wc1 = c.take<float>((size_t)D * m.LDT);
-    float* Wc2 = c.take<float>((size_t)m.KC * D);
+    float* Wc2 = c.take<float>((size_t)m.LDT * D);
     float* dWc1 = c.take<float>((size_t)D * m.LDT);
-    float* dWc2 = c.take<float>((size_t)m.KC * D);
+    float* dWc2 = c.take<float>((size_t)m.LDT * D);
     float* dT2g = c.take<float>(act_block(m) / sizeof(float));
     float* dC = c.take<float>(act_block(m) / sizeof(float));
     float* dT1 = c.take<float>(act_block(m) / sizeof(float));
@@ -277,7 +291,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 0;
             d.B = Wc2; d.ldb = D; d.b_trans = 1;
             d.C = dT2g; d.ldc = m.LDT;
-            d.M = (int)B; d.N = m.KC; d.K = D;
+            d.M = (int)B; d.N = m.LDT; d.K = D;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
         }
         {   // dWc2 = T2g^T (x * g)          -> dW (NS x D) and dbias (N x D).  Computed as the transposed product
@@ -286,7 +300,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 1;
             d.B = T2g; d.ldb = m.LDT; d.b_trans = 0;
             d.C = dWc2; d.ldc = D; d.c_trans = 1;
-            d.M = D; d.N = m.KC; d.K = (int)B;
+            d.M = D; d.N = m.LDT; d.K = (int)B;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             RN_HIP(hipMemcpyAsync(dW_host[l], dWc2, (size_t)m.NS * D * sizeof(float), hipMemcpyDeviceToDevice, st));
             RN_HIP(hipMemcpyAsync(dbias_host[l], dWc2 + (size_t)m.NS * D, (size_t)N * D * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -296,7 +310,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc2; d.ldb = D; d.b_trans = 0;
             d.C = dx; d.ldc = D;
-            d.M = (int)B; d.N = D; d.K = m.KC;
+            d.M = (int)B; d.N = D; d.K = m.KP;
             d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
             d.accumulate = dx_started ? 1 : 0;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
@@ -326,7 +340,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             d.A = xl; d.lda = D; d.a_trans = 1;
             d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
             d.C = dWc1; d.ldc = m.LDT;
-            d.M = D; d.N = m.KC; d.K = (int)B;
+            d.M = D; d.N = m.LDT; d.K = (int)B;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             int gg = rn_cdiv((int64_t)D * m.KC, 256);
             if (gg > 2048) gg = 2048;
@@ -338,7 +352,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
             d.C = (l == 0) ? dx : gprev; d.ldc = D;
-            d.M = (int)B; d.N = D; d.K = m.KC;
+            d.M = (int)B; d.N = D; d.K = m.KP;
             d.accumulate = (l == 0) ? 1 : 0;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
         }

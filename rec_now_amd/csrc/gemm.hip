@@ -49,6 +49,22 @@ struct Tile {
     static constexpr bool RAGGED = (NF4 % GEMM_THREADS) != 0;                   // last slot only for some threads
     static constexpr int LD = KC ? ROWS + 1 : ROWS;
     float4 v[NV];
+    unsigned off[NV];     // element offset of this thread's float4 inside a tile; tile-invariant (set once by init)
+
+    // A tile's addresses are (block-uniform tile base) + off[i]: the base lives in SGPRs and advances per k-tile, the
+    // offsets are loop-invariant 32-bit VGPRs.  (Per-load 64-bit addresses recomputed every tile cost ~10 VALU each and,
+    // under the 256-register cap, got spilled -- the reload's vmcnt(0) then serialised every tile's loads.)
+    __device__ __forceinline__ void init(int64_t ld) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int r, k;
+            coords(threadIdx.x + i * GEMM_THREADS, r, k);
+            off[i] = KC ? (unsigned)(r * ld + k) : (unsigned)(k * ld + r);
+        }
+    }
+    __device__ __forceinline__ static int64_t tile_base(int64_t ld, int r0, int k0) {
+        return KC ? (int64_t)r0 * ld + k0 : (int64_t)k0 * ld + r0;
+    }
 
     __device__ __forceinline__ static void coords(int idx, int& r, int& k) {   // first element of this thread's float4
         if (KC) { k = (idx % (BK / 4)) * 4; r = idx / (BK / 4); }
@@ -62,14 +78,13 @@ struct Tile {
     __device__ __forceinline__ void load_fast(const float* __restrict__ p, const float* __restrict__ p2, int mode, int act,
                                               int64_t ld, int r0, int k0) {
         float4 y[NV];
+        const float* __restrict__ tb = p + tile_base(ld, r0, k0);
+        const float* __restrict__ tb2 = SECOND ? p2 + tile_base(ld, r0, k0) : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            int r, k;
-            coords(threadIdx.x + i * GEMM_THREADS, r, k);
-            const int64_t off = KC ? (int64_t)(r0 + r) * ld + (k0 + k) : (int64_t)(k0 + k) * ld + (r0 + r);
             if (has(i)) {
-                v[i] = *reinterpret_cast<const float4*>(p + off);
-                if (SECOND) y[i] = *reinterpret_cast<const float4*>(p2 + off);
+                v[i] = *reinterpret_cast<const float4*>(tb + off[i]);
+                if (SECOND) y[i] = *reinterpret_cast<const float4*>(tb2 + off[i]);
             }
         }
         if (SECOND) {
@@ -147,16 +162,17 @@ struct Tile {
         for (int i = 0; i < NV; ++i) v[i] = make_float4(x[i][0] * y[i][0], x[i][1] * y[i][1], x[i][2] * y[i][2], x[i][3] * y[i][3]);
     }
 
+    template <bool EDGE>
     __device__ __forceinline__ void load(bool fast, const float* __restrict__ p, const float* __restrict__ p2, int mode,
                                          int act, int64_t ld, int r0, int k0, int R, int Kend, int64_t ld2 = 0, int hq = 1) {
         if (mode == RECNOW_OPMODE_OUTER) {
-            if (fast) load_outer_fast(p, p2, ld, ld2, hq, r0, k0);
+            if (!EDGE || fast) load_outer_fast(p, p2, ld, ld2, hq, r0, k0);
             else load_outer_safe(p, p2, ld, ld2, hq, r0, k0, R, Kend);
         } else if (mode == RECNOW_OPMODE_NONE) {
-            if (fast) load_fast<false>(p, p2, mode, act, ld, r0, k0);
+            if (!EDGE || fast) load_fast<false>(p, p2, mode, act, ld, r0, k0);
             else load_safe<false>(p, p2, mode, act, ld, r0, k0, R, Kend);
         } else {
-            if (fast) load_fast<true>(p, p2, mode, act, ld, r0, k0);
+            if (!EDGE || fast) load_fast<true>(p, p2, mode, act, ld, r0, k0);
             else load_safe<true>(p, p2, mode, act, ld, r0, k0, R, Kend);
         }
     }
@@ -184,7 +200,9 @@ __device__ __forceinline__ bool gemm_aligned(const void* p, int64_t ld, int64_t 
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0) && (sb % 4 == 0);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC>
+// EDGE = false: every tile of the launch is in bounds and 16-byte aligned (checked on the host) -> no bounds code at
+// all (lean: no spills under the 256-register cap).  EDGE = true: general shapes, clamped loads and predicated stores.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, bool EDGE>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)      // >= 2 waves/SIMD: VGPR+AGPR <= 256, two workgroups per CU
 k_gemm(const GemmK p) {
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
@@ -206,10 +224,10 @@ k_gemm(const GemmK p) {
     const float* B2b = p.B2 ? p.B2 + (p.b_mode == RECNOW_OPMODE_OUTER ? 0 : (int64_t)bidx * p.sB) : nullptr;
     // block-uniform: rows of this tile all in bounds and every float4 16-byte aligned
     const bool a_outer = p.a_mode == RECNOW_OPMODE_OUTER, b_outer = p.b_mode == RECNOW_OPMODE_OUTER;
-    const bool a_fast = (m0 + BM <= p.M) && gemm_aligned(p.A, p.lda, p.sA) &&
-                        (a_outer ? (p.a_hq % 4 == 0) : (!p.A2 || gemm_aligned(p.A2, p.lda, p.sA)));
-    const bool b_fast = (n0 + BN <= p.N) && gemm_aligned(p.B, p.ldb, p.sB) &&
-                        (b_outer ? (p.b_hq % 4 == 0) : (!p.B2 || gemm_aligned(p.B2, p.ldb, p.sB)));
+    const bool a_fast = !EDGE || ((m0 + BM <= p.M) && gemm_aligned(p.A, p.lda, p.sA) &&
+                                  (a_outer ? (p.a_hq % 4 == 0) : (!p.A2 || gemm_aligned(p.A2, p.lda, p.sA))));
+    const bool b_fast = !EDGE || ((n0 + BN <= p.N) && gemm_aligned(p.B, p.ldb, p.sB) &&
+                                  (b_outer ? (p.b_hq % 4 == 0) : (!p.B2 || gemm_aligned(p.B2, p.ldb, p.sB))));
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -226,11 +244,13 @@ k_gemm(const GemmK p) {
 
     TA ta;
     TB tb;
+    ta.init(p.lda);
+    tb.init(p.ldb);
     const int ntile = (k_end - k_begin + BK - 1) / BK;
     if (ntile > 0) {
-        const bool kf = k_begin + BK <= k_end;
-        ta.load(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end, p.a_ld2, p.a_hq);
-        tb.load(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end, p.b_ld2, p.b_hq);
+        const bool kf = !EDGE || (k_begin + BK <= k_end);
+        ta.template load<EDGE>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end, p.a_ld2, p.a_hq);
+        tb.template load<EDGE>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end, p.b_ld2, p.b_hq);
         ta.store(As);
         tb.store(Bs);
     }
@@ -239,15 +259,15 @@ k_gemm(const GemmK p) {
         const int cur = t & 1;
         if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
             const int k0 = k_begin + (t + 1) * BK;
-            const bool kf = k0 + BK <= k_end;
-            ta.load(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
-            tb.load(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
+            const bool kf = !EDGE || (k0 + BK <= k_end);
+            ta.template load<EDGE>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
+            tb.template load<EDGE>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
         }
         const float* as = As + cur * A_SZ + a_off;
         const float* bs = Bs + cur * B_SZ + b_off;
         // ONE loop form for full and tail tiles (two forms make the compiler shuffle every accumulator between them):
         // kv = valid k of this tile; rows beyond it are zero in LDS, so the (at most one) surplus k-step adds zeros.
-        const int kv = min(BK, k_end - (k_begin + t * BK));
+        const int kv = EDGE ? min(BK, k_end - (k_begin + t * BK)) : BK;
         float a0[TM], b0[TN], a1[TM], b1[TN];      // explicit fragment double buffer: step kk+2 loads under step kk's MFMAs
 #pragma unroll
         for (int i = 0; i < TM; ++i) a0[i] = as[i * 32];
@@ -288,6 +308,62 @@ k_gemm(const GemmK p) {
 
     // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    if constexpr (!EDGE) {
+        // Lean epilogue: each 32x32 accumulator sub-tile goes through a wave-private LDS buffer (36-float rows) so that
+        // global traffic is float4 per lane (8 lanes = one 128-B row segment) with every epilogue operand of the
+        // sub-tile in flight at once -- 4 wide loads/stores instead of 16 + 16 dependent dword round trips.
+        float* stg = smem + wave * (32 * 36);          // the k-loop's last barrier has retired every As/Bs read
+        const int rr0 = lane >> 3, cc = (lane & 7) * 4;
+        float* Cb = p.splitk > 1 ? p.partial + ((int64_t)z * p.M) * p.N : p.C + (int64_t)bidx * p.sC;
+        const int64_t ldc = p.splitk > 1 ? p.N : p.ldc;
+        const bool plain = p.splitk > 1;
+        const float* biasb = (!plain && p.bias) ? p.bias + (int64_t)bidx * p.sBias : nullptr;
+        const float* Eb = (!plain && p.emul) ? p.emul + (int64_t)bidx * p.sE : nullptr;
+        const bool accum = !plain && p.accumulate;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row0 = m0 + wm * TM * 32 + i * 32, col0 = n0 + wn * TN * 32 + j * 32 + cc;
+                float4 ev[4], cv[4];
+                if (Eb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const float4*>(Eb + (int64_t)(row0 + q * 8 + rr0) * p.lde + col0);
+                }
+                if (accum) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cv[q] = *reinterpret_cast<const float4*>(Cb + (int64_t)(row0 + q * 8 + rr0) * ldc + col0);
+                }
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (biasb) bv = *reinterpret_cast<const float4*>(biasb + col0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + row_l) * 36 + col_l] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 a = *reinterpret_cast<const float4*>(stg + (q * 8 + rr0) * 36 + cc);
+                    float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+                    if (!plain && p.act != RECNOW_ACT_LINEAR) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col0 + e < p.act_cols) v[e] = rn_act(v[e], p.act);
+                    }
+                    if (Eb) {
+                        const float ee[4] = {ev[q].x, ev[q].y, ev[q].z, ev[q].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(ee[e], p.e_act) : ee[e];
+                    }
+                    if (accum) { v[0] += cv[q].x; v[1] += cv[q].y; v[2] += cv[q].z; v[3] += cv[q].w; }
+                    *reinterpret_cast<float4*>(Cb + (int64_t)(row0 + q * 8 + rr0) * ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    } else {
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);          // block-uniform
     if (p.splitk > 1) {
         float* P = p.partial + ((int64_t)z * p.M) * p.N;
@@ -347,6 +423,7 @@ k_gemm(const GemmK p) {
                 if (interior || (row < p.M && col < p.N)) Cb[(int64_t)row * c_rs + (int64_t)col * c_cs] = v[r];
             }
         }
+    }
 }
 
 // sum the split-K slabs in slice order (deterministic) and apply the epilogue
@@ -411,11 +488,12 @@ size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
 }
 
 template <int BM, int BN, int WM, int WN, int BK>
-static int launch_cfg(const GemmK& k, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
+static int launch_cfg(const GemmK& k, bool a_kc, bool b_kc, bool edge, dim3 grid, hipStream_t st) {
 #define RN_GEMM_LAUNCH(AKC, BKC)                                                                                        \
     do {                                                                                                                \
         constexpr size_t lds = 2 * BK * (size_t)(Tile<BM, BK, AKC>::LD + Tile<BN, BK, BKC>::LD) * sizeof(float);        \
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC>), grid, GEMM_THREADS, lds, st, k);                     \
+        if (edge) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, true>), grid, GEMM_THREADS, lds, st, k);     \
+        else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, false>), grid, GEMM_THREADS, lds, st, k);         \
     } while (0)
     if (a_kc && b_kc) RN_GEMM_LAUNCH(true, true);
     else if (a_kc && !b_kc) RN_GEMM_LAUNCH(true, false);
@@ -424,6 +502,26 @@ static int launch_cfg(const GemmK& k, bool a_kc, bool b_kc, dim3 grid, hipStream
 #undef RN_GEMM_LAUNCH
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
+}
+
+static inline bool host_aligned(const void* p, int64_t ld, int64_t sb) {
+    return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (sb % 4 == 0);
+}
+// the lean (EDGE = false) kernel needs every tile in bounds and every float4 aligned
+static bool gemm_interior(const recnow_gemm_desc* d, const GemmCfg& c, int bk, int kchunk, bool split) {
+    if (d->M % c.BM || d->N % c.BN || d->K % bk || kchunk % bk) return false;
+    if (!host_aligned(d->A, d->lda, d->a_batch_stride) || !host_aligned(d->B, d->ldb, d->b_batch_stride)) return false;
+    if (d->a_mode == RECNOW_OPMODE_OUTER) { if (d->a_hq % 4) return false; }
+    else if (d->a_mode != RECNOW_OPMODE_NONE && !host_aligned(d->A2, d->lda, d->a_batch_stride)) return false;
+    if (d->b_mode == RECNOW_OPMODE_OUTER) { if (d->b_hq % 4) return false; }
+    else if (d->b_mode != RECNOW_OPMODE_NONE && !host_aligned(d->B2, d->ldb, d->b_batch_stride)) return false;
+    // the lean epilogue is float4 along the columns of C (the split-K slabs always qualify: N is a tile multiple)
+    if (!split) {
+        if (d->c_trans || !host_aligned(d->C, d->ldc, d->c_batch_stride)) return false;
+        if (d->emul && !host_aligned(d->emul, d->lde, d->e_batch_stride)) return false;
+        if (d->bias && !host_aligned(d->bias, 4, d->bias_batch_stride)) return false;
+    }
+    return true;
 }
 
 int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -461,12 +559,14 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     // short-K products (K <= 256, e.g. the K = N*S+N = 130 contractions of DCN-v2) are prologue/epilogue dominated:
     // BK = 16 halves the LDS footprint so 4 workgroups per CU overlap each other's load/store phases.
     const bool short_k = d->K <= 256;
-    if (c.BM == 256 && c.BN == 32) rc = launch_cfg<256, 32, 4, 1, 32>(k, a_kc, b_kc, grid, st);
-    else if (c.BM == 256 && c.BN == 64) rc = launch_cfg<256, 64, 4, 1, 32>(k, a_kc, b_kc, grid, st);
-    else if (c.BN == 160) rc = short_k ? launch_cfg<128, 160, 4, 1, 16>(k, a_kc, b_kc, grid, st)
-                                      : launch_cfg<128, 160, 4, 1, 32>(k, a_kc, b_kc, grid, st);
-    else rc = short_k ? launch_cfg<128, 128, 2, 2, 16>(k, a_kc, b_kc, grid, st)
-                      : launch_cfg<128, 128, 2, 2, 32>(k, a_kc, b_kc, grid, st);
+    const bool bk16 = short_k && c.BM == 128;
+    const bool edge = !gemm_interior(d, c, bk16 ? 16 : 32, k.kchunk, k.splitk > 1);
+    if (c.BM == 256 && c.BN == 32) rc = launch_cfg<256, 32, 4, 1, 32>(k, a_kc, b_kc, edge, grid, st);
+    else if (c.BM == 256 && c.BN == 64) rc = launch_cfg<256, 64, 4, 1, 32>(k, a_kc, b_kc, edge, grid, st);
+    else if (c.BN == 160) rc = short_k ? launch_cfg<128, 160, 4, 1, 16>(k, a_kc, b_kc, edge, grid, st)
+                                      : launch_cfg<128, 160, 4, 1, 32>(k, a_kc, b_kc, edge, grid, st);
+    else rc = short_k ? launch_cfg<128, 128, 2, 2, 16>(k, a_kc, b_kc, edge, grid, st)
+                      : launch_cfg<128, 128, 2, 2, 32>(k, a_kc, b_kc, edge, grid, st);
     rn_prof_end(pr, st);
     if (rc) return rc;
     if (k.splitk > 1) {

@@ -1,5 +1,5 @@
 """Microbenchmark of recnow_gemm on the shapes the DCN-v2 step uses (+ a square reference).  GPU only.
-usage: python tools/gemm_bench.py [reps]"""
+usage: python tools/gemm_bench.py [reps] [shape_index]"""
 import ctypes
 import sys
 import os
@@ -22,6 +22,13 @@ SHAPES = [
     ('dxl    dT1 Wc1^T     (B,130)x(130,D)', B, D, KC, 0, 1, LDT, LDT, D, 0, 0, 0),
     ('dWc1   xl^T dT1      (D,B)x(B,130)', D, KC, B, 1, 0, D, LDT, LDT, 0, 0, 0),
     ('dWc2^T (x*g)^T T2g   (D,B)x(B,130)', D, KC, B, 1, 0, D, LDT, D, 1, 0, 1),
+    # tile-aligned (padded) versions of the same products: N 130 -> 160 columns, K 130 -> 144, leading dim 160
+    ('pad GEMM1  (B,D)x(D,160)', B, 160, D, 0, 0, D, 160, 160, 0, 0, 0),
+    ('pad GEMM3  (B,144)x(144,D)', B, D, 144, 0, 0, 160, D, D, 0, 1, 0),
+    ('pad dT2g   (B,D)x(D,160) A*A2', B, 160, D, 0, 1, D, D, 160, 1, 0, 0),
+    ('pad dxl    (B,144)x(144,D)', B, D, 144, 0, 1, 160, 160, D, 0, 0, 0),
+    ('pad dWc1   (D,B)x(B,160)', D, 160, B, 1, 0, D, 160, 160, 0, 0, 0),
+    ('pad dWc2^T (D,B)x(B,160) A*A2', D, 160, B, 1, 0, D, 160, D, 1, 0, 1),
     ('square 4096^3 NN', 4096, 4096, 4096, 0, 0, 4096, 4096, 4096, 0, 0, 0),
     ('square 4096^3 NT', 4096, 4096, 4096, 0, 1, 4096, 4096, 4096, 0, 0, 0),
 ]
@@ -59,5 +66,7 @@ def run(name, M, N, K, ta, tb, lda, ldb, ldc, a_mode, emul, c_trans):
     print('%-40s %9.1f us  %6.1f TFLOP/s' % (name, us, 2.0 * M * N * K / us / 1e6), flush=True)
 
 
-for s in SHAPES:
-    run(*s)
+only = int(sys.argv[2]) if len(sys.argv) > 2 else None
+for i, s in enumerate(SHAPES):
+    if only is None or i == only:
+        run(*s)
