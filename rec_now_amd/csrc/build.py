@@ -39,7 +39,7 @@ def build(verbose=True, force=False):
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(OUT):
         run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)

@@ -12,419 +12,8 @@
 // lanes 0-31 (k) and 32 consecutive floats for lanes 32-63 (k+1): conflict-free ds_read_b32 with no padding tricks.
 // An operand that is k-contiguous in memory ([m][k]) is loaded as float4 along k (coalesced 128-B rows) and transposed
 // on the LDS write; its row stride is ROWS+1 floats so those 4-B writes are conflict-free too.
-#include "gemm.hpp"
+#include "gemm_kernel.hpp"
 #include "prof.hpp"
-#include <string.h>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define GEMM_BK 32
-#define GEMM_THREADS 256
-
-struct GemmK {
-    const float *A, *A2, *B, *B2, *bias, *emul;
-    float *C, *partial;
-    int64_t lda, ldb, ldc, lde, sA, sB, sC, sBias, sE;
-    int M, N, K, batch;
-    int a_mode, a_act, b_mode, b_act, act, act_cols, e_mode, e_act, accumulate, c_trans, splitk, kchunk;
-    int a_hq, b_hq;            // OUTER mode: operand(row, col) = second[row][col / hq] * first[row][col % hq]
-    int64_t a_ld2, b_ld2;      // row stride of `second` in OUTER mode
-};
-
-__device__ __forceinline__ float4 gemm_combine(float4 x, float4 y, int mode, int act) {
-    if (mode == RECNOW_OPMODE_MUL) return make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
-    return make_float4(x.x * rn_act_grad_from_out(y.x, act), x.y * rn_act_grad_from_out(y.y, act),
-                       x.z * rn_act_grad_from_out(y.z, act), x.w * rn_act_grad_from_out(y.w, act));
-}
-
-// ROWS = BM (A) or BN (B).  KC: operand is k-contiguous in memory ([row][k]); else [k][row].
-// Two loaders, chosen per k-tile by a BLOCK-UNIFORM condition so that no load ever sits under a per-lane branch
-// (a branch around each load makes hipcc drain vmcnt at every merge and serialises the tile's loads):
-//   load_fast: whole tile in bounds and 16-B aligned -> unconditional float4 loads, all in flight together;
-//   load_safe: edge tiles -> unconditional scalar loads from CLAMPED (always valid) addresses + select to zero.
-template <int ROWS, int BK, bool KC>
-struct Tile {
-    static constexpr int NF4 = ROWS * BK / 4;                                   // float4 slots in the tile
-    static constexpr int NV = (NF4 + GEMM_THREADS - 1) / GEMM_THREADS;
-    static constexpr bool RAGGED = (NF4 % GEMM_THREADS) != 0;                   // last slot only for some threads
-    static constexpr int LD = KC ? ROWS + 1 : ROWS;
-    float4 v[NV];
-    unsigned off[NV];     // element offset of this thread's float4 inside a tile; tile-invariant (set once by init)
-
-    // A tile's addresses are (block-uniform tile base) + off[i]: the base lives in SGPRs and advances per k-tile, the
-    // offsets are loop-invariant 32-bit VGPRs.  (Per-load 64-bit addresses recomputed every tile cost ~10 VALU each and,
-    // under the 256-register cap, got spilled -- the reload's vmcnt(0) then serialised every tile's loads.)
-    __device__ __forceinline__ void init(int64_t ld) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            int r, k;
-            coords(threadIdx.x + i * GEMM_THREADS, r, k);
-            off[i] = KC ? (unsigned)(r * ld + k) : (unsigned)(k * ld + r);
-        }
-    }
-    __device__ __forceinline__ static int64_t tile_base(int64_t ld, int r0, int k0) {
-        return KC ? (int64_t)r0 * ld + k0 : (int64_t)k0 * ld + r0;
-    }
-
-    __device__ __forceinline__ static void coords(int idx, int& r, int& k) {   // first element of this thread's float4
-        if (KC) { k = (idx % (BK / 4)) * 4; r = idx / (BK / 4); }
-        else { r = (idx % (ROWS / 4)) * 4; k = idx / (ROWS / 4); }
-    }
-    __device__ __forceinline__ static bool has(int i) {
-        return !RAGGED || i + 1 < NV || (int)threadIdx.x + i * GEMM_THREADS < NF4;
-    }
-
-    template <bool SECOND>
-    __device__ __forceinline__ void load_fast(const float* __restrict__ p, const float* __restrict__ p2, int mode, int act,
-                                              int64_t ld, int r0, int k0) {
-        float4 y[NV];
-        const float* __restrict__ tb = p + tile_base(ld, r0, k0);
-        const float* __restrict__ tb2 = SECOND ? p2 + tile_base(ld, r0, k0) : nullptr;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            if (has(i)) {
-                v[i] = *reinterpret_cast<const float4*>(tb + off[i]);
-                if (SECOND) y[i] = *reinterpret_cast<const float4*>(tb2 + off[i]);
-            }
-        }
-        if (SECOND) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] = gemm_combine(v[i], y[i], mode, act);
-        }
-    }
-
-    template <bool SECOND>
-    __device__ __forceinline__ void load_safe(const float* __restrict__ p, const float* __restrict__ p2, int mode, int act,
-                                              int64_t ld, int r0, int k0, int R, int Kend) {
-        float y[NV][4];
-        float x[NV][4];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            int r, k;
-            coords(threadIdx.x + i * GEMM_THREADS, r, k);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gr = r0 + r + (KC ? 0 : e), gk = k0 + k + (KC ? e : 0);
-                const bool ok = gr < R && gk < Kend;
-                const int cr = min(gr, R - 1), ck = min(gk, Kend - 1);          // always a valid address
-                const int64_t off = KC ? (int64_t)cr * ld + ck : (int64_t)ck * ld + cr;
-                const float a = p[off];
-                x[i][e] = ok ? a : 0.f;
-                if (SECOND) { const float b = p2[off]; y[i][e] = ok ? b : 0.f; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            v[i] = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
-            if (SECOND) v[i] = gemm_combine(v[i], make_float4(y[i][0], y[i][1], y[i][2], y[i][3]), mode, act);
-        }
-    }
-
-    // OUTER mode (CIN's on-the-fly outer product): element (row, col) = p2[row*ld2 + col/hq] * p[row*ld + col%hq], where
-    // (row, col) = (tile row, k) for k-contiguous tiles and (k, tile row) otherwise.  hq % 4 == 0 on the fast path, so
-    // the four elements of a float4 share one p2 value.
-    __device__ __forceinline__ void load_outer_fast(const float* __restrict__ p, const float* __restrict__ p2, int64_t ld,
-                                                    int64_t ld2, int hq, int r0, int k0) {
-        float s2[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            int r, k;
-            coords(threadIdx.x + i * GEMM_THREADS, r, k);
-            const int row = KC ? r0 + r : k0 + k, col = KC ? k0 + k : r0 + r;
-            if (has(i)) {
-                v[i] = *reinterpret_cast<const float4*>(p + (int64_t)row * ld + (col % hq));
-                s2[i] = p2[(int64_t)row * ld2 + (col / hq)];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = make_float4(v[i].x * s2[i], v[i].y * s2[i], v[i].z * s2[i], v[i].w * s2[i]);
-    }
-    __device__ __forceinline__ void load_outer_safe(const float* __restrict__ p, const float* __restrict__ p2, int64_t ld,
-                                                    int64_t ld2, int hq, int r0, int k0, int R, int Kend) {
-        float x[NV][4], y[NV][4];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            int r, k;
-            coords(threadIdx.x + i * GEMM_THREADS, r, k);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gr = r0 + r + (KC ? 0 : e), gk = k0 + k + (KC ? e : 0);
-                const bool ok = gr < R && gk < Kend;
-                const int cr = min(gr, R - 1), ck = min(gk, Kend - 1);
-                const int row = KC ? cr : ck, col = KC ? ck : cr;
-                const float a = p[(int64_t)row * ld + (col % hq)];
-                const float b = p2[(int64_t)row * ld2 + (col / hq)];
-                x[i][e] = ok ? a : 0.f;
-                y[i][e] = b;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = make_float4(x[i][0] * y[i][0], x[i][1] * y[i][1], x[i][2] * y[i][2], x[i][3] * y[i][3]);
-    }
-
-    template <bool EDGE>
-    __device__ __forceinline__ void load(bool fast, const float* __restrict__ p, const float* __restrict__ p2, int mode,
-                                         int act, int64_t ld, int r0, int k0, int R, int Kend, int64_t ld2 = 0, int hq = 1) {
-        if (mode == RECNOW_OPMODE_OUTER) {
-            if (!EDGE || fast) load_outer_fast(p, p2, ld, ld2, hq, r0, k0);
-            else load_outer_safe(p, p2, ld, ld2, hq, r0, k0, R, Kend);
-        } else if (mode == RECNOW_OPMODE_NONE) {
-            if (!EDGE || fast) load_fast<false>(p, p2, mode, act, ld, r0, k0);
-            else load_safe<false>(p, p2, mode, act, ld, r0, k0, R, Kend);
-        } else {
-            if (!EDGE || fast) load_fast<true>(p, p2, mode, act, ld, r0, k0);
-            else load_safe<true>(p, p2, mode, act, ld, r0, k0, R, Kend);
-        }
-    }
-
-    __device__ __forceinline__ void store(float* __restrict__ S) const {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            int r, k;
-            coords(threadIdx.x + i * GEMM_THREADS, r, k);
-            if (!has(i)) continue;
-            if (KC) {
-                float* s = S + k * LD + r;
-                s[0] = v[i].x;
-                s[LD] = v[i].y;
-                s[2 * LD] = v[i].z;
-                s[3 * LD] = v[i].w;
-            } else {
-                *reinterpret_cast<float4*>(S + k * LD + r) = v[i];
-            }
-        }
-    }
-};
-
-__device__ __forceinline__ bool gemm_aligned(const void* p, int64_t ld, int64_t sb) {
-    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0) && (sb % 4 == 0);
-}
-
-// EDGE = false: every tile of the launch is in bounds and 16-byte aligned (checked on the host) -> no bounds code at
-// all (lean: no spills under the 256-register cap).  EDGE = true: general shapes, clamped loads and predicated stores.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, bool EDGE>
-__global__ void __launch_bounds__(GEMM_THREADS, 2)      // >= 2 waves/SIMD: VGPR+AGPR <= 256, two workgroups per CU
-k_gemm(const GemmK p) {
-    constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
-    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
-    using TA = Tile<BM, BK, A_KC>;
-    using TB = Tile<BN, BK, B_KC>;
-    constexpr int A_SZ = BK * TA::LD, B_SZ = BK * TB::LD;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const As = smem;                 // two buffers of A_SZ floats, then two of B_SZ
-    float* const Bs = smem + 2 * A_SZ;
-
-    const int z = blockIdx.z, bidx = z / p.splitk, ks = z % p.splitk;
-    const int k_begin = ks * p.kchunk;
-    const int k_end = min(p.K, k_begin + p.kchunk);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const float* Ab = p.A + (int64_t)bidx * p.sA;
-    const float* A2b = p.A2 ? p.A2 + (p.a_mode == RECNOW_OPMODE_OUTER ? 0 : (int64_t)bidx * p.sA) : nullptr;
-    const float* Bb = p.B + (int64_t)bidx * p.sB;
-    const float* B2b = p.B2 ? p.B2 + (p.b_mode == RECNOW_OPMODE_OUTER ? 0 : (int64_t)bidx * p.sB) : nullptr;
-    // block-uniform: rows of this tile all in bounds and every float4 16-byte aligned
-    const bool a_outer = p.a_mode == RECNOW_OPMODE_OUTER, b_outer = p.b_mode == RECNOW_OPMODE_OUTER;
-    const bool a_fast = !EDGE || ((m0 + BM <= p.M) && gemm_aligned(p.A, p.lda, p.sA) &&
-                                  (a_outer ? (p.a_hq % 4 == 0) : (!p.A2 || gemm_aligned(p.A2, p.lda, p.sA))));
-    const bool b_fast = !EDGE || ((n0 + BN <= p.N) && gemm_aligned(p.B, p.ldb, p.sB) &&
-                                  (b_outer ? (p.b_hq % 4 == 0) : (!p.B2 || gemm_aligned(p.B2, p.ldb, p.sB))));
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int a_off = (lane >> 5) * TA::LD + wm * TM * 32 + (lane & 31);
-    const int b_off = (lane >> 5) * TB::LD + wn * TN * 32 + (lane & 31);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    TA ta;
-    TB tb;
-    ta.init(p.lda);
-    tb.init(p.ldb);
-    const int ntile = (k_end - k_begin + BK - 1) / BK;
-    if (ntile > 0) {
-        const bool kf = !EDGE || (k_begin + BK <= k_end);
-        ta.template load<EDGE>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end, p.a_ld2, p.a_hq);
-        tb.template load<EDGE>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end, p.b_ld2, p.b_hq);
-        ta.store(As);
-        tb.store(Bs);
-    }
-    __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
-            const int k0 = k_begin + (t + 1) * BK;
-            const bool kf = !EDGE || (k0 + BK <= k_end);
-            ta.template load<EDGE>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
-            tb.template load<EDGE>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
-        }
-        const float* as = As + cur * A_SZ + a_off;
-        const float* bs = Bs + cur * B_SZ + b_off;
-        // ONE loop form for full and tail tiles (two forms make the compiler shuffle every accumulator between them):
-        // kv = valid k of this tile; rows beyond it are zero in LDS, so the (at most one) surplus k-step adds zeros.
-        const int kv = EDGE ? min(BK, k_end - (k_begin + t * BK)) : BK;
-        float a0[TM], b0[TN], a1[TM], b1[TN];      // explicit fragment double buffer: step kk+2 loads under step kk's MFMAs
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a0[i] = as[i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b0[j] = bs[j * 32];
-        // sched_barrier(0) pins "issue the NEXT step's ds_reads, then this step's MFMAs": without it hipcc sinks the
-        // reads below the MFMAs and waits lgkmcnt(0) right in front of their first use (seen in the .s).  An fp32
-        // 32x32x2 MFMA group is >= 256 cycles, far longer than the LDS latency, so nothing finer is needed.
-        for (int kk = 0; kk < kv; kk += 4) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            const int kn = min(kk + 4, BK - 2);     // stays inside this buffer on the last iteration (value unused then)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a0[i] = as[kn * TA::LD + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b0[j] = bs[kn * TB::LD + j * 32];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (t + 1 < ntile) {
-            ta.store(As + (cur ^ 1) * A_SZ);
-            tb.store(Bs + (cur ^ 1) * B_SZ);
-        }
-        __syncthreads();
-    }
-
-    // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-    if constexpr (!EDGE) {
-        // Lean epilogue: each 32x32 accumulator sub-tile goes through a wave-private LDS buffer (36-float rows) so that
-        // global traffic is float4 per lane (8 lanes = one 128-B row segment) with every epilogue operand of the
-        // sub-tile in flight at once -- 4 wide loads/stores instead of 16 + 16 dependent dword round trips.
-        float* stg = smem + wave * (32 * 36);          // the k-loop's last barrier has retired every As/Bs read
-        const int rr0 = lane >> 3, cc = (lane & 7) * 4;
-        float* Cb = p.splitk > 1 ? p.partial + ((int64_t)z * p.M) * p.N : p.C + (int64_t)bidx * p.sC;
-        const int64_t ldc = p.splitk > 1 ? p.N : p.ldc;
-        const bool plain = p.splitk > 1;
-        const float* biasb = (!plain && p.bias) ? p.bias + (int64_t)bidx * p.sBias : nullptr;
-        const float* Eb = (!plain && p.emul) ? p.emul + (int64_t)bidx * p.sE : nullptr;
-        const bool accum = !plain && p.accumulate;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row0 = m0 + wm * TM * 32 + i * 32, col0 = n0 + wn * TN * 32 + j * 32 + cc;
-                float4 ev[4], cv[4];
-                if (Eb) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const float4*>(Eb + (int64_t)(row0 + q * 8 + rr0) * p.lde + col0);
-                }
-                if (accum) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cv[q] = *reinterpret_cast<const float4*>(Cb + (int64_t)(row0 + q * 8 + rr0) * ldc + col0);
-                }
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (biasb) bv = *reinterpret_cast<const float4*>(biasb + col0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + row_l) * 36 + col_l] = acc[i][j][r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 a = *reinterpret_cast<const float4*>(stg + (q * 8 + rr0) * 36 + cc);
-                    float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
-                    if (!plain && p.act != RECNOW_ACT_LINEAR) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (col0 + e < p.act_cols) v[e] = rn_act(v[e], p.act);
-                    }
-                    if (Eb) {
-                        const float ee[4] = {ev[q].x, ev[q].y, ev[q].z, ev[q].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(ee[e], p.e_act) : ee[e];
-                    }
-                    if (accum) { v[0] += cv[q].x; v[1] += cv[q].y; v[2] += cv[q].z; v[3] += cv[q].w; }
-                    *reinterpret_cast<float4*>(Cb + (int64_t)(row0 + q * 8 + rr0) * ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        return;
-    } else {
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);          // block-uniform
-    if (p.splitk > 1) {
-        float* P = p.partial + ((int64_t)z * p.M) * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * TN * 32 + j * 32 + col_l;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-                    if (interior || (row < p.M && col < p.N)) P[(int64_t)row * p.N + col] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-    float* Cb = p.C + (int64_t)bidx * p.sC;
-    const float* biasb = p.bias ? p.bias + (int64_t)bidx * p.sBias : nullptr;
-    const float* Eb = p.emul ? p.emul + (int64_t)bidx * p.sE : nullptr;
-    const int64_t c_rs = p.c_trans ? 1 : p.ldc, c_cs = p.c_trans ? p.ldc : 1;     // C[row*c_rs + col*c_cs]
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * TN * 32 + j * 32 + col_l;
-            const int colc = min(col, p.N - 1);
-            const float bv = biasb ? biasb[colc] : 0.f;
-            const int rbase = m0 + wm * TM * 32 + i * 32 + row_l;
-            float e[16], cprev[16];
-            // operands of the epilogue are loaded unconditionally from clamped addresses, 16 at a time
-            if (Eb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-                    e[r] = Eb[(int64_t)row * p.lde + colc];
-                }
-            }
-            if (p.accumulate) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-                    cprev[r] = Cb[(int64_t)row * c_rs + (int64_t)colc * c_cs];
-                }
-            }
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
-            if (p.act != RECNOW_ACT_LINEAR && col < p.act_cols) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = rn_act(v[r], p.act);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (Eb) v[r] *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(e[r], p.e_act) : e[r];
-                if (p.accumulate) v[r] += cprev[r];
-                if (interior || (row < p.M && col < p.N)) Cb[(int64_t)row * c_rs + (int64_t)col * c_cs] = v[r];
-            }
-        }
-    }
-}
 
 // sum the split-K slabs in slice order (deterministic) and apply the epilogue
 __global__ void __launch_bounds__(256)
@@ -467,12 +56,12 @@ static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* 
     int s = 1;
     if (tiles < 256) {
         s = (int)(512 / tiles);
-        const int maxs = d->K / (8 * GEMM_BK);      // at least 8 k-tiles per slice
+        const int maxs = d->K / (8 * 32);      // at least 8 k-tiles per slice
         if (s > maxs) s = maxs;
         if (s < 1) s = 1;
     }
-    int kc = rn_cdiv(rn_cdiv(d->K, s), GEMM_BK) * GEMM_BK;
-    if (kc < GEMM_BK) kc = GEMM_BK;
+    int kc = rn_cdiv(rn_cdiv(d->K, s), 32) * 32;
+    if (kc < 32) kc = 32;
     s = rn_cdiv(d->K, kc);
     if (s < 1) s = 1;
     *splitk = s;
@@ -485,23 +74,6 @@ size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     int s, kc;
     pick_split(d, c, &s, &kc);
     return s > 1 ? rn_align((size_t)s * d->batch * d->M * d->N * sizeof(float)) : 0;
-}
-
-template <int BM, int BN, int WM, int WN, int BK>
-static int launch_cfg(const GemmK& k, bool a_kc, bool b_kc, bool edge, dim3 grid, hipStream_t st) {
-#define RN_GEMM_LAUNCH(AKC, BKC)                                                                                        \
-    do {                                                                                                                \
-        constexpr size_t lds = 2 * BK * (size_t)(Tile<BM, BK, AKC>::LD + Tile<BN, BK, BKC>::LD) * sizeof(float);        \
-        if (edge) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, true>), grid, GEMM_THREADS, lds, st, k);     \
-        else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, false>), grid, GEMM_THREADS, lds, st, k);         \
-    } while (0)
-    if (a_kc && b_kc) RN_GEMM_LAUNCH(true, true);
-    else if (a_kc && !b_kc) RN_GEMM_LAUNCH(true, false);
-    else if (!a_kc && b_kc) RN_GEMM_LAUNCH(false, true);
-    else RN_GEMM_LAUNCH(false, false);
-#undef RN_GEMM_LAUNCH
-    RN_LAUNCH_CHECK();
-    return RECNOW_OK;
 }
 
 static inline bool host_aligned(const void* p, int64_t ld, int64_t sb) {
@@ -561,12 +133,15 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     const bool short_k = d->K <= 256;
     const bool bk16 = short_k && c.BM == 128;
     const bool edge = !gemm_interior(d, c, bk16 ? 16 : 32, k.kchunk, k.splitk > 1);
-    if (c.BM == 256 && c.BN == 32) rc = launch_cfg<256, 32, 4, 1, 32>(k, a_kc, b_kc, edge, grid, st);
-    else if (c.BM == 256 && c.BN == 64) rc = launch_cfg<256, 64, 4, 1, 32>(k, a_kc, b_kc, edge, grid, st);
-    else if (c.BN == 160) rc = short_k ? launch_cfg<128, 160, 4, 1, 16>(k, a_kc, b_kc, edge, grid, st)
-                                      : launch_cfg<128, 160, 4, 1, 32>(k, a_kc, b_kc, edge, grid, st);
-    else rc = short_k ? launch_cfg<128, 128, 2, 2, 16>(k, a_kc, b_kc, edge, grid, st)
-                      : launch_cfg<128, 128, 2, 2, 32>(k, a_kc, b_kc, edge, grid, st);
+    // lean kernels exist for the two big tile families and the (layout, operand-kind) combos the layers use; anything
+    // else (and every edge shape) runs the general kernel of the same tile family.
+    rc = RECNOW_EUNSUPPORTED;
+    if (!edge && c.BM == 128) {
+        const int bk = bk16 ? 16 : 32;
+        rc = (c.BN == 160) ? rn_gemm_launch_lean160(k, a_kc, b_kc, bk, d->a_mode, d->b_mode, grid, st)
+                           : rn_gemm_launch_lean128(k, a_kc, b_kc, bk, d->a_mode, d->b_mode, grid, st);
+    }
+    if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_edge(k, c.BM, c.BN, a_kc, b_kc, grid, st);
     rn_prof_end(pr, st);
     if (rc) return rc;
     if (k.splitk > 1) {
