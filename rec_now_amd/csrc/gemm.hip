@@ -15,27 +15,54 @@
 #include "gemm_kernel.hpp"
 #include "prof.hpp"
 
-// sum the split-K slabs in slice order (deterministic) and apply the epilogue
+// sum the split-K slabs in slice order (deterministic) and apply the epilogue.  float4 per thread along N (the slabs
+// are [M][N] with N % 4 == 0 whenever VEC), four slabs in flight per thread.
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 k_gemm_splitk_reduce(const GemmK p) {
+    constexpr int W = VEC ? 4 : 1;
     const int64_t MN = (int64_t)p.M * p.N;
-    const int64_t total = MN * p.batch;
+    const int64_t total = MN * p.batch / W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)(i / MN);
-        const int64_t mn = i % MN;
+        const int64_t e0 = i * W;
+        const int b = (int)(e0 / MN);
+        const int64_t mn = e0 % MN;
         const int row = (int)(mn / p.N), col = (int)(mn % p.N);
         const float* P = p.partial + ((int64_t)b * p.splitk) * MN + mn;
-        float s = 0.f;
-        for (int k = 0; k < p.splitk; ++k) s += P[(int64_t)k * MN];
-        if (p.bias) s += p.bias[(int64_t)b * p.sBias + col];
-        if (col < p.act_cols) s = rn_act(s, p.act);
-        if (p.emul) {
-            const float e = p.emul[(int64_t)b * p.sE + (int64_t)row * p.lde + col];
-            s *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(e, p.e_act) : e;
+        float s[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) s[e] = 0.f;
+        int k = 0;
+        if (VEC) {
+            for (; k + 4 <= p.splitk; k += 4) {
+                const float4 a0 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 0) * MN);
+                const float4 a1 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 1) * MN);
+                const float4 a2 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 2) * MN);
+                const float4 a3 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 3) * MN);
+                s[0] = (((s[0] + a0.x) + a1.x) + a2.x) + a3.x;
+                s[1 % W] = (((s[1 % W] + a0.y) + a1.y) + a2.y) + a3.y;
+                s[2 % W] = (((s[2 % W] + a0.z) + a1.z) + a2.z) + a3.z;
+                s[3 % W] = (((s[3 % W] + a0.w) + a1.w) + a2.w) + a3.w;
+            }
         }
-        float* c = p.C + (int64_t)b * p.sC + (p.c_trans ? ((int64_t)col * p.ldc + row) : ((int64_t)row * p.ldc + col));
-        if (p.accumulate) s += *c;
-        *c = s;
+        for (; k < p.splitk; ++k) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) s[e] += P[(int64_t)k * MN + e];
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float v = s[e];
+            const int c = col + e;
+            if (p.bias) v += p.bias[(int64_t)b * p.sBias + c];
+            if (c < p.act_cols) v = rn_act(v, p.act);
+            if (p.emul) {
+                const float ev = p.emul[(int64_t)b * p.sE + (int64_t)row * p.lde + c];
+                v *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(ev, p.e_act) : ev;
+            }
+            float* dst = p.C + (int64_t)b * p.sC + (p.c_trans ? ((int64_t)c * p.ldc + row) : ((int64_t)row * p.ldc + c));
+            if (p.accumulate) v += *dst;
+            *dst = v;
+        }
     }
 }
 
@@ -55,7 +82,7 @@ static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* 
     const long long tiles = (long long)rn_cdiv(d->M, c.BM) * rn_cdiv(d->N, c.BN) * d->batch;
     int s = 1;
     if (tiles < 256) {
-        s = (int)(512 / tiles);
+        s = (int)(512 / tiles);          // 256 CUs x 2 resident workgroups
         const int maxs = d->K / (8 * 32);      // at least 8 k-tiles per slice
         if (s > maxs) s = maxs;
         if (s < 1) s = 1;
@@ -141,6 +168,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
         rc = (c.BN == 160) ? rn_gemm_launch_lean160(k, a_kc, b_kc, bk, d->a_mode, d->b_mode, grid, st)
                            : rn_gemm_launch_lean128(k, a_kc, b_kc, bk, d->a_mode, d->b_mode, grid, st);
     }
+    if (!edge && c.BM == 256 && c.BN == 64) rc = rn_gemm_launch_lean64(k, a_kc, b_kc, d->a_mode, d->b_mode, grid, st);
     if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_edge(k, c.BM, c.BN, a_kc, b_kc, grid, st);
     rn_prof_end(pr, st);
     if (rc) return rc;
@@ -148,7 +176,8 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
         const int64_t total = (int64_t)d->M * d->N * d->batch;
         int g = rn_cdiv(total, 256);
         if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(k_gemm_splitk_reduce, g, 256, 0, st, k);
+        if (d->N % 4 == 0) hipLaunchKernelGGL(k_gemm_splitk_reduce<true>, rn_cdiv(total / 4, 256) > 2048 ? 2048 : rn_cdiv(total / 4, 256), 256, 0, st, k);
+        else hipLaunchKernelGGL(k_gemm_splitk_reduce<false>, g, 256, 0, st, k);
         RN_LAUNCH_CHECK();
     }
     return RECNOW_OK;

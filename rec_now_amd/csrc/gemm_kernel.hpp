@@ -430,6 +430,7 @@ k_gemm(const GemmK p) {
 // launchers defined in gemm_inst_*.hip; each returns RECNOW_EUNSUPPORTED when it has no instantiation for the combo
 int rn_gemm_launch_lean128(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k, int b2k, dim3 grid, hipStream_t st);
 int rn_gemm_launch_lean160(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k, int b2k, dim3 grid, hipStream_t st);
+int rn_gemm_launch_lean64(const GemmK& k, bool a_kc, bool b_kc, int a2k, int b2k, dim3 grid, hipStream_t st);
 int rn_gemm_launch_edge(const GemmK& k, int bm, int bn, bool a_kc, bool b_kc, dim3 grid, hipStream_t st);
 
 template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BKC, bool EDGE, int A2K, int B2K>
