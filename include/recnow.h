@@ -208,6 +208,13 @@ typedef struct recnow_gemm_desc {
     int a_hq; int b_hq;               /* OUTER mode: inner width hq (A2/B2 hold the [row][col / hq] factor) */
     int64_t a_ld2; int64_t b_ld2;     /* OUTER mode: row stride of A2 / B2 */
     int c_trans;                      /* 1: store the result transposed, C[n][m] (ldc = row stride of that layout) */
+    /* Side product (lean 128x128 kernels, batch 1): sp_r <= 4 extra output columns computed on the VALU from the A tile
+     * in LDS:  sp_cx[m*sp_cx_ms + r*sp_cx_rs] = sum_k A'[m][k] * sp_bx[k*sp_bx_ks + r*sp_bx_rs]  (A' = A after its
+     * operand mode).  DCN-v2 uses it for the N gate columns so that N*S + N = 130 runs as exactly 128 MFMA columns. */
+    const float* sp_bx; float* sp_cx; int64_t sp_bx_ks, sp_bx_rs, sp_cx_ms, sp_cx_rs; int sp_r; int sp_pad;
+    /* Rank-R epilogue update (lean 128x128 kernels, batch 1): before bias-activation / emul,
+     *   v[m][n] += sum_{r < eu_r <= 4} eu_p[m*eu_pms + r] * eu_q[r*eu_qrs + n*eu_qns]  (K = 128 + 2 as exactly 128). */
+    const float* eu_p; const float* eu_q; int64_t eu_pms, eu_qrs, eu_qns; int eu_r; int eu_pad;
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;

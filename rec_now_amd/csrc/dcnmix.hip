@@ -43,6 +43,23 @@ __global__ void k_pack_w1(const float* __restrict__ U, const float* __restrict__
         Wc1[i] = v;
     }
 }
+// exact path: Wc1[d][n*S+s] = U[n][d][s]   (D x NS, no gate columns)
+__global__ void k_pack_u(const float* __restrict__ U, int D, int S, int N, float* __restrict__ Wc1) {
+    const int NS = N * S;
+    const int64_t total = (int64_t)D * NS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i / NS), c = (int)(i % NS);
+        Wc1[i] = U[((int64_t)(c / S) * D + d) * S + (c % S)];
+    }
+}
+__global__ void k_unpack_u(const float* __restrict__ dWc1, int D, int S, int N, float* __restrict__ dU) {
+    const int NS = N * S;
+    const int64_t total = (int64_t)D * NS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i / NS), c = (int)(i % NS);
+        dU[((int64_t)(c / S) * D + d) * S + (c % S)] = dWc1[i];
+    }
+}
 // dU[n][d][s] = dWc1[d][n*S+s];  dK[d][n] = dWc1[d][NS+n]
 __global__ void k_unpack_w1(const float* __restrict__ dWc1, int D, int S, int N, int LDT, float* __restrict__ dU, float* __restrict__ dK) {
     const int64_t total = (int64_t)D * (N * S + N);
@@ -110,10 +127,18 @@ k_dcnmix_gate_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, 
 struct MixDims {
     int64_t B;
     int D, S, N, L, NS, KC, LDT, KP;   // KC = NS + N; LDT/KP = padded width / depth
+    bool exact;                        // exact-128 formulation (side products + rank-N epilogue updates)
 };
+// Exact formulation: every D-sized product has exactly NS MFMA columns / NS-deep K; the N gate columns and the N
+// gate-weighted bias rows are VALU side products / rank-N epilogue updates of the lean 128x128 GEMM kernels.
+static inline bool mix_exact(int64_t B, int D, int S, int N) {
+    return (N * S) % 128 == 0 && D % 128 == 0 && B % 256 == 0 && N <= 4;
+}
 static inline MixDims mix_dims(int64_t B, int D, int S, int N, int L) {
     MixDims m;
     m.B = B; m.D = D; m.S = S; m.N = N; m.L = L; m.NS = N * S; m.KC = N * S + N; m.LDT = ldt_of(S, N); m.KP = kp_of(S, N);
+    m.exact = mix_exact(B, D, S, N);
+    if (m.exact) m.LDT = m.KP;      // [NS main | N gate | zero pad to a multiple of 16]: N = NS products + side product, K = KP products
     return m;
 }
 static inline size_t act_block(const MixDims& m) { return rn_align((size_t)m.B * m.LDT * sizeof(float)); }
@@ -133,6 +158,11 @@ static size_t mix_gemm_ws(const MixDims& m) {
                               {m.S, m.S, (int)m.B}, {(int)m.B, m.S, m.S}};
     for (int i = 0; i < 6; ++i) {
         d.M = shapes[i][0]; d.N = shapes[i][1]; d.K = shapes[i][2]; d.batch = (i >= 4) ? m.N : 1;
+        const size_t s = rn_gemm_ws_bytes(&d);
+        if (s > best) best = s;
+    }
+    if (m.exact) {           // exact-path split-K products carry 4 side columns per slab row
+        d.M = m.D; d.N = m.NS; d.K = (int)m.B; d.batch = 1; d.sp_r = m.N;
         const size_t s = rn_gemm_ws_bytes(&d);
         if (s > best) best = s;
     }
@@ -203,6 +233,42 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
         float* T2 = (float*)(sv + (size_t)(3 * l + 1) * act_block(m));
         float* T2g = (float*)(sv + (size_t)(3 * l + 2) * act_block(m));
         float* out = (l == L - 1) ? y : xmid + (size_t)l * (xbuf(m) / sizeof(float));
+        if (m.exact) {
+            if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
+            {   // GEMM1: T1[:, :NS] = act_inner(x_l U);  gate logits T1[:, NS:NS+N] = x_l K as the VALU side product
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = xl; d.lda = D; d.a_trans = 0;
+                d.B = Wc1; d.ldb = m.LDT; d.b_trans = 0;
+                d.C = T1; d.ldc = m.LDT;
+                d.M = (int)B; d.N = m.NS; d.K = D;
+                d.act = act_inner;
+                d.sp_bx = gate_host[l]; d.sp_bx_ks = N; d.sp_bx_rs = 1; d.sp_cx = T1 + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            }
+            {   // GEMM2: H2_n = act_outer(H1_n V_n)
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
+                d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 0;
+                d.C = T2; d.ldc = m.LDT; d.c_batch_stride = S;
+                d.M = (int)B; d.N = S; d.K = S; d.batch = N;
+                d.act = act_outer;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            }
+            hipLaunchKernelGGL(k_dcnmix_gate_fwd, gate_grid(B), 256, 0, st, T1, T2, T2g, B, S, N, m.LDT);
+            RN_LAUNCH_CHECK();
+            {   // GEMM3: out = x * ([G*H2 | G | 0] [W; b; 0]): K zero-padded NS+N -> KP (a 16-deep k-tile more is cheaper
+                // than a rank-N epilogue update: 215 vs 233 us measured)
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
+                d.B = Wc2; d.ldb = D; d.b_trans = 0;
+                d.C = out; d.ldc = D;
+                d.M = (int)B; d.N = D; d.K = m.KP;
+                d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            }
+            xl = out;
+            continue;
+        }
         if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
         {   // GEMM1: T1 = [act_inner(x_l U) | x_l K]
             recnow_gemm_desc d = rn_gemm_desc_zero();
@@ -285,6 +351,81 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
         const float* T2g = (const float*)(sv + (size_t)(3 * l + 2) * act_block(m));
         const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));
         float* gprev = (l == 0) ? nullptr : ((l & 1) ? gbuf0 : gbuf1);
+        if (m.exact) {
+            int pg = rn_cdiv((int64_t)D * m.NS, 256);
+            if (pg > 2048) pg = 2048;
+            if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
+            {   // dT2g[:, :NS] = (x*g) W^T;  gate columns dT2g[:, NS+n] = (x*g) . bias_n as the side product
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 0;
+                d.B = W_host[l]; d.ldb = D; d.b_trans = 1;
+                d.C = dT2g; d.ldc = m.LDT;
+                d.M = (int)B; d.N = m.NS; d.K = D;
+                d.sp_bx = bias_host[l]; d.sp_bx_ks = 1; d.sp_bx_rs = D; d.sp_cx = dT2g + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            }
+            {   // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 1;
+                d.B = T2g; d.ldb = m.LDT; d.b_trans = 0;
+                d.C = dW_host[l]; d.ldc = D; d.c_trans = 1;
+                d.M = D; d.N = m.NS; d.K = (int)B;
+                d.sp_bx = T2g + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            }
+            {   // dx (+)= g * O,  O = [G*H2 | G | 0] [W; b; 0] recomputed
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
+                d.B = Wc2; d.ldb = D; d.b_trans = 0;
+                d.C = dx; d.ldc = D;
+                d.M = (int)B; d.N = D; d.K = m.KP;
+                d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
+                d.accumulate = dx_started ? 1 : 0;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+                dx_started = true;
+            }
+            hipLaunchKernelGGL(k_dcnmix_gate_bwd, gate_grid(B), 256, 0, st, dT2g, T2, dC, dT1, B, S, N, m.LDT, act_outer);
+            RN_LAUNCH_CHECK();
+            {   // dV_n = H1_n^T dC_n
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 1;
+                d.B = dC; d.ldb = m.LDT; d.b_batch_stride = S; d.b_trans = 0;
+                d.C = dV_host[l]; d.ldc = S; d.c_batch_stride = (int64_t)S * S;
+                d.M = S; d.N = S; d.K = (int)B; d.batch = N;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            }
+            {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n)
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = dC; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
+                d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 1;
+                d.C = dT1; d.ldc = m.LDT; d.c_batch_stride = S;
+                d.M = (int)B; d.N = S; d.K = S; d.batch = N;
+                d.emul = T1; d.lde = m.LDT; d.e_batch_stride = S; d.e_mode = RECNOW_OPMODE_ACTGRAD; d.e_act = act_inner;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            }
+            {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = xl; d.lda = D; d.a_trans = 1;
+                d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
+                d.C = dWc1; d.ldc = m.NS;
+                d.M = D; d.N = m.NS; d.K = (int)B;
+                d.sp_bx = dT1 + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dgate_host[l]; d.sp_cx_ms = N; d.sp_cx_rs = 1; d.sp_r = N;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+                hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st, dWc1, D, S, N, dU_host[l]);
+                RN_LAUNCH_CHECK();
+            }
+            {   // gradient w.r.t. x_l: [dA | dlogits | 0] [U | K | 0]^T  (K zero-padded to KP)
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
+                d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
+                d.C = (l == 0) ? dx : gprev; d.ldc = D;
+                d.M = (int)B; d.N = D; d.K = m.KP;
+                d.accumulate = (l == 0) ? 1 : 0;
+                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+            }
+            g = gprev;
+            continue;
+        }
         if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
         {   // dT2g = (x * g) Wc2^T
             recnow_gemm_desc d = rn_gemm_desc_zero();

@@ -21,13 +21,13 @@ template <bool VEC>
 __global__ void __launch_bounds__(256)
 k_gemm_splitk_reduce(const GemmK p) {
     constexpr int W = VEC ? 4 : 1;
-    const int64_t MN = (int64_t)p.M * p.N;
+    const int64_t MN = (int64_t)p.M * p.npart;          // one slab
     const int64_t total = MN * p.batch / W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e0 = i * W;
         const int b = (int)(e0 / MN);
         const int64_t mn = e0 % MN;
-        const int row = (int)(mn / p.N), col = (int)(mn % p.N);
+        const int row = (int)(mn / p.npart), col = (int)(mn % p.npart);
         const float* P = p.partial + ((int64_t)b * p.splitk) * MN + mn;
         float s[W];
 #pragma unroll
@@ -53,6 +53,10 @@ k_gemm_splitk_reduce(const GemmK p) {
         for (int e = 0; e < W; ++e) {
             float v = s[e];
             const int c = col + e;
+            if (c >= p.N) {                      // side-product columns ride behind the N main columns of a slab row
+                if (c - p.N < p.sp_r) p.cx[(int64_t)row * p.cx_ms + (int64_t)(c - p.N) * p.cx_rs] = v;
+                continue;
+            }
             if (p.bias) v += p.bias[(int64_t)b * p.sBias + c];
             if (c < p.act_cols) v = rn_act(v, p.act);
             if (p.emul) {
@@ -100,7 +104,7 @@ size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     const GemmCfg c = pick_cfg(d->N);
     int s, kc;
     pick_split(d, c, &s, &kc);
-    return s > 1 ? rn_align((size_t)s * d->batch * d->M * d->N * sizeof(float)) : 0;
+    return s > 1 ? rn_align((size_t)s * d->batch * d->M * (d->N + (d->sp_r > 0 ? 4 : 0)) * sizeof(float)) : 0;
 }
 
 static inline bool host_aligned(const void* p, int64_t ld, int64_t sb) {
@@ -116,7 +120,7 @@ static bool gemm_interior(const recnow_gemm_desc* d, const GemmCfg& c, int bk, i
     else if (d->b_mode != RECNOW_OPMODE_NONE && !host_aligned(d->B2, d->ldb, d->b_batch_stride)) return false;
     // the lean epilogue is float4 along the columns of C (the split-K slabs always qualify: N is a tile multiple)
     if (!split) {
-        if (d->c_trans || !host_aligned(d->C, d->ldc, d->c_batch_stride)) return false;
+        if (!d->c_trans && !host_aligned(d->C, d->ldc, d->c_batch_stride)) return false;
         if (d->emul && !host_aligned(d->emul, d->lde, d->e_batch_stride)) return false;
         if (d->bias && !host_aligned(d->bias, 4, d->bias_batch_stride)) return false;
     }
@@ -141,9 +145,16 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     k.act = d->act; k.act_cols = d->act_cols > 0 ? d->act_cols : d->N; k.e_mode = d->e_mode; k.e_act = d->e_act;
     k.accumulate = d->accumulate; k.c_trans = d->c_trans;
     k.a_hq = d->a_hq > 0 ? d->a_hq : 1; k.b_hq = d->b_hq > 0 ? d->b_hq : 1; k.a_ld2 = d->a_ld2; k.b_ld2 = d->b_ld2;
+    k.bx = d->sp_bx; k.cx = d->sp_cx; k.bx_ks = d->sp_bx_ks; k.bx_rs = d->sp_bx_rs; k.cx_ms = d->sp_cx_ms; k.cx_rs = d->sp_cx_rs;
+    k.sp_r = d->sp_r;
+    k.eu_p = d->eu_p; k.eu_q = d->eu_q; k.eu_pms = d->eu_pms; k.eu_qrs = d->eu_qrs; k.eu_qns = d->eu_qns; k.eu_r = d->eu_r;
+    k.npart = d->N + (d->sp_r > 0 ? 4 : 0);
+    if (d->sp_r < 0 || d->sp_r > 4 || d->eu_r < 0 || d->eu_r > 4 || (d->sp_r > 0 && d->eu_r > 0)) return RECNOW_EINVAL;
+    if (d->sp_r > 0 && (!d->sp_bx || !d->sp_cx || d->batch != 1)) return RECNOW_EINVAL;
+    if (d->eu_r > 0 && (!d->eu_p || !d->eu_q || d->batch != 1)) return RECNOW_EINVAL;
     pick_split(d, c, &k.splitk, &k.kchunk);
     if (k.splitk > 1) {
-        const size_t need = rn_align((size_t)k.splitk * d->batch * d->M * d->N * sizeof(float));
+        const size_t need = rn_align((size_t)k.splitk * d->batch * d->M * k.npart * sizeof(float));
         if (!ws || ws_bytes < need) return RECNOW_EWORKSPACE;
         k.partial = (float*)ws;
     }
@@ -163,7 +174,12 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     // lean kernels exist for the two big tile families and the (layout, operand-kind) combos the layers use; anything
     // else (and every edge shape) runs the general kernel of the same tile family.
     rc = RECNOW_EUNSUPPORTED;
-    if (!edge && c.BM == 128) {
+    const int xf = (d->sp_r > 0 ? 1 : 0) | (d->eu_r > 0 ? 2 : 0);
+    if (xf) {        // side product / rank-R update exist only in the lean 128x128 kernels: the caller guarantees the shape
+        if (edge || c.BM != 128 || c.BN != 128) return RECNOW_EUNSUPPORTED;
+        rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
+        if (rc) return rc;
+    } else if (!edge && c.BM == 128) {
         const int bk = bk16 ? 16 : 32;
         rc = (c.BN == 160) ? rn_gemm_launch_lean160(k, a_kc, b_kc, bk, d->a_mode, d->b_mode, grid, st)
                            : rn_gemm_launch_lean128(k, a_kc, b_kc, bk, d->a_mode, d->b_mode, grid, st);
@@ -173,7 +189,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     rn_prof_end(pr, st);
     if (rc) return rc;
     if (k.splitk > 1) {
-        const int64_t total = (int64_t)d->M * d->N * d->batch;
+        const int64_t total = (int64_t)d->M * k.npart * d->batch;
         int g = rn_cdiv(total, 256);
         if (g > 2048) g = 2048;
         if (d->N % 4 == 0) hipLaunchKernelGGL(k_gemm_splitk_reduce<true>, rn_cdiv(total / 4, 256) > 2048 ? 2048 : rn_cdiv(total / 4, 256), 256, 0, st, k);

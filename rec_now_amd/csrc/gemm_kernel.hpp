@@ -20,6 +20,18 @@ struct GemmK {
     int a_mode, a_act, b_mode, b_act, act, act_cols, e_mode, e_act, accumulate, c_trans, splitk, kchunk;
     int a_hq, b_hq;            // OUTER mode: operand(row, col) = second[row][col / hq] * first[row][col % hq]
     int64_t a_ld2, b_ld2;      // row stride of `second` in OUTER mode
+    // XF & 1 -- side product: Cx[m][r] = sum_k A'[m][k] * Bx[k][r] for r < sp_r <= 4, computed on the VALU from the A tile
+    // that is already in LDS (A' = A after its operand transform).  Lets a product with N = 128 + 2 run as exactly 128
+    // MFMA columns instead of a 160-wide tile.
+    const float* bx;
+    float* cx;
+    int64_t bx_ks, bx_rs, cx_ms, cx_rs;
+    int sp_r;
+    // XF & 2 -- rank-R epilogue update: v[m][n] += sum_r P[m][r] * Q[r][n] before activation / emul (K = 128 + 2 as 128)
+    const float *eu_p, *eu_q;
+    int64_t eu_pms, eu_qrs, eu_qns;
+    int eu_r;
+    int npart;                 // row width of a split-K slab: N, or N + 4 when a side product rides along
 };
 
 __device__ __forceinline__ f32x4 mk4(float a, float b, float c, float d) {
@@ -202,9 +214,10 @@ __device__ __forceinline__ bool gemm_aligned(const void* p, int64_t ld, int64_t 
 
 // EDGE = false: every tile of the launch is in bounds and 16-byte aligned (checked on the host) -> no bounds code at
 // all (lean: no spills under the 256-register cap).  EDGE = true: general shapes, clamped loads and predicated stores.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, bool EDGE, int A2K, int B2K>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, bool EDGE, int A2K, int B2K, int XF = 0>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)      // >= 2 waves/SIMD: VGPR+AGPR <= 256, two workgroups per CU
 k_gemm(const GemmK p) {
+    static_assert(XF == 0 || (!EDGE && BM == 128), "side product / rank-R update: lean 128-row kernels only");
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
     using TA = Tile<BM, BK, A_KC>;
@@ -213,6 +226,10 @@ k_gemm(const GemmK p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                 // two buffers of A_SZ floats, then two of B_SZ
     float* const Bs = smem + 2 * A_SZ;
+    float* const Bxs = smem + 2 * A_SZ + 2 * B_SZ;     // XF & 1: two buffers of BK x 4 side-product weights
+    const bool sp_on = (XF & 1) && blockIdx.y == 0;    // one column-tile computes the side product of a row-tile
+    f32x4 spacc = mk4(0.f, 0.f, 0.f, 0.f);
+    float bxr[4] = {0.f, 0.f, 0.f, 0.f};
 
     const int z = blockIdx.z, bidx = z / p.splitk, ks = z % p.splitk;
     const int k_begin = ks * p.kchunk;
@@ -253,6 +270,12 @@ k_gemm(const GemmK p) {
         tb.template load<EDGE, B2K>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end, p.b_ld2, p.b_hq);
         ta.store(As);
         tb.store(Bs);
+        if ((XF & 1) && threadIdx.x < BK) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                bxr[r] = r < p.sp_r ? p.bx[(int64_t)(k_begin + threadIdx.x) * p.bx_ks + r * p.bx_rs] : 0.f;
+            *reinterpret_cast<f32x4*>(Bxs + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
+        }
     }
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
@@ -263,6 +286,15 @@ k_gemm(const GemmK p) {
             ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
             tb.template load<EDGE, B2K>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
         }
+        if ((XF & 1) && t + 1 < ntile && threadIdx.x < BK) {
+            const int kx = k_begin + (t + 1) * BK + threadIdx.x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bxr[r] = r < p.sp_r ? p.bx[(int64_t)kx * p.bx_ks + r * p.bx_rs] : 0.f;
+        }
+        // VALU side product off the A tile in LDS: thread = (row m, half of the tile's k range); its 2*(BK/4) k's are
+        // spread over the MFMA loop below (2 per iteration) so the FMAs run in the shadow of in-flight MFMAs.
+        const float* asx = As + cur * A_SZ + (threadIdx.x & 127) + (threadIdx.x >> 7) * (BK / 2) * TA::LD;
+        const float* bxs = Bxs + cur * BK * 4 + (threadIdx.x >> 7) * (BK / 2) * 4;
         const float* as = As + cur * A_SZ + a_off;
         const float* bs = Bs + cur * B_SZ + b_off;
         // ONE loop form for full and tail tiles (two forms make the compiler shuffle every accumulator between them):
@@ -281,6 +313,11 @@ k_gemm(const GemmK p) {
             for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
+            if constexpr ((XF & 1) != 0) {
+                const int kq = kk >> 1;        // this iteration's two k's of the thread's half-range
+                spacc += asx[kq * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + kq * 4);
+                spacc += asx[(kq + 1) * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + (kq + 1) * 4);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -302,6 +339,23 @@ k_gemm(const GemmK p) {
         if (t + 1 < ntile) {
             ta.store(As + (cur ^ 1) * A_SZ);
             tb.store(Bs + (cur ^ 1) * B_SZ);
+            if ((XF & 1) && threadIdx.x < BK)
+                *reinterpret_cast<f32x4*>(Bxs + (cur ^ 1) * BK * 4 + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
+        }
+        __syncthreads();
+    }
+    if constexpr ((XF & 1) != 0) {
+        // combine the two k-halves through LDS (free now) and write the side columns
+        if (sp_on && threadIdx.x >= 128) *reinterpret_cast<f32x4*>(smem + (threadIdx.x - 128) * 4) = spacc;
+        __syncthreads();
+        if (sp_on && threadIdx.x < 128) {
+            const f32x4 o = spacc + *reinterpret_cast<const f32x4*>(smem + threadIdx.x * 4);
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+            const int m = m0 + threadIdx.x;
+            for (int r = 0; r < p.sp_r; ++r) {
+                if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = ov[r];
+                else p.cx[(int64_t)m * p.cx_ms + r * p.cx_rs] = ov[r];
+            }
         }
         __syncthreads();
     }
@@ -314,14 +368,36 @@ k_gemm(const GemmK p) {
         // sub-tile in flight at once -- 4 wide loads/stores instead of 16 + 16 dependent dword round trips.
         float* stg = smem + wave * (32 * 36);          // the k-loop's last barrier has retired every As/Bs read
         const int rr0 = lane >> 3, cc = (lane & 7) * 4;
-        float* Cb = p.splitk > 1 ? p.partial + ((int64_t)z * p.M) * p.N : p.C + (int64_t)bidx * p.sC;
-        const int64_t ldc = p.splitk > 1 ? p.N : p.ldc;
+        float* Cb = p.splitk > 1 ? p.partial + ((int64_t)z * p.M) * p.npart : p.C + (int64_t)bidx * p.sC;
+        const int64_t ldc = p.splitk > 1 ? p.npart : p.ldc;
         const bool plain = p.splitk > 1;
         const float* biasb = (!plain && p.bias) ? p.bias + (int64_t)bidx * p.sBias : nullptr;
         const float* Eb = (!plain && p.emul) ? p.emul + (int64_t)bidx * p.sE : nullptr;
         const bool accum = !plain && p.accumulate;
+        // rank-R update operands: Q[r][col] depends only on the column sub-tile j, P[row][r] only on the row sub-tile i.
+        // Loads are unconditional (r clamped to the last valid one, its weight zeroed): no per-load branches.
+        float euq[TN][4][4], eup[4][4];
+        if ((XF & 2) && !plain) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rc = min(r, p.eu_r - 1);
+                    const float on = r < p.eu_r ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        euq[j][r][e] = on * p.eu_q[(int64_t)rc * p.eu_qrs + (int64_t)(n0 + wn * TN * 32 + j * 32 + cc + e) * p.eu_qns];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if ((XF & 2) && !plain) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        eup[q][r] = p.eu_p[(int64_t)(m0 + wm * TM * 32 + i * 32 + q * 8 + rr0) * p.eu_pms + min(r, p.eu_r - 1)];
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row0 = m0 + wm * TM * 32 + i * 32, col0 = n0 + wn * TN * 32 + j * 32 + cc;
@@ -330,9 +406,15 @@ k_gemm(const GemmK p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const float4*>(Eb + (int64_t)(row0 + q * 8 + rr0) * p.lde + col0);
                 }
+                const bool ctr = !plain && p.c_trans;      // transposed store C[n][m]: scalar accesses (block-uniform, rare)
                 if (accum) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cv[q] = *reinterpret_cast<const float4*>(Cb + (int64_t)(row0 + q * 8 + rr0) * ldc + col0);
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t rw = row0 + q * 8 + rr0;
+                        if (!ctr) cv[q] = *reinterpret_cast<const float4*>(Cb + rw * ldc + col0);
+                        else cv[q] = make_float4(Cb[(int64_t)col0 * ldc + rw], Cb[(int64_t)(col0 + 1) * ldc + rw],
+                                                 Cb[(int64_t)(col0 + 2) * ldc + rw], Cb[(int64_t)(col0 + 3) * ldc + rw]);
+                    }
                 }
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (biasb) bv = *reinterpret_cast<const float4*>(biasb + col0);
@@ -345,6 +427,12 @@ k_gemm(const GemmK p) {
                 for (int q = 0; q < 4; ++q) {
                     float4 a = *reinterpret_cast<const float4*>(stg + (q * 8 + rr0) * 36 + cc);
                     float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+                    if ((XF & 2) && !plain) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += eup[q][r] * euq[j][r][e];
+                    }
                     if (!plain && p.act != RECNOW_ACT_LINEAR) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -357,11 +445,17 @@ k_gemm(const GemmK p) {
                             v[e] *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(ee[e], p.e_act) : ee[e];
                     }
                     if (accum) { v[0] += cv[q].x; v[1] += cv[q].y; v[2] += cv[q].z; v[3] += cv[q].w; }
-                    *reinterpret_cast<float4*>(Cb + (int64_t)(row0 + q * 8 + rr0) * ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+                    const int64_t rw = row0 + q * 8 + rr0;
+                    if (!ctr) *reinterpret_cast<float4*>(Cb + rw * ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Cb[(int64_t)(col0 + e) * ldc + rw] = v[e];
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+        }
         return;
     } else {
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);          // block-uniform
@@ -433,8 +527,9 @@ int rn_gemm_launch_lean160(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k
 int rn_gemm_launch_lean64(const GemmK& k, bool a_kc, bool b_kc, int a2k, int b2k, dim3 grid, hipStream_t st);
 int rn_gemm_launch_edge(const GemmK& k, int bm, int bn, bool a_kc, bool b_kc, dim3 grid, hipStream_t st);
 
-template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BKC, bool EDGE, int A2K, int B2K>
+template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BKC, bool EDGE, int A2K, int B2K, int XF = 0>
 static inline void rn_gemm_launch_one(const GemmK& k, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = 2 * BK * (size_t)(Tile<BM, BK, AKC>::LD + Tile<BN, BK, BKC>::LD) * sizeof(float);
-    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, EDGE, A2K, B2K>), grid, GEMM_THREADS, lds, st, k);
+    constexpr size_t lds = (2 * BK * (size_t)(Tile<BM, BK, AKC>::LD + Tile<BN, BK, BKC>::LD) + ((XF & 1) ? 2 * BK * 4 : 0)) * sizeof(float);
+    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, EDGE, A2K, B2K, XF>), grid, GEMM_THREADS, lds, st, k);
 }
+int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k, int b2k, int xf, dim3 grid, hipStream_t st);

@@ -371,3 +371,52 @@ def test_cin_fwd_bwd_vs_oracle(dev, B, F, D, Hs, oi, sc, as_list):
         close(a.grad, b.grad)
     for k in range(1, len(ext)):
         close(layer.idx2weight[k].grad, w64[k - 1].grad)
+
+
+# ---- GEMM side product / rank-R epilogue update (the exact-128 formulation of DCN-v2) ------------------------------------
+@pytest.mark.parametrize('ta,splitk_shape', [(0, False), (1, True)])
+def test_gemm_side_product_and_rank_update(dev, ta, splitk_shape):
+    from rec_now_amd import _lib
+    rng = np.random.default_rng(17 + ta)
+    M, N, K = (256, 128, 8192) if splitk_shape else (512, 128, 256)
+    A = rng.uniform(-1, 1, (K, M) if ta else (M, K)).astype(np.float32)
+    Bm = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    Bx = rng.uniform(-1, 1, (K, 2)).astype(np.float32)
+    Ad, Bd, Bxd = (torch.from_numpy(v).to(dev) for v in (A, Bm, Bx))
+    C = torch.empty((M, N), device=dev)
+    Cx = torch.full((M, 2), 7.0, device=dev)
+    lib = _lib.load()
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.a_trans = Ad.data_ptr(), A.shape[1], ta
+    d.B, d.ldb = Bd.data_ptr(), N
+    d.C, d.ldc = C.data_ptr(), N
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    d.sp_bx, d.sp_cx, d.sp_bx_ks, d.sp_bx_rs, d.sp_cx_ms, d.sp_cx_rs, d.sp_r = Bxd.data_ptr(), Cx.data_ptr(), 2, 1, 2, 1, 2
+    ws = _lib.workspace(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)), dev)
+    _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.stream())
+    A64 = A.astype(np.float64).T if ta else A.astype(np.float64)
+    bound = 3e-7 * K
+    assert np.abs(C.cpu().numpy() - A64 @ Bm.astype(np.float64)).max() <= bound
+    assert np.abs(Cx.cpu().numpy() - A64 @ Bx.astype(np.float64)).max() <= bound
+    if not ta:
+        # rank-2 epilogue update: C = (A B + P Q) * E
+        P = rng.uniform(-1, 1, (M, 2)).astype(np.float32)
+        Q = rng.uniform(-1, 1, (2, N)).astype(np.float32)
+        E = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        Pd, Qd, Ed = (torch.from_numpy(v).to(dev) for v in (P, Q, E))
+        d2 = _lib.GemmDesc()
+        d2.A, d2.lda = Ad.data_ptr(), K
+        d2.B, d2.ldb = Bd.data_ptr(), N
+        d2.C, d2.ldc = C.data_ptr(), N
+        d2.M, d2.N, d2.K, d2.batch = M, N, K, 1
+        d2.emul, d2.lde, d2.e_mode = Ed.data_ptr(), N, 1
+        d2.eu_p, d2.eu_q, d2.eu_pms, d2.eu_qrs, d2.eu_qns, d2.eu_r = Pd.data_ptr(), Qd.data_ptr(), 2, N, 1, 2
+        _lib.call('recnow_gemm', ctypes.byref(d2), _lib.ptr(ws), ws.numel(), _lib.stream())
+        ref = (A64 @ Bm.astype(np.float64) + P.astype(np.float64) @ Q.astype(np.float64)) * E
+        assert np.abs(C.cpu().numpy() - ref).max() <= bound
+
+
+@pytest.mark.parametrize('B,D,S,N,L', [(512, 256, 64, 2, 2), (256, 128, 32, 4, 1)])
+def test_dcn_mix_exact128_path_vs_oracle(dev, B, D, S, N, L):
+    """Shapes with N*S, D multiples of 128 and B a multiple of 256 take the side-product formulation (dcnmix.hip)."""
+    test_dcn_mix_fwd_bwd_vs_oracle(dev, B, D, S, N, L, 'tanh', 'tanh')

@@ -29,12 +29,25 @@ SHAPES = [
     ('pad dxl    (B,144)x(144,D)', B, D, 144, 0, 1, 160, 160, D, 0, 0, 0),
     ('pad dWc1   (D,B)x(B,160)', D, 160, B, 1, 0, D, 160, 160, 0, 0, 0),
     ('pad dWc2^T (D,B)x(B,160) A*A2', D, 160, B, 1, 0, D, 160, D, 1, 0, 1),
+    # exact-128 versions (no side product here: pure MFMA part)
+    ('x128 GEMM1  (B,D)x(D,128)', B, 128, D, 0, 0, D, 128, 132, 0, 0, 0),
+    ('x128 GEMM3  (B,128)x(128,D)', B, D, 128, 0, 0, 132, D, D, 0, 1, 0),
+    ('x128 dT2g   (B,D)x(D,128) A*A2', B, 128, D, 0, 1, D, D, 132, 1, 0, 0),
+    ('x128 dxl    (B,128)x(128,D)', B, D, 128, 0, 1, 132, 128, D, 0, 0, 0),
+    ('x128 dU     (D,B)x(B,128)', D, 128, B, 1, 0, D, 132, 128, 0, 0, 0),
+    ('x128 dW^T   (D,B)x(B,128) A*A2', D, 128, B, 1, 0, D, 132, D, 1, 0, 1),
+    ('x128+SP GEMM1', B, 128, D, 0, 0, D, 128, 132, 0, 0, 0, 1),
+    ('x128+EU GEMM3', B, D, 128, 0, 0, 132, D, D, 0, 1, 0, 2),
+    ('x128+SP dT2g', B, 128, D, 0, 1, D, D, 132, 1, 0, 0, 1),
+    ('x128+EU dxl', B, D, 128, 0, 1, 132, 128, D, 0, 0, 0, 2),
+    ('x128+SP dU', D, 128, B, 1, 0, D, 132, 128, 0, 0, 0, 1),
+    ('x128+SP dW^T', D, 128, B, 1, 0, D, 132, D, 1, 0, 1, 1),
     ('square 4096^3 NN', 4096, 4096, 4096, 0, 0, 4096, 4096, 4096, 0, 0, 0),
     ('square 4096^3 NT', 4096, 4096, 4096, 0, 1, 4096, 4096, 4096, 0, 0, 0),
 ]
 
 
-def run(name, M, N, K, ta, tb, lda, ldb, ldc, a_mode, emul, c_trans):
+def run(name, M, N, K, ta, tb, lda, ldb, ldc, a_mode, emul, c_trans, xf=0):
     rows_a = K if ta else M
     rows_b = N if tb else K
     A = torch.randn(rows_a, lda, device=dev) * 0.1
@@ -51,6 +64,12 @@ def run(name, M, N, K, ta, tb, lda, ldb, ldc, a_mode, emul, c_trans):
     d.M, d.N, d.K, d.batch = M, N, K, 1
     if emul:
         d.emul, d.lde, d.e_mode = E.data_ptr(), N, 1
+    if xf == 1:
+        BX = torch.randn(K, 2, device=dev); CX = torch.empty(M, 2, device=dev)
+        d.sp_bx, d.sp_cx, d.sp_bx_ks, d.sp_bx_rs, d.sp_cx_ms, d.sp_cx_rs, d.sp_r = BX.data_ptr(), CX.data_ptr(), 2, 1, 2, 1, 2
+    if xf == 2:
+        PP = torch.randn(M, 2, device=dev); QQ = torch.randn(2, N, device=dev)
+        d.eu_p, d.eu_q, d.eu_pms, d.eu_qrs, d.eu_qns, d.eu_r = PP.data_ptr(), QQ.data_ptr(), 2, N, 1, 2
     ws = _lib.workspace(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)), dev)
     st = _lib.stream()
     for _ in range(2):
