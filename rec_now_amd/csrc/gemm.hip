@@ -227,6 +227,25 @@ k_colsum_final(const float* __restrict__ part, int nslab, int64_t N, float* __re
     out[col] = accumulate ? out[col] + s : s;
 }
 
+// narrow matrices (N < 64): one workgroup column-strip per (column, row-chunk), all 256 threads walk the rows
+#define CS_NARROW_ROWS 8192
+__global__ void __launch_bounds__(256)
+k_colsum_narrow(const float* __restrict__ X, const float* __restrict__ X2, int mode, int act, int64_t M, int64_t N, int64_t ld,
+                float* __restrict__ part) {
+    __shared__ float red[16];
+    const int64_t col = blockIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_NARROW_ROWS, r1 = min(M, r0 + CS_NARROW_ROWS);
+    float s = 0.f;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        float v = X[r * ld + col];
+        if (mode == RECNOW_OPMODE_MUL) v *= X2[r * ld + col];
+        else if (mode == RECNOW_OPMODE_ACTGRAD) v *= rn_act_grad_from_out(X2[r * ld + col], act);
+        s += v;
+    }
+    s = block_sum<float>(s, red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * N + col] = s;
+}
+
 size_t rn_colsum_ws_bytes(int64_t M, int64_t N) {
     return rn_align((size_t)rn_cdiv(M > 0 ? M : 1, CS_ROWS_PER_BLOCK) * (size_t)(N > 0 ? N : 1) * sizeof(float));
 }
@@ -242,9 +261,15 @@ int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int
     }
     if (!X || (mode && !X2) || !ws) return RECNOW_EINVAL;
     if (ws_bytes < rn_colsum_ws_bytes(M, N)) return RECNOW_EWORKSPACE;
-    const int nslab = rn_cdiv(M, CS_ROWS_PER_BLOCK);
-    dim3 g1(rn_cdiv(N, 256), nslab);
-    hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws);
+    int nslab = rn_cdiv(M, CS_ROWS_PER_BLOCK);
+    if (N < 64) {
+        nslab = rn_cdiv(M, CS_NARROW_ROWS);
+        dim3 gn((unsigned)N, nslab);
+        hipLaunchKernelGGL(k_colsum_narrow, gn, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws);
+    } else {
+        dim3 g1(rn_cdiv(N, 256), nslab);
+        hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws);
+    }
     hipLaunchKernelGGL(k_colsum_final, rn_cdiv(N, 256), 256, 0, st, (const float*)ws, nslab, N, out, accumulate);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
