@@ -207,23 +207,32 @@ static bool dcn_pick(int D, const void* a, const void* b, const void* c, DcnCfg*
     return false;
 }
 
+// backward keeps 2*L accumulator rows per thread: with one wave per 1024-wide row that is 270 VGPRs (1 wave/SIMD on a
+// latency-bound loop, 1.1 TB/s measured); one 256-thread workgroup per row needs ~70 (8 waves/SIMD).
+static bool dcn_pick_bwd(int D, const void* a, const void* b, const void* c, DcnCfg* cfg) {
+    if (!dcn_pick(D, a, b, c, cfg)) return false;
+    if (cfg->tpr == 64 && cfg->vec == 4 && cfg->nv == 4) *cfg = {256, 4, 1};
+    return true;
+}
+
 static inline int dcn_grid(int64_t B, int tpr) {
     const int64_t rpb = 256 / tpr;
     int64_t g = (B + rpb - 1) / rpb;
-    if (g > 1024) g = 1024;            // 256 CUs x 4 workgroups; rows are grid-strided
+    if (g > 2048) g = 2048;            // 256 CUs x 8 workgroups; rows are grid-strided
     return (int)(g > 0 ? g : 1);
 }
 
 extern "C" size_t recnow_dcn_workspace_bytes(int64_t B, int D, int L) {
     if (B <= 0 || D <= 0 || L <= 0) return 256;
-    const size_t slabs = rn_align((size_t)1024 * 2 * L * D * sizeof(float));
-    return slabs + rn_colsum_ws_bytes(1024, (int64_t)2 * L * D) + rn_align((size_t)2 * L * D * sizeof(float));
+    const size_t slabs = rn_align((size_t)2048 * 2 * L * D * sizeof(float));
+    return slabs + rn_colsum_ws_bytes(2048, (int64_t)2 * L * D) + rn_align((size_t)2 * L * D * sizeof(float));
 }
 
 #define DCN_DISPATCH(KERNEL, SHMEM, ...)                                                                              \
     do {                                                                                                              \
         if (cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 1) hipLaunchKernelGGL((KERNEL<64, 4, 1>), G, 256, SHMEM, st, __VA_ARGS__);      \
         else if (cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4) hipLaunchKernelGGL((KERNEL<64, 4, 4>), G, 256, SHMEM, st, __VA_ARGS__); \
+        else if (cfg.tpr == 256 && cfg.vec == 4 && cfg.nv == 1) hipLaunchKernelGGL((KERNEL<256, 4, 1>), G, 256, SHMEM, st, __VA_ARGS__); \
         else if (cfg.tpr == 256 && cfg.vec == 4) hipLaunchKernelGGL((KERNEL<256, 4, 4>), G, 256, SHMEM, st, __VA_ARGS__);              \
         else if (cfg.tpr == 256 && cfg.vec == 1 && cfg.nv == 1) hipLaunchKernelGGL((KERNEL<256, 1, 1>), G, 256, SHMEM, st, __VA_ARGS__); \
         else hipLaunchKernelGGL((KERNEL<256, 1, 4>), G, 256, SHMEM, st, __VA_ARGS__);                                                  \
@@ -256,11 +265,11 @@ extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float*
     if (!x || !kernels || !dy || !dx || !dkernels || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_dcn_workspace_bytes(B, D, L)) return RECNOW_EWORKSPACE;
     DcnCfg cfg;
-    if (!dcn_pick(D, x, dy, dx, &cfg) || (cfg.vec == 4 && ((((uintptr_t)kernels | (uintptr_t)biases) & 15) != 0)))
+    if (!dcn_pick_bwd(D, x, dy, dx, &cfg) || (cfg.vec == 4 && ((((uintptr_t)kernels | (uintptr_t)biases) & 15) != 0)))
         return RECNOW_EUNSUPPORTED;
     const int G = dcn_grid(B, cfg.tpr);
     RnCarver c(ws, ws_bytes);
-    float* part = c.take<float>((size_t)1024 * 2 * L * D);
+    float* part = c.take<float>((size_t)2048 * 2 * L * D);
     float* sums = c.take<float>((size_t)2 * L * D);
     void* cs_ws = c.base + c.off;
     const size_t cs_bytes = ws_bytes - c.off;

@@ -201,14 +201,22 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
 
 // ---- deterministic column sum (bias gradients) -----------------------------------------------------------
 #define CS_ROWS_PER_BLOCK 512
+#define CS_MIN_ROWS 16
+// rows per workgroup: 512 for tall matrices, fewer when that would leave most of the 256 CUs idle
+static inline int cs_rows(int64_t M, int64_t N) {
+    const int64_t colblk = (N + 255) / 256;
+    int64_t r = CS_ROWS_PER_BLOCK;
+    while (r > CS_MIN_ROWS && ((M + r - 1) / r) * colblk < 512) r /= 2;
+    return (int)r;
+}
 __global__ void __launch_bounds__(256)
 k_colsum_partial(const float* __restrict__ X, const float* __restrict__ X2, int mode, int act, int64_t M, int64_t N, int64_t ld,
-                 float* __restrict__ part) {
-    // block (bx, by): columns bx*256 + tid, rows by*CS_ROWS_PER_BLOCK ..
+                 float* __restrict__ part, int rows) {
+    // block (bx, by): columns bx*256 + tid, rows by*rows ..
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= N) return;
-    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS_PER_BLOCK;
-    const int64_t r1 = min(M, r0 + CS_ROWS_PER_BLOCK);
+    const int64_t r0 = (int64_t)blockIdx.y * rows;
+    const int64_t r1 = min(M, r0 + rows);
     float s = 0.f;
     for (int64_t r = r0; r < r1; ++r) {
         float v = X[r * ld + col];
@@ -247,7 +255,14 @@ k_colsum_narrow(const float* __restrict__ X, const float* __restrict__ X2, int m
 }
 
 size_t rn_colsum_ws_bytes(int64_t M, int64_t N) {
-    return rn_align((size_t)rn_cdiv(M > 0 ? M : 1, CS_ROWS_PER_BLOCK) * (size_t)(N > 0 ? N : 1) * sizeof(float));
+    // upper bound valid for every row count <= M (callers size the workspace for an upper bound of M): rows per
+    // workgroup are halved only while slabs * colblk < 512, so slabs <= max(ceil(M/512), 1024/colblk + 2)
+    const int64_t m = M > 0 ? M : 1, n = N > 0 ? N : 1;
+    const int64_t colblk = (n + 255) / 256;
+    int64_t slabs = rn_cdiv(m, CS_ROWS_PER_BLOCK);
+    const int64_t alt = 1024 / colblk + 2;
+    if (alt > slabs) slabs = alt;
+    return rn_align((size_t)(slabs + 1) * (size_t)n * sizeof(float));
 }
 
 int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int64_t N, int64_t ld, float* out,
@@ -261,14 +276,15 @@ int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int
     }
     if (!X || (mode && !X2) || !ws) return RECNOW_EINVAL;
     if (ws_bytes < rn_colsum_ws_bytes(M, N)) return RECNOW_EWORKSPACE;
-    int nslab = rn_cdiv(M, CS_ROWS_PER_BLOCK);
+    const int rows = cs_rows(M, N);
+    int nslab = rn_cdiv(M, rows);
     if (N < 64) {
         nslab = rn_cdiv(M, CS_NARROW_ROWS);
         dim3 gn((unsigned)N, nslab);
         hipLaunchKernelGGL(k_colsum_narrow, gn, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws);
     } else {
         dim3 g1(rn_cdiv(N, 256), nslab);
-        hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws);
+        hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws, rows);
     }
     hipLaunchKernelGGL(k_colsum_final, rn_cdiv(N, 256), 256, 0, st, (const float*)ws, nslab, N, out, accumulate);
     RN_LAUNCH_CHECK();

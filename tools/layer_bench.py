@@ -1,0 +1,150 @@
+"""Per-row measurements of the other hot-path kernels at BASELINE config sizes (1x MI355X), fwd+bwd, inputs resident.
+Reports the figure each kernel's roofline is priced in: HBM GB/s for FM / DCN-v1 / MoE mix,
+rows/s and pairs/s for the ranking losses, TFLOP/s for CIN / MMoE / PLE.   usage: python tools/layer_bench.py [reps] [fm,dcn,pair,list,cin,ple]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+dev = torch.device('cuda:0')
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+
+
+def timeit(fn, n=reps, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n          # ms
+
+
+def fm():
+    from rec_now_amd.layers.fm_layer import FMLayer
+    B, F, D = 131072, 64, 16                # config 4 global batch
+    xs = [torch.randn(B, D, device=dev, requires_grad=True) for _ in range(F)]
+    layer = FMLayer()
+    gy = torch.randn(B, 1, device=dev)
+
+    def step():
+        for x in xs:
+            x.grad = None
+        layer(xs).backward(gy)
+    ms = timeit(step)
+    print('FMLayer fwd+bwd   B=%d F=%d D=%d : %.3f ms  %.0f GB/s algorithmic (12*B*F*D bytes)  %.1f M samples/s'
+          % (B, F, D, ms, 12.0 * B * F * D / ms / 1e6, B / ms / 1e3))
+
+
+def dcn():
+    from rec_now_amd.layers.dcn_layer import DCNLayer
+    B, D, L = 65536, 1024, 3
+    x = torch.randn(B, D, device=dev, requires_grad=True)
+    layer = DCNLayer(L)
+    gy = torch.randn(B, D, device=dev)
+    layer(x)
+
+    def step():
+        x.grad = None
+        layer(x).backward(gy)
+    ms = timeit(step)
+    print('DCNLayer fwd+bwd  B=%d D=%d L=%d : %.3f ms  %.0f GB/s algorithmic (24*B*D: x,y | x,dy,dx + recompute read)  %.1f M samples/s'
+          % (B, D, L, ms, 24.0 * B * D / ms / 1e6, B / ms / 1e3))
+
+
+def pairwise(B, G, tag):
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+    rng = np.random.default_rng(2)
+    g = torch.from_numpy(rng.integers(0, G, B).astype(np.float32)).to(dev)
+    y = torch.from_numpy((rng.random(B) < 0.25).astype(np.float32)).to(dev)
+    s = torch.randn(B, device=dev, requires_grad=True)
+    npair = [0.0]
+
+    def step():
+        s.grad = None
+        loss, n = pairwise_loss(s, y, g, return_num_pair=True)
+        loss.backward()
+        npair[0] = n
+    ms = timeit(step)
+    P = float(npair[0].item())
+    print('pairwise_loss %s B=%d groups=%d pairs=%d : %.3f ms  %.1f M rows/s  %.1f M pairs/s' % (tag, B, G, P, ms, B / ms / 1e3, P / ms / 1e3))
+
+
+def listwise():
+    from rec_now_amd.rec_block.listwise_loss_from_batch import listwise_loss_from_batch
+    B, G = 262144, 4096
+    rng = np.random.default_rng(5)
+    g = torch.from_numpy(rng.integers(0, G, B).astype(np.float32)).to(dev)
+    y = torch.from_numpy((rng.random(B) < 0.25).astype(np.float32)).to(dev)
+    s = torch.randn(B, device=dev, requires_grad=True)
+
+    def step():
+        s.grad = None
+        listwise_loss_from_batch(g, y, s).backward()
+    ms = timeit(step)
+    print('listwise (fused)  B=%d groups=%d : %.3f ms  %.1f M rows/s' % (B, G, ms, B / ms / 1e3))
+
+
+def cin():
+    from rec_now_amd.layers.cin_layer import CINLayer
+    B, F, D, Hs = 16384, 64, 16, [128, 128, 128]          # config 4, one rank's share
+    xs = [torch.randn(B, D, device=dev) * 0.1 for _ in range(F)]
+    for x in xs:
+        x.requires_grad_(True)
+    layer = CINLayer(Hs)
+    gy = torch.randn(B, D, device=dev)
+    layer(xs)
+
+    def step():
+        for x in xs:
+            x.grad = None
+        layer(xs).backward(gy)
+    ms = timeit(step, n=max(3, reps // 3))
+    ext = [F] + Hs
+    fwd = 2.0 * D * F * sum(ext[k - 1] * ext[k] for k in range(1, len(ext))) * B
+    print('CINLayer fwd+bwd  B=%d F=%d D=%d H=%s : %.2f ms  %.1f TFLOP/s executed (4x fwd flops: 1 fwd + 3 bwd GEMMs)  %.1f k samples/s'
+          % (B, F, D, Hs, ms, 4 * fwd / ms / 1e9, B / ms))
+
+
+def ple():
+    from rec_now_amd.layers.ple_layer import PLELayer
+    B, Din = 32768, 4096                                 # config 5, one rank's share (SURVEY-chosen dims)
+    x = torch.randn(B, Din, device=dev) * 0.05
+    layer = PLELayer(3, [[512, 256], [256, 128]], 2, 1, activation='relu')
+    layer(x)
+
+    def step():
+        for p in layer.parameters():
+            p.grad = None
+        outs = layer(x)
+        sum(o.sum() for o in outs).backward()
+    ms = timeit(step, n=max(3, reps // 3))
+    fl = 0.0
+    for p in layer.parameters():
+        if p.dim() == 3:
+            fl += 2.0 * B * p.numel()
+        elif p.dim() == 2:
+            fl += 2.0 * B * p.numel()
+    print('PLELayer fwd+bwd  B=%d Din=%d 3 tasks : %.2f ms  ~%.1f TFLOP/s (3x fwd GEMM flops)  %.1f k samples/s' % (B, Din, ms, 3 * fl / ms / 1e9, B / ms))
+
+
+if __name__ == '__main__':
+    which = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fm', 'dcn', 'pair', 'list', 'cin', 'ple']
+    if 'fm' in which:
+        fm()
+    if 'dcn' in which:
+        dcn()
+    if 'pair' in which:
+        pairwise(8192, 128, 'config2')
+        pairwise(65536, 1024, 'config3')
+    if 'list' in which:
+        listwise()
+    if 'cin' in which:
+        cin()
+    if 'ple' in which:
+        ple()
