@@ -123,3 +123,35 @@ def test_pair_order_is_row_major():
     y = torch.tensor([1., 0., 0., 1., 2.])
     pos, neg = R.pair_indices(y, g)
     assert pos.tolist() == [0, 3, 4, 4] and neg.tolist() == [2, 1, 0, 2]
+
+
+# ---- the plain-C restatement (oracle/pairs_oracle.c) is pinned to the same goldens and to the dense oracle ----------------
+def test_c_oracle_reference_goldens():
+    import pairs_oracle as C
+    g = [1, 1, 2, 2, 2]
+    s = [0, 1, 2, 3, 4]
+    y = [1.1, 0, 0, 1, 1]
+    loss, _, P = C.pairwise_bpr(g, y, s, power=-0.5)
+    assert P == 3 and abs(loss - 0.5415076) < 1e-4
+    loss, _, _ = C.pairwise_bpr(g, y, s, mask=[1, 1, 0, 0, 0], power=-0.5)
+    assert abs(loss - 1.3132617) < 1e-4
+
+
+def test_c_oracle_equals_dense_oracle():
+    import pairs_oracle as C
+    rng = np.random.default_rng(0)
+    B = 700
+    g = rng.integers(0, 11, B).astype(np.float32)
+    y = rng.integers(0, 3, B).astype(np.float32)
+    s = rng.normal(size=B).astype(np.float32)
+    m = rng.random(B) < 0.8
+    for wrong in (False, True):
+        pos, neg = C.pair_indices(g, y, s, m, flags=1 | (2 if wrong else 0))
+        rpos, rneg = R.pair_indices(torch.from_numpy(y), torch.from_numpy(g), wrong, torch.from_numpy(s), torch.from_numpy(m))
+        assert np.array_equal(pos, rpos.numpy()) and np.array_equal(neg, rneg.numpy())
+    s64 = torch.from_numpy(s).double().requires_grad_(True)
+    rl = R.pairwise_loss(s64, torch.from_numpy(y).double(), torch.from_numpy(g), click_occurance_power=-0.5, mask=torch.from_numpy(m))
+    rl.backward()
+    loss, d, _ = C.pairwise_bpr(g, y, s, m, power=-0.5)
+    assert abs(loss - rl.item()) < 1e-9 * max(1, abs(rl.item())) + 1e-7
+    assert np.abs(d - s64.grad.numpy()).max() < 1e-7

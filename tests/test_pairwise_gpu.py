@@ -226,3 +226,28 @@ def test_full_size_properties_config3(dev):
     assert abs(loss_p.item() - loss.item()) <= 1e-5 * abs(loss.item())
     loss2 = M.pairwise_loss(sd.detach(), yd, gd)
     assert loss2.item() == loss.item()
+
+
+def test_pair_indices_bit_exact_vs_c_oracle_large(dev):
+    """B = 20000 (beyond what the dense (B,B) oracle can hold comfortably): the HIP pair list must equal the plain-C
+    restatement of the reference formulation (oracle/pairs_oracle.c) element for element; fused loss/grad too."""
+    import pairs_oracle as C
+    M = _mod()
+    rng = np.random.default_rng(77)
+    B = 20000
+    g = rng.integers(0, 300, B).astype(np.float32)
+    y = rng.integers(0, 3, B).astype(np.float32)
+    s = rng.normal(size=B).astype(np.float32)
+    m = rng.random(B) < 0.9
+    pos, neg = M.pair_indices(torch.from_numpy(s).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(g).to(dev),
+                              mask=torch.from_numpy(m).to(dev))
+    cpos, cneg = C.pair_indices(g, y, s, m)
+    assert np.array_equal(pos.cpu().numpy(), cpos) and np.array_equal(neg.cpu().numpy(), cneg)
+    sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+    loss, n = M.pairwise_loss(sd, torch.from_numpy(y).to(dev), torch.from_numpy(g).to(dev), return_num_pair=True,
+                              click_occurance_power=-0.5, mask=torch.from_numpy(m).to(dev))
+    loss.backward()
+    closs, cd, P = C.pairwise_bpr(g, y, s, m, power=-0.5)
+    assert int(n.item()) == P == len(cpos)
+    assert abs(loss.item() - closs) <= RTOL * abs(closs)
+    assert np.abs(sd.grad.cpu().numpy() - cd).max() <= RTOL * np.abs(cd).max()
