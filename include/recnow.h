@@ -215,6 +215,8 @@ typedef struct recnow_gemm_desc {
     /* Rank-R epilogue update (lean 128x128 kernels, batch 1): before bias-activation / emul,
      *   v[m][n] += sum_{r < eu_r <= 4} eu_p[m*eu_pms + r] * eu_q[r*eu_qrs + n*eu_qns]  (K = 128 + 2 as exactly 128). */
     const float* eu_p; const float* eu_q; int64_t eu_pms, eu_qrs, eu_qns; int eu_r; int eu_pad;
+    double prof_flops;                /* algorithmic flops of this product for the measurement hook (0: 2*M*N*K*batch);
+                                         callers that zero-pad K or move columns to a side product state the true count */
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;

@@ -241,6 +241,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
                 d.B = Wc1; d.ldb = m.LDT; d.b_trans = 0;
                 d.C = T1; d.ldc = m.LDT;
                 d.M = (int)B; d.N = m.NS; d.K = D;
+                d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.act = act_inner;
                 d.sp_bx = gate_host[l]; d.sp_bx_ks = N; d.sp_bx_rs = 1; d.sp_cx = T1 + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
@@ -263,6 +264,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
                 d.B = Wc2; d.ldb = D; d.b_trans = 0;
                 d.C = out; d.ldc = D;
                 d.M = (int)B; d.N = D; d.K = m.KP;
+                d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             }
@@ -361,6 +363,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
                 d.B = W_host[l]; d.ldb = D; d.b_trans = 1;
                 d.C = dT2g; d.ldc = m.LDT;
                 d.M = (int)B; d.N = m.NS; d.K = D;
+                d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.sp_bx = bias_host[l]; d.sp_bx_ks = 1; d.sp_bx_rs = D; d.sp_cx = dT2g + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             }
@@ -370,6 +373,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
                 d.B = T2g; d.ldb = m.LDT; d.b_trans = 0;
                 d.C = dW_host[l]; d.ldc = D; d.c_trans = 1;
                 d.M = D; d.N = m.NS; d.K = (int)B;
+                d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.sp_bx = T2g + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             }
@@ -379,6 +383,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
                 d.B = Wc2; d.ldb = D; d.b_trans = 0;
                 d.C = dx; d.ldc = D;
                 d.M = (int)B; d.N = D; d.K = m.KP;
+                d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
                 d.accumulate = dx_started ? 1 : 0;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
@@ -409,6 +414,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
                 d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
                 d.C = dWc1; d.ldc = m.NS;
                 d.M = D; d.N = m.NS; d.K = (int)B;
+                d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.sp_bx = dT1 + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dgate_host[l]; d.sp_cx_ms = N; d.sp_cx_rs = 1; d.sp_r = N;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
                 hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st, dWc1, D, S, N, dU_host[l]);
@@ -420,6 +426,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
                 d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
                 d.C = (l == 0) ? dx : gprev; d.ldc = D;
                 d.M = (int)B; d.N = D; d.K = m.KP;
+                d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.accumulate = (l == 0) ? 1 : 0;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             }

@@ -165,7 +165,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     int rc;
     const int tag = (c.BM == 256 && c.BN == 32) ? RN_TAG_GEMM_256x32 : (c.BM == 256) ? RN_TAG_GEMM_256x64
                   : (c.BN == 160) ? RN_TAG_GEMM_128x160 : RN_TAG_GEMM_128x128;
-    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(tag, 2.0 * d->M * d->N * (double)d->K * d->batch, st) : nullptr;
+    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(tag, d->prof_flops > 0.0 ? d->prof_flops : 2.0 * d->M * d->N * (double)d->K * d->batch, st) : nullptr;
     // short-K products (K <= 256, e.g. the K = N*S+N = 130 contractions of DCN-v2) are prologue/epilogue dominated:
     // BK = 16 halves the LDS footprint so 4 workgroups per CU overlap each other's load/store phases.
     const bool short_k = d->K <= 256;

@@ -42,6 +42,8 @@ SHAPES = [
     ('x128+EU dxl', B, D, 128, 0, 1, 132, 128, D, 0, 0, 0, 2),
     ('x128+SP dU', D, 128, B, 1, 0, D, 132, 128, 0, 0, 0, 1),
     ('x128+SP dW^T', D, 128, B, 1, 0, D, 132, D, 1, 0, 1, 1),
+    ('pad160 GEMM3 (B,160)x(160,D) BK32', B, D, 160, 0, 0, 160, D, D, 0, 1, 0),
+    ('pad160 dxl   (B,160)x(160,D) BK32', B, D, 160, 0, 1, 160, 160, D, 0, 0, 0),
     ('square 4096^3 NN', 4096, 4096, 4096, 0, 0, 4096, 4096, 4096, 0, 0, 0),
     ('square 4096^3 NT', 4096, 4096, 4096, 0, 1, 4096, 4096, 4096, 0, 0, 0),
 ]
