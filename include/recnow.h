@@ -287,7 +287,10 @@ int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* 
                        const float* const* bias_host, const float* const* gate_host, const float* dy, const void* saved,
                        size_t saved_bytes, int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* dx,
                        float* const* dU_host, float* const* dV_host, float* const* dW_host, float* const* dbias_host,
-                       float* const* dgate_host, void* ws, size_t ws_bytes, void* stream);
+                       float* const* dgate_host, void* ws, size_t ws_bytes, void* stream, void* stream2);
+/* stream2: optional second hipStream_t (NULL or == stream: single-stream).  When given, the weight-gradient products and
+ * the dx recompute run on it concurrently with the data-gradient chain on `stream`, ordered by events created and
+ * destroyed inside the call; on return all of stream2's work is ordered before later work submitted to `stream`. */
 
 /* ------------------------------------------------------------------------------------------------------------
  * CINLayer (xDeepFM Compressed Interaction Network): rec_now/layers/cin_layer.py:72-122

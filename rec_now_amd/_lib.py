@@ -52,7 +52,7 @@ SIGNATURES = {
     'recnow_dcn_mix_workspace_bytes': (_Z, [_L, _I, _I, _I, _I]),
     'recnow_dcn_mix_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P]),
     'recnow_dcn_mix_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
-                                 _Z, _P]),
+                                 _Z, _P, _P]),
     'recnow_cin_saved_bytes': (_Z, [_L, _I, _I, _P, _I]),
     'recnow_cin_workspace_bytes': (_Z, [_L, _I, _I, _P, _I]),
     'recnow_cin_fwd': (_I, [_P, _P, _L, _I, _I, _P, _I, _I, _I, _P, _P, _Z, _P, _Z, _P]),
@@ -132,6 +132,17 @@ def ptr(t):
 
 def stream():
     return _P(torch.cuda.current_stream().cuda_stream)
+
+
+_side_streams = {}
+
+
+def side_stream(device):
+    """One extra HIP stream per device for the entry points that accept a `stream2` (concurrent independent GEMMs)."""
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _P(_side_streams[key].cuda_stream)
 
 
 def workspace(nbytes, device):

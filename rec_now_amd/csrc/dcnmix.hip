@@ -179,8 +179,9 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
     s += rn_align((size_t)m.LDT * D * sizeof(float));        // dWc2
     s += 3 * act_block(m);                                   // dT2g, dC, dT1
     s += 2 * xbuf(m);                                        // inter-layer gradient ping-pong
-    s += mix_gemm_ws(m);
-    return s + 256;
+    s += 2 * rn_align(mix_gemm_ws(m));                       // split-K slabs: chain stream + side stream
+    s += (size_t)L * (rn_align((size_t)D * m.LDT * sizeof(float)) + rn_align((size_t)m.LDT * D * sizeof(float)));   // per-layer packs
+    return s + 4096;
 }
 
 static int pack_weights(const MixDims& m, const float* U, const float* V, const float* W, const float* bias, const float* K,
@@ -306,12 +307,176 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
     return RECNOW_OK;
 }
 
+
+// ---- exact-128 backward, optionally on two streams -----------------------------------------------------------------
+// The data-gradient chain (dT2g -> gate_bwd -> dA -> dxl) is sequential; the weight-gradient products and the dx
+// recompute only consume its intermediates.  Every big GEMM here alternates an MFMA-bound main loop with an HBM-bound
+// epilogue and all workgroups of one launch run in phase, so a single stream leaves ~40 % of the MFMA pipe idle.  With a
+// second stream (st2 != st) the side products run concurrently with the chain and fill those phases.  Ordering is by
+// events only; results are identical to the single-stream order (dx is accumulated by the side stream, then joined).
+struct MixEvents {
+    hipEvent_t e[64];
+    int n = 0;
+    hipEvent_t make() {
+        hipEvent_t ev = nullptr;
+        if (n < 64 && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) e[n++] = ev;
+        return ev;
+    }
+    ~MixEvents() {
+        for (int i = 0; i < n; ++i) (void)hipEventDestroy(e[i]);
+    }
+};
+#define MIX_SIGNAL(ev, from)                                  \
+    do {                                                      \
+        if (two) { ev = evs.make(); if (!ev) return RECNOW_EINVAL; RN_HIP(hipEventRecord(ev, from)); } \
+    } while (0)
+#define MIX_WAIT(ev, on)                                      \
+    do {                                                      \
+        if (two && ev) RN_HIP(hipStreamWaitEvent(on, ev, 0)); \
+    } while (0)
+
+static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const* U_host, const float* const* V_host,
+                            const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
+                            const float* dy, const char* sv, int act_inner, int act_outer, float* dx, float* const* dU_host,
+                            float* const* dV_host, float* const* dW_host, float* const* dbias_host, float* const* dgate_host,
+                            void* ws, size_t ws_bytes, hipStream_t st, hipStream_t st2) {
+    const int64_t B = m.B;
+    const int D = m.D, S = m.S, N = m.N, L = m.L;
+    const bool two = st2 != nullptr && st2 != st;
+    if (!two) st2 = st;
+    RnCarver c(ws, ws_bytes);
+    float* Wc1_all = c.take<float>((size_t)L * D * m.LDT);        // per-layer packs: the side stream reads them later
+    float* Wc2_all = c.take<float>((size_t)L * m.LDT * D);
+    float* dWc1 = c.take<float>((size_t)D * m.LDT);
+    float* dT2g = c.take<float>(act_block(m) / sizeof(float));
+    float* dC = c.take<float>(act_block(m) / sizeof(float));
+    float* dT1 = c.take<float>(act_block(m) / sizeof(float));
+    float* gbuf0 = c.take<float>(xbuf(m) / sizeof(float));
+    float* gbuf1 = c.take<float>(xbuf(m) / sizeof(float));
+    const size_t gemm_ws = mix_gemm_ws(m);
+    void* gws = c.take<char>(gemm_ws);                              // split-K slabs of the chain stream
+    void* gws2 = c.take<char>(gemm_ws);                             // ... and of the side stream
+    if (!c.ok()) return RECNOW_EWORKSPACE;
+    const float* xmid = (const float*)(sv + (size_t)L * 3 * act_block(m));
+    MixEvents evs;
+    int rc;
+    for (int l = 0; l < L; ++l)
+        if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1_all + (size_t)l * D * m.LDT,
+                               Wc2_all + (size_t)l * m.LDT * D, st)))
+            return rc;
+    hipEvent_t e_g = nullptr;        // "g of this layer (and the packs) are ready" -> side stream may start the layer
+    MIX_SIGNAL(e_g, st);
+    hipEvent_t e_side_prev = nullptr;   // side stream finished the previous (higher) layer: dT1/dC/g buffers reusable
+    hipEvent_t e_dx = nullptr;          // side stream's last dx accumulation
+    const float* g = dy;
+    bool dx_started = false;
+    int pg = rn_cdiv((int64_t)D * m.NS, 256);
+    if (pg > 2048) pg = 2048;
+    for (int l = L - 1; l >= 0; --l) {
+        const float* T1 = (const float*)(sv + (size_t)(3 * l) * act_block(m));
+        const float* T2 = (const float*)(sv + (size_t)(3 * l + 1) * act_block(m));
+        const float* T2g = (const float*)(sv + (size_t)(3 * l + 2) * act_block(m));
+        const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));
+        float* gprev = (l == 0) ? nullptr : ((l & 1) ? gbuf0 : gbuf1);
+        const float* Wc1 = Wc1_all + (size_t)l * D * m.LDT;
+        const float* Wc2 = Wc2_all + (size_t)l * m.LDT * D;
+        // ---------------- side stream, part 1: needs only g_l and saved activations
+        MIX_WAIT(e_g, st2);
+        {   // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 1;
+            d.B = T2g; d.ldb = m.LDT; d.b_trans = 0;
+            d.C = dW_host[l]; d.ldc = D; d.c_trans = 1;
+            d.M = D; d.N = m.NS; d.K = (int)B;
+            d.prof_flops = 2.0 * (double)B * D * m.KC;
+            d.sp_bx = T2g + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
+            if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
+        }
+        {   // dx (+)= g * O,  O = [G*H2 | G | 0] [W; b; 0] recomputed
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
+            d.B = Wc2; d.ldb = D; d.b_trans = 0;
+            d.C = dx; d.ldc = D;
+            d.M = (int)B; d.N = D; d.K = m.KP;
+            d.prof_flops = 2.0 * (double)B * D * m.KC;
+            d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
+            d.accumulate = dx_started ? 1 : 0;
+            if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
+            dx_started = true;
+            if (l == 0) MIX_SIGNAL(e_dx, st2);
+        }
+        // ---------------- chain stream
+        {   // dT2g[:, :NS] = (x*g) W^T;  gate columns dT2g[:, NS+n] = (x*g) . bias_n as the side product
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 0;
+            d.B = W_host[l]; d.ldb = D; d.b_trans = 1;
+            d.C = dT2g; d.ldc = m.LDT;
+            d.M = (int)B; d.N = m.NS; d.K = D;
+            d.prof_flops = 2.0 * (double)B * D * m.KC;
+            d.sp_bx = bias_host[l]; d.sp_bx_ks = 1; d.sp_bx_rs = D; d.sp_cx = dT2g + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
+            if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
+        }
+        MIX_WAIT(e_side_prev, st);          // dC / dT1 (and the g buffer about to be rewritten) are free again
+        hipLaunchKernelGGL(k_dcnmix_gate_bwd, gate_grid(B), 256, 0, st, dT2g, T2, dC, dT1, B, S, N, m.LDT, act_outer);
+        RN_LAUNCH_CHECK();
+        {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n)
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = dC; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
+            d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 1;
+            d.C = dT1; d.ldc = m.LDT; d.c_batch_stride = S;
+            d.M = (int)B; d.N = S; d.K = S; d.batch = N;
+            d.emul = T1; d.lde = m.LDT; d.e_batch_stride = S; d.e_mode = RECNOW_OPMODE_ACTGRAD; d.e_act = act_inner;
+            if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
+        }
+        hipEvent_t e_dT1 = nullptr;
+        MIX_SIGNAL(e_dT1, st);
+        if (l == 0) MIX_WAIT(e_dx, st);     // dx is complete on the side stream before the chain adds the last term
+        {   // gradient w.r.t. x_l: [dA | dlogits | 0] [U | K | 0]^T  (K zero-padded to KP)
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
+            d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
+            d.C = (l == 0) ? dx : gprev; d.ldc = D;
+            d.M = (int)B; d.N = D; d.K = m.KP;
+            d.prof_flops = 2.0 * (double)B * D * m.KC;
+            d.accumulate = (l == 0) ? 1 : 0;
+            if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
+        }
+        if (l > 0) MIX_SIGNAL(e_g, st);
+        // ---------------- side stream, part 2: needs dC / dT1 of this layer
+        MIX_WAIT(e_dT1, st2);
+        {   // dV_n = H1_n^T dC_n
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 1;
+            d.B = dC; d.ldb = m.LDT; d.b_batch_stride = S; d.b_trans = 0;
+            d.C = dV_host[l]; d.ldc = S; d.c_batch_stride = (int64_t)S * S;
+            d.M = S; d.N = S; d.K = (int)B; d.batch = N;
+            if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
+        }
+        {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = xl; d.lda = D; d.a_trans = 1;
+            d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
+            d.C = dWc1; d.ldc = m.NS;
+            d.M = D; d.N = m.NS; d.K = (int)B;
+            d.prof_flops = 2.0 * (double)B * D * m.KC;
+            d.sp_bx = dT1 + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dgate_host[l]; d.sp_cx_ms = N; d.sp_cx_rs = 1; d.sp_r = N;
+            if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
+            hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st2, dWc1, D, S, N, dU_host[l]);
+            RN_LAUNCH_CHECK();
+        }
+        MIX_SIGNAL(e_side_prev, st2);
+        g = gprev;
+    }
+    MIX_WAIT(e_side_prev, st);              // join: everything the side stream produced is ordered before later work on st
+    return RECNOW_OK;
+}
+
 extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* const* V_host,
                                   const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
                                   const float* dy, const void* saved, size_t saved_bytes, int64_t B, int D, int S, int N, int L,
                                   int act_inner, int act_outer, float* dx, float* const* dU_host, float* const* dV_host,
                                   float* const* dW_host, float* const* dbias_host, float* const* dgate_host, void* ws,
-                                  size_t ws_bytes, void* stream) {
+                                  size_t ws_bytes, void* stream, void* stream2) {
     if (B < 0 || D < 1 || S < 1 || N < 1 || L < 1 || B > 0x7fffffffll) return RECNOW_EINVAL;
     if (N > 64) return RECNOW_EUNSUPPORTED;
     if (!dU_host || !dV_host || !dW_host || !dbias_host || !dgate_host) return RECNOW_EINVAL;
@@ -330,6 +495,9 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
     if (saved_bytes < recnow_dcn_mix_saved_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
     if (ws_bytes < recnow_dcn_mix_workspace_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
     const MixDims m = mix_dims(B, D, S, N, L);
+    if (m.exact)
+        return dcnmix_bwd_exact(m, x, U_host, V_host, W_host, bias_host, gate_host, dy, (const char*)saved, act_inner, act_outer, dx,
+                                dU_host, dV_host, dW_host, dbias_host, dgate_host, ws, ws_bytes, st, (hipStream_t)stream2);
     RnCarver c(ws, ws_bytes);
     float* Wc1 = c.take<float>((size_t)D * m.LDT);
     float* Wc2 = c.take<float>((size_t)m.LDT * D);
@@ -353,86 +521,6 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
         const float* T2g = (const float*)(sv + (size_t)(3 * l + 2) * act_block(m));
         const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));
         float* gprev = (l == 0) ? nullptr : ((l & 1) ? gbuf0 : gbuf1);
-        if (m.exact) {
-            int pg = rn_cdiv((int64_t)D * m.NS, 256);
-            if (pg > 2048) pg = 2048;
-            if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
-            {   // dT2g[:, :NS] = (x*g) W^T;  gate columns dT2g[:, NS+n] = (x*g) . bias_n as the side product
-                recnow_gemm_desc d = rn_gemm_desc_zero();
-                d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 0;
-                d.B = W_host[l]; d.ldb = D; d.b_trans = 1;
-                d.C = dT2g; d.ldc = m.LDT;
-                d.M = (int)B; d.N = m.NS; d.K = D;
-                d.prof_flops = 2.0 * (double)B * D * m.KC;
-                d.sp_bx = bias_host[l]; d.sp_bx_ks = 1; d.sp_bx_rs = D; d.sp_cx = dT2g + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-            }
-            {   // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
-                recnow_gemm_desc d = rn_gemm_desc_zero();
-                d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 1;
-                d.B = T2g; d.ldb = m.LDT; d.b_trans = 0;
-                d.C = dW_host[l]; d.ldc = D; d.c_trans = 1;
-                d.M = D; d.N = m.NS; d.K = (int)B;
-                d.prof_flops = 2.0 * (double)B * D * m.KC;
-                d.sp_bx = T2g + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-            }
-            {   // dx (+)= g * O,  O = [G*H2 | G | 0] [W; b; 0] recomputed
-                recnow_gemm_desc d = rn_gemm_desc_zero();
-                d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
-                d.B = Wc2; d.ldb = D; d.b_trans = 0;
-                d.C = dx; d.ldc = D;
-                d.M = (int)B; d.N = D; d.K = m.KP;
-                d.prof_flops = 2.0 * (double)B * D * m.KC;
-                d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
-                d.accumulate = dx_started ? 1 : 0;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-                dx_started = true;
-            }
-            hipLaunchKernelGGL(k_dcnmix_gate_bwd, gate_grid(B), 256, 0, st, dT2g, T2, dC, dT1, B, S, N, m.LDT, act_outer);
-            RN_LAUNCH_CHECK();
-            {   // dV_n = H1_n^T dC_n
-                recnow_gemm_desc d = rn_gemm_desc_zero();
-                d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 1;
-                d.B = dC; d.ldb = m.LDT; d.b_batch_stride = S; d.b_trans = 0;
-                d.C = dV_host[l]; d.ldc = S; d.c_batch_stride = (int64_t)S * S;
-                d.M = S; d.N = S; d.K = (int)B; d.batch = N;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-            }
-            {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n)
-                recnow_gemm_desc d = rn_gemm_desc_zero();
-                d.A = dC; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
-                d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 1;
-                d.C = dT1; d.ldc = m.LDT; d.c_batch_stride = S;
-                d.M = (int)B; d.N = S; d.K = S; d.batch = N;
-                d.emul = T1; d.lde = m.LDT; d.e_batch_stride = S; d.e_mode = RECNOW_OPMODE_ACTGRAD; d.e_act = act_inner;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-            }
-            {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
-                recnow_gemm_desc d = rn_gemm_desc_zero();
-                d.A = xl; d.lda = D; d.a_trans = 1;
-                d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
-                d.C = dWc1; d.ldc = m.NS;
-                d.M = D; d.N = m.NS; d.K = (int)B;
-                d.prof_flops = 2.0 * (double)B * D * m.KC;
-                d.sp_bx = dT1 + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dgate_host[l]; d.sp_cx_ms = N; d.sp_cx_rs = 1; d.sp_r = N;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-                hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st, dWc1, D, S, N, dU_host[l]);
-                RN_LAUNCH_CHECK();
-            }
-            {   // gradient w.r.t. x_l: [dA | dlogits | 0] [U | K | 0]^T  (K zero-padded to KP)
-                recnow_gemm_desc d = rn_gemm_desc_zero();
-                d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
-                d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
-                d.C = (l == 0) ? dx : gprev; d.ldc = D;
-                d.M = (int)B; d.N = D; d.K = m.KP;
-                d.prof_flops = 2.0 * (double)B * D * m.KC;
-                d.accumulate = (l == 0) ? 1 : 0;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-            }
-            g = gprev;
-            continue;
-        }
         if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
         {   // dT2g = (x * g) Wc2^T
             recnow_gemm_desc d = rn_gemm_desc_zero();

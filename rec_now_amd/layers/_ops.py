@@ -138,6 +138,13 @@ class DCNFunction(torch.autograd.Function):
         return dx, dk, db, None
 
 
+import os
+# Opt-in: run the weight-gradient products of the DCN-v2 backward on a second HIP stream (recnow_dcn_mix_bwd's stream2).
+# Measured on MI355X at the north-star shape: 5.43 vs 5.54 ms/step (-2 %), every GEMM already fills all 256 CUs, so the
+# default stays single-stream (per-launch timings then remain meaningful for the roofline hook).
+DCN_MIX_TWO_STREAMS = os.environ.get('RECNOW_TWO_STREAMS', '0') == '1'
+
+
 # ---- DCN-v2 mix ---------------------------------------------------------------------------------------------------
 class DCNMixFunction(torch.autograd.Function):
     """All L layers of DCNMixLayer.  params = U_0..U_{L-1}, V_0.., W_0.., bias_0.., gate_0.. (5*L tensors)."""
@@ -174,7 +181,8 @@ class DCNMixFunction(torch.autograd.Function):
         _lib.call('recnow_dcn_mix_bwd', _lib.ptr(x), _host_ptr_array(U), _host_ptr_array(V), _host_ptr_array(W),
                   _host_ptr_array(bias), _host_ptr_array(gate), _lib.ptr(dy), _lib.ptr(saved), saved.numel(), B, D, S, N, L,
                   act_inner, act_outer, _lib.ptr(dx), _host_ptr_array(dU), _host_ptr_array(dV), _host_ptr_array(dW),
-                  _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(ws), ws.numel(), _lib.stream())
+                  _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(ws), ws.numel(), _lib.stream(),
+                  _lib.side_stream(x.device) if DCN_MIX_TWO_STREAMS else None)
         return (dx, None, None, None) + tuple(grads)
 
 

@@ -420,3 +420,24 @@ def test_gemm_side_product_and_rank_update(dev, ta, splitk_shape):
 def test_dcn_mix_exact128_path_vs_oracle(dev, B, D, S, N, L):
     """Shapes with N*S, D multiples of 128 and B a multiple of 256 take the side-product formulation (dcnmix.hip)."""
     test_dcn_mix_fwd_bwd_vs_oracle(dev, B, D, S, N, L, 'tanh', 'tanh')
+
+
+def test_dcn_mix_backward_on_two_streams_matches_single_stream(dev, monkeypatch):
+    """recnow_dcn_mix_bwd(stream2=...) orders the side stream by events only: gradients are bit-identical."""
+    from rec_now_amd.layers import _ops
+    from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
+    torch.manual_seed(5)
+    x = (torch.randn(1024, 256, device=dev) * 0.3)
+    layer = DCNMixLayer(dim_sub_space=64, num_layer=3, num_expert=2)
+    layer(x[:8])
+    grads = []
+    for two in (False, True):
+        monkeypatch.setattr(_ops, 'DCN_MIX_TWO_STREAMS', two)
+        xi = x.clone().requires_grad_(True)
+        for p in layer.parameters():
+            p.grad = None
+        layer(xi).square().sum().backward()
+        torch.cuda.synchronize()
+        grads.append([xi.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
