@@ -18,6 +18,7 @@
 // multiples of 128) and K of the (N*S+N)-deep products rounded up to 16/32, all zero padded, so every GEMM of the layer
 // takes the lean interior kernel (no bounds code) whenever B is a multiple of 256.  Zero columns/rows are inert.
 #include "gemm.hpp"
+#include "dcnmix_mid.hpp"
 
 static inline int ldt_of(int S, int N) {
     const int kc = N * S + N;
@@ -180,6 +181,7 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
     s += 3 * act_block(m);                                   // dT2g, dC, dT1
     s += 2 * xbuf(m);                                        // inter-layer gradient ping-pong
     s += 2 * rn_align(mix_gemm_ws(m));                       // split-K slabs: chain stream + side stream
+    s += rn_mix_mid_bwd_ws_bytes(B, S, N);                   // per-workgroup dV partials of the fused sub-space backward
     s += (size_t)L * (rn_align((size_t)D * m.LDT * sizeof(float)) + rn_align((size_t)m.LDT * D * sizeof(float)));   // per-layer packs
     return s + 4096;
 }
@@ -202,6 +204,54 @@ static inline int gate_grid(int64_t B) {
     int64_t g = (B + 3) / 4;
     if (g > 4096) g = 4096;
     return (int)(g > 0 ? g : 1);
+}
+
+
+// Sub-space stage: the fused streaming kernels of dcnmix_mid.hip when the shape fits them, else batched GEMMs + gate kernels.
+static int mix_mid_fwd(const MixDims& m, const float* T1, const float* V, float* T2, float* T2g, int act_outer, void* gws,
+                       size_t gws_bytes, hipStream_t st) {
+    if (rn_mix_mid_supported(m.S, m.N, m.LDT)) return rn_mix_mid_fwd(T1, V, T2, T2g, m.B, m.S, m.N, m.LDT, act_outer, st);
+    int rc;
+    {   // GEMM2: H2_n = act_outer(H1_n V_n), batched over the N experts
+        recnow_gemm_desc d = rn_gemm_desc_zero();
+        d.A = T1; d.lda = m.LDT; d.a_batch_stride = m.S; d.a_trans = 0;
+        d.B = V; d.ldb = m.S; d.b_batch_stride = (int64_t)m.S * m.S; d.b_trans = 0;
+        d.C = T2; d.ldc = m.LDT; d.c_batch_stride = m.S;
+        d.M = (int)m.B; d.N = m.S; d.K = m.S; d.batch = m.N;
+        d.act = act_outer;
+        if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+    }
+    hipLaunchKernelGGL(k_dcnmix_gate_fwd, gate_grid(m.B), 256, 0, st, T1, T2, T2g, m.B, m.S, m.N, m.LDT);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+// dT2g -> dT1 = [dA | dlogits | 0] and dV.  dC is scratch of the unfused route only; mid_ws holds the fused route's partials.
+static int mix_mid_bwd(const MixDims& m, const float* dT2g, const float* T2, const float* T1, const float* V, float* dC, float* dT1,
+                       float* dV, int act_inner, int act_outer, void* mid_ws, size_t mid_ws_bytes, void* gws, size_t gws_bytes,
+                       hipStream_t st) {
+    if (rn_mix_mid_supported(m.S, m.N, m.LDT))
+        return rn_mix_mid_bwd(dT2g, T2, T1, V, dT1, dV, m.B, m.S, m.N, m.LDT, act_inner, act_outer, mid_ws, mid_ws_bytes, st);
+    int rc;
+    hipLaunchKernelGGL(k_dcnmix_gate_bwd, gate_grid(m.B), 256, 0, st, dT2g, T2, dC, dT1, m.B, m.S, m.N, m.LDT, act_outer);
+    RN_LAUNCH_CHECK();
+    {   // dV_n = H1_n^T dC_n            (S x S), K = B
+        recnow_gemm_desc d = rn_gemm_desc_zero();
+        d.A = T1; d.lda = m.LDT; d.a_batch_stride = m.S; d.a_trans = 1;
+        d.B = dC; d.ldb = m.LDT; d.b_batch_stride = m.S; d.b_trans = 0;
+        d.C = dV; d.ldc = m.S; d.c_batch_stride = (int64_t)m.S * m.S;
+        d.M = m.S; d.N = m.S; d.K = (int)m.B; d.batch = m.N;
+        if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+    }
+    {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n)  -> first NS columns of dT1
+        recnow_gemm_desc d = rn_gemm_desc_zero();
+        d.A = dC; d.lda = m.LDT; d.a_batch_stride = m.S; d.a_trans = 0;
+        d.B = V; d.ldb = m.S; d.b_batch_stride = (int64_t)m.S * m.S; d.b_trans = 1;
+        d.C = dT1; d.ldc = m.LDT; d.c_batch_stride = m.S;
+        d.M = (int)m.B; d.N = m.S; d.K = m.S; d.batch = m.N;
+        d.emul = T1; d.lde = m.LDT; d.e_batch_stride = m.S; d.e_mode = RECNOW_OPMODE_ACTGRAD; d.e_act = act_inner;
+        if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+    }
+    return RECNOW_OK;
 }
 
 extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, const float* const* V_host,
@@ -247,17 +297,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
                 d.sp_bx = gate_host[l]; d.sp_bx_ks = N; d.sp_bx_rs = 1; d.sp_cx = T1 + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             }
-            {   // GEMM2: H2_n = act_outer(H1_n V_n)
-                recnow_gemm_desc d = rn_gemm_desc_zero();
-                d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
-                d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 0;
-                d.C = T2; d.ldc = m.LDT; d.c_batch_stride = S;
-                d.M = (int)B; d.N = S; d.K = S; d.batch = N;
-                d.act = act_outer;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-            }
-            hipLaunchKernelGGL(k_dcnmix_gate_fwd, gate_grid(B), 256, 0, st, T1, T2, T2g, B, S, N, m.LDT);
-            RN_LAUNCH_CHECK();
+            if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
             {   // GEMM3: out = x * ([G*H2 | G | 0] [W; b; 0]): K zero-padded NS+N -> KP (a 16-deep k-tile more is cheaper
                 // than a rank-N epilogue update: 215 vs 233 us measured)
                 recnow_gemm_desc d = rn_gemm_desc_zero();
@@ -282,17 +322,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
             d.act = act_inner; d.act_cols = m.NS;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
         }
-        {   // GEMM2: H2_n = act_outer(H1_n V_n), batched over the N experts
-            recnow_gemm_desc d = rn_gemm_desc_zero();
-            d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
-            d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 0;
-            d.C = T2; d.ldc = m.LDT; d.c_batch_stride = S;
-            d.M = (int)B; d.N = S; d.K = S; d.batch = N;
-            d.act = act_outer;
-            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-        }
-        hipLaunchKernelGGL(k_dcnmix_gate_fwd, gate_grid(B), 256, 0, st, T1, T2, T2g, B, S, N, m.LDT);
-        RN_LAUNCH_CHECK();
+        if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
         {   // GEMM3: out = x * (T2g [W; b])
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
@@ -356,6 +386,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     const size_t gemm_ws = mix_gemm_ws(m);
     void* gws = c.take<char>(gemm_ws);                              // split-K slabs of the chain stream
     void* gws2 = c.take<char>(gemm_ws);                             // ... and of the side stream
+    const size_t mid_ws_bytes = rn_mix_mid_bwd_ws_bytes(B, S, N);
+    void* mid_ws = c.take<char>(mid_ws_bytes);
     if (!c.ok()) return RECNOW_EWORKSPACE;
     const float* xmid = (const float*)(sv + (size_t)L * 3 * act_block(m));
     MixEvents evs;
@@ -416,18 +448,10 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.sp_bx = bias_host[l]; d.sp_bx_ks = 1; d.sp_bx_rs = D; d.sp_cx = dT2g + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
             if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
         }
-        MIX_WAIT(e_side_prev, st);          // dC / dT1 (and the g buffer about to be rewritten) are free again
-        hipLaunchKernelGGL(k_dcnmix_gate_bwd, gate_grid(B), 256, 0, st, dT2g, T2, dC, dT1, B, S, N, m.LDT, act_outer);
-        RN_LAUNCH_CHECK();
-        {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n)
-            recnow_gemm_desc d = rn_gemm_desc_zero();
-            d.A = dC; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
-            d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 1;
-            d.C = dT1; d.ldc = m.LDT; d.c_batch_stride = S;
-            d.M = (int)B; d.N = S; d.K = S; d.batch = N;
-            d.emul = T1; d.lde = m.LDT; d.e_batch_stride = S; d.e_mode = RECNOW_OPMODE_ACTGRAD; d.e_act = act_inner;
-            if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
-        }
+        MIX_WAIT(e_side_prev, st);          // dT1 (and the g buffer about to be rewritten) are free again
+        // gate backward, dA_n = (dC_n V_n^T) * act_inner'(H1_n) and dV_n = H1_n^T dC_n
+        if ((rc = mix_mid_bwd(m, dT2g, T2, T1, V_host[l], dC, dT1, dV_host[l], act_inner, act_outer, mid_ws, mid_ws_bytes, gws, gemm_ws, st)))
+            return rc;
         hipEvent_t e_dT1 = nullptr;
         MIX_SIGNAL(e_dT1, st);
         if (l == 0) MIX_WAIT(e_dx, st);     // dx is complete on the side stream before the chain adds the last term
@@ -444,14 +468,6 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         if (l > 0) MIX_SIGNAL(e_g, st);
         // ---------------- side stream, part 2: needs dC / dT1 of this layer
         MIX_WAIT(e_dT1, st2);
-        {   // dV_n = H1_n^T dC_n
-            recnow_gemm_desc d = rn_gemm_desc_zero();
-            d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 1;
-            d.B = dC; d.ldb = m.LDT; d.b_batch_stride = S; d.b_trans = 0;
-            d.C = dV_host[l]; d.ldc = S; d.c_batch_stride = (int64_t)S * S;
-            d.M = S; d.N = S; d.K = (int)B; d.batch = N;
-            if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
-        }
         {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = xl; d.lda = D; d.a_trans = 1;
@@ -508,6 +524,9 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
     float* dT1 = c.take<float>(act_block(m) / sizeof(float));
     float* gbuf0 = c.take<float>(xbuf(m) / sizeof(float));
     float* gbuf1 = c.take<float>(xbuf(m) / sizeof(float));
+    const size_t mid_ws_bytes = rn_mix_mid_bwd_ws_bytes(B, S, N);
+    void* mid_ws = c.take<char>(mid_ws_bytes);
+    if (!c.ok()) return RECNOW_EWORKSPACE;
     void* gws = c.base + c.off;
     const size_t gws_bytes = ws_bytes - c.off;
     const char* sv = (const char*)saved;
@@ -552,25 +571,8 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             dx_started = true;
         }
-        hipLaunchKernelGGL(k_dcnmix_gate_bwd, gate_grid(B), 256, 0, st, dT2g, T2, dC, dT1, B, S, N, m.LDT, act_outer);
-        RN_LAUNCH_CHECK();
-        {   // dV_n = H1_n^T dC_n            (S x S), K = B
-            recnow_gemm_desc d = rn_gemm_desc_zero();
-            d.A = T1; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 1;
-            d.B = dC; d.ldb = m.LDT; d.b_batch_stride = S; d.b_trans = 0;
-            d.C = dV_host[l]; d.ldc = S; d.c_batch_stride = (int64_t)S * S;
-            d.M = S; d.N = S; d.K = (int)B; d.batch = N;
-            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-        }
-        {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n)  -> first NS columns of dT1
-            recnow_gemm_desc d = rn_gemm_desc_zero();
-            d.A = dC; d.lda = m.LDT; d.a_batch_stride = S; d.a_trans = 0;
-            d.B = V_host[l]; d.ldb = S; d.b_batch_stride = (int64_t)S * S; d.b_trans = 1;
-            d.C = dT1; d.ldc = m.LDT; d.c_batch_stride = S;
-            d.M = (int)B; d.N = S; d.K = S; d.batch = N;
-            d.emul = T1; d.lde = m.LDT; d.e_batch_stride = S; d.e_mode = RECNOW_OPMODE_ACTGRAD; d.e_act = act_inner;
-            if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
-        }
+        if ((rc = mix_mid_bwd(m, dT2g, T2, T1, V_host[l], dC, dT1, dV_host[l], act_inner, act_outer, mid_ws, mid_ws_bytes, gws, gws_bytes, st)))
+            return rc;
         {   // dWc1 = x_l^T dT1              -> dU, dgate
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = xl; d.lda = D; d.a_trans = 1;

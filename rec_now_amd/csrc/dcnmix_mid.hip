@@ -1,0 +1,293 @@
+// The sub-space stage of DCNMixLayer, /root/reference/rec_now/layers/dcn_mix_layer.py:137-138 (einsum 'bns,nst->bnt' +
+// activation_outer) and :146-149 (softmax gate and its product with the expert outputs), fused into one streaming kernel
+// per direction.  The S x S products are 1-2 GFLOP per layer at the north-star shape - nothing for the MFMA pipe - while
+// the generic route (batched GEMM + gate kernel; gate-backward kernel + two batched GEMMs) costs five launches that each
+// stream the (B, N*S) activations through HBM again.  Here a workgroup keeps every expert's S x S matrix in LDS, walks
+// 32-row tiles of the activations, and does all of it per tile:
+//   forward : T2 = [act_outer(H1_n V_n) | G | 0],  T2g = [G_n * H2_n | G | 0],  G = softmax(logits)   (logits = T1[:, NS:NS+N])
+//   backward: dC = G_n * dT2g * act_outer'(H2);  dlogits = G * (dG - <G, dG>),  dG_n = <dT2g_n, H2_n> + dT2g[:, NS+n];
+//             dT1 = [(dC_n V_n^T) * act_inner'(H1_n) | dlogits | 0];  dV_n = H1_n^T dC_n accumulated in AGPRs over the
+//             workgroup's tiles, written as one partial per workgroup and summed in a fixed order (deterministic).
+// dC never goes to HBM.  Products use v_mfma_f32_32x32x2_f32 (exact fp32) on 32x32 output blocks; LDS tiles are row-major
+// with an odd row stride so the per-lane ds_read_b32 of both operand shapes is bank-conflict free.
+#include "common.hpp"
+#include "dcnmix_mid.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MID_ROWS 32          // rows per tile
+#define MID_NMAX 8           // experts (registers of the gate code)
+#define MID_VITEMS 4         // dV output blocks per wave
+
+static inline size_t mid_fwd_lds(int S, int N) { return ((size_t)N * S * S + (size_t)MID_ROWS * (N * S + 1) + (size_t)MID_ROWS * N) * sizeof(float); }
+static inline size_t mid_bwd_lds(int S, int N) {
+    return ((size_t)N * S * S + 2 * (size_t)MID_ROWS * (N * S + 1) + 2 * (size_t)MID_ROWS * N) * sizeof(float);
+}
+
+bool rn_mix_mid_supported(int S, int N, int LDT) {
+    if (S != 32 && S != 64) return false;
+    if (N < 1 || N > MID_NMAX) return false;
+    if (N * (S / 32) * (S / 32) > 4 * MID_VITEMS) return false;
+    if (LDT % 4 != 0) return false;
+    return mid_bwd_lds(S, N) <= 140 * 1024;
+}
+
+static inline int mid_grid(int64_t B) {
+    const int64_t tiles = (B + MID_ROWS - 1) / MID_ROWS;
+    return (int)(tiles < 512 ? (tiles > 0 ? tiles : 1) : 512);
+}
+
+size_t rn_mix_mid_bwd_ws_bytes(int64_t B, int S, int N) { return rn_align((size_t)mid_grid(B) * N * S * S * sizeof(float)); }
+
+template <int S>
+__global__ void __launch_bounds__(256)
+k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* __restrict__ T2, float* __restrict__ T2g, int64_t B,
+              int N, int LDT, int act_outer) {
+    extern __shared__ float lds[];
+    const int NS = N * S, LDA = NS + 1;
+    float* Vs = lds;                       // [n][k][col]
+    float* As = Vs + N * S * S;            // [row][NS] stride LDA
+    float* Gs = As + MID_ROWS * LDA;       // [row][n]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid * 4; i < N * S * S; i += 1024) *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(V + i);
+    const int64_t ntiles = (B + MID_ROWS - 1) / MID_ROWS;
+    const int cpr = NS / 4;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * MID_ROWS;
+        __syncthreads();
+        for (int c = tid; c < MID_ROWS * cpr; c += 256) {
+            const int r = c / cpr, k4 = (c - r * cpr) * 4;
+            const int64_t row = r0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < B) v = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
+            float* d = As + r * LDA + k4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        if (tid < MID_ROWS) {
+            const int64_t row = r0 + tid;
+            if (row < B) {
+                float lg[MID_NMAX];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int n = 0; n < MID_NMAX; ++n) {
+                    lg[n] = n < N ? T1[row * LDT + NS + n] : -INFINITY;
+                    mx = lg[n] > mx ? lg[n] : mx;
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int n = 0; n < MID_NMAX; ++n) {
+                    lg[n] = n < N ? expf(lg[n] - mx) : 0.f;
+                    sum += lg[n];
+                }
+#pragma unroll
+                for (int n = 0; n < MID_NMAX; ++n)
+                    if (n < N) {
+                        const float g = lg[n] / sum;
+                        Gs[tid * N + n] = g;
+                        T2[row * LDT + NS + n] = g;
+                        T2g[row * LDT + NS + n] = g;
+                    }
+                for (int c = NS + N; c < LDT; ++c) { T2[row * LDT + c] = 0.f; T2g[row * LDT + c] = 0.f; }
+            } else {
+                for (int n = 0; n < N; ++n) Gs[tid * N + n] = 0.f;
+            }
+        }
+        __syncthreads();
+        const int nitems = N * (S / 32);
+        for (int item = w; item < nitems; item += 4) {                    // wave-uniform
+            const int n = item / (S / 32), cb = item - n * (S / 32);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = As + (lane & 31) * LDA + n * S + (lane >> 5);
+            const float* bp = Vs + n * S * S + (lane >> 5) * S + cb * 32 + (lane & 31);
+#pragma unroll 8
+            for (int st = 0; st < S / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], bp[2 * st * S], acc, 0, 0, 0);
+            const int col = n * S + cb * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t row = r0 + rr;
+                const float h2 = rn_act(acc[r], act_outer);
+                if (row < B) {
+                    T2[row * LDT + col] = h2;
+                    T2g[row * LDT + col] = Gs[rr * N + n] * h2;
+                }
+            }
+        }
+    }
+}
+
+template <int S>
+__global__ void __launch_bounds__(256)
+k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1, const float* __restrict__ V,
+              float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B, int N, int LDT, int act_inner, int act_outer) {
+    extern __shared__ float lds[];
+    const int NS = N * S, LDA = NS + 1;
+    float* VTs = lds;                      // [n][t][s] = V[n][s][t]
+    float* Cs = VTs + N * S * S;           // dC tile
+    float* Hs = Cs + MID_ROWS * LDA;       // H1 tile
+    float* Ps = Hs + MID_ROWS * LDA;       // [row][n]  <dT2g_n, H2_n>
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < N * S * S; i += 256) {
+        const int n = i / (S * S), rem = i - n * S * S, s = rem / S, t = rem - s * S;
+        VTs[n * S * S + t * S + s] = V[i];
+    }
+    f32x16 accV[MID_VITEMS];
+#pragma unroll
+    for (int j = 0; j < MID_VITEMS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accV[j][r] = 0.f;
+    const int64_t ntiles = (B + MID_ROWS - 1) / MID_ROWS;
+    const int cpr = NS / 4;
+    constexpr int GL = S / 4;              // lanes holding one (row, expert) segment
+    const int nvitems = N * (S / 32) * (S / 32);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * MID_ROWS;
+        __syncthreads();
+        for (int c = tid; c < MID_ROWS * cpr; c += 256) {                 // trip count is block-uniform (NS % 32 == 0)
+            const int r = c / cpr, k4 = (c - r * cpr) * 4, n = k4 / S;
+            const int64_t row = r0 + r;
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f), h = d, a = d;
+            float g = 0.f;
+            if (row < B) {
+                d = *reinterpret_cast<const float4*>(dT2g + row * LDT + k4);
+                h = *reinterpret_cast<const float4*>(T2 + row * LDT + k4);
+                a = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
+                g = T2[row * LDT + NS + n];
+            }
+            float* cd = Cs + r * LDA + k4;
+            cd[0] = g * d.x * rn_act_grad_from_out(h.x, act_outer);
+            cd[1] = g * d.y * rn_act_grad_from_out(h.y, act_outer);
+            cd[2] = g * d.z * rn_act_grad_from_out(h.z, act_outer);
+            cd[3] = g * d.w * rn_act_grad_from_out(h.w, act_outer);
+            float* hd = Hs + r * LDA + k4;
+            hd[0] = a.x; hd[1] = a.y; hd[2] = a.z; hd[3] = a.w;
+            float p = d.x * h.x + d.y * h.y + d.z * h.z + d.w * h.w;
+#pragma unroll
+            for (int o = GL / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+            if ((c & (GL - 1)) == 0) Ps[r * N + n] = p;
+        }
+        __syncthreads();
+        if (tid < MID_ROWS) {
+            const int64_t row = r0 + tid;
+            if (row < B) {
+                float g[MID_NMAX], dg[MID_NMAX];
+                float dot = 0.f;
+#pragma unroll
+                for (int n = 0; n < MID_NMAX; ++n) {
+                    g[n] = n < N ? T2[row * LDT + NS + n] : 0.f;
+                    dg[n] = n < N ? Ps[tid * N + n] + dT2g[row * LDT + NS + n] : 0.f;
+                    dot += g[n] * dg[n];
+                }
+#pragma unroll
+                for (int n = 0; n < MID_NMAX; ++n)
+                    if (n < N) dT1[row * LDT + NS + n] = g[n] * (dg[n] - dot);
+                for (int c = NS + N; c < LDT; ++c) dT1[row * LDT + c] = 0.f;
+            }
+        }
+        // dA_n = (dC_n V_n^T) * act_inner'(H1_n): 32x32 output blocks (n, cb)
+        const int nitems = N * (S / 32);
+        for (int item = w; item < nitems; item += 4) {
+            const int n = item / (S / 32), cb = item - n * (S / 32);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = Cs + (lane & 31) * LDA + n * S + (lane >> 5);
+            const float* bp = VTs + n * S * S + (lane >> 5) * S + cb * 32 + (lane & 31);
+#pragma unroll 8
+            for (int st = 0; st < S / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], bp[2 * st * S], acc, 0, 0, 0);
+            const int col = n * S + cb * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t row = r0 + rr;
+                if (row < B) dT1[row * LDT + col] = acc[r] * rn_act_grad_from_out(Hs[rr * LDA + col], act_inner);
+            }
+        }
+        // dV_n += H1_n^T dC_n over this tile's 32 rows: output blocks (n, mb, cb) stay in registers across tiles
+#pragma unroll
+        for (int j = 0; j < MID_VITEMS; ++j) {
+            const int item = w + 4 * j;
+            if (item < nvitems) {
+                const int n = item / ((S / 32) * (S / 32)), rem = item - n * (S / 32) * (S / 32), mb = rem / (S / 32), cb = rem - mb * (S / 32);
+                const float* ap = Hs + (lane >> 5) * LDA + n * S + mb * 32 + (lane & 31);
+                const float* bp = Cs + (lane >> 5) * LDA + n * S + cb * 32 + (lane & 31);
+#pragma unroll 8
+                for (int st = 0; st < MID_ROWS / 2; ++st)
+                    accV[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st * LDA], bp[2 * st * LDA], accV[j], 0, 0, 0);
+            }
+        }
+    }
+    float* P = dVpart + (int64_t)blockIdx.x * N * S * S;
+#pragma unroll
+    for (int j = 0; j < MID_VITEMS; ++j) {
+        const int item = w + 4 * j;
+        if (item < nvitems) {
+            const int n = item / ((S / 32) * (S / 32)), rem = item - n * (S / 32) * (S / 32), mb = rem / (S / 32), cb = rem - mb * (S / 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                P[n * S * S + (mb * 32 + rr) * S + cb * 32 + (lane & 31)] = accV[j][r];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mix_dv_reduce(const float* __restrict__ part, int nparts, int total, float* __restrict__ dV) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= nparts; g += 4) {
+        s0 += part[(int64_t)g * total + i];
+        s1 += part[(int64_t)(g + 1) * total + i];
+        s2 += part[(int64_t)(g + 2) * total + i];
+        s3 += part[(int64_t)(g + 3) * total + i];
+    }
+    for (; g < nparts; ++g) s0 += part[(int64_t)g * total + i];
+    dV[i] = (s0 + s1) + (s2 + s3);
+}
+
+template <typename K>
+static int mid_allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) RN_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return RECNOW_OK;
+}
+
+int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64_t B, int S, int N, int LDT, int act_outer, hipStream_t st) {
+    if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
+    const size_t lds = mid_fwd_lds(S, N);
+    int rc;
+    if (S == 32) {
+        if ((rc = mid_allow_lds(k_mix_mid_fwd<32>, lds))) return rc;
+        hipLaunchKernelGGL(k_mix_mid_fwd<32>, mid_grid(B), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
+    } else {
+        if ((rc = mid_allow_lds(k_mix_mid_fwd<64>, lds))) return rc;
+        hipLaunchKernelGGL(k_mix_mid_fwd<64>, mid_grid(B), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
+    }
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const float* V, float* dT1, float* dV, int64_t B, int S, int N,
+                   int LDT, int act_inner, int act_outer, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
+    if (ws_bytes < rn_mix_mid_bwd_ws_bytes(B, S, N)) return RECNOW_EWORKSPACE;
+    const size_t lds = mid_bwd_lds(S, N);
+    const int grid = mid_grid(B);
+    float* part = (float*)ws;
+    int rc;
+    if (S == 32) {
+        if ((rc = mid_allow_lds(k_mix_mid_bwd<32>, lds))) return rc;
+        hipLaunchKernelGGL(k_mix_mid_bwd<32>, grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer);
+    } else {
+        if ((rc = mid_allow_lds(k_mix_mid_bwd<64>, lds))) return rc;
+        hipLaunchKernelGGL(k_mix_mid_bwd<64>, grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer);
+    }
+    RN_LAUNCH_CHECK();
+    const int total = N * S * S;
+    hipLaunchKernelGGL(k_mix_dv_reduce, rn_cdiv(total, 256), 256, 0, st, part, grid, total, dV);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
