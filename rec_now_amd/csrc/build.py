@@ -10,6 +10,8 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'librecnow_hip.so')
 OBJ_DIR = os.path.join(HERE, 'build')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+if os.environ.get('RECNOW_TRACE') == '1':        # diagnostic build: per-workgroup timestamps in the GEMM kernels (tools/gemm_trace.py)
+    FLAGS.append('-DRN_GEMM_TRACE')
 
 
 def _newer(src, dst, deps):

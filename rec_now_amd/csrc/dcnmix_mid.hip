@@ -17,7 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MID_ROWS 32          // rows per tile
 #define MID_NMAX 8           // experts (registers of the gate code)
-#define MID_VITEMS 4         // dV output blocks per wave
+#define MID_VITEMS 4         // max dV output blocks per wave
+#define MID_PRE 4            // float4 chunks per thread prefetched one tile ahead (covers N*S <= 128)
 
 static inline size_t mid_fwd_lds(int S, int N) { return ((size_t)N * S * S + (size_t)MID_ROWS * (N * S + 1) + (size_t)MID_ROWS * N) * sizeof(float); }
 static inline size_t mid_bwd_lds(int S, int N) {
@@ -40,7 +41,7 @@ static inline int mid_grid(int64_t B) {
 size_t rn_mix_mid_bwd_ws_bytes(int64_t B, int S, int N) { return rn_align((size_t)mid_grid(B) * N * S * S * sizeof(float)); }
 
 template <int S>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* __restrict__ T2, float* __restrict__ T2g, int64_t B,
               int N, int LDT, int act_outer) {
     extern __shared__ float lds[];
@@ -52,14 +53,39 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
     for (int i = tid * 4; i < N * S * S; i += 1024) *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(V + i);
     const int64_t ntiles = (B + MID_ROWS - 1) / MID_ROWS;
     const int cpr = NS / 4;
+    const int nch = MID_ROWS * cpr / 256;          // float4 chunks per thread and tile (NS % 32 == 0)
+    // The next tile's rows are fetched into registers before this tile's MFMA phase: HBM latency hides under it.
+    float4 pv[MID_PRE];
+    float plg[MID_NMAX];
+    auto prefetch = [&](int64_t r0) {
+#pragma unroll
+        for (int i = 0; i < MID_PRE; ++i) {
+            pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nch) {
+                const int c = tid + 256 * i, r = c / cpr, k4 = (c - r * cpr) * 4;
+                if (r0 + r < B) pv[i] = *reinterpret_cast<const float4*>(T1 + (r0 + r) * LDT + k4);
+            }
+        }
+        if (tid < MID_ROWS) {
+#pragma unroll
+            for (int n = 0; n < MID_NMAX; ++n) plg[n] = (n < N && r0 + tid < B) ? T1[(r0 + tid) * LDT + NS + n] : -INFINITY;
+        }
+    };
+    prefetch((int64_t)blockIdx.x * MID_ROWS);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * MID_ROWS;
         __syncthreads();
-        for (int c = tid; c < MID_ROWS * cpr; c += 256) {
-            const int r = c / cpr, k4 = (c - r * cpr) * 4;
-            const int64_t row = r0 + r;
+#pragma unroll
+        for (int i = 0; i < MID_PRE; ++i)
+            if (i < nch) {
+                const int c = tid + 256 * i, r = c / cpr, k4 = (c - r * cpr) * 4;
+                float* d = As + r * LDA + k4;
+                d[0] = pv[i].x; d[1] = pv[i].y; d[2] = pv[i].z; d[3] = pv[i].w;
+            }
+        for (int i = MID_PRE; i < nch; ++i) {        // wider than the prefetch registers (N*S > 128): fetched in place
+            const int c = tid + 256 * i, r = c / cpr, k4 = (c - r * cpr) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < B) v = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
+            if (r0 + r < B) v = *reinterpret_cast<const float4*>(T1 + (r0 + r) * LDT + k4);
             float* d = As + r * LDA + k4;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
@@ -69,14 +95,11 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
                 float lg[MID_NMAX];
                 float mx = -INFINITY;
 #pragma unroll
-                for (int n = 0; n < MID_NMAX; ++n) {
-                    lg[n] = n < N ? T1[row * LDT + NS + n] : -INFINITY;
-                    mx = lg[n] > mx ? lg[n] : mx;
-                }
+                for (int n = 0; n < MID_NMAX; ++n) mx = plg[n] > mx ? plg[n] : mx;
                 float sum = 0.f;
 #pragma unroll
                 for (int n = 0; n < MID_NMAX; ++n) {
-                    lg[n] = n < N ? expf(lg[n] - mx) : 0.f;
+                    lg[n] = n < N ? expf(plg[n] - mx) : 0.f;
                     sum += lg[n];
                 }
 #pragma unroll
@@ -93,6 +116,7 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
             }
         }
         __syncthreads();
+        if (tile + gridDim.x < ntiles) prefetch((tile + gridDim.x) * MID_ROWS);
         const int nitems = N * (S / 32);
         for (int item = w; item < nitems; item += 4) {                    // wave-uniform
             const int n = item / (S / 32), cb = item - n * (S / 32);
@@ -118,8 +142,8 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
     }
 }
 
-template <int S>
-__global__ void __launch_bounds__(256)
+template <int S, int VI>
+__global__ void __launch_bounds__(256, 2)
 k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1, const float* __restrict__ V,
               float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B, int N, int LDT, int act_inner, int act_outer) {
     extern __shared__ float lds[];
@@ -133,59 +157,88 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
         const int n = i / (S * S), rem = i - n * S * S, s = rem / S, t = rem - s * S;
         VTs[n * S * S + t * S + s] = V[i];
     }
-    f32x16 accV[MID_VITEMS];
+    f32x16 accV[VI];
 #pragma unroll
-    for (int j = 0; j < MID_VITEMS; ++j)
+    for (int j = 0; j < VI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accV[j][r] = 0.f;
     const int64_t ntiles = (B + MID_ROWS - 1) / MID_ROWS;
     const int cpr = NS / 4;
     constexpr int GL = S / 4;              // lanes holding one (row, expert) segment
     const int nvitems = N * (S / 32) * (S / 32);
+    const int nch = MID_ROWS * cpr / 256;          // float4 chunks per thread and tile: block-uniform (NS % 32 == 0)
+    float4 pd[MID_PRE], ph[MID_PRE], pa[MID_PRE];
+    float pg[MID_PRE];
+    float pgg[MID_NMAX], pdg[MID_NMAX];            // gate row of thread tid < 32
+    auto fetch = [&](int64_t r0, int i, float4& d, float4& h, float4& a, float& g) {
+        const int c = tid + 256 * i, r = c / cpr, k4 = (c - r * cpr) * 4, n = k4 / S;
+        const int64_t row = r0 + r;
+        d = make_float4(0.f, 0.f, 0.f, 0.f); h = d; a = d; g = 0.f;
+        if (row < B) {
+            d = *reinterpret_cast<const float4*>(dT2g + row * LDT + k4);
+            h = *reinterpret_cast<const float4*>(T2 + row * LDT + k4);
+            a = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
+            g = T2[row * LDT + NS + n];
+        }
+    };
+    auto stage = [&](int i, const float4& d, const float4& h, const float4& a, float g) {
+        const int c = tid + 256 * i, r = c / cpr, k4 = (c - r * cpr) * 4, n = k4 / S;
+        float* cd = Cs + r * LDA + k4;
+        cd[0] = g * d.x * rn_act_grad_from_out(h.x, act_outer);
+        cd[1] = g * d.y * rn_act_grad_from_out(h.y, act_outer);
+        cd[2] = g * d.z * rn_act_grad_from_out(h.z, act_outer);
+        cd[3] = g * d.w * rn_act_grad_from_out(h.w, act_outer);
+        float* hd = Hs + r * LDA + k4;
+        hd[0] = a.x; hd[1] = a.y; hd[2] = a.z; hd[3] = a.w;
+        float p = d.x * h.x + d.y * h.y + d.z * h.z + d.w * h.w;
+#pragma unroll
+        for (int o = GL / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);      // all 64 lanes run every chunk
+        if ((c & (GL - 1)) == 0) Ps[r * N + n] = p;
+    };
+    auto prefetch = [&](int64_t r0) {
+#pragma unroll
+        for (int i = 0; i < MID_PRE; ++i)
+            if (i < nch) fetch(r0, i, pd[i], ph[i], pa[i], pg[i]);
+        if (tid < MID_ROWS) {
+#pragma unroll
+            for (int n = 0; n < MID_NMAX; ++n) {
+                const bool ok = n < N && r0 + tid < B;
+                pgg[n] = ok ? T2[(r0 + tid) * LDT + NS + n] : 0.f;
+                pdg[n] = ok ? dT2g[(r0 + tid) * LDT + NS + n] : 0.f;
+            }
+        }
+    };
+    prefetch((int64_t)blockIdx.x * MID_ROWS);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * MID_ROWS;
         __syncthreads();
-        for (int c = tid; c < MID_ROWS * cpr; c += 256) {                 // trip count is block-uniform (NS % 32 == 0)
-            const int r = c / cpr, k4 = (c - r * cpr) * 4, n = k4 / S;
-            const int64_t row = r0 + r;
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f), h = d, a = d;
-            float g = 0.f;
-            if (row < B) {
-                d = *reinterpret_cast<const float4*>(dT2g + row * LDT + k4);
-                h = *reinterpret_cast<const float4*>(T2 + row * LDT + k4);
-                a = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
-                g = T2[row * LDT + NS + n];
-            }
-            float* cd = Cs + r * LDA + k4;
-            cd[0] = g * d.x * rn_act_grad_from_out(h.x, act_outer);
-            cd[1] = g * d.y * rn_act_grad_from_out(h.y, act_outer);
-            cd[2] = g * d.z * rn_act_grad_from_out(h.z, act_outer);
-            cd[3] = g * d.w * rn_act_grad_from_out(h.w, act_outer);
-            float* hd = Hs + r * LDA + k4;
-            hd[0] = a.x; hd[1] = a.y; hd[2] = a.z; hd[3] = a.w;
-            float p = d.x * h.x + d.y * h.y + d.z * h.z + d.w * h.w;
 #pragma unroll
-            for (int o = GL / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-            if ((c & (GL - 1)) == 0) Ps[r * N + n] = p;
+        for (int i = 0; i < MID_PRE; ++i)
+            if (i < nch) stage(i, pd[i], ph[i], pa[i], pg[i]);
+        for (int i = MID_PRE; i < nch; ++i) {        // wider than the prefetch registers (N*S > 128): fetched in place
+            float4 d, h, a;
+            float g;
+            fetch(r0, i, d, h, a, g);
+            stage(i, d, h, a, g);
         }
         __syncthreads();
         if (tid < MID_ROWS) {
             const int64_t row = r0 + tid;
             if (row < B) {
-                float g[MID_NMAX], dg[MID_NMAX];
+                float dg[MID_NMAX];
                 float dot = 0.f;
 #pragma unroll
                 for (int n = 0; n < MID_NMAX; ++n) {
-                    g[n] = n < N ? T2[row * LDT + NS + n] : 0.f;
-                    dg[n] = n < N ? Ps[tid * N + n] + dT2g[row * LDT + NS + n] : 0.f;
-                    dot += g[n] * dg[n];
+                    dg[n] = n < N ? Ps[tid * N + n] + pdg[n] : 0.f;
+                    dot += pgg[n] * dg[n];
                 }
 #pragma unroll
                 for (int n = 0; n < MID_NMAX; ++n)
-                    if (n < N) dT1[row * LDT + NS + n] = g[n] * (dg[n] - dot);
+                    if (n < N) dT1[row * LDT + NS + n] = pgg[n] * (dg[n] - dot);
                 for (int c = NS + N; c < LDT; ++c) dT1[row * LDT + c] = 0.f;
             }
         }
+        if (tile + gridDim.x < ntiles) prefetch((tile + gridDim.x) * MID_ROWS);
         // dA_n = (dC_n V_n^T) * act_inner'(H1_n): 32x32 output blocks (n, cb)
         const int nitems = N * (S / 32);
         for (int item = w; item < nitems; item += 4) {
@@ -207,7 +260,7 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
         }
         // dV_n += H1_n^T dC_n over this tile's 32 rows: output blocks (n, mb, cb) stay in registers across tiles
 #pragma unroll
-        for (int j = 0; j < MID_VITEMS; ++j) {
+        for (int j = 0; j < VI; ++j) {
             const int item = w + 4 * j;
             if (item < nvitems) {
                 const int n = item / ((S / 32) * (S / 32)), rem = item - n * (S / 32) * (S / 32), mb = rem / (S / 32), cb = rem - mb * (S / 32);
@@ -221,7 +274,7 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
     }
     float* P = dVpart + (int64_t)blockIdx.x * N * S * S;
 #pragma unroll
-    for (int j = 0; j < MID_VITEMS; ++j) {
+    for (int j = 0; j < VI; ++j) {
         const int item = w + 4 * j;
         if (item < nvitems) {
             const int n = item / ((S / 32) * (S / 32)), rem = item - n * (S / 32) * (S / 32), mb = rem / (S / 32), cb = rem - mb * (S / 32);
@@ -234,19 +287,30 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
     }
 }
 
-__global__ void __launch_bounds__(256) k_mix_dv_reduce(const float* __restrict__ part, int nparts, int total, float* __restrict__ dV) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = 0;
-    for (; g + 4 <= nparts; g += 4) {
-        s0 += part[(int64_t)g * total + i];
-        s1 += part[(int64_t)(g + 1) * total + i];
-        s2 += part[(int64_t)(g + 2) * total + i];
-        s3 += part[(int64_t)(g + 3) * total + i];
+// dV[i] = sum over workgroup partials, fixed order: 64 elements x 16 strided part groups per block, then a 16-term LDS sum.
+__global__ void __launch_bounds__(1024) k_mix_dv_reduce(const float* __restrict__ part, int nparts, int total, float* __restrict__ dV) {
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + e;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    if (i < total) {
+        int g = q;
+        for (; g + 16 * 7 < nparts; g += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += part[(int64_t)(g + 16 * u) * total + i];
+        }
+        for (; g < nparts; g += 16) s[0] += part[(int64_t)g * total + i];
     }
-    for (; g < nparts; ++g) s0 += part[(int64_t)g * total + i];
-    dV[i] = (s0 + s1) + (s2 + s3);
+    red[q][e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (q == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += red[u][e];
+        dV[i] = t;
+    }
 }
 
 template <typename K>
@@ -278,16 +342,24 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
     const int grid = mid_grid(B);
     float* part = (float*)ws;
     int rc;
+    const int vi = (N * (S / 32) * (S / 32) + 3) / 4;          // dV output blocks per wave
+#define MID_BWD(SS, VV)                                                                                                       \
+    do {                                                                                                                      \
+        if ((rc = mid_allow_lds(k_mix_mid_bwd<SS, VV>, lds))) return rc;                                                      \
+        hipLaunchKernelGGL((k_mix_mid_bwd<SS, VV>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer); \
+    } while (0)
     if (S == 32) {
-        if ((rc = mid_allow_lds(k_mix_mid_bwd<32>, lds))) return rc;
-        hipLaunchKernelGGL(k_mix_mid_bwd<32>, grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer);
+        if (vi <= 1) MID_BWD(32, 1);
+        else MID_BWD(32, 2);
     } else {
-        if ((rc = mid_allow_lds(k_mix_mid_bwd<64>, lds))) return rc;
-        hipLaunchKernelGGL(k_mix_mid_bwd<64>, grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer);
+        if (vi <= 1) MID_BWD(64, 1);
+        else if (vi <= 2) MID_BWD(64, 2);
+        else MID_BWD(64, 4);
     }
+#undef MID_BWD
     RN_LAUNCH_CHECK();
     const int total = N * S * S;
-    hipLaunchKernelGGL(k_mix_dv_reduce, rn_cdiv(total, 256), 256, 0, st, part, grid, total, dV);
+    hipLaunchKernelGGL(k_mix_dv_reduce, rn_cdiv(total, 64), 1024, 0, st, part, grid, total, dV);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

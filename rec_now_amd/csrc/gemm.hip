@@ -153,6 +153,10 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     if (d->sp_r > 0 && (!d->sp_bx || !d->sp_cx || d->batch != 1)) return RECNOW_EINVAL;
     if (d->eu_r > 0 && (!d->eu_p || !d->eu_q || d->batch != 1)) return RECNOW_EINVAL;
     pick_split(d, c, &k.splitk, &k.kchunk);
+    k.trace = nullptr;
+#ifdef RN_GEMM_TRACE
+    if (const char* t = getenv("RECNOW_GEMM_TRACE")) k.trace = (long long*)strtoull(t, nullptr, 10);
+#endif
     if (k.splitk > 1) {
         const size_t need = rn_align((size_t)k.splitk * d->batch * d->M * k.npart * sizeof(float));
         if (!ws || ws_bytes < need) return RECNOW_EWORKSPACE;
@@ -179,6 +183,10 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
         if (edge || c.BM != 128 || c.BN != 128) return RECNOW_EUNSUPPORTED;
         rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
+    } else if (!edge && bk16 && c.BN == 128 && a_kc && k.splitk == 1 && d->batch == 1 && d->a_mode == 0 && d->b_mode == 0 &&
+               !d->bias && d->act == RECNOW_ACT_LINEAR && !d->c_trans && (!d->emul || d->e_mode == RECNOW_OPMODE_MUL)) {
+        // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)
+        rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), st);
     } else if (!edge && c.BM == 128) {
         const int bk = bk16 ? 16 : 32;
         rc = (c.BN == 160) ? rn_gemm_launch_lean160(k, a_kc, b_kc, bk, d->a_mode, d->b_mode, grid, st)

@@ -32,7 +32,13 @@ struct GemmK {
     int64_t eu_pms, eu_qrs, eu_qns;
     int eu_r;
     int npart;                 // row width of a split-K slab: N, or N + 4 when a side product rides along
+    long long* trace;          // RN_GEMM_TRACE builds only: 8 int64 per workgroup (phase timestamps, HW id)
 };
+
+// Order one wave's LDS writes against its own later LDS reads (and reads against later overwrites).  DS instructions of a
+// wave execute in issue order, so only the compiler has to be stopped from moving them; waiting on lgkmcnt alone (not a
+// fence, which also drains vmcnt) keeps the epilogue's global stores asynchronous.
+#define RN_LDS_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ f32x4 mk4(float a, float b, float c, float d) {
     f32x4 r;
@@ -231,6 +237,15 @@ k_gemm(const GemmK p) {
     f32x4 spacc = mk4(0.f, 0.f, 0.f, 0.f);
     float bxr[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifdef RN_GEMM_TRACE      // per-workgroup phase timestamps for tools/gemm_trace.py (build with RECNOW_TRACE=1)
+#define RN_TR(i) do { if (p.trace && threadIdx.x == 0) p.trace[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8ll + (i)] = wall_clock64(); } while (0)
+    if (p.trace && threadIdx.x == 0)
+        p.trace[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8ll + 4] =
+            __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11)) | ((long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) << 32);
+#else
+#define RN_TR(i) do { } while (0)
+#endif
+    RN_TR(0);
     const int z = blockIdx.z, bidx = z / p.splitk, ks = z % p.splitk;
     const int k_begin = ks * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
@@ -278,6 +293,7 @@ k_gemm(const GemmK p) {
         }
     }
     __syncthreads();
+    RN_TR(1);
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
@@ -360,6 +376,7 @@ k_gemm(const GemmK p) {
         __syncthreads();
     }
 
+    RN_TR(2);
     // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     if constexpr (!EDGE) {
@@ -420,9 +437,7 @@ k_gemm(const GemmK p) {
                 if (biasb) bv = *reinterpret_cast<const float4*>(biasb + col0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + row_l) * 36 + col_l] = acc[i][j][r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                RN_LDS_WAVE_SYNC();
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 a = *reinterpret_cast<const float4*>(stg + (q * 8 + rr0) * 36 + cc);
@@ -452,10 +467,10 @@ k_gemm(const GemmK p) {
                         for (int e = 0; e < 4; ++e) Cb[(int64_t)(col0 + e) * ldc + rw] = v[e];
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                RN_LDS_WAVE_SYNC();
             }
         }
+        RN_TR(3);
         return;
     } else {
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);          // block-uniform
@@ -533,3 +548,5 @@ static inline void rn_gemm_launch_one(const GemmK& k, dim3 grid, hipStream_t st)
     hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, EDGE, A2K, B2K, XF>), grid, GEMM_THREADS, lds, st, k);
 }
 int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k, int b2k, int xf, dim3 grid, hipStream_t st);
+// persistent short-K kernel (gemm_shortk.hip): ep = (emul ? 1 : 0) | (accumulate ? 2 : 0)
+int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, hipStream_t st);

@@ -1,0 +1,218 @@
+// Persistent short-K GEMM:  C[M][N] = (A[M][K] B) [* emul] [+ C],  K <= 512, exact fp32 on v_mfma_f32_32x32x2_f32.
+//
+// The K = N*S+N (= 130 -> 144) deep products of DCNMixLayer (reference rec_now/layers/dcn_mix_layer.py:141-143 and their
+// backward) have 4096 output tiles of 128x128 with only nine 16-deep k-tiles each.  Launched as one workgroup per tile
+// (k_gemm) every tile pays an exposed prologue (first operand fetch, ~3 us) and epilogue (4-16 us) around a ~31 us main loop
+// that shares the CU's MFMA pipe four ways; per-workgroup timestamps (tools/gemm_trace.py) show the four co-resident
+// workgroups of a CU running those phases in lockstep, so the pipe idles a quarter of the time.
+// Here the grid is one wave of co-resident workgroups (4 per CU) that each walk a list of tiles:
+//   * the next tile's first k-tile is fetched under the current tile's last MFMA step and parked in the free LDS buffer, so
+//     a workgroup goes from epilogue straight into MFMAs: there is no prologue after the first tile;
+//   * the epilogue requests the operands of sub-tile s+1 before it stages and stores sub-tile s, and never waits on a store;
+//   * tiles are handed out XCD-aware: workgroup b runs on XCD b % 8 (round-robin dispatch), and the 8 column tiles of one
+//     row tile go to consecutive workgroups of the SAME XCD, so the A row-panel is fetched into one L2 instead of eight.
+#include "gemm_kernel.hpp"
+
+#define SK_BM 128
+#define SK_BN 128
+#define SK_BK 16
+
+template <bool B_KC, int EP>
+__global__ void __launch_bounds__(GEMM_THREADS, (EP == 3 ? 3 : 4))
+k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
+    using TA = Tile<SK_BM, SK_BK, true>;
+    using TB = Tile<SK_BN, SK_BK, B_KC>;
+    constexpr int A_SZ = SK_BK * TA::LD, B_SZ = SK_BK * TB::LD, BUF = A_SZ + B_SZ;
+    static_assert(4 * 16 * 36 <= BUF, "half sub-tile staging of 4 waves fits one operand buffer");
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // [A0 | B0 | A1 | B1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int a_off = (lane >> 5) * TA::LD + wm * 64 + (lane & 31);
+    const int b_off = (lane >> 5) * TB::LD + wn * 64 + (lane & 31);
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    const int rr0 = lane >> 3, cc = (lane & 7) * 4;
+    const unsigned e_lane = (unsigned)((wm * 64 + rr0) * p.lde + wn * 64 + cc);     // this lane's element inside a tile of emul / C
+    const unsigned c_lane = (unsigned)((wm * 64 + rr0) * p.ldc + wn * 64 + cc);
+    const int nk = p.K / SK_BK;
+    const int ntiles = row_tiles * col_tiles;
+
+    // slot (= workgroup index + round * grid) -> tile.  XCD-aware: slots of one XCD enumerate (row tile, column tile) with
+    // the column tile fastest; row tiles are dealt round-robin to the 8 XCDs.
+    auto tile_of = [&](int slot, int& m0, int& n0) {
+        int rt, ct;
+        if (xcd_aware) {
+            const int xcd = slot & 7, idx = slot >> 3;
+            rt = (idx / col_tiles) * 8 + xcd;
+            ct = idx % col_tiles;
+        } else {
+            rt = slot / col_tiles;
+            ct = slot % col_tiles;
+        }
+        m0 = rt * SK_BM;
+        n0 = ct * SK_BN;
+    };
+
+    TA ta;
+    TB tb;
+    ta.init(p.lda);
+    tb.init(p.ldb);
+    int slot = blockIdx.x;
+    if (slot >= ntiles) return;
+    int m0, n0;
+    tile_of(slot, m0, n0);
+    ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0, 0);
+    tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0, 0);
+    ta.store(smem);
+    tb.store(smem + A_SZ);
+    __syncthreads();
+    int f = 0;                                     // buffer holding k-tile 0 of the current tile
+    for (; slot < ntiles; slot += gridDim.x) {
+        const int nslot = slot + gridDim.x;
+        const bool has_next = nslot < ntiles;
+        int m0n = 0, n0n = 0;
+        if (has_next) tile_of(nslot, m0n, n0n);
+#ifdef RN_GEMM_TRACE
+#define SK_TR(i) do { if (p.trace && threadIdx.x == 0) p.trace[(long long)slot * 8 + (i)] = wall_clock64(); } while (0)
+        if (p.trace && threadIdx.x == 0) {
+            p.trace[(long long)slot * 8 + 5] = clock64();
+            p.trace[(long long)slot * 8 + 4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11)) |
+                                               ((long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) << 32);
+        }
+#else
+#define SK_TR(i) do { } while (0)
+#endif
+        SK_TR(0); SK_TR(1);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int t = 0; t < nk; ++t) {
+            const int cur = (f + t) & 1;
+            const bool more = t + 1 < nk;
+            if (more) {
+                ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0, (t + 1) * SK_BK);
+                tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0, (t + 1) * SK_BK);
+            } else if (has_next) {                 // next tile's first k-tile flies under this tile's last MFMAs
+                ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0n, 0);
+                tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0n, 0);
+            }
+            const float* as = smem + cur * BUF + a_off;
+            const float* bs = smem + cur * BUF + A_SZ + b_off;
+            float a0[2], b0[2], a1[2], b1[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a0[i] = as[i * 32];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b0[j] = bs[j * 32];
+#pragma unroll
+            for (int kk = 0; kk < SK_BK; kk += 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 4 < SK_BK) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a0[i] = as[(kk + 4) * TA::LD + i * 32];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b0[j] = bs[(kk + 4) * TB::LD + j * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more || has_next) {
+                ta.store(smem + (cur ^ 1) * BUF);
+                tb.store(smem + (cur ^ 1) * BUF + A_SZ);
+            }
+            __syncthreads();
+        }
+        SK_TR(2);
+        // buffer `fr` was consumed by the last k-tile and is free: staging space of the epilogue (16 rows x 36 per wave)
+        const int fr = (f + nk - 1) & 1;
+        float* stg = smem + fr * BUF + wave * (16 * 36);
+        // Epilogue addresses = (tile- and sub-tile-uniform 64-bit base, kept in SGPRs) + (lane offset, 32-bit, tile-invariant).
+        f32x4 ev[2][4], cv[2][4];
+        const float* Et = (EP & 1) ? p.emul + (int64_t)m0 * p.lde + n0 : nullptr;
+        float* Ct = p.C + (int64_t)m0 * p.ldc + n0;
+        auto issue = [&](int s2, int buf) {
+            const int i = s2 >> 1, j = s2 & 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (EP & 1) ev[buf][q] = *reinterpret_cast<const f32x4*>(Et + (int64_t)(i * 32 + q * 8) * p.lde + j * 32 + e_lane);
+                if (EP & 2) cv[buf][q] = *reinterpret_cast<const f32x4*>(Ct + (int64_t)(i * 32 + q * 8) * p.ldc + j * 32 + c_lane);
+            }
+        };
+        if (EP) issue(0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int i = s2 >> 1, j = s2 & 1, buf = s2 & 1;
+            if (EP && s2 + 1 < 4) issue(s2 + 1, buf ^ 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {          // accumulator registers 8h..8h+7 hold rows 16h..16h+15 of the sub-tile
+#pragma unroll
+                for (int r = 0; r < 8; ++r) stg[((r & 3) + 8 * (r >> 2) + row_l) * 36 + col_l] = acc[i][j][8 * h + r];
+                RN_LDS_WAVE_SYNC();
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rr0) * 36 + cc);
+                    if (EP & 1) v = v * ev[buf][2 * h + q];
+                    if (EP & 2) v = v + cv[buf][2 * h + q];
+                    *reinterpret_cast<f32x4*>(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane) = v;
+                }
+                RN_LDS_WAVE_SYNC();
+            }
+        }
+        SK_TR(3);
+#ifdef RN_GEMM_TRACE
+        if (p.trace && threadIdx.x == 0) p.trace[(long long)slot * 8 + 6] = clock64();
+#endif
+        __syncthreads();                            // every wave is out of the staging buffer before k-tile 1 overwrites it
+        f = (f + nk) & 1;
+        m0 = m0n;
+        n0 = n0n;
+    }
+}
+
+template <bool B_KC, int EP>
+static int launch_sk(const GemmK& k, hipStream_t st) {
+    using TA = Tile<SK_BM, SK_BK, true>;
+    using TB = Tile<SK_BN, SK_BK, B_KC>;
+    constexpr size_t lds = 2 * SK_BK * (size_t)(TA::LD + TB::LD) * sizeof(float);
+    const int rt = k.M / SK_BM, ct = k.N / SK_BN;
+    const int resident = 256 * (EP == 3 ? 3 : 4);
+    int grid = rt * ct < resident ? rt * ct : resident;
+    const int xcd = (rt % 8 == 0 && grid % 8 == 0) ? 1 : 0;
+    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP>), grid, GEMM_THREADS, lds, st, k, rt, ct, xcd);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+// ep: bit 0 = multiply by emul, bit 1 = accumulate into C.  The caller guarantees: M, N multiples of 128, K a multiple of
+// 16, A k-contiguous, every operand 16-byte aligned, batch == 1, no bias / activation / transposed store.
+int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, hipStream_t st) {
+    if (b_kc) {
+        switch (ep) {
+            case 0: return launch_sk<true, 0>(k, st);
+            case 1: return launch_sk<true, 1>(k, st);
+            case 2: return launch_sk<true, 2>(k, st);
+            default: return launch_sk<true, 3>(k, st);
+        }
+    }
+    switch (ep) {
+        case 0: return launch_sk<false, 0>(k, st);
+        case 1: return launch_sk<false, 1>(k, st);
+        case 2: return launch_sk<false, 2>(k, st);
+        default: return launch_sk<false, 3>(k, st);
+    }
+}
