@@ -217,6 +217,12 @@ typedef struct recnow_gemm_desc {
     const float* eu_p; const float* eu_q; int64_t eu_pms, eu_qrs, eu_qns; int eu_r; int eu_pad;
     double prof_flops;                /* algorithmic flops of this product for the measurement hook (0: 2*M*N*K*batch);
                                          callers that zero-pad K or move columns to a side product state the true count */
+    /* Second output of the same accumulators (short-K persistent kernel only: K <= 256, K % 16 == 0, M, N multiples of
+     * 128, A [M][K], batch 1, no bias / activation / transposed store; anything else returns RECNOW_EUNSUPPORTED):
+     *   c2_mode 1:  C2[m][n]  = acc                    (DCN-v2 forward keeps O next to y = x * O)
+     *   c2_mode 2:  C2[m][n] += acc * E2[m][n]         (DCN-v2 backward: dx += g_l * O_l in the kernel that produces g_l)
+     * `acc` is the raw product A B, before emul / accumulate are applied for C. */
+    float* C2; int64_t ldc2; const float* E2; int64_t lde2; int c2_mode; int c2_pad;
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;

@@ -145,11 +145,14 @@ static inline MixDims mix_dims(int64_t B, int D, int S, int N, int L) {
 static inline size_t act_block(const MixDims& m) { return rn_align((size_t)m.B * m.LDT * sizeof(float)); }
 static inline size_t xbuf(const MixDims& m) { return rn_align((size_t)m.B * m.D * sizeof(float)); }
 
-// saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D)
+// saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D);
+// exact path: then O_0..O_{L-2} (B x D)
 extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D <= 0 || S <= 0 || N <= 0 || L <= 0) return 256;
     const MixDims m = mix_dims(B, D, S, N, L);
-    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + 256;
+    // exact path: O_l = T2g_l [W; b] of every layer but the last is kept next to x_{l+1} = x * O_l (second output of GEMM3),
+    // so the backward adds g_l * O_l to dx inside the kernel that produces g_l instead of recomputing the product.
+    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) * (m.exact ? 2 : 1) + 256;
 }
 
 static size_t mix_gemm_ws(const MixDims& m) {
@@ -277,6 +280,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
     const size_t gws_bytes = ws_bytes - c.off;
     char* sv = (char*)saved;
     float* xmid = (float*)(sv + (size_t)L * 3 * act_block(m));
+    float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));        // exact path only
     int rc;
     const float* xl = x;
     for (int l = 0; l < L; ++l) {
@@ -307,6 +311,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
                 d.M = (int)B; d.N = D; d.K = m.KP;
                 d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
+                if (l < L - 1) { d.C2 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.ldc2 = D; d.c2_mode = 1; }
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             }
             xl = out;
@@ -390,6 +395,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     void* mid_ws = c.take<char>(mid_ws_bytes);
     if (!c.ok()) return RECNOW_EWORKSPACE;
     const float* xmid = (const float*)(sv + (size_t)L * 3 * act_block(m));
+    const float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));
     MixEvents evs;
     int rc;
     for (int l = 0; l < L; ++l)
@@ -401,7 +407,6 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     hipEvent_t e_side_prev = nullptr;   // side stream finished the previous (higher) layer: dT1/dC/g buffers reusable
     hipEvent_t e_dx = nullptr;          // side stream's last dx accumulation
     const float* g = dy;
-    bool dx_started = false;
     int pg = rn_cdiv((int64_t)D * m.NS, 256);
     if (pg > 2048) pg = 2048;
     for (int l = L - 1; l >= 0; --l) {
@@ -424,7 +429,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.sp_bx = T2g + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
             if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
         }
-        {   // dx (+)= g * O,  O = [G*H2 | G | 0] [W; b; 0] recomputed
+        if (l == L - 1) {   // top layer: dx = g * O,  O = [G*H2 | G | 0] [W; b; 0] recomputed (lower layers kept their O)
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc2; d.ldb = D; d.b_trans = 0;
@@ -432,10 +437,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = (int)B; d.N = D; d.K = m.KP;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
-            d.accumulate = dx_started ? 1 : 0;
             if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
-            dx_started = true;
-            if (l == 0) MIX_SIGNAL(e_dx, st2);
+            MIX_SIGNAL(e_dx, st2);
         }
         // ---------------- chain stream
         {   // dT2g[:, :NS] = (x*g) W^T;  gate columns dT2g[:, NS+n] = (x*g) . bias_n as the side product
@@ -454,8 +457,9 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             return rc;
         hipEvent_t e_dT1 = nullptr;
         MIX_SIGNAL(e_dT1, st);
-        if (l == 0) MIX_WAIT(e_dx, st);     // dx is complete on the side stream before the chain adds the last term
-        {   // gradient w.r.t. x_l: [dA | dlogits | 0] [U | K | 0]^T  (K zero-padded to KP)
+        if (l == L - 1) MIX_WAIT(e_dx, st);     // dx was initialised on the side stream before the chain starts adding to it
+        {   // gradient w.r.t. x_l: g_{l-1} = [dA | dlogits | 0] [U | K | 0]^T  (K zero-padded to KP).  The same accumulators
+            // also update dx += g_{l-1} * O_{l-1} (second output); layer 0's x_l is x itself, its term goes straight into dx.
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
@@ -463,6 +467,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = (int)B; d.N = D; d.K = m.KP;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.accumulate = (l == 0) ? 1 : 0;
+            if (l > 0) { d.C2 = dx; d.ldc2 = D; d.E2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.lde2 = D; d.c2_mode = 2; }
             if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
         }
         if (l > 0) MIX_SIGNAL(e_g, st);

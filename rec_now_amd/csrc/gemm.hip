@@ -154,6 +154,9 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     if (d->eu_r > 0 && (!d->eu_p || !d->eu_q || d->batch != 1)) return RECNOW_EINVAL;
     pick_split(d, c, &k.splitk, &k.kchunk);
     k.trace = nullptr;
+    k.C2 = d->C2; k.E2 = d->E2; k.ldc2 = d->ldc2; k.lde2 = d->lde2;
+    if (d->c2_mode < 0 || d->c2_mode > 2 || (d->c2_mode && !d->C2) || (d->c2_mode == 2 && !d->E2)) return RECNOW_EINVAL;
+    if (d->c2_mode && (d->K > 256 || d->batch != 1)) return RECNOW_EUNSUPPORTED;      // short-K kernel only
 #ifdef RN_GEMM_TRACE
     if (const char* t = getenv("RECNOW_GEMM_TRACE")) k.trace = (long long*)strtoull(t, nullptr, 10);
 #endif
@@ -180,13 +183,17 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     rc = RECNOW_EUNSUPPORTED;
     const int xf = (d->sp_r > 0 ? 1 : 0) | (d->eu_r > 0 ? 2 : 0);
     if (xf) {        // side product / rank-R update exist only in the lean 128x128 kernels: the caller guarantees the shape
-        if (edge || c.BM != 128 || c.BN != 128) return RECNOW_EUNSUPPORTED;
+        if (edge || c.BM != 128 || c.BN != 128 || d->c2_mode) return RECNOW_EUNSUPPORTED;
         rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
     } else if (!edge && bk16 && c.BN == 128 && a_kc && k.splitk == 1 && d->batch == 1 && d->a_mode == 0 && d->b_mode == 0 &&
                !d->bias && d->act == RECNOW_ACT_LINEAR && !d->c_trans && (!d->emul || d->e_mode == RECNOW_OPMODE_MUL)) {
         // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)
-        rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), st);
+        if (d->c2_mode && (!host_aligned(d->C2, d->ldc2, 0) || (d->c2_mode == 2 && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
+        rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, st);
+        if (rc) return rc;
+    } else if (d->c2_mode) {
+        return RECNOW_EUNSUPPORTED;          // the second output exists only in the short-K kernel
     } else if (!edge && c.BM == 128) {
         const int bk = bk16 ? 16 : 32;
         rc = (c.BN == 160) ? rn_gemm_launch_lean160(k, a_kc, b_kc, bk, d->a_mode, d->b_mode, grid, st)

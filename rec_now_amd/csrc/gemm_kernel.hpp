@@ -32,6 +32,9 @@ struct GemmK {
     int64_t eu_pms, eu_qrs, eu_qns;
     int eu_r;
     int npart;                 // row width of a split-K slab: N, or N + 4 when a side product rides along
+    float* C2;                 // second output of the short-K kernel (c2_mode 1: C2 = acc; 2: C2 += acc * E2)
+    const float* E2;
+    int64_t ldc2, lde2;
     long long* trace;          // RN_GEMM_TRACE builds only: 8 int64 per workgroup (phase timestamps, HW id)
 };
 
@@ -549,4 +552,4 @@ static inline void rn_gemm_launch_one(const GemmK& k, dim3 grid, hipStream_t st)
 }
 int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k, int b2k, int xf, dim3 grid, hipStream_t st);
 // persistent short-K kernel (gemm_shortk.hip): ep = (emul ? 1 : 0) | (accumulate ? 2 : 0)
-int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, hipStream_t st);
+int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st);

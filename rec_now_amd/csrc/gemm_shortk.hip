@@ -17,8 +17,9 @@
 #define SK_BN 128
 #define SK_BK 16
 
-template <bool B_KC, int EP>
-__global__ void __launch_bounds__(GEMM_THREADS, (EP == 3 ? 3 : 4))
+// EP: bit 0 = C *= emul, bit 1 = C += C_old.   DUAL: 0 none, 1: C2 = acc, 2: C2 += acc * E2.
+template <bool B_KC, int EP, int DUAL>
+__global__ void __launch_bounds__(GEMM_THREADS, ((EP == 3 || DUAL == 2) ? 3 : 4))
 k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
@@ -33,6 +34,8 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     const int rr0 = lane >> 3, cc = (lane & 7) * 4;
     const unsigned e_lane = (unsigned)((wm * 64 + rr0) * p.lde + wn * 64 + cc);     // this lane's element inside a tile of emul / C
     const unsigned c_lane = (unsigned)((wm * 64 + rr0) * p.ldc + wn * 64 + cc);
+    const unsigned f_lane = (unsigned)((wm * 64 + rr0) * p.lde2 + wn * 64 + cc);
+    const unsigned d_lane = (unsigned)((wm * 64 + rr0) * p.ldc2 + wn * 64 + cc);
     const int nk = p.K / SK_BK;
     const int ntiles = row_tiles * col_tiles;
 
@@ -142,22 +145,28 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
         const int fr = (f + nk - 1) & 1;
         float* stg = smem + fr * BUF + wave * (16 * 36);
         // Epilogue addresses = (tile- and sub-tile-uniform 64-bit base, kept in SGPRs) + (lane offset, 32-bit, tile-invariant).
-        f32x4 ev[2][4], cv[2][4];
+        f32x4 ev[2][4], cv[2][4], fv[2][4], dv[2][4];
         const float* Et = (EP & 1) ? p.emul + (int64_t)m0 * p.lde + n0 : nullptr;
         float* Ct = p.C + (int64_t)m0 * p.ldc + n0;
+        const float* Ft = (DUAL == 2) ? p.E2 + (int64_t)m0 * p.lde2 + n0 : nullptr;
+        float* Dt = DUAL ? p.C2 + (int64_t)m0 * p.ldc2 + n0 : nullptr;
         auto issue = [&](int s2, int buf) {
             const int i = s2 >> 1, j = s2 & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (EP & 1) ev[buf][q] = *reinterpret_cast<const f32x4*>(Et + (int64_t)(i * 32 + q * 8) * p.lde + j * 32 + e_lane);
                 if (EP & 2) cv[buf][q] = *reinterpret_cast<const f32x4*>(Ct + (int64_t)(i * 32 + q * 8) * p.ldc + j * 32 + c_lane);
+                if (DUAL == 2) {
+                    fv[buf][q] = *reinterpret_cast<const f32x4*>(Ft + (int64_t)(i * 32 + q * 8) * p.lde2 + j * 32 + f_lane);
+                    dv[buf][q] = *reinterpret_cast<const f32x4*>(Dt + (int64_t)(i * 32 + q * 8) * p.ldc2 + j * 32 + d_lane);
+                }
             }
         };
-        if (EP) issue(0, 0);
+        if (EP || DUAL == 2) issue(0, 0);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
             const int i = s2 >> 1, j = s2 & 1, buf = s2 & 1;
-            if (EP && s2 + 1 < 4) issue(s2 + 1, buf ^ 1);
+            if ((EP || DUAL == 2) && s2 + 1 < 4) issue(s2 + 1, buf ^ 1);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {          // accumulator registers 8h..8h+7 hold rows 16h..16h+15 of the sub-tile
 #pragma unroll
@@ -165,10 +174,15 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 RN_LDS_WAVE_SYNC();
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rr0) * 36 + cc);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rr0) * 36 + cc);
+                    f32x4 v = a;
                     if (EP & 1) v = v * ev[buf][2 * h + q];
                     if (EP & 2) v = v + cv[buf][2 * h + q];
                     *reinterpret_cast<f32x4*>(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane) = v;
+                    if (DUAL == 1) *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) = a;
+                    if (DUAL == 2)
+                        *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) =
+                            dv[buf][2 * h + q] + a * fv[buf][2 * h + q];
                 }
                 RN_LDS_WAVE_SYNC();
             }
@@ -184,35 +198,38 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     }
 }
 
-template <bool B_KC, int EP>
+template <bool B_KC, int EP, int DUAL>
 static int launch_sk(const GemmK& k, hipStream_t st) {
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
     constexpr size_t lds = 2 * SK_BK * (size_t)(TA::LD + TB::LD) * sizeof(float);
     const int rt = k.M / SK_BM, ct = k.N / SK_BN;
-    const int resident = 256 * (EP == 3 ? 3 : 4);
+    const int resident = 256 * ((EP == 3 || DUAL == 2) ? 3 : 4);
     int grid = rt * ct < resident ? rt * ct : resident;
     const int xcd = (rt % 8 == 0 && grid % 8 == 0) ? 1 : 0;
-    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP>), grid, GEMM_THREADS, lds, st, k, rt, ct, xcd);
+    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL>), grid, GEMM_THREADS, lds, st, k, rt, ct, xcd);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
 
-// ep: bit 0 = multiply by emul, bit 1 = accumulate into C.  The caller guarantees: M, N multiples of 128, K a multiple of
-// 16, A k-contiguous, every operand 16-byte aligned, batch == 1, no bias / activation / transposed store.
-int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, hipStream_t st) {
+// ep: bit 0 = multiply by emul, bit 1 = accumulate into C.  c2_mode: second output (recnow_gemm_desc).  The caller
+// guarantees: M, N multiples of 128, K a multiple of 16, A k-contiguous, every operand 16-byte aligned, batch == 1, no
+// bias / activation / transposed store.  Second outputs are instantiated for the two products DCN-v2 uses them in.
+int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st) {
+    if (c2_mode == 1) return (!b_kc && ep == 1) ? launch_sk<false, 1, 1>(k, st) : RECNOW_EUNSUPPORTED;
+    if (c2_mode == 2) return (b_kc && ep == 0) ? launch_sk<true, 0, 2>(k, st) : RECNOW_EUNSUPPORTED;
     if (b_kc) {
         switch (ep) {
-            case 0: return launch_sk<true, 0>(k, st);
-            case 1: return launch_sk<true, 1>(k, st);
-            case 2: return launch_sk<true, 2>(k, st);
-            default: return launch_sk<true, 3>(k, st);
+            case 0: return launch_sk<true, 0, 0>(k, st);
+            case 1: return launch_sk<true, 1, 0>(k, st);
+            case 2: return launch_sk<true, 2, 0>(k, st);
+            default: return launch_sk<true, 3, 0>(k, st);
         }
     }
     switch (ep) {
-        case 0: return launch_sk<false, 0>(k, st);
-        case 1: return launch_sk<false, 1>(k, st);
-        case 2: return launch_sk<false, 2>(k, st);
-        default: return launch_sk<false, 3>(k, st);
+        case 0: return launch_sk<false, 0, 0>(k, st);
+        case 1: return launch_sk<false, 1, 0>(k, st);
+        case 2: return launch_sk<false, 2, 0>(k, st);
+        default: return launch_sk<false, 3, 0>(k, st);
     }
 }

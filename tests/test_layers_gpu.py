@@ -441,3 +441,64 @@ def test_dcn_mix_backward_on_two_streams_matches_single_stream(dev, monkeypatch)
         grads.append([xi.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+# ---- persistent short-K kernel: every epilogue form, tile counts above and below one resident wave of workgroups -------------
+@pytest.mark.parametrize('M,N,K,tb', [(256, 256, 144, 0), (1024, 1024, 48, 1), (16384, 1024, 144, 0), (384, 128, 16, 1)])
+@pytest.mark.parametrize('form', ['plain', 'emul', 'accum', 'emul_accum', 'dual_raw', 'dual_fma'])
+def test_gemm_short_k_persistent_kernel(dev, M, N, K, tb, form):
+    from rec_now_amd import _lib
+    if form == 'dual_raw' and tb:
+        pytest.skip('C2 = acc is instantiated for B stored [K][N] (DCN-v2 GEMM3)')
+    if form == 'dual_fma' and not tb:
+        pytest.skip('C2 += acc * E2 is instantiated for B stored [N][K] (DCN-v2 dxl)')
+    rng = np.random.default_rng(M + K + tb)
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    Bm = rng.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32)
+    E = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    E2 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    D0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    Ad, Bd, Ed, E2d = (torch.from_numpy(v).to(dev) for v in (A, Bm, E, E2))
+    C = torch.from_numpy(C0.copy()).to(dev)
+    C2 = torch.from_numpy(D0.copy()).to(dev)
+    lib = _lib.load()
+    d = _lib.GemmDesc()
+    d.A, d.lda = Ad.data_ptr(), K
+    d.B, d.ldb, d.b_trans = Bd.data_ptr(), Bm.shape[1], tb
+    d.C, d.ldc = C.data_ptr(), N
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    P = A.astype(np.float64) @ (Bm.astype(np.float64).T if tb else Bm.astype(np.float64))
+    ref, ref2 = P, None
+    if form in ('emul', 'emul_accum', 'dual_raw'):
+        d.emul, d.lde, d.e_mode = Ed.data_ptr(), N, 1
+        ref = ref * E
+    if form in ('accum', 'emul_accum'):
+        d.accumulate = 1
+        ref = ref + C0
+    if form == 'dual_raw':
+        d.C2, d.ldc2, d.c2_mode = C2.data_ptr(), N, 1
+        ref2 = P
+    if form == 'dual_fma':
+        d.C2, d.ldc2, d.E2, d.lde2, d.c2_mode = C2.data_ptr(), N, E2d.data_ptr(), N, 2
+        ref2 = D0 + P * E2
+    ws = _lib.workspace(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)), dev)
+    _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.stream())
+    bound = 3e-7 * K + 1e-6
+    assert np.abs(C.cpu().numpy() - ref).max() <= bound
+    if ref2 is not None:
+        assert np.abs(C2.cpu().numpy() - ref2).max() <= bound
+
+
+def test_gemm_second_output_outside_short_k_is_unsupported(dev):
+    from rec_now_amd import _lib
+    lib = _lib.load()
+    A = torch.zeros(128, 1024, device=dev)
+    Bm = torch.zeros(1024, 128, device=dev)
+    C = torch.zeros(128, 128, device=dev)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = A.data_ptr(), 1024, Bm.data_ptr(), 128, C.data_ptr(), 128
+    d.M, d.N, d.K, d.batch = 128, 128, 1024, 1
+    d.C2, d.ldc2, d.c2_mode = C.data_ptr(), 128, 1
+    ws = _lib.workspace(256, dev)
+    assert lib.recnow_gemm(ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.stream()) == -3
