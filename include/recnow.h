@@ -223,6 +223,11 @@ typedef struct recnow_gemm_desc {
      *   c2_mode 2:  C2[m][n] += acc * E2[m][n]         (DCN-v2 backward: dx += g_l * O_l in the kernel that produces g_l)
      * `acc` is the raw product A B, before emul / accumulate are applied for C. */
     float* C2; int64_t ldc2; const float* E2; int64_t lde2; int c2_mode; int c2_pad;
+    /* Elementwise side output of the A stream (lean 128x128 kernels with a side product, A [M][K], a_mode MUL, batch 1,
+     * N <= 128 so that every A element is loaded exactly once, no split-K):
+     *   as_out[m][k] = A[m][k] * as_in[m][k]      (both with A's leading dimension lda)
+     * DCN-v2 backward: the dT2g product streams g = dL/dy anyway and writes dx = g * O on the way. */
+    const float* as_in; float* as_out;
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;

@@ -146,13 +146,13 @@ static inline size_t act_block(const MixDims& m) { return rn_align((size_t)m.B *
 static inline size_t xbuf(const MixDims& m) { return rn_align((size_t)m.B * m.D * sizeof(float)); }
 
 // saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D);
-// exact path: then O_0..O_{L-2} (B x D)
+// exact path: then O_0..O_{L-1} (B x D)
 extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D <= 0 || S <= 0 || N <= 0 || L <= 0) return 256;
     const MixDims m = mix_dims(B, D, S, N, L);
-    // exact path: O_l = T2g_l [W; b] of every layer but the last is kept next to x_{l+1} = x * O_l (second output of GEMM3),
-    // so the backward adds g_l * O_l to dx inside the kernel that produces g_l instead of recomputing the product.
-    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) * (m.exact ? 2 : 1) + 256;
+    // exact path: O_l = T2g_l [W; b] of every layer is kept next to x_{l+1} = x * O_l (second output of GEMM3), so the
+    // backward forms dx = sum_l g_l * O_l inside kernels that stream g_l anyway instead of recomputing the products.
+    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + 256;
 }
 
 static size_t mix_gemm_ws(const MixDims& m) {
@@ -311,7 +311,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
                 d.M = (int)B; d.N = D; d.K = m.KP;
                 d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
-                if (l < L - 1) { d.C2 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.ldc2 = D; d.c2_mode = 1; }
+                d.C2 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.ldc2 = D; d.c2_mode = 1;
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             }
             xl = out;
@@ -381,7 +381,6 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     if (!two) st2 = st;
     RnCarver c(ws, ws_bytes);
     float* Wc1_all = c.take<float>((size_t)L * D * m.LDT);        // per-layer packs: the side stream reads them later
-    float* Wc2_all = c.take<float>((size_t)L * m.LDT * D);
     float* dWc1 = c.take<float>((size_t)D * m.LDT);
     float* dT2g = c.take<float>(act_block(m) / sizeof(float));
     float* dC = c.take<float>(act_block(m) / sizeof(float));
@@ -398,14 +397,17 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     const float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));
     MixEvents evs;
     int rc;
-    for (int l = 0; l < L; ++l)
-        if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1_all + (size_t)l * D * m.LDT,
-                               Wc2_all + (size_t)l * m.LDT * D, st)))
-            return rc;
+    {
+        int pgw = rn_cdiv((int64_t)D * m.LDT, 256);
+        if (pgw > 2048) pgw = 2048;
+        for (int l = 0; l < L; ++l) {      // [U | K | 0] of every layer (W and bias are used in place)
+            hipLaunchKernelGGL(k_pack_w1, pgw, 256, 0, st, U_host[l], gate_host[l], D, S, N, m.LDT, Wc1_all + (size_t)l * D * m.LDT);
+            RN_LAUNCH_CHECK();
+        }
+    }
     hipEvent_t e_g = nullptr;        // "g of this layer (and the packs) are ready" -> side stream may start the layer
     MIX_SIGNAL(e_g, st);
     hipEvent_t e_side_prev = nullptr;   // side stream finished the previous (higher) layer: dT1/dC/g buffers reusable
-    hipEvent_t e_dx = nullptr;          // side stream's last dx accumulation
     const float* g = dy;
     int pg = rn_cdiv((int64_t)D * m.NS, 256);
     if (pg > 2048) pg = 2048;
@@ -416,7 +418,6 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));
         float* gprev = (l == 0) ? nullptr : ((l & 1) ? gbuf0 : gbuf1);
         const float* Wc1 = Wc1_all + (size_t)l * D * m.LDT;
-        const float* Wc2 = Wc2_all + (size_t)l * m.LDT * D;
         // ---------------- side stream, part 1: needs only g_l and saved activations
         MIX_WAIT(e_g, st2);
         {   // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
@@ -429,17 +430,6 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.sp_bx = T2g + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
             if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
         }
-        if (l == L - 1) {   // top layer: dx = g * O,  O = [G*H2 | G | 0] [W; b; 0] recomputed (lower layers kept their O)
-            recnow_gemm_desc d = rn_gemm_desc_zero();
-            d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
-            d.B = Wc2; d.ldb = D; d.b_trans = 0;
-            d.C = dx; d.ldc = D;
-            d.M = (int)B; d.N = D; d.K = m.KP;
-            d.prof_flops = 2.0 * (double)B * D * m.KC;
-            d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
-            if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
-            MIX_SIGNAL(e_dx, st2);
-        }
         // ---------------- chain stream
         {   // dT2g[:, :NS] = (x*g) W^T;  gate columns dT2g[:, NS+n] = (x*g) . bias_n as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
@@ -449,6 +439,10 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = (int)B; d.N = m.NS; d.K = D;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.sp_bx = bias_host[l]; d.sp_bx_ks = 1; d.sp_bx_rs = D; d.sp_cx = dT2g + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
+            if (l == L - 1) {      // top layer: this product streams g = dy anyway -> dx = dy * O_{L-1} written on the way
+                d.as_in = omid + (size_t)l * (xbuf(m) / sizeof(float));
+                d.as_out = dx;
+            }
             if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
         }
         MIX_WAIT(e_side_prev, st);          // dT1 (and the g buffer about to be rewritten) are free again
@@ -457,7 +451,6 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             return rc;
         hipEvent_t e_dT1 = nullptr;
         MIX_SIGNAL(e_dT1, st);
-        if (l == L - 1) MIX_WAIT(e_dx, st);     // dx was initialised on the side stream before the chain starts adding to it
         {   // gradient w.r.t. x_l: g_{l-1} = [dA | dlogits | 0] [U | K | 0]^T  (K zero-padded to KP).  The same accumulators
             // also update dx += g_{l-1} * O_{l-1} (second output); layer 0's x_l is x itself, its term goes straight into dx.
             recnow_gemm_desc d = rn_gemm_desc_zero();

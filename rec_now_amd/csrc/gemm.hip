@@ -155,6 +155,8 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     pick_split(d, c, &k.splitk, &k.kchunk);
     k.trace = nullptr;
     k.C2 = d->C2; k.E2 = d->E2; k.ldc2 = d->ldc2; k.lde2 = d->lde2;
+    k.as_in = d->as_in; k.as_out = d->as_out;
+    if ((d->as_in != nullptr) != (d->as_out != nullptr)) return RECNOW_EINVAL;
     if (d->c2_mode < 0 || d->c2_mode > 2 || (d->c2_mode && !d->C2) || (d->c2_mode == 2 && !d->E2)) return RECNOW_EINVAL;
     if (d->c2_mode && (d->K > 256 || d->batch != 1)) return RECNOW_EUNSUPPORTED;      // short-K kernel only
 #ifdef RN_GEMM_TRACE
@@ -181,7 +183,13 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     // lean kernels exist for the two big tile families and the (layout, operand-kind) combos the layers use; anything
     // else (and every edge shape) runs the general kernel of the same tile family.
     rc = RECNOW_EUNSUPPORTED;
-    const int xf = (d->sp_r > 0 ? 1 : 0) | (d->eu_r > 0 ? 2 : 0);
+    int xf = (d->sp_r > 0 ? 1 : 0) | (d->eu_r > 0 ? 2 : 0);
+    if (d->as_out) {      // A-stream side output: instantiated with the side product of dT2g; every A element loaded exactly once
+        if (xf != 1 || d->a_trans || d->a_mode != RECNOW_OPMODE_MUL || d->batch != 1 || k.splitk != 1 || d->N > c.BN ||
+            !host_aligned(d->as_in, d->lda, 0) || !host_aligned(d->as_out, d->lda, 0))
+            return RECNOW_EUNSUPPORTED;
+        xf |= 4;
+    }
     if (xf) {        // side product / rank-R update exist only in the lean 128x128 kernels: the caller guarantees the shape
         if (edge || c.BM != 128 || c.BN != 128 || d->c2_mode) return RECNOW_EUNSUPPORTED;
         rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);

@@ -32,6 +32,8 @@ struct GemmK {
     int64_t eu_pms, eu_qrs, eu_qns;
     int eu_r;
     int npart;                 // row width of a split-K slab: N, or N + 4 when a side product rides along
+    const float* as_in;        // XF & 4: elementwise side output of the A stream, as_out = A * as_in (layout of A)
+    float* as_out;
     float* C2;                 // second output of the short-K kernel (c2_mode 1: C2 = acc; 2: C2 += acc * E2)
     const float* E2;
     int64_t ldc2, lde2;
@@ -107,6 +109,26 @@ struct Tile {
         if (SECOND) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) v[i] = gemm_combine(v[i], y[i], mode, act);
+        }
+    }
+
+    // load_fast<true> (MUL) that also writes side_out = first * side_in for the elements it loads (XF & 4)
+    __device__ __forceinline__ void load_fast_side(const float* __restrict__ p, const float* __restrict__ p2,
+                                                   const float* __restrict__ p3, float* __restrict__ out, int64_t ld, int r0, int k0) {
+        f32x4 y[NV], z[NV];
+        const int64_t base = tile_base(ld, r0, k0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (has(i)) {
+                v[i] = *reinterpret_cast<const f32x4*>(p + base + off[i]);
+                y[i] = *reinterpret_cast<const f32x4*>(p2 + base + off[i]);
+                z[i] = *reinterpret_cast<const f32x4*>(p3 + base + off[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (has(i)) *reinterpret_cast<f32x4*>(out + base + off[i]) = v[i] * z[i];
+            v[i] = v[i] * y[i];
         }
     }
 
@@ -227,6 +249,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC
 __global__ void __launch_bounds__(GEMM_THREADS, 2)      // >= 2 waves/SIMD: VGPR+AGPR <= 256, two workgroups per CU
 k_gemm(const GemmK p) {
     static_assert(XF == 0 || (!EDGE && BM == 128), "side product / rank-R update: lean 128-row kernels only");
+    static_assert((XF & 4) == 0 || (A_KC && A2K == RECNOW_OPMODE_MUL), "A-stream side output: A [M][K] in MUL mode");
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
     using TA = Tile<BM, BK, A_KC>;
@@ -284,7 +307,8 @@ k_gemm(const GemmK p) {
     const int ntile = (k_end - k_begin + BK - 1) / BK;
     if (ntile > 0) {
         const bool kf = !EDGE || (k_begin + BK <= k_end);
-        ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end, p.a_ld2, p.a_hq);
+        if constexpr ((XF & 4) != 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k_begin);
+        else ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end, p.a_ld2, p.a_hq);
         tb.template load<EDGE, B2K>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end, p.b_ld2, p.b_hq);
         ta.store(As);
         tb.store(Bs);
@@ -302,7 +326,8 @@ k_gemm(const GemmK p) {
         if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
             const int k0 = k_begin + (t + 1) * BK;
             const bool kf = !EDGE || (k0 + BK <= k_end);
-            ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
+            if constexpr ((XF & 4) != 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k0);
+            else ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
             tb.template load<EDGE, B2K>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
         }
         if ((XF & 1) && t + 1 < ntile && threadIdx.x < BK) {

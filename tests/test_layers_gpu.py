@@ -502,3 +502,31 @@ def test_gemm_second_output_outside_short_k_is_unsupported(dev):
     d.C2, d.ldc2, d.c2_mode = C.data_ptr(), 128, 1
     ws = _lib.workspace(256, dev)
     assert lib.recnow_gemm(ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.stream()) == -3
+
+
+def test_gemm_a_stream_side_output(dev):
+    """C = (A*A2) B^T with a side product, while as_out = A * as_in is written from the A tiles the kernel loads anyway."""
+    from rec_now_amd import _lib
+    rng = np.random.default_rng(23)
+    M, N, K = 512, 128, 256
+    A, A2, T = (rng.uniform(-1, 1, (M, K)).astype(np.float32) for _ in range(3))
+    Bm = rng.uniform(-1, 1, (N, K)).astype(np.float32)
+    Bx = rng.uniform(-1, 1, (2, K)).astype(np.float32)
+    Ad, A2d, Td, Bd, Bxd = (torch.from_numpy(v).to(dev) for v in (A, A2, T, Bm, Bx))
+    C = torch.empty((M, N), device=dev)
+    Cx = torch.empty((M, 2), device=dev)
+    out = torch.full((M, K), 9.0, device=dev)
+    lib = _lib.load()
+    d = _lib.GemmDesc()
+    d.A, d.A2, d.a_mode, d.lda = Ad.data_ptr(), A2d.data_ptr(), 1, K
+    d.B, d.ldb, d.b_trans = Bd.data_ptr(), K, 1
+    d.C, d.ldc = C.data_ptr(), N
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    d.sp_bx, d.sp_cx, d.sp_bx_ks, d.sp_bx_rs, d.sp_cx_ms, d.sp_cx_rs, d.sp_r = Bxd.data_ptr(), Cx.data_ptr(), 1, K, 2, 1, 2
+    d.as_in, d.as_out = Td.data_ptr(), out.data_ptr()
+    ws = _lib.workspace(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)) + 256, dev)
+    _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.stream())
+    X = (A * A2).astype(np.float64)
+    assert np.abs(C.cpu().numpy() - X @ Bm.astype(np.float64).T).max() <= 3e-7 * K
+    assert np.abs(Cx.cpu().numpy() - X @ Bx.astype(np.float64).T).max() <= 3e-7 * K
+    assert np.array_equal(out.cpu().numpy(), A * T)
