@@ -322,6 +322,53 @@ int recnow_cin_bwd(const float* const* weights_host, const float* dout, const vo
                    int F, const int* hidden_host, int L, int output_input, int sum_channel, float* demb,
                    float* const* dweights_host, void* ws, size_t ws_bytes, void* stream);
 
+/* ============================================================================================================
+ * SURVEY.md section 8f rows (neighbours of the hot path).
+ * ========================================================================================================== */
+
+/* InnerPNNLayer: rec_now/layers/inner_pnn_layer.py:25-53.  out[b][p] = <x_r[b], x_c[b]> over the F(F-1)/2 field pairs
+ * r < c in r-major order (:41-45).  fields / dfields: DEVICE arrays of F device pointers to contiguous (B,D) fp32
+ * tensors (the reference's list input); out, dout: (B, F(F-1)/2).  D <= 64.
+ * Backward: dx_f[b][:] = sum_{g != f} dout[b][p(f,g)] * x_g[b][:]. */
+int recnow_inner_pnn_fwd(const float* const* fields, int F, int64_t B, int D, float* out, void* stream);
+int recnow_inner_pnn_bwd(const float* const* fields, float* const* dfields, int F, int64_t B, int D, const float* dout,
+                         void* stream);
+
+/* SENETLayer: rec_now/layers/senet_layer.py:93-119.  Fields may have different widths: dims[f], offs[f] (first column of
+ * field f in the concatenation, total = sum dims) are DEVICE int32 arrays.
+ *   squeeze (:104-110):      sq[b][f] = mean_d x_f[b][d]                                  sq: (B,F)
+ *   scale   (:112-117):      out[b][offs[f]+d] = x_f[b][d] * w[b][f]                      w: (B,F) excitation, out: (B,total)
+ *   scale_bwd_w:             dw[b][f] = sum_d dout[b][offs[f]+d] * x_f[b][d]
+ *   scale_bwd_x:             dx_f[b][d] = dout[b][offs[f]+d] * w[b][f] + dsq[b][f] / dims[f]   (dsq = gradient w.r.t. sq)
+ * The two Dense layers between squeeze and scale (:46-66) are recnow_multi_dense_* with N = 1. */
+int recnow_senet_squeeze(const float* const* fields, const int32_t* dims, int F, int64_t B, float* sq, void* stream);
+int recnow_senet_scale_fwd(const float* const* fields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
+                           const float* w, float* out, void* stream);
+int recnow_senet_scale_bwd_w(const float* const* fields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
+                             const float* dout, float* dw, void* stream);
+int recnow_senet_scale_bwd_x(float* const* dfields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
+                             const float* w, const float* dout, const float* dsq, void* stream);
+
+/* attention_by_dot_product: rec_now/rec_block/attention.py:12-38.  user (B,L,D), doc (B,D), D <= 256:
+ *   s_l = <user[b][l], doc[b]> (max(.,0) when filter_neg, :31-32);  mat[b] = sum_l user[b][l] * s_l;  score_sum[b] = sum_l s_l
+ * Backward recomputes s; dmat (B,D) / dsum (B) may be NULL (no gradient from that output). */
+int recnow_attention_dot_fwd(const float* user, const float* doc, int64_t B, int L, int D, int filter_neg, float* mat,
+                             float* score_sum, void* stream);
+int recnow_attention_dot_bwd(const float* user, const float* doc, const float* dmat, const float* dsum, int64_t B, int L,
+                             int D, int filter_neg, float* duser, float* ddoc, void* stream);
+
+/* focal_crossentropy_loss: rec_now/rec_block/focal_loss.py:12-66.  alpha <= 0 / gamma <= 0 switch the respective factor
+ * off (the reference's `if alpha:` / `if gamma:`).  loss_elem (B) and/or loss_mean (1) may be NULL; the mean is summed in
+ * double in a fixed order (ws: recnow_focal_loss_workspace_bytes).
+ * Backward: dlogits[i] = dloss_i/dlogit_i * (gelem ? gelem[i] : 1) * (gscalar ? *gscalar : 1) * scale  (scale = 1/B for the
+ * mean); stop_weight_gradient as :60-61. */
+size_t recnow_focal_loss_workspace_bytes(int64_t B);
+int recnow_focal_loss_fwd(const float* labels, const float* logits, int64_t B, float alpha, float gamma, float* loss_elem,
+                          float* loss_mean, void* ws, size_t ws_bytes, void* stream);
+int recnow_focal_loss_bwd(const float* labels, const float* logits, int64_t B, float alpha, float gamma,
+                          int stop_weight_gradient, const float* gelem, const float* gscalar, float scale, float* dlogits,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the GEMM kernels on the launch stream.
  * recnow_prof_enable(capacity > 0) arms `capacity` launch slots, (0) disables.  recnow_prof_collect synchronises and

@@ -342,6 +342,85 @@ def ple_layer(inputs, layers, is_shared_tasks, activation=None):
     return [o for o in outputs[-1] if o is not None]                                # :318-321
 
 
+# ----------------------------------------------------------------------------------------------
+# SURVEY.md section 8f rows (the callers / neighbours of the hot path), same conventions as above
+# ----------------------------------------------------------------------------------------------
+def inner_pnn_layer(inputs):
+    """layers/inner_pnn_layer.py:25-53. inputs: list of F (B,D) tensors -> (B, F*(F-1)/2); pair order r < c, r-major (:41-45)."""
+    x = torch.stack(inputs, 0)                                  # (F,B,D), :38-39
+    F = x.shape[0]
+    row = [r for r in range(F - 1) for _ in range(r + 1, F)]
+    col = [c for r in range(F - 1) for c in range(r + 1, F)]
+    prod = x[row] * x[col]                                      # :47-49
+    return prod.sum(-1).transpose(0, 1)                         # :51-52
+
+
+def senet_layer(inputs, kernels, biases, activation_inner='tanh', activation_outer='tanh'):
+    """layers/senet_layer.py:93-119. inputs: list of F (B,D_f); kernels = [(F,mid), (mid,F)], biases or None.
+    mid = max(round(F * reduction_ratio), 1) (:68-74) is implied by the kernel shapes."""
+    if not isinstance(inputs, list):
+        inputs = [inputs]
+    sq = torch.cat([x.mean(-1, keepdim=True) for x in inputs], -1)      # :104-110
+    h = sq @ kernels[0]
+    if biases is not None and biases[0] is not None:
+        h = h + biases[0]
+    h = _act(activation_inner)(h)
+    w = h @ kernels[1]
+    if biases is not None and biases[1] is not None:
+        w = w + biases[1]
+    w = _act(activation_outer)(w)                                        # :111
+    pos_idx = [f for f, x in enumerate(inputs) for _ in range(x.shape[-1])]   # :86-88
+    ew = w[:, pos_idx]                                                   # embedding_wise_weight.py:27-36
+    return torch.cat(inputs, -1) * ew                                    # :114-117
+
+
+def focal_crossentropy_loss(labels, logits, alpha=0.25, gamma=2.0, stop_weight_gradient=False, return_mean=True):
+    """rec_block/focal_loss.py:12-66."""
+    if alpha and (alpha <= 0.0 or alpha >= 1.0):
+        raise ValueError('Value of alpha should be greater than zero and less than one.')      # :43-44
+    if gamma and gamma < 0:
+        raise ValueError('Value of gamma should be greater than or equal to zero.')            # :45-46
+    fl = torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-logits.abs()))   # :48 (TF's stable form)
+    if alpha:
+        fl = (labels * alpha + (1 - labels) * (1 - alpha)) * fl                                 # :50-53
+    if gamma:
+        p = torch.sigmoid(logits)
+        sim = labels * p + (1 - labels) * (1 - p)                                               # :56-57
+        mod = torch.pow(1.0 - sim, gamma)                                                       # :59
+        if stop_weight_gradient:
+            mod = mod.detach()                                                                  # :60-61
+        fl = mod * fl
+    return fl.mean() if return_mean else fl                                                     # :64-66
+
+
+def attention_by_dot_product(user_emb, doc_emb, filter_neg=False):
+    """rec_block/attention.py:12-38. user_emb (B,L,D), doc_emb (B,D) -> (B,D), (B,1)."""
+    score = (user_emb * doc_emb[:, None, :]).sum(2, keepdim=True)       # :28-30
+    if filter_neg:
+        score = torch.clamp(score, min=0.0)                              # :31-32
+    mat = (user_emb * score).sum(1)                                      # :33-34
+    return mat, score.squeeze(2).sum(1, keepdim=True)                    # :36-38
+
+
+def embedding_using_sparse_batch_segment_ids(params, slots, target_slots, ids, weights=None, method='sum'):
+    """rec_block/embedding_util.py:239-324 with embedding_func = row lookup in `params` (V,D) (the docstring's own example,
+    :254-256).  slots, ids: (B,C) integer; target_slots: list of T ints; weights (B,C) or None -> (B,T,D).
+    Column c of row b is pooled into target t iff slots[b][c] == target_slots[t]; 'mean' divides by the number of pooled
+    entries (unsorted_segment_mean: empty segments give 0)."""
+    B, C = ids.shape
+    T = len(target_slots)
+    emb = params[ids.reshape(-1).long()].reshape(B, C, -1)
+    if weights is not None:
+        emb = emb * weights[:, :, None]
+    ts = torch.as_tensor(list(target_slots), dtype=slots.dtype)
+    m = (slots[:, :, None] == ts[None, None, :]).to(emb.dtype)           # (B,C,T)
+    out = torch.einsum('bct,bcd->btd', m, emb)
+    if method == 'mean':
+        cnt = m.sum(1)                                                   # (B,T)
+        out = torch.where(cnt[:, :, None] > 0, out / cnt.clamp(min=1)[:, :, None], torch.zeros_like(out))
+    return out
+
+
 def calc_sum_of_abs_diff(arr1, arr2):
     """util/numpy_tools.py:12-27 -- the parity metric of every reference test."""
     import numpy as np

@@ -1,0 +1,148 @@
+"""SENETLayer -- drop-in for rec_now/layers/senet_layer.py (/root/reference/rec_now/layers/senet_layer.py:14-119)."""
+import torch
+
+from .. import _lib
+from ._keras import DenseBase, Layer, activation_code
+from ._ops import multi_dense
+
+
+class _Holder:
+    """Per-call device arrays shared by the squeeze and scale nodes."""
+
+    def __init__(self, xs):
+        dev = xs[0].device
+        self.F = len(xs)
+        self.xs = xs
+        dims = [int(x.shape[-1]) for x in xs]
+        offs = [0]
+        for d in dims[:-1]:
+            offs.append(offs[-1] + d)
+        self.total = sum(dims)
+        self.dims_list = dims
+        self.dims = torch.tensor(dims, dtype=torch.int32, device=dev)
+        self.offs = torch.tensor(offs, dtype=torch.int32, device=dev)
+        self.ptrs = _lib.ptr_array(xs, dev)
+        self.dsq = None
+
+
+class _SenetFunction(torch.autograd.Function):
+    """out = concat(fields) * w[:, field_of_column]  with  w = excite(mean_d fields)  as ONE autograd node: the excitation
+    MLP runs inside forward under torch.enable_grad so that its own (MultiDense) backward can be replayed in backward,
+    and the field gradient dx_f = dout * w + dsq / D_f is written in a single pass."""
+
+    @staticmethod
+    def forward(ctx, excite, n_params, *args):
+        params, fields = args[:n_params], args[n_params:]
+        xs = [_lib.f32c(x, 'SENET input') for x in fields]
+        B = xs[0].shape[0]
+        for x in xs:
+            if x.dim() != 2 or x.shape[0] != B:
+                raise ValueError('SENET inputs must be (B, D_f) tensors with one batch size')
+        h = _Holder(xs)
+        dev = xs[0].device
+        sq = torch.empty((B, h.F), dtype=torch.float32, device=dev)
+        _lib.call('recnow_senet_squeeze', _lib.ptr(h.ptrs), _lib.ptr(h.dims), h.F, B, _lib.ptr(sq), _lib.stream())
+        with torch.enable_grad():
+            sq_leaf = sq.detach().requires_grad_(True)
+            w = excite(sq_leaf)                                   # (B, F), the two Dense layers on the MFMA GEMM
+        wd = _lib.f32c(w.detach(), 'excitation')
+        out = torch.empty((B, h.total), dtype=torch.float32, device=dev)
+        _lib.call('recnow_senet_scale_fwd', _lib.ptr(h.ptrs), _lib.ptr(h.dims), _lib.ptr(h.offs), h.F, h.total, B, _lib.ptr(wd),
+                  _lib.ptr(out), _lib.stream())
+        ctx.h, ctx.sq_leaf, ctx.w, ctx.wd, ctx.params = h, sq_leaf, w, wd, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, B = ctx.h, ctx.wd.shape[0]
+        dev = ctx.wd.device
+        dout = _lib.f32c(dout, 'grad')
+        dw = torch.empty((B, h.F), dtype=torch.float32, device=dev)
+        _lib.call('recnow_senet_scale_bwd_w', _lib.ptr(h.ptrs), _lib.ptr(h.dims), _lib.ptr(h.offs), h.F, h.total, B, _lib.ptr(dout),
+                  _lib.ptr(dw), _lib.stream())
+        live = [i for i, p in enumerate(ctx.params) if p.requires_grad]
+        got = torch.autograd.grad(ctx.w, [ctx.sq_leaf] + [ctx.params[i] for i in live], dw, allow_unused=True)
+        grads = [got[0]] + [None] * len(ctx.params)
+        for k, i in enumerate(live):
+            grads[1 + i] = got[1 + k]
+        dsq = grads[0] if grads[0] is not None else torch.zeros_like(dw)
+        dsq = _lib.f32c(dsq, 'grad')
+        dxs = [torch.empty_like(x) for x in h.xs]
+        dptrs = _lib.ptr_array(dxs, dev)
+        _lib.call('recnow_senet_scale_bwd_x', _lib.ptr(dptrs), _lib.ptr(h.dims), _lib.ptr(h.offs), h.F, h.total, B, _lib.ptr(ctx.wd),
+                  _lib.ptr(dout), _lib.ptr(dsq), _lib.stream())
+        return (None, None) + tuple(grads[1:]) + tuple(dxs)
+
+
+class _Dense(Layer):
+    """keras.layers.Dense(units, activation, use_bias, ...) of the excitation MLP (:52-65) on recnow_multi_dense (N = 1)."""
+
+    def __init__(self, units, activation, use_bias, kernel_initializer, bias_initializer, name):
+        super().__init__(name=name)
+        self.units, self.use_bias = units, use_bias
+        self.act_code, self.act_callable = activation_code(activation)
+        self.kernel_initializer, self.bias_initializer = kernel_initializer, bias_initializer
+
+    def build(self, input_shape):
+        self.kernel = self.add_weight('kernel', shape=[int(input_shape[-1]), self.units], initializer=self.kernel_initializer)
+        self.bias = self.add_weight('bias', shape=[self.units], initializer=self.bias_initializer) if self.use_bias else None
+        self.built = True
+
+    def call(self, inputs):
+        d, u = self.kernel.shape
+        bias = self.bias.reshape(1, 1, u) if self.bias is not None else None
+        y = multi_dense(inputs, self.kernel.reshape(1, d, u), bias, self.act_code if self.act_code is not None else 0)[0]
+        return self.act_callable(y) if self.act_callable is not None else y
+
+
+class SENETLayer(DenseBase):
+    """Squeeze-Excitation network over field embeddings (FiBiNET); fields may have different widths.
+
+    Symbols: B batch size, F fields, Df width of field f, total_dim = sum(Df).
+    """
+
+    def __init__(self, reduction_ratio, activation_inner='tanh', activation_outer='tanh', **kwargs):
+        super().__init__(0, **kwargs)
+        self.reduction_ratio = reduction_ratio
+        self.activation_inner = activation_inner
+        self.activation_outer = activation_outer
+
+    def _get_middle_dim(self):
+        return max(round(self.num_field * self.reduction_ratio), 1)       # :68-74
+
+    def _build_senet(self):
+        name = f"{self.name}/senet"
+        dims = [self.middle_dim, self.num_field]
+        acts = [self.activation_inner, self.activation_outer]
+        return torch.nn.ModuleList([
+            _Dense(dim, act, self.use_bias, self.kernel_initializer, self.bias_initializer, name=f'{name}/dense_{idx}')
+            for idx, (dim, act) in enumerate(zip(dims, acts))])
+
+    def build(self, input_shape):
+        if not isinstance(input_shape, list):
+            input_shape = [input_shape]
+        self.num_field = len(input_shape)
+        self.total_dim = sum(int(s[-1]) for s in input_shape)
+        self.pos_idx = [f for f, s in enumerate(input_shape) for _ in range(int(s[-1]))]      # :84-88
+        self.middle_dim = self._get_middle_dim()
+        self.senet = self._build_senet()
+        shape = (None, self.num_field)
+        for layer in self.senet:                     # build eagerly so the parameters exist before the first call
+            layer._build_device = self._build_device
+            layer.build(shape)
+            layer.built = True
+            shape = (None, layer.units)
+        self.built = True
+
+    def _excite(self, sq):
+        h = sq
+        for layer in self.senet:
+            h = layer(h)
+        return h
+
+    def call(self, inputs):
+        """inputs: list of F tensors (B, Df) (a single tensor is wrapped, :101-102).  Returns (B, total_dim)."""
+        if not isinstance(inputs, (list, tuple)):
+            inputs = [inputs]
+        params = [p for layer in self.senet for p in layer.parameters()]
+        return _SenetFunction.apply(self._excite, len(params), *params, *inputs)

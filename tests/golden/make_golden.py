@@ -165,5 +165,29 @@ def ple():
     print('%-16s sum|oracle-golden| = %.3g / %.3g' % ('ple', d1, d2))
 
 
+def inner_pnn():
+    # tests/layers/test_inner_pnn_layer.py:18-39
+    r = TFSeededRNG(1)
+    xs = [r.normal([4, 2], mean=float(f), stddev=1.0, seed=f) for f in range(3)]
+    golden = [[2.3125873, 1.9014311, 10.842302], [1.5337583, 2.2996788, 13.424303],
+              [-0.799806, -8.9576435, 1.9083395], [0.07315224, 1.5779386, 4.7213144]]
+    got = R.inner_pnn_layer([T(x) for x in xs]).numpy()
+    _save('inner_pnn', golden, got, inputs=np.stack(xs))
+
+
+def senet():
+    # tests/layers/test_senet_layer.py:18-39: fields of width 1, 2, 3; reduction_ratio 0.3 -> middle_dim max(round(0.9), 1) = 1
+    r = TFSeededRNG(1)
+    xs = [r.random_normal_initializer([2, d]) for d in (1, 2, 3)]
+    k0 = r.glorot_uniform([3, 1])
+    k1 = r.glorot_uniform([1, 3])
+    b0, b1 = np.zeros((1,), np.float32), np.zeros((3,), np.float32)
+    golden = [[-0.00147045, -0.00081997, 0.00221329, 0.00113419, 0.00100974, -0.00180815],
+              [-0.00311359, -0.00019354, 0.00409976, -0.00334057, 0.00116946, 0.00371958]]
+    got = R.senet_layer([T(x) for x in xs], [T(k0), T(k1)], [T(b0), T(b1)]).numpy()
+    _save('senet', golden, got, input_0=xs[0], input_1=xs[1], input_2=xs[2], dense_0_kernel=k0, dense_1_kernel=k1,
+          dense_0_bias=b0, dense_1_bias=b1)
+
+
 if __name__ == '__main__':
-    fm(); dcn(); multi_dense(); mmoe(); dcn_mix(); cin(); ple()
+    fm(); dcn(); multi_dense(); mmoe(); dcn_mix(); cin(); ple(); inner_pnn(); senet()

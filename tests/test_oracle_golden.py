@@ -155,3 +155,62 @@ def test_c_oracle_equals_dense_oracle():
     loss, d, _ = C.pairwise_bpr(g, y, s, m, power=-0.5)
     assert abs(loss - rl.item()) < 1e-9 * max(1, abs(rl.item())) + 1e-7
     assert np.abs(d - s64.grad.numpy()).max() < 1e-7
+
+
+# ---- SURVEY section 8f rows -----------------------------------------------------------------------------------------
+def test_inner_pnn(golden):
+    # /root/reference/tests/layers/test_inner_pnn_layer.py:18-39
+    g = golden('inner_pnn')
+    out = R.inner_pnn_layer([T(x) for x in g['inputs']])
+    assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+
+
+def test_senet(golden):
+    # /root/reference/tests/layers/test_senet_layer.py:18-39
+    g = golden('senet')
+    out = R.senet_layer([T(g['input_%d' % i]) for i in range(3)], [T(g['dense_0_kernel']), T(g['dense_1_kernel'])],
+                        [T(g['dense_0_bias']), T(g['dense_1_bias'])])
+    assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+
+
+def test_focal_loss_literals():
+    # /root/reference/tests/rec_block/test_focal_loss.py:17-28
+    labels = torch.tensor([1, 1, 0, 0], dtype=torch.float32).reshape(-1, 1)
+    logits = torch.tensor([0.9, 0.8, 0.7, 0.6], dtype=torch.float32).reshape(-1, 1)
+    assert abs(float(R.focal_crossentropy_loss(labels, logits, alpha=None, gamma=None)) - 0.71323216) < 1e-5
+    assert abs(float(R.focal_crossentropy_loss(labels, logits, alpha=0.25, gamma=None)) - 0.44589227) < 1e-5
+    assert abs(float(R.focal_crossentropy_loss(labels, logits, alpha=None, gamma=1)) - 0.40516436) < 1e-5
+
+
+ATTN_USER = [[[0.1, 0.2], [-0.1, -0.2]], [[0.3, 0.4], [-0.3, -0.4]]]
+ATTN_DOC = [[0.1, 0.2], [0.3, 0.4]]
+ATTN_GOLDEN = {False: ([[0.01, 0.02], [0.15, 0.2]], [[0.0], [0.0]]), True: ([[0.005, 0.01], [0.075, 0.1]], [[0.05], [0.25]])}
+
+
+def test_attention_by_dot_product_literals():
+    # /root/reference/tests/rec_block/test_attention.py:19-56
+    for filter_neg, (gm, gs) in ATTN_GOLDEN.items():
+        mat, score = R.attention_by_dot_product(torch.tensor(ATTN_USER), torch.tensor(ATTN_DOC), filter_neg=filter_neg)
+        assert R.calc_sum_of_abs_diff(mat.numpy(), gm) < TOL
+        assert R.calc_sum_of_abs_diff(score.numpy(), gs) < TOL
+
+
+def embed_pool_case():
+    """/root/reference/tests/rec_block/test_embedding_util.py:71-109 (inputs and the two expected results)."""
+    import numpy as np
+    params = np.array([[i, -i] for i in range(40)], np.float32)
+    ids = np.array([[0, 10, 20, 30], [21, 30, 31, 1]], np.int64)
+    slots = ((ids.astype(np.float64) + 0.5) / 10.0).astype(np.int32)
+    weights = ids.astype(np.float32) * 10.0
+    exp_w = [[[1000., -1000.], [9000., -9000.]], [[0., 0.], [18610., -18610.]]]
+    exp_n = [[[10., -10.], [30., -30.]], [[0., 0.], [61., -61.]]]
+    return params, ids, slots, [1, 3], weights, exp_w, exp_n
+
+
+def test_embedding_pool_literals():
+    import numpy as np
+    params, ids, slots, targets, weights, exp_w, exp_n = embed_pool_case()
+    out = R.embedding_using_sparse_batch_segment_ids(T(params), T(slots), targets, T(ids), weights=T(weights))
+    assert np.array_equal(out.numpy(), np.array(exp_w, np.float32))
+    out = R.embedding_using_sparse_batch_segment_ids(T(params), T(slots), targets, T(ids))
+    assert np.array_equal(out.numpy(), np.array(exp_n, np.float32))
