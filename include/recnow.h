@@ -369,6 +369,35 @@ int recnow_focal_loss_bwd(const float* labels, const float* logits, int64_t B, f
                           int stop_weight_gradient, const float* gelem, const float* gscalar, float scale, float* dlogits,
                           void* stream);
 
+/* Pooled embedding lookup by slot: rec_now/rec_block/embedding_util.py:239-324 (and :138-195 for the slot -> target map).
+ *   recnow_slot_targets:   seg[i] = index of slots[i] in targets[0..T) or -1;  key[i] (optional) = ids[i] if seg[i] >= 0 else
+ *                          -1 (all-ones: sorts after every id >= 0 in recnow_group_segments).  slot_dtype: RECNOW_KEY_I32/I64
+ *                          (slots and targets share it; targets is a DEVICE array).  N = B*C entries.
+ *   recnow_embed_pool_fwd: out[b][t][:] = sum_{c: seg[b][c]==t} weights[b][c] * table[rows[b][c]][:]  (mean != 0: divided by the
+ *                          number of pooled entries, empty segments 0 - tf.math.unsorted_segment_mean).  rows: row index into
+ *                          `table` per entry (the ids themselves, or the inverse index of recnow_embed_unique); weights, cnt
+ *                          (B,T entry counts, needed by the 'mean' backward) may be NULL.  No atomics: fixed summation order.
+ *   recnow_embed_unique:   from the sort of `key` (recnow_group_keys(I64) + recnow_group_segments): unique[s] = id of sorted
+ *                          segment s, inverse[entry] = s, *n_unique = number of real ids (the -1 segment excluded).
+ *   recnow_embed_rows_bwd: drows[s][:] = sum over the entries of segment s of w * dout[b][t][:] (/cnt): the gradient of row
+ *                          unique[s]; row_ids[s] = that id (-1 for the unpooled segment and for unused slots s >= n_seg).
+ *                          drows / row_ids hold N slots.  The entry range is cut into fixed chunks (a hot id may own millions of
+ *                          entries); pieces are joined in ascending chunk order (ws: recnow_embed_rows_bwd_workspace_bytes).
+ *   recnow_embed_scatter_rows: dtable[row_ids[s]][:] = drows[s][:] into a zero-initialised dense (V,D) gradient. */
+int recnow_slot_targets(const void* slots, int slot_dtype, const void* targets, int T, const int64_t* ids, int64_t N,
+                        int32_t* seg, int64_t* key, void* stream);
+int recnow_embed_pool_fwd(const float* table, int D, const int64_t* rows, const int32_t* seg, const float* weights, int64_t B,
+                          int C, int T, int mean, float* out, float* cnt, void* stream);
+int recnow_embed_unique(const int64_t* key, const int32_t* order, const int32_t* seg_id, const int32_t* seg_first,
+                        const int32_t* n_seg, int64_t N, int64_t* unique, int64_t* inverse, int32_t* n_unique, void* stream);
+size_t recnow_embed_rows_bwd_workspace_bytes(int64_t N, int D);
+int recnow_embed_rows_bwd(const int64_t* key, const int32_t* order, const int32_t* seg_id, const int32_t* seg_first,
+                          const int32_t* n_seg, const int32_t* seg, const float* weights, const float* cnt, const float* dout,
+                          int64_t N, int C, int T, int D, int mean, float* drows, int64_t* row_ids, void* ws, size_t ws_bytes,
+                          void* stream);
+int recnow_embed_scatter_rows(const float* drows, const int64_t* row_ids, int64_t n_slots, int D, int64_t V, float* dtable,
+                              void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the GEMM kernels on the launch stream.
  * recnow_prof_enable(capacity > 0) arms `capacity` launch slots, (0) disables.  recnow_prof_collect synchronises and

@@ -141,61 +141,106 @@ extern "C" int recnow_inner_pnn_bwd(const float* const* fields, float* const* df
 
 // ---------------------------------------------------------------------------------------------------------------------
 // SENET.  Fields may have different widths: dims[f], offs[f] (column of field f in the concatenation) are DEVICE int32
-// arrays.  Thread = (row b, field f) with b fastest: a wave covers 64 consecutive rows of one (B, D_f) tensor, i.e. one
-// contiguous 64*D_f*4-byte block.
+// arrays.
 //   squeeze:   sq[b][f]  = mean_d x_f[b][d]                                   (:104-107)
 //   scale:     out[b][offs[f]+d] = x_f[b][d] * w[b][f]                        (:112-117)
 //   backward:  dw[b][f] = sum_d dout[b][offs[f]+d] * x_f[b][d];   dx_f[b][d] = dout * w[b][f] + dsq[b][f] / D_f
 // ---------------------------------------------------------------------------------------------------------------------
+// Thread = (row b, field f) with f FASTEST: a wave covers 64 consecutive fields of one row, so the concatenated (B,total)
+// tensors (out, dout) are touched as one contiguous run per wave, and each lane streams its own field row x_f[b][0..D_f) as
+// float4s (every 64-byte line it touches is used completely).
+__device__ __forceinline__ bool senet_vec(const float* p, int D) { return (D & 3) == 0 && ((uintptr_t)p & 15) == 0; }
+
 __global__ void __launch_bounds__(256)
 k_senet_squeeze(const float* const* __restrict__ fields, const int* __restrict__ dims, int F, int64_t B, float* __restrict__ sq) {
-    const int f = blockIdx.y;
-    const int D = dims[f];
-    const float* x = fields[f];
-    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+    const int64_t n = B * F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        const int D = dims[f];
+        const float* x = fields[f] + b * D;
         float s = 0.f;
-        for (int d = 0; d < D; ++d) s += x[b * D + d];
-        sq[b * F + f] = s / (float)D;
+        if (senet_vec(fields[f], D)) {
+            for (int d = 0; d < D; d += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(x + d);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            for (int d = 0; d < D; ++d) s += x[d];
+        }
+        sq[i] = s / (float)D;
     }
 }
 __global__ void __launch_bounds__(256)
 k_senet_scale(const float* const* __restrict__ fields, const int* __restrict__ dims, const int* __restrict__ offs, int F, int total,
               int64_t B, const float* __restrict__ w, float* __restrict__ out) {
-    const int f = blockIdx.y;
-    const int D = dims[f], o = offs[f];
-    const float* x = fields[f];
-    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
-        const float wf = w[b * F + f];
-        for (int d = 0; d < D; ++d) out[b * total + o + d] = x[b * D + d] * wf;
+    const int64_t n = B * F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        const int D = dims[f];
+        const float* x = fields[f] + b * D;
+        float* o = out + b * total + offs[f];
+        const float wf = w[i];
+        if (senet_vec(fields[f], D) && senet_vec(o, D) && (total & 3) == 0) {
+            for (int d = 0; d < D; d += 4) {
+                float4 v = *reinterpret_cast<const float4*>(x + d);
+                v.x *= wf; v.y *= wf; v.z *= wf; v.w *= wf;
+                *reinterpret_cast<float4*>(o + d) = v;
+            }
+        } else {
+            for (int d = 0; d < D; ++d) o[d] = x[d] * wf;
+        }
     }
 }
 __global__ void __launch_bounds__(256)
 k_senet_dw(const float* const* __restrict__ fields, const int* __restrict__ dims, const int* __restrict__ offs, int F, int total,
            int64_t B, const float* __restrict__ dout, float* __restrict__ dw) {
-    const int f = blockIdx.y;
-    const int D = dims[f], o = offs[f];
-    const float* x = fields[f];
-    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+    const int64_t n = B * F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        const int D = dims[f];
+        const float* x = fields[f] + b * D;
+        const float* g = dout + b * total + offs[f];
         float s = 0.f;
-        for (int d = 0; d < D; ++d) s += dout[b * total + o + d] * x[b * D + d];
-        dw[b * F + f] = s;
+        if (senet_vec(fields[f], D) && senet_vec(g, D) && (total & 3) == 0) {
+            for (int d = 0; d < D; d += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(x + d), q = *reinterpret_cast<const float4*>(g + d);
+                s += (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w);
+            }
+        } else {
+            for (int d = 0; d < D; ++d) s += g[d] * x[d];
+        }
+        dw[i] = s;
     }
 }
 __global__ void __launch_bounds__(256)
 k_senet_dx(float* const* __restrict__ dfields, const int* __restrict__ dims, const int* __restrict__ offs, int F, int total, int64_t B,
            const float* __restrict__ w, const float* __restrict__ dout, const float* __restrict__ dsq) {
-    const int f = blockIdx.y;
-    const int D = dims[f], o = offs[f];
-    float* dx = dfields[f];
-    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
-        const float wf = w[b * F + f], q = dsq[b * F + f] / (float)D;
-        for (int d = 0; d < D; ++d) dx[b * D + d] = dout[b * total + o + d] * wf + q;
+    const int64_t n = B * F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        const int D = dims[f];
+        float* dx = dfields[f] + b * D;
+        const float* g = dout + b * total + offs[f];
+        const float wf = w[i], q = dsq[i] / (float)D;
+        if (senet_vec(dfields[f], D) && senet_vec(g, D) && (total & 3) == 0) {
+            for (int d = 0; d < D; d += 4) {
+                float4 v = *reinterpret_cast<const float4*>(g + d);
+                v.x = v.x * wf + q; v.y = v.y * wf + q; v.z = v.z * wf + q; v.w = v.w * wf + q;
+                *reinterpret_cast<float4*>(dx + d) = v;
+            }
+        } else {
+            for (int d = 0; d < D; ++d) dx[d] = g[d] * wf + q;
+        }
     }
 }
-static inline dim3 senet_grid(int64_t B, int F) {
-    int64_t g = (B + 255) / 256;
-    if (g > 2048) g = 2048;
-    return dim3((unsigned)(g > 0 ? g : 1), (unsigned)F);
+static inline int senet_grid(int64_t B, int F) {
+    int64_t g = (B * F + 255) / 256;
+    if (g > 8192) g = 8192;
+    return (int)(g > 0 ? g : 1);
 }
 extern "C" int recnow_senet_squeeze(const float* const* fields, const int32_t* dims, int F, int64_t B, float* sq, void* stream) {
     if (F < 1 || F > 65535 || B < 0) return RECNOW_EINVAL;
@@ -240,89 +285,113 @@ extern "C" int recnow_senet_scale_bwd_x(float* const* dfields, const int32_t* di
 //   du[b][l][d] = dmat[b][d] * s_l + ds_l * doc[b][d];   ddoc[b][d] = sum_l ds_l * u[b][l][d]
 // HBM-bound: 4*B*L*D bytes forward, 8*B*L*D backward.
 // ---------------------------------------------------------------------------------------------------------------------
-#define ATTN_NCH 4      // 64-wide chunks of D kept in registers (D <= 256)
+#define ATTN_NCH 4      // 64-wide chunks of D kept in registers when one wave serves one row (64 < D <= 256)
+// GS lanes serve one row (GS = 16 / 32 / 64 for D <= 16 / 32 / more): a wave streams 64/GS rows at once, the per-row dot
+// products reduce inside the lane group with log2(GS) shuffles.
+template <int GS>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = GS / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int GS>
 __global__ void __launch_bounds__(256)
 k_attn_dot_fwd(const float* __restrict__ user, const float* __restrict__ doc, int64_t B, int L, int D, int filter_neg,
                float* __restrict__ mat, float* __restrict__ ssum) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
-        const float* u = user + b * L * D;
-        float dc[ATTN_NCH], acc[ATTN_NCH];
+    constexpr int RPW = 64 / GS, NCH = GS == 64 ? ATTN_NCH : 1;
+    const int lane = threadIdx.x & 63, gl = lane % GS, gr = lane / GS;
+    const int64_t nrg = (B + RPW - 1) / RPW;                    // row groups; every lane of a wave runs the same trip counts
+    for (int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); rg < nrg; rg += (int64_t)gridDim.x * 4) {
+        const int64_t b = rg * RPW + gr;
+        const bool ok = b < B;
+        const float* u = user + (ok ? b : 0) * L * D;
+        float dc[NCH], acc[NCH];
 #pragma unroll
-        for (int j = 0; j < ATTN_NCH; ++j) {
-            const int d = j * 64 + lane;
-            dc[j] = d < D ? doc[b * D + d] : 0.f;
+        for (int j = 0; j < NCH; ++j) {
+            const int d = j * 64 + gl;
+            dc[j] = (ok && d < D) ? doc[b * D + d] : 0.f;
             acc[j] = 0.f;
         }
         float tot = 0.f;
         for (int l = 0; l < L; ++l) {
-            float uv[ATTN_NCH], p = 0.f;
+            float uv[NCH], p = 0.f;
 #pragma unroll
-            for (int j = 0; j < ATTN_NCH; ++j) {
-                const int d = j * 64 + lane;
-                uv[j] = d < D ? u[(int64_t)l * D + d] : 0.f;
+            for (int j = 0; j < NCH; ++j) {
+                const int d = j * 64 + gl;
+                uv[j] = (ok && d < D) ? u[(int64_t)l * D + d] : 0.f;
                 p += uv[j] * dc[j];
             }
-            float s = wave_sum(p);
-            if (filter_neg) s = fmaxf(s, 0.f);
-            tot += s;
+            float sc = group_sum<GS>(p);
+            if (filter_neg) sc = fmaxf(sc, 0.f);
+            tot += sc;
 #pragma unroll
-            for (int j = 0; j < ATTN_NCH; ++j) acc[j] += uv[j] * s;
+            for (int j = 0; j < NCH; ++j) acc[j] += uv[j] * sc;
         }
 #pragma unroll
-        for (int j = 0; j < ATTN_NCH; ++j) {
-            const int d = j * 64 + lane;
-            if (d < D) mat[b * D + d] = acc[j];
+        for (int j = 0; j < NCH; ++j) {
+            const int d = j * 64 + gl;
+            if (ok && d < D) mat[b * D + d] = acc[j];
         }
-        if (lane == 0) ssum[b] = tot;
+        if (ok && gl == 0) ssum[b] = tot;
     }
 }
+template <int GS>
 __global__ void __launch_bounds__(256)
 k_attn_dot_bwd(const float* __restrict__ user, const float* __restrict__ doc, const float* __restrict__ dmat,
                const float* __restrict__ dsum, int64_t B, int L, int D, int filter_neg, float* __restrict__ duser,
                float* __restrict__ ddoc) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
-        const float* u = user + b * L * D;
-        float* du = duser + b * L * D;
-        const float gs = dsum ? dsum[b] : 0.f;
-        float dc[ATTN_NCH], gm[ATTN_NCH], acc[ATTN_NCH];
+    constexpr int RPW = 64 / GS, NCH = GS == 64 ? ATTN_NCH : 1;
+    const int lane = threadIdx.x & 63, gl = lane % GS, gr = lane / GS;
+    const int64_t nrg = (B + RPW - 1) / RPW;
+    for (int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); rg < nrg; rg += (int64_t)gridDim.x * 4) {
+        const int64_t b = rg * RPW + gr;
+        const bool ok = b < B;
+        const float* u = user + (ok ? b : 0) * L * D;
+        float* du = duser + (ok ? b : 0) * L * D;
+        const float gs = (ok && dsum) ? dsum[b] : 0.f;
+        float dc[NCH], gm[NCH], acc[NCH];
 #pragma unroll
-        for (int j = 0; j < ATTN_NCH; ++j) {
-            const int d = j * 64 + lane;
-            dc[j] = d < D ? doc[b * D + d] : 0.f;
-            gm[j] = (d < D && dmat) ? dmat[b * D + d] : 0.f;
+        for (int j = 0; j < NCH; ++j) {
+            const int d = j * 64 + gl;
+            dc[j] = (ok && d < D) ? doc[b * D + d] : 0.f;
+            gm[j] = (ok && d < D && dmat) ? dmat[b * D + d] : 0.f;
             acc[j] = 0.f;
         }
         for (int l = 0; l < L; ++l) {
-            float uv[ATTN_NCH], p = 0.f, q = 0.f;
+            float uv[NCH], p = 0.f, q = 0.f;
 #pragma unroll
-            for (int j = 0; j < ATTN_NCH; ++j) {
-                const int d = j * 64 + lane;
-                uv[j] = d < D ? u[(int64_t)l * D + d] : 0.f;
+            for (int j = 0; j < NCH; ++j) {
+                const int d = j * 64 + gl;
+                uv[j] = (ok && d < D) ? u[(int64_t)l * D + d] : 0.f;
                 p += uv[j] * dc[j];
                 q += uv[j] * gm[j];
             }
-            const float sraw = wave_sum(p);
-            float ds = wave_sum(q) + gs;
-            float s = sraw;
+            const float sraw = group_sum<GS>(p);
+            float ds = group_sum<GS>(q) + gs;
+            float sc = sraw;
             if (filter_neg) {
-                s = fmaxf(sraw, 0.f);
+                sc = fmaxf(sraw, 0.f);
                 if (!(sraw > 0.f)) ds = 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < ATTN_NCH; ++j) {
-                const int d = j * 64 + lane;
-                if (d < D) du[(int64_t)l * D + d] = gm[j] * s + ds * dc[j];
+            for (int j = 0; j < NCH; ++j) {
+                const int d = j * 64 + gl;
+                if (ok && d < D) du[(int64_t)l * D + d] = gm[j] * sc + ds * dc[j];
                 acc[j] += ds * uv[j];
             }
         }
 #pragma unroll
-        for (int j = 0; j < ATTN_NCH; ++j) {
-            const int d = j * 64 + lane;
-            if (d < D) ddoc[b * D + d] = acc[j];
+        for (int j = 0; j < NCH; ++j) {
+            const int d = j * 64 + gl;
+            if (ok && d < D) ddoc[b * D + d] = acc[j];
         }
     }
+}
+static inline int attn_grid(int64_t B, int gs) {
+    const int64_t nrg = (B + (64 / gs) - 1) / (64 / gs);
+    int64_t g = (nrg + 3) / 4;
+    if (g > 8192) g = 8192;
+    return (int)(g > 0 ? g : 1);
 }
 extern "C" int recnow_attention_dot_fwd(const float* user, const float* doc, int64_t B, int L, int D, int filter_neg, float* mat,
                                         float* score_sum, void* stream) {
@@ -330,9 +399,10 @@ extern "C" int recnow_attention_dot_fwd(const float* user, const float* doc, int
     if (D > 64 * ATTN_NCH) return RECNOW_EUNSUPPORTED;
     if (B == 0) return RECNOW_OK;
     if ((L > 0 && !user) || !doc || !mat || !score_sum) return RECNOW_EINVAL;
-    int64_t g = (B + 3) / 4;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_attn_dot_fwd, (int)g, 256, 0, (hipStream_t)stream, user, doc, B, L, D, filter_neg, mat, score_sum);
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 16) hipLaunchKernelGGL(k_attn_dot_fwd<16>, attn_grid(B, 16), 256, 0, st, user, doc, B, L, D, filter_neg, mat, score_sum);
+    else if (D <= 32) hipLaunchKernelGGL(k_attn_dot_fwd<32>, attn_grid(B, 32), 256, 0, st, user, doc, B, L, D, filter_neg, mat, score_sum);
+    else hipLaunchKernelGGL(k_attn_dot_fwd<64>, attn_grid(B, 64), 256, 0, st, user, doc, B, L, D, filter_neg, mat, score_sum);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -342,9 +412,10 @@ extern "C" int recnow_attention_dot_bwd(const float* user, const float* doc, con
     if (D > 64 * ATTN_NCH) return RECNOW_EUNSUPPORTED;
     if (B == 0) return RECNOW_OK;
     if ((L > 0 && (!user || !duser)) || !doc || !ddoc) return RECNOW_EINVAL;
-    int64_t g = (B + 3) / 4;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_attn_dot_bwd, (int)g, 256, 0, (hipStream_t)stream, user, doc, dmat, dsum, B, L, D, filter_neg, duser, ddoc);
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 16) hipLaunchKernelGGL(k_attn_dot_bwd<16>, attn_grid(B, 16), 256, 0, st, user, doc, dmat, dsum, B, L, D, filter_neg, duser, ddoc);
+    else if (D <= 32) hipLaunchKernelGGL(k_attn_dot_bwd<32>, attn_grid(B, 32), 256, 0, st, user, doc, dmat, dsum, B, L, D, filter_neg, duser, ddoc);
+    else hipLaunchKernelGGL(k_attn_dot_bwd<64>, attn_grid(B, 64), 256, 0, st, user, doc, dmat, dsum, B, L, D, filter_neg, duser, ddoc);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

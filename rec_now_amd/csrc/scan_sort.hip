@@ -330,7 +330,12 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     hipLaunchKernelGGL(k_sort_plan, 1, 256, 0, st, ghist, B, n_words, plan);
     for (int p = 0; p < n_words * 4; ++p) {
         hipLaunchKernelGGL(k_sort_blockhist, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, blockhist, nblk);
-        hipLaunchKernelGGL(k_sort_scan, 1, 1024, 0, st, blockhist, 256 * nblk, p, plan);
+        if (256 * (int64_t)nblk <= 32768) {
+            hipLaunchKernelGGL(k_sort_scan, 1, 1024, 0, st, blockhist, 256 * nblk, p, plan);
+        } else {        // millions of keys (pooled embedding ids): device-wide scan, in place (a skipped pass scans stale counts, unused)
+            int rc2 = rn_scan<unsigned, unsigned, 0>(blockhist, blockhist, 256 * (int64_t)nblk, 0, scan_ws, scan_ws_bytes, st);
+            if (rc2) return rc2;
+        }
         hipLaunchKernelGGL(k_sort_scatter, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, blockhist, nblk);
     }
     hipLaunchKernelGGL(k_seg_heads, G, T, 0, st, words, solo, B, n_words, n_words_first, plan, idx0, idx1, order, head, shead);

@@ -1,0 +1,89 @@
+"""GPU parity for the pooled embedding lookup: rec_block/embedding_util.py against the reference's
+own test vectors (bit-exact: the vectors are small integers) and, forward + backward, against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import dense_ref as R
+from test_oracle_golden import embed_pool_case
+
+pytestmark = pytest.mark.gpu
+T_ = torch.from_numpy
+
+
+def test_sparse_batch_segment_ids_of_targets_reference_vector(dev):
+    # /root/reference/tests/rec_block/test_embedding_util.py:55-69 (integer path: exact)
+    from rec_now_amd.rec_block.embedding_util import sparse_batch_segment_ids_of_targets
+    slots = torch.tensor([[0, 1, 1, 2, 3, 3], [1, 3, 3, 2, 5, 5]], device=dev)
+    mask, sp_segment_ids, num_rows, num_ids, num_segments = sparse_batch_segment_ids_of_targets(slots, [1, 3, 5])
+    assert mask.cpu().tolist() == [[False, True, True, False, True, True], [True, True, True, False, True, True]]
+    assert sp_segment_ids.cpu().tolist() == [0, 0, 1, 1, 3, 4, 4, 5, 5]
+    assert (num_rows, num_ids, num_segments) == (2, 3, 6)
+
+
+@pytest.mark.parametrize('path', ['table', 'callable_unique', 'callable_no_unique'])
+def test_embedding_using_sparse_batch_segment_ids_reference_vectors(dev, path):
+    # /root/reference/tests/rec_block/test_embedding_util.py:71-109
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    params, ids, slots, target_slots, weights, exp_w, exp_n = embed_pool_case()
+    pd = T_(params).to(dev)
+    if path == 'table':
+        embedding_func = EmbeddingTable(pd)
+    else:
+        def embedding_func(i): return pd[i]
+    kw = dict(use_unique=(path != 'callable_no_unique'))
+    out = embedding_using_sparse_batch_segment_ids(embedding_func, T_(slots).to(dev), target_slots, T_(ids).to(dev),
+                                                   weights=T_(weights).to(dev), **kw)
+    assert np.array_equal(out.detach().cpu().numpy(), np.array(exp_w, np.float32))
+    out = embedding_using_sparse_batch_segment_ids(embedding_func, T_(slots).to(dev), target_slots, T_(ids).to(dev), weights=None, **kw)
+    assert np.array_equal(out.detach().cpu().numpy(), np.array(exp_n, np.float32))
+
+
+@pytest.mark.parametrize('B,C,T,D,V,method,use_w', [(1, 1, 1, 1, 3, 'sum', False), (37, 20, 5, 16, 50, 'sum', True), (300, 64, 24, 16, 1000, 'mean', True),
+                                                    (64, 33, 3, 70, 7, 'mean', False), (5, 8, 4, 8, 100, 'sum', True)])
+@pytest.mark.parametrize('path', ['table', 'callable_unique', 'callable_no_unique'])
+def test_embedding_pool_fwd_bwd_vs_oracle(dev, B, C, T, D, V, method, use_w, path):
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    rng = np.random.default_rng(B * 7 + C + T + D)
+    n_slots = T + 3
+    slots = rng.integers(0, n_slots, (B, C)).astype(np.int32)
+    target_slots = [int(v) for v in rng.permutation(n_slots)[:T]]
+    ids = rng.integers(0, V, (B, C)).astype(np.int64)
+    if B > 4:
+        ids[: B // 2, : max(C // 2, 1)] = 1 % V                      # a hot id with many entries
+    weights = rng.uniform(0.5, 1.5, (B, C)).astype(np.float32) if use_w else None
+    params = rng.normal(size=(V, D)).astype(np.float32)
+    gout = rng.normal(size=(B, T, D)).astype(np.float32)
+    table = torch.nn.Parameter(T_(params).to(dev))
+    if path == 'table':
+        embedding_func = EmbeddingTable(table)
+    else:
+        from rec_now_amd.rec_block.embedding_util import EmbeddingTable as ET
+        lookup = ET(table)
+        def embedding_func(i): return lookup(i)                 # a user callable (here: the HIP row lookup)
+    out = embedding_using_sparse_batch_segment_ids(embedding_func, T_(slots).to(dev), target_slots, T_(ids).to(dev),
+                                                   weights=None if weights is None else T_(weights).to(dev), method=method,
+                                                   use_unique=(path != 'callable_no_unique'))
+    out.backward(T_(gout).to(dev))
+    p64 = T_(params).double().requires_grad_(True)
+    ref = R.embedding_using_sparse_batch_segment_ids(p64, T_(slots), target_slots, T_(ids), None if weights is None else T_(weights).double(), method)
+    ref.backward(T_(gout).double())
+    scale = max(float(ref.detach().abs().max()), 1.0)
+    assert np.abs(out.detach().cpu().double().numpy() - ref.detach().numpy()).max() <= 1e-5 * scale
+    gs = max(float(p64.grad.abs().max()), 1.0)
+    assert np.abs(table.grad.cpu().double().numpy() - p64.grad.numpy()).max() <= 1e-5 * gs
+
+
+def test_embedding_pool_no_target_present_and_errors(dev):
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    table = EmbeddingTable(torch.ones(4, 2, device=dev))
+    ids = torch.tensor([[0, 1], [2, 3]], device=dev)
+    slots = torch.tensor([[7, 7], [7, 7]], device=dev)
+    out = embedding_using_sparse_batch_segment_ids(table, slots, [1, 2], ids, method='mean')
+    assert out.shape == (2, 2, 2) and float(out.abs().sum()) == 0.0
+    out = embedding_using_sparse_batch_segment_ids(lambda i: torch.ones(i.numel(), 2, device=dev), slots, [1, 2], ids)
+    assert out.shape == (2, 2, 2) and float(out.abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        embedding_using_sparse_batch_segment_ids(table, slots, [1, 1], ids)
+    with pytest.raises(ValueError):
+        embedding_using_sparse_batch_segment_ids(table, slots, [1], ids, method='max')

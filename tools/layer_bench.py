@@ -1,6 +1,6 @@
 """Per-row measurements of the other hot-path kernels at BASELINE config sizes (1x MI355X), fwd+bwd, inputs resident.
 Reports the figure each kernel's roofline is priced in: HBM GB/s for FM / DCN-v1 / MoE mix,
-rows/s and pairs/s for the ranking losses, TFLOP/s for CIN / MMoE / PLE.   usage: python tools/layer_bench.py [reps] [fm,dcn,pair,list,cin,ple]"""
+rows/s and pairs/s for the ranking losses, TFLOP/s for CIN / MMoE / PLE.   usage: python tools/layer_bench.py [reps] [fm,dcn,pair,list,cin,ple,ipnn,senet,attn,focal,embed]"""
 import os
 import sys
 
@@ -133,8 +133,96 @@ def ple():
     print('PLELayer fwd+bwd  B=%d Din=%d 3 tasks : %.2f ms  ~%.1f TFLOP/s (3x fwd GEMM flops)  %.1f k samples/s' % (B, Din, ms, 3 * fl / ms / 1e9, B / ms))
 
 
+def ipnn():
+    from rec_now_amd.layers.inner_pnn_layer import InnerPNNLayer
+    B, F, D = 131072, 64, 16
+    xs = [torch.randn(B, D, device=dev, requires_grad=True) for _ in range(F)]
+    P = F * (F - 1) // 2
+    gy = torch.randn(B, P, device=dev)
+    layer = InnerPNNLayer()
+
+    def step():
+        for x in xs:
+            x.grad = None
+        layer(xs).backward(gy)
+    ms = timeit(step)
+    print('InnerPNN fwd+bwd  B=%d F=%d D=%d P=%d : %.3f ms  %.0f GB/s algorithmic (8*B*P + 12*B*F*D bytes)  %.1f M samples/s'
+          % (B, F, D, P, ms, (8.0 * B * P + 12.0 * B * F * D) / ms / 1e6, B / ms / 1e3))
+
+
+def senet():
+    from rec_now_amd.layers.senet_layer import SENETLayer
+    B, F, D = 131072, 64, 16
+    xs = [torch.randn(B, D, device=dev, requires_grad=True) for _ in range(F)]
+    gy = torch.randn(B, F * D, device=dev)
+    layer = SENETLayer(0.25)
+    layer(xs)
+
+    def step():
+        for x in xs:
+            x.grad = None
+        layer(xs).backward(gy)
+    ms = timeit(step)
+    print('SENETLayer fwd+bwd B=%d F=%d D=%d : %.3f ms  %.0f GB/s algorithmic (24*B*F*D bytes: x x2 fwd, x dout x2 + dx bwd)  %.1f M samples/s'
+          % (B, F, D, ms, 24.0 * B * F * D / ms / 1e6, B / ms / 1e3))
+
+
+def attn():
+    from rec_now_amd.rec_block.attention import attention_by_dot_product
+    B, L, D = 131072, 50, 16
+    u = torch.randn(B, L, D, device=dev, requires_grad=True)
+    d = torch.randn(B, D, device=dev, requires_grad=True)
+    gm = torch.randn(B, D, device=dev)
+
+    def step():
+        u.grad = None
+        d.grad = None
+        mat, s = attention_by_dot_product(u, d, filter_neg=True)
+        (mat * gm).sum().add(s.sum()).backward()
+    ms = timeit(step)
+    print('attention_by_dot_product fwd+bwd B=%d L=%d D=%d : %.3f ms  %.0f GB/s algorithmic (12*B*L*D bytes)  %.1f M samples/s'
+          % (B, L, D, ms, 12.0 * B * L * D / ms / 1e6, B / ms / 1e3))
+
+
+def focal():
+    from rec_now_amd.rec_block.focal_loss import focal_crossentropy_loss
+    B = 1 << 22
+    x = torch.randn(B, device=dev, requires_grad=True)
+    z = (torch.rand(B, device=dev) < 0.25).float()
+
+    def step():
+        x.grad = None
+        focal_crossentropy_loss(z, x).backward()
+    ms = timeit(step)
+    print('focal_crossentropy_loss fwd+bwd B=%d : %.3f ms  %.0f GB/s algorithmic (20*B bytes)  %.0f M samples/s' % (B, ms, 20.0 * B / ms / 1e6, B / ms / 1e3))
+
+
+def embed():
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    B, C, T, D, V = 65536, 100, 64, 16, 1 << 20          # c3: 64 pooled fields x 16-dim from 100 id columns per row
+    rng = np.random.default_rng(7)
+    slots = torch.from_numpy(rng.integers(0, 80, (B, C)).astype(np.int32)).to(dev)
+    ids = torch.from_numpy((rng.zipf(1.3, (B, C)) % V).astype(np.int64)).to(dev)
+    table = EmbeddingTable(torch.randn(V, D, device=dev) * 0.05)
+    gy = torch.randn(B, T, D, device=dev)
+    targets = list(range(T))
+
+    def fwd():
+        return embedding_using_sparse_batch_segment_ids(table, slots, targets, ids)
+
+    def step():
+        table.weight.grad = None
+        fwd().backward(gy)
+    ms_f = timeit(fwd)
+    ms = timeit(step)
+    pooled = float((slots < T).sum().item())
+    print('embedding pooled lookup B=%d C=%d T=%d D=%d V=%d : fwd %.3f ms (%.0f GB/s: 4*D bytes gathered per pooled id + 16 B/id + 4*B*T*D out), '
+          'fwd+bwd %.3f ms (sort by id + per-id reduction + dense scatter)  %.1f M ids/s'
+          % (B, C, T, D, V, ms_f, (pooled * 4 * D + 16.0 * B * C + 4.0 * B * T * D) / ms_f / 1e6, ms, B * C / ms / 1e3))
+
+
 if __name__ == '__main__':
-    which = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fm', 'dcn', 'pair', 'list', 'cin', 'ple']
+    which = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fm', 'dcn', 'pair', 'list', 'cin', 'ple', 'ipnn', 'senet', 'attn', 'focal', 'embed']
     if 'fm' in which:
         fm()
     if 'dcn' in which:
@@ -148,3 +236,6 @@ if __name__ == '__main__':
         cin()
     if 'ple' in which:
         ple()
+    for name, fn in (('ipnn', ipnn), ('senet', senet), ('attn', attn), ('focal', focal), ('embed', embed)):
+        if name in which:
+            fn()
