@@ -340,14 +340,18 @@ int recnow_inner_pnn_bwd(const float* const* fields, float* const* dfields, int 
  *   scale   (:112-117):      out[b][offs[f]+d] = x_f[b][d] * w[b][f]                      w: (B,F) excitation, out: (B,total)
  *   scale_bwd_w:             dw[b][f] = sum_d dout[b][offs[f]+d] * x_f[b][d]
  *   scale_bwd_x:             dx_f[b][d] = dout[b][offs[f]+d] * w[b][f] + dsq[b][f] / dims[f]   (dsq = gradient w.r.t. sq)
+ * uniform_d > 0: the caller's promise that every field is uniform_d wide and all tensors are 16-byte aligned (selects the
+ * float4 path when uniform_d/4 is a power of two); 0: general widths, staged through LDS (one concatenated row must fit:
+ * total <= 12287).
  * The two Dense layers between squeeze and scale (:46-66) are recnow_multi_dense_* with N = 1. */
-int recnow_senet_squeeze(const float* const* fields, const int32_t* dims, int F, int64_t B, float* sq, void* stream);
+int recnow_senet_squeeze(const float* const* fields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
+                         float* sq, int uniform_d, void* stream);
 int recnow_senet_scale_fwd(const float* const* fields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
-                           const float* w, float* out, void* stream);
+                           const float* w, float* out, int uniform_d, void* stream);
 int recnow_senet_scale_bwd_w(const float* const* fields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
-                             const float* dout, float* dw, void* stream);
+                             const float* dout, float* dw, int uniform_d, void* stream);
 int recnow_senet_scale_bwd_x(float* const* dfields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
-                             const float* w, const float* dout, const float* dsq, void* stream);
+                             const float* w, const float* dout, const float* dsq, int uniform_d, void* stream);
 
 /* attention_by_dot_product: rec_now/rec_block/attention.py:12-38.  user (B,L,D), doc (B,D), D <= 256:
  *   s_l = <user[b][l], doc[b]> (max(.,0) when filter_neg, :31-32);  mat[b] = sum_l user[b][l] * s_l;  score_sum[b] = sum_l s_l

@@ -17,15 +17,20 @@
 template <int DMAX>
 __global__ void __launch_bounds__(256)
 k_ipnn_fwd(const float* const* __restrict__ fields, int F, int64_t B, int D, float* __restrict__ out) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int LD = D + 1;
-    float* xs = lds + (size_t)w * F * LD;
+    // two images of the row's F x D block: xb (row stride DMAX, 16-byte aligned: x_r is read as float4 BROADCASTS, 4x fewer
+    // LDS instructions than scalar reads, which is what bounds this kernel) and xs (stride D+1: conflict-free per-lane reads)
+    float* xb = lds + (size_t)w * F * (DMAX + LD);
+    float* xs = xb + F * DMAX;
     const int64_t P = (int64_t)F * (F - 1) / 2;
     for (int64_t b = (int64_t)blockIdx.x * nw + w; b < B; b += (int64_t)gridDim.x * nw) {
-        for (int i = lane; i < F * D; i += 64) {
-            const int f = i / D, d = i - f * D;
-            xs[f * LD + d] = fields[f][b * D + d];
+        for (int i = lane; i < F * DMAX; i += 64) {
+            const int f = i / DMAX, d = i - f * DMAX;
+            const float v = d < D ? fields[f][b * D + d] : 0.f;
+            xb[i] = v;
+            if (d < D) xs[f * LD + d] = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes, then its reads
         float* ob = out + b * P;
@@ -38,8 +43,10 @@ k_ipnn_fwd(const float* const* __restrict__ fields, int F, int64_t B, int D, flo
             for (int r = 0; r < rmax; ++r) {
                 float s = 0.f;
 #pragma unroll
-                for (int d = 0; d < DMAX; ++d)
-                    if (d < D) s += xs[r * LD + d] * xc[d];
+                for (int d = 0; d < DMAX; d += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xb + r * DMAX + d);
+                    s += v.x * xc[d] + v.y * xc[d + 1] + v.z * xc[d + 2] + v.w * xc[d + 3];
+                }
                 if (c > r && c < F) ob[(int64_t)r * F - (int64_t)r * (r + 1) / 2 + (c - r - 1)] = s;
             }
         }
@@ -52,16 +59,15 @@ template <int DMAX>
 __global__ void __launch_bounds__(256)
 k_ipnn_bwd(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int64_t B, int D,
            const float* __restrict__ dout) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int LD = D + 1;
     const int P = F * (F - 1) / 2;
-    float* xs = lds + (size_t)w * (F * LD + P);
-    float* gs = xs + F * LD;
+    float* xb = lds + (size_t)w * (F * DMAX + P);        // x rows, stride DMAX (float4 broadcasts)
+    float* gs = xb + F * DMAX;
     for (int64_t b = (int64_t)blockIdx.x * nw + w; b < B; b += (int64_t)gridDim.x * nw) {
-        for (int i = lane; i < F * D; i += 64) {
-            const int f = i / D, d = i - f * D;
-            xs[f * LD + d] = fields[f][b * D + d];
+        for (int i = lane; i < F * DMAX; i += 64) {
+            const int f = i / DMAX, d = i - f * DMAX;
+            xb[i] = d < D ? fields[f][b * D + d] : 0.f;
         }
         for (int i = lane; i < P; i += 64) gs[i] = dout[b * P + i];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -74,14 +80,22 @@ k_ipnn_bwd(const float* const* __restrict__ fields, float* const* __restrict__ d
                 const int r = min(f, g), c = max(f, g);
                 const float wgt = (f < F && g != f) ? gs[r * F - r * (r + 1) / 2 + (c - r - 1)] : 0.f;
 #pragma unroll
-                for (int d = 0; d < DMAX; ++d)
-                    if (d < D) acc[d] += wgt * xs[g * LD + d];
+                for (int d = 0; d < DMAX; d += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xb + g * DMAX + d);
+                    acc[d] += wgt * v.x; acc[d + 1] += wgt * v.y; acc[d + 2] += wgt * v.z; acc[d + 3] += wgt * v.w;
+                }
             }
             if (f < F) {
                 float* o = dfields[f] + b * D;
+                if ((D & 3) == 0 && ((uintptr_t)dfields[f] & 15) == 0) {
 #pragma unroll
-                for (int d = 0; d < DMAX; ++d)
-                    if (d < D) o[d] = acc[d];
+                    for (int d = 0; d < DMAX; d += 4)
+                        if (d < D) *reinterpret_cast<float4*>(o + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
+                } else {
+#pragma unroll
+                    for (int d = 0; d < DMAX; ++d)
+                        if (d < D) o[d] = acc[d];
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next row overwrites the tile
@@ -89,7 +103,8 @@ k_ipnn_bwd(const float* const* __restrict__ fields, float* const* __restrict__ d
 }
 
 static int ipnn_cfg(int F, int D, bool bwd, int* waves, size_t* lds) {
-    const size_t per_wave = ((size_t)F * (D + 1) + (bwd ? (size_t)F * (F - 1) / 2 : 0)) * sizeof(float);
+    const int dmax = D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64;
+    const size_t per_wave = ((size_t)F * dmax + (bwd ? (size_t)F * (F - 1) / 2 : (size_t)F * (D + 1))) * sizeof(float);
     int w = 4;
     while (w > 1 && per_wave * w > 64 * 1024) w >>= 1;
     if (per_wave * w > 64 * 1024) return RECNOW_EUNSUPPORTED;
@@ -146,136 +161,179 @@ extern "C" int recnow_inner_pnn_bwd(const float* const* fields, float* const* df
 //   scale:     out[b][offs[f]+d] = x_f[b][d] * w[b][f]                        (:112-117)
 //   backward:  dw[b][f] = sum_d dout[b][offs[f]+d] * x_f[b][d];   dx_f[b][d] = dout * w[b][f] + dsq[b][f] / D_f
 // ---------------------------------------------------------------------------------------------------------------------
-// Thread = (row b, field f) with f FASTEST: a wave covers 64 consecutive fields of one row, so the concatenated (B,total)
-// tensors (out, dout) are touched as one contiguous run per wave, and each lane streams its own field row x_f[b][0..D_f) as
-// float4s (every 64-byte line it touches is used completely).
-__device__ __forceinline__ bool senet_vec(const float* p, int D) { return (D & 3) == 0 && ((uintptr_t)p & 15) == 0; }
-
+// A workgroup owns R consecutive rows.  Every field's R x D_f block is CONTIGUOUS in its (B, D_f) tensor and every R-row
+// slab of the concatenated (B, total) tensors is contiguous too, so all global traffic is long coalesced runs; the
+// re-arrangement between the two layouts goes through an LDS tile [R][total].
+//   squeeze: tile <- fields;  sq[b][f] = mean over the tile columns of f
+//   scale:   tile <- fields * w[b][f];  out slab <- tile
+//   dw:      tile <- dout slab;  dw[b][f] = <tile columns of f, x_f[b]>
+//   dx:      tile <- dout slab;  dx_f block <- tile * w + dsq / D_f
+#define SENET_MODE_SQUEEZE 0
+#define SENET_MODE_SCALE 1
+#define SENET_MODE_DW 2
+#define SENET_MODE_DX 3
+template <int MODE>
 __global__ void __launch_bounds__(256)
-k_senet_squeeze(const float* const* __restrict__ fields, const int* __restrict__ dims, int F, int64_t B, float* __restrict__ sq) {
-    const int64_t n = B * F;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t b = i / F;
-        const int f = (int)(i - b * F);
-        const int D = dims[f];
-        const float* x = fields[f] + b * D;
-        float s = 0.f;
-        if (senet_vec(fields[f], D)) {
-            for (int d = 0; d < D; d += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(x + d);
-                s += (v.x + v.y) + (v.z + v.w);
-            }
-        } else {
-            for (int d = 0; d < D; ++d) s += x[d];
+k_senet_tile(const float* const* __restrict__ fields, float* const* __restrict__ dfields, const int* __restrict__ dims,
+             const int* __restrict__ offs, int F, int total, int64_t B, int R, const float* __restrict__ w,
+             const float* __restrict__ in, const float* __restrict__ dsq, float* __restrict__ out) {
+    extern __shared__ float tile[];                  // [R][total + 1]
+    const int LDT = total + 1;
+    const int tid = threadIdx.x;
+    for (int64_t b0 = (int64_t)blockIdx.x * R; b0 < B; b0 += (int64_t)gridDim.x * R) {
+        const int rows = (int)min((int64_t)R, B - b0);
+        __syncthreads();
+        if (MODE == SENET_MODE_DW || MODE == SENET_MODE_DX) {          // dout slab -> tile
+            const float* src = in + b0 * total;
+            for (int i = tid; i < rows * total; i += 256) tile[(i / total) * LDT + (i % total)] = src[i];
+            __syncthreads();
         }
-        sq[i] = s / (float)D;
-    }
-}
-__global__ void __launch_bounds__(256)
-k_senet_scale(const float* const* __restrict__ fields, const int* __restrict__ dims, const int* __restrict__ offs, int F, int total,
-              int64_t B, const float* __restrict__ w, float* __restrict__ out) {
-    const int64_t n = B * F;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t b = i / F;
-        const int f = (int)(i - b * F);
-        const int D = dims[f];
-        const float* x = fields[f] + b * D;
-        float* o = out + b * total + offs[f];
-        const float wf = w[i];
-        if (senet_vec(fields[f], D) && senet_vec(o, D) && (total & 3) == 0) {
-            for (int d = 0; d < D; d += 4) {
-                float4 v = *reinterpret_cast<const float4*>(x + d);
-                v.x *= wf; v.y *= wf; v.z *= wf; v.w *= wf;
-                *reinterpret_cast<float4*>(o + d) = v;
+        for (int f = 0; f < F; ++f) {
+            const int D = dims[f], o = offs[f];
+            const int n = rows * D;
+            if (MODE == SENET_MODE_SQUEEZE) {
+                const float* x = fields[f] + b0 * D;
+                for (int i = tid; i < n; i += 256) tile[(i / D) * LDT + o + (i % D)] = x[i];
+            } else if (MODE == SENET_MODE_SCALE) {
+                const float* x = fields[f] + b0 * D;
+                for (int i = tid; i < n; i += 256) {
+                    const int r = i / D;
+                    tile[r * LDT + o + (i % D)] = x[i] * w[(b0 + r) * F + f];
+                }
+            } else if (MODE == SENET_MODE_DW) {                          // tile <- tile * x (products), summed below
+                const float* x = fields[f] + b0 * D;
+                for (int i = tid; i < n; i += 256) tile[(i / D) * LDT + o + (i % D)] *= x[i];
+            } else {                                                     // DX: straight to the field gradient block
+                float* dx = dfields[f] + b0 * D;
+                for (int i = tid; i < n; i += 256) {
+                    const int r = i / D;
+                    dx[i] = tile[r * LDT + o + (i % D)] * w[(b0 + r) * F + f] + dsq[(b0 + r) * F + f] / (float)D;
+                }
             }
-        } else {
-            for (int d = 0; d < D; ++d) o[d] = x[d] * wf;
         }
-    }
-}
-__global__ void __launch_bounds__(256)
-k_senet_dw(const float* const* __restrict__ fields, const int* __restrict__ dims, const int* __restrict__ offs, int F, int total,
-           int64_t B, const float* __restrict__ dout, float* __restrict__ dw) {
-    const int64_t n = B * F;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t b = i / F;
-        const int f = (int)(i - b * F);
-        const int D = dims[f];
-        const float* x = fields[f] + b * D;
-        const float* g = dout + b * total + offs[f];
-        float s = 0.f;
-        if (senet_vec(fields[f], D) && senet_vec(g, D) && (total & 3) == 0) {
-            for (int d = 0; d < D; d += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(x + d), q = *reinterpret_cast<const float4*>(g + d);
-                s += (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w);
+        if (MODE == SENET_MODE_DX) continue;
+        __syncthreads();
+        if (MODE == SENET_MODE_SCALE) {                                  // tile -> out slab
+            float* dst = out + b0 * total;
+            for (int i = tid; i < rows * total; i += 256) dst[i] = tile[(i / total) * LDT + (i % total)];
+        } else {                                                         // per (row, field) sums over the field's columns
+            for (int i = tid; i < rows * F; i += 256) {
+                const int r = i / F, f = i - r * F;
+                const int D = dims[f], o = offs[f];
+                float s = 0.f;
+                for (int d = 0; d < D; ++d) s += tile[r * LDT + o + d];
+                out[(b0 + r) * F + f] = MODE == SENET_MODE_SQUEEZE ? s / (float)D : s;
             }
-        } else {
-            for (int d = 0; d < D; ++d) s += g[d] * x[d];
-        }
-        dw[i] = s;
-    }
-}
-__global__ void __launch_bounds__(256)
-k_senet_dx(float* const* __restrict__ dfields, const int* __restrict__ dims, const int* __restrict__ offs, int F, int total, int64_t B,
-           const float* __restrict__ w, const float* __restrict__ dout, const float* __restrict__ dsq) {
-    const int64_t n = B * F;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t b = i / F;
-        const int f = (int)(i - b * F);
-        const int D = dims[f];
-        float* dx = dfields[f] + b * D;
-        const float* g = dout + b * total + offs[f];
-        const float wf = w[i], q = dsq[i] / (float)D;
-        if (senet_vec(dfields[f], D) && senet_vec(g, D) && (total & 3) == 0) {
-            for (int d = 0; d < D; d += 4) {
-                float4 v = *reinterpret_cast<const float4*>(g + d);
-                v.x = v.x * wf + q; v.y = v.y * wf + q; v.z = v.z * wf + q; v.w = v.w * wf + q;
-                *reinterpret_cast<float4*>(dx + d) = v;
-            }
-        } else {
-            for (int d = 0; d < D; ++d) dx[d] = g[d] * wf + q;
         }
     }
 }
-static inline int senet_grid(int64_t B, int F) {
-    int64_t g = (B * F + 255) / 256;
-    if (g > 8192) g = 8192;
-    return (int)(g > 0 ? g : 1);
+// Fast path for the usual case of equal field widths D with D % 4 == 0 and D/4 a power of two: thread = (row b, float4 q of
+// the concatenated row).  Every access is a float4; the concatenated tensors are touched fully coalesced, the field tensors
+// in 4*D-byte runs; nothing is staged and all loads of a thread are independent.  (row, field) sums reduce over the D/4
+// adjacent lanes of the field with shuffles (groups are lane-aligned because total/4 is a multiple of D/4).
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_senet_uniform(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int D, int64_t B,
+                const float* __restrict__ w, const float* __restrict__ in, const float* __restrict__ dsq, float* __restrict__ out) {
+    const int Q = D / 4, QT = F * Q;                 // float4s per field row / per concatenated row
+    const int64_t n = B * QT;
+    const int64_t nround = (n + 255) / 256 * 256;    // whole waves stay in the loop: the shuffles need every lane
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (int64_t)gridDim.x * 256) {
+        const bool ok = i < n;
+        const int64_t b = ok ? i / QT : 0;
+        const int q = ok ? (int)(i - b * QT) : 0;
+        const int f = q / Q, d = (q - f * Q) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE != SENET_MODE_DX && ok) v = *reinterpret_cast<const float4*>(fields[f] + b * D + d);
+        if (MODE == SENET_MODE_SCALE) {
+            if (ok) {
+                const float wf = w[b * F + f];
+                *reinterpret_cast<float4*>(out + b * (int64_t)(F * D) + q * 4) = make_float4(v.x * wf, v.y * wf, v.z * wf, v.w * wf);
+            }
+        } else if (MODE == SENET_MODE_DX) {
+            if (ok) {
+                const float4 g = *reinterpret_cast<const float4*>(in + b * (int64_t)(F * D) + q * 4);
+                const float wf = w[b * F + f], qq = dsq[b * F + f] / (float)D;
+                *reinterpret_cast<float4*>(dfields[f] + b * D + d) = make_float4(g.x * wf + qq, g.y * wf + qq, g.z * wf + qq, g.w * wf + qq);
+            }
+        } else {
+            float s;
+            if (MODE == SENET_MODE_DW) {
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) g = *reinterpret_cast<const float4*>(in + b * (int64_t)(F * D) + q * 4);
+                s = (v.x * g.x + v.y * g.y) + (v.z * g.z + v.w * g.w);
+            } else {
+                s = (v.x + v.y) + (v.z + v.w);
+            }
+            for (int o = Q / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (ok && d == 0) out[b * F + f] = MODE == SENET_MODE_SQUEEZE ? s / (float)D : s;
+        }
+    }
 }
-extern "C" int recnow_senet_squeeze(const float* const* fields, const int32_t* dims, int F, int64_t B, float* sq, void* stream) {
-    if (F < 1 || F > 65535 || B < 0) return RECNOW_EINVAL;
-    if (B == 0) return RECNOW_OK;
-    if (!fields || !dims || !sq) return RECNOW_EINVAL;
-    hipLaunchKernelGGL(k_senet_squeeze, senet_grid(B, F), 256, 0, (hipStream_t)stream, fields, dims, F, B, sq);
+// uniform_d: the caller's promise that every field is D wide and every field / concatenated tensor is 16-byte aligned
+static inline int senet_uniform_ok(int D, int F, int total) {
+    if (D < 4 || (D & 3) || D * F != total) return 0;
+    const int q = D / 4;
+    return (q & (q - 1)) == 0 && q <= 64 ? D : 0;
+}
+static int senet_launch(int mode, const float* const* fields, float* const* dfields, const int32_t* dims, const int32_t* offs, int F,
+                        int total, int64_t B, const float* w, const float* in, const float* dsq, float* out, int uniform_d, hipStream_t st) {
+    if (uniform_d > 0) {
+        const int64_t n = B * (total / 4);
+        int64_t g = (n + 255) / 256;
+        if (g > 16384) g = 16384;
+        const int D = uniform_d;
+        switch (mode) {
+            case SENET_MODE_SQUEEZE: hipLaunchKernelGGL(k_senet_uniform<SENET_MODE_SQUEEZE>, (int)g, 256, 0, st, fields, dfields, F, D, B, w, in, dsq, out); break;
+            case SENET_MODE_SCALE: hipLaunchKernelGGL(k_senet_uniform<SENET_MODE_SCALE>, (int)g, 256, 0, st, fields, dfields, F, D, B, w, in, dsq, out); break;
+            case SENET_MODE_DW: hipLaunchKernelGGL(k_senet_uniform<SENET_MODE_DW>, (int)g, 256, 0, st, fields, dfields, F, D, B, w, in, dsq, out); break;
+            default: hipLaunchKernelGGL(k_senet_uniform<SENET_MODE_DX>, (int)g, 256, 0, st, fields, dfields, F, D, B, w, in, dsq, out); break;
+        }
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
+    int R = (int)((48 * 1024) / ((size_t)(total + 1) * sizeof(float)));
+    if (R < 1) return RECNOW_EUNSUPPORTED;            // one row of the concatenation must fit in LDS (total <= 12287)
+    if (R > 32) R = 32;
+    const size_t lds = (size_t)R * (total + 1) * sizeof(float);
+    int64_t g = (B + R - 1) / R;
+    if (g > 4096) g = 4096;
+    switch (mode) {
+        case SENET_MODE_SQUEEZE: hipLaunchKernelGGL(k_senet_tile<SENET_MODE_SQUEEZE>, (int)g, 256, lds, st, fields, dfields, dims, offs, F, total, B, R, w, in, dsq, out); break;
+        case SENET_MODE_SCALE: hipLaunchKernelGGL(k_senet_tile<SENET_MODE_SCALE>, (int)g, 256, lds, st, fields, dfields, dims, offs, F, total, B, R, w, in, dsq, out); break;
+        case SENET_MODE_DW: hipLaunchKernelGGL(k_senet_tile<SENET_MODE_DW>, (int)g, 256, lds, st, fields, dfields, dims, offs, F, total, B, R, w, in, dsq, out); break;
+        default: hipLaunchKernelGGL(k_senet_tile<SENET_MODE_DX>, (int)g, 256, lds, st, fields, dfields, dims, offs, F, total, B, R, w, in, dsq, out); break;
+    }
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
+}
+extern "C" int recnow_senet_squeeze(const float* const* fields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
+                                    float* sq, int uniform_d, void* stream) {
+    if (F < 1 || B < 0 || total < 1) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!fields || !dims || !offs || !sq) return RECNOW_EINVAL;
+    return senet_launch(SENET_MODE_SQUEEZE, fields, nullptr, dims, offs, F, total, B, nullptr, nullptr, nullptr, sq, senet_uniform_ok(uniform_d, F, total), (hipStream_t)stream);
 }
 extern "C" int recnow_senet_scale_fwd(const float* const* fields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
-                                      const float* w, float* out, void* stream) {
-    if (F < 1 || F > 65535 || B < 0 || total < 1) return RECNOW_EINVAL;
+                                      const float* w, float* out, int uniform_d, void* stream) {
+    if (F < 1 || B < 0 || total < 1) return RECNOW_EINVAL;
     if (B == 0) return RECNOW_OK;
     if (!fields || !dims || !offs || !w || !out) return RECNOW_EINVAL;
-    hipLaunchKernelGGL(k_senet_scale, senet_grid(B, F), 256, 0, (hipStream_t)stream, fields, dims, offs, F, total, B, w, out);
-    RN_LAUNCH_CHECK();
-    return RECNOW_OK;
+    return senet_launch(SENET_MODE_SCALE, fields, nullptr, dims, offs, F, total, B, w, nullptr, nullptr, out, senet_uniform_ok(uniform_d, F, total), (hipStream_t)stream);
 }
 extern "C" int recnow_senet_scale_bwd_w(const float* const* fields, const int32_t* dims, const int32_t* offs, int F, int total,
-                                        int64_t B, const float* dout, float* dw, void* stream) {
-    if (F < 1 || F > 65535 || B < 0 || total < 1) return RECNOW_EINVAL;
+                                        int64_t B, const float* dout, float* dw, int uniform_d, void* stream) {
+    if (F < 1 || B < 0 || total < 1) return RECNOW_EINVAL;
     if (B == 0) return RECNOW_OK;
     if (!fields || !dims || !offs || !dout || !dw) return RECNOW_EINVAL;
-    hipLaunchKernelGGL(k_senet_dw, senet_grid(B, F), 256, 0, (hipStream_t)stream, fields, dims, offs, F, total, B, dout, dw);
-    RN_LAUNCH_CHECK();
-    return RECNOW_OK;
+    return senet_launch(SENET_MODE_DW, fields, nullptr, dims, offs, F, total, B, nullptr, dout, nullptr, dw, senet_uniform_ok(uniform_d, F, total), (hipStream_t)stream);
 }
 extern "C" int recnow_senet_scale_bwd_x(float* const* dfields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
-                                        const float* w, const float* dout, const float* dsq, void* stream) {
-    if (F < 1 || F > 65535 || B < 0 || total < 1) return RECNOW_EINVAL;
+                                        const float* w, const float* dout, const float* dsq, int uniform_d, void* stream) {
+    if (F < 1 || B < 0 || total < 1) return RECNOW_EINVAL;
     if (B == 0) return RECNOW_OK;
     if (!dfields || !dims || !offs || !w || !dout || !dsq) return RECNOW_EINVAL;
-    hipLaunchKernelGGL(k_senet_dx, senet_grid(B, F), 256, 0, (hipStream_t)stream, dfields, dims, offs, F, total, B, w, dout, dsq);
-    RN_LAUNCH_CHECK();
-    return RECNOW_OK;
+    return senet_launch(SENET_MODE_DX, nullptr, dfields, dims, offs, F, total, B, w, dout, dsq, nullptr, senet_uniform_ok(uniform_d, F, total), (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -22,7 +22,9 @@ class _Holder:
         self.dims = torch.tensor(dims, dtype=torch.int32, device=dev)
         self.offs = torch.tensor(offs, dtype=torch.int32, device=dev)
         self.ptrs = _lib.ptr_array(xs, dev)
-        self.dsq = None
+        # equal widths and 16-byte aligned rows: the float4 kernels (torch allocations are 256-byte aligned; views may not be)
+        same = len(set(dims)) == 1 and dims[0] % 4 == 0 and all(x.data_ptr() % 16 == 0 for x in xs)
+        self.uniform = dims[0] if same else 0
 
 
 class _SenetFunction(torch.autograd.Function):
@@ -41,14 +43,14 @@ class _SenetFunction(torch.autograd.Function):
         h = _Holder(xs)
         dev = xs[0].device
         sq = torch.empty((B, h.F), dtype=torch.float32, device=dev)
-        _lib.call('recnow_senet_squeeze', _lib.ptr(h.ptrs), _lib.ptr(h.dims), h.F, B, _lib.ptr(sq), _lib.stream())
+        _lib.call('recnow_senet_squeeze', _lib.ptr(h.ptrs), _lib.ptr(h.dims), _lib.ptr(h.offs), h.F, h.total, B, _lib.ptr(sq), h.uniform, _lib.stream())
         with torch.enable_grad():
             sq_leaf = sq.detach().requires_grad_(True)
             w = excite(sq_leaf)                                   # (B, F), the two Dense layers on the MFMA GEMM
         wd = _lib.f32c(w.detach(), 'excitation')
         out = torch.empty((B, h.total), dtype=torch.float32, device=dev)
         _lib.call('recnow_senet_scale_fwd', _lib.ptr(h.ptrs), _lib.ptr(h.dims), _lib.ptr(h.offs), h.F, h.total, B, _lib.ptr(wd),
-                  _lib.ptr(out), _lib.stream())
+                  _lib.ptr(out), h.uniform, _lib.stream())
         ctx.h, ctx.sq_leaf, ctx.w, ctx.wd, ctx.params = h, sq_leaf, w, wd, params
         return out
 
@@ -59,7 +61,7 @@ class _SenetFunction(torch.autograd.Function):
         dout = _lib.f32c(dout, 'grad')
         dw = torch.empty((B, h.F), dtype=torch.float32, device=dev)
         _lib.call('recnow_senet_scale_bwd_w', _lib.ptr(h.ptrs), _lib.ptr(h.dims), _lib.ptr(h.offs), h.F, h.total, B, _lib.ptr(dout),
-                  _lib.ptr(dw), _lib.stream())
+                  _lib.ptr(dw), h.uniform, _lib.stream())
         live = [i for i, p in enumerate(ctx.params) if p.requires_grad]
         got = torch.autograd.grad(ctx.w, [ctx.sq_leaf] + [ctx.params[i] for i in live], dw, allow_unused=True)
         grads = [got[0]] + [None] * len(ctx.params)
@@ -70,7 +72,7 @@ class _SenetFunction(torch.autograd.Function):
         dxs = [torch.empty_like(x) for x in h.xs]
         dptrs = _lib.ptr_array(dxs, dev)
         _lib.call('recnow_senet_scale_bwd_x', _lib.ptr(dptrs), _lib.ptr(h.dims), _lib.ptr(h.offs), h.F, h.total, B, _lib.ptr(ctx.wd),
-                  _lib.ptr(dout), _lib.ptr(dsq), _lib.stream())
+                  _lib.ptr(dout), _lib.ptr(dsq), h.uniform, _lib.stream())
         return (None, None) + tuple(grads[1:]) + tuple(dxs)
 
 
