@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events in the timed region')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -119,13 +120,18 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
 
     from rec_now_amd import _lib, dp
     from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss_fused
     lib = _lib.load()
+    dp.FORCE_COLLECTIVES = bool(args.force_dist)
 
     torch.manual_seed(3)                      # identical replicated weights on every rank
     model = Model()
@@ -146,7 +152,7 @@ def main():
         return loss_val
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,7 +191,7 @@ def main():
                                                     'tflops': (fl[t] / (ms[t] * 1e-3) / 1e12) if ms[t] > 0 else None}
                                      for t in GEMM_TAGS if cnt[t] > 0}}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -212,7 +218,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

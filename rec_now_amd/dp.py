@@ -15,8 +15,11 @@ import torch.distributed as dist
 SMALL_POSIVITE_FLOAT = 1.0e-10
 
 
+FORCE_COLLECTIVES = False      # diagnostics: run the collectives even in a 1-rank process group (bench.py --force-dist)
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def shard_rows_by_group(group_ids, world_size):
