@@ -38,6 +38,16 @@ static inline int mid_grid(int64_t B) {
     return (int)(tiles < 512 ? (tiles > 0 ? tiles : 1) : 512);
 }
 
+// forward: as many workgroups as the LDS footprint lets a CU hold (the kernel is latency-bound per workgroup)
+static inline int mid_fwd_grid(int64_t B, size_t lds) {
+    const int64_t tiles = (B + MID_ROWS - 1) / MID_ROWS;
+    int per_cu = (int)((160 * 1024) / (lds + 1024));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    const int64_t cap = 256 * per_cu;
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+
 size_t rn_mix_mid_bwd_ws_bytes(int64_t B, int S, int N) { return rn_align((size_t)mid_grid(B) * N * S * S * sizeof(float)); }
 
 template <int S>
@@ -325,10 +335,10 @@ int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64
     int rc;
     if (S == 32) {
         if ((rc = mid_allow_lds(k_mix_mid_fwd<32>, lds))) return rc;
-        hipLaunchKernelGGL(k_mix_mid_fwd<32>, mid_grid(B), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
+        hipLaunchKernelGGL(k_mix_mid_fwd<32>, mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
     } else {
         if ((rc = mid_allow_lds(k_mix_mid_fwd<64>, lds))) return rc;
-        hipLaunchKernelGGL(k_mix_mid_fwd<64>, mid_grid(B), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
+        hipLaunchKernelGGL(k_mix_mid_fwd<64>, mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
     }
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
