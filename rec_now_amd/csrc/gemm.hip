@@ -249,13 +249,30 @@ k_colsum_partial(const float* __restrict__ X, const float* __restrict__ X2, int 
     }
     part[(int64_t)blockIdx.y * N + col] = s;
 }
-__global__ void __launch_bounds__(256)
+// out[col] = sum over slabs, fixed order: 64 columns x 16 strided slab groups per workgroup, then a 16-term LDS sum (a
+// column-per-thread loop over hundreds of slabs is a chain of dependent-latency loads: 84 us for 512 slabs, measured)
+__global__ void __launch_bounds__(1024)
 k_colsum_final(const float* __restrict__ part, int nslab, int64_t N, float* __restrict__ out, int accumulate) {
-    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (col >= N) return;
-    float s = 0.f;
-    for (int i = 0; i < nslab; ++i) s += part[(int64_t)i * N + col];
-    out[col] = accumulate ? out[col] + s : s;
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 64 + e;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        int i = q;
+        for (; i + 48 < nslab; i += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += part[(int64_t)(i + 16 * u) * N + col];
+        }
+        for (; i < nslab; i += 16) s[0] += part[(int64_t)i * N + col];
+    }
+    red[q][e] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (q == 0 && col < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += red[u][e];
+        out[col] = accumulate ? out[col] + t : t;
+    }
 }
 
 // narrow matrices (N < 64): one workgroup column-strip per (column, row-chunk), all 256 threads walk the rows
@@ -309,7 +326,7 @@ int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int
         dim3 g1(rn_cdiv(N, 256), nslab);
         hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws, rows);
     }
-    hipLaunchKernelGGL(k_colsum_final, rn_cdiv(N, 256), 256, 0, st, (const float*)ws, nslab, N, out, accumulate);
+    hipLaunchKernelGGL(k_colsum_final, rn_cdiv(N, 64), 1024, 0, st, (const float*)ws, nslab, N, out, accumulate);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

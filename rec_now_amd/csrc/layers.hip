@@ -1,115 +1,9 @@
 // MultiDenseLayer (batched GEMM + bias + activation) and the softmax-gate mixing of MMoE / PLE.
 //   /root/reference/rec_now/layers/multi_dense_layer.py:80-94
 //   /root/reference/rec_now/layers/mmoe_layer.py:109-117, /root/reference/rec_now/layers/ple_layer.py:274-293
+#include <stdlib.h>
 #include "gemm.hpp"
 
-
-// ---- skinny outputs (N*U <= 8, e.g. the (B,1024)x(1024,1) scoring head): HBM-bound GEMV-style kernels ---------------
-// A 256x32 MFMA tile would be 1/32 full; these kernels read x exactly once (forward, dkernel) and write dx once.
-#define SK_MAX 8
-
-// y[n][b][u] = act(x[n|0][b][:] . W[n][:][u] + bias[n][u]);  one wave per row b
-__global__ void __launch_bounds__(256)
-k_skinny_fwd(const float* __restrict__ x, int64_t xs, const float* __restrict__ W, const float* __restrict__ bias, int64_t B, int D,
-             int U, int N, int act, float* __restrict__ y) {
-    const int lane = threadIdx.x & 63;
-    const int NU = N * U;
-    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
-        float acc[SK_MAX];
-#pragma unroll
-        for (int q = 0; q < SK_MAX; ++q) acc[q] = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const float* xr = x + (int64_t)n * xs + b * D;
-            for (int d = lane * 4; d < D; d += 256) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + d);
-                const float xv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int q = 0; q < SK_MAX; ++q) {
-                    if (q / U == n && q < NU) {
-                        const int u = q % U;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[q] += xv[e] * W[((int64_t)n * D + d + e) * U + u];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < SK_MAX; ++q) {
-            const float t = wave_sum(acc[q]);
-            if (lane == 0 && q < NU) y[((int64_t)(q / U) * B + b) * U + (q % U)] = rn_act(t + (bias ? bias[q] : 0.f), act);
-        }
-    }
-}
-
-// dx[n|0][b][d] = sum_{u (and n when broadcast)} dz[n][b][u] * W[n][d][u],  dz = dy * act'(y)
-__global__ void __launch_bounds__(256)
-k_skinny_dx(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ W, int64_t B, int D, int U, int N,
-            int act, int batched, float* __restrict__ dx) {
-    const int64_t nq = (int64_t)(batched ? N : 1) * B * (D / 4);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % (D / 4)) * 4;
-        const int64_t t = i / (D / 4);
-        const int64_t b = t % B;
-        const int n0 = batched ? (int)(t / B) : 0, n1 = batched ? n0 + 1 : N;
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int n = n0; n < n1; ++n)
-            for (int u = 0; u < U; ++u) {
-                const int64_t yi = ((int64_t)n * B + b) * U + u;
-                const float dz = dy[yi] * rn_act_grad_from_out(y[yi], act);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += dz * W[((int64_t)n * D + d + e) * U + u];
-            }
-        *reinterpret_cast<float4*>(dx + ((int64_t)n0 * B + b) * D + d) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-}
-
-// part[chunk][q][d] = sum_{b in chunk} x[n|0][b][d] * dz[n][b][u], q = n*U + u;  thread = one column d
-#define SK_ROWS 256
-__global__ void __launch_bounds__(256)
-k_skinny_dw_partial(const float* __restrict__ x, int64_t xs, const float* __restrict__ dy, const float* __restrict__ y, int64_t B,
-                    int D, int U, int N, int act, float* __restrict__ part) {
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.y * SK_ROWS, b1 = min(B, b0 + SK_ROWS);
-    const int NU = N * U;
-    float acc[SK_MAX];
-#pragma unroll
-    for (int q = 0; q < SK_MAX; ++q) acc[q] = 0.f;
-    if (d < D) {
-        for (int64_t b = b0; b < b1; ++b) {
-#pragma unroll
-            for (int q = 0; q < SK_MAX; ++q) {
-                if (q < NU) {
-                    const int n = q / U;
-                    const int64_t yi = ((int64_t)n * B + b) * U + (q % U);
-                    acc[q] += x[(int64_t)n * xs + b * D + d] * (dy[yi] * rn_act_grad_from_out(y[yi], act));
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < SK_MAX; ++q)
-            if (q < NU) part[((int64_t)blockIdx.y * NU + q) * D + d] = acc[q];
-    }
-}
-// dW[n][d][u] = sum_chunks part[chunk][n*U+u][d]
-__global__ void __launch_bounds__(256)
-k_skinny_dw_final(const float* __restrict__ part, int nchunk, int D, int U, int N, float* __restrict__ dW) {
-    const int64_t total = (int64_t)N * D * U;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int u = (int)(i % U);
-        const int64_t t = i / U;
-        const int d = (int)(t % D), n = (int)(t / D);
-        float s = 0.f;
-        for (int c = 0; c < nchunk; ++c) s += part[((int64_t)c * N * U + n * U + u) * D + d];
-        dW[i] = s;
-    }
-}
-
-static inline bool skinny_ok(const float* x, int64_t B, int D, int U, int N) {
-    return N * U <= SK_MAX && D % 4 == 0 && D >= 64 && (((uintptr_t)x & 15) == 0);
-}
-static inline size_t skinny_ws_bytes(int64_t B, int D, int U, int N) {
-    return rn_align((size_t)rn_cdiv(B > 0 ? B : 1, SK_ROWS) * N * U * D * sizeof(float));
-}
 
 // ---- N*U == 1 (one output column, the scoring head): three streaming kernels at HBM speed ---------------------------
 // y[b] = act(x[b,:] . w + bias);   one wave per row, w held in registers across the rows a wave owns (D <= 4096)
@@ -189,8 +83,7 @@ extern "C" size_t recnow_multi_dense_workspace_bytes(int64_t B, int D, int U, in
     d.M = (int)B; d.N = D; d.K = U; d.batch = N;
     t = rn_gemm_ws_bytes(&d);
     if (t > s) s = t;
-    size_t sk = (N * U <= SK_MAX) ? skinny_ws_bytes(B, D, U, N) : 0;
-    if (N == 1 && U == 1 && head_ws_bytes(B, D) > sk) sk = head_ws_bytes(B, D);
+    const size_t sk = (N == 1 && U == 1) ? head_ws_bytes(B, D) : 0;
     return (s > sk ? s : sk) + rn_colsum_ws_bytes(B, U) + 256;
 }
 
@@ -206,13 +99,6 @@ extern "C" int recnow_multi_dense_fwd(const float* x, int x_batched, const float
         if (D <= 256) hipLaunchKernelGGL(k_head_fwd<1>, g, 256, 0, hs, x, kernel, bias, B, D, act, y);
         else if (D <= 1024) hipLaunchKernelGGL(k_head_fwd<4>, g, 256, 0, hs, x, kernel, bias, B, D, act, y);
         else hipLaunchKernelGGL(k_head_fwd<16>, g, 256, 0, hs, x, kernel, bias, B, D, act, y);
-        RN_LAUNCH_CHECK();
-        return RECNOW_OK;
-    }
-    if (skinny_ok(x, B, D, U, N)) {
-        int g = rn_cdiv(B, 4);
-        if (g > 8192) g = 8192;
-        hipLaunchKernelGGL(k_skinny_fwd, g, 256, 0, (hipStream_t)stream, x, x_batched ? B * D : (int64_t)0, kernel, bias, B, D, U, N, act, y);
         RN_LAUNCH_CHECK();
         return RECNOW_OK;
     }
@@ -256,32 +142,6 @@ extern "C" int recnow_multi_dense_bwd(const float* x, int x_batched, const float
             RN_LAUNCH_CHECK();
         }
         if (dbias && (rc = rn_colsum(dy, y, zmode, act, B, 1, 1, dbias, 0, ws, ws_bytes, st))) return rc;
-        return RECNOW_OK;
-    }
-    if (skinny_ok(x, B, D, U, N) && (!dx || (((uintptr_t)dx & 15) == 0))) {
-        if (dkernel) {
-            if (ws_bytes < skinny_ws_bytes(B, D, U, N)) return RECNOW_EWORKSPACE;
-            const int nchunk = rn_cdiv(B, SK_ROWS);
-            dim3 g1(rn_cdiv(D, 256), nchunk);
-            hipLaunchKernelGGL(k_skinny_dw_partial, g1, 256, 0, st, x, x_batched ? B * D : (int64_t)0, dy, y, B, D, U, N, act, (float*)ws);
-            int g2 = rn_cdiv((int64_t)N * D * U, 256);
-            if (g2 > 2048) g2 = 2048;
-            hipLaunchKernelGGL(k_skinny_dw_final, g2, 256, 0, st, (const float*)ws, nchunk, D, U, N, dkernel);
-            RN_LAUNCH_CHECK();
-        }
-        if (dx) {
-            int64_t nq = (int64_t)(x_batched ? N : 1) * B * (D / 4);
-            int g = rn_cdiv(nq, 256);
-            if (g > 8192) g = 8192;
-            hipLaunchKernelGGL(k_skinny_dx, g, 256, 0, st, dy, y, kernel, B, D, U, N, act, x_batched, dx);
-            RN_LAUNCH_CHECK();
-        }
-        if (dbias) {
-            for (int n = 0; n < N; ++n)
-                if ((rc = rn_colsum(dy + (int64_t)n * B * U, y + (int64_t)n * B * U, zmode, act, B, U, U, dbias + (int64_t)n * U, 0, ws,
-                                    ws_bytes, st)))
-                    return rc;
-        }
         return RECNOW_OK;
     }
     if (dkernel) {   // dkernel[n] = x[n]^T dZ[n]      (D x U), K = B, split-K
