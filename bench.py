@@ -108,6 +108,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events in the timed region')
+    ap.add_argument('--graph', action='store_true', help='capture the step into a HIP graph and replay it (SURVEY 8f.1; launch-bound small batches)')
+    ap.add_argument('--rows', type=int, default=B_PER_GPU, help='rows per GPU (diagnostics; the metric is defined at 65536)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
     args = ap.parse_args()
 
@@ -135,7 +137,8 @@ def main():
 
     torch.manual_seed(3)                      # identical replicated weights on every rank
     model = Model()
-    x, groups, labels = synth_batch(B_PER_GPU, 3, rank)
+    rows = args.rows
+    x, groups, labels = synth_batch(rows, 3, rank)
     xd, gd, yd = (torch.from_numpy(v).to(dev) for v in (x, groups, labels))
     model(xd[:256])                           # lazy build on the device
     params = [p for p in model.parameters()]
@@ -158,13 +161,26 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    prof = not args.no_prof
+    graph = None
+    if args.graph:
+        if use_dist:
+            raise SystemExit('--graph is a single-GPU diagnostic')
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_loss = step()
+        run_step = lambda: (graph.replay(), graph_loss)[1]     # noqa: E731
+        for _ in range(2):
+            run_step()
+    else:
+        run_step = step
+    prof = not args.no_prof and graph is None
     if prof:
         _lib.check(lib.recnow_prof_enable(64 * (args.steps + 1)), 'recnow_prof_enable')
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run_step()
     sync()
     elapsed = time.perf_counter() - t0
     roofline = None
@@ -198,7 +214,7 @@ def main():
     if rank == 0:
         out = {
             'metric': 'samples/sec fwd+bwd, in-batch pairwise + DCN-v2, B=65536 at 1/2/4/8 GPUs',
-            'value': B_PER_GPU * world * args.steps / elapsed,
+            'value': rows * world * args.steps / elapsed,
             'unit': 'samples/s',
             'n_gpus': world,
             'steps': args.steps,
@@ -211,7 +227,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
                                    'in-batch pairwise (logistic), B=65536 rows per GPU, 64 fields x 16-dim, ~64 rows/group',
-                       'global_batch': B_PER_GPU * world, 'parallelism': 'dp%d' % world,
+                       'global_batch': rows * world, 'hip_graph': bool(args.graph), 'parallelism': 'dp%d' % world,
                        'loss': float(loss.item())},
             'roofline': roofline,
         }

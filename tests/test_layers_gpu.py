@@ -416,7 +416,7 @@ def test_gemm_side_product_and_rank_update(dev, ta, splitk_shape):
         assert np.abs(C.cpu().numpy() - ref).max() <= bound
 
 
-@pytest.mark.parametrize('B,D,S,N,L', [(512, 256, 64, 2, 2), (256, 128, 32, 4, 1)])
+@pytest.mark.parametrize('B,D,S,N,L', [(512, 256, 64, 2, 2), (256, 128, 32, 4, 1), (1024, 1024, 64, 2, 3), (256, 2048, 64, 2, 1)])
 def test_dcn_mix_exact128_path_vs_oracle(dev, B, D, S, N, L):
     """Shapes with N*S, D multiples of 128 and B a multiple of 256 take the side-product formulation (dcnmix.hip)."""
     test_dcn_mix_fwd_bwd_vs_oracle(dev, B, D, S, N, L, 'tanh', 'tanh')
