@@ -217,14 +217,14 @@ typedef struct recnow_gemm_desc {
     const float* eu_p; const float* eu_q; int64_t eu_pms, eu_qrs, eu_qns; int eu_r; int eu_pad;
     double prof_flops;                /* algorithmic flops of this product for the measurement hook (0: 2*M*N*K*batch);
                                          callers that zero-pad K or move columns to a side product state the true count */
-    /* Second output of the same accumulators (short-K persistent kernel only: K <= 256, K % 16 == 0, M, N multiples of
+    /* Second output of the same accumulators (short-K persistent kernel only: K <= 512, K % 16 == 0, M, N multiples of
      * 128, A [M][K], batch 1, no bias / activation / transposed store; anything else returns RECNOW_EUNSUPPORTED):
      *   c2_mode 1:  C2[m][n]  = acc                    (DCN-v2 forward keeps O next to y = x * O)
      *   c2_mode 2:  C2[m][n] += acc * E2[m][n]         (DCN-v2 backward: dx += g_l * O_l in the kernel that produces g_l)
      * `acc` is the raw product A B, before emul / accumulate are applied for C. */
     float* C2; int64_t ldc2; const float* E2; int64_t lde2; int c2_mode; int c2_pad;
     /* Elementwise side output of the A stream (lean 128x128 kernels with a side product, A [M][K], a_mode MUL, batch 1,
-     * N <= 128 so that every A element is loaded exactly once, no split-K):
+     * no split-K; written by the workgroups of the first column tile):
      *   as_out[m][k] = A[m][k] * as_in[m][k]      (both with A's leading dimension lda)
      * DCN-v2 backward: the dT2g product streams g = dL/dy anyway and writes dx = g * O on the way. */
     const float* as_in; float* as_out;

@@ -133,7 +133,7 @@ struct MixDims {
 // Exact formulation: every D-sized product has exactly NS MFMA columns / NS-deep K; the N gate columns and the N
 // gate-weighted bias rows are VALU side products / rank-N epilogue updates of the lean 128x128 GEMM kernels.
 static inline bool mix_exact(int64_t B, int D, int S, int N) {
-    return (N * S) % 128 == 0 && D % 128 == 0 && B % 256 == 0 && N <= 4;
+    return (N * S) % 128 == 0 && D % 128 == 0 && B % 256 == 0 && N <= 4 && kp_of(S, N) <= 512;     // second outputs: K <= 512
 }
 static inline MixDims mix_dims(int64_t B, int D, int S, int N, int L) {
     MixDims m;

@@ -158,7 +158,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     k.as_in = d->as_in; k.as_out = d->as_out;
     if ((d->as_in != nullptr) != (d->as_out != nullptr)) return RECNOW_EINVAL;
     if (d->c2_mode < 0 || d->c2_mode > 2 || (d->c2_mode && !d->C2) || (d->c2_mode == 2 && !d->E2)) return RECNOW_EINVAL;
-    if (d->c2_mode && (d->K > 256 || d->batch != 1)) return RECNOW_EUNSUPPORTED;      // short-K kernel only
+    if (d->c2_mode && (d->K > 512 || d->K % 16 || d->batch != 1)) return RECNOW_EUNSUPPORTED;      // short-K kernel only
 #ifdef RN_GEMM_TRACE
     if (const char* t = getenv("RECNOW_GEMM_TRACE")) k.trace = (long long*)strtoull(t, nullptr, 10);
 #endif
@@ -177,15 +177,15 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(tag, d->prof_flops > 0.0 ? d->prof_flops : 2.0 * d->M * d->N * (double)d->K * d->batch, st) : nullptr;
     // short-K products (K <= 256, e.g. the K = N*S+N = 130 contractions of DCN-v2) are prologue/epilogue dominated:
     // BK = 16 halves the LDS footprint so 4 workgroups per CU overlap each other's load/store phases.
-    const bool short_k = d->K <= 256;
+    const bool short_k = d->K <= 256 || (d->c2_mode && d->K <= 512);
     const bool bk16 = short_k && c.BM == 128;
     const bool edge = !gemm_interior(d, c, bk16 ? 16 : 32, k.kchunk, k.splitk > 1);
     // lean kernels exist for the two big tile families and the (layout, operand-kind) combos the layers use; anything
     // else (and every edge shape) runs the general kernel of the same tile family.
     rc = RECNOW_EUNSUPPORTED;
     int xf = (d->sp_r > 0 ? 1 : 0) | (d->eu_r > 0 ? 2 : 0);
-    if (d->as_out) {      // A-stream side output: instantiated with the side product of dT2g; every A element loaded exactly once
-        if (xf != 1 || d->a_trans || d->a_mode != RECNOW_OPMODE_MUL || d->batch != 1 || k.splitk != 1 || d->N > c.BN ||
+    if (d->as_out) {      // A-stream side output: instantiated with the side product of dT2g; written by the first column tile
+        if (xf != 1 || d->a_trans || d->a_mode != RECNOW_OPMODE_MUL || d->batch != 1 || k.splitk != 1 ||
             !host_aligned(d->as_in, d->lda, 0) || !host_aligned(d->as_out, d->lda, 0))
             return RECNOW_EUNSUPPORTED;
         xf |= 4;

@@ -307,7 +307,7 @@ k_gemm(const GemmK p) {
     const int ntile = (k_end - k_begin + BK - 1) / BK;
     if (ntile > 0) {
         const bool kf = !EDGE || (k_begin + BK <= k_end);
-        if constexpr ((XF & 4) != 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k_begin);
+        if ((XF & 4) != 0 && blockIdx.y == 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k_begin);      // one column tile writes the side output
         else ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k_begin, p.M, k_end, p.a_ld2, p.a_hq);
         tb.template load<EDGE, B2K>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k_begin, p.N, k_end, p.b_ld2, p.b_hq);
         ta.store(As);
@@ -326,7 +326,7 @@ k_gemm(const GemmK p) {
         if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
             const int k0 = k_begin + (t + 1) * BK;
             const bool kf = !EDGE || (k0 + BK <= k_end);
-            if constexpr ((XF & 4) != 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k0);
+            if ((XF & 4) != 0 && blockIdx.y == 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k0);
             else ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
             tb.template load<EDGE, B2K>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
         }

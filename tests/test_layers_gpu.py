@@ -530,3 +530,15 @@ def test_gemm_a_stream_side_output(dev):
     assert np.abs(C.cpu().numpy() - X @ Bm.astype(np.float64).T).max() <= 3e-7 * K
     assert np.abs(Cx.cpu().numpy() - X @ Bx.astype(np.float64).T).max() <= 3e-7 * K
     assert np.array_equal(out.cpu().numpy(), A * T)
+
+
+# ---- DCN-v2 shape sweep: every dispatch corner (exact-128 / padded path, fused sub-space stage or batched GEMMs, split-K or
+# not, tails in B / D / S) against the oracle ---------------------------------------------------------------------------
+@pytest.mark.parametrize('B,D,S,N,L', [
+    (256, 1024, 64, 2, 2), (768, 1024, 64, 2, 1), (4096, 1024, 64, 2, 1), (8192, 512, 64, 2, 2),      # exact path, B < 32768
+    (1000, 1024, 64, 2, 2), (255, 1024, 64, 2, 1),                                                  # B tail -> padded path
+    (512, 1000, 64, 2, 1), (512, 96, 64, 2, 2),                                                     # D tail
+    (512, 256, 32, 4, 2), (512, 256, 32, 2, 1), (512, 256, 64, 1, 2), (512, 256, 64, 4, 1),         # N*S = 128, 64, 64, 256
+    (512, 256, 8, 2, 1), (300, 70, 5, 3, 2), (512, 256, 128, 1, 1), (640, 384, 32, 8, 1)])          # S without a fused kernel
+def test_dcn_mix_shape_sweep(dev, B, D, S, N, L):
+    test_dcn_mix_fwd_bwd_vs_oracle(dev, B, D, S, N, L, 'tanh', 'tanh')
