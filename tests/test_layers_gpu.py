@@ -542,3 +542,76 @@ def test_gemm_a_stream_side_output(dev):
     (512, 256, 8, 2, 1), (300, 70, 5, 3, 2), (512, 256, 128, 1, 1), (640, 384, 32, 8, 1)])          # S without a fused kernel
 def test_dcn_mix_shape_sweep(dev, B, D, S, N, L):
     test_dcn_mix_fwd_bwd_vs_oracle(dev, B, D, S, N, L, 'tanh', 'tanh')
+
+
+# ---- GEMM fuzz: random shapes x operand modes x epilogues through every dispatch branch (lean / general / short-K / split-K) ----
+def _act_np(v, act):
+    return [v, np.maximum(v, 0), np.tanh(v), 1 / (1 + np.exp(-v))][act]
+
+
+def _actgrad_np(y, act):
+    return [np.ones_like(y), (y > 0).astype(np.float64), 1 - y * y, y * (1 - y)][act]
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_gemm_fuzz(dev, seed):
+    from rec_now_amd import _lib
+    rng = np.random.default_rng(1000 + seed)
+    pick = lambda *v: v[rng.integers(len(v))]                       # noqa: E731
+    M = int(pick(1, 37, 128, 256, 384, 512, 1000, 2048))
+    N = int(pick(1, 6, 32, 64, 100, 128, 160, 256, 300))
+    K = int(pick(1, 16, 48, 144, 256, 288, 1000, 1024, 4096))
+    batch = int(pick(1, 1, 1, 2, 3))
+    ta, tb = int(pick(0, 1)), int(pick(0, 1))
+    a_mode, b_mode = int(pick(0, 0, 1, 2)), int(pick(0, 0, 0, 2))
+    act = int(pick(0, 0, 1, 2, 3))
+    use_bias, use_emul, accum, c_trans = bool(pick(0, 1)), int(pick(0, 0, 1, 2)), bool(pick(0, 0, 1)), bool(pick(0, 0, 0, 1))
+    if c_trans and batch > 1:
+        c_trans = False
+    A = rng.uniform(-1, 1, (batch, K, M) if ta else (batch, M, K)).astype(np.float32)
+    A2 = rng.uniform(0.1, 0.9, A.shape).astype(np.float32)
+    Bm = rng.uniform(-1, 1, (batch, N, K) if tb else (batch, K, N)).astype(np.float32)
+    B2 = rng.uniform(0.1, 0.9, Bm.shape).astype(np.float32)
+    bias = rng.uniform(-1, 1, (batch, N)).astype(np.float32)
+    E = rng.uniform(0.1, 0.9, (batch, M, N)).astype(np.float32)
+    C0 = rng.uniform(-1, 1, (batch, N, M) if c_trans else (batch, M, N)).astype(np.float32)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)     # noqa: E731
+    Ad, A2d, Bd, B2d, bd, Ed, Cd = t(A), t(A2), t(Bm), t(B2), t(bias), t(E), t(C0.copy())
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.a_batch_stride, d.a_trans = Ad.data_ptr(), A.shape[2], A.shape[1] * A.shape[2], ta
+    d.B, d.ldb, d.b_batch_stride, d.b_trans = Bd.data_ptr(), Bm.shape[2], Bm.shape[1] * Bm.shape[2], tb
+    d.C, d.ldc, d.c_batch_stride, d.c_trans = Cd.data_ptr(), C0.shape[2], C0.shape[1] * C0.shape[2], int(c_trans)
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    a_act, b_act, e_act = int(pick(1, 2, 3)), int(pick(1, 2, 3)), int(pick(1, 2, 3))
+    A64, B64 = A.astype(np.float64), Bm.astype(np.float64)
+    if a_mode:
+        d.A2, d.a_mode, d.a_act = A2d.data_ptr(), a_mode, a_act
+        A64 = A64 * (A2 if a_mode == 1 else _actgrad_np(A2.astype(np.float64), a_act))
+    if b_mode:
+        d.B2, d.b_mode, d.b_act = B2d.data_ptr(), b_mode, b_act
+        B64 = B64 * _actgrad_np(B2.astype(np.float64), b_act)
+    if ta:
+        A64 = A64.transpose(0, 2, 1)
+    if tb:
+        B64 = B64.transpose(0, 2, 1)
+    ref = A64 @ B64
+    mag = np.abs(A64) @ np.abs(B64)
+    if use_bias:
+        d.bias, d.bias_batch_stride = bd.data_ptr(), N
+        ref = ref + bias[:, None, :]
+    d.act = act
+    ref = _act_np(ref, act)
+    if use_emul:
+        d.emul, d.lde, d.e_batch_stride, d.e_mode, d.e_act = Ed.data_ptr(), N, M * N, use_emul, e_act
+        ref = ref * (E if use_emul == 1 else _actgrad_np(E.astype(np.float64), e_act))
+    if accum:
+        d.accumulate = 1
+        ref = ref + (C0.transpose(0, 2, 1) if c_trans else C0)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)) + 256, dev)
+    _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.stream())
+    out = Cd.cpu().numpy().astype(np.float64)
+    if c_trans:
+        out = out.transpose(0, 2, 1)
+    bound = 3e-7 * mag.max() + 2e-6
+    assert np.abs(out - ref).max() <= bound, (M, N, K, batch, ta, tb, a_mode, b_mode, act, use_bias, use_emul, accum, c_trans)
