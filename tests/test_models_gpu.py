@@ -1,0 +1,88 @@
+"""GPU parity of the BASELINE.json model compositions end to end (small batches, forward + backward through every
+autograd node) against the oracle:
+  configs[3]: embeddings -> CINLayer || FMLayer -> Dense head -> pairwise_loss
+  configs[4]: x -> PLELayer (3 tasks) -> per-task heads -> listwise loss on task 0 (+ the other heads summed, so every
+              weight gets a gradient)"""
+import numpy as np
+import pytest
+import torch
+
+import dense_ref as R
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def close(a, b, rtol=RTOL, scale=None):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    s = max(np.abs(b).max() if scale is None else scale, 1e-30)
+    err = np.abs(a - b).max()
+    assert err <= rtol * s, 'max err %.3g vs scale %.3g (rel %.3g)' % (err, s, err / s)
+
+
+def test_config4_cin_fm_pairwise(dev):
+    from rec_now_amd.layers.cin_layer import CINLayer
+    from rec_now_amd.layers.fm_layer import FMLayer
+    from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+    rng = np.random.default_rng(4)
+    B, F, D, Hs = 640, 12, 8, [16, 16, 8]
+    xs = [rng.normal(0, 0.4, (B, D)).astype(np.float32) for _ in range(F)]
+    groups = rng.integers(0, 20, B).astype(np.float32)
+    labels = (rng.random(B) < 0.3).astype(np.float32)
+    cin, fm, head = CINLayer(Hs), FMLayer(), MultiDenseLayer(1, 1)
+    xd = [torch.from_numpy(x).to(dev).requires_grad_(True) for x in xs]
+    feat = torch.cat([cin(xd), fm(xd)], dim=1)                        # (B, D + 1)
+    scores = head(feat).reshape(-1)
+    loss = pairwise_loss(scores, torch.from_numpy(labels).to(dev), torch.from_numpy(groups).to(dev))
+    loss.backward()
+    w64 = [cin.idx2weight[k].detach().cpu().double().requires_grad_(True) for k in range(1, len(Hs) + 1)]
+    hk = head.kernel.detach().cpu().double().requires_grad_(True)
+    hb = head.bias.detach().cpu().double().requires_grad_(True)
+    x64 = [torch.from_numpy(x).double().requires_grad_(True) for x in xs]
+    rfeat = torch.cat([R.cin_layer(x64, w64, F, D, True, True), R.fm_layer(x64)], dim=1)
+    rs = R.multi_dense_layer(rfeat, hk, hb).reshape(-1)
+    ref = R.pairwise_loss(rs, torch.from_numpy(labels).double(), torch.from_numpy(groups))
+    ref.backward()
+    close(loss, ref)
+    gs = max(float(v.grad.abs().max()) for v in x64)
+    for a, b in zip(xd, x64):
+        close(a.grad, b.grad, scale=gs)
+    for k in range(1, len(Hs) + 1):
+        close(cin.idx2weight[k].grad, w64[k - 1].grad)
+    close(head.kernel.grad, hk.grad)
+
+
+def test_config5_ple_listwise(dev, golden):
+    from rec_now_amd.layers.ple_layer import PLELayer
+    from rec_now_amd.rec_block.listwise_loss_from_batch import listwise_loss_from_batch
+    from test_layers_gpu import _load_ple
+    from test_oracle_golden import ple_layers_from_fixture
+    g = golden('ple')                                                  # weights of the reference's PLE test (2 tasks, 3 layers)
+    rng = np.random.default_rng(5)
+    B = 700
+    x = rng.normal(0, 1, (B, 4)).astype(np.float32)
+    groups = rng.integers(0, 25, B).astype(np.float32)
+    labels = (rng.random(B) < 0.3).astype(np.float32)
+    layer = PLELayer(2, [[2, 3], [2, 3], [3, 2]], [4, 3, 2], 1, name='PLE', activation='tanh')
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    layer(xd)
+    _load_ple(layer, g)
+    outs = layer(xd)
+    hw = rng.normal(size=(2, 2)).astype(np.float32)                    # fixed linear heads: logit_t = out_t . hw[t]
+    logit0 = outs[0] @ torch.from_numpy(hw[0]).to(dev)
+    loss = listwise_loss_from_batch(torch.from_numpy(groups).to(dev), torch.from_numpy(labels).to(dev), logit0)
+    total = loss + 0.01 * (outs[1] @ torch.from_numpy(hw[1]).to(dev)).sum()
+    total.backward()
+    g64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in g.items() if k.startswith('l')}
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    routs = R.ple_layer(x64, ple_layers_from_fixture(g64, to=lambda v: v), [True, False, False], activation='tanh')
+    rlogit0 = routs[0] @ torch.from_numpy(hw[0]).double()
+    _, rl, rz = R.to_listwise_sample(torch.from_numpy(groups), torch.from_numpy(labels).double(), rlogit0)
+    rloss = R.listwise_loss_via_softmax_cross_entropy_with_logits(rl, rz)
+    rtotal = rloss + 0.01 * (routs[1] @ torch.from_numpy(hw[1]).double()).sum()
+    rtotal.backward()
+    close(loss, rloss)
+    close(xd.grad, x64.grad)
