@@ -615,3 +615,22 @@ def test_gemm_fuzz(dev, seed):
         out = out.transpose(0, 2, 1)
     bound = 3e-7 * mag.max() + 2e-6
     assert np.abs(out - ref).max() <= bound, (M, N, K, batch, ta, tb, a_mode, b_mode, act, use_bias, use_emul, accum, c_trans)
+
+
+# ---- layer shape sweeps at sizes that reach the lean / split-K / head kernels (the small cases above mostly run the general
+# kernels): MultiDense with 1..8 and hundreds of output columns, CIN with tile-aligned and ragged widths ---------------------
+@pytest.mark.parametrize('B,D,U,N,batched,act', [
+    (4096, 1024, 1, 1, False, None), (4096, 1024, 1, 1, False, 'sigmoid'),                      # scoring head kernels
+    (4096, 1024, 6, 1, False, None), (2048, 4096, 8, 1, False, 'tanh'),                         # narrow outputs -> MFMA GEMM
+    (2048, 1024, 4, 2, False, 'tanh'), (1024, 512, 256, 2, False, 'tanh'),
+    (1024, 512, 256, 2, True, 'tanh'), (8192, 256, 128, 1, False, 'sigmoid'),
+    (1000, 333, 77, 3, True, 'tanh'), (256, 2048, 512, 4, False, None)])
+def test_multi_dense_shape_sweep(dev, B, D, U, N, batched, act):
+    test_multi_dense_fwd_bwd_vs_oracle(dev, B, D, U, N, batched, act)
+
+
+@pytest.mark.parametrize('B,F,D,Hs,oi,sc,as_list', [
+    (512, 16, 16, [32, 32], True, True, True), (256, 64, 16, [128, 128], True, True, True), (256, 8, 32, [64], False, True, False),
+    (300, 12, 16, [128, 20, 128], True, False, True), (1024, 4, 8, [256], False, False, True), (128, 33, 4, [65, 31], True, True, True)])
+def test_cin_shape_sweep(dev, B, F, D, Hs, oi, sc, as_list):
+    test_cin_fwd_bwd_vs_oracle(dev, B, F, D, Hs, oi, sc, as_list)
