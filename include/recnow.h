@@ -268,13 +268,15 @@ int recnow_moe_mix_bwd(const float* gates, const float* const* experts, const fl
  *   x_{l+1} = act(x0 * (x_l . w_l) + b_l),  l = 0..L-1;  all L layers fused in one pass over x0 (HBM-bound: 8*B*D
  *   bytes forward, 20*B*D backward incl. the recompute read).
  *   kernels: (L,D) (row l = kernel_l[:,0]); biases: (L,D) or NULL (use_bias=False); y: (B,D).
- * Backward recomputes the forward per row from x0 (nothing saved): dx (B,D), dkernels (L,D), dbiases (L,D) or NULL.
+ *   csave: optional (B,L) output of the forward, the per-row scalars c_l = x_l . w_l.  Given to the backward, x_l is
+ *   elementwise in x0 (one dot-reduce per layer, a wave per row); csave == NULL: the backward recomputes the forward per row
+ *   from x0 (nothing saved).  dx (B,D), dkernels (L,D), dbiases (L,D) or NULL.
  * ---------------------------------------------------------------------------------------------------------- */
 size_t recnow_dcn_workspace_bytes(int64_t B, int D, int L);
 int recnow_dcn_fwd(const float* x, const float* kernels, const float* biases, int64_t B, int D, int L, int act, float* y,
-                   void* stream);
-int recnow_dcn_bwd(const float* x, const float* kernels, const float* biases, const float* dy, int64_t B, int D, int L,
-                   int act, float* dx, float* dkernels, float* dbiases, void* ws, size_t ws_bytes, void* stream);
+                   float* csave, void* stream);
+int recnow_dcn_bwd(const float* x, const float* kernels, const float* biases, const float* dy, const float* csave, int64_t B,
+                   int D, int L, int act, float* dx, float* dkernels, float* dbiases, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * DCNMixLayer (DCN-v2 mixture of low-rank experts, reference variant without residual):

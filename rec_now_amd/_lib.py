@@ -46,8 +46,8 @@ SIGNATURES = {
     'recnow_moe_mix_fwd': (_I, [_P, _P, _I, _L, _I, _I, _P, _P, _P]),
     'recnow_moe_mix_bwd': (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _I, _P]),
     'recnow_dcn_workspace_bytes': (_Z, [_L, _I, _I]),
-    'recnow_dcn_fwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
-    'recnow_dcn_bwd': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    'recnow_dcn_fwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
+    'recnow_dcn_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     'recnow_dcn_mix_saved_bytes': (_Z, [_L, _I, _I, _I, _I]),
     'recnow_dcn_mix_workspace_bytes': (_Z, [_L, _I, _I, _I, _I]),
     'recnow_dcn_mix_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P]),

@@ -3,7 +3,8 @@
 // HBM-bound.  All L layers are fused: a row of x0 lives in the registers of TPR threads (one wave, or one 256-thread
 // workgroup for wide rows), every layer is a dot-reduce + elementwise update on registers, so forward moves 8*B*D
 // bytes (read x0, write y) and backward 16*B*D (read x0, dy; write dx) + tiny weight-gradient slabs.
-// Backward saves nothing: it recomputes x_l from x0 for each layer (O(L^2) dot-reduces on registers, L <= 4).
+// Backward needs only the L scalars c_l = x_l . w_l per row (csave, optional output of the forward): x_l is then elementwise
+// in x0.  Without csave it recomputes x_l from x0 for each layer (O(L^2) dot-reduces on registers, L <= 4).
 // Weight/bias gradients accumulate in registers over the rows a thread group owns, are combined per workgroup through
 // LDS and finally summed over workgroups by the deterministic column-sum (no float atomics).
 #include "gemm.hpp"
@@ -11,15 +12,19 @@
 #define DCN_MAX_L 4
 
 template <int TPR>
-__device__ __forceinline__ float row_sum(float v, float* red /* [rows_per_block][4] */) {
+__device__ __forceinline__ float row_sum(float v, float* red /* [4]: one slot per wave of the workgroup */) {
     v = wave_sum(v);
     if (TPR == 64) return v;
-    // 256 threads = 4 waves share one row
-    const int w = threadIdx.x >> 6;
+    // TPR / 64 waves share one row (256 threads: 4 waves = 1 row, 128 threads: 2 rows of 2 waves)
+    constexpr int NWR = TPR / 64;
+    const int w = threadIdx.x >> 6, first = (w / NWR) * NWR;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) s += red[first + i];
+    return s;
 }
 
 template <int TPR, int VEC, int NV>
@@ -64,7 +69,7 @@ __device__ __forceinline__ float row_dot(const float (&a)[NV][VEC], const float 
 template <int TPR, int VEC, int NV>
 __global__ void __launch_bounds__(256)
 k_dcn_fwd(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases, int64_t B, int D, int L,
-          int act, float* __restrict__ y) {
+          int act, float* __restrict__ y, float* __restrict__ csave) {
     __shared__ float red[4];
     constexpr int RPB = 256 / TPR;
     const int t = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
@@ -80,6 +85,7 @@ k_dcn_fwd(const float* __restrict__ x, const float* __restrict__ kernels, const 
         for (int l = 0; l < L; ++l) {
             row_load<TPR, VEC, NV>(w, kernels + (int64_t)l * D, D, t);
             const float c = row_sum<TPR>(row_dot<VEC, NV>(xl, w), red);
+            if (csave && ok && t == 0) csave[row * L + l] = c;        // the layer's scalar x_l . w_l: all the backward needs of x_l
             if (biases) row_load<TPR, VEC, NV>(bb, biases + (int64_t)l * D, D, t);
 #pragma unroll
             for (int i = 0; i < NV; ++i)
@@ -191,6 +197,110 @@ k_dcn_bwd(const float* __restrict__ x, const float* __restrict__ kernels, const 
     }
 }
 
+
+// Backward with the forward's per-row scalars c_l = x_l . w_l (csave, B x L floats): x_l = act(x0 * c_{l-1} + b_{l-1}) is then
+// elementwise in x0, so a layer costs ONE dot-reduce (dc = <dz, x0>) instead of l + 2, and with a wave per row the reduce is
+// shuffles only (no LDS, no barrier).  Same slab layout as k_dcn_bwd.
+template <int TPR, int VEC, int NV>
+__global__ void __launch_bounds__(256)
+k_dcn_bwd_saved(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases,
+                const float* __restrict__ dy, const float* __restrict__ csave, int64_t B, int D, int L, int act,
+                float* __restrict__ dx, float* __restrict__ part) {
+    __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) float comb[];
+    constexpr int RPB = 256 / TPR;
+    const int t = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
+    float dw[DCN_MAX_L][NV][VEC], db[DCN_MAX_L][NV][VEC];
+#pragma unroll
+    for (int l = 0; l < DCN_MAX_L; ++l)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dw[l][i][e] = db[l][i][e] = 0.f;
+
+    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += (int64_t)gridDim.x * RPB) {
+        const int64_t row = row0 + rsub;
+        const bool ok = row < B;
+        float x0[NV][VEC], g[NV][VEC], dx0[NV][VEC], tmp[NV][VEC];
+        row_load<TPR, VEC, NV>(x0, x + (ok ? row : 0) * D, ok ? D : 0, t);
+        row_load<TPR, VEC, NV>(g, dy + (ok ? row : 0) * D, ok ? D : 0, t);
+        float cs[DCN_MAX_L];
+#pragma unroll
+        for (int l = 0; l < DCN_MAX_L; ++l) cs[l] = (ok && l < L) ? csave[row * L + l] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dx0[i][e] = 0.f;
+#pragma unroll
+        for (int li = 0; li < DCN_MAX_L; ++li) {
+            const int l = L - 1 - li;           // layers L-1 .. 0, compile-time accumulator index li
+            if (l < 0) continue;
+            float c = 0.f, cprev = 0.f;
+#pragma unroll
+            for (int q = 0; q < DCN_MAX_L; ++q) {
+                if (q == l) c = cs[q];
+                if (q == l - 1) cprev = cs[q];
+            }
+            // dz = g * act'(out_l),  out_l = act(x0 * c_l + b_l)   (kept in g's registers)
+            if (biases) row_load<TPR, VEC, NV>(tmp, biases + (int64_t)l * D, D, t);
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float out = rn_act(x0[i][e] * c + (biases ? tmp[i][e] : 0.f), act);
+                    g[i][e] *= rn_act_grad_from_out(out, act);
+                    p += g[i][e] * x0[i][e];
+                }
+            const float dc = row_sum<TPR>(p, red);
+            if (biases && l > 0) row_load<TPR, VEC, NV>(tmp, biases + (int64_t)(l - 1) * D, D, t);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xl = l == 0 ? x0[i][e] : rn_act(x0[i][e] * cprev + (biases ? tmp[i][e] : 0.f), act);
+                    db[li][i][e] += g[i][e];
+                    dx0[i][e] += g[i][e] * c;
+                    dw[li][i][e] += xl * dc;
+                }
+            row_load<TPR, VEC, NV>(tmp, kernels + (int64_t)l * D, D, t);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[i][e] = dc * tmp[i][e];       // gradient w.r.t. x_l
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dx0[i][e] += g[i][e];             // x_0 is x0 itself
+        if (ok) row_store<TPR, VEC, NV>(dx0, dx + row * D, D, t);
+    }
+
+    float* slab = part + (int64_t)blockIdx.x * 2 * L * D;
+#pragma unroll
+    for (int li = 0; li < DCN_MAX_L; ++li) {
+        const int l = L - 1 - li;
+        if (l < 0) continue;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float* dst = slab + (int64_t)(which * L + l) * D;
+            if (TPR == 256) {
+                row_store<TPR, VEC, NV>(which ? db[li] : dw[li], dst, D, t);
+            } else {
+                __syncthreads();
+                row_store<TPR, VEC, NV>(which ? db[li] : dw[li], comb + rsub * D, D, t);
+                __syncthreads();
+                for (int d = threadIdx.x; d < D; d += 256) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RPB; ++r) s += comb[r * D + d];
+                    dst[d] = s;
+                }
+            }
+        }
+    }
+}
+
 struct DcnCfg {
     int tpr, vec, nv;
 };
@@ -232,6 +342,7 @@ extern "C" size_t recnow_dcn_workspace_bytes(int64_t B, int D, int L) {
     do {                                                                                                              \
         if (cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 1) hipLaunchKernelGGL((KERNEL<64, 4, 1>), G, 256, SHMEM, st, __VA_ARGS__);      \
         else if (cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4) hipLaunchKernelGGL((KERNEL<64, 4, 4>), G, 256, SHMEM, st, __VA_ARGS__); \
+        else if (cfg.tpr == 128 && cfg.vec == 4 && cfg.nv == 2) hipLaunchKernelGGL((KERNEL<128, 4, 2>), G, 256, SHMEM, st, __VA_ARGS__); \
         else if (cfg.tpr == 256 && cfg.vec == 4 && cfg.nv == 1) hipLaunchKernelGGL((KERNEL<256, 4, 1>), G, 256, SHMEM, st, __VA_ARGS__); \
         else if (cfg.tpr == 256 && cfg.vec == 4) hipLaunchKernelGGL((KERNEL<256, 4, 4>), G, 256, SHMEM, st, __VA_ARGS__);              \
         else if (cfg.tpr == 256 && cfg.vec == 1 && cfg.nv == 1) hipLaunchKernelGGL((KERNEL<256, 1, 1>), G, 256, SHMEM, st, __VA_ARGS__); \
@@ -239,7 +350,7 @@ extern "C" size_t recnow_dcn_workspace_bytes(int64_t B, int D, int L) {
     } while (0)
 
 extern "C" int recnow_dcn_fwd(const float* x, const float* kernels, const float* biases, int64_t B, int D, int L, int act, float* y,
-                              void* stream) {
+                              float* csave, void* stream) {
     if (B < 0 || D < 1 || L < 1) return RECNOW_EINVAL;
     if (B == 0) return RECNOW_OK;
     if (!x || !kernels || !y) return RECNOW_EINVAL;
@@ -247,13 +358,13 @@ extern "C" int recnow_dcn_fwd(const float* x, const float* kernels, const float*
     if (!dcn_pick(D, x, y, kernels, &cfg) || (biases && (((uintptr_t)biases & 15) != 0) && cfg.vec == 4)) return RECNOW_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int G = dcn_grid(B, cfg.tpr);
-    DCN_DISPATCH(k_dcn_fwd, 0, x, kernels, biases, B, D, L, act, y);
+    DCN_DISPATCH(k_dcn_fwd, 0, x, kernels, biases, B, D, L, act, y, csave);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
 
-extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float* biases, const float* dy, int64_t B, int D, int L,
-                              int act, float* dx, float* dkernels, float* dbiases, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float* biases, const float* dy, const float* csave, int64_t B,
+                              int D, int L, int act, float* dx, float* dkernels, float* dbiases, void* ws, size_t ws_bytes, void* stream) {
     if (B < 0 || D < 1 || L < 1) return RECNOW_EINVAL;
     if (L > DCN_MAX_L) return RECNOW_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -265,16 +376,20 @@ extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float*
     if (!x || !kernels || !dy || !dx || !dkernels || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_dcn_workspace_bytes(B, D, L)) return RECNOW_EWORKSPACE;
     DcnCfg cfg;
-    if (!dcn_pick_bwd(D, x, dy, dx, &cfg) || (cfg.vec == 4 && ((((uintptr_t)kernels | (uintptr_t)biases) & 15) != 0)))
+    // with the saved scalars a wave per row fits the register file (no recompute state); without them one workgroup per row
+    if (!(csave ? dcn_pick(D, x, dy, dx, &cfg) : dcn_pick_bwd(D, x, dy, dx, &cfg)) ||
+        (cfg.vec == 4 && ((((uintptr_t)kernels | (uintptr_t)biases) & 15) != 0)))
         return RECNOW_EUNSUPPORTED;
+    if (csave && cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4) cfg = {128, 4, 2};     // 2 waves per wide row: half the registers per lane
     const int G = dcn_grid(B, cfg.tpr);
     RnCarver c(ws, ws_bytes);
     float* part = c.take<float>((size_t)2048 * 2 * L * D);
     float* sums = c.take<float>((size_t)2 * L * D);
     void* cs_ws = c.base + c.off;
     const size_t cs_bytes = ws_bytes - c.off;
-    const size_t shmem = cfg.tpr == 64 ? (size_t)4 * D * sizeof(float) : 0;
-    DCN_DISPATCH(k_dcn_bwd, shmem, x, kernels, biases, dy, B, D, L, act, dx, part);
+    const size_t shmem = cfg.tpr < 256 ? (size_t)(256 / cfg.tpr) * D * sizeof(float) : 0;
+    if (csave) DCN_DISPATCH(k_dcn_bwd_saved, shmem, x, kernels, biases, dy, csave, B, D, L, act, dx, part);
+    else DCN_DISPATCH(k_dcn_bwd, shmem, x, kernels, biases, dy, B, D, L, act, dx, part);
     RN_LAUNCH_CHECK();
     int rc = rn_colsum(part, nullptr, 0, 0, G, (int64_t)2 * L * D, (int64_t)2 * L * D, sums, 0, cs_ws, cs_bytes, st);
     if (rc) return rc;

@@ -111,18 +111,19 @@ class DCNFunction(torch.autograd.Function):
         B, D = x.shape
         L = kernels.shape[0]
         y = torch.empty_like(x)
+        csave = torch.empty((B, L), dtype=torch.float32, device=x.device)      # per-row scalars x_l . w_l for the backward
         rc = getattr(_lib.load(), 'recnow_dcn_fwd')(_lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases), B, D, L, act_code,
-                                                     _lib.ptr(y), _lib.stream())
+                                                     _lib.ptr(y), _lib.ptr(csave), _lib.stream())
         if rc == -3:
             raise NotImplementedError('DCNLayer kernels support input_dim <= 4096 (multiple of 4) or <= 1024 otherwise; got %d' % D)
         _lib.check(rc, 'recnow_dcn_fwd')
-        ctx.save_for_backward(x, kernels, biases if biases is not None else x.new_empty(0))
+        ctx.save_for_backward(x, kernels, biases if biases is not None else x.new_empty(0), csave)
         ctx.meta = (B, D, L, act_code, biases is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, kernels, biases = ctx.saved_tensors
+        x, kernels, biases, csave = ctx.saved_tensors
         B, D, L, act_code, has_bias = ctx.meta
         dy = _lib.f32c(dy, 'grad')
         dx = torch.empty_like(x)
@@ -130,8 +131,8 @@ class DCNFunction(torch.autograd.Function):
         db = torch.empty_like(kernels) if has_bias else None
         lib = _lib.load()
         ws = _lib.workspace(lib.recnow_dcn_workspace_bytes(B, D, L), x.device)
-        rc = lib.recnow_dcn_bwd(_lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases) if has_bias else None, _lib.ptr(dy), B, D, L,
-                                act_code, _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.stream())
+        rc = lib.recnow_dcn_bwd(_lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases) if has_bias else None, _lib.ptr(dy),
+                                _lib.ptr(csave) if L <= 4 else None, B, D, L, act_code, _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.stream())
         if rc == -3:
             raise NotImplementedError('DCNLayer backward supports degree_of_cross <= 4')
         _lib.check(rc, 'recnow_dcn_bwd')

@@ -634,3 +634,26 @@ def test_multi_dense_shape_sweep(dev, B, D, U, N, batched, act):
     (300, 12, 16, [128, 20, 128], True, False, True), (1024, 4, 8, [256], False, False, True), (128, 33, 4, [65, 31], True, True, True)])
 def test_cin_shape_sweep(dev, B, F, D, Hs, oi, sc, as_list):
     test_cin_fwd_bwd_vs_oracle(dev, B, F, D, Hs, oi, sc, as_list)
+
+
+def test_dcn_backward_without_saved_scalars_matches(dev):
+    """recnow_dcn_bwd(csave = NULL) recomputes the forward per row; with csave it uses the forward's scalars: same gradients."""
+    from rec_now_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    B, D, L = 700, 1024, 3
+    x, dy = (torch.from_numpy(rng.normal(0, 1, (B, D)).astype(np.float32)).to(dev) for _ in range(2))
+    k = torch.from_numpy((rng.uniform(-1, 1, (L, D)) / np.sqrt(D)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.uniform(-0.5, 0.5, (L, D)).astype(np.float32)).to(dev)
+    y = torch.empty_like(x)
+    cs = torch.empty((B, L), device=dev)
+    _lib.call('recnow_dcn_fwd', _lib.ptr(x), _lib.ptr(k), _lib.ptr(b), B, D, L, 2, _lib.ptr(y), _lib.ptr(cs), _lib.stream())
+    ws = _lib.workspace(lib.recnow_dcn_workspace_bytes(B, D, L), dev)
+    outs = []
+    for c in (cs, None):
+        dx, dk, db = torch.empty_like(x), torch.empty_like(k), torch.empty_like(b)
+        _lib.call('recnow_dcn_bwd', _lib.ptr(x), _lib.ptr(k), _lib.ptr(b), _lib.ptr(dy), _lib.ptr(c), B, D, L, 2, _lib.ptr(dx), _lib.ptr(dk),
+                  _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.stream())
+        outs.append((dx, dk, db))
+    for a, r in zip(*outs):
+        close(a, r, rtol=2e-6)

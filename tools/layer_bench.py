@@ -53,8 +53,8 @@ def dcn():
         x.grad = None
         layer(x).backward(gy)
     ms = timeit(step)
-    print('DCNLayer fwd+bwd  B=%d D=%d L=%d : %.3f ms  %.0f GB/s algorithmic (24*B*D: x,y | x,dy,dx + recompute read)  %.1f M samples/s'
-          % (B, D, L, ms, 24.0 * B * D / ms / 1e6, B / ms / 1e3))
+    print('DCNLayer fwd+bwd  B=%d D=%d L=%d : %.3f ms  %.0f GB/s algorithmic (20*B*D bytes: x,y | x,dy,dx)  %.1f M samples/s'
+          % (B, D, L, ms, 20.0 * B * D / ms / 1e6, B / ms / 1e3))
 
 
 def pairwise(B, G, tag):
