@@ -12,8 +12,9 @@ Data-parallel (weak scaling): every rank owns whole groups, the loss is combined
 (rec_now_amd/dp.py).  Prints ONE JSON line on rank 0.
 
 roofline:     the dominant kernel is the exact-fp32 MFMA GEMM; `achieved` = algorithmic flops (2*M*N*K per launch)
-              / HIP-event time of every launch of the busiest GEMM tile family during the timed steps, measured by
-              the library's own event hook on the launch stream (recnow_prof_*).
+              / HIP-event time of the launches of the busiest GEMM tile family during the timed steps (every 5th launch
+              is timed: 18 launches per step, so every launch position is sampled equally), measured by the library's
+              own event hook on the launch stream (recnow_prof_*).
 cpu_baseline: the oracle (dense O(B^2) reference formulation, torch CPU, oracle/dense_ref.py) timed on this host on a
               bounded sample of the same workload (B_s rows with the same 64 rows/group), rank 0, N = 1 only.
 """
@@ -37,6 +38,7 @@ D = N_FIELD * EMB_DIM
 SUB, LAYERS, EXPERTS = 64, 3, 2
 ROWS_PER_GROUP = 64
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PROF_EVERY = 5                        # time every 5th GEMM launch (18 per step: every launch position gets sampled)
 GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>'}
 
 
@@ -131,7 +133,7 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     from rec_now_amd import _lib, dp
-    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss_fused
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import group_rows, pairwise_loss_fused
     lib = _lib.load()
     dp.FORCE_COLLECTIVES = bool(args.force_dist)
 
@@ -144,11 +146,20 @@ def main():
     params = [p for p in model.parameters()]
     reducer = dp.GradientAllReducer(params)
 
+    side = torch.cuda.Stream(device=dev)
+
     def step():
         for p in params:
             p.grad = None
+        # the grouping of the batch (sort by group id, segments) does not depend on the scores: it runs on a side stream
+        # under the forward pass.  Still part of the step: the group ids are an input of every step.
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            seg = group_rows(gd)
         scores = model(xd)
-        local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False)
+        main.wait_stream(side)
+        local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False, segments=seg)
         loss_bw, loss_val, _ = dp.global_pairwise_loss(local_sum, n_pair)
         loss_bw.backward()
         reducer.all_reduce()
@@ -177,6 +188,7 @@ def main():
     prof = not args.no_prof and graph is None
     if prof:
         _lib.check(lib.recnow_prof_enable(64 * (args.steps + 1)), 'recnow_prof_enable')
+        _lib.check(lib.recnow_prof_sample_every(PROF_EVERY), 'recnow_prof_sample_every')
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -201,7 +213,7 @@ def main():
                 pass
             roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'kernel': GEMM_TAGS[tag],
-                        'launches': cnt[tag], 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
+                        'launches': cnt[tag], 'sampled': 'every %dth launch of the timed region' % PROF_EVERY, 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
                         'algorithmic_flops_per_launch': fl[tag] / cnt[tag],
                         'all_gemm': {GEMM_TAGS[t]: {'launches': cnt[t], 'ms': ms[t],
                                                     'tflops': (fl[t] / (ms[t] * 1e-3) / 1e12) if ms[t] > 0 else None}

@@ -411,6 +411,9 @@ int recnow_embed_scatter_rows(const float* drows, const int64_t* row_ids, int64_
  * 3 = k_gemm<256,64>, 4 = k_gemm<256,32>: launches, total milliseconds, total algorithmic flops (2*M*N*K*batch).
  * ---------------------------------------------------------------------------------------------------------- */
 int recnow_prof_enable(int capacity);
+/* Time only every n-th GEMM launch (default 1 = all): the two timing events around a launch cost ~2 us of stream
+ * serialisation each; with n coprime to the launches per step every launch position is sampled equally often. */
+int recnow_prof_sample_every(int n);
 int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host);
 
 #ifdef __cplusplus

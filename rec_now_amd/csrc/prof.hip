@@ -4,11 +4,14 @@
 static bool g_on = false;
 static std::vector<RnProfRecord> g_pool;
 static size_t g_used = 0;
+static int g_every = 1;          // time one launch in g_every (timing events serialise the stream around the launch)
+static unsigned g_seq = 0;
 
 bool rn_prof_on() { return g_on; }
 
 RnProfRecord* rn_prof_begin(int tag, double flops, hipStream_t st) {
     if (!g_on || g_used >= g_pool.size()) return nullptr;
+    if ((g_seq++ % (unsigned)g_every) != 0) return nullptr;
     RnProfRecord* r = &g_pool[g_used++];
     r->tag = tag;
     r->flops = flops;
@@ -35,6 +38,14 @@ extern "C" int recnow_prof_enable(int capacity) {
         RN_HIP(hipEventCreate(&r.e1));
     }
     g_on = true;
+    return RECNOW_OK;
+}
+
+// Time every n-th GEMM launch only (n >= 1; choose n coprime to the launches per step so every launch position is sampled).
+extern "C" int recnow_prof_sample_every(int n) {
+    if (n < 1) return RECNOW_EINVAL;
+    g_every = n;
+    g_seq = 0;
     return RECNOW_OK;
 }
 

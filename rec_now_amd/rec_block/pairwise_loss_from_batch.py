@@ -170,11 +170,19 @@ class _PairBprFused(torch.autograd.Function):
         return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None
 
 
+def group_rows(groups):
+    """The score-independent half of the loss: canonical keys -> radix sort -> segments of `groups` (tensor or list of
+    tensors, as `pairwise_loss` takes them).  The result can be handed to `pairwise_loss_fused(..., segments=...)`, so a
+    training step can build it on a side stream while the model's forward pass is still producing the scores."""
+    return build_segments(groups)
+
+
 def pairwise_loss_fused(outputs, labels, groups, only_use_wrong_order_pair=False, click_occurance_power=0.0, mask=None,
-                        factor=1.0, reduce_mean=True):
+                        factor=1.0, reduce_mean=True, segments=None):
     """Fused BPR pairwise loss; returns (loss, n_pair) as 0-dim tensors, no host sync.  `pairwise_loss` routes here
-    whenever the defaults make it possible; exposed because it also accepts `factor` / `reduce_mean`."""
-    seg = build_segments(groups)
+    whenever the defaults make it possible; exposed because it also accepts `factor` / `reduce_mean` and a precomputed
+    `segments=group_rows(groups)` (then `groups` is not looked at again)."""
+    seg = segments if segments is not None else build_segments(groups)
     flags = _FLAG_LABEL_GT | (_FLAG_WRONG_ORDER if only_use_wrong_order_pair else 0)
     return _PairBprFused.apply(outputs, labels, mask, seg, flags, factor, click_occurance_power, reduce_mean)
 
