@@ -189,6 +189,53 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
     return s + 4096;
 }
 
+
+// One launch packs the weights of ALL layers (exact path): Wc1_l = [U_l | K_l | 0] (D x LDT) and, when Wc2 != NULL,
+// Wc2_l = [W_l; b_l; 0] (LDT x D).  Replaces 4 tiny launches per layer in front of every product.
+#define MIX_PACK_MAX_L 8
+struct MixPackPtrs {
+    const float* U[MIX_PACK_MAX_L];
+    const float* K[MIX_PACK_MAX_L];
+    const float* W[MIX_PACK_MAX_L];
+    const float* b[MIX_PACK_MAX_L];
+};
+__global__ void __launch_bounds__(256)
+k_pack_all(MixPackPtrs p, int L, int D, int S, int N, int LDT, float* __restrict__ Wc1, float* __restrict__ Wc2) {
+    const int NS = N * S, KC = NS + N;
+    const int64_t per = (int64_t)D * LDT, total = (int64_t)L * per * (Wc2 ? 2 : 1);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t j = i % ((int64_t)L * per);
+        const int l = (int)(j / per);
+        const int64_t e = j - (int64_t)l * per;
+        if (i < (int64_t)L * per) {                      // Wc1_l[d][c]
+            const int d = (int)(e / LDT), c = (int)(e % LDT);
+            float v = 0.f;
+            if (c < NS) v = p.U[l][((int64_t)(c / S) * D + d) * S + (c % S)];
+            else if (c < KC) v = p.K[l][(int64_t)d * N + (c - NS)];
+            Wc1[j] = v;
+        } else {                                         // Wc2_l[k][d]
+            const int k = (int)(e / D), d = (int)(e % D);
+            float v = 0.f;
+            if (k < NS) v = p.W[l][(int64_t)k * D + d];
+            else if (k < KC) v = p.b[l][(int64_t)(k - NS) * D + d];
+            Wc2[j] = v;
+        }
+    }
+}
+static int pack_all(const MixDims& m, const float* const* U_host, const float* const* W_host, const float* const* bias_host,
+                    const float* const* gate_host, float* Wc1_all, float* Wc2_all, hipStream_t st) {
+    MixPackPtrs p;
+    for (int l = 0; l < m.L; ++l) {
+        p.U[l] = U_host[l]; p.K[l] = gate_host[l]; p.W[l] = W_host[l]; p.b[l] = bias_host[l];
+    }
+    const int64_t total = (int64_t)m.L * m.D * m.LDT * (Wc2_all ? 2 : 1);
+    int g = rn_cdiv(total, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_pack_all, g, 256, 0, st, p, m.L, m.D, m.S, m.N, m.LDT, Wc1_all, Wc2_all);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
 static int pack_weights(const MixDims& m, const float* U, const float* V, const float* W, const float* bias, const float* K,
                         float* Wc1, float* Wc2, hipStream_t st) {
     (void)V;
@@ -276,12 +323,16 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
     c.take<float>((size_t)m.LDT * D);
     c.take<float>(3 * act_block(m) / sizeof(float));
     c.take<float>(2 * xbuf(m) / sizeof(float));
+    const bool pack_once = m.exact && L <= MIX_PACK_MAX_L;          // all layers' packed weights in one launch
+    float* Wc1_all = pack_once ? c.take<float>((size_t)L * D * m.LDT) : nullptr;
+    float* Wc2_all = pack_once ? c.take<float>((size_t)L * m.LDT * D) : nullptr;
     void* gws = c.base + c.off;
     const size_t gws_bytes = ws_bytes - c.off;
     char* sv = (char*)saved;
     float* xmid = (float*)(sv + (size_t)L * 3 * act_block(m));
     float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));        // exact path only
     int rc;
+    if (pack_once && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, st))) return rc;
     const float* xl = x;
     for (int l = 0; l < L; ++l) {
         float* T1 = (float*)(sv + (size_t)(3 * l) * act_block(m));
@@ -289,7 +340,12 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
         float* T2g = (float*)(sv + (size_t)(3 * l + 2) * act_block(m));
         float* out = (l == L - 1) ? y : xmid + (size_t)l * (xbuf(m) / sizeof(float));
         if (m.exact) {
-            if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) return rc;
+            if (pack_once) {
+                Wc1 = Wc1_all + (size_t)l * D * m.LDT;
+                Wc2 = Wc2_all + (size_t)l * m.LDT * D;
+            } else if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) {
+                return rc;
+            }
             {   // GEMM1: T1[:, :NS] = act_inner(x_l U);  gate logits T1[:, NS:NS+N] = x_l K as the VALU side product
                 recnow_gemm_desc d = rn_gemm_desc_zero();
                 d.A = xl; d.lda = D; d.a_trans = 0;
@@ -397,10 +453,12 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     const float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));
     MixEvents evs;
     int rc;
-    {
+    if (L <= MIX_PACK_MAX_L) {             // [U | K | 0] of every layer in one launch (W and bias are used in place)
+        if ((rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, nullptr, st))) return rc;
+    } else {
         int pgw = rn_cdiv((int64_t)D * m.LDT, 256);
         if (pgw > 2048) pgw = 2048;
-        for (int l = 0; l < L; ++l) {      // [U | K | 0] of every layer (W and bias are used in place)
+        for (int l = 0; l < L; ++l) {
             hipLaunchKernelGGL(k_pack_w1, pgw, 256, 0, st, U_host[l], gate_host[l], D, S, N, m.LDT, Wc1_all + (size_t)l * D * m.LDT);
             RN_LAUNCH_CHECK();
         }
