@@ -160,9 +160,14 @@ def main():
         scores = model(xd)
         main.wait_stream(side)
         local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False, segments=seg)
-        loss_bw, loss_val, _ = dp.global_pairwise_loss(local_sum, n_pair)
-        loss_bw.backward()
-        reducer.all_reduce()
+        if use_dist:
+            # one collective per step: backward on the unnormalised local sum; (loss sum, P) ride in the gradient bucket and
+            # the gradients are divided by P_global afterwards (the loss is linear in 1/P) -- no sync between fwd and bwd
+            local_sum.backward()
+            loss_val, _ = reducer.all_reduce_with_loss(local_sum, n_pair)
+        else:
+            loss_bw, loss_val, _ = dp.global_pairwise_loss(local_sum, n_pair)
+            loss_bw.backward()
         return loss_val
 
     def sync():
@@ -245,10 +250,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which is flushed at exit, i.e. after a Python print: flush the C
+        # streams first so that the JSON line is the LAST line on stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -72,40 +72,75 @@ class GradientAllReducer(object):
         if cur:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
+        self._extra = None
+        self._extra_out = None
 
-    def all_reduce(self, async_op=False):
-        """Call after backward.  Gradients missing on this rank count as zero."""
+    def all_reduce_with_loss(self, local_loss_sum, local_count, eps=SMALL_POSIVITE_FLOAT):
+        """ONE collective per step.  The pairwise / listwise loss is linear in 1/P_global, so instead of all-reducing
+        (loss sum, P) before the backward pass (a sync point between forward and backward, `global_pairwise_loss`), run
+        the backward pass on the UNNORMALISED local loss sum, then call this: the two statistics ride in the last gradient
+        bucket, and every gradient is divided by (P_global + eps) afterwards (on the flat buffers).
+        Returns (global mean loss, P_global) as 0-dim tensors (detached).  Works without a process group too."""
+        stats = torch.stack([local_loss_sum.detach().to(torch.float32), local_count.detach().to(torch.float32)])
+        if is_dist():
+            self._extra = stats
+            self.all_reduce(scale=lambda ex: 1.0 / (ex[1] + eps))
+            stats = self._extra_out
+            self._extra = None
+        else:
+            inv = 1.0 / (stats[1] + eps)
+            grads = [p.grad for p in self.params if p.grad is not None]
+            if grads:
+                torch._foreach_mul_(grads, inv)
+        return stats[0] / (stats[1] + eps), stats[1]
+
+    def all_reduce(self, async_op=False, scale=None):
+        """Call after backward.  Gradients missing on this rank count as zero.  Packing / unpacking of a bucket is one
+        `torch.cat` and one multi-tensor copy (not a kernel per parameter).  `scale`: optional callable(extra_out) -> 0-dim
+        tensor the reduced gradients are multiplied with (on the flat buffer, one kernel)."""
         if not is_dist():
             return []
         works = []
+        extra = self._extra
         for i, bucket in enumerate(self.buckets):
             n = sum(p.numel() for p in bucket)
+            parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket]
+            if extra is not None and i == len(self.buckets) - 1:
+                parts.append(extra.to(parts[0].dtype).reshape(-1))
+            total = sum(t.numel() for t in parts)
             flat = self._flat[i]
-            if flat is None or flat.numel() != n or flat.device != bucket[0].device:
-                flat = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
+            if flat is None or flat.numel() != total or flat.device != bucket[0].device:
+                flat = torch.empty(total, dtype=bucket[0].dtype, device=bucket[0].device)
                 self._flat[i] = flat
-            off = 0
-            for p in bucket:
-                k = p.numel()
-                if p.grad is None:
-                    flat[off:off + k].zero_()
-                else:
-                    flat[off:off + k].copy_(p.grad.reshape(-1))
-                off += k
+            torch.cat(parts, out=flat)
             works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), i))
         if async_op:
             return works
-        self.finish(works)
+        self.finish(works, scale)
         return []
 
-    def finish(self, works):
+    def finish(self, works, scale=None):
         for work, i in works:
             work.wait()
+        for work, i in reversed(works):              # the last bucket carries the extras the scale may depend on
+            flat = self._flat[i]
+            n = sum(p.numel() for p in self.buckets[i])
+            if flat.numel() > n:
+                self._extra_out = flat[n:].clone()
+        factor = scale(self._extra_out) if scale is not None else None
+        for work, i in works:
             flat, off = self._flat[i], 0
+            if factor is not None:
+                flat.mul_(factor)
+            dst, src = [], []
             for p in self.buckets[i]:
                 k = p.numel()
+                view = flat[off:off + k].reshape(p.shape)
                 if p.grad is None:
-                    p.grad = flat[off:off + k].reshape(p.shape).clone()
+                    p.grad = view.clone()
                 else:
-                    p.grad.copy_(flat[off:off + k].reshape(p.shape))
+                    dst.append(p.grad)
+                    src.append(view)
                 off += k
+            if dst:
+                torch._foreach_copy_(dst, src)

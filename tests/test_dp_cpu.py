@@ -49,6 +49,14 @@ def _worker(rank, world, port, out):
     loss_bw.backward()
     red = dp.GradientAllReducer([wt])
     red.all_reduce()
+    # the one-collective form: backward on the unnormalised local sum, statistics ride along with the gradients
+    wt2 = torch.from_numpy(w.copy()).requires_grad_(True)
+    sc2 = torch.from_numpy(s[mine]) * wt2[0] + wt2[1]
+    local_sum2, n_pair2 = R.pairwise_loss(sc2, yl, gl, f, return_num_pair=True)
+    local_sum2.backward()
+    loss_val2, p_glob2 = dp.GradientAllReducer([wt2]).all_reduce_with_loss(local_sum2, torch.tensor(n_pair2))
+    assert abs(float(loss_val2) - float(loss_val)) <= 1e-6 * max(1.0, abs(float(loss_val))) and float(p_glob2) == float(p_glob)
+    assert np.abs(wt2.grad.numpy() - wt.grad.numpy()).max() <= 1e-6 * max(1.0, np.abs(wt.grad.numpy()).max())
     out[rank] = (float(loss_val), float(p_glob), wt.grad.numpy().copy(), int(mine.sum()))
     dist.barrier()
     dist.destroy_process_group()
@@ -92,3 +100,8 @@ def test_single_process_passthrough():
     assert abs(float(s.grad) - 1.0 / 3.0) < 1e-6
     lb, lv, n = dp.global_listwise_loss(torch.tensor(0.0), torch.tensor(0.0))
     assert float(lv) == 0.0
+    w = torch.tensor([2.0], requires_grad=True)
+    ls = (w * 3.0).sum()
+    ls.backward()
+    lv, p = dp.GradientAllReducer([w]).all_reduce_with_loss(ls, torch.tensor(3.0))
+    assert abs(float(lv) - 2.0) < 1e-6 and float(p) == 3.0 and abs(float(w.grad) - 1.0) < 1e-6
