@@ -175,3 +175,30 @@ def test_focal_crossentropy_fwd_bwd_vs_oracle(dev, B, alpha, gamma, stop_w, mean
     (ref * torch.from_numpy(g).double()).sum().backward()
     close(out, ref, rtol=2e-5 if gamma and gamma < 1 else RTOL)
     close(xd.grad, x64.grad, rtol=2e-5, scale=max(float(x64.grad.abs().max()), 1e-12))
+
+
+def test_empty_batches(dev):
+    """B = 0 through every widened op, forward and backward (the reference's ops accept empty batches too)."""
+    from rec_now_amd.layers.inner_pnn_layer import InnerPNNLayer
+    from rec_now_amd.layers.senet_layer import SENETLayer
+    from rec_now_amd.rec_block.attention import attention_by_dot_product
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    from rec_now_amd.rec_block.focal_loss import focal_crossentropy_loss
+    z = lambda *s: torch.zeros(*s, device=dev, requires_grad=True)       # noqa: E731
+    out = InnerPNNLayer()([z(0, 4) for _ in range(3)])
+    assert out.shape == (0, 3)
+    out.sum().backward()
+    out = SENETLayer(0.5)([z(0, 4) for _ in range(3)])
+    assert out.shape == (0, 12)
+    out.sum().backward()
+    mat, ssum = attention_by_dot_product(z(0, 3, 4), z(0, 4))
+    assert mat.shape == (0, 4) and ssum.shape == (0, 1)
+    mat.sum().backward()
+    assert focal_crossentropy_loss(torch.zeros(0, device=dev), z(0), return_mean=False).shape == (0,)
+    assert torch.isnan(focal_crossentropy_loss(torch.zeros(0, device=dev), z(0)))          # tf.reduce_mean of nothing
+    table = EmbeddingTable(torch.ones(5, 2, device=dev))
+    ids = torch.zeros(0, 3, dtype=torch.int64, device=dev)
+    out = embedding_using_sparse_batch_segment_ids(table, ids.to(torch.int32), [1], ids)
+    assert out.shape == (0, 1, 2)
+    out.sum().backward()
+    assert embedding_using_sparse_batch_segment_ids(table, torch.zeros(2, 3, dtype=torch.int32, device=dev), [], torch.zeros(2, 3, dtype=torch.int64, device=dev)).shape == (2, 0, 2)
