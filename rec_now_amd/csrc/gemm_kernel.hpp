@@ -319,21 +319,33 @@ k_gemm(const GemmK p) {
             *reinterpret_cast<f32x4*>(Bxs + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
         }
     }
+    // Staging schedule (one register set): the registers hold k-tile t+1 while k-tile t is computed.  They are written to
+    // the free LDS buffer right AFTER the barrier that opens iteration t (not before the barrier that closes it, where every
+    // wave would sit in "wait vmcnt -> ds_write -> barrier" with the MFMA pipe idle), and the loads of k-tile t+2 are
+    // re-issued immediately, so they have a whole iteration of MFMAs to land.
+    auto issue_loads = [&](int t1) {
+        const int k0 = k_begin + t1 * BK;
+        const bool kf = !EDGE || (k0 + BK <= k_end);
+        if ((XF & 4) != 0 && blockIdx.y == 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k0);
+        else ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
+        tb.template load<EDGE, B2K>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
+        if ((XF & 1) && threadIdx.x < BK) {
+            const int kx = k0 + threadIdx.x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bxr[r] = r < p.sp_r ? p.bx[(int64_t)kx * p.bx_ks + r * p.bx_rs] : 0.f;
+        }
+    };
+    if (ntile > 1) issue_loads(1);
     __syncthreads();
     RN_TR(1);
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
-        if (t + 1 < ntile) {                      // next k-tile's global loads fly under this tile's MFMAs
-            const int k0 = k_begin + (t + 1) * BK;
-            const bool kf = !EDGE || (k0 + BK <= k_end);
-            if ((XF & 4) != 0 && blockIdx.y == 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k0);
-            else ta.template load<EDGE, A2K>(a_fast && kf, Ab, A2b, p.a_mode, p.a_act, p.lda, m0, k0, p.M, k_end, p.a_ld2, p.a_hq);
-            tb.template load<EDGE, B2K>(b_fast && kf, Bb, B2b, p.b_mode, p.b_act, p.ldb, n0, k0, p.N, k_end, p.b_ld2, p.b_hq);
-        }
-        if ((XF & 1) && t + 1 < ntile && threadIdx.x < BK) {
-            const int kx = k_begin + (t + 1) * BK + threadIdx.x;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bxr[r] = r < p.sp_r ? p.bx[(int64_t)kx * p.bx_ks + r * p.bx_rs] : 0.f;
+        if (t + 1 < ntile) {                      // k-tile t+1: registers -> the buffer k-tile t-1 was read from
+            ta.store(As + (cur ^ 1) * A_SZ);
+            tb.store(Bs + (cur ^ 1) * B_SZ);
+            if ((XF & 1) && threadIdx.x < BK)
+                *reinterpret_cast<f32x4*>(Bxs + (cur ^ 1) * BK * 4 + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
+            if (t + 2 < ntile) issue_loads(t + 2);
         }
         // VALU side product off the A tile in LDS: thread = (row m, half of the tile's k range); its 2*(BK/4) k's are
         // spread over the MFMA loop below (2 per iteration) so the FMAs run in the shadow of in-flight MFMAs.
@@ -379,12 +391,6 @@ k_gemm(const GemmK p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if (t + 1 < ntile) {
-            ta.store(As + (cur ^ 1) * A_SZ);
-            tb.store(Bs + (cur ^ 1) * B_SZ);
-            if ((XF & 1) && threadIdx.x < BK)
-                *reinterpret_cast<f32x4*>(Bxs + (cur ^ 1) * BK * 4 + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
         }
         __syncthreads();
     }
