@@ -32,6 +32,7 @@ struct GemmK {
     int64_t eu_pms, eu_qrs, eu_qns;
     int eu_r;
     int npart;                 // row width of a split-K slab: N, or N + 4 when a side product rides along
+    int xcd_remap;             // split-K, one column tile, gridDim.z % 8 == 0: row tiles of a k-slab share an XCD (see k_gemm)
     const float* as_in;        // XF & 4: elementwise side output of the A stream, as_out = A * as_in (layout of A)
     float* as_out;
     float* C2;                 // second output of the short-K kernel (c2_mode 1: C2 = acc; 2: C2 += acc * E2)
@@ -272,10 +273,20 @@ k_gemm(const GemmK p) {
 #define RN_TR(i) do { } while (0)
 #endif
     RN_TR(0);
-    const int z = blockIdx.z, bidx = z / p.splitk, ks = z % p.splitk;
+    // Split-K with few row tiles (the K = B weight-gradient products: 8 row tiles x 64 slabs): the row tiles of one k-slab
+    // read the same B panel, but consecutive workgroups land on different XCDs (round-robin dispatch), i.e. on different
+    // L2s -- the panel was fetched from HBM once per XCD (PMC: +270 MB per launch).  xcd_remap re-labels the workgroups so
+    // that the row tiles of a slab are the consecutive workgroups OF ONE XCD.  Pure re-labelling of (blockIdx.x, blockIdx.z).
+    int bx = blockIdx.x, z = blockIdx.z;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, lin = bx + gx * z, xcd = lin & 7, i = lin >> 3;
+        z = xcd * ((int)gridDim.z >> 3) + i / gx;
+        bx = i % gx;
+    }
+    const int bidx = z / p.splitk, ks = z % p.splitk;
     const int k_begin = ks * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = blockIdx.y * BN;
     const bool a_outer = (A2K >= 0 ? A2K : p.a_mode) == RECNOW_OPMODE_OUTER, b_outer = (B2K >= 0 ? B2K : p.b_mode) == RECNOW_OPMODE_OUTER;
     const float* Ab = p.A + (int64_t)bidx * p.sA;
     const float* A2b = p.A2 ? p.A2 + (a_outer ? 0 : (int64_t)bidx * p.sA) : nullptr;
