@@ -171,6 +171,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     if (gz > 65535) return RECNOW_EUNSUPPORTED;
     dim3 grid(rn_cdiv(d->M, c.BM), rn_cdiv(d->N, c.BN), (unsigned)gz);
     k.xcd_remap = (k.splitk > 1 && d->batch == 1 && grid.y == 1 && gz % 8 == 0 && grid.x > 1) ? 1 : 0;
+    if (!k.xcd_remap && grid.y > 1 && grid.x % 8 == 0 && d->sp_r == 0 && !d->as_out) k.xcd_remap = 2;
     const bool a_kc = d->a_trans == 0, b_kc = d->b_trans != 0;
     int rc;
     const int tag = (c.BM == 256 && c.BN == 32) ? RN_TAG_GEMM_256x32 : (c.BM == 256) ? RN_TAG_GEMM_256x64

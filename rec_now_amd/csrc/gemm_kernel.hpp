@@ -260,6 +260,7 @@ k_gemm(const GemmK p) {
     float* const As = smem;                 // two buffers of A_SZ floats, then two of B_SZ
     float* const Bs = smem + 2 * A_SZ;
     float* const Bxs = smem + 2 * A_SZ + 2 * B_SZ;     // XF & 1: two buffers of BK x 4 side-product weights
+    // (sp_on / side output use blockIdx.y directly: those launches are never remapped in y, see rn_gemm)
     const bool sp_on = (XF & 1) && blockIdx.y == 0;    // one column-tile computes the side product of a row-tile
     f32x4 spacc = mk4(0.f, 0.f, 0.f, 0.f);
     float bxr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -277,16 +278,22 @@ k_gemm(const GemmK p) {
     // read the same B panel, but consecutive workgroups land on different XCDs (round-robin dispatch), i.e. on different
     // L2s -- the panel was fetched from HBM once per XCD (PMC: +270 MB per launch).  xcd_remap re-labels the workgroups so
     // that the row tiles of a slab are the consecutive workgroups OF ONE XCD.  Pure re-labelling of (blockIdx.x, blockIdx.z).
-    int bx = blockIdx.x, z = blockIdx.z;
-    if (p.xcd_remap) {
+    int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+    if (p.xcd_remap == 1) {
         const int gx = gridDim.x, lin = bx + gx * z, xcd = lin & 7, i = lin >> 3;
         z = xcd * ((int)gridDim.z >> 3) + i / gx;
         bx = i % gx;
+    } else if (p.xcd_remap == 2) {
+        // several column tiles per row tile (gridDim.x % 8 == 0): the column tiles of one row tile become consecutive
+        // workgroups of one XCD, so the A row panel is fetched into one L2 once instead of once per column tile
+        const int gx = gridDim.x, gy = gridDim.y, lin = bx + gx * by, xcd = lin & 7, i = lin >> 3;
+        bx = (i / gy) * 8 + xcd;
+        by = i % gy;
     }
     const int bidx = z / p.splitk, ks = z % p.splitk;
     const int k_begin = ks * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
-    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const bool a_outer = (A2K >= 0 ? A2K : p.a_mode) == RECNOW_OPMODE_OUTER, b_outer = (B2K >= 0 ? B2K : p.b_mode) == RECNOW_OPMODE_OUTER;
     const float* Ab = p.A + (int64_t)bidx * p.sA;
     const float* A2b = p.A2 ? p.A2 + (a_outer ? 0 : (int64_t)bidx * p.sA) : nullptr;
