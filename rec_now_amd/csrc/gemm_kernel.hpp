@@ -270,6 +270,7 @@ k_gemm(const GemmK p) {
     if (p.trace && threadIdx.x == 0)
         p.trace[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8ll + 4] =
             __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11)) | ((long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) << 32);
+    if (p.trace && threadIdx.x == 0) p.trace[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8ll + 5] = clock64();
 #else
 #define RN_TR(i) do { } while (0)
 #endif
@@ -523,6 +524,9 @@ k_gemm(const GemmK p) {
             }
         }
         RN_TR(3);
+#ifdef RN_GEMM_TRACE
+        if (p.trace && threadIdx.x == 0) p.trace[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8ll + 6] = clock64();
+#endif
         return;
     } else {
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);          // block-uniform
