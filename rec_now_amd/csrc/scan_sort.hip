@@ -278,6 +278,129 @@ __global__ void k_seg_empty(int32_t* seg_first, int32_t* n_seg) {
     n_seg[1] = 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Small batches (B <= 8192, one 32-bit key word): the whole grouping -- stable LSD radix sort, segment heads, segment ids --
+// in ONE workgroup on LDS-resident keys.  The general path above is ~24 launches of a few microseconds each, which is all
+// of the time at BASELINE config 2 (B = 8192: 0.24 ms per loss, launch-latency bound).
+//   1024 threads, thread t owns the 8 consecutive positions [8t, 8t+8) of the current order (so ranks are stable);
+//   4-bit digits: a thread's 16 digit counters (each <= 8) pack into one 64-bit register; passes whose digit is constant
+//   over the batch are skipped (OR/AND of all keys); counters [16][1024] u16 are scanned block-wide in digit-major order.
+// ------------------------------------------------------------------------------------------------
+#define GS_T 1024
+#define GS_KPT 8
+#define GS_MAXB (GS_T * GS_KPT)
+
+__device__ __forceinline__ unsigned gs_block_exclusive_scan(unsigned v, unsigned* wsum /* [16] */, unsigned* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned x = wsum[i];
+        if (i < w) off += x;
+        tot += x;
+    }
+    if (total) *total = tot;
+    return off + inc - v;
+}
+
+__global__ void __launch_bounds__(GS_T)
+k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int B, int32_t* __restrict__ order,
+              int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gs_lds[];
+    uint32_t* key0 = reinterpret_cast<uint32_t*>(gs_lds);
+    uint32_t* key1 = key0 + GS_MAXB;
+    uint16_t* idx0 = reinterpret_cast<uint16_t*>(key1 + GS_MAXB);
+    uint16_t* idx1 = idx0 + GS_MAXB;
+    uint16_t* cnt = idx1 + GS_MAXB;                       // [16][GS_T]
+    unsigned* wsum = reinterpret_cast<unsigned*>(cnt + 16 * GS_T);   // [16] + 2
+    const int tid = threadIdx.x;
+    unsigned vor = 0, vand = 0xffffffffu;
+    for (int i = tid; i < B; i += GS_T) {
+        const uint32_t k = words[i];
+        key0[i] = k;
+        idx0[i] = (uint16_t)i;
+        vor |= k;
+        vand &= k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vor |= __shfl_xor(vor, o, 64);
+        vand &= __shfl_xor(vand, o, 64);
+    }
+    if ((tid & 63) == 0) { wsum[tid >> 6] = vor; wsum[16 + (tid >> 6)] = vand; }      // wsum has room for 32 words (see host)
+    __syncthreads();
+    vor = 0; vand = 0xffffffffu;
+    for (int i = 0; i < 16; ++i) { vor |= wsum[i]; vand &= wsum[16 + i]; }
+    const unsigned varying = vor ^ vand;                  // bits that differ somewhere in the batch
+    __syncthreads();
+    uint32_t* ka = key0; uint32_t* kb = key1;
+    uint16_t* ia = idx0; uint16_t* ib = idx1;
+    const int lo = tid * GS_KPT, hi = min(B, lo + GS_KPT);
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 4 * pass;
+        if (((varying >> shift) & 15u) == 0) continue;    // block-uniform: this digit is the same for every key
+        unsigned long long c64 = 0;
+        for (int i = lo; i < hi; ++i) c64 += 1ull << (4 * ((ka[i] >> shift) & 15u));
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d * GS_T + tid] = (uint16_t)((c64 >> (4 * d)) & 15u);
+        __syncthreads();
+        // exclusive scan of the flattened [digit][thread] counters: thread t owns entries [16t, 16t + 16)
+        unsigned loc[16], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { loc[j] = cnt[tid * 16 + j]; sum += loc[j]; }
+        unsigned run = gs_block_exclusive_scan(sum, wsum, nullptr);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { cnt[tid * 16 + j] = (uint16_t)run; run += loc[j]; }
+        __syncthreads();
+        unsigned long long r64 = 0;                       // running per-digit rank inside this thread's chunk
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t k = ka[i];
+            const unsigned d = (k >> shift) & 15u;
+            const unsigned dst = cnt[d * GS_T + tid] + (unsigned)((r64 >> (4 * d)) & 15u);
+            r64 += 1ull << (4 * d);
+            kb[dst] = k;
+            ib[dst] = ia[i];
+        }
+        __syncthreads();
+        uint32_t* tk = ka; ka = kb; kb = tk;
+        uint16_t* ti = ia; ia = ib; ib = ti;
+    }
+    // segment heads over the sorted order; solo rows (NaN / inf ids) are segments of their own
+    unsigned heads = 0, nh = 0;
+    for (int i = lo; i < hi; ++i) {
+        bool h = true;
+        if (i > 0) h = (ka[i] != ka[i - 1]) || solo[ia[i]] || solo[ia[i - 1]];
+        heads |= (h ? 1u : 0u) << (i - lo);
+        nh += h ? 1u : 0u;
+    }
+    unsigned total = 0;
+    unsigned g = gs_block_exclusive_scan(nh, wsum, &total);
+    for (int i = lo; i < hi; ++i) {
+        const bool h = (heads >> (i - lo)) & 1u;
+        if (h) { seg_first[g] = i; ++g; }
+        order[i] = (int32_t)ia[i];
+        seg_id[i] = (int32_t)g - 1;
+        super_id[i] = (int32_t)g - 1;
+    }
+    if (tid == 0) {
+        seg_first[total] = B;
+        n_seg[0] = (int32_t)total;
+        n_seg[1] = (int32_t)total;
+    }
+}
+static inline size_t gs_lds_bytes() { return (size_t)GS_MAXB * (4 + 4 + 2 + 2) + (size_t)16 * GS_T * 2 + 34 * sizeof(unsigned); }
+
 extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) {
     if (B < 0 || n_words < 1 || n_words > RN_MAX_WORDS) return 0;
     const int nblk = rn_cdiv(B > 0 ? B : 1, RN_TILE);
@@ -305,6 +428,12 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     }
     if (!words || !solo || !order || !seg_id || !super_id || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_group_segments_workspace_bytes(B, n_words)) return RECNOW_EWORKSPACE;
+    if (B <= GS_MAXB && n_words == 1) {           // small batch, one key word: everything in one workgroup
+        RN_HIP(hipFuncSetAttribute((const void*)k_group_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+        hipLaunchKernelGGL(k_group_small, 1, GS_T, gs_lds_bytes(), st, words, solo, (int)B, order, seg_id, seg_first, super_id, n_seg);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
     const int nblk = rn_cdiv(B, RN_TILE);
     RnCarver c(ws, ws_bytes);
     SortPlan* plan = c.take<SortPlan>(1);
