@@ -1,9 +1,8 @@
 """PLELayer -- drop-in for rec_now/layers/ple_layer.py (/root/reference/rec_now/layers/ple_layer.py:16-321).
 Progressive Layered Extraction: per layer, shared and task-specific expert groups (MultiDenseLayer stacks) mixed by
-softmax gates.  The control flow below follows the reference method by method; the compute is the batched fp32 MFMA
-GEMM (experts, gates) and the fused softmax-mix kernel (no concat of expert outputs is materialised)."""
-import copy
-
+softmax gates.  Same constructor, weights (by Keras name) and outputs as the reference; the wiring is a plan resolved at
+build time, the compute is the batched fp32 MFMA GEMM (experts, gates) and the fused softmax-mix kernel (no concat of
+expert outputs is materialised)."""
 import torch
 from torch import nn
 
@@ -44,162 +43,107 @@ class _ExpertDNN(Layer):
 
 
 class PLELayer(DenseBase):
-    """Symbols: B batch size, D input dim, N experts relevant to a task at a layer, dim_out DNN output dim."""
+    """Progressive Layered Extraction.  Task groups = `num_shared_task` shared groups followed by `num_task` task-specific
+    ones; per PLE layer every group owns a stack of batched expert DNNs and (except the shared groups of the last layer) a
+    softmax gate over the experts it may see: a specific group sees its own experts and the shared ones, a shared group
+    sees all of them.
+
+    Symbols: B batch size, D input dim, N experts visible to a group at a layer, dim_out last DNN width of a layer.
+
+    The wiring is resolved once in `build` into a plan (which previous outputs feed a group, which expert groups its gate
+    mixes), `call` just walks the plan; the variable names are the reference's
+    (`{name}/ple_layer_{l}/task_{group}/.../MultiDenseLayer_{i}/kernel`, `{name}/ple_gate_{l}/task_{group}/dense/kernel`).
+    """
 
     def __init__(self, num_task, list_of_dnn_dims, list_of_num_experts_per_task, num_shared_task=1, **kwargs):
         if not isinstance(list_of_dnn_dims, list):
-            raise TypeError('`list_of_dnn_dims` must be a list or list[list]')
+            raise TypeError('`list_of_dnn_dims` must be a list or list[list]')                  # reference :42-43
         super().__init__(0, **kwargs)
-        self.num_task = num_task
-        self.num_shared_task = num_shared_task
-        self.num_total_task = num_task + num_shared_task
         if num_shared_task > num_task:
-            # reference :108 builds the shared names with range(num_task); every zip() then silently drops task groups
+            # reference :108 names the shared groups with range(num_task); its zip()s then silently drop task groups
             # (SURVEY Appendix B15).  Refuse instead of reproducing the truncation.
             raise ValueError('num_shared_task > num_task is not supported (the reference silently drops task groups)')
-        self.list_of_dnn_dims, self.list_of_num_experts_per_task, self.is_shared_tasks, self.task_names = \
-            self._get_normalized_params(num_task, num_shared_task, list_of_dnn_dims, list_of_num_experts_per_task)
+        self.num_task, self.num_shared_task = num_task, num_shared_task
+        self.num_total_task = num_task + num_shared_task
+        dims, experts, shared, names = self._get_normalized_params(num_task, num_shared_task, list_of_dnn_dims,
+                                                                   list_of_num_experts_per_task)
+        self.list_of_dnn_dims, self.list_of_num_experts_per_task = dims, experts
+        self.is_shared_tasks, self.task_names = shared, names
 
+    # -- argument normalisation (class methods of the reference, :63-113: the reference's tests call them) ------------
     @classmethod
     def _extend_int_list(cls, list_or_int, size_extend):
-        if not isinstance(list_or_int, (int, list)):
-            raise TypeError('`list_or_int` must be of type `int` or `list of int`, but got `%s`' % type(list_or_int))
+        """int or list of int -> list of at least `size_extend` ints, padded with its last element."""
         if isinstance(list_or_int, int):
-            list_or_int = [list_or_int]
-        if not list_or_int:
+            values = [list_or_int]
+        elif isinstance(list_or_int, list):
+            values = list(list_or_int)
+        else:
+            raise TypeError('`list_or_int` must be of type `int` or `list of int`, but got `%s`' % type(list_or_int))
+        if len(values) == 0:
             raise ValueError('list can not be empty')
-        list_or_int = copy.copy(list_or_int)
-        while len(list_or_int) < size_extend:
-            list_or_int.append(list_or_int[-1])
-        return list_or_int
+        return values + [values[-1]] * max(0, size_extend - len(values))
 
     @classmethod
     def _get_normalized_params(cls, num_task, num_shared_task, list_of_dnn_dims, list_of_num_experts_per_task):
-        num_total_task = num_task + num_shared_task
-        num_layer = len(list_of_dnn_dims)
-        list_of_num_experts_per_task = cls._extend_int_list(list_of_num_experts_per_task, num_layer)
-        list_of_num_experts_per_task = [cls._extend_int_list(n, num_total_task) for n in list_of_num_experts_per_task]
-        list_of_dnn_dims = [cls._extend_int_list(dim, 1) for dim in list_of_dnn_dims]
-        is_shared_tasks = [True] * num_shared_task
-        task_names = [f'shared_{task_idx}' for task_idx in range(num_task)]       # sic (reference :108)
-        for task_idx in range(num_task):
-            is_shared_tasks.append(False)
-            task_names.append(f'special_{task_idx}')
-        return list_of_dnn_dims, list_of_num_experts_per_task, is_shared_tasks, task_names
+        n_groups, n_layers = num_task + num_shared_task, len(list_of_dnn_dims)
+        per_layer = cls._extend_int_list(list_of_num_experts_per_task, n_layers)
+        experts = [cls._extend_int_list(v, n_groups) for v in per_layer]
+        dims = [cls._extend_int_list(v, 1) for v in list_of_dnn_dims]
+        shared = [g < num_shared_task for g in range(n_groups)]
+        # shared groups are named with range(num_task) in the reference (:108); identical whenever the constructor accepts
+        names = ['shared_%d' % g for g in range(num_task)] + ['special_%d' % g for g in range(num_task)]
+        return dims, experts, shared, names
 
-    def _get_dnn_name(self, layer_name, task_name):
-        return f'{self.name}/ple_layer_{layer_name}/task_{task_name}'
-
-    def _get_gate_name(self, layer_name, task_name):
-        return f'{self.name}/ple_gate_{layer_name}/task_{task_name}'
-
-    def _build_one_dnn(self, dnn_dims, num_experts, layer_name, task_name):
-        name = self._get_dnn_name(layer_name, task_name)
-        layers = []
-        for idx, dim in enumerate(dnn_dims):
-            is_last_layer = idx == len(dnn_dims) - 1
-            activation = None if is_last_layer else self.activation
-            layers.append(MultiDenseLayer(dim, num_experts, activation=activation, name=f'{name}/MultiDenseLayer_{idx}',
-                                          **self._dense_kwargs()))
-        return _ExpertDNN(layers, name)
-
-    def _build_one_gate(self, units, layer_name, task_name):
-        name = self._get_gate_name(layer_name, task_name)
-        return _GateDense(units, f'{name}/dense')
-
-    def _get_experts_num(self, num_experts_per_task):
-        num_total_experts = 0
-        num_shared_experts = 0
-        for is_shared_task, num_experts in zip(self.is_shared_tasks, num_experts_per_task):
-            num_total_experts += num_experts
-            if is_shared_task:
-                num_shared_experts += num_experts
-        return num_total_experts, num_shared_experts
-
-    def _build_one_layer(self, layer_idx, dnn_dims, num_experts_per_task, num_layer):
-        is_last_layer = layer_idx == num_layer - 1
-        layer_dnns = []
-        layer_gates = []
-        num_total_experts, num_shared_experts = self._get_experts_num(num_experts_per_task)
-        task_params = zip(self.is_shared_tasks, self.task_names, num_experts_per_task)
-        for is_shared_task, task_name, num_experts in task_params:
-            layer_dnns.append(self._build_one_dnn(dnn_dims, num_experts, layer_idx, task_name))
-            if is_shared_task and is_last_layer:
-                layer_gates.append(None)
-            else:
-                gate_output_dim = num_experts + num_shared_experts if not is_shared_task else num_total_experts
-                layer_gates.append(self._build_one_gate(gate_output_dim, layer_idx, task_name))
-        return layer_dnns, layer_gates
+    # -- build: modules + wiring plan -------------------------------------------------------------------------------
+    def _expert_stack(self, layer_idx, group_name, widths, n_experts):
+        scope = '%s/ple_layer_%s/task_%s' % (self.name, layer_idx, group_name)
+        stack = [MultiDenseLayer(width, n_experts, activation=self.activation if i + 1 < len(widths) else None,
+                                 name='%s/MultiDenseLayer_%d' % (scope, i), **self._dense_kwargs())
+                 for i, width in enumerate(widths)]
+        return _ExpertDNN(stack, scope)
 
     def build(self, input_shape):
-        num_layer = len(self.list_of_dnn_dims)
-        self.dnns = []
-        self.gates = []
-        layer_params = zip(range(num_layer), self.list_of_dnn_dims, self.list_of_num_experts_per_task)
-        for layer_idx, dnn_dims, num_experts_per_task in layer_params:
-            layer_dnns, layer_gates = self._build_one_layer(layer_idx, dnn_dims, num_experts_per_task, num_layer)
-            self.dnns.append(layer_dnns)
-            self.gates.append(layer_gates)
-        # register for nn.Module bookkeeping (parameters(), .to(), state_dict())
-        self._dnn_modules = nn.ModuleList([m for layer in self.dnns for m in layer])
-        self._gate_modules = nn.ModuleList([m for layer in self.gates for m in layer if m is not None])
+        n_layers = len(self.list_of_dnn_dims)
+        groups = list(zip(self.is_shared_tasks, self.task_names))           # zip truncation == the reference's
+        shared_ids = [g for g, (is_shared, _) in enumerate(groups) if is_shared]
+        self.dnns, self.gates, self._plan = [], [], []
+        for l in range(n_layers):
+            n_exp = self.list_of_num_experts_per_task[l]
+            n_all = sum(n for n, _ in zip(n_exp, groups))
+            n_shared = sum(n_exp[g] for g in shared_ids)
+            stacks, gates, wiring = [], [], []
+            for g, (is_shared, gname) in enumerate(groups):
+                stacks.append(self._expert_stack(l, gname, self.list_of_dnn_dims[l], n_exp[g]))
+                if is_shared and l == n_layers - 1:
+                    gates.append(None)                                        # shared groups feed nobody after the last layer
+                else:
+                    units = n_all if is_shared else n_exp[g] + n_shared
+                    gates.append(_GateDense(units, '%s/ple_gate_%s/task_%s/dense' % (self.name, l, gname)))
+                # what this group reads / mixes: every group (shared) or itself followed by the shared groups (specific)
+                sees = list(range(len(groups))) if is_shared else [g] + shared_ids
+                wiring.append(sees)
+            self.dnns.append(stacks)
+            self.gates.append(gates)
+            self._plan.append(wiring)
+        # nn.Module bookkeeping (parameters(), .to(), state_dict())
+        self._dnn_modules = nn.ModuleList([m for stacks in self.dnns for m in stacks])
+        self._gate_modules = nn.ModuleList([m for gates in self.gates for m in gates if m is not None])
         self.built = True
 
-    def _get_input(self, last_layer_outputs, task_idx, is_shared_task):
-        if is_shared_task:
-            return torch.cat(last_layer_outputs, dim=-1)
-        inputs = [last_layer_outputs[task_idx]]
-        for last_output, shared in zip(last_layer_outputs, self.is_shared_tasks):
-            if shared:
-                inputs.append(last_output)
-        return torch.cat(inputs, dim=-1)
-
-    def _get_gate_input(self, dnn_outputs, task_idx, is_shared_task):
-        """The experts a gate mixes, as a list of (B, dim_out) tensors in the reference's concat order (:238-257):
-        all groups for a shared task; own group then the shared groups for a specific task.  No concat is made."""
-        if is_shared_task:
-            groups = list(dnn_outputs)
-        else:
-            groups = [dnn_outputs[task_idx]]
-            for last_output, shared in zip(dnn_outputs, self.is_shared_tasks):
-                if shared:
-                    groups.append(last_output)
-        experts = []
-        for g in groups:
-            experts.extend(g.unbind(0))
-        return experts
-
-    def _apply_dnns(self, is_first_layer, inputs, outputs, layer_dnns):
-        dnn_outputs = []
-        task_inputs = []
-        dnn_params = zip(range(self.num_total_task), self.is_shared_tasks, layer_dnns)
-        for task_idx, is_shared_task, dnn in dnn_params:
-            last_layer_outputs = None if is_first_layer else outputs[-1]
-            dnn_input = inputs if is_first_layer else self._get_input(last_layer_outputs, task_idx, is_shared_task)
-            task_inputs.append(dnn_input)
-            dnn_outputs.append(dnn(dnn_input))            # (N, B, dim_out)
-        return dnn_outputs, task_inputs
-
-    def _apply_gates(self, is_last_layer, dnn_outputs, task_inputs, layer_gates):
-        gated_outputs = []
-        gate_params = zip(range(self.num_total_task), self.is_shared_tasks, layer_gates)
-        for task_idx, is_shared_task, gate in gate_params:
-            if is_shared_task and is_last_layer:
-                gated_outputs.append(None)
-                continue
-            gate_logits = gate(task_inputs[task_idx])                                   # (B, N)
-            experts = self._get_gate_input(dnn_outputs, task_idx, is_shared_task)       # N x (B, dim_out)
-            gated_outputs.append(moe_mix(gate_logits, experts))                         # (B, dim_out)
-        return gated_outputs
-
+    # -- call ---------------------------------------------------------------------------------------------------------
     def call(self, inputs):
-        """inputs (B, D).  Returns the num_task task outputs (shared tasks excluded), each (B, dim_out)."""
-        num_layer = len(self.list_of_dnn_dims)
-        outputs = []
-        for layer_idx in range(num_layer):
-            is_first_layer = layer_idx == 0
-            is_last_layer = layer_idx == num_layer - 1
-            dnn_outputs, task_inputs = self._apply_dnns(is_first_layer, inputs, outputs, self.dnns[layer_idx])
-            gated_outputs = self._apply_gates(is_last_layer, dnn_outputs, task_inputs, self.gates[layer_idx])
-            outputs.append(gated_outputs)
-        return [output for output in outputs[-1] if output is not None]
+        """inputs (B, D).  Returns the num_task task outputs (shared groups excluded), each (B, dim_out)."""
+        prev = None                                             # gated outputs of the previous PLE layer, one per group
+        for stacks, gates, wiring in zip(self.dnns, self.gates, self._plan):
+            feeds = [inputs if prev is None else torch.cat([prev[s] for s in sees], dim=-1) for sees in wiring]
+            expert_out = [stack(feed) for stack, feed in zip(stacks, feeds)]                  # per group: (N_g, B, dim_out)
+            mixed = []
+            for gate, feed, sees in zip(gates, feeds, wiring):
+                if gate is None:
+                    mixed.append(None)
+                    continue
+                visible = [e for s in sees for e in expert_out[s].unbind(0)]                  # no concat: a list of (B, dim_out)
+                mixed.append(moe_mix(gate(feed), visible))                                    # softmax gate fused in the mix kernel
+            prev = mixed
+        return [out for out in prev if out is not None]
