@@ -18,25 +18,20 @@ class CINLayer(Layer):
         self.embedding_dim = embedding_dim
         self.initializer = initializer
 
-    def _extend_hidden_sizes(self):
-        return [self.num_field] + self.hidden_sizes
-
     def build(self, input_shape):
+        """F and D from the input (a list of F (B, D) shapes, or one (B, F*D) shape with `embedding_dim` given); then one
+        weight per hidden layer k >= 1: `weight_of_layer{k}` of shape [1, 1, H_k, H_{k-1} * F] with H_0 = F."""
         if isinstance(input_shape, list):
-            self.num_field = len(input_shape)
-            self.embedding_dim = int(input_shape[0][-1])
-        else:
-            if self.embedding_dim <= 0:
-                raise ValueError('embedding_dim shall bigger than 0 when inputs is not a list of embeddings.')
+            self.num_field, self.embedding_dim = len(input_shape), int(input_shape[0][-1])
+        elif self.embedding_dim > 0:
             self.num_field = int(int(input_shape[-1]) / self.embedding_dim)
-        extended_hidden_sizes = self._extend_hidden_sizes()
-        self.idx2weight = {}
-        for layer_idx in range(1, len(extended_hidden_sizes)):
-            num_channel = extended_hidden_sizes[layer_idx]
-            num_prev_channel = extended_hidden_sizes[layer_idx - 1]
-            shape = [1, 1, num_channel, num_prev_channel * self.num_field]
-            self.idx2weight[layer_idx] = self.add_weight('weight_of_layer%s' % layer_idx, shape=shape,
-                                                         initializer=self.initializer, dtype=self.dtype, trainable=True)
+        else:
+            raise ValueError('embedding_dim shall bigger than 0 when inputs is not a list of embeddings.')
+        widths = [self.num_field] + self.hidden_sizes
+        self.idx2weight = {
+            k: self.add_weight('weight_of_layer%s' % k, shape=[1, 1, widths[k], widths[k - 1] * self.num_field],
+                               initializer=self.initializer, dtype=self.dtype, trainable=True)
+            for k in range(1, len(widths))}
         self.built = True
 
     def call(self, inputs, output_input=True, sum_channel=True):

@@ -17,25 +17,16 @@ class DCNLayer(DenseBase):
         if self.act_code is None:
             raise NotImplementedError('DCNLayer fuses activations linear/relu/tanh/sigmoid only')
 
-    def _build_kernels(self):
-        self.kernels = [self.add_weight(f'kernel_{layer_idx}', shape=[self.input_dim, 1],
-                                        initializer=self.kernel_initializer, regularizer=self.kernel_regularizer,
-                                        constraint=self.kernel_constraint, dtype=self.dtype, trainable=True)
-                        for layer_idx in range(self.degree_of_cross)]
-
-    def _build_biases(self):
-        self.biases = [self.add_weight(f'bias_{layer_idx}', shape=[1, self.input_dim],
-                                       initializer=self.bias_initializer, regularizer=self.bias_regularizer,
-                                       constraint=self.bias_constraint, dtype=self.dtype, trainable=True)
-                       for layer_idx in range(self.degree_of_cross)]
-
     def build(self, input_shape):
-        self.input_dim = int(input_shape[-1])
-        self._build_kernels()
-        if self.use_bias:
-            self._build_biases()
-        else:
-            self.biases = None
+        """kernel_l (D, 1) and, with use_bias, bias_l (1, D) for l < degree_of_cross (the reference's names and shapes)."""
+        D = self.input_dim = int(input_shape[-1])
+        make = lambda kind, l, shape, init, reg, con: self.add_weight(       # noqa: E731
+            '%s_%d' % (kind, l), shape=shape, initializer=init, regularizer=reg, constraint=con, dtype=self.dtype, trainable=True)
+        L = self.degree_of_cross
+        self.kernels = [make('kernel', l, [D, 1], self.kernel_initializer, self.kernel_regularizer, self.kernel_constraint)
+                        for l in range(L)]
+        self.biases = ([make('bias', l, [1, D], self.bias_initializer, self.bias_regularizer, self.bias_constraint)
+                        for l in range(L)] if self.use_bias else None)
         self.built = True
 
     def call(self, inputs):

@@ -36,28 +36,22 @@ class DCNMixLayer(Layer):
         if cb_i is not None or cb_o is not None:
             raise NotImplementedError('DCNMixLayer fuses activations linear/relu/tanh/sigmoid only')
 
-    def _build_dnn_params(self, dim_in):
-        N, S = self.num_expert, self.dim_sub_space
-        self.origin_to_sub_kernels = [self.add_weight('origin_to_sub_kernels_of_layer%s' % l, shape=[N, dim_in, S],
-                                                      initializer=self.kernel_initializer) for l in range(self.num_layer)]
-        self.sub_to_sub_kernels = [self.add_weight('sub_to_sub_kernels_of_layer%s' % l, shape=[N, S, S],
-                                                   initializer=self.kernel_initializer) for l in range(self.num_layer)]
-        self.sub_to_origin_kernels = [self.add_weight('sub_to_origin_kernels_of_layer%s' % l, shape=[N, S, dim_in],
-                                                      initializer=self.kernel_initializer) for l in range(self.num_layer)]
-        self.biases = [self.add_weight('bias_of_layer%s' % l, shape=[1, N, dim_in], initializer=self.bias_initializer)
-                       for l in range(self.num_layer)]
-
-    def _build_gates(self, input_shape):
-        from torch import nn
-        self.gate_layers = nn.ModuleList([_GateDense(self.num_expert, 'gate_of_layer%s' % l) for l in range(self.num_layer)])
-        for g in self.gate_layers:            # keras creates these kernels at first call; same RNG order (after the dnn params)
-            g._build_device = self._build_device
-            g.build(input_shape)
-
     def build(self, input_shape):
-        dim_in = int(input_shape[-1])
-        self._build_dnn_params(dim_in)
-        self._build_gates(input_shape)
+        """Per layer l: origin_to_sub (N, D, S), sub_to_sub (N, S, S), sub_to_origin (N, S, D) kernels, bias (1, N, D) and the
+        bias-free gate Dense (D, N) -- created family by family, gates last, which is the order Keras draws them in (the
+        reference builds its gate layers lazily at the first call)."""
+        from torch import nn
+        D, N, S, L = int(input_shape[-1]), self.num_expert, self.dim_sub_space, self.num_layer
+        family = lambda stem, shape, init: [self.add_weight('%s_of_layer%s' % (stem, l), shape=shape, initializer=init)   # noqa: E731
+                                            for l in range(L)]
+        self.origin_to_sub_kernels = family('origin_to_sub_kernels', [N, D, S], self.kernel_initializer)
+        self.sub_to_sub_kernels = family('sub_to_sub_kernels', [N, S, S], self.kernel_initializer)
+        self.sub_to_origin_kernels = family('sub_to_origin_kernels', [N, S, D], self.kernel_initializer)
+        self.biases = family('bias', [1, N, D], self.bias_initializer)
+        self.gate_layers = nn.ModuleList([_GateDense(N, 'gate_of_layer%s' % l) for l in range(L)])
+        for gate in self.gate_layers:
+            gate._build_device = self._build_device
+            gate.build(input_shape)
         self.built = True
 
     def call(self, inputs):

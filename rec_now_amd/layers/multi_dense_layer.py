@@ -18,28 +18,21 @@ class MultiDenseLayer(DenseBase):
         super().__init__(units, **kwargs)
         self.num_dnn = int(num_dnn)
 
-    def _build_kernel(self, last_dim):
-        self.kernel = self.add_weight('kernel', shape=[self.num_dnn, last_dim, self.units],          # (N, D, U)
-                                      initializer=self.kernel_initializer, regularizer=self.kernel_regularizer,
-                                      constraint=self.kernel_constraint, dtype=self.dtype, trainable=True)
-
-    def _build_bias(self):
-        if self.use_bias:
-            self.bias = self.add_weight('bias', shape=[self.num_dnn, 1, self.units],                  # (N, 1, U)
-                                        initializer=self.bias_initializer, regularizer=self.bias_regularizer,
-                                        constraint=self.bias_constraint, dtype=self.dtype, trainable=True)
-        else:
-            self.bias = None
-
     def build(self, input_shape):
+        """Creates `kernel` (N, D, U) and, with use_bias, `bias` (N, 1, U) -- the reference's variable names and shapes."""
         if str(self.dtype) not in ('float32', 'torch.float32'):
-            # reference :66-69 accepts any floating dtype; the kernels here are fp32
-            raise TypeError('Unable to build `MultiDenseLayer` layer with non-float32 dtype %s' % (self.dtype,))
-        last_dim = input_shape[-1]
-        if last_dim is None:
+            raise TypeError('Unable to build `MultiDenseLayer` layer with non-float32 dtype %s' % (self.dtype,))   # kernels are fp32
+        width = input_shape[-1]
+        if width is None:
             raise ValueError('The last dimension of the inputs to `Dense` should be defined. Found `None`.')
-        self._build_kernel(int(last_dim))
-        self._build_bias()
+        n, u = self.num_dnn, self.units
+        common = dict(dtype=self.dtype, trainable=True)
+        self.kernel = self.add_weight('kernel', shape=[n, int(width), u], initializer=self.kernel_initializer,
+                                      regularizer=self.kernel_regularizer, constraint=self.kernel_constraint, **common)
+        self.bias = None
+        if self.use_bias:
+            self.bias = self.add_weight('bias', shape=[n, 1, u], initializer=self.bias_initializer,
+                                        regularizer=self.bias_regularizer, constraint=self.bias_constraint, **common)
         self.built = True
 
     def call(self, inputs):
