@@ -6,6 +6,7 @@
 //   focal_crossentropy_loss    /root/reference/rec_now/rec_block/focal_loss.py:12-66
 // Same conventions as fm.hip: `fields` is a DEVICE array of F device pointers to contiguous (B, D_f) fp32 tensors (the
 // reference's list-of-tensors input), no float atomics, every reduction in a fixed order.
+#include <stdlib.h>
 #include "common.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -102,6 +103,243 @@ k_ipnn_bwd(const float* const* __restrict__ fields, float* const* __restrict__ d
     }
 }
 
+// Forward on the matrix cores: the pair products of one row b are the strict upper triangle of the Gram matrix
+// G = X X^T of its F x D field matrix (F <= 64, D in {4, 8, 12, 16}; one row b per wave per step).
+//  * loads: D/4 consecutive lanes read the D/4 float4 pieces of one field's row, so each field row is one coalesced
+//    request (one lane per field row -- 64 scattered 16-byte pieces per instruction -- ran the loads at 1.35 TB/s); the
+//    next row's pieces are requested before this row is consumed;
+//  * the tile goes through LDS once to reach the MFMA operand image.  With v_mfma_f32_32x32x2_f32 (exact fp32) lane l
+//    supplies row l%32, k-slot l/32; the contraction order is free as long as A and B agree, so k-slot h of step kk is
+//    element h*D/2 + kk: lane (j, h) reads the contiguous half row [h*D/2, (h+1)*D/2) of field 32*I + j, and the A image of
+//    row block I IS the B image of column block I -- 2 * D/2 VGPRs feed the three needed tiles (0,0), (0,1), (1,1);
+//  * C map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  The row's P results are contiguous in
+//    `out`; they are collected in LDS (over the dead input tile) and written as whole 16-byte pieces -- ragged per-pair-row
+//    dword stores made the L2 fetch the output lines (0.66 ms instead of 0.60 with everything else equal).
+typedef float ipnn_acc16 __attribute__((ext_vector_type(16)));
+typedef float ipnn_acc4 __attribute__((ext_vector_type(4)));
+// LDS hand-over inside ONE wave (the tiles are wave-private): outstanding LDS operations retired, no vmcnt drain
+#define IPNN_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+template <int D>
+__global__ void __launch_bounds__(256)
+k_ipnn_fwd_gram(const float* const* __restrict__ fields, int F, int64_t B, int64_t wstride, float* __restrict__ out) {
+    constexpr int CPF = D / 4;                                    // float4 pieces per field row
+    constexpr int NLD = (64 * CPF + 63) / 64;                     // load instructions per row of b (F <= 64)
+    constexpr int XS = D == 16 ? 20 : D == 8 ? 12 : D;            // LDS row stride of the input tile: half-row reads spread over the banks
+    constexpr int HD = D / 2;
+    extern __shared__ __attribute__((aligned(16))) float ipnn_lds[];
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int64_t P = (int64_t)F * (F - 1) / 2;
+    float* tile = ipnn_lds + (threadIdx.x >> 6) * wstride;        // this wave's input tile, then its P results
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const bool two = F > 32;
+    // which piece of which field this lane fetches in load step t (same for every row b)
+    const float* src[NLD];
+    int dst[NLD];
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) {
+        const int idx = t * 64 + lane, f = idx / CPF, c = idx - f * CPF;
+        src[t] = f < F ? fields[f] + 4 * c : nullptr;
+        dst[t] = f * XS + 4 * c;
+    }
+    ipnn_acc4 nx[NLD];                       // native vectors: arrays of HIP's float4 struct are copied with memcpy and stay in scratch
+    int64_t bb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bb < B) {
+#pragma unroll
+        for (int t = 0; t < NLD; ++t)
+            if (src[t]) nx[t] = *reinterpret_cast<const ipnn_acc4*>(src[t] + bb * D);
+    }
+    for (; bb < B; bb += nw) {
+        const int64_t b = __builtin_amdgcn_readfirstlane((int)bb);          // row of this wave, uniform for the compiler too (B < 2^31)
+#pragma unroll
+        for (int t = 0; t < NLD; ++t)
+            if (src[t]) *reinterpret_cast<ipnn_acc4*>(tile + dst[t]) = nx[t];
+        if (bb + nw < B) {
+#pragma unroll
+            for (int t = 0; t < NLD; ++t)
+                if (src[t]) nx[t] = *reinterpret_cast<const ipnn_acc4*>(src[t] + (bb + nw) * D);
+        }
+        IPNN_WAVE_SYNC();                                                   // the tile is private to this wave
+        float a0[HD], a1[HD];
+#pragma unroll
+        for (int k = 0; k < HD; k += 2) {
+            const float2 u = *reinterpret_cast<const float2*>(tile + j * XS + h * HD + k);
+            a0[k] = u.x; a0[k + 1] = u.y;
+            const float2 w = *reinterpret_cast<const float2*>(tile + (32 + j) * XS + h * HD + k);      // garbage rows (f >= F) only reach pairs that are never stored
+            a1[k] = w.x; a1[k + 1] = w.y;
+        }
+        IPNN_WAVE_SYNC();                                                   // operands are in registers: the tile may be overwritten
+        ipnn_acc16 g00, g01, g11;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { g00[v] = 0.f; g01[v] = 0.f; g11[v] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < HD; ++kk) g00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], a0[kk], g00, 0, 0, 0);
+        if (two) {
+#pragma unroll
+            for (int kk = 0; kk < HD; ++kk) {
+                g01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], a1[kk], g01, 0, 0, 0);
+                g11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], a1[kk], g11, 0, 0, 0);
+            }
+        }
+        int jo = j, ho = h;                          // opaque per row: keeps the 48 result offsets from being hoisted into
+        asm volatile("" : "+v"(jo), "+v"(ho));        // ~80 live VGPRs (occupancy); they cost a few VALU each to recompute
+        // pair (r, c), r < c < F, lives at r*F - r*(r+1)/2 + (c - r - 1)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = (v & 3) + 8 * (v >> 2) + 4 * ho;
+            const int base = r * F - r * (r + 1) / 2 - r - 1;
+            if (j > r && j < F) tile[base + jo] = g00[v];
+            if (two && 32 + j < F) tile[base + 32 + jo] = g01[v];
+        }
+        if (two) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int base = r * F - r * (r + 1) / 2 - r - 1;
+                if (32 + j > r && 32 + j < F) tile[base + 32 + jo] = g11[v];
+            }
+        }
+        IPNN_WAVE_SYNC();
+        float* og = out + b * P;
+        if (((P & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+            for (int64_t i = lane * 4; i < P; i += 256) *reinterpret_cast<float4*>(og + i) = *reinterpret_cast<const float4*>(tile + i);
+        } else {
+            for (int64_t i = lane; i < P; i += 64) og[i] = tile[i];
+        }
+        IPNN_WAVE_SYNC();                                                   // results read back before the next tile lands
+    }
+}
+
+// Backward on the matrix cores: dX = (U + U^T) X for the row's F x D field matrix X, U the strict upper triangle
+// holding the row's P incoming gradients.  v_mfma_f32_16x16x4_f32: A[i][k] from lane (i = l%16, k = l/16), B[k][d] from
+// lane (d = l%16, k = l/16), C rows 4*(l/16) + reg, col l%16 -- D <= 16 is the N dimension, no wasted half tile.
+//  * the P gradients stay in their packed order in LDS: U[r][c] = lin[T(r) + c] with T(r) = r*F - r*(r+1)/2 - r - 1.
+//    Term U X reads A = U[16I+i][4kk+k'] (per-lane T(16I+i), the k step is an immediate); term U^T X reads
+//    A = U[4kk+k'][16I+i] (T(4kk+k') recomputed per k step).  Blocks entirely below the diagonal are skipped at compile
+//    time (kk < 4I for U, kk > 4I+3 for U^T): 80 MFMAs of 16x16x4 per row at F = 64; the rest is masked by c > r, c < F.
+//  * X goes through LDS as in the forward (coalesced float4 pieces, row stride 16); rows >= F of the tile are zeroed
+//    once and never written, so k slots past F contribute exact zeros;
+//  * dX leaves through the dead X tile, so every field row is again one coalesced 16*D/4-byte store.
+// Both inputs of the next row are requested before this row is consumed.  F <= 64, D in {4, 8, 12, 16}.
+// both inputs of row `row` of the backward kernel below -> registers
+template <int D>
+__device__ __forceinline__ void ipnn_bwd_request(const float* const (&src)[D / 4], ipnn_acc4 (&nx)[D / 4], ipnn_acc4 (&nd)[8], const float* dout,
+                                                 int64_t row, int64_t P, int lane, int vec) {
+#pragma unroll
+    for (int t = 0; t < D / 4; ++t)
+        if (src[t]) nx[t] = *reinterpret_cast<const ipnn_acc4*>(src[t] + row * D);
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q * 256 + lane * 4 < P) nd[q] = *reinterpret_cast<const ipnn_acc4*>(dout + row * P + q * 256 + lane * 4);
+    }
+}
+// "these values exist now": keeps the LDS reads of one k step ahead of their masks (see the kernel)
+template <int NB>
+__device__ __forceinline__ void ipnn_keep(float (&u)[NB], float (&l)[NB]) {
+    if constexpr (NB == 1) asm volatile("" : "+v"(u[0]), "+v"(l[0]));
+    else if constexpr (NB == 2) asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(l[0]), "+v"(l[1]));
+    else if constexpr (NB == 3) asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]));
+    else asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]));
+}
+template <int D, int NB>                          // NB = ceil(F / 16): 16-row blocks of dX, and 4*NB k steps
+__global__ void __launch_bounds__(256)
+k_ipnn_bwd_gram(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int64_t B, int64_t wstride,
+                const float* __restrict__ dout, int vec) {
+    constexpr int CPF = D / 4;                                    // float4 pieces per field row = load steps per row of b
+    constexpr int NQ = 8;                                         // float4 pieces of the packed gradients per lane (P <= 2016)
+    extern __shared__ __attribute__((aligned(16))) float ipnn_lds[];
+    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    const int64_t P = (int64_t)F * (F - 1) / 2;
+    float* xt = ipnn_lds + (threadIdx.x >> 6) * wstride;          // [64][16] X tile, later dX
+    float* lin = xt + 64 * 16;                                    // packed gradients of the row
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int i = lane; i < 64 * 16; i += 64) xt[i] = 0.f;
+    const float* src[CPF];
+    float* dsrc[CPF];
+    int dst[CPF];
+#pragma unroll
+    for (int t = 0; t < CPF; ++t) {
+        const int idx = t * 64 + lane, f = idx / CPF, c = idx - f * CPF;
+        src[t] = f < F ? fields[f] + 4 * c : nullptr;
+        dsrc[t] = f < F ? dfields[f] + 4 * c : nullptr;
+        dst[t] = f * 16 + 4 * c;
+    }
+    ipnn_acc4 nx[CPF], nd[NQ];             // native vectors: arrays of HIP's float4 struct are copied with memcpy and stay in scratch
+    int64_t bb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bb < B) ipnn_bwd_request<D>(src, nx, nd, dout, bb, P, lane, vec);
+    // T(r) of this lane's rows, clamped to a valid row so that masked-out reads stay inside the wave's LDS
+    int t1[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const int r = min(16 * I + i16, F - 1);
+        t1[I] = r * F - r * (r + 1) / 2 - r - 1;
+    }
+    for (; bb < B; bb += nw) {
+        const int64_t b = __builtin_amdgcn_readfirstlane((int)bb);          // row of this wave, uniform for the compiler too (B < 2^31)
+#pragma unroll
+        for (int t = 0; t < CPF; ++t)
+            if (src[t]) *reinterpret_cast<ipnn_acc4*>(xt + dst[t]) = nx[t];
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q * 256 + lane * 4 < P) *reinterpret_cast<ipnn_acc4*>(lin + q * 256 + lane * 4) = nd[q];
+        } else {
+            for (int64_t i = lane; i < P; i += 64) lin[i] = dout[b * P + i];
+        }
+        if (bb + nw < B) ipnn_bwd_request<D>(src, nx, nd, dout, bb + nw, P, lane, vec);
+        IPNN_WAVE_SYNC();
+        float bx[4 * NB];
+#pragma unroll
+        for (int kk = 0; kk < 4 * NB; ++kk) bx[kk] = xt[(4 * kk + kq) * 16 + i16];
+        ipnn_acc4 acc[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) acc[I] = ipnn_acc4{0.f, 0.f, 0.f, 0.f};
+        int io = i16, ko = kq;                       // opaque per row: the masks and offsets below are row-invariant, and hoisting
+        asm volatile("" : "+v"(io), "+v"(ko));        // ~160 of them out of the row loop spills SGPRs and VGPRs
+#pragma unroll
+        for (int kk = 0; kk < 4 * NB; ++kk) {                               // k slots >= F: zero X rows, masked A
+            const int ck = 4 * kk + ko;                                     // this lane's k slot: a column of U, a row of U^T
+            const int rk = min(ck, F - 1);
+            const int t2 = rk * F - rk * (rk + 1) / 2 - rk - 1;
+            // all A values of the k step first, unconditionally (the addresses are clamped into the wave's LDS), then one
+            // opaque statement: left alone, the compiler sinks every read under its mask -- a branch, a wait and an
+            // accumulator shuffle per MFMA
+            float au[NB], al[NB];
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+                au[I] = kk >= 4 * I ? lin[t1[I] + ck] : 0.f;                // U X:   A[i][k] = U[16I+i][ck], blocks on/above the diagonal
+                al[I] = kk <= 4 * I + 3 ? lin[t2 + 16 * I + io] : 0.f;      // U^T X: A[i][k] = U[ck][16I+i], blocks on/below it
+            }
+            ipnn_keep<NB>(au, al);
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+                const int ri = 16 * I + io;
+                if (kk >= 4 * I) {
+                    const float a = (ck > ri && ck < F) ? au[I] : 0.f;
+                    acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[kk], acc[I], 0, 0, 0);
+                }
+                if (kk <= 4 * I + 3) {
+                    const float a = (ri > ck && ri < F) ? al[I] : 0.f;
+                    acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[kk], acc[I], 0, 0, 0);
+                }
+            }
+        }
+        IPNN_WAVE_SYNC();                                                   // every lane has its B operands: the X tile is dead
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int f = 16 * I + 4 * kq + v;
+                if (f < F) xt[f * 16 + i16] = acc[I][v];                    // rows >= F stay zero for the next row's k slots
+            }
+        IPNN_WAVE_SYNC();
+#pragma unroll
+        for (int t = 0; t < CPF; ++t)
+            if (dsrc[t]) *reinterpret_cast<ipnn_acc4*>(dsrc[t] + b * D) = *reinterpret_cast<const ipnn_acc4*>(xt + dst[t]);
+        IPNN_WAVE_SYNC();                                                   // dX read back before the next X tile lands
+    }
+}
+
 static int ipnn_cfg(int F, int D, bool bwd, int* waves, size_t* lds) {
     const int dmax = D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64;
     const size_t per_wave = ((size_t)F * dmax + (bwd ? (size_t)F * (F - 1) / 2 : (size_t)F * (D + 1))) * sizeof(float);
@@ -120,11 +358,26 @@ extern "C" int recnow_inner_pnn_fwd(const float* const* fields, int F, int64_t B
     if (D > 64) return RECNOW_EUNSUPPORTED;
     int waves;
     size_t lds;
+    hipStream_t st = (hipStream_t)stream;
+    if (F <= 64 && (D == 4 || D == 8 || D == 12 || D == 16) && B <= 0x7fffffffll) {
+        int64_t gs = (B + 3) / 4;
+        if (gs > 16384) gs = 16384;
+        // per wave: the input tile (64 rows, padded stride <= 20 floats), later overwritten by the row's P results
+        const int64_t P = (int64_t)F * (F - 1) / 2;
+        int64_t wstride = 64 * 20;
+        if (((P + 3) & ~3ll) > wstride) wstride = (P + 3) & ~3ll;
+        const size_t slds = 4 * (size_t)wstride * sizeof(float);
+        if (D == 16) hipLaunchKernelGGL(k_ipnn_fwd_gram<16>, (int)gs, 256, slds, st, fields, F, B, wstride, out);
+        else if (D == 12) hipLaunchKernelGGL(k_ipnn_fwd_gram<12>, (int)gs, 256, slds, st, fields, F, B, wstride, out);
+        else if (D == 8) hipLaunchKernelGGL(k_ipnn_fwd_gram<8>, (int)gs, 256, slds, st, fields, F, B, wstride, out);
+        else hipLaunchKernelGGL(k_ipnn_fwd_gram<4>, (int)gs, 256, slds, st, fields, F, B, wstride, out);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
     int rc = ipnn_cfg(F, D, false, &waves, &lds);
     if (rc) return rc;
     int64_t g = (B + waves - 1) / waves;
     if (g > 4096) g = 4096;
-    hipStream_t st = (hipStream_t)stream;
     if (D <= 8) hipLaunchKernelGGL(k_ipnn_fwd<8>, (int)g, waves * 64, lds, st, fields, F, B, D, out);
     else if (D <= 16) hipLaunchKernelGGL(k_ipnn_fwd<16>, (int)g, waves * 64, lds, st, fields, F, B, D, out);
     else if (D <= 32) hipLaunchKernelGGL(k_ipnn_fwd<32>, (int)g, waves * 64, lds, st, fields, F, B, D, out);
@@ -141,11 +394,36 @@ extern "C" int recnow_inner_pnn_bwd(const float* const* fields, float* const* df
     if (D > 64) return RECNOW_EUNSUPPORTED;
     int waves;
     size_t lds;
+    hipStream_t st = (hipStream_t)stream;
+    if (F >= 2 && F <= 64 && (D == 4 || D == 8 || D == 12 || D == 16) && B <= 0x7fffffffll) {
+        int64_t gs = (B + 3) / 4;
+        if (gs > 16384) gs = 16384;
+        const int64_t P = (int64_t)F * (F - 1) / 2;
+        // per wave: the [64][16] X tile, then the packed gradients (+64: masked-out reads of the last rows stay inside)
+        const int64_t wstride = 64 * 16 + ((P + 64 + 3) & ~3ll);
+        const size_t slds = 4 * (size_t)wstride * sizeof(float);
+        const int vec = (P & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0;       // rows of dout are float4-addressable
+#define IPNN_BWD_LAUNCH(DD, NBB) hipLaunchKernelGGL((k_ipnn_bwd_gram<DD, NBB>), (int)gs, 256, slds, st, fields, dfields, F, B, wstride, dout, vec)
+#define IPNN_BWD_LAUNCH_D(DD)                                                                                            \
+    do {                                                                                                                 \
+        if (F <= 16) IPNN_BWD_LAUNCH(DD, 1);                                                                             \
+        else if (F <= 32) IPNN_BWD_LAUNCH(DD, 2);                                                                        \
+        else if (F <= 48) IPNN_BWD_LAUNCH(DD, 3);                                                                        \
+        else IPNN_BWD_LAUNCH(DD, 4);                                                                                     \
+    } while (0)
+        if (D == 16) IPNN_BWD_LAUNCH_D(16);
+        else if (D == 12) IPNN_BWD_LAUNCH_D(12);
+        else if (D == 8) IPNN_BWD_LAUNCH_D(8);
+        else IPNN_BWD_LAUNCH_D(4);
+#undef IPNN_BWD_LAUNCH_D
+#undef IPNN_BWD_LAUNCH
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
     int rc = ipnn_cfg(F, D, true, &waves, &lds);
     if (rc) return rc;
     int64_t g = (B + waves - 1) / waves;
     if (g > 4096) g = 4096;
-    hipStream_t st = (hipStream_t)stream;
     if (D <= 8) hipLaunchKernelGGL(k_ipnn_bwd<8>, (int)g, waves * 64, lds, st, fields, dfields, F, B, D, dout);
     else if (D <= 16) hipLaunchKernelGGL(k_ipnn_bwd<16>, (int)g, waves * 64, lds, st, fields, dfields, F, B, D, dout);
     else if (D <= 32) hipLaunchKernelGGL(k_ipnn_bwd<32>, (int)g, waves * 64, lds, st, fields, dfields, F, B, D, dout);

@@ -33,7 +33,11 @@ def test_inner_pnn_reference_golden(dev, golden):
     assert calc_sum_of_abs_diff(result, g['golden']) < 1e-5
 
 
-@pytest.mark.parametrize('B,F,D', [(1, 2, 1), (5, 3, 2), (300, 64, 16), (129, 70, 8), (64, 130, 4), (33, 7, 64), (10, 1, 4)])
+@pytest.mark.parametrize('B,F,D', [(1, 2, 1), (5, 3, 2), (300, 64, 16), (129, 70, 8), (64, 130, 4), (33, 7, 64), (10, 1, 4),
+                                   # the Gram (MFMA) forward: one / two row blocks, every D it takes, ragged F, and more rows than
+                                   # waves in the grid (the prefetching row loop)
+                                   (257, 33, 12), (131, 40, 8), (100, 32, 4), (50, 17, 16), (77, 63, 12), (3, 2, 4),
+                                   (70001, 8, 4), (66000, 34, 8)])
 def test_inner_pnn_fwd_bwd_vs_oracle(dev, B, F, D):
     from rec_now_amd.layers.inner_pnn_layer import InnerPNNLayer
     rng = np.random.default_rng(B + 3 * F + D)
