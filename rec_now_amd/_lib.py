@@ -168,6 +168,23 @@ def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+_SMALL_CONST = {}
+
+
+def const_array(values, dtype, device):
+    """Small read-only device array holding `values`, uploaded once per distinct content: the tables of the list-of-tensor
+    kernels (base pointers, field widths, column offsets) repeat from step to step -- the caching allocator hands the same
+    blocks back -- and every fresh upload is a host-blocking copy of a few hundred bytes."""
+    key = (str(device), dtype, tuple(values))
+    hit = _SMALL_CONST.get(key)
+    if hit is None:
+        if len(_SMALL_CONST) >= 1024:
+            _SMALL_CONST.clear()
+        hit = torch.tensor(key[2], dtype=dtype).to(device)
+        _SMALL_CONST[key] = hit
+    return hit
+
+
 def ptr_array(tensors, device):
     """Device array of base pointers (int64) for list-of-tensor kernels."""
-    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(device, non_blocking=True)
+    return const_array([t.data_ptr() for t in tensors], torch.int64, device)

@@ -234,22 +234,41 @@ static inline int cs_rows(int64_t M, int64_t N) {
     while (r > CS_MIN_ROWS && ((M + r - 1) / r) * colblk < 512) r /= 2;
     return (int)r;
 }
+__device__ __forceinline__ float cs_term(const float* __restrict__ X, const float* __restrict__ X2, int mode, int act, int64_t i) {
+    float v = X[i];
+    if (mode == RECNOW_OPMODE_MUL) v *= X2[i];
+    else if (mode == RECNOW_OPMODE_ACTGRAD) v *= rn_act_grad_from_out(X2[i], act);
+    return v;
+}
 __global__ void __launch_bounds__(256)
 k_colsum_partial(const float* __restrict__ X, const float* __restrict__ X2, int mode, int act, int64_t M, int64_t N, int64_t ld,
-                 float* __restrict__ part, int rows) {
-    // block (bx, by): columns bx*256 + tid, rows by*rows ..
-    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (col >= N) return;
+                 float* __restrict__ part, int rows, int cw) {
+    // block (bx, by): columns bx*cw + (tid % cw), rows by*rows .. ; the 256/cw row lanes of a column take rows rl apart
+    // (cw = 64 or 128 for matrices narrower than 256 columns: all 256 threads load), four loads in flight each, and are
+    // summed in a fixed order through LDS
+    __shared__ float red[256];
+    const int c = threadIdx.x % cw, rlane = threadIdx.x / cw, rl = 256 / cw;
+    const int64_t col = (int64_t)blockIdx.x * cw + c;
     const int64_t r0 = (int64_t)blockIdx.y * rows;
     const int64_t r1 = min(M, r0 + rows);
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-        float v = X[r * ld + col];
-        if (mode == RECNOW_OPMODE_MUL) v *= X2[r * ld + col];
-        else if (mode == RECNOW_OPMODE_ACTGRAD) v *= rn_act_grad_from_out(X2[r * ld + col], act);
-        s += v;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < N) {
+        int64_t r = r0 + rlane;
+        for (; r + 3 * rl < r1; r += 4 * rl) {
+            s0 += cs_term(X, X2, mode, act, r * ld + col);
+            s1 += cs_term(X, X2, mode, act, (r + rl) * ld + col);
+            s2 += cs_term(X, X2, mode, act, (r + 2 * rl) * ld + col);
+            s3 += cs_term(X, X2, mode, act, (r + 3 * rl) * ld + col);
+        }
+        for (; r < r1; r += rl) s0 += cs_term(X, X2, mode, act, r * ld + col);
     }
-    part[(int64_t)blockIdx.y * N + col] = s;
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rlane == 0 && col < N) {
+        float t = red[c];
+        for (int u = 1; u < rl; ++u) t += red[u * cw + c];
+        part[(int64_t)blockIdx.y * N + col] = t;
+    }
 }
 // out[col] = sum over slabs, fixed order: 64 columns x 16 strided slab groups per workgroup, then a 16-term LDS sum (a
 // column-per-thread loop over hundreds of slabs is a chain of dependent-latency loads: 84 us for 512 slabs, measured)
@@ -325,8 +344,9 @@ int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int
         dim3 gn((unsigned)N, nslab);
         hipLaunchKernelGGL(k_colsum_narrow, gn, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws);
     } else {
-        dim3 g1(rn_cdiv(N, 256), nslab);
-        hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws, rows);
+        const int cw = N <= 64 ? 64 : N <= 128 ? 128 : 256;
+        dim3 g1(rn_cdiv(N, cw), nslab);
+        hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws, rows, cw);
     }
     hipLaunchKernelGGL(k_colsum_final, rn_cdiv(N, 64), 1024, 0, st, (const float*)ws, nslab, N, out, accumulate);
     RN_LAUNCH_CHECK();

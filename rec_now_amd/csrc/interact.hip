@@ -505,46 +505,53 @@ k_senet_tile(const float* const* __restrict__ fields, float* const* __restrict__
         }
     }
 }
-// Fast path for the usual case of equal field widths D with D % 4 == 0 and D/4 a power of two: thread = (row b, float4 q of
-// the concatenated row).  Every access is a float4; the concatenated tensors are touched fully coalesced, the field tensors
-// in 4*D-byte runs; nothing is staged and all loads of a thread are independent.  (row, field) sums reduce over the D/4
-// adjacent lanes of the field with shuffles (groups are lane-aligned because total/4 is a multiple of D/4).
+// Fast path for the usual case of equal field widths D with D % 4 == 0 and D/4 a power of two: thread = (group of
+// SENET_RU consecutive rows, float4 q of the concatenated row).  Every access is a float4; the concatenated tensors are
+// touched in whole-row runs, and the SENET_RU rows of a field -- SENET_RU*4*D contiguous bytes of its tensor -- are read
+// (written) by the same wave, so field lines are not split between workgroups on different XCDs (one row per thread left
+// every 128-byte field line half-used by two L2s).  Nothing is staged and the SENET_RU loads of a thread are independent.
+// (row, field) sums reduce over the D/4 adjacent lanes of the field with shuffles (groups are lane-aligned because total/4
+// is a multiple of D/4).
+#define SENET_RU 4
+typedef float senet_f4 __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_senet_uniform(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int D, int64_t B,
                 const float* __restrict__ w, const float* __restrict__ in, const float* __restrict__ dsq, float* __restrict__ out) {
     const int Q = D / 4, QT = F * Q;                 // float4s per field row / per concatenated row
-    const int64_t n = B * QT;
+    const int64_t n = (B + SENET_RU - 1) / SENET_RU * QT;       // (row group, q) items
     const int64_t nround = (n + 255) / 256 * 256;    // whole waves stay in the loop: the shuffles need every lane
+    const int64_t FD = (int64_t)F * D;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (int64_t)gridDim.x * 256) {
         const bool ok = i < n;
-        const int64_t b = ok ? i / QT : 0;
-        const int q = ok ? (int)(i - b * QT) : 0;
+        const int64_t grp = ok ? i / QT : 0;
+        const int q = ok ? (int)(i - grp * QT) : 0;
         const int f = q / Q, d = (q - f * Q) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE != SENET_MODE_DX && ok) v = *reinterpret_cast<const float4*>(fields[f] + b * D + d);
-        if (MODE == SENET_MODE_SCALE) {
-            if (ok) {
-                const float wf = w[b * F + f];
-                *reinterpret_cast<float4*>(out + b * (int64_t)(F * D) + q * 4) = make_float4(v.x * wf, v.y * wf, v.z * wf, v.w * wf);
-            }
-        } else if (MODE == SENET_MODE_DX) {
-            if (ok) {
-                const float4 g = *reinterpret_cast<const float4*>(in + b * (int64_t)(F * D) + q * 4);
-                const float wf = w[b * F + f], qq = dsq[b * F + f] / (float)D;
-                *reinterpret_cast<float4*>(dfields[f] + b * D + d) = make_float4(g.x * wf + qq, g.y * wf + qq, g.z * wf + qq, g.w * wf + qq);
-            }
-        } else {
-            float s;
-            if (MODE == SENET_MODE_DW) {
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) g = *reinterpret_cast<const float4*>(in + b * (int64_t)(F * D) + q * 4);
-                s = (v.x * g.x + v.y * g.y) + (v.z * g.z + v.w * g.w);
+        const int64_t b0 = grp * SENET_RU;
+        const float* xf = fields[f] + d;
+        senet_f4 v[SENET_RU], g[SENET_RU];
+        bool live[SENET_RU];
+#pragma unroll
+        for (int j = 0; j < SENET_RU; ++j) {
+            live[j] = ok && b0 + j < B;
+            v[j] = senet_f4{0.f, 0.f, 0.f, 0.f};
+            g[j] = v[j];
+            if (MODE != SENET_MODE_DX && live[j]) v[j] = *reinterpret_cast<const senet_f4*>(xf + (b0 + j) * D);
+            if ((MODE == SENET_MODE_DX || MODE == SENET_MODE_DW) && live[j]) g[j] = *reinterpret_cast<const senet_f4*>(in + (b0 + j) * FD + q * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < SENET_RU; ++j) {
+            const int64_t b = b0 + j;
+            if (MODE == SENET_MODE_SCALE) {
+                if (live[j]) *reinterpret_cast<senet_f4*>(out + b * FD + q * 4) = v[j] * w[b * F + f];
+            } else if (MODE == SENET_MODE_DX) {
+                if (live[j]) *reinterpret_cast<senet_f4*>(dfields[f] + b * D + d) = g[j] * w[b * F + f] + dsq[b * F + f] / (float)D;
             } else {
-                s = (v.x + v.y) + (v.z + v.w);
+                float s = MODE == SENET_MODE_DW ? (v[j].x * g[j].x + v[j].y * g[j].y) + (v[j].z * g[j].z + v[j].w * g[j].w)
+                                                : (v[j].x + v[j].y) + (v[j].z + v[j].w);
+                for (int o = Q / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (live[j] && d == 0) out[b * F + f] = MODE == SENET_MODE_SQUEEZE ? s / (float)D : s;
             }
-            for (int o = Q / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (ok && d == 0) out[b * F + f] = MODE == SENET_MODE_SQUEEZE ? s / (float)D : s;
         }
     }
 }
@@ -557,7 +564,7 @@ static inline int senet_uniform_ok(int D, int F, int total) {
 static int senet_launch(int mode, const float* const* fields, float* const* dfields, const int32_t* dims, const int32_t* offs, int F,
                         int total, int64_t B, const float* w, const float* in, const float* dsq, float* out, int uniform_d, hipStream_t st) {
     if (uniform_d > 0) {
-        const int64_t n = B * (total / 4);
+        const int64_t n = (B + SENET_RU - 1) / SENET_RU * (total / 4);       // (row group, float4 of the concatenated row) items
         int64_t g = (n + 255) / 256;
         if (g > 16384) g = 16384;
         const int D = uniform_d;

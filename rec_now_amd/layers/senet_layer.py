@@ -19,8 +19,8 @@ class _Holder:
             offs.append(offs[-1] + d)
         self.total = sum(dims)
         self.dims_list = dims
-        self.dims = torch.tensor(dims, dtype=torch.int32, device=dev)
-        self.offs = torch.tensor(offs, dtype=torch.int32, device=dev)
+        self.dims = _lib.const_array(dims, torch.int32, dev)
+        self.offs = _lib.const_array(offs, torch.int32, dev)
         self.ptrs = _lib.ptr_array(xs, dev)
         # equal widths and 16-byte aligned rows: the float4 kernels (torch allocations are 256-byte aligned; views may not be)
         same = len(set(dims)) == 1 and dims[0] % 4 == 0 and all(x.data_ptr() % 16 == 0 for x in xs)

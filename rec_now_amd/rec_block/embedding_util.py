@@ -33,7 +33,7 @@ def _slot_targets(slots, target_slots, ids, want_key):
     if slots.dim() != 2:
         raise ValueError('slots must be a (B, C) matrix')
     dev = slots.device
-    targets = torch.tensor(target_slots, dtype=tdt, device=dev)
+    targets = _lib.const_array(target_slots, tdt, dev)
     seg = torch.empty(slots.shape, dtype=torch.int32, device=dev)
     key = torch.empty(slots.shape, dtype=torch.int64, device=dev) if want_key else None
     _lib.call('recnow_slot_targets', _lib.ptr(slots), sdt, _lib.ptr(targets), len(target_slots), _lib.ptr(ids) if want_key else None,
