@@ -156,50 +156,93 @@ extern "C" int recnow_embed_unique(const int64_t* key, const int32_t* order, con
 
 // drows[s][:] = sum over the entries e of sorted segment s of  w_e * dout[b_e][t_e][:] (/ cnt[b_e][t_e] for 'mean').
 // Ids are heavy-tailed (one hot id can own a third of the batch), so the work is split by ENTRIES, not by ids:
-//   pass 1: one wave per chunk of EMB_CH consecutive sorted entries walks them in order and closes a run whenever the id
-//           changes.  A run that is a whole segment goes straight to drows[s]; the (at most two) runs cut by the chunk
-//           boundary go to part[chunk][0] (run touching the chunk start) / part[chunk][1] (run touching the chunk end).
-//   pass 2: one workgroup per segment that crosses a chunk boundary adds its pieces in ascending chunk order: four waves
-//           take the four quarters of the chunk range, the quarters are combined in wave order.  Fixed order => deterministic.
-#define EMB_CH 128
+//   pass 1: a group of LPE lanes (LPE = pow2 >= D, 16..64; 64/LPE groups per wave) walks one chunk of EMB_CH consecutive
+//           sorted entries in order and closes a run whenever the id changes.  A run that is a whole segment goes
+//           straight to drows[s]; the (at most two) runs cut by the chunk boundary go to part[chunk][0] (run touching the
+//           chunk start) / part[chunk][1] (run touching the chunk end).  Everything about an entry except its gradient
+//           row is known before the walk -- a run starts at max(chunk start, segment start), so "whole segment" and the
+//           slot follow from seg_first alone -- and is fetched by the group's lanes in parallel, one or two entries per
+//           lane, then handed around with shuffles; the walk itself only gathers dout rows, four in flight.  (Walking
+//           with the whole wave and fetching order -> seg -> cnt -> dout per entry was a chain of four dependent
+//           latencies per entry with a quarter of the lanes active at D = 16: 1.2 ms for 6.5 M entries.)
+//   pass 2: one workgroup per segment that crosses a chunk boundary adds its pieces: 256/DL piece lanes x DL dims, four
+//           loads in flight each, combined through LDS in lane order.  Fixed order => deterministic.
+#define EMB_CH 32
+#define EMB_JU 16
+#define EMB_JSHORT 16      // segments spread over fewer chunks than this are joined by one lane group
+template <int LPE>
 __global__ void __launch_bounds__(256)
 k_embed_rows_chunks(const int64_t* __restrict__ key, const int32_t* __restrict__ order, const int32_t* __restrict__ seg_id,
                     const int32_t* __restrict__ seg_first, const int32_t* __restrict__ seg, const float* __restrict__ weights,
                     const float* __restrict__ cnt, const float* __restrict__ dout, int64_t N, int C, int T, int D, int mean,
                     float* __restrict__ drows, float* __restrict__ part, int64_t* __restrict__ row_ids) {
-    const int lane = threadIdx.x & 63;
+    constexpr int G = 64 / LPE;                                   // chunks walked side by side in one wave
+    constexpr int NQ = (EMB_CH + LPE - 1) / LPE;                  // entries described per lane
+    const int lane = threadIdx.x & 63, g = lane / LPE, dl = lane % LPE;
     const int64_t nchunk = (N + EMB_CH - 1) / EMB_CH;
-    for (int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ch < nchunk; ch += (int64_t)gridDim.x * 4) {
-        const int64_t k0 = ch * EMB_CH, k1 = min(N, k0 + EMB_CH);
-        for (int d0 = 0; d0 < D; d0 += 64) {
-            const int d = d0 + lane;
-            float a = 0.f;
-            int64_t run0 = k0;
-            int s = seg_id[k0];
-            for (int64_t k = k0; k < k1; ++k) {
+    for (int64_t cb = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G; cb < nchunk; cb += (int64_t)gridDim.x * 4 * G) {
+        const int64_t ch = cb + g;
+        const int64_t k0 = ch * EMB_CH, k1 = ch < nchunk ? min(N, k0 + EMB_CH) : k0;
+        const int n = (int)(k1 - k0);                             // group-uniform
+        // ---- what this lane knows about entries q*LPE + dl of the chunk
+        int64_t m_off[NQ], m_key[NQ];                             // first float of the gradient row (-1: none), id
+        float m_wt[NQ];
+        int m_sid[NQ], m_flag[NQ];                                // segment; bit0 closes a run, bit1 whole segment, bit2 slot
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = q * LPE + dl;
+            m_off[q] = -1; m_key[q] = EMB_SENTINEL; m_wt[q] = 0.f; m_sid[q] = 0; m_flag[q] = 0;
+            if (i < n) {
+                const int64_t k = k0 + i;
                 const int e = order[k];
                 const int t = seg[e];
-                if (t >= 0) {                              // entries of the unpooled (-1) segment carry no gradient
+                const int sid = seg_id[k];
+                if (t >= 0) {                                     // entries of the unpooled (-1) segment carry no gradient
                     const int64_t b = e / C;
                     float wt = weights ? weights[e] : 1.f;
                     if (mean) wt /= cnt[b * T + t];
-                    if (d < D) a += wt * dout[(b * T + t) * (int64_t)D + d];
+                    m_wt[q] = wt;
+                    m_off[q] = (b * T + t) * (int64_t)D;
                 }
-                const bool last = k + 1 == k1;
-                const int sn = last ? -1 : seg_id[k + 1];
-                if (last || sn != s) {                     // close the run [run0, k]
-                    const bool whole = run0 == seg_first[s] && k + 1 == seg_first[s + 1];
-                    if (whole) {
-                        if (d < D) drows[s * (int64_t)D + d] = a;
-                        if (d0 == 0 && lane == 0 && row_ids) row_ids[s] = key[order[run0]];
-                    } else {
-                        // a cut run touches the chunk start, the chunk end, or both (then it is the whole chunk: slot 0)
-                        const int slot = run0 == k0 ? 0 : 1;
-                        if (d < D) part[(ch * 2 + slot) * (int64_t)D + d] = a;
+                const bool closes = k + 1 == k1 || seg_id[k + 1] != sid;
+                const int64_t first = seg_first[sid], end = seg_first[sid + 1];
+                const bool whole = first >= k0 && end <= k1;      // the run starts at max(k0, first)
+                m_sid[q] = sid;
+                m_flag[q] = (closes ? 1 : 0) | (whole ? 2 : 0) | (first > k0 ? 4 : 0);
+                if (row_ids && closes && whole) m_key[q] = key[e];          // all entries of a segment carry its id
+            }
+        }
+        for (int d0 = 0; d0 < D; d0 += LPE) {                     // more than one slice only for D > 64
+            const int d = d0 + dl;
+            float a = 0.f;
+            for (int i0 = 0; i0 < n; i0 += 4) {
+                float v[4], wt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u, q = NQ > 1 && i >= LPE ? 1 : 0, srcl = i % LPE;
+                    const int64_t off = __shfl(q ? m_off[NQ - 1] : m_off[0], srcl, LPE);
+                    wt[u] = __shfl(q ? m_wt[NQ - 1] : m_wt[0], srcl, LPE);
+                    v[u] = (i < n && off >= 0 && d < D) ? dout[off + d] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u;
+                    if (i >= n) break;
+                    const int q = NQ > 1 && i >= LPE ? 1 : 0, srcl = i % LPE;
+                    a += wt[u] * v[u];
+                    const int flag = __shfl(q ? m_flag[NQ - 1] : m_flag[0], srcl, LPE);
+                    if (flag & 1) {                               // close the run ending at entry i
+                        if (flag & 2) {
+                            const int sid = __shfl(q ? m_sid[NQ - 1] : m_sid[0], srcl, LPE);
+                            const int64_t id = __shfl(q ? m_key[NQ - 1] : m_key[0], srcl, LPE);
+                            if (d < D) drows[sid * (int64_t)D + d] = a;
+                            if (d == 0 && row_ids) row_ids[sid] = id;
+                        } else if (d < D) {
+                            // a cut run touches the chunk start, the chunk end, or both (then it is the whole chunk: slot 0)
+                            part[(((flag & 4) ? nchunk : 0) + ch) * (int64_t)D + d] = a;     // slot-major: [2][nchunk][D]
+                        }
+                        a = 0.f;
                     }
-                    a = 0.f;
-                    run0 = k + 1;
-                    s = sn;
                 }
             }
         }
@@ -207,33 +250,77 @@ k_embed_rows_chunks(const int64_t* __restrict__ key, const int32_t* __restrict__
 }
 __global__ void __launch_bounds__(256)
 k_embed_rows_join(const int64_t* __restrict__ key, const int32_t* __restrict__ order, const int32_t* __restrict__ seg_id,
-                  const int32_t* __restrict__ seg_first, int64_t N, int D, const float* __restrict__ part, float* __restrict__ drows,
-                  int64_t* __restrict__ row_ids) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+                  const int32_t* __restrict__ seg_first, int64_t N, int D, int DL, const float* __restrict__ part,
+                  float* __restrict__ drows, int64_t* __restrict__ row_ids) {
+    __shared__ float red[256];
+    __shared__ int64_t own[256];
+    __shared__ int nown;
+    const int pl = threadIdx.x / DL, dl = threadIdx.x % DL, NPL = 256 / DL;
     const int64_t nchunk = (N + EMB_CH - 1) / EMB_CH;
-    for (int64_t c = 1 + blockIdx.x; c < nchunk; c += gridDim.x) {         // boundary between chunks c-1 and c (block-uniform)
-        const int s = seg_id[c * EMB_CH];
-        if (seg_id[c * EMB_CH - 1] != s) continue;                          // no segment crosses this boundary
-        const int64_t f = seg_first[s], l = seg_first[s + 1] - 1;           // first / last sorted position of the segment
-        if (f / EMB_CH != c - 1) continue;                                  // another boundary block owns this segment
-        const int64_t c0 = c - 1, c1 = l / EMB_CH;                          // chunks c0 .. c1 hold pieces of s
-        // piece of chunk x: slot 1 in c0 unless the segment starts exactly at the chunk start, slot 0 in every later chunk
-        const int64_t npiece = c1 - c0 + 1, per = (npiece + 3) / 4;
-        for (int d0 = 0; d0 < D; d0 += 64) {
-            const int d = d0 + lane;
-            float a = 0.f;
-            const int64_t x0 = c0 + w * per, x1 = min(c1 + 1, x0 + per);
-            for (int64_t x = x0; x < x1; ++x) {
-                const int slot = (x == c0 && f != c0 * EMB_CH) ? 1 : 0;
-                if (d < D) a += part[(x * 2 + slot) * (int64_t)D + d];
+    for (int64_t base = 1 + (int64_t)blockIdx.x * NPL; base < nchunk; base += (int64_t)gridDim.x * NPL) {
+        if (threadIdx.x == 0) nown = 0;
+        __syncthreads();
+        {   // boundary between chunks c-1 and c, one per group of DL lanes: does a segment cross it, and does it start in
+            // chunk c-1 (then this boundary owns it)?  Few pieces (the usual case: ids with a handful of entries) are added
+            // right here in chunk order; long segments are left to the whole workgroup below.
+            const int64_t c = base + pl;
+            if (c < nchunk) {
+                const int s = seg_id[c * EMB_CH];
+                const int64_t f = seg_first[s];
+                if (seg_id[c * EMB_CH - 1] == s && f / EMB_CH == c - 1) {
+                    const int64_t c0 = c - 1, c1 = (seg_first[s + 1] - 1) / EMB_CH;
+                    if (c1 - c0 < EMB_JSHORT) {
+                        const int64_t first_slot = f != c0 * EMB_CH ? 1 : 0;
+                        for (int d = dl; d < D; d += DL) {
+                            float t = part[(first_slot * nchunk + c0) * (int64_t)D + d];
+                            for (int64_t x = c0 + 1; x <= c1; ++x) t += part[x * (int64_t)D + d];
+                            drows[s * (int64_t)D + d] = t;
+                        }
+                        if (dl == 0 && row_ids) row_ids[s] = key[order[f]];
+                    } else if (dl == 0) {
+                        own[atomicAdd(&nown, 1)] = c;
+                    }
+                }
             }
-            __syncthreads();
-            red[w][lane] = a;
-            __syncthreads();
-            if (w == 0 && d < D) drows[s * (int64_t)D + d] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
         }
-        if (threadIdx.x == 0 && row_ids) row_ids[s] = key[order[f]];
+        __syncthreads();
+        const int no = nown;
+        for (int o = 0; o < no; ++o) {                            // list order varies from run to run, the sums do not
+            const int64_t c = own[o];
+            const int s = seg_id[c * EMB_CH];
+            const int64_t f = seg_first[s], l = seg_first[s + 1] - 1;       // first / last sorted position of the segment
+            const int64_t c0 = c - 1, c1 = l / EMB_CH;                      // chunks c0 .. c1 hold pieces of s
+            // piece of chunk x: slot 1 in c0 unless the segment starts exactly at the chunk start, slot 0 in every later chunk
+            const int64_t first_slot = f != c0 * EMB_CH ? 1 : 0;
+            for (int d0 = 0; d0 < D; d0 += DL) {
+                const int d = d0 + dl;
+                float acc[EMB_JU];                                          // EMB_JU loads in flight per thread (one hot id: 65 K pieces)
+#pragma unroll
+                for (int u = 0; u < EMB_JU; ++u) acc[u] = 0.f;
+                if (d < D) {
+                    int64_t x = c0 + pl;
+                    if (x == c0 && x <= c1) { acc[0] = part[(first_slot * nchunk + x) * (int64_t)D + d]; x += NPL; }
+                    for (; x + (EMB_JU - 1) * NPL <= c1; x += EMB_JU * NPL) {
+#pragma unroll
+                        for (int u = 0; u < EMB_JU; ++u) acc[u] += part[(x + u * NPL) * (int64_t)D + d];
+                    }
+                    for (; x <= c1; x += NPL) acc[0] += part[x * (int64_t)D + d];
+                }
+                float a0 = 0.f;
+#pragma unroll
+                for (int u = 0; u < EMB_JU; ++u) a0 += acc[u];
+                __syncthreads();
+                red[threadIdx.x] = a0;
+                __syncthreads();
+                if (pl == 0 && d < D) {
+                    float t = red[dl];
+                    for (int u = 1; u < NPL; ++u) t += red[u * DL + dl];
+                    drows[s * (int64_t)D + d] = t;
+                }
+            }
+            if (threadIdx.x == 0 && row_ids) row_ids[s] = key[order[f]];
+        }
+        __syncthreads();
     }
 }
 __global__ void k_embed_rows_tail(const int32_t* __restrict__ n_seg, int64_t N, int64_t* __restrict__ row_ids) {
@@ -254,14 +341,17 @@ extern "C" int recnow_embed_rows_bwd(const int64_t* key, const int32_t* order, c
     if (!ws || ws_bytes < recnow_embed_rows_bwd_workspace_bytes(N, D)) return RECNOW_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nchunk = (N + EMB_CH - 1) / EMB_CH;
-    int64_t g = (nchunk + 3) / 4;
+    const int LPE = D <= 16 ? 16 : D <= 32 ? 32 : 64;             // lanes per entry; also the dims lanes of the join
+    int64_t g = (nchunk + 4 * (64 / LPE) - 1) / (4 * (64 / LPE));
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(k_embed_rows_chunks, (int)g, 256, 0, st, key, order, seg_id, seg_first, seg, weights, cnt, dout, N, C, T, D, mean,
-                       drows, (float*)ws, row_ids);
+    if (LPE == 16) hipLaunchKernelGGL(k_embed_rows_chunks<16>, (int)g, 256, 0, st, key, order, seg_id, seg_first, seg, weights, cnt, dout, N, C, T, D, mean, drows, (float*)ws, row_ids);
+    else if (LPE == 32) hipLaunchKernelGGL(k_embed_rows_chunks<32>, (int)g, 256, 0, st, key, order, seg_id, seg_first, seg, weights, cnt, dout, N, C, T, D, mean, drows, (float*)ws, row_ids);
+    else hipLaunchKernelGGL(k_embed_rows_chunks<64>, (int)g, 256, 0, st, key, order, seg_id, seg_first, seg, weights, cnt, dout, N, C, T, D, mean, drows, (float*)ws, row_ids);
     if (nchunk > 1) {
-        int64_t gj = nchunk - 1;
+        const int64_t per = 256 / LPE;                            // boundaries per workgroup and step
+        int64_t gj = (nchunk - 1 + per - 1) / per;
         if (gj > 16384) gj = 16384;
-        hipLaunchKernelGGL(k_embed_rows_join, (int)gj, 256, 0, st, key, order, seg_id, seg_first, N, D, (const float*)ws, drows, row_ids);
+        hipLaunchKernelGGL(k_embed_rows_join, (int)gj, 256, 0, st, key, order, seg_id, seg_first, N, D, LPE, (const float*)ws, drows, row_ids);
     }
     if (row_ids) hipLaunchKernelGGL(k_embed_rows_tail, 64, 256, 0, st, n_seg, N, row_ids);
     RN_LAUNCH_CHECK();
