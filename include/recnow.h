@@ -377,16 +377,17 @@ int recnow_focal_loss_bwd(const float* labels, const float* logits, int64_t B, f
 
 /* Pooled embedding lookup by slot: rec_now/rec_block/embedding_util.py:239-324 (and :138-195 for the slot -> target map).
  *   recnow_slot_targets:   seg[i] = index of slots[i] in targets[0..T) or -1;  key[i] (optional) = ids[i] if seg[i] >= 0 else
- *                          -1 (all-ones: sorts after every id >= 0 in recnow_group_segments).  slot_dtype: RECNOW_KEY_I32/I64
+ *                          INT64_MIN (sorts after every id >= 0 as an unsigned radix key in recnow_group_segments, and costs
+ *                          one extra 8-bit pass where all-ones cost five).  slot_dtype: RECNOW_KEY_I32/I64
  *                          (slots and targets share it; targets is a DEVICE array).  N = B*C entries.
  *   recnow_embed_pool_fwd: out[b][t][:] = sum_{c: seg[b][c]==t} weights[b][c] * table[rows[b][c]][:]  (mean != 0: divided by the
  *                          number of pooled entries, empty segments 0 - tf.math.unsorted_segment_mean).  rows: row index into
  *                          `table` per entry (the ids themselves, or the inverse index of recnow_embed_unique); weights, cnt
  *                          (B,T entry counts, needed by the 'mean' backward) may be NULL.  No atomics: fixed summation order.
  *   recnow_embed_unique:   from the sort of `key` (recnow_group_keys(I64) + recnow_group_segments): unique[s] = id of sorted
- *                          segment s, inverse[entry] = s, *n_unique = number of real ids (the -1 segment excluded).
+ *                          segment s, inverse[entry] = s, *n_unique = number of real ids (the INT64_MIN segment excluded).
  *   recnow_embed_rows_bwd: drows[s][:] = sum over the entries of segment s of w * dout[b][t][:] (/cnt): the gradient of row
- *                          unique[s]; row_ids[s] = that id (-1 for the unpooled segment and for unused slots s >= n_seg).
+ *                          unique[s]; row_ids[s] = that id (INT64_MIN for the unpooled segment and for unused slots s >= n_seg).
  *                          drows / row_ids hold N slots.  The entry range is cut into fixed chunks (a hot id may own millions of
  *                          entries); pieces are joined in ascending chunk order (ws: recnow_embed_rows_bwd_workspace_bytes).
  *   recnow_embed_scatter_rows: dtable[row_ids[s]][:] = drows[s][:] into a zero-initialised dense (V,D) gradient. */

@@ -12,19 +12,44 @@
 // All of it is HBM/latency-bound integer + gather work; nothing here wants the MFMA pipe.
 #include "common.hpp"
 
-#define EMB_SENTINEL (-1ll)        // key of entries that are not pooled: all-ones sorts last in the unsigned radix order
+// key of entries that are not pooled: INT64_MIN.  As an unsigned radix key it sorts after every id >= 0, and only its top
+// byte differs from the zero high bytes of real ids, so it costs ONE extra 8-bit pass (all-ones made every pass non-trivial:
+// 8 passes instead of 3 for 20-bit ids).
+#define EMB_SENTINEL ((int64_t)0x8000000000000000ull)
 
+// The target list lives in LDS (padded to a multiple of 4 with copies of its last entry) and is scanned from the back
+// without an early exit, so the smallest matching index wins as in a forward search; reading targets[j] from memory inside
+// a search loop with a break was a chain of up to T scalar-load latencies per entry (0.26 ms for 6.5 M entries, T = 64).
+#define SLOT_PIECE 4096
 template <typename ST>
 __global__ void __launch_bounds__(256)
 k_slot_targets(const ST* __restrict__ slots, const ST* __restrict__ targets, int T, const int64_t* __restrict__ ids, int64_t N,
                int32_t* __restrict__ seg, int64_t* __restrict__ key) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
-        const ST s = slots[i];
-        int t = -1;
-        for (int j = 0; j < T; ++j)
-            if (targets[j] == s) { t = j; break; }
-        seg[i] = t;
-        if (key) key[i] = t >= 0 ? ids[i] : EMB_SENTINEL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tg_raw[];
+    ST* tg = reinterpret_cast<ST*>(tg_raw);
+    // target lists longer than SLOT_PIECE go through LDS piece by piece (front to back; an earlier piece's match stands)
+    for (int p0 = 0; p0 < max(T, 1); p0 += SLOT_PIECE) {
+        const int tp = min(SLOT_PIECE, T - p0), T4 = (tp + 3) & ~3;
+        __syncthreads();
+        for (int j = threadIdx.x; j < T4; j += 256) tg[j] = targets[p0 + min(j, tp - 1)];
+        __syncthreads();
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+            const ST s = slots[i];
+            int t = -1;
+            for (int j = T4 - 4; j >= 0; j -= 4) {
+                t = tg[j + 3] == s ? min(j + 3, tp - 1) : t;          // a padded copy reports the entry it copies
+                t = tg[j + 2] == s ? min(j + 2, tp - 1) : t;
+                t = tg[j + 1] == s ? min(j + 1, tp - 1) : t;
+                t = tg[j] == s ? j : t;
+            }
+            t = t >= 0 ? p0 + t : -1;
+            if (p0 > 0) {
+                const int before = seg[i];
+                t = before >= 0 ? before : t;
+            }
+            seg[i] = t;
+            if (key && p0 + SLOT_PIECE >= T) key[i] = t >= 0 ? ids[i] : EMB_SENTINEL;
+        }
     }
 }
 
@@ -37,9 +62,9 @@ extern "C" int recnow_slot_targets(const void* slots, int slot_dtype, const void
     if (g > 4096) g = 4096;
     hipStream_t st = (hipStream_t)stream;
     if (slot_dtype == RECNOW_KEY_I32)
-        hipLaunchKernelGGL(k_slot_targets<int32_t>, (int)g, 256, 0, st, (const int32_t*)slots, (const int32_t*)targets, T, ids, N, seg, key);
+        hipLaunchKernelGGL(k_slot_targets<int32_t>, (int)g, 256, (size_t)((min(T, SLOT_PIECE) + 3) & ~3) * sizeof(int32_t) + 16, st, (const int32_t*)slots, (const int32_t*)targets, T, ids, N, seg, key);
     else
-        hipLaunchKernelGGL(k_slot_targets<int64_t>, (int)g, 256, 0, st, (const int64_t*)slots, (const int64_t*)targets, T, ids, N, seg, key);
+        hipLaunchKernelGGL(k_slot_targets<int64_t>, (int)g, 256, (size_t)((min(T, SLOT_PIECE) + 3) & ~3) * sizeof(int64_t) + 16, st, (const int64_t*)slots, (const int64_t*)targets, T, ids, N, seg, key);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -59,13 +84,42 @@ k_embed_pool_fwd(const float* __restrict__ table, int D, const int64_t* __restri
     for (int64_t b = (int64_t)blockIdx.x * nw + w; b < B; b += (int64_t)gridDim.x * nw) {
         for (int i = lane; i < G * T * D + T; i += 64) acc[i] = 0.f;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int c = grp; c < C; c += G) {
-            const int t = seg[b * C + c];
-            if (t < 0) continue;
-            const float wt = weights ? weights[b * C + c] : 1.f;
-            const float* row = table + rows[b * C + c] * (int64_t)D;
-            float* a = acc + (grp * T + t) * D;
-            for (int d = gl; d < D; d += GS) a[d] += wt * row[d];
+        // The row's entries, 64 at a time: lane l fetches (target, table row, weight) of entry c0 + l -- coalesced, all in
+        // flight at once -- and the groups take them round-robin through shuffles, four table rows in flight per group.
+        // (Fetching seg -> rows -> table row per entry was three dependent latencies per step at two waves per SIMD.)
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            const int cl = c0 + lane;
+            int m_t = -1;
+            int64_t m_row = 0;
+            float m_w = 0.f;
+            if (cl < C) {
+                m_t = seg[b * C + cl];
+                if (m_t >= 0) {
+                    m_row = rows[b * C + cl];
+                    m_w = weights ? weights[b * C + cl] : 1.f;
+                }
+            }
+            const int nc = min(64, C - c0);                                  // wave-uniform
+            for (int j0 = 0; j0 < nc; j0 += 4 * G) {
+                float v[4], wv[4];
+                int tv[4];
+                int64_t rv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u * G + grp, 63);                 // this group's entry (lanes past nc hold t = -1)
+                    tv[u] = __shfl(m_t, j, 64);
+                    rv[u] = __shfl(m_row, j, 64);
+                    wv[u] = __shfl(m_w, j, 64);
+                    if (j0 + u * G + grp >= nc) tv[u] = -1;
+                }
+                for (int d = gl; d < D; d += GS) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = tv[u] >= 0 ? table[rv[u] * (int64_t)D + d] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (tv[u] >= 0) acc[(grp * T + tv[u]) * D + d] += wv[u] * v[u];
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (mean || cnt_out) {                              // entry counts per target: lane t walks the row (C is small)
@@ -360,13 +414,15 @@ extern "C" int recnow_embed_rows_bwd(const int64_t* key, const int32_t* order, c
 
 // dtable[row_ids[s]][:] = drows[s][:] for every used slot s (row ids are unique: one writer per table row)
 __global__ void __launch_bounds__(256)
-k_embed_scatter(const float* __restrict__ drows, const int64_t* __restrict__ row_ids, int64_t n_slots, int D, int64_t V,
+k_embed_scatter(const float* __restrict__ drows, const int64_t* __restrict__ row_ids, int64_t n_slots, int D, int64_t V, int LPE,
                 float* __restrict__ dtable) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < n_slots; s += (int64_t)gridDim.x * 4) {
+    // a group of LPE lanes (pow2 >= D, 16..64) per slot: at D = 16 a wave moves four rows per step
+    const int gl = threadIdx.x % LPE;
+    const int64_t per = 256 / LPE;
+    for (int64_t s = (int64_t)blockIdx.x * per + threadIdx.x / LPE; s < n_slots; s += (int64_t)gridDim.x * per) {
         const int64_t id = row_ids[s];
         if (id < 0 || id >= V) continue;
-        for (int d = lane; d < D; d += 64) dtable[id * D + d] = drows[s * (int64_t)D + d];
+        for (int d = gl; d < D; d += LPE) dtable[id * D + d] = drows[s * (int64_t)D + d];
     }
 }
 extern "C" int recnow_embed_scatter_rows(const float* drows, const int64_t* row_ids, int64_t n_slots, int D, int64_t V, float* dtable,
@@ -374,9 +430,10 @@ extern "C" int recnow_embed_scatter_rows(const float* drows, const int64_t* row_
     if (n_slots < 0 || D < 1 || V < 0) return RECNOW_EINVAL;
     if (n_slots == 0 || V == 0) return RECNOW_OK;
     if (!drows || !row_ids || !dtable) return RECNOW_EINVAL;
-    int64_t g = (n_slots + 3) / 4;
+    const int LPE = D <= 16 ? 16 : D <= 32 ? 32 : 64;
+    int64_t g = (n_slots + 256 / LPE - 1) / (256 / LPE);
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_embed_scatter, (int)g, 256, 0, (hipStream_t)stream, drows, row_ids, n_slots, D, V, dtable);
+    hipLaunchKernelGGL(k_embed_scatter, (int)g, 256, 0, (hipStream_t)stream, drows, row_ids, n_slots, D, V, LPE, dtable);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

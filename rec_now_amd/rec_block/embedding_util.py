@@ -24,7 +24,7 @@ def _slot_tensor(slots):
 
 
 def _slot_targets(slots, target_slots, ids, want_key):
-    """(B,C) slots -> seg (B,C) int32 target index or -1, and optionally the int64 sort key (id, or -1 when not pooled)."""
+    """(B,C) slots -> seg (B,C) int32 target index or -1, and optionally the int64 sort key (id, or KEY_NOT_POOLED)."""
     if not isinstance(target_slots, list):
         target_slots = list(target_slots)
     if len(set(target_slots)) != len(target_slots):
@@ -54,6 +54,9 @@ def sparse_batch_segment_ids_of_targets(slots, target_slots):
     rows = torch.arange(B, dtype=torch.int32, device=seg.device).reshape(-1, 1) * T
     sp = (seg + rows)[mask]
     return mask, sp, B, T, B * T
+
+
+KEY_NOT_POOLED = -(1 << 63)      # sort key of entries that are not pooled (include/recnow.h, recnow_slot_targets)
 
 
 class EmbeddingTable(torch.nn.Module):
@@ -176,7 +179,7 @@ def embedding_using_sparse_batch_segment_ids(embedding_func, slots, target_slots
         # but weight in no segment.  Done through the unique path with identity inverse = one lookup per entry.
         emb = embedding_func(torch.where(seg.reshape(-1) >= 0, ids.reshape(-1), torch.zeros_like(ids.reshape(-1))))
         rows = torch.arange(N, dtype=torch.int64, device=dev).reshape(B, C)
-        srt_id = _Sorted(torch.where(seg >= 0, rows, torch.full_like(rows, -1)))
+        srt_id = _Sorted(torch.where(seg >= 0, rows, torch.full_like(rows, KEY_NOT_POOLED)))
         return _PoolFunction.apply(emb, rows, seg, weights, T, mean, srt_id, True)
     s = srt.segments()
     unique = torch.empty(max(N, 1), dtype=torch.int64, device=dev)

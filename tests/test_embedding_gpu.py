@@ -20,6 +20,26 @@ def test_sparse_batch_segment_ids_of_targets_reference_vector(dev):
     assert sp_segment_ids.cpu().tolist() == [0, 0, 1, 1, 3, 4, 4, 5, 5]
     assert (num_rows, num_ids, num_segments) == (2, 3, 6)
 
+@pytest.mark.parametrize('T,n_slots,dtype', [(1, 4, np.int32), (3, 9, np.int32), (64, 80, np.int32), (66, 70, np.int64), (5000, 6000, np.int64),
+                                             (4097, 5000, np.int32), (0, 5, np.int32)])
+def test_slot_target_map_exact(dev, T, n_slots, dtype):
+    """seg[b][c] = index of slots[b][c] in target_slots or -1 (embedding_util.py:138-195), and the sort key: the id of pooled
+    entries, KEY_NOT_POOLED otherwise.  Covers target lists that are not a multiple of 4 and longer than one LDS piece."""
+    from rec_now_amd.rec_block import embedding_util as E
+    rng = np.random.default_rng(T + n_slots)
+    slots = rng.integers(0, n_slots, (37, 29)).astype(dtype)
+    if dtype == np.int64:
+        slots[0, :5] = (1 << 40) + np.arange(5)                   # wide slot values
+    targets = [int(v) for v in rng.permutation(n_slots)[:T]]
+    if dtype == np.int64 and T > 2:
+        targets[1] = (1 << 40) + 3
+    ids = rng.integers(0, 1 << 40, slots.shape).astype(np.int64)
+    seg, key = E._slot_targets(T_(slots).to(dev), targets, T_(ids).to(dev), True)
+    pos = {v: i for i, v in enumerate(targets)}
+    exp = np.array([[pos.get(int(v), -1) for v in row] for row in slots], np.int32)
+    assert np.array_equal(seg.cpu().numpy(), exp)
+    assert np.array_equal(key.cpu().numpy(), np.where(exp >= 0, ids, E.KEY_NOT_POOLED))
+
 
 @pytest.mark.parametrize('path', ['table', 'callable_unique', 'callable_no_unique'])
 def test_embedding_using_sparse_batch_segment_ids_reference_vectors(dev, path):
@@ -40,7 +60,9 @@ def test_embedding_using_sparse_batch_segment_ids_reference_vectors(dev, path):
 
 
 @pytest.mark.parametrize('B,C,T,D,V,method,use_w', [(1, 1, 1, 1, 3, 'sum', False), (37, 20, 5, 16, 50, 'sum', True), (300, 64, 24, 16, 1000, 'mean', True),
-                                                    (64, 33, 3, 70, 7, 'mean', False), (5, 8, 4, 8, 100, 'sum', True)])
+                                                    (64, 33, 3, 70, 7, 'mean', False), (5, 8, 4, 8, 100, 'sum', True),
+                                                    # more than 64 id columns (two metadata rounds), D = 32 / 12 lane groups
+                                                    (40, 130, 9, 32, 300, 'sum', True), (33, 65, 70, 12, 40, 'mean', False)])
 @pytest.mark.parametrize('path', ['table', 'callable_unique', 'callable_no_unique'])
 def test_embedding_pool_fwd_bwd_vs_oracle(dev, B, C, T, D, V, method, use_w, path):
     from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
