@@ -3,9 +3,10 @@
 //   /root/reference/rec_now/rec_block/embedding_util.py:138-195  sparse_batch_segment_ids_of_targets (slot -> target index)
 // The reference masks the (B,C) id matrix down to the entries whose slot is a target slot, runs tf.unique over them, looks
 // the unique ids up, gathers back and pools with unsorted_segment_sum/mean into (B,T,D).  Here:
-//   k_slot_targets   : slot -> target index (-1 = not pooled) and the sort key (id, or all-ones for unpooled entries)
-//   k_embed_pool_fwd : one wave per batch row walks its C entries; 64/D lane groups take entries round-robin and
-//                      accumulate into private (T,D) LDS tiles that are summed in a fixed order at the end - no atomics
+//   k_slot_targets   : slot -> target index (-1 = not pooled) and the sort key (id, or INT64_MIN for unpooled entries)
+//   k_embed_pool_fwd : one wave per batch row; its C entries are described by all lanes at once, then 64/D lane groups
+//                      take them round-robin (shuffles) and accumulate into private (T,D) LDS tiles that are summed in a
+//                      fixed order at the end - no atomics
 //   k_embed_unique   : after the radix sort of the keys (scan_sort.hip): unique ids in sorted order + inverse index
 //   k_embed_rows_*   : per-id sums of w * dout[b][t][:] over that id's entries, split by entry chunks (hot ids), fixed order
 //   k_embed_scatter  : unique gradient rows -> dense (V,D) table gradient (each row written by exactly one wave)
