@@ -1,0 +1,40 @@
+"""Random-shape sweep of the widened rows (InnerPNN, SENET, pooled embedding lookup) against the oracle on the GPU.
+Not part of the test suite (minutes of small launches); usage: python tools/fuzz_widened.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import test_embedding_gpu as TE      # noqa: E402
+import test_interact_gpu as TI       # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device('cuda:0')
+bad = 0
+for i in range(n):
+    B = int(rng.choice([1, 2, 3, 5, 31, 64, 257, 1000]))
+    F = int(rng.integers(2, 66))
+    D = int(rng.choice([1, 2, 3, 4, 8, 12, 16, 20, 32]))
+    try:
+        TI.test_inner_pnn_fwd_bwd_vs_oracle(dev, B, F, D)
+    except Exception as e:          # noqa: BLE001
+        bad += 1
+        print('InnerPNN FAIL', B, F, D, repr(e)[:200])
+    C = int(rng.integers(1, 140))
+    T = int(rng.integers(1, 70))
+    De = int(rng.choice([1, 4, 8, 12, 16, 24, 32, 48, 64, 70]))
+    V = int(rng.integers(1, 500))
+    try:
+        TE.test_embedding_pool_fwd_bwd_vs_oracle(dev, B, C, T, De, V, str(rng.choice(['sum', 'mean'])), bool(rng.integers(0, 2)),
+                                                 str(rng.choice(['table', 'callable_unique', 'callable_no_unique'])))
+    except Exception as e:          # noqa: BLE001
+        bad += 1
+        print('embedding FAIL', B, C, T, De, V, repr(e)[:200])
+print('cases', n, 'failures', bad)
+sys.exit(1 if bad else 0)
