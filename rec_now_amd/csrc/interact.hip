@@ -1,4 +1,5 @@
-// Neighbours of the hot path, all HBM- or VALU-bound streaming kernels over rows:
+// Neighbours of the hot path, streaming kernels over rows (InnerPNN's contractions run on
+// the fp32 matrix cores; everything else is HBM-bound):
 //   InnerPNNLayer   /root/reference/rec_now/layers/inner_pnn_layer.py:25-53
 //   SENETLayer      /root/reference/rec_now/layers/senet_layer.py:93-119 (squeeze / excite-scale; the two Dense layers
 //                   in between run on the GEMM of multi_dense)
@@ -6,12 +7,12 @@
 //   focal_crossentropy_loss    /root/reference/rec_now/rec_block/focal_loss.py:12-66
 // Same conventions as fm.hip: `fields` is a DEVICE array of F device pointers to contiguous (B, D_f) fp32 tensors (the
 // reference's list-of-tensors input), no float atomics, every reduction in a fixed order.
-#include <stdlib.h>
 #include "common.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // InnerPNN: out[b][p(r,c)] = <x_r[b], x_c[b]>, r < c, p = r*F - r(r+1)/2 + (c - r - 1)           (:41-52)
-// One wave per row.  The row's F x D block sits in LDS (row stride D+1: conflict-free per-lane reads); lane <-> column
+// General shapes (F > 64 or D not in {4, 8, 12, 16}; the usual shapes take the MFMA kernels k_ipnn_*_gram further down):
+// one wave per row.  The row's F x D block sits in LDS (row stride D+1: conflict-free per-lane reads); lane <-> column
 // field c keeps x_c in registers, x_r is an LDS broadcast.  Stores of one r are consecutive in p: coalesced.
 // VALU-bound: F*D FMAs per lane and row (half of them below the diagonal) against 4*F*(F-1)/2 output bytes.
 // ---------------------------------------------------------------------------------------------------------------------
