@@ -180,9 +180,11 @@ def const_array(values, dtype, device):
     if hit is None:
         if len(_SMALL_CONST) >= 1024:
             _SMALL_CONST.clear()
-        hit = torch.tensor(key[2], dtype=dtype).to(device)
+        host = torch.tensor(key[2], dtype=dtype)
+        # the host copy is kept with the entry: a stream capture records this upload with the host address
+        hit = (host.to(device, non_blocking=True), host)
         _SMALL_CONST[key] = hit
-    return hit
+    return hit[0]
 
 
 def ptr_array(tensors, device):

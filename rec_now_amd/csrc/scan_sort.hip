@@ -68,7 +68,9 @@ extern "C" int recnow_group_keys(const void* group, int dtype, int64_t B, uint32
 
 // ------------------------------------------------------------------------------------------------
 // radix sort of row indices by n_words x 32-bit keys, 8-bit digits, LSD, stable.
-// Only the index array is permuted; a pass gathers its digit through the index (arrays are <= a few MB -> L2).
+// The index array is permuted, and beside it the values of the key word being sorted travel in the same order, so that
+// only the first pass on a word gathers it through the index (for millions of keys every gathered 4-byte word costs a
+// 64-byte sector; the first pass of all reads through the identity order, i.e. coalesced).
 // Passes whose digit is constant over all rows are skipped on the device (plan), so float-encoded small ids
 // cost 2-3 passes instead of 4.
 // ------------------------------------------------------------------------------------------------
@@ -79,8 +81,11 @@ extern "C" int recnow_group_keys(const void* group, int dtype, int64_t B, uint32
 struct SortPlan {
     int trivial[RN_MAX_PASS];
     int src[RN_MAX_PASS];     // which index buffer (0/1) pass p reads
+    int carried[RN_MAX_PASS]; // the key buffer beside that index buffer already holds pass p's word in that order
     int final_buf;            // buffer holding the sorted order after the last pass
-    int pad[3];
+    int final_word;           // key word whose values lie beside that order in the key buffer (-1: none)
+    int word_const[RN_MAX_WORDS];   // word w has one value over the whole batch (all four digits trivial)
+    int pad[2];
 };
 
 // global histograms of every digit of every word (permutation invariant -> computed once, on the input order)
@@ -113,13 +118,24 @@ __global__ void k_sort_plan(const unsigned* __restrict__ ghist, int64_t B, int n
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int cur = 0;
+        int cur = 0, word_in_buf = -1;
         for (int p = 0; p < np; ++p) {
+            const int w = n_words - 1 - p / 4;
             plan->trivial[p] = triv[p];
             plan->src[p] = cur;
-            if (!triv[p]) cur ^= 1;
+            plan->carried[p] = word_in_buf == w;
+            if (!triv[p]) {                      // the scatter of pass p leaves word w beside the permuted indices
+                cur ^= 1;
+                word_in_buf = w;
+            }
         }
         plan->final_buf = cur;
+        plan->final_word = word_in_buf;
+        for (int w = 0; w < n_words; ++w) {
+            int c = 1;
+            for (int d = 0; d < 4; ++d) c &= triv[(n_words - 1 - w) * 4 + d];
+            plan->word_const[w] = c;
+        }
     }
 }
 
@@ -130,19 +146,22 @@ __global__ void k_iota(int32_t* a, int64_t n) {
 
 __global__ void __launch_bounds__(256)
 k_sort_blockhist(const uint32_t* __restrict__ words, int64_t B, int n_words, int pass, const SortPlan* __restrict__ plan,
-                 const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1, unsigned* __restrict__ blockhist, int nblk) {
+                 const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1, const uint32_t* __restrict__ key0,
+                 const uint32_t* __restrict__ key1, unsigned* __restrict__ blockhist, int nblk) {
     if (plan->trivial[pass]) return;
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     const int32_t* src = plan->src[pass] ? idx1 : idx0;
+    const uint32_t* ksrc = plan->src[pass] ? key1 : key0;
+    const bool carried = plan->carried[pass];
     const uint32_t* wk = words + (int64_t)(n_words - 1 - pass / 4) * B;
     const int shift = 8 * (pass % 4);
     const int64_t base = (int64_t)blockIdx.x * RN_TILE;
 #pragma unroll
     for (int r = 0; r < RN_TILE / 256; ++r) {
         int64_t e = base + r * 256 + threadIdx.x;
-        if (e < B) atomicAdd(&h[(wk[src[e]] >> shift) & 255u], 1u);
+        if (e < B) atomicAdd(&h[((carried ? ksrc[e] : wk[src[e]]) >> shift) & 255u], 1u);
     }
     __syncthreads();
     blockhist[(int64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];   // digit-major
@@ -180,7 +199,8 @@ k_sort_scan(unsigned* __restrict__ blockhist, int n, int pass, const SortPlan* _
 // stable scatter: wave w of the block owns RN_TILE/4 consecutive keys, 8 rounds of 64 consecutive keys.
 __global__ void __launch_bounds__(256)
 k_sort_scatter(const uint32_t* __restrict__ words, int64_t B, int n_words, int pass, const SortPlan* __restrict__ plan,
-               int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, const unsigned* __restrict__ blockoff, int nblk) {
+               int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, uint32_t* __restrict__ key0, uint32_t* __restrict__ key1,
+               const unsigned* __restrict__ blockoff, int nblk) {
     if (plan->trivial[pass]) return;
     __shared__ unsigned wcnt[4][256];
     for (int t = threadIdx.x; t < 1024; t += 256) (&wcnt[0][0])[t] = 0;
@@ -188,19 +208,24 @@ k_sort_scatter(const uint32_t* __restrict__ words, int64_t B, int n_words, int p
     const int sb = plan->src[pass];
     const int32_t* src = sb ? idx1 : idx0;
     int32_t* dst = sb ? idx0 : idx1;
+    const uint32_t* ksrc = sb ? key1 : key0;
+    uint32_t* kdst = sb ? key0 : key1;
+    const bool carried = plan->carried[pass];
     const uint32_t* wk = words + (int64_t)(n_words - 1 - pass / 4) * B;
     const int shift = 8 * (pass % 4);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wbase = (int64_t)blockIdx.x * RN_TILE + w * (RN_TILE / 4);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int32_t my_idx[RN_TILE / 256];
+    uint32_t my_key[RN_TILE / 256];
     unsigned my_dr[RN_TILE / 256];        // digit | (rank_in_wave << 8)
 #pragma unroll
     for (int r = 0; r < RN_TILE / 256; ++r) {
         const int64_t e = wbase + r * 64 + lane;
         const bool ok = e < B;
         int32_t id = ok ? src[e] : 0;
-        unsigned d = ok ? ((wk[id] >> shift) & 255u) : 0u;
+        const uint32_t kv = ok ? (carried ? ksrc[e] : wk[id]) : 0u;
+        unsigned d = (kv >> shift) & 255u;
         unsigned long long peers = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -212,6 +237,7 @@ k_sort_scatter(const uint32_t* __restrict__ words, int64_t B, int n_words, int p
         const unsigned rank = prior + (unsigned)__popcll(peers & lt);
         if (ok && (peers & lt) == 0ull) wcnt[w][d] = prior + (unsigned)__popcll(peers);   // leader = lowest peer
         my_idx[r] = id;
+        my_key[r] = kv;
         my_dr[r] = d | (rank << 8);
     }
     __syncthreads();
@@ -223,6 +249,7 @@ k_sort_scatter(const uint32_t* __restrict__ words, int64_t B, int n_words, int p
             unsigned off = blockoff[(int64_t)d * nblk + blockIdx.x] + rank;
             for (int pw = 0; pw < w; ++pw) off += wcnt[pw][d];
             dst[off] = my_idx[r];
+            kdst[off] = my_key[r];
         }
     }
 }
@@ -232,11 +259,12 @@ k_sort_scatter(const uint32_t* __restrict__ words, int64_t B, int n_words, int p
 // ------------------------------------------------------------------------------------------------
 __global__ void k_seg_heads(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int64_t B, int n_words,
                             int n_words_first, const SortPlan* __restrict__ plan, const int32_t* __restrict__ idx0,
-                            const int32_t* __restrict__ idx1, int32_t* __restrict__ order, int32_t* __restrict__ head,
-                            int32_t* __restrict__ shead) {
+                            const int32_t* __restrict__ idx1, const uint32_t* __restrict__ key0, const uint32_t* __restrict__ key1,
+                            int32_t* __restrict__ order, int32_t* __restrict__ head, int32_t* __restrict__ shead) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= B) return;
     const int32_t* fin = plan->final_buf ? idx1 : idx0;
+    const uint32_t* kfin = plan->final_buf ? key1 : key0;       // values of word plan->final_word in sorted order
     const int32_t i = fin[k];
     order[k] = i;
     int h = 1, sh = 1;
@@ -245,7 +273,9 @@ __global__ void k_seg_heads(const uint32_t* __restrict__ words, const uint8_t* _
         const bool s = solo[i] | solo[j];
         bool diff_first = false, diff_any = false;
         for (int w = 0; w < n_words; ++w) {
-            const bool d = words[(int64_t)w * B + i] != words[(int64_t)w * B + j];
+            if (plan->word_const[w]) continue;                   // one value over the batch: neighbours cannot differ in it
+            const bool d = w == plan->final_word ? kfin[k] != kfin[k - 1]
+                                                 : words[(int64_t)w * B + i] != words[(int64_t)w * B + j];
             diff_any |= d;
             if (w < n_words_first) diff_first |= d;
         }
@@ -407,7 +437,7 @@ extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) 
     size_t s = 0;
     s += rn_align(sizeof(SortPlan));
     s += rn_align((size_t)n_words * 4 * 256 * sizeof(unsigned));    // ghist
-    s += 2 * rn_align((size_t)(B + 1) * sizeof(int32_t));           // idx0, idx1
+    s += 4 * rn_align((size_t)(B + 1) * sizeof(int32_t));           // idx0, idx1, key0, key1
     s += rn_align((size_t)256 * nblk * sizeof(unsigned));           // blockhist
     s += 4 * rn_align((size_t)(B + 1) * sizeof(int32_t));           // head, shead, seg_incl, super_incl
     s += rn_scan_ws_bytes(B);
@@ -440,6 +470,8 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     unsigned* ghist = c.take<unsigned>((size_t)n_words * 4 * 256);
     int32_t* idx0 = c.take<int32_t>(B + 1);
     int32_t* idx1 = c.take<int32_t>(B + 1);
+    uint32_t* key0 = c.take<uint32_t>(B + 1);
+    uint32_t* key1 = c.take<uint32_t>(B + 1);
     unsigned* blockhist = c.take<unsigned>((size_t)256 * nblk);
     int32_t* head = c.take<int32_t>(B + 1);
     int32_t* shead = c.take<int32_t>(B + 1);
@@ -458,16 +490,16 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     }
     hipLaunchKernelGGL(k_sort_plan, 1, 256, 0, st, ghist, B, n_words, plan);
     for (int p = 0; p < n_words * 4; ++p) {
-        hipLaunchKernelGGL(k_sort_blockhist, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, blockhist, nblk);
+        hipLaunchKernelGGL(k_sort_blockhist, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, key0, key1, blockhist, nblk);
         if (256 * (int64_t)nblk <= 32768) {
             hipLaunchKernelGGL(k_sort_scan, 1, 1024, 0, st, blockhist, 256 * nblk, p, plan);
         } else {        // millions of keys (pooled embedding ids): device-wide scan, in place (a skipped pass scans stale counts, unused)
             int rc2 = rn_scan<unsigned, unsigned, 0>(blockhist, blockhist, 256 * (int64_t)nblk, 0, scan_ws, scan_ws_bytes, st);
             if (rc2) return rc2;
         }
-        hipLaunchKernelGGL(k_sort_scatter, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, blockhist, nblk);
+        hipLaunchKernelGGL(k_sort_scatter, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, key0, key1, blockhist, nblk);
     }
-    hipLaunchKernelGGL(k_seg_heads, G, T, 0, st, words, solo, B, n_words, n_words_first, plan, idx0, idx1, order, head, shead);
+    hipLaunchKernelGGL(k_seg_heads, G, T, 0, st, words, solo, B, n_words, n_words_first, plan, idx0, idx1, key0, key1, order, head, shead);
     RN_LAUNCH_CHECK();
     int rc = rn_inclusive_scan_i32(head, seg_incl, B, scan_ws, scan_ws_bytes, st);
     if (rc) return rc;
