@@ -187,6 +187,13 @@ def const_array(values, dtype, device):
     return hit[0]
 
 
+def block_ptr_array(buf, n_blocks):
+    """Device array of the base pointers of the n_blocks equal, consecutive blocks of the contiguous tensor `buf`
+    (buf[f] for f < n_blocks) -- without creating n_blocks views first."""
+    base, step = buf.data_ptr(), buf.numel() // n_blocks * buf.element_size()
+    return const_array([base + f * step for f in range(n_blocks)], torch.int64, buf.device)
+
+
 def ptr_array(tensors, device):
     """Device array of base pointers (int64) for list-of-tensor kernels."""
     return const_array([t.data_ptr() for t in tensors], torch.int64, device)

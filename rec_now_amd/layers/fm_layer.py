@@ -29,8 +29,7 @@ class _FMFunction(torch.autograd.Function):
         gy = _lib.f32c(gy, 'grad').reshape(-1)
         dx = torch.empty((F, B, D), dtype=torch.float32, device=S.device)
         ptrs = _lib.ptr_array(xs, S.device)
-        base, step = dx.data_ptr(), B * D * 4          # the F gradient blocks of dx, without making F views first
-        dptrs = _lib.const_array([base + f * step for f in range(F)], torch.int64, S.device)
+        dptrs = _lib.block_ptr_array(dx, F)
         _lib.call('recnow_fm_bwd', _lib.ptr(ptrs), _lib.ptr(dptrs), F, B, D, _lib.ptr(S), _lib.ptr(gy), _lib.stream())
         return tuple(dx.unbind(0))
 

@@ -30,7 +30,7 @@ class _InnerPNNFunction(torch.autograd.Function):
         dout = _lib.f32c(dout, 'grad')
         dx = torch.empty((F, B, D), dtype=torch.float32, device=dev)
         ptrs = _lib.ptr_array(list(xs), dev)
-        dptrs = _lib.ptr_array([dx[f] for f in range(F)], dev)
+        dptrs = _lib.block_ptr_array(dx, F)
         _lib.call('recnow_inner_pnn_bwd', _lib.ptr(ptrs), _lib.ptr(dptrs), F, B, D, _lib.ptr(dout), _lib.stream())
         return tuple(dx.unbind(0))
 

@@ -69,8 +69,12 @@ class _SenetFunction(torch.autograd.Function):
             grads[1 + i] = got[1 + k]
         dsq = grads[0] if grads[0] is not None else torch.zeros_like(dw)
         dsq = _lib.f32c(dsq, 'grad')
-        dxs = [torch.empty_like(x) for x in h.xs]
-        dptrs = _lib.ptr_array(dxs, dev)
+        if h.uniform:                               # equal widths: one buffer, F blocks (one allocation instead of F)
+            dx = torch.empty((h.F, B, h.uniform), dtype=torch.float32, device=dev)
+            dxs, dptrs = dx.unbind(0), _lib.block_ptr_array(dx, h.F)
+        else:
+            dxs = [torch.empty_like(x) for x in h.xs]
+            dptrs = _lib.ptr_array(dxs, dev)
         _lib.call('recnow_senet_scale_bwd_x', _lib.ptr(dptrs), _lib.ptr(h.dims), _lib.ptr(h.offs), h.F, h.total, B, _lib.ptr(ctx.wd),
                   _lib.ptr(dout), _lib.ptr(dsq), h.uniform, _lib.stream())
         return (None, None) + tuple(grads[1:]) + tuple(dxs)
