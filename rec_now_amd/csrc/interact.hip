@@ -242,7 +242,7 @@ __device__ __forceinline__ void ipnn_keep(float (&u)[NB], float (&l)[NB]) {
     else if constexpr (NB == 3) asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]));
     else asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]));
 }
-template <int D, int NB>                          // NB = ceil(F / 16): 16-row blocks of dX, and 4*NB k steps
+template <int D, int NB, bool FULL>               // NB = ceil(F / 16): 16-row blocks of dX, and 4*NB k steps; FULL: F == 16*NB
 __global__ void __launch_bounds__(256)
 k_ipnn_bwd_gram(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int64_t B, int64_t wstride,
                 const float* __restrict__ dout, int vec) {
@@ -315,12 +315,14 @@ k_ipnn_bwd_gram(const float* const* __restrict__ fields, float* const* __restric
 #pragma unroll
             for (int I = 0; I < NB; ++I) {
                 const int ri = 16 * I + io;
+                // FULL (F == 16 * NB: no ragged edge): only the four k steps whose block straddles the diagonal need a mask
+                const bool straddle = kk >= 4 * I && kk <= 4 * I + 3;
                 if (kk >= 4 * I) {
-                    const float a = (ck > ri && ck < F) ? au[I] : 0.f;
+                    const float a = (FULL && !straddle) ? au[I] : ((ck > ri && ck < F) ? au[I] : 0.f);
                     acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[kk], acc[I], 0, 0, 0);
                 }
                 if (kk <= 4 * I + 3) {
-                    const float a = (ri > ck && ri < F) ? al[I] : 0.f;
+                    const float a = (FULL && !straddle) ? al[I] : ((ri > ck && ri < F) ? al[I] : 0.f);
                     acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[kk], acc[I], 0, 0, 0);
                 }
             }
@@ -404,7 +406,11 @@ extern "C" int recnow_inner_pnn_bwd(const float* const* fields, float* const* df
         const int64_t wstride = 64 * 16 + ((P + 64 + 3) & ~3ll);
         const size_t slds = 4 * (size_t)wstride * sizeof(float);
         const int vec = (P & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0;       // rows of dout are float4-addressable
-#define IPNN_BWD_LAUNCH(DD, NBB) hipLaunchKernelGGL((k_ipnn_bwd_gram<DD, NBB>), (int)gs, 256, slds, st, fields, dfields, F, B, wstride, dout, vec)
+#define IPNN_BWD_LAUNCH(DD, NBB)                                                                                         \
+    do {                                                                                                                 \
+        if (F == 16 * NBB) hipLaunchKernelGGL((k_ipnn_bwd_gram<DD, NBB, true>), (int)gs, 256, slds, st, fields, dfields, F, B, wstride, dout, vec); \
+        else hipLaunchKernelGGL((k_ipnn_bwd_gram<DD, NBB, false>), (int)gs, 256, slds, st, fields, dfields, F, B, wstride, dout, vec);             \
+    } while (0)
 #define IPNN_BWD_LAUNCH_D(DD)                                                                                            \
     do {                                                                                                                 \
         if (F <= 16) IPNN_BWD_LAUNCH(DD, 1);                                                                             \
