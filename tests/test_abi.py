@@ -31,3 +31,20 @@ def test_cpu_tensor_is_refused_loudly():
     from rec_now_amd.layers.fm_layer import FMLayer
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         FMLayer()([torch.zeros(2, 4), torch.zeros(2, 4)])
+
+
+def test_small_device_tables_are_uploaded_once_per_content():
+    """_lib.const_array / block_ptr_array: host logic of the pointer / width tables of the list-of-tensor kernels (the device
+    argument may be the CPU here: only the caching and the address arithmetic are under test)."""
+    import torch
+    from rec_now_amd import _lib
+    cpu = torch.device('cpu')
+    a = _lib.const_array([3, 5, 7], torch.int32, cpu)
+    assert a.dtype == torch.int32 and a.tolist() == [3, 5, 7]
+    assert _lib.const_array((3, 5, 7), torch.int32, cpu) is a                 # same content -> the same upload
+    assert _lib.const_array([3, 5, 8], torch.int32, cpu) is not a
+    assert _lib.const_array([3, 5, 7], torch.int64, cpu) is not a
+    buf = torch.zeros(4, 6, 5)
+    p = _lib.block_ptr_array(buf, 4)
+    assert p.dtype == torch.int64 and p.tolist() == [buf[f].data_ptr() for f in range(4)]
+    assert _lib.ptr_array([buf[1], buf[3]], cpu).tolist() == [buf[1].data_ptr(), buf[3].data_ptr()]
