@@ -89,12 +89,14 @@ struct SortPlan {
 };
 
 // global histograms of every digit of every word (permutation invariant -> computed once, on the input order)
-__global__ void k_sort_ghist(const uint32_t* __restrict__ words, int64_t B, int n_words, unsigned* __restrict__ ghist) {
+__global__ void k_sort_ghist(const uint32_t* __restrict__ words, int64_t B, int n_words, unsigned* __restrict__ ghist,
+                             int32_t* __restrict__ idx0) {
     extern __shared__ unsigned sh[];           // [n_words*4][256]
     const int nb = n_words * 4 * 256;
     for (int t = threadIdx.x; t < nb; t += blockDim.x) sh[t] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        idx0[i] = (int32_t)i;                   // the identity order the first pass starts from
         for (int w = 0; w < n_words; ++w) {
             uint32_t k = words[(int64_t)w * B + i];
 #pragma unroll
@@ -139,11 +141,6 @@ __global__ void k_sort_plan(const unsigned* __restrict__ ghist, int64_t B, int n
     }
 }
 
-__global__ void k_iota(int32_t* a, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = (int32_t)i;
-}
-
 __global__ void __launch_bounds__(256)
 k_sort_blockhist(const uint32_t* __restrict__ words, int64_t B, int n_words, int pass, const SortPlan* __restrict__ plan,
                  const int32_t* __restrict__ idx0, const int32_t* __restrict__ idx1, const uint32_t* __restrict__ key0,
@@ -167,43 +164,40 @@ k_sort_blockhist(const uint32_t* __restrict__ words, int64_t B, int n_words, int
     blockhist[(int64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];   // digit-major
 }
 
-// exclusive scan of blockhist[256*nblk] in place, single block of 1024 threads
-__global__ void __launch_bounds__(1024)
-k_sort_scan(unsigned* __restrict__ blockhist, int n, int pass, const SortPlan* __restrict__ plan) {
-    if (plan->trivial[pass]) return;
-    __shared__ unsigned wsum[16];
-    const int per = (n + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(n, lo + per);
-    unsigned s = 0;
-    for (int i = lo; i < hi; ++i) s += blockhist[i];
-    // block exclusive scan of s
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        unsigned t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    unsigned woff = 0;
-    for (int i = 0; i < w; ++i) woff += wsum[i];
-    unsigned run = woff + inc - s;
-    for (int i = lo; i < hi; ++i) {
-        unsigned v = blockhist[i];
-        blockhist[i] = run;
-        run += v;
-    }
-}
-
 // stable scatter: wave w of the block owns RN_TILE/4 consecutive keys, 8 rounds of 64 consecutive keys.
 __global__ void __launch_bounds__(256)
 k_sort_scatter(const uint32_t* __restrict__ words, int64_t B, int n_words, int pass, const SortPlan* __restrict__ plan,
                int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, uint32_t* __restrict__ key0, uint32_t* __restrict__ key1,
-               const unsigned* __restrict__ blockoff, int nblk) {
+               const unsigned* __restrict__ blockoff, int nblk, int scan_here) {
     if (plan->trivial[pass]) return;
     __shared__ unsigned wcnt[4][256];
+    __shared__ unsigned boff[256];          // scan_here: this block's first output position of every digit
+    __shared__ unsigned wtot[4];
     for (int t = threadIdx.x; t < 1024; t += 256) (&wcnt[0][0])[t] = 0;
+    if (scan_here) {
+        // `blockoff` holds the RAW digit-major counts [256][nblk]: thread d adds up digit d's row (the part before this block
+        // separately), then the 256 row totals are scanned -- one launch less per pass than a separate scan kernel, which
+        // matters because a grouping call is a chain of ~30 few-microsecond launches
+        const unsigned* row = blockoff + (int64_t)threadIdx.x * nblk;
+        unsigned before = 0, total = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const unsigned v = row[b];
+            before += b < (int)blockIdx.x ? v : 0u;
+            total += v;
+        }
+        const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        unsigned inc = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(inc, o, 64);
+            if (ln >= o) inc += t;
+        }
+        if (ln == 63) wtot[wv] = inc;
+        __syncthreads();
+        unsigned woff = 0;
+        for (int i = 0; i < wv; ++i) woff += wtot[i];
+        boff[threadIdx.x] = woff + inc - total + before;
+    }
     __syncthreads();
     const int sb = plan->src[pass];
     const int32_t* src = sb ? idx1 : idx0;
@@ -246,7 +240,7 @@ k_sort_scatter(const uint32_t* __restrict__ words, int64_t B, int n_words, int p
         const int64_t e = wbase + r * 64 + lane;
         if (e < B) {
             const unsigned d = my_dr[r] & 255u, rank = my_dr[r] >> 8;
-            unsigned off = blockoff[(int64_t)d * nblk + blockIdx.x] + rank;
+            unsigned off = (scan_here ? boff[d] : blockoff[(int64_t)d * nblk + blockIdx.x]) + rank;
             for (int pw = 0; pw < w; ++pw) off += wcnt[pw][d];
             dst[off] = my_idx[r];
             kdst[off] = my_key[r];
@@ -482,22 +476,20 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
 
     RN_HIP(hipMemsetAsync(ghist, 0, (size_t)n_words * 4 * 256 * sizeof(unsigned), st));
     const int T = 256, G = rn_cdiv(B, T);
-    hipLaunchKernelGGL(k_iota, G, T, 0, st, idx0, B);
     {
         int gh = rn_cdiv(B, 256 * 8);
         if (gh > 512) gh = 512;
-        hipLaunchKernelGGL(k_sort_ghist, gh, 256, (size_t)n_words * 4 * 256 * sizeof(unsigned), st, words, B, n_words, ghist);
+        hipLaunchKernelGGL(k_sort_ghist, gh, 256, (size_t)n_words * 4 * 256 * sizeof(unsigned), st, words, B, n_words, ghist, idx0);
     }
     hipLaunchKernelGGL(k_sort_plan, 1, 256, 0, st, ghist, B, n_words, plan);
     for (int p = 0; p < n_words * 4; ++p) {
         hipLaunchKernelGGL(k_sort_blockhist, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, key0, key1, blockhist, nblk);
-        if (256 * (int64_t)nblk <= 32768) {
-            hipLaunchKernelGGL(k_sort_scan, 1, 1024, 0, st, blockhist, 256 * nblk, p, plan);
-        } else {        // millions of keys (pooled embedding ids): device-wide scan, in place (a skipped pass scans stale counts, unused)
+        const int scan_here = nblk <= 128;      // few blocks: every scatter workgroup scans the raw counts itself
+        if (!scan_here) {   // millions of keys (pooled embedding ids): device-wide scan, in place (a skipped pass scans stale counts, unused)
             int rc2 = rn_scan<unsigned, unsigned, 0>(blockhist, blockhist, 256 * (int64_t)nblk, 0, scan_ws, scan_ws_bytes, st);
             if (rc2) return rc2;
         }
-        hipLaunchKernelGGL(k_sort_scatter, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, key0, key1, blockhist, nblk);
+        hipLaunchKernelGGL(k_sort_scatter, nblk, 256, 0, st, words, B, n_words, p, plan, idx0, idx1, key0, key1, blockhist, nblk, scan_here);
     }
     hipLaunchKernelGGL(k_seg_heads, G, T, 0, st, words, solo, B, n_words, n_words_first, plan, idx0, idx1, key0, key1, order, head, shead);
     RN_LAUNCH_CHECK();
