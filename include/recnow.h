@@ -46,6 +46,8 @@ extern "C" {
 /* pair predicate flags */
 #define RECNOW_PAIR_LABEL_GT 1    /* keep (i,j) only if label_i > label_j   (pairwise_loss_from_batch.py:189)     */
 #define RECNOW_PAIR_WRONG_ORDER 2 /* keep (i,j) only if score_i < score_j   (pairwise_loss_from_batch.py:197-203) */
+#define RECNOW_PAIR_MEMBERS_PACKED 256 /* recnow_pair_bpr_fwdbwd only: the workspace is the one recnow_pair_count just
+                                          used with the same scores / labels / mask / order -- its packed rows are reused */
 
 int recnow_abi_version(void);
 

@@ -26,10 +26,17 @@ __device__ __forceinline__ Member load_member(const float* __restrict__ scores, 
     return m;
 }
 
+// zero_b / zero_1 (optional): the B per-row counters and the one total that the counting kernel adds into -- cleared here
+// instead of by two memset launches (a loss call is a chain of few-microsecond launches; each one removed is ~4 us)
 __global__ void k_pack_members(const float* __restrict__ scores, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
-                               const int32_t* __restrict__ order, int64_t B, Member* __restrict__ out) {
+                               const int32_t* __restrict__ order, int64_t B, Member* __restrict__ out,
+                               unsigned long long* __restrict__ zero_b, unsigned long long* __restrict__ zero_1) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < B) out[k] = load_member(scores, labels, mask, order, k);
+    if (k < B) {
+        out[k] = load_member(scores, labels, mask, order, k);
+        if (zero_b) zero_b[k] = 0ull;
+    }
+    if (k == 0 && zero_1) *zero_1 = 0ull;
 }
 
 template <int FLAGS>
@@ -250,8 +257,9 @@ extern "C" size_t recnow_pairwise_workspace_bytes(int64_t B) {
 
 // The Member array lives at the start of the pairwise workspace; every entry point re-packs it (B x 16 B).
 static int pack_members(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order, int64_t B,
-                        Member* mem, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_members, rn_cdiv(B, 256), 256, 0, st, scores, labels, mask, order, B, mem);
+                        Member* mem, hipStream_t st, int64_t* zero_b = nullptr, int64_t* zero_1 = nullptr) {
+    hipLaunchKernelGGL(k_pack_members, rn_cdiv(B, 256), 256, 0, st, scores, labels, mask, order, B, mem,
+                       (unsigned long long*)zero_b, (unsigned long long*)zero_1);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -262,13 +270,14 @@ extern "C" int recnow_pair_count(const float* scores, const float* labels, const
                                  size_t ws_bytes, void* stream) {
     if (B < 0 || !n_pair) return RECNOW_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    RN_HIP(hipMemsetAsync(n_pair, 0, sizeof(int64_t), st));
-    if (B == 0) return RECNOW_OK;
+    if (B == 0) {
+        RN_HIP(hipMemsetAsync(n_pair, 0, sizeof(int64_t), st));
+        return RECNOW_OK;
+    }
     if (!scores || !labels || !order || !seg_id || !seg_first || !super_id || !cnt_row || !cnt_super || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
     Member* mem = (Member*)ws;
-    RN_HIP(hipMemsetAsync(cnt_super, 0, (size_t)B * sizeof(int64_t), st));
-    int rc = pack_members(scores, labels, mask, order, B, mem, st);
+    int rc = pack_members(scores, labels, mask, order, B, mem, st, cnt_super, n_pair);      // also clears cnt_super[0..B) and *n_pair
     if (rc) return rc;
     const int G = rn_cdiv(B, RN_PW_T);
     RN_DISPATCH_FLAGS(k_pair_count, mem, seg_id, seg_first, super_id, B, cnt_row, (unsigned long long*)cnt_super,
@@ -323,7 +332,8 @@ extern "C" int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, 
     Member* mem = c.take<Member>(B + 1);
     const int G = rn_cdiv(B, RN_PW_T);
     double* part = c.take<double>(G > RN_VEC_BLOCKS ? G : RN_VEC_BLOCKS);
-    int rc = pack_members(scores, labels, mask, order, B, mem, st);
+    // RECNOW_PAIR_MEMBERS_PACKED: `ws` still holds the members recnow_pair_count packed from these very inputs
+    int rc = (flags & RECNOW_PAIR_MEMBERS_PACKED) ? RECNOW_OK : pack_members(scores, labels, mask, order, B, mem, st);
     if (rc) return rc;
     RN_DISPATCH_FLAGS(k_pair_bpr, mem, seg_id, seg_first, super_id, (const unsigned long long*)cnt_super,
                       (const unsigned long long*)n_pair, B, factor, power, reduce_mean, part, dscores);

@@ -21,6 +21,7 @@ from ._segments import build_segments
 SMALL_POSIVITE_FLOAT = 1.0E-10   # reference :13 (spelling kept)
 
 _FLAG_LABEL_GT, _FLAG_WRONG_ORDER = 1, 2
+_FLAG_MEMBERS_PACKED = 256          # RECNOW_PAIR_MEMBERS_PACKED: the workspace of _count is handed straight to the loss kernel
 
 
 def _generate_pair_mask(sample_group_idx_var, only_upper_band=False):
@@ -156,7 +157,7 @@ class _PairBprFused(torch.autograd.Function):
         dscores = torch.empty(max(B, 1), dtype=torch.float32, device=seg.device)
         _lib.call('recnow_pair_bpr_fwdbwd', _lib.ptr(scores), _lib.ptr(labs), _lib.ptr(m), _lib.ptr(seg.order),
                   _lib.ptr(seg.seg_id), _lib.ptr(seg.seg_first), _lib.ptr(seg.super_id), _lib.ptr(cnt_super),
-                  _lib.ptr(n_pair), B, flags, float(factor), float(power), 1 if reduce_mean else 0, _lib.ptr(loss),
+                  _lib.ptr(n_pair), B, flags | _FLAG_MEMBERS_PACKED, float(factor), float(power), 1 if reduce_mean else 0, _lib.ptr(loss),
                   _lib.ptr(dscores), _lib.ptr(ws), ws.numel(), _lib.stream())
         ctx.save_for_backward(dscores[:B])
         ctx.shape = outputs.shape
