@@ -109,3 +109,28 @@ def test_embedding_pool_no_target_present_and_errors(dev):
         embedding_using_sparse_batch_segment_ids(table, slots, [1, 1], ids)
     with pytest.raises(ValueError):
         embedding_using_sparse_batch_segment_ids(table, slots, [1], ids, method='max')
+
+
+def test_embedding_pool_gradient_is_bitwise_reproducible(dev):
+    """No float atomics anywhere on the path: the table gradient of the pooled lookup is bit-identical from run to run,
+    including a hot id whose entries span hundreds of 32-entry chunks (the workgroup join) and ids with a handful of entries
+    (the lane-group join)."""
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    rng = np.random.default_rng(5)
+    B, C, T, D, V = 3000, 40, 12, 16, 5000
+    slots = T_(rng.integers(0, T + 2, (B, C)).astype(np.int32)).to(dev)
+    ids = (rng.zipf(1.3, (B, C)) % V).astype(np.int64)
+    ids[:, :8] = 7                                                  # 24 000 entries of one id
+    ids = T_(ids).to(dev)
+    w = T_(rng.uniform(0.5, 1.5, (B, C)).astype(np.float32)).to(dev)
+    gy = T_(rng.normal(size=(B, T, D)).astype(np.float32)).to(dev)
+    params = T_(rng.normal(size=(V, D)).astype(np.float32)).to(dev)
+    grads = []
+    for _ in range(3):
+        table = EmbeddingTable(torch.nn.Parameter(params.clone()))
+        out = embedding_using_sparse_batch_segment_ids(table, slots, list(range(T)), ids, weights=w, method='mean')
+        out.backward(gy)
+        grads.append((out.detach().clone(), table.weight.grad.clone()))
+    for o, g in grads[1:]:
+        assert torch.equal(o, grads[0][0]) and torch.equal(g, grads[0][1])
+    assert float(grads[0][1][7].abs().sum()) > 0

@@ -206,3 +206,25 @@ def test_empty_batches(dev):
     assert out.shape == (0, 1, 2)
     out.sum().backward()
     assert embedding_using_sparse_batch_segment_ids(table, torch.zeros(2, 3, dtype=torch.int32, device=dev), [], torch.zeros(2, 3, dtype=torch.int64, device=dev)).shape == (2, 0, 2)
+
+
+def test_inner_pnn_and_senet_bitwise_reproducible(dev):
+    """Fixed summation order everywhere (MFMA accumulation order, LDS hand-overs inside one wave): identical bits per run."""
+    from rec_now_amd.layers.inner_pnn_layer import InnerPNNLayer
+    from rec_now_amd.layers.senet_layer import SENETLayer
+    rng = np.random.default_rng(3)
+    B, F, D = 5000, 64, 16
+    xs = [torch.from_numpy(rng.normal(size=(B, D)).astype(np.float32)).to(dev) for _ in range(F)]
+    gp = torch.from_numpy(rng.normal(size=(B, F * (F - 1) // 2)).astype(np.float32)).to(dev)
+    gs = torch.from_numpy(rng.normal(size=(B, F * D)).astype(np.float32)).to(dev)
+    torch.manual_seed(0)
+    senet = SENETLayer(0.5)
+    runs = []
+    for _ in range(3):
+        leaves = [x.clone().requires_grad_(True) for x in xs]
+        y = InnerPNNLayer()(leaves)
+        y.backward(gp)
+        z = SENETLayer.__call__(senet, [x.clone().requires_grad_(True) for x in xs])
+        runs.append((y.detach().clone(), torch.stack([x.grad for x in leaves]), z.detach().clone()))
+    for y, g, z in runs[1:]:
+        assert torch.equal(y, runs[0][0]) and torch.equal(g, runs[0][1]) and torch.equal(z, runs[0][2])
