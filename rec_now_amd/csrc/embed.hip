@@ -4,9 +4,9 @@
 // The reference masks the (B,C) id matrix down to the entries whose slot is a target slot, runs tf.unique over them, looks
 // the unique ids up, gathers back and pools with unsorted_segment_sum/mean into (B,T,D).  Here:
 //   k_slot_targets   : slot -> target index (-1 = not pooled) and the sort key (id, or INT64_MIN for unpooled entries)
-//   k_embed_pool_fwd : one wave per batch row; its C entries are described by all lanes at once, then 64/D lane groups
-//                      take them round-robin (shuffles) and accumulate into private (T,D) LDS tiles that are summed in a
-//                      fixed order at the end - no atomics
+//   k_embed_pool_fwd : one wave per batch row; its C entries are described by all lanes at once, then each of the 64/D lane
+//                      groups takes the entries of ITS targets (t % groups) in ascending order and adds their table rows
+//                      into one (T,D) LDS tile - no float atomics on data (entry counts are whole numbers)
 //   k_embed_unique   : after the radix sort of the keys (scan_sort.hip): unique ids in sorted order + inverse index
 //   k_embed_rows_*   : per-id sums of w * dout[b][t][:] over that id's entries, split by entry chunks (hot ids), fixed order
 //   k_embed_scatter  : unique gradient rows -> dense (V,D) table gradient (each row written by exactly one wave)
@@ -80,14 +80,16 @@ k_embed_pool_fwd(const float* __restrict__ table, int D, const int64_t* __restri
     int GS = 1;                                    // lanes per entry: D rounded up to a power of two, at most 64
     while (GS < D && GS < 64) GS <<= 1;
     const int G = 64 / GS, grp = lane / GS, gl = lane % GS;
-    float* acc = lds + (size_t)w * (G * T * D + T);          // [G][T][D] then cnt[T]
-    float* cnt = acc + G * T * D;
+    float* acc = lds + (size_t)w * (T * D + T);              // [T][D] then cnt[T]
+    float* cnt = acc + T * D;
     for (int64_t b = (int64_t)blockIdx.x * nw + w; b < B; b += (int64_t)gridDim.x * nw) {
-        for (int i = lane; i < G * T * D + T; i += 64) acc[i] = 0.f;
+        for (int i = lane; i < T * D + T; i += 64) acc[i] = 0.f;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // The row's entries, 64 at a time: lane l fetches (target, table row, weight) of entry c0 + l -- coalesced, all in
-        // flight at once -- and the groups take them round-robin through shuffles, four table rows in flight per group.
-        // (Fetching seg -> rows -> table row per entry was three dependent latencies per step at two waves per SIMD.)
+        // flight at once.  Lane group g then owns the targets t with t % G == g: it takes its entries in ascending order
+        // from a ballot mask, four table rows in flight, and adds them into the ONE [T][D] tile -- groups never meet on a
+        // target, so there are no per-group copies to clear and add up (those 16 KB per wave held the kernel to two waves
+        // per SIMD) and no atomics.  (Before that: seg -> rows -> table row fetched per entry, three dependent latencies.)
         for (int c0 = 0; c0 < C; c0 += 64) {
             const int cl = c0 + lane;
             int m_t = -1;
@@ -98,43 +100,42 @@ k_embed_pool_fwd(const float* __restrict__ table, int D, const int64_t* __restri
                 if (m_t >= 0) {
                     m_row = rows[b * C + cl];
                     m_w = weights ? weights[b * C + cl] : 1.f;
+                    atomicAdd(&cnt[m_t], 1.f);                               // whole numbers: exact in any order
                 }
             }
-            const int nc = min(64, C - c0);                                  // wave-uniform
-            for (int j0 = 0; j0 < nc; j0 += 4 * G) {
+            unsigned long long mine = 0ull;                                  // entries of this round that belong to this lane's group
+            for (int g = 0; g < G; ++g) {
+                const unsigned long long bal = __ballot(m_t >= 0 && (m_t % G) == g);
+                mine = g == grp ? bal : mine;
+            }
+            while (__ballot(mine != 0ull)) {                                 // the whole wave stays in: the shuffles below read lanes of other groups
                 float v[4], wv[4];
                 int tv[4];
                 int64_t rv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int j = min(j0 + u * G + grp, 63);                 // this group's entry (lanes past nc hold t = -1)
-                    tv[u] = __shfl(m_t, j, 64);
+                    const bool have = mine != 0ull;
+                    const int j = have ? __ffsll((long long)mine) - 1 : 0;
+                    const int tj = __shfl(m_t, j, 64);                       // shuffles by every lane, selects afterwards
                     rv[u] = __shfl(m_row, j, 64);
                     wv[u] = __shfl(m_w, j, 64);
-                    if (j0 + u * G + grp >= nc) tv[u] = -1;
+                    tv[u] = have ? tj : -1;
+                    mine &= mine - 1ull;                                     // 0 stays 0
                 }
                 for (int d = gl; d < D; d += GS) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) v[u] = tv[u] >= 0 ? table[rv[u] * (int64_t)D + d] : 0.f;
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (tv[u] >= 0) acc[(grp * T + tv[u]) * D + d] += wv[u] * v[u];
+                        if (tv[u] >= 0) acc[tv[u] * D + d] += wv[u] * v[u];
                 }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (mean || cnt_out) {                              // entry counts per target: lane t walks the row (C is small)
-            for (int t = lane; t < T; t += 64) {
-                int n = 0;
-                for (int c = 0; c < C; ++c) n += seg[b * C + c] == t;
-                cnt[t] = (float)n;
-                if (cnt_out) cnt_out[b * T + t] = (float)n;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        if (cnt_out)
+            for (int t = lane; t < T; t += 64) cnt_out[b * T + t] = cnt[t];
         for (int i = lane; i < T * D; i += 64) {
-            float s = 0.f;
-            for (int g = 0; g < G; ++g) s += acc[g * T * D + i];
+            float s = acc[i];
             if (mean) {
                 const float n = cnt[i / D];
                 s = n > 0.f ? s / n : 0.f;
@@ -148,7 +149,7 @@ k_embed_pool_fwd(const float* __restrict__ table, int D, const int64_t* __restri
 static int pool_cfg(int T, int D, int* waves, size_t* lds) {
     int GS = 1;
     while (GS < D && GS < 64) GS <<= 1;
-    const size_t per_wave = ((size_t)(64 / GS) * T * D + T) * sizeof(float);
+    const size_t per_wave = ((size_t)T * D + T) * sizeof(float);
     int w = 4;
     while (w > 1 && per_wave * w > 64 * 1024) w >>= 1;
     if (per_wave * w > 64 * 1024) return RECNOW_EUNSUPPORTED;
