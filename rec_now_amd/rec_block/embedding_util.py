@@ -97,7 +97,7 @@ class _PoolFunction(torch.autograd.Function):
         B, C = seg.shape
         D = table.shape[1]
         dev = seg.device
-        out = torch.zeros((B, T, D), dtype=torch.float32, device=dev)
+        out = torch.empty((B, T, D), dtype=torch.float32, device=dev)       # every element is written by the kernel
         cnt = torch.empty((B, T), dtype=torch.float32, device=dev) if mean else None
         _lib.call('recnow_embed_pool_fwd', _lib.ptr(table), D, _lib.ptr(rows), _lib.ptr(seg), _lib.ptr(weights), B, C, T,
                   1 if mean else 0, _lib.ptr(out), _lib.ptr(cnt), _lib.stream())
