@@ -782,7 +782,7 @@ __device__ __forceinline__ void focal_terms(float z, float x, float alpha, float
     af = alpha > 0.f ? z * alpha + (1.f - z) * (1.f - alpha) : 1.f;
     p = rn_sigmoid(x);
     one_m_sim = 1.f - (z * p + (1.f - z) * (1.f - p));
-    mod = gamma > 0.f ? powf(one_m_sim, gamma) : 1.f;
+    mod = gamma == 2.f ? one_m_sim * one_m_sim : gamma == 1.f ? one_m_sim : gamma > 0.f ? powf(one_m_sim, gamma) : 1.f;   // gamma = 2 is the default
 }
 __global__ void __launch_bounds__(256)
 k_focal_fwd(const float* __restrict__ labels, const float* __restrict__ logits, int64_t B, float alpha, float gamma,
@@ -799,11 +799,19 @@ k_focal_fwd(const float* __restrict__ labels, const float* __restrict__ logits, 
     s = block_sum<double>(s, red);
     if (threadIdx.x == 0 && part) part[blockIdx.x] = s;
 }
-__global__ void k_focal_mean(const double* __restrict__ part, int n, int64_t B, float* __restrict__ mean) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += part[i];
-        *mean = (float)(s / (double)B);
+// fixed order: thread t adds partials t, t+256, ..., then the 256 sums are added in thread order (one thread walking all
+// partials was a chain of ~1000 dependent loads: 55 us, a third of the whole loss)
+__global__ void __launch_bounds__(256)
+k_focal_mean(const double* __restrict__ part, int n, int64_t B, float* __restrict__ mean) {
+    __shared__ double sums[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += sums[i];
+        *mean = (float)(t / (double)B);
     }
 }
 __global__ void __launch_bounds__(256)
@@ -817,7 +825,7 @@ k_focal_bwd(const float* __restrict__ labels, const float* __restrict__ logits, 
         float d = mod * (p - z);
         if (gamma > 0.f && !stop_w) {
             // d mod/dx = gamma (1-sim)^(gamma-1) * d(1-sim)/dx,  d(1-sim)/dx = -(2z-1) p (1-p)
-            const float pw = (oms > 0.f || gamma >= 1.f) ? powf(oms, gamma - 1.f) : 0.f;
+            const float pw = gamma == 2.f ? oms : gamma == 1.f ? 1.f : (oms > 0.f || gamma >= 1.f) ? powf(oms, gamma - 1.f) : 0.f;
             d += ce * gamma * pw * (-(2.f * z - 1.f) * p * (1.f - p));
         }
         dlogits[i] = af * d * (gelem ? gelem[i] * gsc : gsc);
@@ -843,7 +851,7 @@ extern "C" int recnow_focal_loss_fwd(const float* labels, const float* logits, i
     hipLaunchKernelGGL(k_focal_fwd, g, 256, 0, st, labels, logits, B, alpha, gamma, loss_elem, loss_mean ? (double*)ws : nullptr);
     RN_LAUNCH_CHECK();
     if (loss_mean) {
-        hipLaunchKernelGGL(k_focal_mean, 1, 64, 0, st, (const double*)ws, g, B, loss_mean);
+        hipLaunchKernelGGL(k_focal_mean, 1, 256, 0, st, (const double*)ws, g, B, loss_mean);
         RN_LAUNCH_CHECK();
     }
     return RECNOW_OK;

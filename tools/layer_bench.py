@@ -12,7 +12,7 @@ dev = torch.device('cuda:0')
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 
 
-def timeit(fn, n=reps, warm=3):
+def timeit(fn, n=reps, warm=10):
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,6 +23,27 @@ def timeit(fn, n=reps, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n          # ms
+
+
+def timeit_graph(fn, n=reps):
+    """The same step replayed from a captured HIP graph: no Python or launch overhead between kernels, i.e. the GPU time of
+    the step.  Returns None when the step cannot be captured (data-dependent host work)."""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return timeit(g.replay, n)
+    except Exception as e:          # noqa: BLE001
+        torch.cuda.synchronize()
+        print('   (graph capture not possible: %s)' % repr(e)[:120])
+        return None
 
 
 def fm():
@@ -39,6 +60,10 @@ def fm():
     ms = timeit(step)
     print('FMLayer fwd+bwd   B=%d F=%d D=%d : %.3f ms  %.0f GB/s algorithmic (12*B*F*D bytes)  %.1f M samples/s'
           % (B, F, D, ms, 12.0 * B * F * D / ms / 1e6, B / ms / 1e3))
+    mg = timeit_graph(step)
+    if mg:
+        print('   replayed from a HIP graph (no host time between the 2 kernels and autograd\'s 64 leaves): %.3f ms  %.0f GB/s'
+              % (mg, 12.0 * B * F * D / mg / 1e6))
 
 
 def dcn():
@@ -55,6 +80,9 @@ def dcn():
     ms = timeit(step)
     print('DCNLayer fwd+bwd  B=%d D=%d L=%d : %.3f ms  %.0f GB/s algorithmic (20*B*D bytes: x,y | x,dy,dx)  %.1f M samples/s'
           % (B, D, L, ms, 20.0 * B * D / ms / 1e6, B / ms / 1e3))
+    mg = timeit_graph(step)
+    if mg:
+        print('   replayed from a HIP graph (GPU time of the step): %.3f ms  %.0f GB/s' % (mg, 20.0 * B * D / mg / 1e6))
 
 
 def pairwise(B, G, tag):
@@ -73,6 +101,9 @@ def pairwise(B, G, tag):
     ms = timeit(step)
     P = float(npair[0].item())
     print('pairwise_loss %s B=%d groups=%d pairs=%d : %.3f ms  %.1f M rows/s  %.1f M pairs/s' % (tag, B, G, P, ms, B / ms / 1e3, P / ms / 1e3))
+    mg = timeit_graph(step)
+    if mg:
+        print('   replayed from a HIP graph (GPU time of the step): %.3f ms  %.1f M rows/s' % (mg, B / mg / 1e3))
 
 
 def listwise():
@@ -88,6 +119,9 @@ def listwise():
         listwise_loss_from_batch(g, y, s).backward()
     ms = timeit(step)
     print('listwise (fused)  B=%d groups=%d : %.3f ms  %.1f M rows/s' % (B, G, ms, B / ms / 1e3))
+    mg = timeit_graph(step)
+    if mg:
+        print('   replayed from a HIP graph (GPU time of the step): %.3f ms  %.1f M rows/s' % (mg, B / mg / 1e3))
 
 
 def cin():
@@ -148,6 +182,9 @@ def ipnn():
     ms = timeit(step)
     print('InnerPNN fwd+bwd  B=%d F=%d D=%d P=%d : %.3f ms  %.0f GB/s algorithmic (8*B*P + 12*B*F*D bytes)  %.1f M samples/s'
           % (B, F, D, P, ms, (8.0 * B * P + 12.0 * B * F * D) / ms / 1e6, B / ms / 1e3))
+    mg = timeit_graph(step)
+    if mg:
+        print('   replayed from a HIP graph (GPU time of the step): %.3f ms  %.0f GB/s' % (mg, (8.0 * B * P + 12.0 * B * F * D) / mg / 1e6))
 
 
 def senet():
@@ -165,6 +202,9 @@ def senet():
     ms = timeit(step)
     print('SENETLayer fwd+bwd B=%d F=%d D=%d : %.3f ms  %.0f GB/s algorithmic (24*B*F*D bytes: x x2 fwd, x dout x2 + dx bwd)  %.1f M samples/s'
           % (B, F, D, ms, 24.0 * B * F * D / ms / 1e6, B / ms / 1e3))
+    mg = timeit_graph(step)
+    if mg:
+        print('   replayed from a HIP graph (GPU time of the step): %.3f ms  %.0f GB/s' % (mg, 24.0 * B * F * D / mg / 1e6))
 
 
 def attn():
@@ -182,6 +222,9 @@ def attn():
     ms = timeit(step)
     print('attention_by_dot_product fwd+bwd B=%d L=%d D=%d : %.3f ms  %.0f GB/s algorithmic (12*B*L*D bytes)  %.1f M samples/s'
           % (B, L, D, ms, 12.0 * B * L * D / ms / 1e6, B / ms / 1e3))
+    mg = timeit_graph(step)
+    if mg:
+        print('   replayed from a HIP graph (GPU time of the step): %.3f ms  %.0f GB/s' % (mg, 12.0 * B * L * D / mg / 1e6))
 
 
 def focal():
@@ -195,6 +238,9 @@ def focal():
         focal_crossentropy_loss(z, x).backward()
     ms = timeit(step)
     print('focal_crossentropy_loss fwd+bwd B=%d : %.3f ms  %.0f GB/s algorithmic (20*B bytes)  %.0f M samples/s' % (B, ms, 20.0 * B / ms / 1e6, B / ms / 1e3))
+    mg = timeit_graph(step)
+    if mg:
+        print('   replayed from a HIP graph (GPU time of the step): %.3f ms  %.0f GB/s' % (mg, 20.0 * B / mg / 1e6))
 
 
 def embed():
