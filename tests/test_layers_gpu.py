@@ -624,7 +624,9 @@ def test_gemm_fuzz(dev, seed):
     (4096, 1024, 6, 1, False, None), (2048, 4096, 8, 1, False, 'tanh'),                         # narrow outputs -> MFMA GEMM
     (2048, 1024, 4, 2, False, 'tanh'), (1024, 512, 256, 2, False, 'tanh'),
     (1024, 512, 256, 2, True, 'tanh'), (8192, 256, 128, 1, False, 'sigmoid'),
-    (1000, 333, 77, 3, True, 'tanh'), (256, 2048, 512, 4, False, None)])
+    (1000, 333, 77, 3, True, 'tanh'), (256, 2048, 512, 4, False, None),
+    # narrow layers with a long batch (SENET's excitation MLP): register-tile weight gradient instead of the split-K GEMM
+    (5000, 64, 32, 1, False, 'tanh'), (4096, 32, 64, 1, False, None), (9001, 128, 32, 1, False, 'sigmoid'), (4500, 16, 16, 1, False, 'relu')])
 def test_multi_dense_shape_sweep(dev, B, D, U, N, batched, act):
     test_multi_dense_fwd_bwd_vs_oracle(dev, B, D, U, N, batched, act)
 
