@@ -743,6 +743,89 @@ static inline int attn_grid(int64_t B, int gs) {
     if (g > 8192) g = 8192;
     return (int)(g > 0 ? g : 1);
 }
+// float4 variants for D % 4 == 0, CPL = D/4 in {1, 2, 4, 8, 16}: 16 lanes per batch row (4 rows per wave) walk the row's
+// L*D contiguous floats as float4 pieces -- 256 contiguous bytes per row and load instruction, ATTN_V4 independent loads in
+// flight per lane -- so piece k = lane + 16*i belongs to position l = k / CPL and columns 4*(k % CPL)..+3, and k % CPL is the
+// same for every piece of a lane.  A score needs a reduce over only the CPL lanes of one position (log2 CPL shuffles, not
+// log2 D), the column sums over positions are reduced once at the end.  (One dword per lane and position, with a full
+// shuffle tree per position, ran at 2.9 TB/s.)
+#define ATTN_V4 4
+typedef float attn_f4 __attribute__((ext_vector_type(4)));
+template <int CPL, bool BWD>
+__global__ void __launch_bounds__(256)
+k_attn_dot_v4(const float* __restrict__ user, const float* __restrict__ doc, const float* __restrict__ dmat,
+              const float* __restrict__ dsum, int64_t B, int L, int filter_neg, float* __restrict__ out_vec /* mat | ddoc */,
+              float* __restrict__ ssum, float* __restrict__ duser) {
+    constexpr int D = 4 * CPL;
+    const int lane = threadIdx.x & 63, gl = lane & 15, gr = lane >> 4;
+    const int c = gl % CPL;
+    const int64_t nrg = (B + 3) / 4;
+    const int nv = L * CPL;                                     // float4 pieces per row
+    for (int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); rg < nrg; rg += (int64_t)gridDim.x * 4) {
+        const int64_t b = rg * 4 + gr;
+        const bool ok = b < B;
+        const attn_f4* u4 = reinterpret_cast<const attn_f4*>(user + (ok ? b : 0) * (int64_t)L * D);
+        attn_f4* du4 = BWD ? reinterpret_cast<attn_f4*>(duser + (ok ? b : 0) * (int64_t)L * D) : nullptr;
+        const attn_f4 zero = {0.f, 0.f, 0.f, 0.f};
+        const attn_f4 dcv = ok ? *reinterpret_cast<const attn_f4*>(doc + b * D + 4 * c) : zero;
+        const attn_f4 gmv = (BWD && ok && dmat) ? *reinterpret_cast<const attn_f4*>(dmat + b * D + 4 * c) : zero;
+        const float gs = (BWD && ok && dsum) ? dsum[b] : 0.f;
+        attn_f4 acc = zero;
+        float tot = 0.f;
+        for (int k0 = 0; k0 < nv; k0 += 16 * ATTN_V4) {
+            attn_f4 uv[ATTN_V4];
+#pragma unroll
+            for (int i = 0; i < ATTN_V4; ++i) {
+                const int k = k0 + 16 * i + gl;
+                uv[i] = (ok && k < nv) ? u4[k] : zero;
+            }
+#pragma unroll
+            for (int i = 0; i < ATTN_V4; ++i) {
+                const int k = k0 + 16 * i + gl;
+                float p = (uv[i].x * dcv.x + uv[i].y * dcv.y) + (uv[i].z * dcv.z + uv[i].w * dcv.w);
+                float q = BWD ? (uv[i].x * gmv.x + uv[i].y * gmv.y) + (uv[i].z * gmv.z + uv[i].w * gmv.w) : 0.f;
+#pragma unroll
+                for (int o = CPL / 2; o > 0; o >>= 1) {
+                    p += __shfl_xor(p, o, 64);
+                    if (BWD) q += __shfl_xor(q, o, 64);
+                }
+                float sc = p;
+                if (filter_neg) sc = fmaxf(p, 0.f);
+                if (!BWD) {
+                    if (c == 0) tot += sc;                      // pieces past the row are zero: they add nothing
+                    acc += uv[i] * sc;
+                } else {
+                    float ds = q + gs;
+                    if (filter_neg && !(p > 0.f)) ds = 0.f;
+                    if (ok && k < nv) du4[k] = gmv * sc + dcv * ds;
+                    acc += uv[i] * ds;
+                }
+            }
+        }
+        // columns 4c..4c+3 were accumulated by the LPR lanes c, c + CPL, ...: add them up (and the score total of the c == 0 lanes)
+#pragma unroll
+        for (int o = CPL; o < 16; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+            if (!BWD) tot += __shfl_xor(tot, o, 64);
+        }
+        if (ok && gl < CPL) *reinterpret_cast<attn_f4*>(out_vec + b * D + 4 * c) = acc;
+        if (!BWD && ok && gl == 0) ssum[b] = tot;
+    }
+}
+static inline int attn_cpl(int D, const void* a, const void* b2, const void* c2, const void* d2) {
+    if (D % 4 || ((((uintptr_t)a | (uintptr_t)b2 | (uintptr_t)c2 | (uintptr_t)d2) & 15) != 0)) return 0;
+    const int cpl = D / 4;
+    return (cpl == 1 || cpl == 2 || cpl == 4 || cpl == 8 || cpl == 16) ? cpl : 0;
+}
+#define ATTN_V4_LAUNCH(BWD, ...)                                                                                          \
+    switch (cpl) {                                                                                                       \
+        case 1: hipLaunchKernelGGL((k_attn_dot_v4<1, BWD>), attn_grid(B, 16), 256, 0, st, __VA_ARGS__); break;           \
+        case 2: hipLaunchKernelGGL((k_attn_dot_v4<2, BWD>), attn_grid(B, 16), 256, 0, st, __VA_ARGS__); break;           \
+        case 4: hipLaunchKernelGGL((k_attn_dot_v4<4, BWD>), attn_grid(B, 16), 256, 0, st, __VA_ARGS__); break;           \
+        case 8: hipLaunchKernelGGL((k_attn_dot_v4<8, BWD>), attn_grid(B, 16), 256, 0, st, __VA_ARGS__); break;           \
+        default: hipLaunchKernelGGL((k_attn_dot_v4<16, BWD>), attn_grid(B, 16), 256, 0, st, __VA_ARGS__); break;         \
+    }
 extern "C" int recnow_attention_dot_fwd(const float* user, const float* doc, int64_t B, int L, int D, int filter_neg, float* mat,
                                         float* score_sum, void* stream) {
     if (B < 0 || L < 0 || D < 1) return RECNOW_EINVAL;
@@ -750,6 +833,11 @@ extern "C" int recnow_attention_dot_fwd(const float* user, const float* doc, int
     if (B == 0) return RECNOW_OK;
     if ((L > 0 && !user) || !doc || !mat || !score_sum) return RECNOW_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (const int cpl = attn_cpl(D, user, doc, mat, nullptr)) {
+        ATTN_V4_LAUNCH(false, user, doc, (const float*)nullptr, (const float*)nullptr, B, L, filter_neg, mat, score_sum, (float*)nullptr);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
     if (D <= 16) hipLaunchKernelGGL(k_attn_dot_fwd<16>, attn_grid(B, 16), 256, 0, st, user, doc, B, L, D, filter_neg, mat, score_sum);
     else if (D <= 32) hipLaunchKernelGGL(k_attn_dot_fwd<32>, attn_grid(B, 32), 256, 0, st, user, doc, B, L, D, filter_neg, mat, score_sum);
     else hipLaunchKernelGGL(k_attn_dot_fwd<64>, attn_grid(B, 64), 256, 0, st, user, doc, B, L, D, filter_neg, mat, score_sum);
@@ -763,6 +851,11 @@ extern "C" int recnow_attention_dot_bwd(const float* user, const float* doc, con
     if (B == 0) return RECNOW_OK;
     if ((L > 0 && (!user || !duser)) || !doc || !ddoc) return RECNOW_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (const int cpl = attn_cpl(D, user, doc, dmat, (const void*)((uintptr_t)duser | (uintptr_t)ddoc))) {
+        ATTN_V4_LAUNCH(true, user, doc, dmat, dsum, B, L, filter_neg, ddoc, (float*)nullptr, duser);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
     if (D <= 16) hipLaunchKernelGGL(k_attn_dot_bwd<16>, attn_grid(B, 16), 256, 0, st, user, doc, dmat, dsum, B, L, D, filter_neg, duser, ddoc);
     else if (D <= 32) hipLaunchKernelGGL(k_attn_dot_bwd<32>, attn_grid(B, 32), 256, 0, st, user, doc, dmat, dsum, B, L, D, filter_neg, duser, ddoc);
     else hipLaunchKernelGGL(k_attn_dot_bwd<64>, attn_grid(B, 64), 256, 0, st, user, doc, dmat, dsum, B, L, D, filter_neg, duser, ddoc);

@@ -120,7 +120,10 @@ def test_attention_by_dot_product_reference_literals(dev):
         assert calc_sum_of_abs_diff(attn_score, true_attn_score) < 1e-5
 
 
-@pytest.mark.parametrize('B,L,D,filter_neg', [(1, 1, 1, False), (33, 7, 16, True), (257, 50, 64, False), (5, 3, 200, True), (4, 0, 8, False)])
+@pytest.mark.parametrize('B,L,D,filter_neg', [(1, 1, 1, False), (33, 7, 16, True), (257, 50, 64, False), (5, 3, 200, True), (4, 0, 8, False),
+                                             # the float4 kernels: every lanes-per-position count, ragged piece counts, rows % 4 != 0
+                                             (131, 50, 16, True), (66, 5, 4, False), (39, 9, 8, True), (70, 11, 32, False), (7, 1, 16, True),
+                                             (1026, 65, 16, False), (35, 6, 12, True)])
 def test_attention_by_dot_product_fwd_bwd_vs_oracle(dev, B, L, D, filter_neg):
     from rec_now_amd.rec_block.attention import attention_by_dot_product
     rng = np.random.default_rng(B + L + D)
