@@ -136,6 +136,81 @@ k_small_xty(const float* __restrict__ x, const float* __restrict__ dy, const flo
     for (int q = 0; q < NQ; ++q) dst[q] = acc[q];
 }
 
+// Forward and input gradient of the same narrow layers: out[B][NO] = in'[B][KI] * Wm (+ bias, activation), with
+//   forward : in' = x,                    Wm[k][n] = kernel[k][n]        (KI = D, NO = U)
+//   dx      : in' = dy * act'(y) (zmode), Wm[k][n] = kernel[n][k]        (KI = U, NO = D)
+// The (B, 64) x (64, 16)-sized products moved 40 MB in 46-64 us as one-column-tile GEMMs; here a workgroup takes 64 rows:
+// the input tile and the whole weight matrix sit in LDS, a thread owns NO/4 outputs of one row.
+#define ND_ROWS 64
+static inline bool narrow_ok(int64_t B, int D, int U, int N) {
+    return N == 1 && B >= 4096 && D % 4 == 0 && U % 4 == 0 && D <= 128 && U <= 128 && (int64_t)D * U <= 4096;
+}
+template <int NQ>                                  // outputs per thread = NO / 4, NO = 4 * NQ
+__global__ void __launch_bounds__(256)
+k_narrow_dense(const float* __restrict__ in, const float* __restrict__ in2, int zmode, int in_act, const float* __restrict__ w,
+               int w_trans, const float* __restrict__ bias, int act, int64_t B, int KI, float* __restrict__ out) {
+    constexpr int NO = 4 * NQ;
+    extern __shared__ __attribute__((aligned(16))) float nd_lds[];
+    float* ws = nd_lds;                            // [KI][NO]
+    float* xs = ws + KI * NO;                      // [ND_ROWS][KI + 1], later the [ND_ROWS][NO] results (KI * NO % 4 == 0: 16-byte aligned)
+    const int LDX = KI + 1;
+    for (int i = threadIdx.x; i < KI * NO; i += 256) {
+        const int k = i / NO, n = i - k * NO;
+        ws[i] = w_trans ? w[n * KI + k] : w[i];
+    }
+    const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * NQ;
+    float bv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bv[q] = bias ? bias[c0 + q] : 0.f;
+    for (int64_t b0 = (int64_t)blockIdx.x * ND_ROWS; b0 < B; b0 += (int64_t)gridDim.x * ND_ROWS) {
+        const int rows = (int)min((int64_t)ND_ROWS, B - b0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < ND_ROWS * KI; i += 256) {
+            const int rr = i / KI, k = i - rr * KI;
+            float v = 0.f;
+            if (rr < rows) {
+                v = in[b0 * KI + i];
+                if (zmode == RECNOW_OPMODE_ACTGRAD) v *= rn_act_grad_from_out(in2[b0 * KI + i], in_act);
+            }
+            xs[rr * LDX + k] = v;
+        }
+        __syncthreads();
+        float acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = bv[q];
+        for (int k = 0; k < KI; ++k) {
+            const float xv = xs[r * LDX + k];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] += xv * ws[k * NO + c0 + q];
+        }
+        // the 64 x NO results are ONE contiguous block of `out`: hand them over through LDS (over the dead input tile) so that
+        // the stores are whole coalesced runs instead of NQ dwords per lane at a 4*NO-byte stride
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xs[r * NO + c0 + q] = rn_act(acc[q], act);
+        __syncthreads();
+        float* o = out + b0 * NO;
+        for (int i = threadIdx.x * 4; i < rows * NO; i += 1024) *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(xs + i);
+    }
+}
+static int narrow_dense(const float* in, const float* in2, int zmode, int in_act, const float* w, int w_trans, const float* bias,
+                        int act, int64_t B, int KI, int NO, float* out, hipStream_t st) {
+    int64_t g = (B + ND_ROWS - 1) / ND_ROWS;
+    if (g > 2048) g = 2048;
+    const size_t lds = ((size_t)KI * NO + (size_t)ND_ROWS * (KI + 1 > NO ? KI + 1 : NO)) * sizeof(float);
+#define ND_CASE(Q) case Q: hipLaunchKernelGGL(k_narrow_dense<Q>, (int)g, 256, lds, st, in, in2, zmode, in_act, w, w_trans, bias, act, B, KI, out); break;
+    switch (NO / 4) {
+        ND_CASE(1) ND_CASE(2) ND_CASE(3) ND_CASE(4) ND_CASE(5) ND_CASE(6) ND_CASE(7) ND_CASE(8) ND_CASE(9) ND_CASE(10) ND_CASE(11)
+        ND_CASE(12) ND_CASE(13) ND_CASE(14) ND_CASE(15) ND_CASE(16) ND_CASE(17) ND_CASE(18) ND_CASE(19) ND_CASE(20) ND_CASE(21)
+        ND_CASE(22) ND_CASE(23) ND_CASE(24) ND_CASE(25) ND_CASE(26) ND_CASE(27) ND_CASE(28) ND_CASE(29) ND_CASE(30) ND_CASE(31)
+        ND_CASE(32)
+        default: return RECNOW_EUNSUPPORTED;
+    }
+#undef ND_CASE
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
 // ---- MultiDense ------------------------------------------------------------------------------------------
 extern "C" size_t recnow_multi_dense_workspace_bytes(int64_t B, int D, int U, int N) {
     if (B <= 0 || D <= 0 || U <= 0 || N <= 0) return 256;
@@ -169,6 +244,7 @@ extern "C" int recnow_multi_dense_fwd(const float* x, int x_batched, const float
         RN_LAUNCH_CHECK();
         return RECNOW_OK;
     }
+    if (narrow_ok(B, D, U, N)) return narrow_dense(x, nullptr, RECNOW_OPMODE_NONE, 0, kernel, 0, bias, act, B, D, U, y, (hipStream_t)stream);
     recnow_gemm_desc d = rn_gemm_desc_zero();
     d.A = x; d.lda = D; d.a_batch_stride = x_batched ? B * D : 0; d.a_trans = 0;
     d.B = kernel; d.ldb = U; d.b_batch_stride = (int64_t)D * U; d.b_trans = 0;
@@ -241,7 +317,9 @@ extern "C" int recnow_multi_dense_bwd(const float* x, int x_batched, const float
                                 ws_bytes, st)))
                 return rc;
     }
-    if (dx) {        // dx[n] = dZ[n] kernel[n]^T
+    if (dx && narrow_ok(B, D, U, N)) {
+        if ((rc = narrow_dense(dy, y, zmode, act, kernel, 1, nullptr, RECNOW_ACT_LINEAR, B, U, D, dx, st))) return rc;
+    } else if (dx) {        // dx[n] = dZ[n] kernel[n]^T
         recnow_gemm_desc d = rn_gemm_desc_zero();
         d.A = dy; d.A2 = y; d.a_mode = zmode; d.a_act = act; d.lda = U; d.a_trans = 0;
         d.B = kernel; d.ldb = U; d.b_trans = 1;            // kernel[n] stored [D][U] = [N_out][K]
