@@ -1,4 +1,5 @@
-"""Random-shape sweep of the widened rows (InnerPNN, SENET, pooled embedding lookup) against the oracle on the GPU.
+"""Random-shape sweep of the widened rows (InnerPNN, SENET, attention, focal loss, pooled embedding lookup) and of the
+narrow MultiDense kernels against the oracle on the GPU.
 Not part of the test suite (minutes of small launches); usage: python tools/fuzz_widened.py [n_cases] [seed]"""
 import os
 import sys
@@ -12,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import test_embedding_gpu as TE      # noqa: E402
 import test_interact_gpu as TI       # noqa: E402
+import test_layers_gpu as TL         # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -36,5 +38,27 @@ for i in range(n):
     except Exception as e:          # noqa: BLE001
         bad += 1
         print('embedding FAIL', B, C, T, De, V, repr(e)[:200])
+    try:
+        F2 = int(rng.integers(1, 40))
+        same = bool(rng.integers(0, 2))
+        dims = [int(rng.choice([4, 8, 16]))] * F2 if same else [int(rng.integers(1, 20)) for _ in range(F2)]
+        Bs = int(rng.choice([1, 3, 64, 257, 4100, 5000]))
+        TI.test_senet_fwd_bwd_vs_oracle(dev, Bs, dims, float(rng.choice([0.25, 0.5, 1.0])), bool(rng.integers(0, 2)))
+    except Exception as e:          # noqa: BLE001
+        bad += 1
+        print('SENET FAIL', Bs, dims[:4], len(dims), repr(e)[:200])
+    try:
+        La, Da = int(rng.integers(0, 70)), int(rng.choice([1, 4, 8, 12, 16, 20, 32, 64, 100]))
+        TI.test_attention_by_dot_product_fwd_bwd_vs_oracle(dev, B, La, Da, bool(rng.integers(0, 2)))
+    except Exception as e:          # noqa: BLE001
+        bad += 1
+        print('attention FAIL', B, La, Da, repr(e)[:200])
+    try:
+        Dm, Um = int(rng.choice([4, 8, 16, 32, 64, 128])), int(rng.choice([4, 8, 16, 32, 64, 128]))
+        Bm = int(rng.choice([4096, 4100, 6001]))
+        TL.test_multi_dense_shape_sweep(dev, Bm, Dm, Um, 1, False, [None, 'tanh', 'relu', 'sigmoid'][int(rng.integers(0, 4))])
+    except Exception as e:          # noqa: BLE001
+        bad += 1
+        print('multi_dense FAIL', Bm, Dm, Um, repr(e)[:200])
 print('cases', n, 'failures', bad)
 sys.exit(1 if bad else 0)
