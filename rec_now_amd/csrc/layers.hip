@@ -87,23 +87,25 @@ static inline int xty_blocks(int64_t B) {
     return (int)(g > 1024 ? 1024 : g);
 }
 static inline size_t xty_ws_bytes(int64_t B, int D, int U) {
-    return rn_align((size_t)xty_blocks(B) * D * U * sizeof(float)) + rn_colsum_ws_bytes(xty_blocks(B), (int64_t)D * U);
+    return rn_align((size_t)xty_blocks(B) * D * U * sizeof(float)) + rn_align((size_t)xty_blocks(B) * U * sizeof(float)) +
+           rn_colsum_ws_bytes(xty_blocks(B), (int64_t)D * U);
 }
 // thread t owns outputs [t*NQ, t*NQ + NQ) of the row-major (D, U) result: one row m, NQ consecutive columns -- per batch
 // row that is one x value and NQ/4 float4 pieces of dZ from LDS for NQ FMAs
 template <int NQ>
 __global__ void __launch_bounds__(256)
 k_small_xty(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y, int zmode, int act, int64_t B,
-            int D, int U, float* __restrict__ part) {
+            int D, int U, float* __restrict__ part, float* __restrict__ part_b /* optional [blocks][U]: column sums of dZ (bias gradient) */) {
     extern __shared__ __attribute__((aligned(16))) float xty_lds[];
     float* zs = xty_lds;                       // [XTY_ROWS][U]   (first: 16-byte aligned rows, U % 4 == 0 whenever NQ >= 4)
     float* xs = zs + XTY_ROWS * U;             // [XTY_ROWS][D]
     const int64_t per = (B + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(B, r0 + per);
     const int o0 = threadIdx.x * NQ, m = o0 / U, n0 = o0 % U;
-    float acc[NQ];
+    float acc[NQ], bz[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+    for (int q = 0; q < NQ; ++q) acc[q] = bz[q] = 0.f;
+    const float first = (part_b && m == 0) ? 1.f : 0.f;          // the threads of row 0 of dkernel also add up their dZ columns
     for (int64_t c0 = r0; c0 < r1; c0 += XTY_ROWS) {
         const int rows = (int)min((int64_t)XTY_ROWS, r1 - c0);
         __syncthreads();
@@ -124,16 +126,25 @@ k_small_xty(const float* __restrict__ x, const float* __restrict__ dy, const flo
                 for (int q = 0; q < NQ; q += 4) {
                     const float4 z = *reinterpret_cast<const float4*>(zs + r * U + n0 + q);
                     acc[q] += xv * z.x; acc[q + 1] += xv * z.y; acc[q + 2] += xv * z.z; acc[q + 3] += xv * z.w;
+                    bz[q] += first * z.x; bz[q + 1] += first * z.y; bz[q + 2] += first * z.z; bz[q + 3] += first * z.w;
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q] += xv * zs[r * U + n0 + q];
+                for (int q = 0; q < NQ; ++q) {
+                    const float z = zs[r * U + n0 + q];
+                    acc[q] += xv * z;
+                    bz[q] += first * z;
+                }
             }
         }
     }
     float* dst = part + (int64_t)blockIdx.x * D * U + o0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) dst[q] = acc[q];
+    if (part_b && m == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) part_b[(int64_t)blockIdx.x * U + n0 + q] = bz[q];
+    }
 }
 
 // Forward and input gradient of the same narrow layers: out[B][NO] = in'[B][KI] * Wm (+ bias, activation), with
@@ -291,18 +302,23 @@ extern "C" int recnow_multi_dense_bwd(const float* x, int x_batched, const float
         if (ws_bytes < xty_ws_bytes(B, D, U)) return RECNOW_EWORKSPACE;
         const int nb = xty_blocks(B);
         float* part = (float*)ws;
-        char* cws = (char*)ws + rn_align((size_t)nb * D * U * sizeof(float));
+        float* part_b = dbias ? (float*)((char*)ws + rn_align((size_t)nb * D * U * sizeof(float))) : nullptr;
+        char* cws = (char*)ws + rn_align((size_t)nb * D * U * sizeof(float)) + rn_align((size_t)nb * U * sizeof(float));
         const size_t lds = (size_t)XTY_ROWS * (D + U) * sizeof(float);
         switch (D * U / 256) {
-            case 1: hipLaunchKernelGGL(k_small_xty<1>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part); break;
-            case 2: hipLaunchKernelGGL(k_small_xty<2>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part); break;
-            case 4: hipLaunchKernelGGL(k_small_xty<4>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part); break;
-            case 8: hipLaunchKernelGGL(k_small_xty<8>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part); break;
-            default: hipLaunchKernelGGL(k_small_xty<16>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part); break;
+            case 1: hipLaunchKernelGGL(k_small_xty<1>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part, part_b); break;
+            case 2: hipLaunchKernelGGL(k_small_xty<2>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part, part_b); break;
+            case 4: hipLaunchKernelGGL(k_small_xty<4>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part, part_b); break;
+            case 8: hipLaunchKernelGGL(k_small_xty<8>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part, part_b); break;
+            default: hipLaunchKernelGGL(k_small_xty<16>, nb, 256, lds, st, x, dy, y, zmode, act, B, D, U, part, part_b); break;
         }
         RN_LAUNCH_CHECK();
         if ((rc = rn_colsum(part, nullptr, 0, 0, nb, (int64_t)D * U, (int64_t)D * U, dkernel, 0, cws, ws_bytes - (size_t)(cws - (char*)ws), st)))
             return rc;
+        if (dbias) {                              // the same pass produced per-workgroup column sums of dZ
+            if ((rc = rn_colsum(part_b, nullptr, 0, 0, nb, U, U, dbias, 0, cws, ws_bytes - (size_t)(cws - (char*)ws), st))) return rc;
+            dbias = nullptr;
+        }
     } else if (dkernel) {   // dkernel[n] = x[n]^T dZ[n]      (D x U), K = B, split-K
         recnow_gemm_desc d = rn_gemm_desc_zero();
         d.A = x; d.lda = D; d.a_batch_stride = x_batched ? B * D : 0; d.a_trans = 1;
