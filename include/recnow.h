@@ -357,6 +357,22 @@ int recnow_senet_scale_bwd_w(const float* const* fields, const int32_t* dims, co
 int recnow_senet_scale_bwd_x(float* const* dfields, const int32_t* dims, const int32_t* offs, int F, int total, int64_t B,
                              const float* w, const float* dout, const float* dsq, int uniform_d, void* stream);
 
+/* SENETLayer in one pass per direction (senet_layer.py:93-119), for equal field widths D (D % 4 == 0, D/4 a power of two,
+ * F*D/4 <= 256), F <= 64, hidden width M <= 64 and RECNOW_ACT_* activations: squeeze, the F -> M -> F excitation and the
+ * scaling read the fields once.  W1 (F,M), b1 (M), W2 (M,F), b2 (F) row-major (b1 / b2 may be NULL).
+ *   fwd: out (B, F*D); saves sq (B,F), h (B,M) = act1(sq W1 + b1), w (B,F) = act2(h W2 + b2) for the backward pass.
+ *   bwd: dfields[f] (B,D), dW1, db1, dW2, db2 (db1 / db2 may be NULL); deterministic (fixed-order partial sums).
+ * recnow_senet_fused_supported returns 1 when (F, D, M) is inside these limits. */
+int recnow_senet_fused_supported(int F, int D, int M);
+size_t recnow_senet_fused_workspace_bytes(int64_t B, int F, int M);
+int recnow_senet_fused_fwd(const float* const* fields, int F, int D, int64_t B, const float* W1, const float* b1, const float* W2,
+                           const float* b2, int M, int act1, int act2, float* out, float* sq_save, float* h_save, float* w_save,
+                           void* stream);
+int recnow_senet_fused_bwd(const float* const* fields, float* const* dfields, int F, int D, int64_t B, const float* W1,
+                           const float* W2, int M, int act1, int act2, const float* dout, const float* sq_save,
+                           const float* h_save, const float* w_save, float* dW1, float* db1, float* dW2, float* db2, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* attention_by_dot_product: rec_now/rec_block/attention.py:12-38.  user (B,L,D), doc (B,D), D <= 256:
  *   s_l = <user[b][l], doc[b]> (max(.,0) when filter_neg, :31-32);  mat[b] = sum_l user[b][l] * s_l;  score_sum[b] = sum_l s_l
  * Backward recomputes s; dmat (B,D) / dsum (B) may be NULL (no gradient from that output). */

@@ -63,6 +63,10 @@ SIGNATURES = {
     'recnow_senet_scale_fwd': (_I, [_P, _P, _P, _I, _I, _L, _P, _P, _I, _P]),
     'recnow_senet_scale_bwd_w': (_I, [_P, _P, _P, _I, _I, _L, _P, _P, _I, _P]),
     'recnow_senet_scale_bwd_x': (_I, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _I, _P]),
+    'recnow_senet_fused_supported': (_I, [_I, _I, _I]),
+    'recnow_senet_fused_workspace_bytes': (_Z, [_L, _I, _I]),
+    'recnow_senet_fused_fwd': (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'recnow_senet_fused_bwd': (_I, [_P, _P, _I, _I, _L, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'recnow_attention_dot_fwd': (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'recnow_attention_dot_bwd': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'recnow_focal_loss_workspace_bytes': (_Z, [_L]),

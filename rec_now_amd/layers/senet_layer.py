@@ -80,6 +80,49 @@ class _SenetFunction(torch.autograd.Function):
         return (None, None) + tuple(grads[1:]) + tuple(dxs)
 
 
+class _SenetFused(torch.autograd.Function):
+    """The whole layer as one kernel per direction (recnow_senet_fused_*): equal field widths, built-in activations, small
+    F and hidden width.  Inputs: the two Dense kernels (+ biases or None), then the fields."""
+
+    @staticmethod
+    def forward(ctx, act1, act2, w1, b1, w2, b2, *fields):
+        xs = [_lib.f32c(x, 'SENET input') for x in fields]
+        B, D = xs[0].shape
+        F, M = len(xs), w1.shape[1]
+        dev = xs[0].device
+        w1c, w2c = _lib.f32c(w1.detach(), 'kernel'), _lib.f32c(w2.detach(), 'kernel')
+        b1c = _lib.f32c(b1.detach(), 'bias') if b1 is not None else None
+        b2c = _lib.f32c(b2.detach(), 'bias') if b2 is not None else None
+        out = torch.empty((B, F * D), dtype=torch.float32, device=dev)
+        sq = torch.empty((B, F), dtype=torch.float32, device=dev)
+        h = torch.empty((B, M), dtype=torch.float32, device=dev)
+        w = torch.empty((B, F), dtype=torch.float32, device=dev)
+        ptrs = _lib.ptr_array(xs, dev)
+        _lib.call('recnow_senet_fused_fwd', _lib.ptr(ptrs), F, D, B, _lib.ptr(w1c), _lib.ptr(b1c), _lib.ptr(w2c), _lib.ptr(b2c), M,
+                  act1, act2, _lib.ptr(out), _lib.ptr(sq), _lib.ptr(h), _lib.ptr(w), _lib.stream())
+        ctx.save_for_backward(w1c, w2c, sq, h, w, *xs)
+        ctx.meta = (act1, act2, b1 is not None, b2 is not None, ptrs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w1c, w2c, sq, h, w, *xs = ctx.saved_tensors
+        act1, act2, has_b1, has_b2, ptrs = ctx.meta
+        B, D = xs[0].shape
+        F, M = len(xs), w1c.shape[1]
+        dev = dout.device
+        dout = _lib.f32c(dout, 'grad')
+        dx = torch.empty((F, B, D), dtype=torch.float32, device=dev)
+        dw1, dw2 = torch.empty_like(w1c), torch.empty_like(w2c)
+        db1 = torch.empty(M, dtype=torch.float32, device=dev) if has_b1 else None
+        db2 = torch.empty(F, dtype=torch.float32, device=dev) if has_b2 else None
+        ws = _lib.workspace(_lib.load().recnow_senet_fused_workspace_bytes(B, F, M), dev)
+        _lib.call('recnow_senet_fused_bwd', _lib.ptr(ptrs), _lib.ptr(_lib.block_ptr_array(dx, F)), F, D, B, _lib.ptr(w1c), _lib.ptr(w2c), M,
+                  act1, act2, _lib.ptr(dout), _lib.ptr(sq), _lib.ptr(h), _lib.ptr(w), _lib.ptr(dw1), _lib.ptr(db1), _lib.ptr(dw2),
+                  _lib.ptr(db2), _lib.ptr(ws), ws.numel(), _lib.stream())
+        return (None, None, dw1, db1, dw2, db2) + tuple(dx.unbind(0))
+
+
 class _Dense(Layer):
     """keras.layers.Dense(units, activation, use_bias, ...) of the excitation MLP (:52-65) on recnow_multi_dense (N = 1)."""
 
@@ -150,5 +193,22 @@ class SENETLayer(DenseBase):
         """inputs: list of F tensors (B, Df) (a single tensor is wrapped, :101-102).  Returns (B, total_dim)."""
         if not isinstance(inputs, (list, tuple)):
             inputs = [inputs]
+        fused = self._fused_plan(inputs)
+        if fused is not None:
+            d0, d1 = self.senet
+            return _SenetFused.apply(fused[0], fused[1], d0.kernel, d0.bias, d1.kernel, d1.bias, *inputs)
         params = [p for layer in self.senet for p in layer.parameters()]
         return _SenetFunction.apply(self._excite, len(params), *params, *inputs)
+
+    def _fused_plan(self, inputs):
+        """(act1, act2) codes when the one-kernel-per-direction path applies: equal widths inside the kernel's limits,
+        built-in activations, 16-byte aligned fp32 CUDA fields."""
+        d0, d1 = self.senet
+        if d0.act_code is None or d1.act_code is None:
+            return None
+        x0 = inputs[0]
+        if not all(isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 2 and x.shape == x0.shape for x in inputs):
+            return None
+        if not _lib.load().recnow_senet_fused_supported(len(inputs), int(x0.shape[1]), int(d0.units)):
+            return None
+        return d0.act_code, d1.act_code
