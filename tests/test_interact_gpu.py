@@ -77,7 +77,11 @@ def test_senet_reference_golden(dev, golden):
 
 
 @pytest.mark.parametrize('B,dims,ratio,use_bias', [(7, [1, 2, 3], 0.3, True), (300, [16] * 24, 0.25, True), (65, [4, 8, 4, 32, 1], 0.9, False),
-                                                   (1, [5], 1.0, True)])
+                                                   (1, [5], 1.0, True),
+                                                   # the one-pass kernels: no bias, rows % 4 != 0, widest / narrowest shapes they take, one
+                                                   # field, hidden width 1; and shapes just outside (F > 64, F*D/4 > 256) on the unfused path
+                                                   (1001, [16] * 64, 1.0, False), (6, [4] * 64, 0.5, True), (130, [64] * 16, 0.1, True),
+                                                   (9, [8], 1.0, True), (33, [4] * 3, 0.2, False), (50, [4] * 65, 0.5, True), (20, [32] * 40, 0.25, True)])
 def test_senet_fwd_bwd_vs_oracle(dev, B, dims, ratio, use_bias):
     from rec_now_amd.layers.senet_layer import SENETLayer
     rng = np.random.default_rng(B + len(dims))
