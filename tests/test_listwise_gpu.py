@@ -168,3 +168,40 @@ def test_full_size_properties_config5(dev):
     assert np.abs(gsum).max() < 1e-8
     loss2 = M.listwise_loss_from_batch(gd, yd, sd.detach())
     assert loss2.item() == loss.item()
+
+
+def test_skewed_group_sizes_vs_oracle(dev):
+    """Zipf(1.2) list lengths capped at 2048 (one list spans many waves' worth of rows, most lists are singletons and
+    therefore invalid): fused loss / gradient against the dense fp64 oracle."""
+    M = _mod()
+    rng = np.random.default_rng(9)
+    B = 6000
+    sizes = []
+    while sum(sizes) < B:
+        sizes.append(int(min(rng.zipf(1.2), 2048, B - sum(sizes))))
+    g = np.repeat(np.arange(len(sizes)), sizes)
+    rng.shuffle(g)
+    g = g.astype(np.float32)
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    s = rng.normal(size=B).astype(np.float32)
+    s64 = torch.from_numpy(s).double().requires_grad_(True)
+    rm, rl, rz = R.to_listwise_sample(torch.from_numpy(g), torch.from_numpy(y).double(), s64)
+    rloss = R.listwise_loss_via_softmax_cross_entropy_with_logits(rl, rz)
+    rloss.backward()
+    sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+    loss, nv = M.listwise_loss_from_batch(torch.from_numpy(g).to(dev), torch.from_numpy(y).to(dev), sd, return_num_list=True)
+    loss.backward()
+    assert int(nv.item()) == rl.shape[0] > 0
+    assert abs(loss.item() - rloss.item()) <= RTOL * abs(rloss.item())
+    assert np.abs(sd.grad.cpu().numpy() - s64.grad.numpy()).max() <= RTOL * np.abs(s64.grad.numpy()).max()
+
+
+def test_empty_batch(dev):
+    """B = 0: no list at all -> the mean over zero lists is NaN in the reference and nan_to_zero turns it into 0."""
+    M = _mod()
+    z = torch.zeros(0, device=dev)
+    s = torch.zeros(0, device=dev, requires_grad=True)
+    loss, nv = M.listwise_loss_from_batch(z, z, s, return_num_list=True)
+    assert loss.item() == 0.0 and int(nv.item()) == 0
+    m, lab, lg = M.to_listwise_sample(z, z, s.detach())
+    assert lab.shape == (0, 0) and lg.shape == (0, 0)

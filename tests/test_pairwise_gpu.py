@@ -251,3 +251,52 @@ def test_pair_indices_bit_exact_vs_c_oracle_large(dev):
     assert int(n.item()) == P == len(cpos)
     assert abs(loss.item() - closs) <= RTOL * abs(closs)
     assert np.abs(sd.grad.cpu().numpy() - cd).max() <= RTOL * np.abs(cd).max()
+
+
+def _zipf_groups(rng, B, a=1.2, cap=2048):
+    """SURVEY 8d, config 2 skewed variant: group sizes ~ Zipf(a) capped at `cap`, rows shuffled."""
+    sizes = []
+    while sum(sizes) < B:
+        sizes.append(int(min(rng.zipf(a), cap, B - sum(sizes))))
+    g = np.repeat(np.arange(len(sizes)), sizes)
+    rng.shuffle(g)
+    return g.astype(np.float32)
+
+
+@pytest.mark.parametrize('power', [0.0, -0.5])
+def test_skewed_group_sizes_vs_c_oracle(dev, power):
+    """B = 8192 with Zipf(1.2) group sizes capped at 2048 (a few giant groups beside many singletons): pair list bit-exact
+    against the plain-C restatement, loss / gradient within 1e-5."""
+    import pairs_oracle as C
+    M = _mod()
+    rng = np.random.default_rng(2)
+    B = 8192
+    g = _zipf_groups(rng, B)
+    assert np.bincount(g.astype(np.int64)).max() >= 1024          # the case really is skewed
+    y = (rng.random(B) < 0.25).astype(np.float32)
+    s = rng.normal(size=B).astype(np.float32)
+    m = np.ones(B, dtype=bool)
+    gd, yd = torch.from_numpy(g).to(dev), torch.from_numpy(y).to(dev)
+    pos, neg = M.pair_indices(torch.from_numpy(s).to(dev), yd, gd)
+    cpos, cneg = C.pair_indices(g, y, s, m)
+    assert np.array_equal(pos.cpu().numpy(), cpos) and np.array_equal(neg.cpu().numpy(), cneg)
+    sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+    loss, n = M.pairwise_loss(sd, yd, gd, return_num_pair=True, click_occurance_power=power)
+    loss.backward()
+    closs, cd, P = C.pairwise_bpr(g, y, s, m, power=power)
+    assert int(n.item()) == P == len(cpos)
+    assert abs(loss.item() - closs) <= RTOL * abs(closs)
+    assert np.abs(sd.grad.cpu().numpy() - cd).max() <= RTOL * np.abs(cd).max()
+
+
+def test_empty_batch(dev):
+    """B = 0: the reference's dense formulation gives sum over an empty (0,0) mask / (0 + 1e-10) = 0 and no pairs."""
+    M = _mod()
+    s = torch.zeros(0, device=dev, requires_grad=True)
+    y = torch.zeros(0, device=dev)
+    g = torch.zeros(0, device=dev)
+    loss, n = M.pairwise_loss(s, y, g, return_num_pair=True)
+    loss.backward()
+    assert loss.item() == 0.0 and n.item() == 0.0 and s.grad.shape == (0,)
+    pos, neg = M.pair_indices(s.detach(), y, g)
+    assert pos.numel() == 0 and neg.numel() == 0
