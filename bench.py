@@ -111,6 +111,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events in the timed region')
     ap.add_argument('--graph', action='store_true', help='capture the step into a HIP graph and replay it (SURVEY 8f.1; launch-bound small batches)')
+    ap.add_argument('--no-input-grad', action='store_true', help='diagnostic: x is data without a gradient (the metric keeps d loss / d x: in a model x is the embedding output)')
     ap.add_argument('--rows', type=int, default=B_PER_GPU, help='rows per GPU (diagnostics; the metric is defined at 65536)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
     args = ap.parse_args()
@@ -143,6 +144,9 @@ def main():
     x, groups, labels = synth_batch(rows, 3, rank)
     xd, gd, yd = (torch.from_numpy(v).to(dev) for v in (x, groups, labels))
     model(xd[:256])                           # lazy build on the device
+    # The step includes the gradient w.r.t. x (in a model x is the concatenated embedding output and needs it); a data-only
+    # x lets DCNMixLayer drop every dx product (--no-input-grad, reported as a diagnostic only).
+    xd.requires_grad_(not args.no_input_grad)
     params = [p for p in model.parameters()]
     reducer = dp.GradientAllReducer(params)
 
@@ -151,6 +155,7 @@ def main():
     def step():
         for p in params:
             p.grad = None
+        xd.grad = None
         # the grouping of the batch (sort by group id, segments) does not depend on the scores: it runs on a side stream
         # under the forward pass.  Still part of the step: the group ids are an input of every step.
         main = torch.cuda.current_stream()
@@ -244,7 +249,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
                                    'in-batch pairwise (logistic), B=65536 rows per GPU, 64 fields x 16-dim, ~64 rows/group',
-                       'global_batch': rows * world, 'hip_graph': bool(args.graph), 'parallelism': 'dp%d' % world,
+                       'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(args.graph), 'parallelism': 'dp%d' % world,
                        'loss': float(loss.item())},
             'roofline': roofline,
         }

@@ -297,7 +297,10 @@ size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N, int L);
 int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, const float* const* V_host, const float* const* W_host,
                        const float* const* bias_host, const float* const* gate_host, int64_t B, int D, int S, int N, int L,
                        int act_inner, int act_outer, float* y, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
-                       void* stream);
+                       void* stream, int need_dx);
+/* need_dx: 0 when the caller will not ask for the gradient w.r.t. x (x is data, as under tf.GradientTape.gradient(loss,
+ * weights)): the forward then keeps nothing that only dx needs.  recnow_dcn_mix_bwd must be given dx == NULL after such a
+ * forward, and may be given dx == NULL after any forward: the products and passes that only feed dx are not launched. */
 int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* const* V_host, const float* const* W_host,
                        const float* const* bias_host, const float* const* gate_host, const float* dy, const void* saved,
                        size_t saved_bytes, int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* dx,

@@ -307,7 +307,7 @@ static int mix_mid_bwd(const MixDims& m, const float* dT2g, const float* T2, con
 extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, const float* const* V_host,
                                   const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
                                   int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* y, void* saved,
-                                  size_t saved_bytes, void* ws, size_t ws_bytes, void* stream) {
+                                  size_t saved_bytes, void* ws, size_t ws_bytes, void* stream, int need_dx) {
     if (B < 0 || D < 1 || S < 1 || N < 1 || L < 1 || B > 0x7fffffffll) return RECNOW_EINVAL;
     if (N > 64) return RECNOW_EUNSUPPORTED;
     if (B == 0) return RECNOW_OK;
@@ -367,7 +367,7 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
                 d.M = (int)B; d.N = D; d.K = m.KP;
                 d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
-                d.C2 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.ldc2 = D; d.c2_mode = 1;
+                if (need_dx) { d.C2 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.ldc2 = D; d.c2_mode = 1; }     // O_l only feeds dx
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
             }
             xl = out;
@@ -497,7 +497,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = (int)B; d.N = m.NS; d.K = D;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.sp_bx = bias_host[l]; d.sp_bx_ks = 1; d.sp_bx_rs = D; d.sp_cx = dT2g + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
-            if (l == L - 1) {      // top layer: this product streams g = dy anyway -> dx = dy * O_{L-1} written on the way
+            if (l == L - 1 && dx) {      // top layer: this product streams g = dy anyway -> dx = dy * O_{L-1} written on the way
                 d.as_in = omid + (size_t)l * (xbuf(m) / sizeof(float));
                 d.as_out = dx;
             }
@@ -509,7 +509,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             return rc;
         hipEvent_t e_dT1 = nullptr;
         MIX_SIGNAL(e_dT1, st);
-        {   // gradient w.r.t. x_l: g_{l-1} = [dA | dlogits | 0] [U | K | 0]^T  (K zero-padded to KP).  The same accumulators
+        if (l > 0 || dx) {   // gradient w.r.t. x_l (layer 0's is part of dx only): g_{l-1} = [dA | dlogits | 0] [U | K | 0]^T  (K zero-padded to KP).  The same accumulators
             // also update dx += g_{l-1} * O_{l-1} (second output); layer 0's x_l is x itself, its term goes straight into dx.
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
@@ -518,7 +518,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = (int)B; d.N = D; d.K = m.KP;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.accumulate = (l == 0) ? 1 : 0;
-            if (l > 0) { d.C2 = dx; d.ldc2 = D; d.E2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.lde2 = D; d.c2_mode = 2; }
+            if (l > 0 && dx) { d.C2 = dx; d.ldc2 = D; d.E2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.lde2 = D; d.c2_mode = 2; }
             if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
         }
         if (l > 0) MIX_SIGNAL(e_g, st);
@@ -563,7 +563,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
         }
         return RECNOW_OK;
     }
-    if (!x || !U_host || !V_host || !W_host || !bias_host || !gate_host || !dy || !saved || !dx || !ws) return RECNOW_EINVAL;
+    if (!x || !U_host || !V_host || !W_host || !bias_host || !gate_host || !dy || !saved || !ws) return RECNOW_EINVAL;     // dx may be NULL
     if (saved_bytes < recnow_dcn_mix_saved_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
     if (ws_bytes < recnow_dcn_mix_workspace_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
     const MixDims m = mix_dims(B, D, S, N, L);
@@ -616,7 +616,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             RN_HIP(hipMemcpyAsync(dW_host[l], dWc2, (size_t)m.NS * D * sizeof(float), hipMemcpyDeviceToDevice, st));
             RN_HIP(hipMemcpyAsync(dbias_host[l], dWc2 + (size_t)m.NS * D, (size_t)N * D * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
-        {   // dx (+)= g * O,  O = T2g Wc2 recomputed
+        if (dx) {   // dx (+)= g * O,  O = T2g Wc2 recomputed
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc2; d.ldb = D; d.b_trans = 0;
@@ -641,7 +641,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             hipLaunchKernelGGL(k_unpack_w1, gg, 256, 0, st, dWc1, D, S, N, m.LDT, dU_host[l], dgate_host[l]);
             RN_LAUNCH_CHECK();
         }
-        {   // gradient w.r.t. x_l:  dT1 Wc1^T.  Layer 0's x_l is x itself -> accumulate into dx.
+        if (l > 0 || dx) {   // gradient w.r.t. x_l:  dT1 Wc1^T.  Layer 0's x_l is x itself -> accumulate into dx.
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;

@@ -161,27 +161,30 @@ class DCNMixFunction(torch.autograd.Function):
         saved = _lib.workspace(lib.recnow_dcn_mix_saved_bytes(B, D, S, N, L), x.device)
         ws = _lib.workspace(lib.recnow_dcn_mix_workspace_bytes(B, D, S, N, L), x.device)
         y = torch.empty_like(x)
+        # x is data (no gradient asked for, as under tf.GradientTape.gradient(loss, weights)): nothing that only dx needs
+        # is kept by the forward or launched by the backward
+        need_dx = bool(ctx.needs_input_grad[0])
         _lib.call('recnow_dcn_mix_fwd', _lib.ptr(x), _host_ptr_array(U), _host_ptr_array(V), _host_ptr_array(W),
                   _host_ptr_array(bias), _host_ptr_array(gate), B, D, S, N, L, act_inner, act_outer, _lib.ptr(y),
-                  _lib.ptr(saved), saved.numel(), _lib.ptr(ws), ws.numel(), _lib.stream())
+                  _lib.ptr(saved), saved.numel(), _lib.ptr(ws), ws.numel(), _lib.stream(), int(need_dx))
         ctx.save_for_backward(x, saved, *ps)
-        ctx.meta = (B, D, S, N, L, act_inner, act_outer)
+        ctx.meta = (B, D, S, N, L, act_inner, act_outer, need_dx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, saved, *ps = ctx.saved_tensors
-        B, D, S, N, L, act_inner, act_outer = ctx.meta
+        B, D, S, N, L, act_inner, act_outer, need_dx = ctx.meta
         U, V, W, bias, gate = (ps[i * L:(i + 1) * L] for i in range(5))
         dy = _lib.f32c(dy, 'grad')
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if need_dx else None
         grads = [torch.empty_like(p) for p in ps]
         dU, dV, dW, dbias, dgate = (grads[i * L:(i + 1) * L] for i in range(5))
         lib = _lib.load()
         ws = _lib.workspace(lib.recnow_dcn_mix_workspace_bytes(B, D, S, N, L), x.device)
         _lib.call('recnow_dcn_mix_bwd', _lib.ptr(x), _host_ptr_array(U), _host_ptr_array(V), _host_ptr_array(W),
                   _host_ptr_array(bias), _host_ptr_array(gate), _lib.ptr(dy), _lib.ptr(saved), saved.numel(), B, D, S, N, L,
-                  act_inner, act_outer, _lib.ptr(dx), _host_ptr_array(dU), _host_ptr_array(dV), _host_ptr_array(dW),
+                  act_inner, act_outer, _lib.ptr(dx) if need_dx else None, _host_ptr_array(dU), _host_ptr_array(dV), _host_ptr_array(dW),
                   _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(ws), ws.numel(), _lib.stream(),
                   _lib.side_stream(x.device) if DCN_MIX_TWO_STREAMS else None)
         return (dx, None, None, None) + tuple(grads)

@@ -443,6 +443,33 @@ def test_dcn_mix_backward_on_two_streams_matches_single_stream(dev, monkeypatch)
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('B,D,S,N,L', [(1024, 256, 64, 2, 3), (512, 1024, 64, 2, 1), (300, 130, 7, 3, 2), (257, 64, 16, 2, 1)])
+def test_dcn_mix_input_without_gradient(dev, B, D, S, N, L):
+    """x is data (requires_grad False, the tf.GradientTape.gradient(loss, weights) case): the forward keeps nothing that only
+    dx needs and the backward launches none of the dx products.  The output is bit-identical to the run that also produces
+    dx; the weight gradients agree to rounding (a product that no longer carries a dx side output may be split over K, which
+    changes the summation order only).  Exact-128 shapes and general shapes, one layer and several."""
+    from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
+    torch.manual_seed(B + D)
+    x = torch.randn(B, D, device=dev) * 0.3
+    gy = torch.randn(B, D, device=dev)
+    layer = DCNMixLayer(dim_sub_space=S, num_layer=L, num_expert=N)
+    layer(x[:8])
+    runs = []
+    for need in (True, False):
+        xi = x.clone().requires_grad_(need)
+        for p in layer.parameters():
+            p.grad = None
+        y = layer(xi)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        assert (xi.grad is not None) == need
+        runs.append([y.detach().clone()] + [p.grad.clone() for p in layer.parameters()])
+    assert torch.equal(runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1:], runs[1][1:]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+
+
 # ---- persistent short-K kernel: every epilogue form, tile counts above and below one resident wave of workgroups -------------
 @pytest.mark.parametrize('M,N,K,tb', [(256, 256, 144, 0), (1024, 1024, 48, 1), (16384, 1024, 144, 0), (384, 128, 16, 1)])
 @pytest.mark.parametrize('form', ['plain', 'emul', 'accum', 'emul_accum', 'dual_raw', 'dual_fma'])
