@@ -85,10 +85,24 @@ def dcn():
         print('   replayed from a HIP graph (GPU time of the step): %.3f ms  %.0f GB/s' % (mg, 20.0 * B * D / mg / 1e6))
 
 
+def zipf_groups(rng, B, a=1.2, cap=2048):
+    """SURVEY 8d config 2, skewed variant: group sizes ~ Zipf(a) capped at `cap`, rows shuffled."""
+    sizes = []
+    while sum(sizes) < B:
+        sizes.append(int(min(rng.zipf(a), cap, B - sum(sizes))))
+    g = np.repeat(np.arange(len(sizes)), sizes)
+    rng.shuffle(g)
+    return g.astype(np.float32), len(sizes)
+
+
 def pairwise(B, G, tag):
     from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
     rng = np.random.default_rng(2)
-    g = torch.from_numpy(rng.integers(0, G, B).astype(np.float32)).to(dev)
+    if G == 0:
+        gn, G = zipf_groups(rng, B)
+        g = torch.from_numpy(gn).to(dev)
+    else:
+        g = torch.from_numpy(rng.integers(0, G, B).astype(np.float32)).to(dev)
     y = torch.from_numpy((rng.random(B) < 0.25).astype(np.float32)).to(dev)
     s = torch.randn(B, device=dev, requires_grad=True)
     npair = [0.0]
@@ -275,7 +289,9 @@ if __name__ == '__main__':
         dcn()
     if 'pair' in which:
         pairwise(8192, 128, 'config2')
+        pairwise(8192, 0, 'config2-skewed (Zipf 1.2 group sizes, cap 2048)')
         pairwise(65536, 1024, 'config3')
+        pairwise(65536, 0, 'config3-skewed (Zipf 1.2 group sizes, cap 2048)')
     if 'list' in which:
         listwise()
     if 'cin' in which:
