@@ -92,3 +92,15 @@ __device__ __forceinline__ float rn_act_grad_from_out(float y, int act) {
         default: return 1.f;
     }
 }
+
+// ---- pointers fetched from device-resident pointer arrays (lists of field tensors) ---------------
+// To the compiler such a pointer is GENERIC: loads through it become flat_load, which count on lgkmcnt as well as vmcnt, so
+// the s_waitcnt lgkmcnt(0) behind every scalar fetch of the NEXT pointer also drains the vector loads in flight (FM forward
+// issued its 8 loads per lane one at a time).  These types state that the target is global memory: global_load / global_store,
+// vmcnt only.  Native vectors, because HIP's float4 struct cannot be copied out of a non-generic address space.
+#define RN_GLOBAL __attribute__((address_space(1)))
+typedef float rn_f4 __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(1)))* rn_gcf;
+typedef float __attribute__((address_space(1)))* rn_gf;
+typedef const rn_f4 __attribute__((address_space(1)))* rn_gcf4;
+typedef rn_f4 __attribute__((address_space(1)))* rn_gf4;

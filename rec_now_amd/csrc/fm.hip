@@ -19,25 +19,30 @@ k_fm_fwd_vec4(const float* const* __restrict__ fields, int F, int64_t nchunk /* 
     for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x; q0 < nchunk; q0 += stride) {
         const int64_t q = q0 + threadIdx.x;
         const bool ok = q < nchunk;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(0.f, 0.f, 0.f, 0.f);
+        // Lanes past the end read chunk 0 (no branch around a load); nchunk is a multiple of lanes_per_row, so such a lane's
+        // whole row is past the end and nothing of it is stored.
+        const int64_t qc = ok ? q : 0;
+        rn_f4 s = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
         int f = 0;
         for (; f + FM_UNROLL <= F; f += FM_UNROLL) {
-            float4 v[FM_UNROLL];
+            rn_gcf4 p[FM_UNROLL];
+            rn_f4 v[FM_UNROLL];
 #pragma unroll
-            for (int u = 0; u < FM_UNROLL; ++u)
-                v[u] = ok ? reinterpret_cast<const float4*>(fields[f + u])[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < FM_UNROLL; ++u) p[u] = (rn_gcf4)fields[f + u];       // 8 scalar fetches, one wait
+#pragma unroll
+            for (int u = 0; u < FM_UNROLL; ++u) v[u] = p[u][qc];                     // 8 global loads in flight
 #pragma unroll
             for (int u = 0; u < FM_UNROLL; ++u) {
-                s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
-                sq.x += v[u].x * v[u].x; sq.y += v[u].y * v[u].y; sq.z += v[u].z * v[u].z; sq.w += v[u].w * v[u].w;
+                s += v[u];
+                sq += v[u] * v[u];
             }
         }
         for (; f < F; ++f) {
-            const float4 v = ok ? reinterpret_cast<const float4*>(fields[f])[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+            const rn_f4 v = ((rn_gcf4)fields[f])[qc];
+            s += v;
+            sq += v * v;
         }
-        if (SAVE_S && ok) reinterpret_cast<float4*>(S)[q] = s;
+        if (SAVE_S && ok) reinterpret_cast<rn_f4*>(S)[q] = s;
         float r = (s.x * s.x - sq.x) + (s.y * s.y - sq.y) + (s.z * s.z - sq.z) + (s.w * s.w - sq.w);
         for (int o = lanes_per_row >> 1; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
         if (ok && (q % lanes_per_row) == 0) y[q / lanes_per_row] = 0.5f * r;
@@ -70,21 +75,25 @@ k_fm_bwd_vec4(const float* const* __restrict__ fields, float* const* __restrict_
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nchunk; q += stride) {
         const float g = gy[q / lanes_per_row];
-        const float4 s = reinterpret_cast<const float4*>(S)[q];
+        const rn_f4 s = reinterpret_cast<const rn_f4*>(S)[q];
         int f = 0;
         for (; f + FM_UNROLL <= F; f += FM_UNROLL) {
-            float4 v[FM_UNROLL];
+            rn_gcf4 p[FM_UNROLL];
+            rn_gf4 dp[FM_UNROLL];
+            rn_f4 v[FM_UNROLL];
 #pragma unroll
-            for (int u = 0; u < FM_UNROLL; ++u) v[u] = reinterpret_cast<const float4*>(fields[f + u])[q];
+            for (int u = 0; u < FM_UNROLL; ++u) {
+                p[u] = (rn_gcf4)fields[f + u];
+                dp[u] = (rn_gf4)dfields[f + u];
+            }
 #pragma unroll
-            for (int u = 0; u < FM_UNROLL; ++u)
-                reinterpret_cast<float4*>(dfields[f + u])[q] =
-                    make_float4(g * (s.x - v[u].x), g * (s.y - v[u].y), g * (s.z - v[u].z), g * (s.w - v[u].w));
+            for (int u = 0; u < FM_UNROLL; ++u) v[u] = p[u][q];
+#pragma unroll
+            for (int u = 0; u < FM_UNROLL; ++u) dp[u][q] = g * (s - v[u]);
         }
         for (; f < F; ++f) {
-            const float4 v = reinterpret_cast<const float4*>(fields[f])[q];
-            reinterpret_cast<float4*>(dfields[f])[q] =
-                make_float4(g * (s.x - v.x), g * (s.y - v.y), g * (s.z - v.z), g * (s.w - v.w));
+            const rn_f4 v = ((rn_gcf4)fields[f])[q];
+            ((rn_gf4)dfields[f])[q] = g * (s - v);
         }
     }
 }

@@ -134,12 +134,12 @@ k_ipnn_fwd_gram(const float* const* __restrict__ fields, int F, int64_t B, int64
     const int64_t nw = (int64_t)gridDim.x * 4;
     const bool two = F > 32;
     // which piece of which field this lane fetches in load step t (same for every row b)
-    const float* src[NLD];
+    rn_gcf src[NLD];              // global address space: see common.hpp (no flat loads beside the LDS traffic)
     int dst[NLD];
 #pragma unroll
     for (int t = 0; t < NLD; ++t) {
         const int idx = t * 64 + lane, f = idx / CPF, c = idx - f * CPF;
-        src[t] = f < F ? fields[f] + 4 * c : nullptr;
+        src[t] = f < F ? (rn_gcf)fields[f] + 4 * c : (rn_gcf)nullptr;
         dst[t] = f * XS + 4 * c;
     }
     ipnn_acc4 nx[NLD];                       // native vectors: arrays of HIP's float4 struct are copied with memcpy and stay in scratch
@@ -147,7 +147,7 @@ k_ipnn_fwd_gram(const float* const* __restrict__ fields, int F, int64_t B, int64
     if (bb < B) {
 #pragma unroll
         for (int t = 0; t < NLD; ++t)
-            if (src[t]) nx[t] = *reinterpret_cast<const ipnn_acc4*>(src[t] + bb * D);
+            if (src[t]) nx[t] = *reinterpret_cast<const RN_GLOBAL ipnn_acc4*>(src[t] + bb * D);
     }
     for (; bb < B; bb += nw) {
         const int64_t b = __builtin_amdgcn_readfirstlane((int)bb);          // row of this wave, uniform for the compiler too (B < 2^31)
@@ -157,7 +157,7 @@ k_ipnn_fwd_gram(const float* const* __restrict__ fields, int F, int64_t B, int64
         if (bb + nw < B) {
 #pragma unroll
             for (int t = 0; t < NLD; ++t)
-                if (src[t]) nx[t] = *reinterpret_cast<const ipnn_acc4*>(src[t] + (bb + nw) * D);
+                if (src[t]) nx[t] = *reinterpret_cast<const RN_GLOBAL ipnn_acc4*>(src[t] + (bb + nw) * D);
         }
         IPNN_WAVE_SYNC();                                                   // the tile is private to this wave
         float a0[HD], a1[HD];
@@ -223,11 +223,11 @@ k_ipnn_fwd_gram(const float* const* __restrict__ fields, int F, int64_t B, int64
 // Both inputs of the next row are requested before this row is consumed.  F <= 64, D in {4, 8, 12, 16}.
 // both inputs of row `row` of the backward kernel below -> registers
 template <int D>
-__device__ __forceinline__ void ipnn_bwd_request(const float* const (&src)[D / 4], ipnn_acc4 (&nx)[D / 4], ipnn_acc4 (&nd)[8], const float* dout,
+__device__ __forceinline__ void ipnn_bwd_request(const rn_gcf (&src)[D / 4], ipnn_acc4 (&nx)[D / 4], ipnn_acc4 (&nd)[8], const float* dout,
                                                  int64_t row, int64_t P, int lane, int vec) {
 #pragma unroll
     for (int t = 0; t < D / 4; ++t)
-        if (src[t]) nx[t] = *reinterpret_cast<const ipnn_acc4*>(src[t] + row * D);
+        if (src[t]) nx[t] = *reinterpret_cast<const RN_GLOBAL ipnn_acc4*>(src[t] + row * D);
     if (vec) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
@@ -255,14 +255,14 @@ k_ipnn_bwd_gram(const float* const* __restrict__ fields, float* const* __restric
     float* lin = xt + 64 * 16;                                    // packed gradients of the row
     const int64_t nw = (int64_t)gridDim.x * 4;
     for (int i = lane; i < 64 * 16; i += 64) xt[i] = 0.f;
-    const float* src[CPF];
-    float* dsrc[CPF];
+    rn_gcf src[CPF];
+    rn_gf dsrc[CPF];
     int dst[CPF];
 #pragma unroll
     for (int t = 0; t < CPF; ++t) {
         const int idx = t * 64 + lane, f = idx / CPF, c = idx - f * CPF;
-        src[t] = f < F ? fields[f] + 4 * c : nullptr;
-        dsrc[t] = f < F ? dfields[f] + 4 * c : nullptr;
+        src[t] = f < F ? (rn_gcf)fields[f] + 4 * c : (rn_gcf)nullptr;
+        dsrc[t] = f < F ? (rn_gf)dfields[f] + 4 * c : (rn_gf)nullptr;
         dst[t] = f * 16 + 4 * c;
     }
     ipnn_acc4 nx[CPF], nd[NQ];             // native vectors: arrays of HIP's float4 struct are copied with memcpy and stay in scratch
@@ -338,7 +338,7 @@ k_ipnn_bwd_gram(const float* const* __restrict__ fields, float* const* __restric
         IPNN_WAVE_SYNC();
 #pragma unroll
         for (int t = 0; t < CPF; ++t)
-            if (dsrc[t]) *reinterpret_cast<ipnn_acc4*>(dsrc[t] + b * D) = *reinterpret_cast<const ipnn_acc4*>(xt + dst[t]);
+            if (dsrc[t]) *reinterpret_cast<RN_GLOBAL ipnn_acc4*>(dsrc[t] + b * D) = *reinterpret_cast<const ipnn_acc4*>(xt + dst[t]);
         IPNN_WAVE_SYNC();                                                   // dX read back before the next X tile lands
     }
 }
@@ -535,7 +535,7 @@ k_senet_uniform(const float* const* __restrict__ fields, float* const* __restric
         const int q = ok ? (int)(i - grp * QT) : 0;
         const int f = q / Q, d = (q - f * Q) * 4;
         const int64_t b0 = grp * SENET_RU;
-        const float* xf = fields[f] + d;
+        const rn_gcf xf = (rn_gcf)fields[f] + d;
         senet_f4 v[SENET_RU], g[SENET_RU];
         bool live[SENET_RU];
 #pragma unroll
@@ -543,7 +543,7 @@ k_senet_uniform(const float* const* __restrict__ fields, float* const* __restric
             live[j] = ok && b0 + j < B;
             v[j] = senet_f4{0.f, 0.f, 0.f, 0.f};
             g[j] = v[j];
-            if (MODE != SENET_MODE_DX && live[j]) v[j] = *reinterpret_cast<const senet_f4*>(xf + (b0 + j) * D);
+            if (MODE != SENET_MODE_DX && live[j]) v[j] = *reinterpret_cast<const RN_GLOBAL senet_f4*>(xf + (b0 + j) * D);
             if ((MODE == SENET_MODE_DX || MODE == SENET_MODE_DW) && live[j]) g[j] = *reinterpret_cast<const senet_f4*>(in + (b0 + j) * FD + q * 4);
         }
 #pragma unroll
@@ -552,7 +552,7 @@ k_senet_uniform(const float* const* __restrict__ fields, float* const* __restric
             if (MODE == SENET_MODE_SCALE) {
                 if (live[j]) *reinterpret_cast<senet_f4*>(out + b * FD + q * 4) = v[j] * w[b * F + f];
             } else if (MODE == SENET_MODE_DX) {
-                if (live[j]) *reinterpret_cast<senet_f4*>(dfields[f] + b * D + d) = g[j] * w[b * F + f] + dsq[b * F + f] / (float)D;
+                if (live[j]) *reinterpret_cast<RN_GLOBAL senet_f4*>((rn_gf)dfields[f] + b * D + d) = g[j] * w[b * F + f] + dsq[b * F + f] / (float)D;
             } else {
                 float s = MODE == SENET_MODE_DW ? (v[j].x * g[j].x + v[j].y * g[j].y) + (v[j].z * g[j].z + v[j].w * g[j].w)
                                                 : (v[j].x + v[j].y) + (v[j].z + v[j].w);

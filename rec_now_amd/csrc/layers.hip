@@ -379,7 +379,7 @@ k_moe_mix_fwd(const float* __restrict__ logits, const float* const* __restrict__
             float acc = 0.f;
             for (int n = 0; n < N; ++n) {
                 const float gn = __shfl(g, n, 64);
-                if (u < U) acc += gn * experts[n][b * U + u];
+                if (u < U) acc += gn * ((rn_gcf)experts[n])[b * U + u];      // global address space: see common.hpp
             }
             if (u < U) out[row * U + u] = acc;
         }
@@ -398,7 +398,7 @@ k_moe_mix_bwd(const float* __restrict__ gates, const float* const* __restrict__ 
                 for (int n = 0; n < N; ++n) {
                     float acc = 0.f;
                     for (int t = 0; t < T; ++t) acc += gates[((int64_t)t * B + b) * N + n] * dout[((int64_t)t * B + b) * U + u];
-                    float* de = dexperts[n] + b * U + u;
+                    const rn_gf de = (rn_gf)dexperts[n] + b * U + u;
                     *de = accumulate ? (*de + acc) : acc;
                 }
             }
@@ -410,7 +410,7 @@ k_moe_mix_bwd(const float* __restrict__ gates, const float* const* __restrict__ 
                 float dg_mine = 0.f;
                 for (int n = 0; n < N; ++n) {
                     float p = 0.f;
-                    for (int u = lane; u < U; u += 64) p += dout[row * U + u] * experts[n][b * U + u];
+                    for (int u = lane; u < U; u += 64) p += dout[row * U + u] * ((rn_gcf)experts[n])[b * U + u];
                     p = wave_sum(p);
                     if (lane == n) dg_mine = p;
                 }

@@ -58,7 +58,7 @@ k_senet_fused_fwd(const float* const* __restrict__ fields, SfDims dm, int64_t B,
     const int t = threadIdx.x;
     const bool col = t < QT;
     const int f = col ? t / Q : 0, d = col ? (t - f * Q) * 4 : 0;
-    const float* xf = fields[f] + d;
+    const rn_gcf xf = (rn_gcf)fields[f] + d;      // global address space: see common.hpp
     const int64_t FD = (int64_t)F * D;
     int P = 1;                                             // threads per hidden unit in the first product (power of two <= 8)
     while (P < 8 && 2 * P * SF_R * M <= 256) P *= 2;
@@ -67,7 +67,7 @@ k_senet_fused_fwd(const float* const* __restrict__ fields, SfDims dm, int64_t B,
 #pragma unroll
         for (int j = 0; j < SF_R; ++j) {
             v[j] = sf_f4{0.f, 0.f, 0.f, 0.f};
-            if (col && b0 + j < B) v[j] = *reinterpret_cast<const sf_f4*>(xf + (b0 + j) * D);
+            if (col && b0 + j < B) v[j] = *reinterpret_cast<const RN_GLOBAL sf_f4*>(xf + (b0 + j) * D);
         }
         __syncthreads();                                   // previous step is done with sq / hs / ws (and the weights are loaded)
 #pragma unroll
@@ -143,31 +143,32 @@ k_senet_fused_bwd(const float* const* __restrict__ fields, float* const* __restr
     const int t = threadIdx.x;
     const bool col = t < QT;
     const int f = col ? t / Q : 0, d = col ? (t - f * Q) * 4 : 0;
-    const float* xf = fields[f] + d;
-    float* dxf = dfields[f] + d;
+    const rn_gcf xf = (rn_gcf)fields[f] + d;      // global address space: see common.hpp
+    const rn_gf dxf = (rn_gf)dfields[f] + d;
     const int64_t FD = (int64_t)F * D;
     const int NOUT = 2 * FM + M + F;
     int P = 1;                                             // threads per hidden unit in dz2 W2^T (power of two <= 8)
     while (P < 8 && 2 * P * SF_R * M <= 256) P *= 2;
     // every weight-gradient output is sum_j a[j] * b[j] over the rows j of a step, a and b taken from the row vectors
     float acc[NACC];
-    const float* pa[NACC];
-    const float* pb[NACC];
+    int pa[NACC], pb[NACC];                    // offsets into sf_lds (pointers would be generic: 64-bit, read with flat loads)
+    const int o_ones = (int)(ones - sf_lds), o_sq = (int)(sq - sf_lds), o_hs = (int)(hs - sf_lds), o_z1 = (int)(z1 - sf_lds),
+              o_z2 = (int)(z2 - sf_lds);
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
         const int o = t + 256 * i;
         acc[i] = 0.f;
-        pa[i] = ones; pb[i] = ones;                // o >= NOUT: an unused slot
+        pa[i] = o_ones; pb[i] = o_ones;            // o >= NOUT: an unused slot
         if (o < FM) {                              // dW1[k][m] += sq[k] * dz1[m]
             const int k = o / M, m = o - k * M;
-            pa[i] = sq + k; pb[i] = z1 + m;
+            pa[i] = o_sq + k; pb[i] = o_z1 + m;
         } else if (o < 2 * FM) {                   // dW2[m][k] += h[m] * dz2[k]
             const int m = (o - FM) / F, k = (o - FM) - m * F;
-            pa[i] = hs + m; pb[i] = z2 + k;
+            pa[i] = o_hs + m; pb[i] = o_z2 + k;
         } else if (o < 2 * FM + M) {               // db1[m] += dz1[m]
-            pb[i] = z1 + (o - 2 * FM);
+            pb[i] = o_z1 + (o - 2 * FM);
         } else if (o < NOUT) {                     // db2[k] += dz2[k]
-            pb[i] = z2 + (o - 2 * FM - M);
+            pb[i] = o_z2 + (o - 2 * FM - M);
         }
     }
     for (int64_t b0 = (int64_t)blockIdx.x * SF_R; b0 < B; b0 += (int64_t)gridDim.x * SF_R) {
@@ -176,7 +177,7 @@ k_senet_fused_bwd(const float* const* __restrict__ fields, float* const* __restr
         for (int j = 0; j < SF_R; ++j) {
             v[j] = g[j] = sf_f4{0.f, 0.f, 0.f, 0.f};
             if (col && b0 + j < B) {
-                v[j] = *reinterpret_cast<const sf_f4*>(xf + (b0 + j) * D);
+                v[j] = *reinterpret_cast<const RN_GLOBAL sf_f4*>(xf + (b0 + j) * D);
                 g[j] = *reinterpret_cast<const sf_f4*>(dout + (b0 + j) * FD + t * 4);
             }
         }
@@ -225,14 +226,14 @@ k_senet_fused_bwd(const float* const* __restrict__ fields, float* const* __restr
         for (int i = 0; i < NACC; ++i) {
             float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < SF_R; ++j) a += pa[i][j * SF_RS] * pb[i][j * SF_RS];
+            for (int j = 0; j < SF_R; ++j) a += sf_lds[pa[i] + j * SF_RS] * sf_lds[pb[i] + j * SF_RS];
             acc[i] += a;
         }
         __syncthreads();                                   // dq complete (and z1 read by everyone before the next step rewrites it)
 #pragma unroll
         for (int j = 0; j < SF_R; ++j)
             if (col && b0 + j < B)
-                *reinterpret_cast<sf_f4*>(dxf + (b0 + j) * D) = g[j] * ws[j * SF_RS + f] + dq[j * SF_RS + f] / (float)D;
+                *reinterpret_cast<RN_GLOBAL sf_f4*>(dxf + (b0 + j) * D) = g[j] * ws[j * SF_RS + f] + dq[j * SF_RS + f] / (float)D;
     }
     float* dst = part + (int64_t)blockIdx.x * NOUT;
 #pragma unroll
