@@ -77,19 +77,34 @@ k_fm_bwd_vec4(const float* const* __restrict__ fields, float* const* __restrict_
         const float g = gy[q / lanes_per_row];
         const rn_f4 s = reinterpret_cast<const rn_f4*>(S)[q];
         int f = 0;
-        for (; f + FM_UNROLL <= F; f += FM_UNROLL) {
+        // software pipeline over groups of FM_UNROLL fields: the loads of group n+1 are issued before the stores of group n,
+        // so a wave always has loads in flight (program order "8 loads, wait, 8 stores" exposed the load latency per group)
+        rn_f4 v[FM_UNROLL], nv[FM_UNROLL];
+        if (FM_UNROLL <= F) {
             rn_gcf4 p[FM_UNROLL];
-            rn_gf4 dp[FM_UNROLL];
-            rn_f4 v[FM_UNROLL];
 #pragma unroll
-            for (int u = 0; u < FM_UNROLL; ++u) {
-                p[u] = (rn_gcf4)fields[f + u];
-                dp[u] = (rn_gf4)dfields[f + u];
-            }
+            for (int u = 0; u < FM_UNROLL; ++u) p[u] = (rn_gcf4)fields[u];
 #pragma unroll
             for (int u = 0; u < FM_UNROLL; ++u) v[u] = p[u][q];
+        }
+        for (; f + FM_UNROLL <= F; f += FM_UNROLL) {
+            const bool more = f + 2 * FM_UNROLL <= F;            // block-uniform
+            rn_gf4 dp[FM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FM_UNROLL; ++u) dp[u] = (rn_gf4)dfields[f + u];
+            if (more) {
+                rn_gcf4 p[FM_UNROLL];
+#pragma unroll
+                for (int u = 0; u < FM_UNROLL; ++u) p[u] = (rn_gcf4)fields[f + FM_UNROLL + u];
+#pragma unroll
+                for (int u = 0; u < FM_UNROLL; ++u) nv[u] = p[u][q];
+            }
 #pragma unroll
             for (int u = 0; u < FM_UNROLL; ++u) dp[u][q] = g * (s - v[u]);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < FM_UNROLL; ++u) v[u] = nv[u];
+            }
         }
         for (; f < F; ++f) {
             const rn_f4 v = ((rn_gcf4)fields[f])[q];

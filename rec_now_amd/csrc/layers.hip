@@ -19,18 +19,35 @@ k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float
         wv[i] = d < D ? *reinterpret_cast<const float4*>(w + d) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float bv = bias ? bias[0] : 0.f;
-    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
-        float acc = 0.f;
+    // two rows per step: 2 * NV independent 16-byte loads per lane are in flight before the first reduction starts
+    const int64_t step = (int64_t)gridDim.x * 4;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += 2 * step) {
+        const int64_t b2 = b + step;
+        const bool two = b2 < B;                              // wave-uniform
+        const float* x2 = x + (two ? b2 : b) * D;             // no second row: re-read the first (result unused)
+        float4 v[NV], u[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int d = (i * 64 + lane) * 4;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            u[i] = v[i];
             if (d < D) {
-                const float4 v = *reinterpret_cast<const float4*>(x + b * D + d);
-                acc += v.x * wv[i].x + v.y * wv[i].y + v.z * wv[i].z + v.w * wv[i].w;
+                v[i] = *reinterpret_cast<const float4*>(x + b * D + d);
+                u[i] = *reinterpret_cast<const float4*>(x2 + d);
             }
         }
+        float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            acc += v[i].x * wv[i].x + v[i].y * wv[i].y + v[i].z * wv[i].z + v[i].w * wv[i].w;
+            acc2 += u[i].x * wv[i].x + u[i].y * wv[i].y + u[i].z * wv[i].z + u[i].w * wv[i].w;
+        }
         acc = wave_sum(acc);
-        if (lane == 0) y[b] = rn_act(acc + bv, act);
+        acc2 = wave_sum(acc2);
+        if (lane == 0) {
+            y[b] = rn_act(acc + bv, act);
+            if (two) y[b2] = rn_act(acc2 + bv, act);
+        }
     }
 }
 // dx[b][:] = dz[b] * w,   dz = dy * act'(y)
@@ -54,7 +71,18 @@ k_head_dw_partial(const float* __restrict__ x, const float* __restrict__ dy, con
     const int64_t b0 = (int64_t)blockIdx.x * HEAD_ROWS, b1 = min(B, b0 + HEAD_ROWS);
     for (int d = threadIdx.x * 4; d < D; d += 1024) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t b = b0; b < b1; ++b) {
+        int64_t b = b0;
+        for (; b + 8 <= b1; b += 8) {                 // eight rows requested before the first is used; adds stay in row order
+            float4 v[8];
+            float dz[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = *reinterpret_cast<const float4*>(x + (b + r) * D + d);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dz[r] = dy[b + r] * rn_act_grad_from_out(y[b + r], act);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { acc.x += v[r].x * dz[r]; acc.y += v[r].y * dz[r]; acc.z += v[r].z * dz[r]; acc.w += v[r].w * dz[r]; }
+        }
+        for (; b < b1; ++b) {
             const float dz = dy[b] * rn_act_grad_from_out(y[b], act);
             const float4 v = *reinterpret_cast<const float4*>(x + b * D + d);
             acc.x += v.x * dz; acc.y += v.y * dz; acc.z += v.z * dz; acc.w += v.w * dz;
