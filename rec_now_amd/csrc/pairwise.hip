@@ -84,11 +84,84 @@ __device__ __forceinline__ bool stage_members(const Member* __restrict__ mem, co
         }                                                                 \
     } while (0)
 
+// One candidate of a row's walk.  Labels are strictly ordered in at most one direction, so at most one of (me, o) / (o, me) is a
+// pair; both take their terms from ONE exp(-|x|) (x = the active pair's score difference): softplus(-x) = max(-x, 0) +
+// log(1 + e), sigma(-x) = e / (1 + e) or 1 / (1 + e).  No per-lane branches around the transcendentals (lanes of a wave walk
+// segments of different membership: both sides would be serialised).  Hardware exp2 / log2 / rcp (1 ulp each) instead of libm
+// expf / log1pf / IEEE division: ~25 instead of ~100 instructions per candidate.  e is in (0, 1], so 1 + e is in (1, 2] (never
+// denormal): log(1 + e) is off by at most the rounding of 1 + e, 6e-8 absolute, on terms that sum to O(1) per pair -- two
+// orders below the 1e-5 parity bar (tests compare against the fp64 oracle).
+template <int FLAGS>
+__device__ __forceinline__ void bpr_term(const Member& me, const Member& o, bool other, float factor, float& la, float& ga) {
+    const bool fwd = other && pair_ok<FLAGS>(me, o);      // me is the positive of (me, o)
+    const bool bwd = other && pair_ok<FLAGS>(o, me);      // me is the negative of (o, me)
+    const float d = factor * (me.score - o.score);
+    const float x = fwd ? d : -d;
+    const float ex = __builtin_amdgcn_exp2f(-1.44269504f * fabsf(x));
+    const float inv = __builtin_amdgcn_rcpf(1.f + ex);
+    const float sg = x >= 0.f ? ex * inv : inv;                                          // sigma(-x)
+    const float sp = fmaxf(-x, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);     // softplus(-x)
+    la += fwd ? sp : 0.f;
+    ga += fwd ? -sg : (bwd ? sg : 0.f);
+}
+
+// ---- long segments: a wave per row ------------------------------------------------------------------
+// One thread per row makes the time of a call the latency of the longest walk: a 2048-row group (the Zipf-skewed batches of
+// SURVEY 8d) is 2048 dependent iterations per lane whatever the rest of the batch looks like.  Rows of segments longer than
+// PW_LONG are therefore walked by a whole wave each -- lanes stride over the members (coalesced 16-byte reads), partial sums
+// are joined by the fixed butterfly of wave_sum, so results stay bitwise reproducible -- and parked per sorted position for
+// the thread-per-row kernels below, which skip the walk of such rows.  A workgroup owns 64 consecutive sorted rows (16 per
+// wave); a segment lying strictly inside them is shorter than 64 rows, so looking at the first and the last row's segment
+// decides block-uniformly whether there is anything to do: batches without long groups pay one empty launch.
+#define PW_LONG 512
+template <int FLAGS, int MODE>                     // MODE 0: pair counts;  1: BPR loss and gradient terms
+__global__ void __launch_bounds__(256)
+k_pair_long(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B,
+            float factor, int32_t* __restrict__ long_cnt, float* __restrict__ long_la, float* __restrict__ long_ga) {
+    const int64_t k0 = (int64_t)blockIdx.x * 64;
+    if (k0 >= B) return;
+    const int64_t kl = min(B, k0 + 64) - 1;
+    const int g0 = seg_id[k0], g1 = seg_id[kl];
+    if (seg_first[g0 + 1] - seg_first[g0] <= PW_LONG && seg_first[g1 + 1] - seg_first[g1] <= PW_LONG) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = 0; r < 16; ++r) {
+        const int64_t k = k0 + w * 16 + r;
+        if (k > kl) break;                          // wave-uniform
+        const int g = seg_id[k];
+        const int s = seg_first[g], e = seg_first[g + 1];
+        if (e - s <= PW_LONG) continue;             // wave-uniform
+        const Member me = mem[k];
+        if (MODE == 0) {
+            int cc = 0;
+#pragma unroll 4
+            for (int j = s + lane; j < e; j += 64) {
+                const Member o = mem[j];
+                cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
+            }
+            cc = wave_sum(cc);
+            if (lane == 0) long_cnt[k] = cc;
+        } else {
+            float la = 0.f, ga = 0.f;
+#pragma unroll 4
+            for (int j = s + lane; j < e; j += 64) {
+                const Member o = mem[j];
+                bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
+            }
+            la = wave_sum(la);
+            ga = wave_sum(ga);
+            if (lane == 0) {
+                long_la[k] = la;
+                long_ga[k] = ga;
+            }
+        }
+    }
+}
+
 // ---- count ---------------------------------------------------------------------------------------
 template <int FLAGS>
 __global__ void __launch_bounds__(256)
 k_pair_count(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
-             const int32_t* __restrict__ super_id, int64_t B, int32_t* __restrict__ cnt_row,
+             const int32_t* __restrict__ super_id, int64_t B, const int32_t* __restrict__ long_cnt, int32_t* __restrict__ cnt_row,
              unsigned long long* __restrict__ cnt_super, unsigned long long* __restrict__ n_pair) {
     __shared__ long long red[16];
     __shared__ Member staged[PW_STAGE];
@@ -100,8 +173,10 @@ k_pair_count(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id,
         const Member me = mem[k];
         const int g = seg_id[k];
         const int s = seg_first[g], e = seg_first[g + 1];
+        const bool is_long = e - s > PW_LONG;       // walked by k_pair_long
         int cc = 0;
-        PW_WALK(in_lds, staged, sbase, mem, s, e, j, o, { cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0; });
+        PW_WALK(in_lds, staged, sbase, mem, (is_long ? e : s), e, j, o, { cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0; });
+        if (is_long) cc = long_cnt[k];
         cnt_row[me.row] = cc;
         if (cc) atomicAdd(&cnt_super[super_id[k]], (unsigned long long)cc);   // integer atomics: order-independent
         c = cc;
@@ -147,7 +222,8 @@ __global__ void __launch_bounds__(256)
 k_pair_bpr(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
            const int32_t* __restrict__ super_id, const unsigned long long* __restrict__ cnt_super,
            const unsigned long long* __restrict__ n_pair, int64_t B, float factor, float power, int reduce_mean,
-           double* __restrict__ block_loss, float* __restrict__ dscores) {
+           const float* __restrict__ long_la, const float* __restrict__ long_ga, double* __restrict__ block_loss,
+           float* __restrict__ dscores) {
     __shared__ double red[16];
     __shared__ Member staged[PW_STAGE];
     int sbase;
@@ -164,26 +240,13 @@ k_pair_bpr(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, c
             // cnt == 0: this row takes part in no pair, its weight is never used (avoid 0**negative = inf -> inf*0)
             w = (cnt == 0.f) ? 1.f : ((power == 1.f) ? cnt : powf(cnt, power));
         }
-        // Branch-light walk of the row's segment: labels are strictly ordered in at most one direction, so at most one of
-        // (me, o) / (o, me) is a pair; both take their terms from ONE exp(-|x|) (x = the active pair's score difference):
-        // softplus(-x) = max(-x, 0) + log(1 + e),  sigma(-x) = e / (1 + e) or 1 / (1 + e).  Lanes of a wave walk segments of
-        // different membership, so per-lane branches around the transcendentals would serialise both sides.
-        // Hardware exp2 / log2 / rcp (1 ulp each) instead of libm expf / log1pf / IEEE division: ~25 instead of ~100
-        // instructions per candidate.  e is in (0, 1], so 1 + e is in (1, 2] (never denormal): log(1 + e) is off by at most
-        // the rounding of 1 + e, 6e-8 absolute, on terms that sum to O(1) per pair -- two orders below the 1e-5 parity bar.
+        const bool is_long = e - s > PW_LONG;       // walked by k_pair_long
         float la = 0.f, ga = 0.f;
-        PW_WALK(in_lds, staged, sbase, mem, s, e, j, o, {
-            const bool fwd = j != (int)k && pair_ok<FLAGS>(me, o);      // me is the positive of (me, o)
-            const bool bwd = j != (int)k && pair_ok<FLAGS>(o, me);      // me is the negative of (o, me)
-            const float d = factor * (me.score - o.score);
-            const float x = fwd ? d : -d;
-            const float ex = __builtin_amdgcn_exp2f(-1.44269504f * fabsf(x));
-            const float inv = __builtin_amdgcn_rcpf(1.f + ex);
-            const float sg = x >= 0.f ? ex * inv : inv;                                          // sigma(-x)
-            const float sp = fmaxf(-x, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);     // softplus(-x)
-            la += fwd ? sp : 0.f;
-            ga += fwd ? -sg : (bwd ? sg : 0.f);
-        });
+        PW_WALK(in_lds, staged, sbase, mem, (is_long ? e : s), e, j, o, { bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga); });
+        if (is_long) {
+            la = long_la[k];
+            ga = long_ga[k];
+        }
         const float denom = reduce_mean ? ((float)(*n_pair) + 1.0e-10f) : 1.f;
         dscores[me.row] = w * factor * ga / denom;
         lsum = (double)(w * la);
@@ -260,6 +323,7 @@ extern "C" size_t recnow_pairwise_workspace_bytes(int64_t B) {
     size_t nb = (size_t)rn_cdiv(B > 0 ? B : 1, RN_PW_T);
     if (nb < RN_VEC_BLOCKS) nb = RN_VEC_BLOCKS;
     s += rn_align(nb * sizeof(double));
+    s += 3 * rn_align((size_t)(B > 0 ? B : 1) * sizeof(float));          // k_pair_long: counts, loss and gradient terms per sorted row
     s += rn_scan_ws_bytes(B);
     return s;
 }
@@ -271,6 +335,33 @@ extern "C" size_t recnow_pairwise_workspace_bytes(int64_t B) {
         case 2: hipLaunchKernelGGL(KERNEL<2>, G, RN_PW_T, 0, st, __VA_ARGS__); break;           \
         default: hipLaunchKernelGGL(KERNEL<3>, G, RN_PW_T, 0, st, __VA_ARGS__); break;          \
     }
+
+#define RN_DISPATCH_LONG(MODE, ...)                                                                              \
+    switch (flags & 3) {                                                                                         \
+        case 0: hipLaunchKernelGGL((k_pair_long<0, MODE>), rn_cdiv(B, 64), 256, 0, st, __VA_ARGS__); break;      \
+        case 1: hipLaunchKernelGGL((k_pair_long<1, MODE>), rn_cdiv(B, 64), 256, 0, st, __VA_ARGS__); break;      \
+        case 2: hipLaunchKernelGGL((k_pair_long<2, MODE>), rn_cdiv(B, 64), 256, 0, st, __VA_ARGS__); break;      \
+        default: hipLaunchKernelGGL((k_pair_long<3, MODE>), rn_cdiv(B, 64), 256, 0, st, __VA_ARGS__); break;     \
+    }
+
+// workspace layout: members (B + 1) | per-block loss partials | long-row counts | long-row loss terms | long-row gradient terms
+struct PairWs {
+    Member* mem;
+    double* part;
+    int32_t* long_cnt;
+    float *long_la, *long_ga;
+};
+static inline PairWs pair_ws(void* ws, size_t ws_bytes, int64_t B) {
+    RnCarver c(ws, ws_bytes);
+    PairWs p;
+    p.mem = c.take<Member>(B + 1);
+    const int G = rn_cdiv(B, RN_PW_T);
+    p.part = c.take<double>(G > RN_VEC_BLOCKS ? G : RN_VEC_BLOCKS);
+    p.long_cnt = c.take<int32_t>(B);
+    p.long_la = c.take<float>(B);
+    p.long_ga = c.take<float>(B);
+    return p;
+}
 
 // The Member array lives at the start of the pairwise workspace; every entry point re-packs it (B x 16 B).
 static int pack_members(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order, int64_t B,
@@ -293,11 +384,13 @@ extern "C" int recnow_pair_count(const float* scores, const float* labels, const
     }
     if (!scores || !labels || !order || !seg_id || !seg_first || !super_id || !cnt_row || !cnt_super || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
-    Member* mem = (Member*)ws;
+    const PairWs pw = pair_ws(ws, ws_bytes, B);
+    Member* mem = pw.mem;
     int rc = pack_members(scores, labels, mask, order, B, mem, st, cnt_super, n_pair);      // also clears cnt_super[0..B) and *n_pair
     if (rc) return rc;
     const int G = rn_cdiv(B, RN_PW_T);
-    RN_DISPATCH_FLAGS(k_pair_count, mem, seg_id, seg_first, super_id, B, cnt_row, (unsigned long long*)cnt_super,
+    RN_DISPATCH_LONG(0, mem, seg_id, seg_first, B, 1.f, pw.long_cnt, pw.long_la, pw.long_ga);
+    RN_DISPATCH_FLAGS(k_pair_count, mem, seg_id, seg_first, super_id, B, pw.long_cnt, cnt_row, (unsigned long long*)cnt_super,
                       (unsigned long long*)n_pair);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
@@ -345,15 +438,16 @@ extern "C" int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, 
     if (!scores || !labels || !order || !seg_id || !seg_first || !super_id || !n_pair || !dscores || !ws) return RECNOW_EINVAL;
     if (power != 0.f && !cnt_super) return RECNOW_EINVAL;
     if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
-    RnCarver c(ws, ws_bytes);
-    Member* mem = c.take<Member>(B + 1);
+    const PairWs pw = pair_ws(ws, ws_bytes, B);
+    Member* mem = pw.mem;
     const int G = rn_cdiv(B, RN_PW_T);
-    double* part = c.take<double>(G > RN_VEC_BLOCKS ? G : RN_VEC_BLOCKS);
+    double* part = pw.part;
     // RECNOW_PAIR_MEMBERS_PACKED: `ws` still holds the members recnow_pair_count packed from these very inputs
     int rc = (flags & RECNOW_PAIR_MEMBERS_PACKED) ? RECNOW_OK : pack_members(scores, labels, mask, order, B, mem, st);
     if (rc) return rc;
+    RN_DISPATCH_LONG(1, mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga);
     RN_DISPATCH_FLAGS(k_pair_bpr, mem, seg_id, seg_first, super_id, (const unsigned long long*)cnt_super,
-                      (const unsigned long long*)n_pair, B, factor, power, reduce_mean, part, dscores);
+                      (const unsigned long long*)n_pair, B, factor, power, reduce_mean, pw.long_la, pw.long_ga, part, dscores);
     hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, part, G, (const unsigned long long*)n_pair, (int64_t)0, reduce_mean, loss);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;

@@ -300,3 +300,36 @@ def test_empty_batch(dev):
     assert loss.item() == 0.0 and n.item() == 0.0 and s.grad.shape == (0,)
     pos, neg = M.pair_indices(s.detach(), y, g)
     assert pos.numel() == 0 and neg.numel() == 0
+
+
+@pytest.mark.parametrize('wrong', [False, True])
+def test_long_and_short_groups_side_by_side(dev, wrong):
+    """Groups on both sides of the wave-per-row threshold (512 rows), starting and ending anywhere relative to the 64-row
+    blocks of the long-group kernel and the 256-row blocks of the thread-per-row kernels; three label levels, a sample
+    mask, occurrence weights.  Loss, pair count and gradient against the plain-C restatement."""
+    import pairs_oracle as C
+    M = _mod()
+    rng = np.random.default_rng(31)
+    sizes = [513, 512, 1, 700, 63, 511, 2, 1025, 64, 900, 5, 514]
+    g = np.repeat(np.arange(len(sizes)), sizes)
+    B = g.size
+    rng.shuffle(g)
+    g = g.astype(np.float32)
+    y = rng.integers(0, 3, B).astype(np.float32)
+    s = rng.normal(size=B).astype(np.float32)
+    m = rng.random(B) < 0.9
+    flags = 3 if wrong else 1
+    sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+    loss, n = M.pairwise_loss(sd, torch.from_numpy(y).to(dev), torch.from_numpy(g).to(dev), only_use_wrong_order_pair=wrong,
+                              return_num_pair=True, click_occurance_power=-0.5, mask=torch.from_numpy(m).to(dev))
+    loss.backward()
+    closs, cd, P = C.pairwise_bpr(g, y, s, m, flags=flags, power=-0.5)
+    assert int(n.item()) == P
+    assert abs(loss.item() - closs) <= RTOL * abs(closs)
+    assert np.abs(sd.grad.cpu().numpy() - cd).max() <= RTOL * np.abs(cd).max()
+    # bitwise reproducible run to run (fixed reduction order in both kernels)
+    sd2 = torch.from_numpy(s).to(dev).requires_grad_(True)
+    loss2 = M.pairwise_loss(sd2, torch.from_numpy(y).to(dev), torch.from_numpy(g).to(dev), only_use_wrong_order_pair=wrong,
+                            click_occurance_power=-0.5, mask=torch.from_numpy(m).to(dev))
+    loss2.backward()
+    assert loss2.item() == loss.item() and torch.equal(sd2.grad, sd.grad)
