@@ -84,6 +84,22 @@ __device__ __forceinline__ bool stage_members(const Member* __restrict__ mem, co
         }                                                                 \
     } while (0)
 
+// the same two loops with a stride of one wave: lanes of a wave share the walk of ONE row (k_pair_long)
+#define PW_WALK_STRIDED(IN_LDS, STAGED, SBASE, MEM, S, E, J, O, BODY)    \
+    do {                                                                  \
+        if (IN_LDS) {                                                     \
+            _Pragma("unroll 4") for (int J = (S); J < (E); J += 64) {    \
+                const Member O = (STAGED)[J - (SBASE)];                   \
+                BODY                                                      \
+            }                                                             \
+        } else {                                                          \
+            _Pragma("unroll 4") for (int J = (S); J < (E); J += 64) {    \
+                const Member O = (MEM)[J];                                \
+                BODY                                                      \
+            }                                                             \
+        }                                                                 \
+    } while (0)
+
 // One candidate of a row's walk.  Labels are strictly ordered in at most one direction, so at most one of (me, o) / (o, me) is a
 // pair; both take their terms from ONE exp(-|x|) (x = the active pair's score difference): softplus(-x) = max(-x, 0) +
 // log(1 + e), sigma(-x) = e / (1 + e) or 1 / (1 + e).  No per-lane branches around the transcendentals (lanes of a wave walk
@@ -110,48 +126,55 @@ __device__ __forceinline__ void bpr_term(const Member& me, const Member& o, bool
 // SURVEY 8d) is 2048 dependent iterations per lane whatever the rest of the batch looks like.  Rows of segments longer than
 // PW_LONG are therefore walked by a whole wave each -- lanes stride over the members (coalesced 16-byte reads), partial sums
 // are joined by the fixed butterfly of wave_sum, so results stay bitwise reproducible -- and parked per sorted position for
-// the thread-per-row kernels below, which skip the walk of such rows.  A workgroup owns 64 consecutive sorted rows (16 per
-// wave); a segment lying strictly inside them is shorter than 64 rows, so looking at the first and the last row's segment
-// decides block-uniformly whether there is anything to do: batches without long groups pay one empty launch.
+// the thread-per-row kernels below, which skip the walk of such rows.  A workgroup owns 64 consecutive sorted rows; a segment
+// lying strictly inside them is shorter than 64 rows, so only the first and the last row's segment can be long, and looking at
+// those two decides block-uniformly whether there is anything to do: batches without long groups pay one empty launch.
 #define PW_LONG 512
 template <int FLAGS, int MODE>                     // MODE 0: pair counts;  1: BPR loss and gradient terms
 __global__ void __launch_bounds__(256)
 k_pair_long(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B,
             float factor, int32_t* __restrict__ long_cnt, float* __restrict__ long_la, float* __restrict__ long_ga) {
+    __shared__ Member staged[PW_STAGE];
     const int64_t k0 = (int64_t)blockIdx.x * 64;
     if (k0 >= B) return;
     const int64_t kl = min(B, k0 + 64) - 1;
     const int g0 = seg_id[k0], g1 = seg_id[kl];
-    if (seg_first[g0 + 1] - seg_first[g0] <= PW_LONG && seg_first[g1 + 1] - seg_first[g1] <= PW_LONG) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int r = 0; r < 16; ++r) {
-        const int64_t k = k0 + w * 16 + r;
-        if (k > kl) break;                          // wave-uniform
-        const int g = seg_id[k];
+    // the only segments of these 64 rows that can be long: the first row's and the last row's (everything below is block-uniform)
+    bool staged_used = false;
+    for (int phase = 0; phase < 2; ++phase) {
+        if (phase == 1 && g1 == g0) break;
+        const int g = phase == 0 ? g0 : g1;
         const int s = seg_first[g], e = seg_first[g + 1];
-        if (e - s <= PW_LONG) continue;             // wave-uniform
-        const Member me = mem[k];
-        if (MODE == 0) {
+        if (e - s <= PW_LONG) continue;
+        // members of the segment through LDS when they fit (32 KB): lanes then read consecutive 16-byte records at LDS speed and
+        // the walk is bound by its ~25 VALU instructions per candidate; from global memory it was bound by the read latency
+        const bool in_lds = e - s <= PW_STAGE;
+        if (in_lds) {
+            if (staged_used) __syncthreads();                       // every wave is done with the first segment
+            for (int i = threadIdx.x; i < e - s; i += 256) staged[i] = mem[s + i];
+            __syncthreads();
+            staged_used = true;
+        }
+        const int64_t ka = k0 > s ? k0 : (int64_t)s, kb = kl < (int64_t)e - 1 ? kl : (int64_t)e - 1;
+        for (int64_t k = ka + w; k <= kb; k += 4) {                 // waves take the segment's rows of this block in turn
+            const Member me = mem[k];
             int cc = 0;
-#pragma unroll 4
-            for (int j = s + lane; j < e; j += 64) {
-                const Member o = mem[j];
-                cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
-            }
-            cc = wave_sum(cc);
-            if (lane == 0) long_cnt[k] = cc;
-        } else {
             float la = 0.f, ga = 0.f;
-#pragma unroll 4
-            for (int j = s + lane; j < e; j += 64) {
-                const Member o = mem[j];
-                bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
-            }
-            la = wave_sum(la);
-            ga = wave_sum(ga);
-            if (lane == 0) {
-                long_la[k] = la;
-                long_ga[k] = ga;
+            PW_WALK_STRIDED(in_lds, staged, s, mem, s + lane, e, j, o, {
+                if (MODE == 0) cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
+                else bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
+            });
+            if (MODE == 0) {
+                cc = wave_sum(cc);
+                if (lane == 0) long_cnt[k] = cc;
+            } else {
+                la = wave_sum(la);
+                ga = wave_sum(ga);
+                if (lane == 0) {
+                    long_la[k] = la;
+                    long_ga[k] = ga;
+                }
             }
         }
     }
