@@ -73,15 +73,66 @@ k_dcn_fwd(const float* __restrict__ x, const float* __restrict__ kernels, const 
     __shared__ float red[4];
     constexpr int RPB = 256 / TPR;
     const int t = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
-    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += (int64_t)gridDim.x * RPB) {
+    const int64_t stride = (int64_t)gridDim.x * RPB;
+    if (NV == 1 && L <= DCN_MAX_L) {
+        // One register image per thread and row (D <= TPR * VEC): the L kernel and bias rows are row-invariant and stay in
+        // registers for the whole kernel (read per row and layer they were 2 L dependent L2 round trips between the
+        // reductions), and the next row of x is requested before the current row's L reductions start.
+        float wr[DCN_MAX_L][NV][VEC], br[DCN_MAX_L][NV][VEC];
+#pragma unroll
+        for (int l = 0; l < DCN_MAX_L; ++l) {
+            row_load<TPR, VEC, NV>(wr[l], kernels + (int64_t)(l < L ? l : 0) * D, l < L ? D : 0, t);
+            row_load<TPR, VEC, NV>(br[l], biases ? biases + (int64_t)(l < L ? l : 0) * D : kernels, (biases && l < L) ? D : 0, t);
+        }
+        float xn[NV][VEC];
+        {
+            const int64_t row = (int64_t)blockIdx.x * RPB + rsub;
+            row_load<TPR, VEC, NV>(xn, x + (row < B ? row : 0) * D, row < B ? D : 0, t);
+        }
+        for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += stride) {
+            const int64_t row = row0 + rsub;
+            const bool ok = row < B;
+            float x0[NV][VEC], xl[NV][VEC];
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) xl[i][e] = x0[i][e] = xn[i][e];
+            if (row0 + stride < B) {                                  // block-uniform
+                const int64_t nrow = row0 + stride + rsub;
+                row_load<TPR, VEC, NV>(xn, x + (nrow < B ? nrow : 0) * D, nrow < B ? D : 0, t);
+            }
+#pragma unroll
+            for (int l = 0; l < DCN_MAX_L; ++l) {
+                if (l < L) {
+                    const float c = row_sum<TPR>(row_dot<VEC, NV>(xl, wr[l]), red);
+                    if (csave && ok && t == 0) csave[row * L + l] = c;        // the layer's scalar x_l . w_l: all the backward needs of x_l
+#pragma unroll
+                    for (int i = 0; i < NV; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) xl[i][e] = rn_act(x0[i][e] * c + br[l][i][e], act);
+                }
+            }
+            if (ok) row_store<TPR, VEC, NV>(xl, y + row * D, D, t);
+        }
+        return;
+    }
+    float xn[NV][VEC];                 // the next row of x, requested before the current row's L reductions start
+    {
+        const int64_t row = (int64_t)blockIdx.x * RPB + rsub;
+        row_load<TPR, VEC, NV>(xn, x + (row < B ? row : 0) * D, row < B ? D : 0, t);
+    }
+    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += stride) {
         const int64_t row = row0 + rsub;
         const bool ok = row < B;
         float x0[NV][VEC], xl[NV][VEC], w[NV][VEC], bb[NV][VEC];
-        row_load<TPR, VEC, NV>(x0, x + (ok ? row : 0) * D, ok ? D : 0, t);
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) xl[i][e] = x0[i][e];
+            for (int e = 0; e < VEC; ++e) xl[i][e] = x0[i][e] = xn[i][e];
+        if (row0 + stride < B) {                                      // block-uniform
+            const int64_t nrow = row0 + stride + rsub;
+            row_load<TPR, VEC, NV>(xn, x + (nrow < B ? nrow : 0) * D, nrow < B ? D : 0, t);
+        }
         for (int l = 0; l < L; ++l) {
             row_load<TPR, VEC, NV>(w, kernels + (int64_t)l * D, D, t);
             const float c = row_sum<TPR>(row_dot<VEC, NV>(xl, w), red);
@@ -231,15 +282,45 @@ __device__ __forceinline__ void dcn_bwd_saved_body(const float* __restrict__ x, 
 #pragma unroll
             for (int e = 0; e < VEC; ++e) dw[l][i][e] = db[l][i][e] = 0.f;
 
-    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += (int64_t)gridDim.x * RPB) {
+    // the next row's x, dy and scalars are requested before the current row's L reductions start (NV <= 2: they fit the
+    // register budget; wider register images load in place as before)
+    constexpr bool PRE = NV <= 2;
+    const int64_t stride = (int64_t)gridDim.x * RPB;
+    float xn[NV][VEC], gn[NV][VEC], csn[DCN_MAX_L];
+    if (PRE) {
+        const int64_t row = (int64_t)blockIdx.x * RPB + rsub;
+        const bool ok = row < B;
+        row_load<TPR, VEC, NV>(xn, x + (ok ? row : 0) * D, ok ? D : 0, t);
+        row_load<TPR, VEC, NV>(gn, dy + (ok ? row : 0) * D, ok ? D : 0, t);
+#pragma unroll
+        for (int l = 0; l < DCN_MAX_L; ++l) csn[l] = (ok && l < L) ? csave[row * L + l] : 0.f;
+    }
+    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += stride) {
         const int64_t row = row0 + rsub;
         const bool ok = row < B;
         float x0[NV][VEC], g[NV][VEC], dx0[NV][VEC], tmp[NV][VEC];
-        row_load<TPR, VEC, NV>(x0, x + (ok ? row : 0) * D, ok ? D : 0, t);
-        row_load<TPR, VEC, NV>(g, dy + (ok ? row : 0) * D, ok ? D : 0, t);
         float cs[DCN_MAX_L];
+        if (PRE) {
 #pragma unroll
-        for (int l = 0; l < DCN_MAX_L; ++l) cs[l] = (ok && l < L) ? csave[row * L + l] : 0.f;
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { x0[i][e] = xn[i][e]; g[i][e] = gn[i][e]; }
+#pragma unroll
+            for (int l = 0; l < DCN_MAX_L; ++l) cs[l] = csn[l];
+            if (row0 + stride < B) {                                  // block-uniform
+                const int64_t nrow = row0 + stride + rsub;
+                const bool nok = nrow < B;
+                row_load<TPR, VEC, NV>(xn, x + (nok ? nrow : 0) * D, nok ? D : 0, t);
+                row_load<TPR, VEC, NV>(gn, dy + (nok ? nrow : 0) * D, nok ? D : 0, t);
+#pragma unroll
+                for (int l = 0; l < DCN_MAX_L; ++l) csn[l] = (nok && l < L) ? csave[nrow * L + l] : 0.f;
+            }
+        } else {
+            row_load<TPR, VEC, NV>(x0, x + (ok ? row : 0) * D, ok ? D : 0, t);
+            row_load<TPR, VEC, NV>(g, dy + (ok ? row : 0) * D, ok ? D : 0, t);
+#pragma unroll
+            for (int l = 0; l < DCN_MAX_L; ++l) cs[l] = (ok && l < L) ? csave[row * L + l] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
