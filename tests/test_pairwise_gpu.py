@@ -333,3 +333,33 @@ def test_long_and_short_groups_side_by_side(dev, wrong):
                             click_occurance_power=-0.5, mask=torch.from_numpy(m).to(dev))
     loss2.backward()
     assert loss2.item() == loss.item() and torch.equal(sd2.grad, sd.grad)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_groups_beyond_the_lds_staging_size(dev, seed):
+    """Groups of more than 2048 rows (the LDS staging size of both walks: the wave-per-row kernel and the thread-per-row
+    kernels then read the members from global memory) next to groups of exactly 2048 / 2049 rows and small ones, batch size
+    not a multiple of any block size; pair list, count, loss and gradient against the plain-C restatement."""
+    import pairs_oracle as C
+    M = _mod()
+    rng = np.random.default_rng(100 + seed)
+    sizes = [5000, 2049, 2048, 37, 1, 3, 600, 2500 + seed, 129]
+    g = np.repeat(np.arange(len(sizes)), sizes)
+    B = g.size
+    rng.shuffle(g)
+    g = g.astype(np.float32)
+    y = (rng.random(B) < 0.2).astype(np.float32)
+    s = rng.normal(size=B).astype(np.float32)
+    m = rng.random(B) < 0.95
+    gd, yd, md = torch.from_numpy(g).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(m).to(dev)
+    sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+    loss, n = M.pairwise_loss(sd, yd, gd, return_num_pair=True, click_occurance_power=-0.5, mask=md)
+    loss.backward()
+    closs, cd, P = C.pairwise_bpr(g, y, s, m, power=-0.5)
+    assert int(n.item()) == P
+    assert abs(loss.item() - closs) <= RTOL * abs(closs)
+    assert np.abs(sd.grad.cpu().numpy() - cd).max() <= RTOL * np.abs(cd).max()
+    if seed == 0:
+        pos, neg = M.pair_indices(sd.detach(), yd, gd, mask=md)
+        cpos, cneg = C.pair_indices(g, y, s, m)
+        assert np.array_equal(pos.cpu().numpy(), cpos) and np.array_equal(neg.cpu().numpy(), cneg)
