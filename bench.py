@@ -11,10 +11,12 @@ A step = one forward + backward pass of the hot path over one resident batch (in
 Data-parallel (weak scaling): every rank owns whole groups, the loss is combined with one 2-float all-reduce
 (rec_now_amd/dp.py).  Prints ONE JSON line on rank 0.
 
-roofline:     the dominant kernel is the exact-fp32 MFMA GEMM; `achieved` = algorithmic flops (2*M*N*K per launch)
-              / HIP-event time of the launches of the busiest GEMM tile family during the timed steps (every 5th launch
-              is timed: 18 launches per step, so every launch position is sampled equally), measured by the library's
-              own event hook on the launch stream (recnow_prof_*).
+roofline:     the dominant kernel is the exact-fp32 MFMA GEMM `k_gemm<128,128,..>` (the K = 1024 and K = B products of the
+              step; the K = 144 products run in the persistent `k_gemm_shortk`, a kernel of its own in rocprof and in
+              `all_gemm`); `achieved` = algorithmic flops (2*M*N*K per launch) / HIP-event time of the launches of the
+              busiest GEMM kernel during the timed steps (every 5th launch is timed: 18 launches per step, so every
+              launch position is sampled equally), measured by the library's own event hook on the launch stream
+              (recnow_prof_*).
 cpu_baseline: the oracle (dense O(B^2) reference formulation, torch CPU, oracle/dense_ref.py) timed on this host on a
               bounded sample of the same workload (B_s rows with the same 64 rows/group), rank 0, N = 1 only.
 """
@@ -39,7 +41,8 @@ SUB, LAYERS, EXPERTS = 64, 3, 2
 ROWS_PER_GROUP = 64
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PROF_EVERY = 5                        # time every 5th GEMM launch (18 per step: every launch position gets sampled)
-GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>'}
+GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>',
+             5: 'k_gemm_shortk'}          # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
 
 
 def synth_batch(B, seed, rank=0):

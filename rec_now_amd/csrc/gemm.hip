@@ -174,9 +174,8 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     if (!k.xcd_remap && grid.y > 1 && grid.x % 8 == 0 && d->sp_r == 0 && !d->as_out) k.xcd_remap = 2;
     const bool a_kc = d->a_trans == 0, b_kc = d->b_trans != 0;
     int rc;
-    const int tag = (c.BM == 256 && c.BN == 32) ? RN_TAG_GEMM_256x32 : (c.BM == 256) ? RN_TAG_GEMM_256x64
-                  : (c.BN == 160) ? RN_TAG_GEMM_128x160 : RN_TAG_GEMM_128x128;
-    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(tag, d->prof_flops > 0.0 ? d->prof_flops : 2.0 * d->M * d->N * (double)d->K * d->batch, st) : nullptr;
+    int tag = (c.BM == 256 && c.BN == 32) ? RN_TAG_GEMM_256x32 : (c.BM == 256) ? RN_TAG_GEMM_256x64
+            : (c.BN == 160) ? RN_TAG_GEMM_128x160 : RN_TAG_GEMM_128x128;
     // short-K products (K <= 256, e.g. the K = N*S+N = 130 contractions of DCN-v2) are prologue/epilogue dominated:
     // BK = 16 halves the LDS footprint so 4 workgroups per CU overlap each other's load/store phases.
     const bool short_k = d->K <= 256 || (d->c2_mode && d->K <= 512);
@@ -186,6 +185,12 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     // else (and every edge shape) runs the general kernel of the same tile family.
     rc = RECNOW_EUNSUPPORTED;
     int xf = (d->sp_r > 0 ? 1 : 0) | (d->eu_r > 0 ? 2 : 0);
+    // the persistent short-K kernel takes the plain products below (same condition as its branch)
+    const bool use_shortk = !xf && !d->as_out && !edge && bk16 && c.BN == 128 && a_kc && k.splitk == 1 && d->batch == 1 && d->a_mode == 0 &&
+                            d->b_mode == 0 && !d->bias && d->act == RECNOW_ACT_LINEAR && !d->c_trans &&
+                            (!d->emul || d->e_mode == RECNOW_OPMODE_MUL);
+    if (use_shortk) tag = RN_TAG_GEMM_SHORTK;
+    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(tag, d->prof_flops > 0.0 ? d->prof_flops : 2.0 * d->M * d->N * (double)d->K * d->batch, st) : nullptr;
     if (d->as_out) {      // A-stream side output: instantiated with the side product of dT2g; written by the first column tile
         if (xf != 1 || d->a_trans || d->a_mode != RECNOW_OPMODE_MUL || d->batch != 1 || k.splitk != 1 ||
             !host_aligned(d->as_in, d->lda, 0) || !host_aligned(d->as_out, d->lda, 0))
@@ -196,8 +201,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
         if (edge || c.BM != 128 || c.BN != 128 || d->c2_mode) return RECNOW_EUNSUPPORTED;
         rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
-    } else if (!edge && bk16 && c.BN == 128 && a_kc && k.splitk == 1 && d->batch == 1 && d->a_mode == 0 && d->b_mode == 0 &&
-               !d->bias && d->act == RECNOW_ACT_LINEAR && !d->c_trans && (!d->emul || d->e_mode == RECNOW_OPMODE_MUL)) {
+    } else if (use_shortk) {
         // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)
         if (d->c2_mode && (!host_aligned(d->C2, d->ldc2, 0) || (d->c2_mode == 2 && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
         rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, st);

@@ -12,6 +12,7 @@ struct RnProfRecord {
 #define RN_TAG_GEMM_128x160 2
 #define RN_TAG_GEMM_256x64 3
 #define RN_TAG_GEMM_256x32 4
+#define RN_TAG_GEMM_SHORTK 5        // k_gemm_shortk (persistent, K <= 512): a kernel of its own in rocprof, a family of its own here
 #define RN_TAG_MAX 8
 
 bool rn_prof_on();

@@ -42,8 +42,8 @@ with open('profiles/%s_bench_pmc_hbm.csv' % tag, 'w') as fo:
         b = (2 * fv + wv) * 1024
         w.writerow([k, n, '%.1f' % fv, '%.1f' % wv, '%.0f' % b])
         m = re.match(r'void k_gemm<(\d+), (\d+), (\d+), (\d+),', k)
-        if m or k.startswith('void k_gemm_shortk<'):      # the persistent short-K kernel is a 128x128 (2x2 waves) tile kernel too
-            key = 'k_gemm<%s,%s,%s,%s>' % (m.groups() if m else ('128', '128', '2', '2'))
+        if m or k.startswith('void k_gemm_shortk<'):      # the persistent short-K kernel is a family of its own (bench.py GEMM_TAGS)
+            key = 'k_gemm<%s,%s,%s,%s>' % m.groups() if m else 'k_gemm_shortk'
             fam[key][0] += n
             fam[key][1] += n * b
 traffic = {k: v / n for k, (n, v) in fam.items()}
