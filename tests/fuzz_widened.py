@@ -1,13 +1,14 @@
 """Random-shape sweep of the widened rows (InnerPNN, SENET, attention, focal loss, pooled embedding lookup) and of the
 narrow MultiDense kernels against the oracle on the GPU.
-Not part of the test suite (minutes of small launches); usage: python tools/fuzz_widened.py [n_cases] [seed]"""
+Test infrastructure (it checks against the oracle, so it lives under tests/), but not collected by pytest (minutes of small
+launches); usage: python tests/fuzz_widened.py [n_cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # tests/ -> repository root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
