@@ -82,13 +82,13 @@ def test_senet_reference_golden(dev, golden):
                                                    # field, hidden width 1; and shapes just outside (F > 64, F*D/4 > 256) on the unfused path
                                                    (1001, [16] * 64, 1.0, False), (6, [4] * 64, 0.5, True), (130, [64] * 16, 0.1, True),
                                                    (9, [8], 1.0, True), (33, [4] * 3, 0.2, False), (50, [4] * 65, 0.5, True), (20, [32] * 40, 0.25, True)])
-def test_senet_fwd_bwd_vs_oracle(dev, B, dims, ratio, use_bias):
+def test_senet_fwd_bwd_vs_oracle(dev, B, dims, ratio, use_bias, act_inner='relu'):
     from rec_now_amd.layers.senet_layer import SENETLayer
     rng = np.random.default_rng(B + len(dims))
     xs = [rng.uniform(-1, 1, (B, d)).astype(np.float32) for d in dims]
     total = sum(dims)
     gy = rng.normal(size=(B, total)).astype(np.float32)
-    layer = SENETLayer(ratio, activation_inner='relu', activation_outer='sigmoid', use_bias=use_bias, bias_initializer='random_normal')
+    layer = SENETLayer(ratio, activation_inner=act_inner, activation_outer='sigmoid', use_bias=use_bias, bias_initializer='random_normal')
     xd = [torch.from_numpy(x).to(dev).requires_grad_(True) for x in xs]
     y = layer(xd)
     y.backward(torch.from_numpy(gy).to(dev))
@@ -99,7 +99,7 @@ def test_senet_fwd_bwd_vs_oracle(dev, B, dims, ratio, use_bias):
     k64 = [t.detach().cpu().double().requires_grad_(True) for t in k]
     b64 = [t.detach().cpu().double().requires_grad_(True) for t in bs] if use_bias else None
     x64 = [torch.from_numpy(x).double().requires_grad_(True) for x in xs]
-    ry = R.senet_layer(x64, k64, b64, 'relu', 'sigmoid')
+    ry = R.senet_layer(x64, k64, b64, act_inner, 'sigmoid')
     ry.backward(torch.from_numpy(gy).double())
     close(y, ry)
     for a, b in zip(xd, x64):
