@@ -1,0 +1,53 @@
+"""TEST INFRASTRUCTURE: the fp64 oracle (oracle/dense_ref.py) evaluated over a large batch in row chunks.
+
+The interaction layers are row-separable: outputs and input gradients of a row depend on that row only, and every weight
+gradient is a plain sum over rows.  So the oracle at BASELINE.json's sizes (B = 65536 x D = 1024, where one fp64 autograd
+graph of the whole batch would need tens of GB) is the chunk-wise oracle with the weight gradients accumulated in fp64."""
+import numpy as np
+import torch
+
+
+def weights64(named):
+    """{name: tensor} -> {name: fp64 CPU leaf with requires_grad}."""
+    return {k: v.detach().cpu().double().requires_grad_(True) for k, v in named.items()}
+
+
+def run_chunked(fwd, x, gy, weights, chunk=4096, want_dx=True):
+    """fwd(x64_chunk) -> output tensor or list of tensors, built from the fp64 leaves in `weights` (a dict).
+    gy: upstream gradient(s), same structure as the output, or a callable (lo, hi, outs) -> list of gradients.
+    Returns (outs, dx, wgrads): outs = list of np.float64 arrays for the full batch, dx np array (or None), wgrads dict."""
+    B = x.shape[0]
+    outs_all, dx_all = None, (np.empty(tuple(x.shape), np.float64) if want_dx else None)
+    acc = {k: torch.zeros_like(v) for k, v in weights.items()}
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        for v in weights.values():
+            v.grad = None
+        xc = x[lo:hi].detach().cpu().double().requires_grad_(want_dx)
+        out = fwd(xc)
+        outs = list(out) if isinstance(out, (list, tuple)) else [out]
+        if outs_all is None:
+            outs_all = [np.empty((B,) + tuple(o.shape[1:]), np.float64) for o in outs]
+        for dst, o in zip(outs_all, outs):
+            dst[lo:hi] = o.detach().numpy()
+        if gy is not None:
+            if callable(gy):
+                gs = gy(lo, hi, outs)
+            else:
+                gs = [g[lo:hi].detach().cpu().double() for g in (gy if isinstance(gy, (list, tuple)) else [gy])]
+            torch.autograd.backward(outs, gs)
+            if want_dx:
+                dx_all[lo:hi] = xc.grad.numpy()
+            for k, v in weights.items():
+                if v.grad is not None:
+                    acc[k] += v.grad
+    return outs_all, dx_all, {k: v.numpy() for k, v in acc.items()}
+
+
+def close(a, b, rtol=1e-5, scale=None, what=''):
+    a = a.detach().cpu().double().numpy() if hasattr(a, 'detach') else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if hasattr(b, 'detach') else np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    s = max(np.abs(b).max() if scale is None else scale, 1e-30)
+    err = np.abs(a - b).max()
+    assert err <= rtol * s, '%s: max err %.3g vs scale %.3g (rel %.3g > %.1g)' % (what, err, s, err / s, rtol)

@@ -105,3 +105,98 @@ def test_single_process_passthrough():
     ls.backward()
     lv, p = dp.GradientAllReducer([w]).all_reduce_with_loss(ls, torch.tensor(3.0))
     assert abs(float(lv) - 2.0) < 1e-6 and float(p) == 3.0 and abs(float(w.grad) - 1.0) < 1e-6
+
+
+# ---- world size 4: one-collective form, listwise combination, uneven shards, an empty rank ---------------------------------
+def _owner_uneven(g, world, empty_rank=None):
+    """Whole groups per rank, deliberately uneven: rank 0 owns half of the groups; `empty_rank` owns none."""
+    ranks = [r for r in range(world) if r != empty_rank]
+    uniq = np.unique(g)
+    table = {}
+    for i, gid in enumerate(uniq):
+        table[gid] = ranks[0] if i % 2 == 0 else ranks[1 + (i // 2) % (len(ranks) - 1)]
+    return np.array([table[v] for v in g])
+
+
+def _listwise_sums(g, y, s):
+    """(sum over valid lists of the list loss, number of valid lists) from the oracle, attached to s's graph."""
+    _, rl, rz = R.to_listwise_sample(g, y, s)
+    if rl.shape[0] == 0:
+        return s.sum() * 0.0, 0
+    per_list = R.listwise_loss_via_softmax_cross_entropy_with_logits(rl, rz, do_reduce=False)
+    return per_list.sum(), int(per_list.shape[0])
+
+
+def _worker4(rank, world, port, out, empty_rank):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rec_now_amd import dp
+    g, s, y, w = _make_batch(seed=7, B=900, G=41)
+    mine = _owner_uneven(g, world, empty_rank) == rank
+    gl, yl = torch.from_numpy(g[mine].astype(np.float32)), torch.from_numpy(y[mine])
+    # two parameters in two buckets (bucket_bytes = 8 -> one parameter per bucket): the statistics ride in the LAST bucket
+    wa = torch.from_numpy(w[:2].copy()).requires_grad_(True)
+    wb = torch.from_numpy(w[2:3].copy()).requires_grad_(True)
+    sc = torch.from_numpy(s[mine]) * wa[0] + wa[1] + wb[0] * torch.from_numpy(s[mine]) ** 2
+    f = lambda p, n, wgt: R.bpr_loss_func(p, n, wgt, 1.0, reduce_mean=False)      # noqa: E731
+    if mine.sum() > 0:
+        local_sum, n_pair = R.pairwise_loss(sc, yl, gl, f, return_num_pair=True)
+    else:
+        local_sum, n_pair = sc.sum() * 0.0, 0.0                                     # a rank without rows still joins the collective
+    local_sum.backward()
+    red = dp.GradientAllReducer([wa, wb], bucket_bytes=8)
+    assert len(red.buckets) == 2
+    loss_val, p_glob = red.all_reduce_with_loss(local_sum, torch.tensor(float(n_pair)))
+    # listwise: per-rank sums of list losses + valid-list counts -> global mean over all valid lists
+    wl = torch.from_numpy(w[:2].copy()).requires_grad_(True)
+    sl = torch.from_numpy(s[mine]) * wl[0] + wl[1]
+    lsum, nv = _listwise_sums(gl, yl, sl)
+    lw_bw, lw_val, nv_glob = dp.global_listwise_loss(lsum, torch.tensor(float(nv)))
+    lw_bw.backward()
+    red2 = dp.GradientAllReducer([wl])
+    red2.all_reduce()
+    out[rank] = (float(loss_val), float(p_glob), wa.grad.numpy().copy(), wb.grad.numpy().copy(), int(mine.sum()),
+                 float(lw_val), float(nv_glob), wl.grad.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run4(empty_rank):
+    world = 4
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker4, args=(world, port, out, empty_rank), nprocs=world, join=True)
+    g, s, y, w = _make_batch(seed=7, B=900, G=41)
+    wa = torch.from_numpy(w[:2].copy()).requires_grad_(True)
+    wb = torch.from_numpy(w[2:3].copy()).requires_grad_(True)
+    sc = torch.from_numpy(s) * wa[0] + wa[1] + wb[0] * torch.from_numpy(s) ** 2
+    gt, yt = torch.from_numpy(g.astype(np.float32)), torch.from_numpy(y)
+    loss, n_pair = R.pairwise_loss(sc, yt, gt, return_num_pair=True)
+    loss.backward()
+    wl = torch.from_numpy(w[:2].copy()).requires_grad_(True)
+    _, rl, rz = R.to_listwise_sample(gt, yt, torch.from_numpy(s) * wl[0] + wl[1])
+    lw = R.listwise_loss_via_softmax_cross_entropy_with_logits(rl, rz)
+    lw.backward()
+    sizes = [out[r][4] for r in range(world)]
+    assert sum(sizes) == len(g) and len(set(sizes)) > 1                       # uneven shards
+    if empty_rank is not None:
+        assert sizes[empty_rank] == 0
+    rel = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() / max(1.0, np.abs(np.asarray(b)).max())      # noqa: E731
+    for r in range(world):
+        lv, pg, ga, gb, _, lwv, nvg, gl = out[r]
+        assert pg == n_pair
+        assert rel(lv, float(loss)) <= 2e-6
+        assert rel(ga, wa.grad.numpy()) <= 2e-6 and rel(gb, wb.grad.numpy()) <= 2e-6
+        assert nvg == rl.shape[0]
+        assert rel(lwv, float(lw)) <= 2e-6
+        assert rel(gl, wl.grad.numpy()) <= 2e-6
+
+
+def test_four_ranks_uneven_shards():
+    _run4(None)
+
+
+def test_four_ranks_with_an_empty_rank():
+    _run4(2)
