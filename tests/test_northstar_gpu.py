@@ -100,7 +100,9 @@ def test_config3_model_drop_in_signature(dev, B):
     _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), rds_t, w64, chunk=4096)
     close(xd.grad, rdx, what='dx')
     for name, p in named.items():
-        close(p.grad, rgrads[name], what=name)
+        # d loss / d head bias = sum_i dscore_i, which is 0 in exact arithmetic (every pair adds +t to one row and -t to another):
+        # its error is measured against the magnitude of the terms that cancel
+        close(p.grad, rgrads[name], what=name, scale=np.abs(rds).sum() if name == 'head/bias' else None)
 
 
 def test_config2_pairwise_literal_case(dev):
