@@ -268,7 +268,9 @@ int recnow_moe_mix_bwd(const float* gates, const float* const* experts, const fl
 /* ------------------------------------------------------------------------------------------------------------
  * DCNLayer (DCN-v1 cross, reference variant without residual): rec_now/layers/dcn_layer.py:79-103
  *   x_{l+1} = act(x0 * (x_l . w_l) + b_l),  l = 0..L-1;  all L layers fused in one pass over x0 (HBM-bound: 8*B*D
- *   bytes forward, 20*B*D backward incl. the recompute read).
+ *   bytes forward, 20*B*D backward incl. the recompute read).  Any L, any D, any alignment: the fused register kernels
+ *   cover L <= 4 and D <= 4096 (D % 4 == 0, 16-byte aligned rows; else D <= 1024); other shapes run the same math as
+ *   streaming kernels over the per-row scalars (rows kernel + columns kernel, see csrc/dcn.hip).
  *   kernels: (L,D) (row l = kernel_l[:,0]); biases: (L,D) or NULL (use_bias=False); y: (B,D).
  *   csave: optional (B,L) output of the forward, the per-row scalars c_l = x_l . w_l.  Given to the backward, x_l is
  *   elementwise in x0 (one dot-reduce per layer, a wave per row); csave == NULL: the backward recomputes the forward per row
@@ -279,6 +281,18 @@ int recnow_dcn_fwd(const float* x, const float* kernels, const float* biases, in
                    float* csave, void* stream);
 int recnow_dcn_bwd(const float* x, const float* kernels, const float* biases, const float* dy, const float* csave, int64_t B,
                    int D, int L, int act, float* dx, float* dkernels, float* dbiases, void* ws, size_t ws_bytes, void* stream);
+/* One cross layer with its own layer input (one iteration of the loop at rec_now/layers/dcn_layer.py:91-100):
+ *   z = act(x0 * (x_l . w) + b);  c_out (B) = x_l . w is kept for the backward.  Used when the activation between the layers
+ *   is a user callable (keras.activations.get accepts any, dcn_layer.py:30 via keras.layers.Dense): act = RECNOW_ACT_LINEAR
+ *   here and the callable runs on z.  Any D, any alignment.  w, b: (D); b may be NULL.
+ *   backward: dz is the gradient w.r.t. z; z may be NULL when act is linear.  dx0, dxl (B,D) are written (not accumulated);
+ *   dw (D), db (D, may be NULL). */
+size_t recnow_dcn_step_workspace_bytes(int64_t B, int D);
+int recnow_dcn_step_fwd(const float* x0, const float* xl, const float* w, const float* b, int64_t B, int D, int act, float* z,
+                        float* c_out, void* stream);
+int recnow_dcn_step_bwd(const float* x0, const float* xl, const float* w, const float* z, const float* c, const float* dz,
+                        int64_t B, int D, int act, float* dx0, float* dxl, float* dw, float* db, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * DCNMixLayer (DCN-v2 mixture of low-rank experts, reference variant without residual):

@@ -203,6 +203,8 @@ def listwise_loss_via_softmax_cross_entropy_with_logits(labels_for_softmax, logi
 def _act(name):
     if name is None or name == 'linear':
         return lambda v: v
+    if callable(name):                      # keras.activations.get passes callables through
+        return name
     return {'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid}[name]
 
 

@@ -48,6 +48,9 @@ SIGNATURES = {
     'recnow_dcn_workspace_bytes': (_Z, [_L, _I, _I]),
     'recnow_dcn_fwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'recnow_dcn_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    'recnow_dcn_step_workspace_bytes': (_Z, [_L, _I]),
+    'recnow_dcn_step_fwd': (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    'recnow_dcn_step_bwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'recnow_dcn_mix_saved_bytes': (_Z, [_L, _I, _I, _I, _I]),
     'recnow_dcn_mix_workspace_bytes': (_Z, [_L, _I, _I, _I, _I]),
     'recnow_dcn_mix_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P, _I]),

@@ -410,6 +410,122 @@ k_dcn_bwd_saved_wl(const float* __restrict__ x, const float* __restrict__ kernel
     dcn_bwd_saved_body<TPR, VEC, NV, true>(x, kernels, biases, dy, csave, B, D, L, act, dx, part);
 }
 
+
+// ---- general shapes: any degree_of_cross, any D, any alignment ------------------------------------------------------------
+// The fused kernels above keep a row (and 2 L accumulator rows in the backward) in registers: L <= 4, D <= 4096.  Beyond
+// that the same math runs as three streaming kernels built on the per-row scalars c_l = x_l . w_l (reference
+// rec_now/layers/dcn_layer.py:91-100 has no limit on degree_of_cross or input_dim):
+//   * x_l = act(x0 * c_{l-1} + b_{l-1}) is elementwise in x0, and the gradient that reaches layer l < L-1 is rank one per row,
+//     g_l = dc_{l+1} * w_{l+1}  (dc_l = <dz_l, x0>, dz_l = g_l * act'(out_l));
+//   * rows kernel (one workgroup per row, the row is re-read from L1/L2 once per layer): the L scalars dc_l, then
+//     dx0 = sum_l dz_l * c_l + dc_0 * w_0 in one more pass;
+//   * columns kernel (thread per column, row slabs, one layer per blockIdx.z): dw_l = sum_rows x_l * dc_l, db_l = sum_rows dz_l,
+//     reduced over the slabs by the deterministic column sum.
+__device__ __forceinline__ float dcn_xl(float x0, float cprev, float bprev, int l, int act) {
+    return l == 0 ? x0 : rn_act(x0 * cprev + bprev, act);
+}
+
+// y == NULL: only the scalars are produced (backward without csave)
+__global__ void __launch_bounds__(256)
+k_dcn_fwd_general(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases, int64_t B, int D,
+                  int L, int act, float* __restrict__ y, float* __restrict__ csave) {
+    __shared__ float red[16];
+    for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+        const float* xr = x + row * D;
+        float cprev = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const float* w = kernels + (int64_t)l * D;
+            const float* bp = (biases && l > 0) ? biases + (int64_t)(l - 1) * D : nullptr;
+            float p = 0.f;
+            for (int d = threadIdx.x; d < D; d += 256) p += dcn_xl(xr[d], cprev, bp ? bp[d] : 0.f, l, act) * w[d];
+            const float c = block_sum(p, red);
+            if (csave && threadIdx.x == 0) csave[row * L + l] = c;
+            cprev = c;
+        }
+        if (y) {
+            const float* bp = biases ? biases + (int64_t)(L - 1) * D : nullptr;
+            for (int d = threadIdx.x; d < D; d += 256) y[row * D + d] = rn_act(xr[d] * cprev + (bp ? bp[d] : 0.f), act);
+        }
+    }
+}
+
+// dz_l at one element: g * act'(out_l), out_l = act(x0 * c_l + b_l), g = dy (top layer) or dc_{l+1} * w_{l+1}
+__device__ __forceinline__ float dcn_dz(float x0, float dyv, float c, float b, float dcn, float wn, bool top, int act) {
+    const float out = rn_act(x0 * c + b, act);
+    return (top ? dyv : dcn * wn) * rn_act_grad_from_out(out, act);
+}
+
+__global__ void __launch_bounds__(256)
+k_dcn_bwd_rows_general(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases,
+                       const float* __restrict__ dy, const float* __restrict__ csave, int64_t B, int D, int L, int act,
+                       float* __restrict__ dx, float* __restrict__ dcs) {
+    __shared__ float red[16];
+    extern __shared__ float sc[];          // [L] c_l, then [L] dc_l of the current row
+    float* cs = sc;
+    float* ds = sc + L;
+    for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+        const float* xr = x + row * D;
+        const float* gr = dy + row * D;
+        __syncthreads();
+        for (int l = threadIdx.x; l < L; l += 256) cs[l] = csave[row * L + l];
+        __syncthreads();
+        float dcn = 0.f;
+        for (int l = L - 1; l >= 0; --l) {
+            const bool top = l == L - 1;
+            const float c = cs[l];
+            const float* b = biases ? biases + (int64_t)l * D : nullptr;
+            const float* wn = top ? kernels : kernels + (int64_t)(l + 1) * D;
+            float p = 0.f;
+            for (int d = threadIdx.x; d < D; d += 256) {
+                const float x0 = xr[d];
+                p += dcn_dz(x0, top ? gr[d] : 0.f, c, b ? b[d] : 0.f, dcn, wn[d], top, act) * x0;
+            }
+            const float dc = block_sum(p, red);
+            if (threadIdx.x == 0) { ds[l] = dc; dcs[row * L + l] = dc; }
+            dcn = dc;
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float x0 = xr[d], dyv = gr[d];
+            float acc = ds[0] * kernels[d];          // x_0 is x0 itself: the gradient through the first layer's input
+            for (int l = 0; l < L; ++l) {
+                const bool top = l == L - 1;
+                const float wn = top ? 0.f : kernels[(int64_t)(l + 1) * D + d];
+                acc += dcn_dz(x0, dyv, cs[l], biases ? biases[(int64_t)l * D + d] : 0.f, top ? 0.f : ds[l + 1], wn, top, act) * cs[l];
+            }
+            dx[row * D + d] = acc;
+        }
+    }
+}
+
+// part[slab][2L][D]: rows 0..L-1 dkernel, L..2L-1 dbias.  grid (ceil(D/256), slabs, L)
+__global__ void __launch_bounds__(256)
+k_dcn_bwd_cols_general(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases,
+                       const float* __restrict__ dy, const float* __restrict__ csave, const float* __restrict__ dcs, int64_t B, int D,
+                       int L, int act, float* __restrict__ part) {
+    const int d = blockIdx.x * 256 + threadIdx.x, l = blockIdx.z;
+    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(B, r0 + per);
+    if (d >= D) return;
+    const bool top = l == L - 1;
+    const float b = biases ? biases[(int64_t)l * D + d] : 0.f;
+    const float bprev = (biases && l > 0) ? biases[(int64_t)(l - 1) * D + d] : 0.f;
+    const float wn = top ? 0.f : kernels[(int64_t)(l + 1) * D + d];
+    float aw = 0.f, ab = 0.f;
+    for (int64_t row = r0; row < r1; ++row) {
+        const float x0 = x[row * D + d];
+        const float c = csave[row * L + l], cprev = l > 0 ? csave[row * L + l - 1] : 0.f;
+        const float dc = dcs[row * L + l], dcn = top ? 0.f : dcs[row * L + l + 1];
+        ab += dcn_dz(x0, top ? dy[row * D + d] : 0.f, c, b, dcn, wn, top, act);
+        aw += dcn_xl(x0, cprev, bprev, l, act) * dc;
+    }
+    float* slab = part + (int64_t)blockIdx.y * 2 * L * D;
+    slab[(int64_t)l * D + d] = aw;
+    slab[(int64_t)(L + l) * D + d] = ab;
+}
+
+#define DCN_GENERAL_SLABS 64
+
 struct DcnCfg {
     int tpr, vec, nv;
 };
@@ -444,7 +560,9 @@ static inline int dcn_grid(int64_t B, int tpr) {
 extern "C" size_t recnow_dcn_workspace_bytes(int64_t B, int D, int L) {
     if (B <= 0 || D <= 0 || L <= 0) return 256;
     const size_t slabs = rn_align((size_t)2048 * 2 * L * D * sizeof(float));
-    return slabs + rn_colsum_ws_bytes(2048, (int64_t)2 * L * D) + rn_align((size_t)2 * L * D * sizeof(float));
+    // + the per-row scalars c_l / dc_l of the general path (any L, any D)
+    return slabs + rn_colsum_ws_bytes(2048, (int64_t)2 * L * D) + rn_align((size_t)2 * L * D * sizeof(float)) +
+           2 * rn_align((size_t)B * L * sizeof(float));
 }
 
 #define DCN_DISPATCH(KERNEL, SHMEM, ...)                                                                              \
@@ -464,8 +582,12 @@ extern "C" int recnow_dcn_fwd(const float* x, const float* kernels, const float*
     if (B == 0) return RECNOW_OK;
     if (!x || !kernels || !y) return RECNOW_EINVAL;
     DcnCfg cfg;
-    if (!dcn_pick(D, x, y, kernels, &cfg) || (biases && (((uintptr_t)biases & 15) != 0) && cfg.vec == 4)) return RECNOW_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (!dcn_pick(D, x, y, kernels, &cfg) || (biases && (((uintptr_t)biases & 15) != 0) && cfg.vec == 4)) {
+        hipLaunchKernelGGL(k_dcn_fwd_general, (int)(B < 4096 ? B : 4096), 256, 0, st, x, kernels, biases, B, D, L, act, y, csave);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
     const int G = dcn_grid(B, cfg.tpr);
     DCN_DISPATCH(k_dcn_fwd, 0, x, kernels, biases, B, D, L, act, y, csave);
     RN_LAUNCH_CHECK();
@@ -475,7 +597,6 @@ extern "C" int recnow_dcn_fwd(const float* x, const float* kernels, const float*
 extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float* biases, const float* dy, const float* csave, int64_t B,
                               int D, int L, int act, float* dx, float* dkernels, float* dbiases, void* ws, size_t ws_bytes, void* stream) {
     if (B < 0 || D < 1 || L < 1) return RECNOW_EINVAL;
-    if (L > DCN_MAX_L) return RECNOW_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) {
         if (dkernels) RN_HIP(hipMemsetAsync(dkernels, 0, (size_t)L * D * sizeof(float), st));
@@ -485,17 +606,39 @@ extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float*
     if (!x || !kernels || !dy || !dx || !dkernels || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_dcn_workspace_bytes(B, D, L)) return RECNOW_EWORKSPACE;
     DcnCfg cfg;
-    // with the saved scalars a wave per row fits the register file (no recompute state); without them one workgroup per row
-    if (!(csave ? dcn_pick(D, x, dy, dx, &cfg) : dcn_pick_bwd(D, x, dy, dx, &cfg)) ||
-        (cfg.vec == 4 && ((((uintptr_t)kernels | (uintptr_t)biases) & 15) != 0)))
-        return RECNOW_EUNSUPPORTED;
-    if (csave && cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4) cfg = {128, 4, 2};     // 2 waves per wide row: half the registers per lane
-    const int G = dcn_grid(B, cfg.tpr);
     RnCarver c(ws, ws_bytes);
     float* part = c.take<float>((size_t)2048 * 2 * L * D);
     float* sums = c.take<float>((size_t)2 * L * D);
+    float* dcs = c.take<float>((size_t)B * L);
+    float* cs_own = c.take<float>((size_t)B * L);
     void* cs_ws = c.base + c.off;
     const size_t cs_bytes = ws_bytes - c.off;
+    // with the saved scalars a wave per row fits the register file (no recompute state); without them one workgroup per row
+    if (L > DCN_MAX_L || !(csave ? dcn_pick(D, x, dy, dx, &cfg) : dcn_pick_bwd(D, x, dy, dx, &cfg)) ||
+        (cfg.vec == 4 && ((((uintptr_t)kernels | (uintptr_t)biases) & 15) != 0))) {
+        // general path: any L, D, alignment (see k_dcn_bwd_rows_general)
+        const int GR = (int)(B < 4096 ? B : 4096);
+        if (!csave) {
+            hipLaunchKernelGGL(k_dcn_fwd_general, GR, 256, 0, st, x, kernels, biases, B, D, L, act, (float*)nullptr, cs_own);
+            RN_LAUNCH_CHECK();
+            csave = cs_own;
+        }
+        if ((size_t)2 * L * sizeof(float) > 60 * 1024) return RECNOW_EUNSUPPORTED;           // L > 7680 cross layers
+        hipLaunchKernelGGL(k_dcn_bwd_rows_general, GR, 256, (size_t)2 * L * sizeof(float), st, x, kernels, biases, dy, csave, B, D, L, act, dx, dcs);
+        RN_LAUNCH_CHECK();
+        int slabs = (int)((B + 255) / 256);
+        if (slabs > DCN_GENERAL_SLABS) slabs = DCN_GENERAL_SLABS;
+        if (L > 65535) return RECNOW_EUNSUPPORTED;
+        hipLaunchKernelGGL(k_dcn_bwd_cols_general, dim3((D + 255) / 256, slabs, L), 256, 0, st, x, kernels, biases, dy, csave, dcs, B, D, L, act, part);
+        RN_LAUNCH_CHECK();
+        int rcg = rn_colsum(part, nullptr, 0, 0, slabs, (int64_t)2 * L * D, (int64_t)2 * L * D, sums, 0, cs_ws, cs_bytes, st);
+        if (rcg) return rcg;
+        RN_HIP(hipMemcpyAsync(dkernels, sums, (size_t)L * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (dbiases) RN_HIP(hipMemcpyAsync(dbiases, sums + (size_t)L * D, (size_t)L * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return RECNOW_OK;
+    }
+    if (csave && cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4) cfg = {128, 4, 2};     // 2 waves per wide row: half the registers per lane
+    const int G = dcn_grid(B, cfg.tpr);
     const size_t shmem = cfg.tpr < 256 ? (size_t)(256 / cfg.tpr) * D * sizeof(float) : 0;
     const size_t wl_bytes = (size_t)2 * L * D * sizeof(float);            // kernels + biases of every layer, staged in LDS when they fit
     if (csave && shmem + wl_bytes <= 48 * 1024) DCN_DISPATCH(k_dcn_bwd_saved_wl, shmem + wl_bytes, x, kernels, biases, dy, csave, B, D, L, act, dx, part);
@@ -506,5 +649,108 @@ extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float*
     if (rc) return rc;
     RN_HIP(hipMemcpyAsync(dkernels, sums, (size_t)L * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (dbiases) RN_HIP(hipMemcpyAsync(dbiases, sums + (size_t)L * D, (size_t)L * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return RECNOW_OK;
+}
+
+
+// ---- one cross layer with its own x_l input (the unfused route: user-supplied activation callables between the layers) ----
+//     z = act(x0 * (x_l . w) + b)          reference rec_now/layers/dcn_layer.py:91-99, one iteration of the loop
+// forward: c (B) is kept for the backward.  backward: dzp = dz * act'(z); dc = <dzp, x0>; dx0 = dzp * c; dx_l = dc * w;
+// dw = sum_rows x_l * dc; db = sum_rows dzp.
+__global__ void __launch_bounds__(256)
+k_dcn_step_fwd(const float* __restrict__ x0, const float* __restrict__ xl, const float* __restrict__ w, const float* __restrict__ b,
+               int64_t B, int D, int act, float* __restrict__ z, float* __restrict__ c_out) {
+    __shared__ float red[16];
+    for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+        float p = 0.f;
+        for (int d = threadIdx.x; d < D; d += 256) p += xl[row * D + d] * w[d];
+        const float c = block_sum(p, red);
+        if (threadIdx.x == 0) c_out[row] = c;
+        for (int d = threadIdx.x; d < D; d += 256) z[row * D + d] = rn_act(x0[row * D + d] * c + (b ? b[d] : 0.f), act);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_dcn_step_bwd_rows(const float* __restrict__ x0, const float* __restrict__ w, const float* __restrict__ z, const float* __restrict__ c,
+                    const float* __restrict__ dz, int64_t B, int D, int act, float* __restrict__ dx0, float* __restrict__ dxl,
+                    float* __restrict__ dcs) {
+    __shared__ float red[16];
+    for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+        float p = 0.f;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const int64_t i = row * D + d;
+            p += dz[i] * (act ? rn_act_grad_from_out(z[i], act) : 1.f) * x0[i];
+        }
+        const float dc = block_sum(p, red);
+        if (threadIdx.x == 0) dcs[row] = dc;
+        const float cr = c[row];
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const int64_t i = row * D + d;
+            dx0[i] = dz[i] * (act ? rn_act_grad_from_out(z[i], act) : 1.f) * cr;
+            dxl[i] = dc * w[d];
+        }
+    }
+}
+// part[slab][2][D]
+__global__ void __launch_bounds__(256)
+k_dcn_step_bwd_cols(const float* __restrict__ xl, const float* __restrict__ z, const float* __restrict__ dz, const float* __restrict__ dcs,
+                    int64_t B, int D, int act, float* __restrict__ part) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(B, r0 + per);
+    if (d >= D) return;
+    float aw = 0.f, ab = 0.f;
+    for (int64_t row = r0; row < r1; ++row) {
+        const int64_t i = row * D + d;
+        ab += dz[i] * (act ? rn_act_grad_from_out(z[i], act) : 1.f);
+        aw += xl[i] * dcs[row];
+    }
+    part[((int64_t)blockIdx.y * 2) * D + d] = aw;
+    part[((int64_t)blockIdx.y * 2 + 1) * D + d] = ab;
+}
+
+extern "C" size_t recnow_dcn_step_workspace_bytes(int64_t B, int D) {
+    if (B <= 0 || D <= 0) return 256;
+    return rn_align((size_t)DCN_GENERAL_SLABS * 2 * D * sizeof(float)) + rn_align((size_t)2 * D * sizeof(float)) +
+           rn_align((size_t)B * sizeof(float)) + rn_colsum_ws_bytes(DCN_GENERAL_SLABS, (int64_t)2 * D);
+}
+
+extern "C" int recnow_dcn_step_fwd(const float* x0, const float* xl, const float* w, const float* b, int64_t B, int D, int act, float* z,
+                                   float* c_out, void* stream) {
+    if (B < 0 || D < 1) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!x0 || !xl || !w || !z || !c_out) return RECNOW_EINVAL;
+    hipLaunchKernelGGL(k_dcn_step_fwd, (int)(B < 4096 ? B : 4096), 256, 0, (hipStream_t)stream, x0, xl, w, b, B, D, act, z, c_out);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_dcn_step_bwd(const float* x0, const float* xl, const float* w, const float* z, const float* c, const float* dz,
+                                   int64_t B, int D, int act, float* dx0, float* dxl, float* dw, float* db, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    if (B < 0 || D < 1) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        if (dw) RN_HIP(hipMemsetAsync(dw, 0, (size_t)D * sizeof(float), st));
+        if (db) RN_HIP(hipMemsetAsync(db, 0, (size_t)D * sizeof(float), st));
+        return RECNOW_OK;
+    }
+    if (!x0 || !xl || !w || !c || !dz || !dx0 || !dxl || !dw || !ws || (act != RECNOW_ACT_LINEAR && !z)) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_dcn_step_workspace_bytes(B, D)) return RECNOW_EWORKSPACE;
+    RnCarver cv(ws, ws_bytes);
+    float* part = cv.take<float>((size_t)DCN_GENERAL_SLABS * 2 * D);
+    float* sums = cv.take<float>((size_t)2 * D);
+    float* dcs = cv.take<float>((size_t)B);
+    void* cs_ws = cv.base + cv.off;
+    const size_t cs_bytes = ws_bytes - cv.off;
+    hipLaunchKernelGGL(k_dcn_step_bwd_rows, (int)(B < 4096 ? B : 4096), 256, 0, st, x0, w, z, c, dz, B, D, act, dx0, dxl, dcs);
+    RN_LAUNCH_CHECK();
+    int slabs = (int)((B + 255) / 256);
+    if (slabs > DCN_GENERAL_SLABS) slabs = DCN_GENERAL_SLABS;
+    hipLaunchKernelGGL(k_dcn_step_bwd_cols, dim3((D + 255) / 256, slabs), 256, 0, st, xl, z, dz, dcs, B, D, act, part);
+    RN_LAUNCH_CHECK();
+    int rc = rn_colsum(part, nullptr, 0, 0, slabs, (int64_t)2 * D, (int64_t)2 * D, sums, 0, cs_ws, cs_bytes, st);
+    if (rc) return rc;
+    RN_HIP(hipMemcpyAsync(dw, sums, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (db) RN_HIP(hipMemcpyAsync(db, sums + D, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return RECNOW_OK;
 }

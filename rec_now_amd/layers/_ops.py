@@ -100,7 +100,8 @@ def moe_mix(logits, experts):
 
 # ---- DCN-v1 ----------------------------------------------------------------------------------------------------
 class DCNFunction(torch.autograd.Function):
-    """All L cross layers fused.  kernels (L,D), biases (L,D) or None."""
+    """All L cross layers in one call.  kernels (L,D), biases (L,D) or None.  Any L and D: the library picks the fused register
+    kernels (L <= 4, D <= 4096) or the general streaming kernels."""
 
     @staticmethod
     def forward(ctx, x, kernels, biases, act_code):
@@ -112,11 +113,8 @@ class DCNFunction(torch.autograd.Function):
         L = kernels.shape[0]
         y = torch.empty_like(x)
         csave = torch.empty((B, L), dtype=torch.float32, device=x.device)      # per-row scalars x_l . w_l for the backward
-        rc = getattr(_lib.load(), 'recnow_dcn_fwd')(_lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases), B, D, L, act_code,
-                                                     _lib.ptr(y), _lib.ptr(csave), _lib.stream())
-        if rc == -3:
-            raise NotImplementedError('DCNLayer kernels support input_dim <= 4096 (multiple of 4) or <= 1024 otherwise; got %d' % D)
-        _lib.check(rc, 'recnow_dcn_fwd')
+        _lib.call('recnow_dcn_fwd', _lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases), B, D, L, act_code, _lib.ptr(y), _lib.ptr(csave),
+                  _lib.stream())
         ctx.save_for_backward(x, kernels, biases if biases is not None else x.new_empty(0), csave)
         ctx.meta = (B, D, L, act_code, biases is not None)
         return y
@@ -131,12 +129,45 @@ class DCNFunction(torch.autograd.Function):
         db = torch.empty_like(kernels) if has_bias else None
         lib = _lib.load()
         ws = _lib.workspace(lib.recnow_dcn_workspace_bytes(B, D, L), x.device)
-        rc = lib.recnow_dcn_bwd(_lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases) if has_bias else None, _lib.ptr(dy),
-                                _lib.ptr(csave) if L <= 4 else None, B, D, L, act_code, _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.stream())
-        if rc == -3:
-            raise NotImplementedError('DCNLayer backward supports degree_of_cross <= 4')
-        _lib.check(rc, 'recnow_dcn_bwd')
+        _lib.call('recnow_dcn_bwd', _lib.ptr(x), _lib.ptr(kernels), _lib.ptr(biases) if has_bias else None, _lib.ptr(dy), _lib.ptr(csave),
+                  B, D, L, act_code, _lib.ptr(dx), _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.stream())
         return dx, dk, db, None
+
+
+class DCNStepFunction(torch.autograd.Function):
+    """One cross layer with its own layer input: z = act(x0 * (x_l . w) + b); w (D,), b (D,) or None.  The route for
+    activations that are user callables (act_code 0 here, the callable runs on z)."""
+
+    @staticmethod
+    def forward(ctx, x0, xl, w, b, act_code):
+        x0 = _lib.f32c(x0, 'inputs')
+        xl = _lib.f32c(xl, 'layer input')
+        w = _lib.f32c(w, 'kernel').reshape(-1)
+        if b is not None:
+            b = _lib.f32c(b, 'bias').reshape(-1)
+        B, D = x0.shape
+        z = torch.empty_like(x0)
+        c = torch.empty(max(B, 1), dtype=torch.float32, device=x0.device)
+        _lib.call('recnow_dcn_step_fwd', _lib.ptr(x0), _lib.ptr(xl), _lib.ptr(w), _lib.ptr(b), B, D, act_code, _lib.ptr(z), _lib.ptr(c),
+                  _lib.stream())
+        ctx.save_for_backward(x0, xl, w, z if act_code else x0.new_empty(0), c)
+        ctx.meta = (B, D, act_code, b is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x0, xl, w, z, c = ctx.saved_tensors
+        B, D, act_code, has_bias = ctx.meta
+        dz = _lib.f32c(dz, 'grad')
+        dx0, dxl = torch.empty_like(x0), torch.empty_like(x0)
+        dw = torch.empty(D, dtype=torch.float32, device=x0.device)
+        db = torch.empty(D, dtype=torch.float32, device=x0.device) if has_bias else None
+        lib = _lib.load()
+        ws = _lib.workspace(lib.recnow_dcn_step_workspace_bytes(B, D), x0.device)
+        _lib.call('recnow_dcn_step_bwd', _lib.ptr(x0), _lib.ptr(xl), _lib.ptr(w), _lib.ptr(z) if act_code else None, _lib.ptr(c),
+                  _lib.ptr(dz), B, D, act_code, _lib.ptr(dx0), _lib.ptr(dxl), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), ws.numel(),
+                  _lib.stream())
+        return dx0, dxl, dw, db, None
 
 
 import os

@@ -4,7 +4,7 @@ residual of the paper (:95-98)."""
 import torch
 
 from ._keras import DenseBase
-from ._ops import DCNFunction
+from ._ops import DCNFunction, DCNStepFunction
 
 
 class DCNLayer(DenseBase):
@@ -14,8 +14,6 @@ class DCNLayer(DenseBase):
         """degree_of_cross: number of cross layers; other kwargs as keras.layers.Dense (activation, use_bias, ...)."""
         super().__init__(0, **kwargs)
         self.degree_of_cross = degree_of_cross
-        if self.act_code is None:
-            raise NotImplementedError('DCNLayer fuses activations linear/relu/tanh/sigmoid only')
 
     def build(self, input_shape):
         """kernel_l (D, 1) and, with use_bias, bias_l (1, D) for l < degree_of_cross (the reference's names and shapes)."""
@@ -32,6 +30,14 @@ class DCNLayer(DenseBase):
     def call(self, inputs):
         """inputs (B, D) -> (B, D)."""
         D = self.input_dim
+        if self.act_callable is not None:
+            # a user callable as activation (keras.activations.get accepts any): one cross-layer kernel per layer, the callable
+            # runs between them on torch tensors (its gradient is torch autograd's)
+            layer_input = inputs
+            for l in range(self.degree_of_cross):
+                bias = self.biases[l].reshape(D) if self.use_bias else None
+                layer_input = self.act_callable(DCNStepFunction.apply(inputs, layer_input, self.kernels[l].reshape(D), bias, 0))
+            return layer_input
         kernels = torch.cat([k.reshape(1, D) for k in self.kernels], dim=0)           # (L, D)
         biases = torch.cat([b.reshape(1, D) for b in self.biases], dim=0) if self.use_bias else None
         return DCNFunction.apply(inputs, kernels, biases, self.act_code)

@@ -1,7 +1,7 @@
 """DCNMixLayer -- drop-in for rec_now/layers/dcn_mix_layer.py (/root/reference/rec_now/layers/dcn_mix_layer.py:12-151).
 DCN-v2 mixture of low-rank experts; reference variant WITHOUT the residual term (:150)."""
 from ._keras import Layer, activation_code
-from ._ops import DCNMixFunction
+from ._ops import DCNMixFunction, moe_mix, multi_dense
 
 
 class _GateDense(Layer):
@@ -31,10 +31,10 @@ class DCNMixLayer(Layer):
         self.bias_initializer = bias_initializer
         self.activation_inner = activation_inner
         self.activation_outer = activation_outer
-        self._act_inner, cb_i = activation_code(activation_inner)
-        self._act_outer, cb_o = activation_code(activation_outer)
-        if cb_i is not None or cb_o is not None:
-            raise NotImplementedError('DCNMixLayer fuses activations linear/relu/tanh/sigmoid only')
+        # linear / relu / tanh / sigmoid are fused into the kernels; any other keras-style activation must be a callable on
+        # torch tensors and selects the unfused route of `call` (reference :48-49 takes whatever keras.activations.get accepts)
+        self._act_inner, self._cb_inner = activation_code(activation_inner)
+        self._act_outer, self._cb_outer = activation_code(activation_outer)
 
     def build(self, input_shape):
         """Per layer l: origin_to_sub (N, D, S), sub_to_sub (N, S, S), sub_to_origin (N, S, D) kernels, bias (1, N, D) and the
@@ -56,6 +56,25 @@ class DCNMixLayer(Layer):
 
     def call(self, inputs):
         """inputs (B, D) -> (B, D)."""
+        if self._cb_inner is not None or self._cb_outer is not None:
+            return self._call_unfused(inputs)
         params = (list(self.origin_to_sub_kernels) + list(self.sub_to_sub_kernels) + list(self.sub_to_origin_kernels)
                   + list(self.biases) + [g.kernel for g in self.gate_layers])
         return DCNMixFunction.apply(inputs, self.num_layer, self._act_inner, self._act_outer, *params)
+
+    def _call_unfused(self, inputs):
+        """User-callable activations: the layer as the reference writes it (:135-150), one batched product per line on the
+        MFMA GEMM (`multi_dense`), the softmax gate and the expert mix in the fused mix kernel, the callables in between."""
+        N, D = self.num_expert, int(inputs.shape[-1])
+        layer_input = inputs
+        for l in range(self.num_layer):
+            sub = multi_dense(layer_input, self.origin_to_sub_kernels[l], None, self._act_inner or 0)             # (N, B, S)  :135-136
+            if self._cb_inner is not None:
+                sub = self._cb_inner(sub)
+            sub = multi_dense(sub, self.sub_to_sub_kernels[l], None, self._act_outer or 0)                         # (N, B, S)  :137-138
+            if self._cb_outer is not None:
+                sub = self._cb_outer(sub)
+            origin = multi_dense(sub, self.sub_to_origin_kernels[l], self.biases[l].reshape(N, 1, D), 0)           # (N, B, D)  :141-142
+            logits = multi_dense(layer_input, self.gate_layers[l].kernel.reshape(1, D, N), None, 0)[0]             # (B, N)     :146
+            layer_input = inputs * moe_mix(logits, list(origin.unbind(0)))      # sum_n G_n (x * O_n) = x * sum_n G_n O_n     :143-150
+        return layer_input

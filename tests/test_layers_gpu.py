@@ -243,8 +243,15 @@ def test_dcn_reference_golden(dev, golden):
 
 @pytest.mark.parametrize('B,D,L,act,use_bias', [(5, 3, 3, None, True), (1000, 64, 2, 'tanh', True), (777, 1024, 3, None, True),
                                                 (300, 2048, 4, 'relu', False), (129, 130, 1, 'sigmoid', True),
-                                                (64, 1000, 3, None, True)])
+                                                (64, 1000, 3, None, True),
+                                                # beyond the fused register kernels (reference dcn_layer.py:24-31,91-103 has no limit on
+                                                # degree_of_cross or input_dim): general streaming path
+                                                (600, 1024, 6, 'tanh', True), (300, 8192, 6, None, True), (257, 8200, 2, 'tanh', False),
+                                                (100, 1030, 5, 'sigmoid', True), (33, 4100, 1, 'relu', True), (2100, 64, 9, 'tanh', True),
+                                                # user callables as activation (keras.activations.get): per-layer route
+                                                (300, 96, 3, 'softsign', True), (128, 5000, 2, 'gelu', False)])
 def test_dcn_fwd_bwd_vs_oracle(dev, B, D, L, act, use_bias):
+    act = {'softsign': torch.nn.functional.softsign, 'gelu': torch.nn.functional.gelu}.get(act, act)
     from rec_now_amd.layers.dcn_layer import DCNLayer
     rng = np.random.default_rng(B + D + L)
     x = rng.normal(0, 1, (B, D)).astype(np.float32)
@@ -299,9 +306,13 @@ def test_dcn_mix_reference_golden(dev, golden):
 
 @pytest.mark.parametrize('B,D,S,N,L,ai,ao', [(9, 5, 3, 4, 2, 'tanh', 'tanh'), (500, 64, 16, 2, 3, 'tanh', 'tanh'),
                                               (1000, 256, 64, 2, 2, 'relu', 'sigmoid'), (300, 1024, 64, 2, 3, 'tanh', 'tanh'),
-                                              (257, 130, 7, 3, 1, None, 'tanh')])
+                                              (257, 130, 7, 3, 1, None, 'tanh'),
+                                              # user callables (reference dcn_mix_layer.py:48-49: keras.activations.get): unfused route
+                                              (400, 96, 8, 3, 2, 'softsign', 'tanh'), (300, 256, 64, 2, 2, 'gelu', 'softsign')])
 def test_dcn_mix_fwd_bwd_vs_oracle(dev, B, D, S, N, L, ai, ao):
     from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
+    named = {'softsign': torch.nn.functional.softsign, 'gelu': torch.nn.functional.gelu}
+    ai, ao = named.get(ai, ai), named.get(ao, ao)
     rng = np.random.default_rng(B + D + S)
     x = rng.normal(0, 0.5, (B, D)).astype(np.float32)
     gy = rng.normal(size=(B, D)).astype(np.float32)
@@ -665,12 +676,13 @@ def test_cin_shape_sweep(dev, B, F, D, Hs, oi, sc, as_list):
     test_cin_fwd_bwd_vs_oracle(dev, B, F, D, Hs, oi, sc, as_list)
 
 
-def test_dcn_backward_without_saved_scalars_matches(dev):
-    """recnow_dcn_bwd(csave = NULL) recomputes the forward per row; with csave it uses the forward's scalars: same gradients."""
+@pytest.mark.parametrize('B,D,L', [(700, 1024, 3), (300, 1024, 7), (200, 6000, 2)])
+def test_dcn_backward_without_saved_scalars_matches(dev, B, D, L):
+    """recnow_dcn_bwd(csave = NULL) recomputes the forward per row; with csave it uses the forward's scalars: same gradients
+    (fused kernels and, for L > 4 or D > 4096, the general path through the C ABI)."""
     from rec_now_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(8)
-    B, D, L = 700, 1024, 3
     x, dy = (torch.from_numpy(rng.normal(0, 1, (B, D)).astype(np.float32)).to(dev) for _ in range(2))
     k = torch.from_numpy((rng.uniform(-1, 1, (L, D)) / np.sqrt(D)).astype(np.float32)).to(dev)
     b = torch.from_numpy(rng.uniform(-0.5, 0.5, (L, D)).astype(np.float32)).to(dev)
