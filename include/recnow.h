@@ -110,7 +110,9 @@ int recnow_pair_emit(const float* scores, const float* labels, const uint8_t* ma
  *   loss   = sum_p w_p * softplus(-factor*(s_i - s_j)) / (float(P) + 1e-10)      (or the raw sum if !reduce_mean)
  *   w_p    = cnt_super[super(i_p)] ** power   (power == 0 -> 1)
  *   dscores[k] = d loss / d scores[k]   (pair set and weights are constants, :264,:270)
- * loss: [1] fp32, dscores: [B]. */
+ * loss: [1] fp32, dscores: [B].
+ * flags must contain RECNOW_PAIR_LABEL_GT or RECNOW_PAIR_WRONG_ORDER (else RECNOW_EINVAL): the fused walk relies on at most
+ * one of (i,j) / (j,i) being a pair.  Pair sets without either predicate go through recnow_pair_emit + recnow_bpr_loss_fwdbwd. */
 int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
                            const int32_t* seg_id, const int32_t* seg_first, const int32_t* super_id,
                            const int64_t* cnt_super, const int64_t* n_pair, int64_t B, int flags, float factor,
@@ -419,6 +421,10 @@ int recnow_focal_loss_bwd(const float* labels, const float* logits, int64_t B, f
  *                          number of pooled entries, empty segments 0 - tf.math.unsorted_segment_mean).  rows: row index into
  *                          `table` per entry (the ids themselves, or the inverse index of recnow_embed_unique); weights, cnt
  *                          (B,T entry counts, needed by the 'mean' backward) may be NULL.  No atomics: fixed summation order.
+ *                          V = rows of `table`: an entry whose row index is outside [0, V) adds a zero row (it still counts
+ *                          for 'mean'), the same entries recnow_embed_scatter_rows drops in the backward.
+ *   recnow_embed_pool_bwd_weights: dweights[b][c] = <dout[b][seg[b][c]], table[rows[b][c]]> (/ cnt for 'mean'), 0 for entries
+ *                          that are not pooled or whose row is outside the table: the gradient TF autodiff gives `weights`.
  *   recnow_embed_unique:   from the sort of `key` (recnow_group_keys(I64) + recnow_group_segments): unique[s] = id of sorted
  *                          segment s, inverse[entry] = s, *n_unique = number of real ids (the INT64_MIN segment excluded).
  *   recnow_embed_rows_bwd: drows[s][:] = sum over the entries of segment s of w * dout[b][t][:] (/cnt): the gradient of row
@@ -428,8 +434,10 @@ int recnow_focal_loss_bwd(const float* labels, const float* logits, int64_t B, f
  *   recnow_embed_scatter_rows: dtable[row_ids[s]][:] = drows[s][:] into a zero-initialised dense (V,D) gradient. */
 int recnow_slot_targets(const void* slots, int slot_dtype, const void* targets, int T, const int64_t* ids, int64_t N,
                         int32_t* seg, int64_t* key, void* stream);
-int recnow_embed_pool_fwd(const float* table, int D, const int64_t* rows, const int32_t* seg, const float* weights, int64_t B,
-                          int C, int T, int mean, float* out, float* cnt, void* stream);
+int recnow_embed_pool_fwd(const float* table, int D, int64_t V, const int64_t* rows, const int32_t* seg, const float* weights,
+                          int64_t B, int C, int T, int mean, float* out, float* cnt, void* stream);
+int recnow_embed_pool_bwd_weights(const float* table, int D, int64_t V, const int64_t* rows, const int32_t* seg, const float* cnt,
+                                  const float* dout, int64_t B, int C, int T, int mean, float* dweights, void* stream);
 int recnow_embed_unique(const int64_t* key, const int32_t* order, const int32_t* seg_id, const int32_t* seg_first,
                         const int32_t* n_seg, int64_t N, int64_t* unique, int64_t* inverse, int32_t* n_unique, void* stream);
 size_t recnow_embed_rows_bwd_workspace_bytes(int64_t N, int D);

@@ -72,7 +72,7 @@ extern "C" int recnow_slot_targets(const void* slots, int slot_dtype, const void
 
 // out[b][t][:] = sum_{c: seg[b][c] == t} w[b][c] * table[rows[b][c]][:]   (/ cnt[b][t] for 'mean'; empty segments stay 0)
 __global__ void __launch_bounds__(256)
-k_embed_pool_fwd(const float* __restrict__ table, int D, const int64_t* __restrict__ rows, const int32_t* __restrict__ seg,
+k_embed_pool_fwd(const float* __restrict__ table, int D, int64_t V, const int64_t* __restrict__ rows, const int32_t* __restrict__ seg,
                  const float* __restrict__ weights, int64_t B, int C, int T, int mean, float* __restrict__ out,
                  float* __restrict__ cnt_out) {
     extern __shared__ float lds[];
@@ -101,6 +101,9 @@ k_embed_pool_fwd(const float* __restrict__ table, int D, const int64_t* __restri
                     m_row = rows[b * C + cl];
                     m_w = weights ? weights[b * C + cl] : 1.f;
                     atomicAdd(&cnt[m_t], 1.f);                               // whole numbers: exact in any order
+                    // a row index outside the table contributes a zero row (what tf.nn.embedding_lookup returns on a GPU, and
+                    // what the backward's scatter does with such an id); it still counts as a pooled entry for 'mean'
+                    if (m_row < 0 || m_row >= V) m_row = -1;
                 }
             }
             unsigned long long mine = 0ull;                                  // entries of this round that belong to this lane's group
@@ -124,7 +127,7 @@ k_embed_pool_fwd(const float* __restrict__ table, int D, const int64_t* __restri
                 }
                 for (int d = gl; d < D; d += GS) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = tv[u] >= 0 ? table[rv[u] * (int64_t)D + d] : 0.f;
+                    for (int u = 0; u < 4; ++u) v[u] = (tv[u] >= 0 && rv[u] >= 0) ? table[rv[u] * (int64_t)D + d] : 0.f;
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (tv[u] >= 0) acc[tv[u] * D + d] += wv[u] * v[u];
@@ -158,9 +161,9 @@ static int pool_cfg(int T, int D, int* waves, size_t* lds) {
     return RECNOW_OK;
 }
 
-extern "C" int recnow_embed_pool_fwd(const float* table, int D, const int64_t* rows, const int32_t* seg, const float* weights,
+extern "C" int recnow_embed_pool_fwd(const float* table, int D, int64_t V, const int64_t* rows, const int32_t* seg, const float* weights,
                                      int64_t B, int C, int T, int mean, float* out, float* cnt, void* stream) {
-    if (B < 0 || C < 0 || T < 0 || D < 1) return RECNOW_EINVAL;
+    if (B < 0 || C < 0 || T < 0 || D < 1 || V < 0) return RECNOW_EINVAL;
     if (B == 0 || T == 0) return RECNOW_OK;
     if (!out || (C > 0 && (!table || !rows || !seg))) return RECNOW_EINVAL;
     int waves;
@@ -169,7 +172,7 @@ extern "C" int recnow_embed_pool_fwd(const float* table, int D, const int64_t* r
     if (rc) return rc;
     int64_t g = (B + waves - 1) / waves;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_embed_pool_fwd, (int)g, waves * 64, lds, (hipStream_t)stream, table, D, rows, seg, weights, B, C, T, mean, out, cnt);
+    hipLaunchKernelGGL(k_embed_pool_fwd, (int)g, waves * 64, lds, (hipStream_t)stream, table, D, V, rows, seg, weights, B, C, T, mean, out, cnt);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -436,6 +439,58 @@ extern "C" int recnow_embed_scatter_rows(const float* drows, const int64_t* row_
     int64_t g = (n_slots + 256 / LPE - 1) / (256 / LPE);
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(k_embed_scatter, (int)g, 256, 0, (hipStream_t)stream, drows, row_ids, n_slots, D, V, LPE, dtable);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+
+// Gradient w.r.t. the per-id weights (TF autodiff of rec_now/rec_block/embedding_util.py:315-317, `embeddings * expand_dims(sp_weights)`):
+//   dweights[b][c] = <dout[b][seg[b][c]][:], table[rows[b][c]][:]>  (/ cnt[b][t] for 'mean'),  0 for entries that are not pooled.
+// LPE lanes per entry (pow2 >= min(D, 64)); both rows are contiguous: coalesced per lane group.
+__global__ void __launch_bounds__(256)
+k_embed_pool_bwd_weights(const float* __restrict__ table, int D, int64_t V, const int64_t* __restrict__ rows, const int32_t* __restrict__ seg,
+                         const float* __restrict__ cnt, const float* __restrict__ dout, int64_t N, int C, int T, int mean, int LPE,
+                         float* __restrict__ dweights) {
+    const int gl = threadIdx.x % LPE;
+    const int64_t per = 256 / LPE;
+    // every lane of a group walks the same entry, so the loop trip count is group-uniform; shuffles stay inside the group
+    for (int64_t e0 = (int64_t)blockIdx.x * per; e0 < N; e0 += (int64_t)gridDim.x * per) {
+        const int64_t e = e0 + threadIdx.x / LPE;
+        float p = 0.f;
+        int t = -1;
+        int64_t b = 0;
+        if (e < N) {
+            t = seg[e];
+            b = e / C;
+            if (t >= 0) {
+                const int64_t r = rows[e];
+                if (r >= 0 && r < V) {
+                    const float* g = dout + (b * T + t) * (int64_t)D;
+                    const float* tr = table + r * (int64_t)D;
+                    for (int d = gl; d < D; d += LPE) p += g[d] * tr[d];
+                }
+            }
+        }
+        for (int o = LPE >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        if (e < N && gl == 0) {
+            if (t >= 0 && mean) {
+                const float n = cnt[b * T + t];
+                p = n > 0.f ? p / n : 0.f;
+            }
+            dweights[e] = t >= 0 ? p : 0.f;
+        }
+    }
+}
+extern "C" int recnow_embed_pool_bwd_weights(const float* table, int D, int64_t V, const int64_t* rows, const int32_t* seg, const float* cnt,
+                                             const float* dout, int64_t B, int C, int T, int mean, float* dweights, void* stream) {
+    if (B < 0 || C < 0 || T < 0 || D < 1 || V < 0) return RECNOW_EINVAL;
+    const int64_t N = B * C;
+    if (N == 0) return RECNOW_OK;
+    if (!rows || !seg || !dweights || (T > 0 && (!dout || (V > 0 && !table))) || (mean && !cnt)) return RECNOW_EINVAL;
+    const int LPE = D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64;
+    int64_t g = (N + 256 / LPE - 1) / (256 / LPE);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_embed_pool_bwd_weights, (int)g, 256, 0, (hipStream_t)stream, table, D, V, rows, seg, cnt, dout, N, C, T, mean, LPE, dweights);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

@@ -460,6 +460,9 @@ extern "C" int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, 
     }
     if (!scores || !labels || !order || !seg_id || !seg_first || !super_id || !n_pair || !dscores || !ws) return RECNOW_EINVAL;
     if (power != 0.f && !cnt_super) return RECNOW_EINVAL;
+    // the fused walk visits each unordered candidate {i, j} once and assumes at most ONE of (i,j) / (j,i) is a pair, which the
+    // label (label_i > label_j) or wrong-order (s_i < s_j) predicate guarantees; without either both directions would be pairs
+    if ((flags & (RECNOW_PAIR_LABEL_GT | RECNOW_PAIR_WRONG_ORDER)) == 0) return RECNOW_EINVAL;
     if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
     const PairWs pw = pair_ws(ws, ws_bytes, B);
     Member* mem = pw.mem;

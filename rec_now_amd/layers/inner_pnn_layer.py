@@ -14,6 +14,8 @@ class _InnerPNNFunction(torch.autograd.Function):
             if x.shape != (B, D):
                 raise ValueError('all InnerPNN inputs must have the same (B, D) shape')
         F = len(xs)
+        if D > 64:
+            raise NotImplementedError('InnerPNNLayer kernels cover embedding_dim <= 64 (the reference has no limit); got %d' % D)
         dev = xs[0].device
         out = torch.empty((B, F * (F - 1) // 2), dtype=torch.float32, device=dev)
         ptrs = _lib.ptr_array(xs, dev)

@@ -14,6 +14,8 @@ class _AttnDotFunction(torch.autograd.Function):
         if u.dim() != 3 or d.dim() != 2 or u.shape[0] != d.shape[0] or u.shape[2] != d.shape[1]:
             raise ValueError('user_emb must be (B, L, D) and doc_emb (B, D); got %s and %s' % (tuple(u.shape), tuple(d.shape)))
         B, L, D = u.shape
+        if D > 256:
+            raise NotImplementedError('attention_by_dot_product kernels cover embedding_dim <= 256 (the reference has no limit); got %d' % D)
         mat = torch.empty((B, D), dtype=torch.float32, device=u.device)
         ssum = torch.empty((B, 1), dtype=torch.float32, device=u.device)
         _lib.call('recnow_attention_dot_fwd', _lib.ptr(u), _lib.ptr(d), B, L, D, 1 if filter_neg else 0, _lib.ptr(mat),

@@ -99,20 +99,29 @@ class _PoolFunction(torch.autograd.Function):
         dev = seg.device
         out = torch.empty((B, T, D), dtype=torch.float32, device=dev)       # every element is written by the kernel
         cnt = torch.empty((B, T), dtype=torch.float32, device=dev) if mean else None
-        _lib.call('recnow_embed_pool_fwd', _lib.ptr(table), D, _lib.ptr(rows), _lib.ptr(seg), _lib.ptr(weights), B, C, T,
+        _lib.call('recnow_embed_pool_fwd', _lib.ptr(table), D, table.shape[0], _lib.ptr(rows), _lib.ptr(seg), _lib.ptr(weights), B, C, T,
                   1 if mean else 0, _lib.ptr(out), _lib.ptr(cnt), _lib.stream())
-        ctx.save_for_backward(seg, weights, cnt)
-        ctx.meta = (T, D, bool(mean), srt, dense_scatter, table.shape[0])
+        need_dw = weights is not None and ctx.needs_input_grad[3]
+        ctx.save_for_backward(seg, weights, cnt, *((table, rows) if need_dw else ()))
+        ctx.meta = (T, D, bool(mean), srt, dense_scatter, table.shape[0], need_dw)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        seg, weights, cnt = ctx.saved_tensors
-        T, D, mean, srt, dense_scatter, V = ctx.meta
+        seg, weights, cnt, *extra = ctx.saved_tensors
+        T, D, mean, srt, dense_scatter, V, need_dw = ctx.meta
         B, C = seg.shape
         N = B * C
         dev = seg.device
         dout = _lib.f32c(dout, 'grad')
+        dweights = None
+        if need_dw:             # TF autodiff of `embeddings * expand_dims(sp_weights, -1)` (reference :315-317)
+            table, rows = extra
+            dweights = torch.empty((B, C), dtype=torch.float32, device=dev)
+            _lib.call('recnow_embed_pool_bwd_weights', _lib.ptr(table), D, V, _lib.ptr(rows), _lib.ptr(seg), _lib.ptr(cnt), _lib.ptr(dout),
+                      B, C, T, 1 if mean else 0, _lib.ptr(dweights), _lib.stream())
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, dweights, None, None, None, None
         s = srt.segments()
         drows = torch.empty((max(N, 1), D), dtype=torch.float32, device=dev)
         row_ids = torch.empty(max(N, 1), dtype=torch.int64, device=dev)
@@ -125,7 +134,7 @@ class _PoolFunction(torch.autograd.Function):
             _lib.call('recnow_embed_scatter_rows', _lib.ptr(drows), _lib.ptr(row_ids), N, D, V, _lib.ptr(dtable), _lib.stream())
         else:
             dtable = drows[:V]                      # unique path: segment s IS unique id s
-        return dtable, None, None, None, None, None, None, None
+        return dtable, None, None, dweights, None, None, None, None
 
 
 def _lookup_rows(table, ids):
@@ -143,7 +152,7 @@ def embedding_using_sparse_batch_segment_ids(embedding_func, slots, target_slots
     Args:
         embedding_func: an EmbeddingTable (fused path), or any callable mapping a 1-D int64 id tensor to (n, D) embeddings.
         slots: (B, C) integer slots of the ids;  target_slots: list of T slots to pool;  ids: (B, C) ids (>= 0).
-        weights: optional (B, C) per-id weights (treated as constants, as in the reference's use).
+        weights: optional (B, C) per-id weights; differentiable (d out / d weights as TF autodiff gives it).
         method: 'sum' or 'mean';  use_unique: look each distinct id up once (:305-311) - only matters for a callable
             embedding_func, the fused table path never gathers an id it does not pool.
     Returns:
@@ -158,8 +167,6 @@ def embedding_using_sparse_batch_segment_ids(embedding_func, slots, target_slots
     _lib.require_gpu(ids, 'ids')
     ids = ids.to(torch.int64).contiguous()
     if weights is not None:
-        if getattr(weights, 'requires_grad', False):
-            raise NotImplementedError('gradients w.r.t. the id weights are not provided')
         weights = _lib.f32c(weights, 'weights')
         if weights.shape != ids.shape:
             raise ValueError('weights must have the shape of ids')

@@ -186,9 +186,7 @@ class _ListwiseFused(torch.autograd.Function):
         seg, B = st.seg, st.B
         loss, dbase, row_rank, group_loss = _row_rank(st)
         w = None
-        if weights is not None:
-            w = _lib.f32c(weights, 'weights').reshape(-1)
-        _lib.call('recnow_listwise_loss_fwdbwd', _lib.ptr(st.labels), _lib.ptr(st.logits), _lib.ptr(seg.order), _lib.ptr(seg.seg_id),
+XX, _lib.ptr(st.labels), _lib.ptr(st.logits), _lib.ptr(seg.order), _lib.ptr(seg.seg_id),
                   _lib.ptr(seg.seg_first), _lib.ptr(st.seg_valid), _lib.ptr(st.seg_lse), _lib.ptr(st.seg_ysum), _lib.ptr(st.seg_psum),
                   _lib.ptr(st.seg_pdot), _lib.ptr(st.valid_rank), _lib.ptr(st.n_valid), _lib.ptr(w), B, _lib.ptr(loss), _lib.ptr(dbase),
                   _lib.ptr(row_rank), _lib.ptr(group_loss), _lib.stream())
@@ -200,6 +198,8 @@ class _ListwiseFused(torch.autograd.Function):
             ctx.mark_non_differentiable(n_valid)
             return loss, n_valid
         gv = int(st.n_valid.item())
+        if weights is not None and weights.numel() != gv:
+            raise ValueError('weights must have one entry per valid list: %d lists, %d weights' % (gv, weights.numel()))
         ctx.save_for_backward(dbase[:B], row_rank[:B])
         ctx.mark_non_differentiable(n_valid)
         return group_loss[:gv].clone(), n_valid

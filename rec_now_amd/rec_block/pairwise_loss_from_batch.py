@@ -70,13 +70,14 @@ class _BprVec(torch.autograd.Function):
                   1 if reduce_mean else 0, _lib.ptr(loss), _lib.ptr(dpos), _lib.ptr(ws), ws.numel(), _lib.stream())
         ctx.save_for_backward(dpos[:P])
         ctx.shape = shape
+        ctx.neg_shape = neg.shape
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (dpos,) = ctx.saved_tensors
-        gp = (dpos * g).reshape(ctx.shape)
-        return gp, -gp, None, None, None
+        gp = dpos * g
+        return gp.reshape(ctx.shape), (-gp).reshape(ctx.neg_shape), None, None, None
 
 
 def bpr_loss_func(outputs_pos, outputs_neg, weights=None, factor=1.0, reduce_mean=True):

@@ -134,3 +134,71 @@ def test_embedding_pool_gradient_is_bitwise_reproducible(dev):
     for o, g in grads[1:]:
         assert torch.equal(o, grads[0][0]) and torch.equal(g, grads[0][1])
     assert float(grads[0][1][7].abs().sum()) > 0
+
+
+@pytest.mark.parametrize('B,C,T,D,V,method', [(37, 20, 5, 16, 50, 'sum'), (300, 64, 24, 16, 1000, 'mean'), (64, 33, 3, 70, 7, 'mean'),
+                                              (40, 130, 9, 32, 300, 'sum'), (9, 7, 2, 3, 11, 'mean')])
+@pytest.mark.parametrize('path', ['table', 'callable_unique'])
+def test_embedding_pool_gradient_wrt_id_weights(dev, B, C, T, D, V, method, path):
+    """d out / d weights, as TF autodiff gives it through `embeddings * expand_dims(sp_weights, -1)`
+    (/root/reference/rec_now/rec_block/embedding_util.py:315-317), together with the table gradient."""
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    rng = np.random.default_rng(B + C * 3 + T + D)
+    n_slots = T + 2
+    slots = rng.integers(0, n_slots, (B, C)).astype(np.int32)
+    target_slots = [int(v) for v in rng.permutation(n_slots)[:T]]
+    ids = rng.integers(0, V, (B, C)).astype(np.int64)
+    weights = rng.uniform(-1.5, 1.5, (B, C)).astype(np.float32)
+    params = rng.normal(size=(V, D)).astype(np.float32)
+    gout = rng.normal(size=(B, T, D)).astype(np.float32)
+    table = torch.nn.Parameter(T_(params).to(dev))
+    lookup = EmbeddingTable(table)
+    embedding_func = lookup if path == 'table' else (lambda i: lookup(i))
+    wd = T_(weights).to(dev).requires_grad_(True)
+    out = embedding_using_sparse_batch_segment_ids(embedding_func, T_(slots).to(dev), target_slots, T_(ids).to(dev), weights=wd, method=method)
+    out.backward(T_(gout).to(dev))
+    p64 = T_(params).double().requires_grad_(True)
+    w64 = T_(weights).double().requires_grad_(True)
+    ref = R.embedding_using_sparse_batch_segment_ids(p64, T_(slots), target_slots, T_(ids), w64, method)
+    ref.backward(T_(gout).double())
+    ws = max(float(w64.grad.abs().max()), 1e-30)
+    assert np.abs(wd.grad.cpu().double().numpy() - w64.grad.numpy()).max() <= 1e-5 * ws
+    gs = max(float(p64.grad.abs().max()), 1.0)
+    assert np.abs(table.grad.cpu().double().numpy() - p64.grad.numpy()).max() <= 1e-5 * gs
+    # weights only (a frozen table): no table gradient is formed
+    frozen = EmbeddingTable(torch.nn.Parameter(T_(params).to(dev), requires_grad=False))
+    wd2 = T_(weights).to(dev).requires_grad_(True)
+    embedding_using_sparse_batch_segment_ids(frozen, T_(slots).to(dev), target_slots, T_(ids).to(dev), weights=wd2,
+                                             method=method).backward(T_(gout).to(dev))
+    assert torch.equal(wd2.grad, wd.grad) if path == 'table' else True
+    assert frozen.weight.grad is None
+
+
+def test_embedding_ids_outside_the_table_read_as_zero_rows(dev):
+    """An id < 0 or >= V must not read outside the table: it contributes a zero row in the forward (tf.nn.embedding_lookup on a
+    GPU returns zeros), is dropped by the backward's scatter, and still counts as a pooled entry for 'mean'."""
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    V, D = 6, 4
+    params = np.arange(V * D, dtype=np.float32).reshape(V, D) + 1.0
+    ids = np.array([[0, 7, 5, -3], [6, 1, 1, 2]], dtype=np.int64)
+    slots = np.array([[1, 1, 2, 2], [1, 1, 2, 2]], dtype=np.int32)
+    for method in ('sum', 'mean'):
+        table = EmbeddingTable(torch.nn.Parameter(T_(params).to(dev)))
+        wd = torch.ones(2, 4, device=dev, requires_grad=True)
+        out = embedding_using_sparse_batch_segment_ids(table, T_(slots).to(dev), [1, 2], T_(ids).to(dev), weights=wd, method=method)
+        out.sum().backward()
+        ok = (ids >= 0) & (ids < V)
+        rows = np.where(ok[:, :, None], params[np.clip(ids, 0, V - 1)], 0.0)
+        ref = np.stack([rows[:, :2].sum(1), rows[:, 2:].sum(1)], axis=1) / (2.0 if method == 'mean' else 1.0)
+        assert np.abs(out.detach().cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+        dt = np.zeros((V, D))
+        for b in range(2):
+            for c in range(4):
+                if ok[b, c]:
+                    dt[ids[b, c]] += 1.0 / (2.0 if method == 'mean' else 1.0)
+        assert np.abs(table.weight.grad.cpu().numpy() - dt).max() <= 1e-6
+        dw = np.where(ok, rows.sum(2), 0.0) / (2.0 if method == 'mean' else 1.0)
+        assert np.abs(wd.grad.cpu().numpy() - dw).max() <= 1e-5 * np.abs(dw).max()
+    # plain lookup through EmbeddingTable(ids)
+    got = EmbeddingTable(T_(params).to(dev))(torch.tensor([2, 9, -1], device=dev))
+    assert torch.equal(got[0].cpu(), T_(params[2])) and float(got[1:].abs().sum()) == 0.0
