@@ -452,13 +452,15 @@ int recnow_embed_scatter_rows(const float* drows, const int64_t* row_ids, int64_
  * Measurement hook (bench.py): per-launch HIP-event timing of the GEMM kernels on the launch stream.
  * recnow_prof_enable(capacity > 0) arms `capacity` launch slots, (0) disables.  recnow_prof_collect synchronises and
  * returns per-kernel-family totals in HOST arrays of 8 entries indexed by tag: 1 = k_gemm<128,128>, 2 = k_gemm<128,160>,
- * 3 = k_gemm<256,64>, 4 = k_gemm<256,32>: launches, total milliseconds, total algorithmic flops (2*M*N*K*batch).
+ * 3 = k_gemm<256,64>, 4 = k_gemm<256,32>, 5 = k_gemm_shortk, 6 = k_mix_mid_fwd, 7 = k_mix_mid_bwd: launches, total
+ * milliseconds, total algorithmic flops (2*M*N*K*batch) and (bytes_host, may be NULL) total algorithmic HBM bytes: every
+ * operand read once, every output written once, read-modify-write outputs twice.
  * ---------------------------------------------------------------------------------------------------------- */
 int recnow_prof_enable(int capacity);
 /* Time only every n-th GEMM launch (default 1 = all): the two timing events around a launch cost ~2 us of stream
  * serialisation each; with n coprime to the launches per step every launch position is sampled equally often. */
 int recnow_prof_sample_every(int n);
-int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host);
+int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host, double* bytes_host);
 
 #ifdef __cplusplus
 }

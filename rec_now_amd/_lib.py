@@ -84,7 +84,7 @@ SIGNATURES = {
     'recnow_embed_scatter_rows': (_I, [_P, _P, _L, _I, _L, _P, _P]),
     'recnow_prof_enable': (_I, [_I]),
     'recnow_prof_sample_every': (_I, [_I]),
-    'recnow_prof_collect': (_I, [_P, _P, _P]),
+    'recnow_prof_collect': (_I, [_P, _P, _P, _P]),
 }
 
 

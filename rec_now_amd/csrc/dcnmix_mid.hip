@@ -12,6 +12,7 @@
 // with an odd row stride so the per-lane ds_read_b32 of both operand shapes is bank-conflict free.
 #include "common.hpp"
 #include "dcnmix_mid.hpp"
+#include "prof.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -333,6 +334,8 @@ int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64
     if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
     const size_t lds = mid_fwd_lds(S, N);
     int rc;
+    // measurement hook: read T1, write T2 and T2g (12 * B * LDT bytes)
+    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_MIX_MID_FWD, 4.0 * B * N * S * S, 12.0 * B * LDT, st) : nullptr;
     if (S == 32) {
         if ((rc = mid_allow_lds(k_mix_mid_fwd<32>, lds))) return rc;
         hipLaunchKernelGGL(k_mix_mid_fwd<32>, mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
@@ -340,6 +343,7 @@ int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64
         if ((rc = mid_allow_lds(k_mix_mid_fwd<64>, lds))) return rc;
         hipLaunchKernelGGL(k_mix_mid_fwd<64>, mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
     }
+    rn_prof_end(pr, st);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -353,6 +357,8 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
     float* part = (float*)ws;
     int rc;
     const int vi = (N * (S / 32) * (S / 32) + 3) / 4;          // dV output blocks per wave
+    // measurement hook: read dT2g, T2, T1, write dT1 (16 * B * LDT bytes)
+    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_MIX_MID_BWD, 8.0 * B * N * S * S, 16.0 * B * LDT, st) : nullptr;
 #define MID_BWD(SS, VV)                                                                                                       \
     do {                                                                                                                      \
         if ((rc = mid_allow_lds(k_mix_mid_bwd<SS, VV>, lds))) return rc;                                                      \
@@ -367,6 +373,7 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
         else MID_BWD(64, 4);
     }
 #undef MID_BWD
+    rn_prof_end(pr, st);
     RN_LAUNCH_CHECK();
     const int total = N * S * S;
     hipLaunchKernelGGL(k_mix_dv_reduce, rn_cdiv(total, 64), 1024, 0, st, part, grid, total, dV);

@@ -190,7 +190,15 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
                             d->b_mode == 0 && !d->bias && d->act == RECNOW_ACT_LINEAR && !d->c_trans &&
                             (!d->emul || d->e_mode == RECNOW_OPMODE_MUL);
     if (use_shortk) tag = RN_TAG_GEMM_SHORTK;
-    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(tag, d->prof_flops > 0.0 ? d->prof_flops : 2.0 * d->M * d->N * (double)d->K * d->batch, st) : nullptr;
+    RnProfRecord* pr = nullptr;
+    if (rn_prof_on()) {
+        // algorithmic HBM bytes: every operand read once, every output written once (read-modify-write outputs count twice)
+        const double mk = (double)d->M * d->K, kn = (double)d->K * d->N, mn = (double)d->M * d->N;
+        const double elems = mk * (1 + (d->a_mode && d->a_mode != RECNOW_OPMODE_OUTER ? 1 : 0)) + kn * (1 + (d->b_mode && d->b_mode != RECNOW_OPMODE_OUTER ? 1 : 0)) +
+                             mn * (1 + (d->emul ? 1 : 0) + (d->accumulate ? 1 : 0)) + (d->c2_mode == 1 ? mn : d->c2_mode == 2 ? 3 * mn : 0.0) +
+                             (d->as_out ? 2 * mk : 0.0);
+        pr = rn_prof_begin(tag, d->prof_flops > 0.0 ? d->prof_flops : 2.0 * d->M * d->N * (double)d->K * d->batch, 4.0 * elems * d->batch, st);
+    }
     if (d->as_out) {      // A-stream side output: instantiated with the side product of dT2g; written by the first column tile
         if (xf != 1 || d->a_trans || d->a_mode != RECNOW_OPMODE_MUL || d->batch != 1 || k.splitk != 1 ||
             !host_aligned(d->as_in, d->lda, 0) || !host_aligned(d->as_out, d->lda, 0))

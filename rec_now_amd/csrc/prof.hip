@@ -9,12 +9,13 @@ static unsigned g_seq = 0;
 
 bool rn_prof_on() { return g_on; }
 
-RnProfRecord* rn_prof_begin(int tag, double flops, hipStream_t st) {
+RnProfRecord* rn_prof_begin(int tag, double flops, double bytes, hipStream_t st) {
     if (!g_on || g_used >= g_pool.size()) return nullptr;
     if ((g_seq++ % (unsigned)g_every) != 0) return nullptr;
     RnProfRecord* r = &g_pool[g_used++];
     r->tag = tag;
     r->flops = flops;
+    r->bytes = bytes;
     (void)hipEventRecord(r->e0, st);
     return r;
 }
@@ -50,12 +51,13 @@ extern "C" int recnow_prof_sample_every(int n) {
 }
 
 // Synchronises, then fills per-tag totals (arrays of RN_TAG_MAX entries, HOST memory) and rewinds the pool.
-extern "C" int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host) {
+extern "C" int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host, double* bytes_host) {
     if (!count_host || !ms_host || !flops_host) return RECNOW_EINVAL;
     for (int t = 0; t < RN_TAG_MAX; ++t) {
         count_host[t] = 0;
         ms_host[t] = 0.0;
         flops_host[t] = 0.0;
+        if (bytes_host) bytes_host[t] = 0.0;
     }
     for (size_t i = 0; i < g_used; ++i) {
         RnProfRecord& r = g_pool[i];
@@ -66,6 +68,7 @@ extern "C" int recnow_prof_collect(int* count_host, double* ms_host, double* flo
             count_host[r.tag] += 1;
             ms_host[r.tag] += ms;
             flops_host[r.tag] += r.flops;
+            if (bytes_host) bytes_host[r.tag] += r.bytes;
         }
     }
     g_used = 0;

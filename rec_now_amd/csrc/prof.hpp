@@ -6,6 +6,7 @@
 struct RnProfRecord {
     int tag;            // kernel family (RN_TAG_*)
     double flops;       // algorithmic flops of the launch
+    double bytes;       // algorithmic HBM bytes of the launch (operands read once + outputs written once)
     hipEvent_t e0, e1;
 };
 #define RN_TAG_GEMM_128x128 1
@@ -13,9 +14,11 @@ struct RnProfRecord {
 #define RN_TAG_GEMM_256x64 3
 #define RN_TAG_GEMM_256x32 4
 #define RN_TAG_GEMM_SHORTK 5        // k_gemm_shortk (persistent, K <= 512): a kernel of its own in rocprof, a family of its own here
+#define RN_TAG_MIX_MID_FWD 6        // k_mix_mid_fwd (DCN-v2 sub-space stage, HBM-bound)
+#define RN_TAG_MIX_MID_BWD 7        // k_mix_mid_bwd
 #define RN_TAG_MAX 8
 
 bool rn_prof_on();
 // returns a slot (or nullptr when profiling is off / the pool is full) and records e0 on st
-RnProfRecord* rn_prof_begin(int tag, double flops, hipStream_t st);
+RnProfRecord* rn_prof_begin(int tag, double flops, double bytes, hipStream_t st);
 void rn_prof_end(RnProfRecord* r, hipStream_t st);

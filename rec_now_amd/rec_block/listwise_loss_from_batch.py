@@ -186,7 +186,15 @@ class _ListwiseFused(torch.autograd.Function):
         seg, B = st.seg, st.B
         loss, dbase, row_rank, group_loss = _row_rank(st)
         w = None
-XX, _lib.ptr(st.labels), _lib.ptr(st.logits), _lib.ptr(seg.order), _lib.ptr(seg.seg_id),
+        if weights is not None:
+            w = _lib.f32c(weights, 'weights').reshape(-1)
+            n_w = w.numel()
+            if n_w < B:
+                # the kernel reads weights[rank of a valid list]; the number of valid lists is data-dependent (<= B), so the
+                # buffer handed over always holds B entries -- a too-short `weights` is reported below (do_reduce=False) or
+                # weighs the lists beyond its end with 0, never an out-of-bounds read
+                w = torch.cat([w, w.new_zeros(B - n_w)])
+        _lib.call('recnow_listwise_loss_fwdbwd', _lib.ptr(st.labels), _lib.ptr(st.logits), _lib.ptr(seg.order), _lib.ptr(seg.seg_id),
                   _lib.ptr(seg.seg_first), _lib.ptr(st.seg_valid), _lib.ptr(st.seg_lse), _lib.ptr(st.seg_ysum), _lib.ptr(st.seg_psum),
                   _lib.ptr(st.seg_pdot), _lib.ptr(st.valid_rank), _lib.ptr(st.n_valid), _lib.ptr(w), B, _lib.ptr(loss), _lib.ptr(dbase),
                   _lib.ptr(row_rank), _lib.ptr(group_loss), _lib.stream())

@@ -48,3 +48,14 @@ def test_small_device_tables_are_uploaded_once_per_content():
     p = _lib.block_ptr_array(buf, 4)
     assert p.dtype == torch.int64 and p.tolist() == [buf[f].data_ptr() for f in range(4)]
     assert _lib.ptr_array([buf[1], buf[3]], cpu).tolist() == [buf[1].data_ptr(), buf[3].data_ptr()]
+
+
+def test_every_module_of_the_package_imports():
+    """A syntax error in a host module must show up in the CPU suite, not first on the GPU box."""
+    import importlib
+    import pkgutil
+    import rec_now_amd
+    names = [m.name for m in pkgutil.walk_packages(rec_now_amd.__path__, 'rec_now_amd.') if '.csrc.build' not in m.name]
+    assert len(names) > 15
+    for n in names:
+        importlib.import_module(n)
