@@ -55,7 +55,7 @@ def test_every_module_of_the_package_imports():
     import importlib
     import pkgutil
     import rec_now_amd
-    names = [m.name for m in pkgutil.walk_packages(rec_now_amd.__path__, 'rec_now_amd.') if '.csrc.build' not in m.name]
+    names = [m.name for m in pkgutil.walk_packages(rec_now_amd.__path__, 'rec_now_amd.') if '.csrc.build' not in m.name and not m.name.endswith('librecnow_hip')]
     assert len(names) > 15
     for n in names:
         importlib.import_module(n)
