@@ -12,16 +12,27 @@ Data-parallel (weak scaling): every rank owns whole groups, the loss is combined
 (rec_now_amd/dp.py).  Prints ONE JSON line on rank 0.
 
 roofline:     the dominant kernel is the exact-fp32 MFMA GEMM `k_gemm<128,128,..>` (the K = 1024 and K = B products of the
-              step; the K = 144 products run in the persistent `k_gemm_shortk`, a kernel of its own in rocprof and in
-              `all_gemm`); `achieved` = algorithmic flops (2*M*N*K per launch) / HIP-event time of the launches of the
-              busiest GEMM kernel during the timed steps (every 5th launch is timed: 18 launches per step, so every
-              launch position is sampled equally), measured by the library's own event hook on the launch stream
-              (recnow_prof_*).
-cpu_baseline: the oracle (dense O(B^2) reference formulation, torch CPU, oracle/dense_ref.py) timed on this host on a
-              bounded sample of the same workload (B_s rows with the same 64 rows/group), rank 0, N = 1 only.
+              step); `achieved` = algorithmic flops (2*M*N*K per launch) / HIP-event time of its launches during the timed
+              steps (every 5th launch of the hooked kernels is timed, so every launch position is sampled equally), measured by
+              the library's own event hook on the launch stream (recnow_prof_*).  `hbm_bound_kernels` holds the other side: the
+              K = 144 products (`k_gemm_shortk`, whose fused epilogues stream three to four (B,D) tensors) and the sub-space
+              kernels `k_mix_mid_fwd/bwd` as achieved GB/s of their ALGORITHMIC bytes against the 8 TB/s HBM3E spec.
+              `traffic` (PMC bytes per launch) is read from profiles/traffic.json only while that file's hash of the kernel
+              sources matches this build; otherwise it is null and `traffic_stale` says so.
+parity:       after the timed region ONE more step runs on inputs scaled so that the scores are of O(1) (loss != ln 2; the
+              timed inputs give scores ~1e-8, where a library returning zeros would print the same loss) and is checked
+              (a) on ~256 rows of whole groups: scores and d loss / d x against the fp64 oracle, (b) when the CPU baseline runs:
+              loss, d loss / d x and EVERY weight gradient against the CPU port's step on the same inputs and weights.
+cpu_baseline: rank 0, N = 1 only.  `value`: ONE step of the same workload at the full batch (B = 65536) by the CPU port:
+              oracle/dense_ref.py layers in row chunks (torch CPU fp32, two passes: scores, then forward + backward per chunk
+              with the pair gradient) + the segment-based C pair loss (oracle/pairs_oracle.c, OpenMP); the reference's own dense
+              (B,B) formulation cannot run at this B (>= 100 GB of temporaries), so its figure at B = 8192 is kept beside it in
+              `dense_b8192`.
 """
 import argparse
 import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -40,9 +51,22 @@ D = N_FIELD * EMB_DIM
 SUB, LAYERS, EXPERTS = 64, 3, 2
 ROWS_PER_GROUP = 64
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PROF_EVERY = 5                        # time every 5th GEMM launch (18 per step: every launch position gets sampled)
+PEAK_HBM_GBS = 8000.0                 # same guide, "HBM3E peak BW" (spec; 6.29 TB/s is the measured copy ceiling)
+PROF_EVERY = 5                        # time every 5th hooked launch (24 per step: every launch position gets sampled)
 GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>',
              5: 'k_gemm_shortk'}          # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
+HBM_TAGS = {5: 'k_gemm_shortk', 6: 'k_mix_mid_fwd', 7: 'k_mix_mid_bwd'}
+CHECK_SCALE = 120.0                   # the parity step's inputs: x * 120 (std 6) -> scores of O(0.3), loss != ln 2
+PARITY_TOL = 1e-4                     # GPU fp32 vs CPU-port fp32 at B = 65536 (the fp64 subset check uses 1e-5, north_star)
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources of the library: profiles/traffic.json is only valid for the build it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'rec_now_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'rec_now_amd', 'csrc', '*.hpp'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
 
 
 def synth_batch(B, seed, rank=0):
@@ -65,10 +89,48 @@ class Model(torch.nn.Module):
         return self.head(self.cross(x)).reshape(-1)
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Reference formulation (dense (B,B) masks) on the host CPU, fwd+bwd, on a bounded sample."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import dense_ref as R
+    import pairs_oracle as PO
+    return R, PO
+
+
+def _split(named):
+    """named weights of Model -> the oracle's argument lists."""
+    pick = lambda stem: [named['cross.%s_of_layer%d' % (stem, l)] for l in range(LAYERS)]      # noqa: E731
+    return (pick('origin_to_sub_kernels'), pick('sub_to_sub_kernels'), pick('sub_to_origin_kernels'), pick('bias'),
+            [named['cross.gate_of_layer%d/kernel' % l] for l in range(LAYERS)], named['head.kernel'], named['head.bias'])
+
+
+def cpu_step_full(x, groups, labels, named, chunk=8192):
+    """ONE fwd+bwd step of the workload at the full batch on the host: oracle layers in row chunks (torch CPU fp32) + the
+    segment-based C pair loss.  Returns (loss, dx, {name: grad}, seconds)."""
+    R, PO = _oracle()
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)).requires_grad_(True) for k, v in named.items()}
+    U, V, W, b, K, hk, hb = _split(w)
+    B = x.shape[0]
+    xt = torch.from_numpy(x)
+    fwd = lambda xc: R.multi_dense_layer(R.dcn_mix_layer(xc, U, V, W, b, K), hk, hb).reshape(-1)       # noqa: E731
+    t0 = time.perf_counter()
+    scores = np.empty(B, np.float32)
+    with torch.no_grad():
+        for lo in range(0, B, chunk):
+            scores[lo:lo + chunk] = fwd(xt[lo:lo + chunk]).numpy()
+    loss, ds, n_pair = PO.pairwise_bpr(groups, labels, scores, grouped=True)
+    ds_t = torch.from_numpy(ds.astype(np.float32))
+    dx = np.empty_like(x)
+    for lo in range(0, B, chunk):
+        xc = xt[lo:lo + chunk].clone().requires_grad_(True)
+        fwd(xc).backward(ds_t[lo:lo + chunk])
+        dx[lo:lo + chunk] = xc.grad.numpy()
+    sec = time.perf_counter() - t0
+    return loss, dx, {k: v.grad.numpy() for k, v in w.items()}, scores, n_pair, sec
+
+
+def cpu_dense_b8192(seconds_budget=8.0):
+    """The reference's own dense (B,B) formulation (oracle/dense_ref.py, torch CPU fp32) at the largest B it is practical at."""
+    R, _ = _oracle()
     Bs = 8192
     x, groups, labels = synth_batch(Bs, 3)
     g = torch.Generator().manual_seed(3)
@@ -87,9 +149,7 @@ def cpu_baseline(seconds_budget=20.0):
         for p in params:
             p.grad = None
         s = R.multi_dense_layer(R.dcn_mix_layer(xt, U, V, W, b, K), hk, hb).reshape(-1)
-        loss = R.pairwise_loss(s, yt, gt)
-        loss.backward()
-        return float(loss)
+        R.pairwise_loss(s, yt, gt).backward()
 
     step()
     t0 = time.perf_counter()
@@ -100,10 +160,32 @@ def cpu_baseline(seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 50:
             break
-    return {'value': Bs * n / el, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d steps of fwd+bwd at B=%d (1/8 of the batch, same %d rows/group, same model): dense O(B^2) reference '
-                      'formulation restated on torch-CPU fp32 (oracle/dense_ref.py); TF2 itself is not installable here'
-                      % (n, Bs, ROWS_PER_GROUP)}
+    return {'value': Bs * n / el, 'unit': 'samples/s', 'steps': n, 'rows': Bs,
+            'what': 'dense O(B^2) reference formulation restated on torch-CPU fp32 (oracle/dense_ref.py), 1/8 of the batch, same 64 rows/group'}
+
+
+def rel_err(a, b, scale=None):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    s = max(float(np.abs(b).max()) if scale is None else float(scale), 1e-30)
+    return float(np.abs(a - b).max() / s)
+
+
+def subset_parity(x, groups, labels, named, scores_gpu, dx_gpu, n_pair_gpu, n_groups=4):
+    """~256 rows of whole groups of the full-size GPU step against the fp64 oracle: the layers are row-separable and the pair
+    gradient of a row involves its own group only (the global pair count comes from the labels and groups alone)."""
+    R, PO = _oracle()
+    ids = np.unique(groups)[:n_groups]
+    rows = np.nonzero(np.isin(groups, ids))[0]
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in named.items()}
+    U, V, W, b, K, hk, hb = _split(w)
+    x64 = torch.from_numpy(x[rows]).double().requires_grad_(True)
+    s64 = R.multi_dense_layer(R.dcn_mix_layer(x64, U, V, W, b, K), hk, hb).reshape(-1)
+    _, _, p_total = PO.pairwise_bpr(groups, labels, np.zeros_like(labels), grouped=True)        # pair count: labels and groups only
+    lsum, ds, p_sub = PO.pairwise_bpr(groups[rows], labels[rows], s64.detach().numpy().astype(np.float32))
+    ds_full = ds * (float(np.float32(p_sub)) + 1e-10) / (float(np.float32(p_total)) + 1e-10)      # same terms, global normalisation
+    s64.backward(torch.from_numpy(ds_full))
+    return {'rows': int(rows.size), 'pairs_total_cpu': int(p_total), 'pairs_total_gpu': int(n_pair_gpu),
+            'scores': rel_err(scores_gpu[rows], s64.detach().numpy()), 'dx': rel_err(dx_gpu[rows], x64.grad.numpy())}
 
 
 def main():
@@ -154,18 +236,20 @@ def main():
     reducer = dp.GradientAllReducer(params)
 
     side = torch.cuda.Stream(device=dev)
+    last = {}
 
-    def step():
+    def step(xin=None):
+        xin = xd if xin is None else xin
         for p in params:
             p.grad = None
-        xd.grad = None
+        xin.grad = None
         # the grouping of the batch (sort by group id, segments) does not depend on the scores: it runs on a side stream
         # under the forward pass.  Still part of the step: the group ids are an input of every step.
         main = torch.cuda.current_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
             seg = group_rows(gd)
-        scores = model(xd)
+        scores = model(xin)
         main.wait_stream(side)
         local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False, segments=seg)
         if use_dist:
@@ -176,6 +260,7 @@ def main():
         else:
             loss_bw, loss_val, _ = dp.global_pairwise_loss(local_sum, n_pair)
             loss_bw.backward()
+        last['scores'], last['n_pair'] = scores, n_pair
         return loss_val
 
     def sync():
@@ -213,28 +298,74 @@ def main():
         cnt = (ctypes.c_int * 8)()
         ms = (ctypes.c_double * 8)()
         fl = (ctypes.c_double * 8)()
-        _lib.check(lib.recnow_prof_collect(cnt, ms, fl), 'recnow_prof_collect')
+        by = (ctypes.c_double * 8)()
+        _lib.check(lib.recnow_prof_collect(cnt, ms, fl, by), 'recnow_prof_collect')
         lib.recnow_prof_enable(0)
+        traffic_tab, stale = {}, None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as fh:
+                tj = json.load(fh)
+            stale = tj.get('kernel_source_sha256') != kernel_source_hash()
+            if not stale:
+                traffic_tab = tj['hbm_bytes_per_launch']
+        except (OSError, ValueError, KeyError):
+            stale = None                      # no PMC table at all
         tag = max(GEMM_TAGS, key=lambda t: ms[t])
         if cnt[tag] > 0:
             achieved = fl[tag] / (ms[tag] * 1e-3) / 1e12
-            traffic = None                # HBM bytes per launch from the committed PMC passes (profiles/traffic.json)
-            try:
-                with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as fh:
-                    traffic = json.load(fh)['hbm_bytes_per_launch'].get(GEMM_TAGS[tag])
-            except (OSError, ValueError, KeyError):
-                pass
             roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'kernel': GEMM_TAGS[tag],
-                        'launches': cnt[tag], 'sampled': 'every %dth launch of the timed region' % PROF_EVERY, 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
-                        'algorithmic_flops_per_launch': fl[tag] / cnt[tag],
+                        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic_tab.get(GEMM_TAGS[tag]), 'traffic_stale': stale,
+                        'kernel': GEMM_TAGS[tag],
+                        'launches': cnt[tag], 'sampled': 'every %dth hooked launch of the timed region' % PROF_EVERY, 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
+                        'algorithmic_flops_per_launch': fl[tag] / cnt[tag], 'algorithmic_bytes_per_launch': by[tag] / cnt[tag],
                         'all_gemm': {GEMM_TAGS[t]: {'launches': cnt[t], 'ms': ms[t],
                                                     'tflops': (fl[t] / (ms[t] * 1e-3) / 1e12) if ms[t] > 0 else None}
-                                     for t in GEMM_TAGS if cnt[t] > 0}}
+                                     for t in GEMM_TAGS if cnt[t] > 0},
+                        # the other side of the step: kernels bound by HBM, as achieved GB/s of their algorithmic bytes
+                        'hbm_bound_kernels': {HBM_TAGS[t]: {'bound': 'hbm', 'achieved': by[t] / (ms[t] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
+                                                            'unit': 'GB/s', 'frac': by[t] / (ms[t] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                            'traffic': traffic_tab.get(HBM_TAGS[t]), 'launches': cnt[t],
+                                                            'avg_launch_us': ms[t] * 1e3 / cnt[t],
+                                                            'algorithmic_bytes_per_launch': by[t] / cnt[t]}
+                                              for t in HBM_TAGS if cnt[t] > 0 and ms[t] > 0}}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # ---- parity step (untimed): same shapes and kernels, inputs scaled so that the scores are of O(1) ----------------------
+    parity = None
+    cpu = None
+    if world == 1 and graph is None and not args.no_input_grad:      # N > 1: the same kernels run, checked at N = 1
+        xq = (xd.detach() * CHECK_SCALE).requires_grad_(True)
+        loss_q = step(xq)
+        torch.cuda.synchronize()
+        named = {'cross.' + k: v for k, v in model.cross.named_weights().items()}
+        named['head.kernel'], named['head.bias'] = model.head.kernel, model.head.bias
+        named_np = {k: v.detach().cpu().numpy() for k, v in named.items()}
+        xq_np = x * np.float32(CHECK_SCALE)
+        sc_gpu, dx_gpu = last['scores'].detach().cpu().numpy(), xq.grad.cpu().numpy()
+        parity = {'inputs': 'x * %g' % CHECK_SCALE, 'loss': float(loss_q.item()), 'tolerance': PARITY_TOL}
+        if True:
+            parity['subset_fp64'] = subset_parity(xq_np, groups, labels, named_np, sc_gpu, dx_gpu, int(last['n_pair'].item()))
+            worst = max(parity['subset_fp64']['scores'], parity['subset_fp64']['dx'])
+            if not args.no_cpu_baseline:
+                c_loss, c_dx, c_grads, c_scores, c_pairs, c_sec = cpu_step_full(xq_np, groups, labels, named_np)
+                full = {'loss': rel_err(parity['loss'], c_loss), 'scores': rel_err(sc_gpu, c_scores), 'dx': rel_err(dx_gpu, c_dx),
+                        'pairs_equal': int(last['n_pair'].item()) == int(c_pairs)}
+                for k, v in named.items():
+                    # d loss / d head.bias = sum_i dscore_i cancels to zero: measured on the scale of the other head gradient
+                    full[k] = rel_err(v.grad.cpu().numpy(), c_grads[k], scale=float(np.abs(c_grads['head.kernel']).max()) if k == 'head.bias' else None)
+                parity['cpu_port_fp32'] = full
+                worst = max([worst] + [v for k, v in full.items() if k != 'pairs_equal'])
+                cpu = {'value': rows / c_sec, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                       'sample': '1 step of fwd+bwd at the full batch B=%d (same inputs, weights and 64 rows/group as the parity step): '
+                                 'oracle/dense_ref.py layers in %d-row chunks on torch-CPU fp32 (scores pass, then forward+backward per '
+                                 'chunk) + segment-based C pair loss with OpenMP (oracle/pairs_oracle.c), %.1f s; TF2 itself is not '
+                                 'installable here' % (rows, 8192, c_sec),
+                       'dense_b8192': cpu_dense_b8192()}
+            parity['parity_max_rel'] = worst
+            parity['ok'] = bool(worst <= PARITY_TOL and abs(parity['loss'] - float(np.log(2.0))) > 1e-3)
 
     if rank == 0:
         out = {
@@ -255,9 +386,11 @@ def main():
                        'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(args.graph), 'parallelism': 'dp%d' % world,
                        'loss': float(loss.item())},
             'roofline': roofline,
+            'parity': parity,
+            'parity_max_rel': parity.get('parity_max_rel') if parity else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

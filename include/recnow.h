@@ -232,6 +232,13 @@ typedef struct recnow_gemm_desc {
      *   as_out[m][k] = A[m][k] * as_in[m][k]      (both with A's leading dimension lda)
      * DCN-v2 backward: the dT2g product streams g = dL/dy anyway and writes dx = g * O on the way. */
     const float* as_in; float* as_out;
+    /* More second-output forms of the short-K kernel (same shape rules as c2_mode 1 / 2), used by the model-level fused step
+     * "cross layers + scoring head" (recnow_dcn_mix_score_fwd/bwd):
+     *   c2_mode 3 (emul required, b_trans 0): C2 = acc; C = acc * emul is NOT stored; instead its row-dot with the column
+     *              vector hv (N) leaves as partials hp[m * hp_ld + 2 * (n / 128) + ((n % 128) / 64)], hp_ld >= N / 64: a
+     *              Dense(1) head folded into the epilogue of the product that forms its input.
+     *   c2_mode 4 (b_trans 1, no emul): C = acc; C2[m][n] = acc * E2[m][n] + rv[m] * cv[n] * E3[m][n] (written, not read). */
+    const float* E3; int64_t lde3; const float* rv; const float* cv; const float* hv; float* hp; int hp_ld; int hp_pad;
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;

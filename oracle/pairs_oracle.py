@@ -18,6 +18,7 @@ def _load():
         _lib = ctypes.CDLL(so)
         _lib.oracle_pair_indices.restype = ctypes.c_int64
         _lib.oracle_pairwise_bpr.restype = ctypes.c_int64
+        _lib.oracle_pairwise_bpr_grouped.restype = ctypes.c_int64
     return _lib
 
 
@@ -38,7 +39,7 @@ def pair_indices(groups, labels, scores, mask=None, flags=1):
     return pos[:n], neg[:n]
 
 
-def pairwise_bpr(groups, labels, scores, mask=None, flags=1, factor=1.0, power=0.0):
+def pairwise_bpr(groups, labels, scores, mask=None, flags=1, factor=1.0, power=0.0, grouped=False):
     g = np.ascontiguousarray(groups, np.float32).reshape(-1)
     y = np.ascontiguousarray(labels, np.float32).reshape(-1)
     s = np.ascontiguousarray(scores, np.float32).reshape(-1)
@@ -46,6 +47,7 @@ def pairwise_bpr(groups, labels, scores, mask=None, flags=1, factor=1.0, power=0
     B = g.size
     loss = ctypes.c_double(0.0)
     d = np.zeros(max(B, 1), np.float64)
-    P = _load().oracle_pairwise_bpr(_p(g), _p(y), _p(s), _p(m), ctypes.c_int64(B), flags, ctypes.c_double(factor),
+    fn = _load().oracle_pairwise_bpr_grouped if grouped else _load().oracle_pairwise_bpr
+    P = fn(_p(g), _p(y), _p(s), _p(m), ctypes.c_int64(B), flags, ctypes.c_double(factor),
                                     ctypes.c_double(power), ctypes.byref(loss), _p(d))
     return loss.value, d[:B], P

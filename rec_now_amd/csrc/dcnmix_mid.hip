@@ -156,7 +156,8 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
 template <int S, int VI>
 __global__ void __launch_bounds__(256, 2)
 k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1, const float* __restrict__ V,
-              float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B, int N, int LDT, int act_inner, int act_outer) {
+              float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B, int N, int LDT, int act_inner, int act_outer,
+              const float* __restrict__ rscale /* optional: dT2g is read as rscale[row] * dT2g[row][:] */) {
     extern __shared__ float lds[];
     const int NS = N * S, LDA = NS + 1;
     float* VTs = lds;                      // [n][t][s] = V[n][s][t]
@@ -187,6 +188,10 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
         d = make_float4(0.f, 0.f, 0.f, 0.f); h = d; a = d; g = 0.f;
         if (row < B) {
             d = *reinterpret_cast<const float4*>(dT2g + row * LDT + k4);
+            if (rscale) {
+                const float sc = rscale[row];
+                d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
+            }
             h = *reinterpret_cast<const float4*>(T2 + row * LDT + k4);
             a = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
             g = T2[row * LDT + NS + n];
@@ -215,7 +220,7 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
             for (int n = 0; n < MID_NMAX; ++n) {
                 const bool ok = n < N && r0 + tid < B;
                 pgg[n] = ok ? T2[(r0 + tid) * LDT + NS + n] : 0.f;
-                pdg[n] = ok ? dT2g[(r0 + tid) * LDT + NS + n] : 0.f;
+                pdg[n] = ok ? dT2g[(r0 + tid) * LDT + NS + n] * (rscale ? rscale[r0 + tid] : 1.f) : 0.f;
             }
         }
     };
@@ -349,7 +354,7 @@ int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64
 }
 
 int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const float* V, float* dT1, float* dV, int64_t B, int S, int N,
-                   int LDT, int act_inner, int act_outer, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int LDT, int act_inner, int act_outer, void* ws, size_t ws_bytes, hipStream_t st, const float* rscale) {
     if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
     if (ws_bytes < rn_mix_mid_bwd_ws_bytes(B, S, N)) return RECNOW_EWORKSPACE;
     const size_t lds = mid_bwd_lds(S, N);
@@ -362,7 +367,7 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
 #define MID_BWD(SS, VV)                                                                                                       \
     do {                                                                                                                      \
         if ((rc = mid_allow_lds(k_mix_mid_bwd<SS, VV>, lds))) return rc;                                                      \
-        hipLaunchKernelGGL((k_mix_mid_bwd<SS, VV>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer); \
+        hipLaunchKernelGGL((k_mix_mid_bwd<SS, VV>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer, rscale); \
     } while (0)
     if (S == 32) {
         if (vi <= 1) MID_BWD(32, 1);

@@ -14,6 +14,7 @@ int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2
     X(true, false, 0, 0, 2)     // GEMM3:   T2g W           + gate-weighted bias as rank-2 update
     X(true, true, 1, 0, 1)      // dT2g:    (x*g) W^T       + bias columns as side product
     X(true, true, 1, 0, 5)      //          ... and dx = g * O written from the A stream (top layer)
+    X(true, true, 0, 0, 1)      // dT2g of the top layer under a fused scoring head: x (W * w_head)^T, rows scaled by dscore later
     X(true, true, 0, 0, 2)      // dxl:     dA U^T          + dlogits K^T as rank-2 update
     X(false, false, 0, 0, 1)    // dU:      x_l^T dA        + dgate as side product
     X(false, false, 1, 0, 1)    // dW^T:    (x*g)^T T2g     + dbias as side product

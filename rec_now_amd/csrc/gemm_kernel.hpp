@@ -35,9 +35,15 @@ struct GemmK {
     int xcd_remap;             // split-K, one column tile, gridDim.z % 8 == 0: row tiles of a k-slab share an XCD (see k_gemm)
     const float* as_in;        // XF & 4: elementwise side output of the A stream, as_out = A * as_in (layout of A)
     float* as_out;
-    float* C2;                 // second output of the short-K kernel (c2_mode 1: C2 = acc; 2: C2 += acc * E2)
-    const float* E2;
-    int64_t ldc2, lde2;
+    float* C2;                 // second output of the short-K kernel (c2_mode 1: C2 = acc; 2: C2 += acc * E2;
+    const float* E2;           //   3: C2 = acc, C is NOT written, hp = row-dot partials of acc * emul with hv;
+    int64_t ldc2, lde2;        //   4: C2 = acc * E2 + rv[m] * cv[n] * E3, C2 is not read)
+    const float* E3;           // c2_mode 4: third epilogue tensor (leading dimension lde3)
+    int64_t lde3;
+    const float *rv, *cv;      // c2_mode 4: row / column vectors of the rank-one factor
+    const float* hv;           // c2_mode 3: column vector of the fused row-dot (the scoring head's kernel)
+    float* hp;                 // c2_mode 3: partials hp[m][hp_ld], entry 2 * column tile + wave column
+    int hp_ld;
     long long* trace;          // RN_GEMM_TRACE builds only: 8 int64 per workgroup (phase timestamps, HW id)
 };
 

@@ -17,9 +17,12 @@
 #define SK_BN 128
 #define SK_BK 16
 
-// EP: bit 0 = C *= emul, bit 1 = C += C_old.   DUAL: 0 none, 1: C2 = acc, 2: C2 += acc * E2.
+// EP: bit 0 = C *= emul, bit 1 = C += C_old.   DUAL: 0 none, 1: C2 = acc, 2: C2 += acc * E2,
+// 3 (scoring head folded into the last cross layer): C2 = acc, C = acc * emul is NOT stored, its row-dot with hv leaves as
+//   partials hp[m][2 * column tile + wave column] (fixed order, summed by the consumer);
+// 4 (first dx write of the backward): C = acc, C2 = acc * E2 + rv[m] * cv[n] * E3[m][n] (C2 is written, never read).
 template <bool B_KC, int EP, int DUAL>
-__global__ void __launch_bounds__(GEMM_THREADS, ((EP == 3 || DUAL == 2) ? 3 : 4))
+__global__ void __launch_bounds__(GEMM_THREADS, ((EP == 3 || DUAL == 2 || DUAL == 4) ? 3 : 4))
 k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
@@ -36,6 +39,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     const unsigned c_lane = (unsigned)((wm * 64 + rr0) * p.ldc + wn * 64 + cc);
     const unsigned f_lane = (unsigned)((wm * 64 + rr0) * p.lde2 + wn * 64 + cc);
     const unsigned d_lane = (unsigned)((wm * 64 + rr0) * p.ldc2 + wn * 64 + cc);
+    const unsigned g_lane = (unsigned)((wm * 64 + rr0) * p.lde3 + wn * 64 + cc);
     const int nk = p.K / SK_BK;
     const int ntiles = row_tiles * col_tiles;
 
@@ -146,27 +150,39 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
         float* stg = smem + fr * BUF + wave * (16 * 36);
         // Epilogue addresses = (tile- and sub-tile-uniform 64-bit base, kept in SGPRs) + (lane offset, 32-bit, tile-invariant).
         f32x4 ev[2][4], cv[2][4], fv[2][4], dv[2][4];
+        float rs[2][4];                     // DUAL 4: the rank-one factor's row values of the sub-tile's four row groups
+        f32x4 hv4[2];                       // DUAL 3 / 4: the column vector of the two column sub-tiles
+        float hs[4];                        // DUAL 3: row-dot sums of the current row sub-tile (rows 16h + 8q + rr0)
         const float* Et = (EP & 1) ? p.emul + (int64_t)m0 * p.lde + n0 : nullptr;
         float* Ct = p.C + (int64_t)m0 * p.ldc + n0;
-        const float* Ft = (DUAL == 2) ? p.E2 + (int64_t)m0 * p.lde2 + n0 : nullptr;
+        const float* Ft = (DUAL == 2 || DUAL == 4) ? p.E2 + (int64_t)m0 * p.lde2 + n0 : nullptr;
+        const float* Gt = (DUAL == 4) ? p.E3 + (int64_t)m0 * p.lde3 + n0 : nullptr;
         float* Dt = DUAL ? p.C2 + (int64_t)m0 * p.ldc2 + n0 : nullptr;
+        if (DUAL == 3 || DUAL == 4) {
+            const float* colv = (DUAL == 3 ? p.hv : p.cv) + n0 + wn * 64 + cc;
+            hv4[0] = *reinterpret_cast<const f32x4*>(colv);
+            hv4[1] = *reinterpret_cast<const f32x4*>(colv + 32);
+        }
         auto issue = [&](int s2, int buf) {
             const int i = s2 >> 1, j = s2 & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (EP & 1) ev[buf][q] = *reinterpret_cast<const f32x4*>(Et + (int64_t)(i * 32 + q * 8) * p.lde + j * 32 + e_lane);
                 if (EP & 2) cv[buf][q] = *reinterpret_cast<const f32x4*>(Ct + (int64_t)(i * 32 + q * 8) * p.ldc + j * 32 + c_lane);
-                if (DUAL == 2) {
-                    fv[buf][q] = *reinterpret_cast<const f32x4*>(Ft + (int64_t)(i * 32 + q * 8) * p.lde2 + j * 32 + f_lane);
-                    dv[buf][q] = *reinterpret_cast<const f32x4*>(Dt + (int64_t)(i * 32 + q * 8) * p.ldc2 + j * 32 + d_lane);
+                if (DUAL == 2 || DUAL == 4) fv[buf][q] = *reinterpret_cast<const f32x4*>(Ft + (int64_t)(i * 32 + q * 8) * p.lde2 + j * 32 + f_lane);
+                if (DUAL == 2) dv[buf][q] = *reinterpret_cast<const f32x4*>(Dt + (int64_t)(i * 32 + q * 8) * p.ldc2 + j * 32 + d_lane);
+                if (DUAL == 4) {
+                    dv[buf][q] = *reinterpret_cast<const f32x4*>(Gt + (int64_t)(i * 32 + q * 8) * p.lde3 + j * 32 + g_lane);
+                    rs[buf][q] = p.rv[m0 + wm * 64 + i * 32 + q * 8 + rr0];
                 }
             }
         };
-        if (EP || DUAL == 2) issue(0, 0);
+        if (EP || DUAL == 2 || DUAL == 4) issue(0, 0);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
             const int i = s2 >> 1, j = s2 & 1, buf = s2 & 1;
-            if ((EP || DUAL == 2) && s2 + 1 < 4) issue(s2 + 1, buf ^ 1);
+            if ((EP || DUAL == 2 || DUAL == 4) && s2 + 1 < 4) issue(s2 + 1, buf ^ 1);
+            if (DUAL == 3 && j == 0) hs[0] = hs[1] = hs[2] = hs[3] = 0.f;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {          // accumulator registers 8h..8h+7 hold rows 16h..16h+15 of the sub-tile
 #pragma unroll
@@ -178,13 +194,31 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                     f32x4 v = a;
                     if (EP & 1) v = v * ev[buf][2 * h + q];
                     if (EP & 2) v = v + cv[buf][2 * h + q];
-                    *reinterpret_cast<f32x4*>(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane) = v;
-                    if (DUAL == 1) *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) = a;
+                    if (DUAL != 3) *reinterpret_cast<f32x4*>(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane) = v;
+                    if (DUAL == 1 || DUAL == 3) *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) = a;
                     if (DUAL == 2)
                         *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) =
                             dv[buf][2 * h + q] + a * fv[buf][2 * h + q];
+                    if (DUAL == 3) {
+                        const f32x4 t = v * hv4[j];
+                        hs[2 * h + q] += (t.x + t.y) + (t.z + t.w);
+                    }
+                    if (DUAL == 4)
+                        *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) =
+                            a * fv[buf][2 * h + q] + (hv4[j] * rs[buf][2 * h + q]) * dv[buf][2 * h + q];
                 }
                 RN_LDS_WAVE_SYNC();
+            }
+            if (DUAL == 3 && j == 1) {            // both column sub-tiles of row sub-tile i are in: join the 8 lanes of a row
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = hs[r];
+                    t += __shfl_xor(t, 1, 64);
+                    t += __shfl_xor(t, 2, 64);
+                    t += __shfl_xor(t, 4, 64);
+                    if ((lane & 7) == 0)
+                        p.hp[(int64_t)(m0 + wm * 64 + i * 32 + r * 8 + rr0) * p.hp_ld + 2 * (n0 / SK_BN) + wn] = t;
+                }
             }
         }
         SK_TR(3);
@@ -204,7 +238,7 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
     using TB = Tile<SK_BN, SK_BK, B_KC>;
     constexpr size_t lds = 2 * SK_BK * (size_t)(TA::LD + TB::LD) * sizeof(float);
     const int rt = k.M / SK_BM, ct = k.N / SK_BN;
-    const int resident = 256 * ((EP == 3 || DUAL == 2) ? 3 : 4);
+    const int resident = 256 * ((EP == 3 || DUAL == 2 || DUAL == 4) ? 3 : 4);
     int grid = rt * ct < resident ? rt * ct : resident;
     const int xcd = (rt % 8 == 0 && grid % 8 == 0) ? 1 : 0;
     hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL>), grid, GEMM_THREADS, lds, st, k, rt, ct, xcd);
@@ -218,6 +252,8 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
 int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st) {
     if (c2_mode == 1) return (!b_kc && ep == 1) ? launch_sk<false, 1, 1>(k, st) : RECNOW_EUNSUPPORTED;
     if (c2_mode == 2) return (b_kc && ep == 0) ? launch_sk<true, 0, 2>(k, st) : RECNOW_EUNSUPPORTED;
+    if (c2_mode == 3) return (!b_kc && ep == 1) ? launch_sk<false, 1, 3>(k, st) : RECNOW_EUNSUPPORTED;
+    if (c2_mode == 4) return (b_kc && ep == 0) ? launch_sk<true, 0, 4>(k, st) : RECNOW_EUNSUPPORTED;
     if (b_kc) {
         switch (ep) {
             case 0: return launch_sk<true, 0, 0>(k, st);

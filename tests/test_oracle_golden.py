@@ -214,3 +214,25 @@ def test_embedding_pool_literals():
     assert np.array_equal(out.numpy(), np.array(exp_w, np.float32))
     out = R.embedding_using_sparse_batch_segment_ids(T(params), T(slots), targets, T(ids))
     assert np.array_equal(out.numpy(), np.array(exp_n, np.float32))
+
+
+def test_grouped_c_port_equals_the_quadratic_restatement():
+    """oracle_pairwise_bpr_grouped (the segment-based CPU port bench.py times at B = 65536) against the O(B^2) restatement of
+    the reference formulation: same pair count, loss and gradient, incl. NaN / inf / signed-zero group ids, masks, 3 label levels,
+    wrong-order pairs and occurrence weights."""
+    import pairs_oracle as PO
+    rng = np.random.default_rng(0)
+    for B, G in ((3000, 40), (5000, 7), (2000, 2000), (1, 1), (0, 1)):
+        g = rng.integers(0, G, B).astype(np.float32)
+        if B > 100:
+            g[::97] = np.nan
+            g[5], g[6], g[7] = -0.0, 0.0, np.inf
+        y = rng.integers(0, 3, B).astype(np.float32)
+        s = rng.normal(size=B).astype(np.float32)
+        m = (rng.random(B) < 0.9).astype(np.uint8)
+        for flags, power in ((1, 0.0), (3, -0.5), (1, 1.0)):
+            a = PO.pairwise_bpr(g, y, s, m, flags, 1.3, power)
+            b = PO.pairwise_bpr(g, y, s, m, flags, 1.3, power, grouped=True)
+            assert a[2] == b[2]
+            assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(a[0]))
+            assert B == 0 or np.abs(a[1] - b[1]).max() <= 1e-12

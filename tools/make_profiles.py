@@ -42,12 +42,16 @@ with open('profiles/%s_bench_pmc_hbm.csv' % tag, 'w') as fo:
         b = (2 * fv + wv) * 1024
         w.writerow([k, n, '%.1f' % fv, '%.1f' % wv, '%.0f' % b])
         m = re.match(r'void k_gemm<(\d+), (\d+), (\d+), (\d+),', k)
-        if m or k.startswith('void k_gemm_shortk<'):      # the persistent short-K kernel is a family of its own (bench.py GEMM_TAGS)
-            key = 'k_gemm<%s,%s,%s,%s>' % m.groups() if m else 'k_gemm_shortk'
+        other = [f for f in ('k_gemm_shortk', 'k_mix_mid_fwd', 'k_mix_mid_bwd') if k.startswith('void %s<' % f)]
+        if m or other:      # the persistent short-K kernel and the sub-space kernels are families of their own (bench.py *_TAGS)
+            key = 'k_gemm<%s,%s,%s,%s>' % m.groups() if m else other[0]
             fam[key][0] += n
             fam[key][1] += n * b
 traffic = {k: v / n for k, (n, v) in fam.items()}
-json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2; bytes = (2*FETCH_SIZE + '
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash      # noqa: E402  (bench.py refuses the table when the kernel sources have changed since)
+json.dump({'kernel_source_sha256': kernel_source_hash(),
+           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2; bytes = (2*FETCH_SIZE + '
                      'WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section (FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950); '
                      'launch-weighted mean over the instantiations of each tile family',
            'hbm_bytes_per_launch': traffic}, open('profiles/traffic.json', 'w'), indent=1)
