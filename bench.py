@@ -198,6 +198,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='capture the step into a HIP graph and replay it (SURVEY 8f.1; launch-bound small batches)')
     ap.add_argument('--no-input-grad', action='store_true', help='diagnostic: x is data without a gradient (the metric keeps d loss / d x: in a model x is the embedding output)')
     ap.add_argument('--rows', type=int, default=B_PER_GPU, help='rows per GPU (diagnostics; the metric is defined at 65536)')
+    ap.add_argument('--unfused', action='store_true', help='diagnostic: the drop-in composition head(cross(x)) and pairwise_loss(outputs, labels, groups) '
+                    'instead of the model-level fused node (rec_now_amd/fused.py) with grouping on a side stream')
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
     args = ap.parse_args()
 
@@ -234,6 +236,18 @@ def main():
     xd.requires_grad_(not args.no_input_grad)
     params = [p for p in model.parameters()]
     reducer = dp.GradientAllReducer(params)
+    # fused route (default): cross layers + scoring head as one node; per-layer events let the gradient all-reduce of a layer run
+    # under the backward of the layers below it (dp.LayerwiseReducer).  Stages in the order their gradients become final.
+    from rec_now_amd.fused import GpuEvent, dcn_mix_score, fused_route_available
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+    fused = not args.unfused and fused_route_available(model.cross, model.head, xd)
+    events, layerwise = None, None
+    if fused and use_dist:
+        events = [GpuEvent() for _ in range(LAYERS)]
+        per_layer = lambda l: [model.cross.origin_to_sub_kernels[l], model.cross.sub_to_sub_kernels[l], model.cross.sub_to_origin_kernels[l],     # noqa: E731
+                               model.cross.biases[l], model.cross.gate_layers[l].kernel]
+        stages = [per_layer(LAYERS - 1) + [model.head.kernel, model.head.bias]] + [per_layer(l) for l in range(LAYERS - 2, -1, -1)]
+        layerwise = dp.LayerwiseReducer(stages, [events[l] for l in range(LAYERS - 1, -1, -1)], dev)
 
     side = torch.cuda.Stream(device=dev)
     last = {}
@@ -245,14 +259,29 @@ def main():
         xin.grad = None
         # the grouping of the batch (sort by group id, segments) does not depend on the scores: it runs on a side stream
         # under the forward pass.  Still part of the step: the group ids are an input of every step.
-        main = torch.cuda.current_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            seg = group_rows(gd)
-        scores = model(xin)
-        main.wait_stream(side)
-        local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False, segments=seg)
-        if use_dist:
+        if args.unfused:
+            # the drop-in composition exactly as a user of the reference writes it
+            scores = model(xin)
+            if not use_dist:
+                loss_val, n_pair = pairwise_loss(scores, yd, gd, return_num_pair=True)
+                loss_val.backward()
+                last['scores'], last['n_pair'] = scores, n_pair
+                return loss_val.detach()
+            local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False)
+        else:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                seg = group_rows(gd)
+            scores = dcn_mix_score(model.cross, model.head, xin, layer_events=events) if fused else model(xin)
+            main.wait_stream(side)
+            local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False, segments=seg)
+        if layerwise is not None:
+            # backward on the unnormalised local sum; each layer's bucket is all-reduced behind its event while the layers below
+            # are still in their backward pass; (loss sum, P) ride in the first bucket
+            local_sum.backward()
+            loss_val, _ = layerwise.reduce(local_sum, n_pair)
+        elif use_dist:
             # one collective per step: backward on the unnormalised local sum; (loss sum, P) ride in the gradient bucket and
             # the gradients are divided by P_global afterwards (the loss is linear in 1/P) -- no sync between fwd and bwd
             local_sum.backward()
@@ -384,6 +413,7 @@ def main():
             'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
                                    'in-batch pairwise (logistic), B=65536 rows per GPU, 64 fields x 16-dim, ~64 rows/group',
                        'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(args.graph), 'parallelism': 'dp%d' % world,
+                       'route': 'fused node dcn_mix_score + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
                        'loss': float(loss.item())},
             'roofline': roofline,
             'parity': parity,

@@ -329,6 +329,29 @@ int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* 
                        size_t saved_bytes, int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* dx,
                        float* const* dU_host, float* const* dV_host, float* const* dW_host, float* const* dbias_host,
                        float* const* dgate_host, void* ws, size_t ws_bytes, void* stream, void* stream2);
+
+/* Model-level fusion of the north-star step: the L cross layers followed by a Dense(1) scoring head,
+ *   scores[m] = DCNMix(x)[m] . head_w + head_b        (rec_now/layers/dcn_mix_layer.py:149-150 -> multi_dense_layer.py:90-92
+ *                                                       with units = 1, num_dnn = 1)
+ * The head is folded into the epilogue of the last layer's output product (the layer output is never stored) and its rank-one
+ * gradient dscore (x) head_w is never materialised in the backward (see csrc/dcnmix.hip).  Same saved / workspace sizes as
+ * recnow_dcn_mix_fwd/bwd.  recnow_dcn_mix_score_supported: 1 when the shape takes the fused route (N*S and D multiples of 128,
+ * B a multiple of 256, S in {32, 64}, L <= 8), else 0 -- the caller then composes recnow_dcn_mix_* with recnow_multi_dense_*.
+ * head_w (D), head_b (1) or NULL, scores (B), dscores (B), dhead_w (D), dhead_b (1) or NULL.
+ * layer_events_host: optional HOST array of L hipEvent_t (entries may be NULL): event l is recorded when every weight gradient
+ * of layer l has been issued (layers are walked L-1 .. 0; the head's gradients are complete at event L-1), so a data-parallel
+ * caller can all-reduce a layer's gradients while the lower layers' backward still runs. */
+int recnow_dcn_mix_score_supported(int64_t B, int D, int S, int N, int L);
+int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_host, const float* const* V_host, const float* const* W_host,
+                             const float* const* bias_host, const float* const* gate_host, const float* head_w, const float* head_b,
+                             int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* scores, void* saved,
+                             size_t saved_bytes, void* ws, size_t ws_bytes, void* stream, int need_dx);
+int recnow_dcn_mix_score_bwd(const float* x, const float* const* U_host, const float* const* V_host, const float* const* W_host,
+                             const float* const* bias_host, const float* const* gate_host, const float* head_w, const float* dscores,
+                             const void* saved, size_t saved_bytes, int64_t B, int D, int S, int N, int L, int act_inner,
+                             int act_outer, float* dx, float* const* dU_host, float* const* dV_host, float* const* dW_host,
+                             float* const* dbias_host, float* const* dgate_host, float* dhead_w, float* dhead_b, void* ws,
+                             size_t ws_bytes, void* stream, void* stream2, void* const* layer_events_host);
 /* stream2: optional second hipStream_t (NULL or == stream: single-stream).  When given, the weight-gradient products and
  * the dx recompute run on it concurrently with the data-gradient chain on `stream`, ordered by events created and
  * destroyed inside the call; on return all of stream2's work is ordered before later work submitted to `stream`. */
@@ -468,6 +491,13 @@ int recnow_prof_enable(int capacity);
  * serialisation each; with n coprime to the launches per step every launch position is sampled equally often. */
 int recnow_prof_sample_every(int n);
 int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host, double* bytes_host);
+
+/* HIP events owned through the C ABI (timing disabled): the layer_events_host of recnow_dcn_mix_score_bwd.  A host framework
+ * whose event type is created lazily (torch.cuda.Event) cannot hand a handle over before the first record. */
+int recnow_event_create(void** event_out);
+int recnow_event_destroy(void* event);
+int recnow_event_record(void* event, void* stream);
+int recnow_stream_wait_event(void* stream, void* event);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,10 @@ SIGNATURES = {
     'recnow_dcn_mix_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P, _I]),
     'recnow_dcn_mix_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                                  _Z, _P, _P]),
+    'recnow_dcn_mix_score_supported': (_I, [_L, _I, _I, _I, _I]),
+    'recnow_dcn_mix_score_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P, _I]),
+    'recnow_dcn_mix_score_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
+                                       _P, _P, _Z, _P, _P, _P]),
     'recnow_cin_saved_bytes': (_Z, [_L, _I, _I, _P, _I]),
     'recnow_cin_workspace_bytes': (_Z, [_L, _I, _I, _P, _I]),
     'recnow_cin_fwd': (_I, [_P, _P, _L, _I, _I, _P, _I, _I, _I, _P, _P, _Z, _P, _Z, _P]),
@@ -85,6 +89,10 @@ SIGNATURES = {
     'recnow_prof_enable': (_I, [_I]),
     'recnow_prof_sample_every': (_I, [_I]),
     'recnow_prof_collect': (_I, [_P, _P, _P, _P]),
+    'recnow_event_create': (_I, [_P]),
+    'recnow_event_destroy': (_I, [_P]),
+    'recnow_event_record': (_I, [_P, _P]),
+    'recnow_stream_wait_event': (_I, [_P, _P]),
 }
 
 

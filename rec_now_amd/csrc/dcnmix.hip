@@ -304,24 +304,119 @@ static int mix_mid_bwd(const MixDims& m, const float* dT2g, const float* T2, con
     return RECNOW_OK;
 }
 
-extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, const float* const* V_host,
+
+// ---- model-level fusion: the cross layers + a Dense(1) scoring head ------------------------------------------
+// score[m] = y[m] . w_head + b_head with y = x * O_{L-1} the last layer's output
+// (reference rec_now/layers/dcn_mix_layer.py:149-150 -> multi_dense_layer.py:90-92 with units = 1, num_dnn = 1).
+// Forward: the last GEMM3's epilogue forms y's tile in registers, leaves its row-dot with w_head as 2 * D / 128 partials per row
+// (c2_mode 3) and never stores y.  Backward: the head's gradient dy = dscore (x) w_head is rank one and is never materialised:
+//   dT2g = dscore[m] * (x (W * w_head)^T)          -> plain product with pre-scaled weights, rows scaled when dT2g is read
+//   M    = x^T (dscore * T2g)                      -> dW = w_head * M^T, dbias likewise, and d w_head[c] = sum_k [W; b][k][c] M[c][k]
+//   dx  += dscore[m] * w_head[c] * O_{L-1}[m][c]   -> added in the first kernel that writes dx (c2_mode 4)
+struct MixHead {            // forward
+    const float* w;         // (D)
+    const float* b;         // (1) or NULL
+    float* scores;          // (B)
+};
+struct MixHeadGrad {        // backward
+    const float* w;         // (D)
+    const float* dscores;   // (B)
+    float* dw;              // (D)
+    float* db;              // (1) or NULL
+};
+
+__global__ void __launch_bounds__(256)
+k_head_scores(const float* __restrict__ hp, int np, const float* __restrict__ bias, int64_t B, float* __restrict__ scores) {
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < B; m += (int64_t)gridDim.x * 256) {
+        float s = bias ? bias[0] : 0.f;
+        for (int p = 0; p < np; ++p) s += hp[m * np + p];          // fixed order
+        scores[m] = s;
+    }
+}
+// Wh[k][c] = W[k][c] * wh[c] (k < NS), Wh[NS + n][c] = bias[n][c] * wh[c]
+__global__ void __launch_bounds__(256)
+k_head_scale_w(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ wh, int NS, int N, int D,
+               float* __restrict__ Wh) {
+    const int64_t total = (int64_t)(NS + N) * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i / D), c = (int)(i % D);
+        Wh[i] = (k < NS ? W[i] : bias[(int64_t)(k - NS) * D + c]) * wh[c];
+    }
+}
+// out[m][:] = rs[m] * in[m][:]   (B x LD, float4)
+__global__ void __launch_bounds__(256)
+k_row_scale(const float* __restrict__ in, const float* __restrict__ rs, int64_t B, int LD, float* __restrict__ out) {
+    const int64_t total = B * (LD / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float sc = rs[i / (LD / 4)];
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+// in place: Mw (NS x D) and Mb (N x D) hold M^T = (x^T (dscore * T2g))^T;  dwh[c] = sum_k W[k][c] Mw[k][c] + sum_n bias[n][c] Mb[n][c];
+// then Mw *= wh[c] (= dW) and Mb *= wh[c] (= dbias).  One thread per column, rows walked in order.
+__global__ void __launch_bounds__(256)
+k_head_post(float* __restrict__ Mw, float* __restrict__ Mb, const float* __restrict__ W, const float* __restrict__ bias,
+            const float* __restrict__ wh, int NS, int N, int D, float* __restrict__ dwh) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const float w = wh[c];
+    float s = 0.f;
+    for (int k = 0; k < NS; ++k) {
+        const float m = Mw[(int64_t)k * D + c];
+        s += W[(int64_t)k * D + c] * m;
+        Mw[(int64_t)k * D + c] = m * w;
+    }
+    for (int n = 0; n < N; ++n) {
+        const float m = Mb[(int64_t)n * D + c];
+        s += bias[(int64_t)n * D + c] * m;
+        Mb[(int64_t)n * D + c] = m * w;
+    }
+    dwh[c] = s;
+}
+// dx[m][c] = ds[m] * wh[c] * O[m][c]   (single cross layer under a fused head: the only term that is not a product)
+__global__ void __launch_bounds__(256)
+k_head_dx_top(const float* __restrict__ O, const float* __restrict__ ds, const float* __restrict__ wh, int64_t B, int D, float* __restrict__ dx) {
+    const int64_t total = B * (D / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / (D / 4);
+        const int c4 = (int)(i % (D / 4));
+        const float sc = ds[m];
+        const float4 o = reinterpret_cast<const float4*>(O)[i], w = reinterpret_cast<const float4*>(wh)[c4];
+        reinterpret_cast<float4*>(dx)[i] = make_float4(sc * w.x * o.x, sc * w.y * o.y, sc * w.z * o.z, sc * w.w * o.w);
+    }
+}
+static inline int ew_grid(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    return (int)(g > 0 ? g : 1);
+}
+// the fused head rides on the exact-128 formulation with the fused sub-space kernels
+static inline bool mix_head_ok(const MixDims& m) {
+    return m.exact && rn_mix_mid_supported(m.S, m.N, m.LDT) && 2 * (m.D / 128) <= m.LDT && m.L <= MIX_PACK_MAX_L;
+}
+
+static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const float* const* V_host,
                                   const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
                                   int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* y, void* saved,
-                                  size_t saved_bytes, void* ws, size_t ws_bytes, void* stream, int need_dx) {
+                                  size_t saved_bytes, void* ws, size_t ws_bytes, void* stream, int need_dx, const MixHead* head) {
     if (B < 0 || D < 1 || S < 1 || N < 1 || L < 1 || B > 0x7fffffffll) return RECNOW_EINVAL;
     if (N > 64) return RECNOW_EUNSUPPORTED;
     if (B == 0) return RECNOW_OK;
-    if (!x || !U_host || !V_host || !W_host || !bias_host || !gate_host || !y || !saved || !ws) return RECNOW_EINVAL;
+    if (!x || !U_host || !V_host || !W_host || !bias_host || !gate_host || (!y && !head) || !saved || !ws) return RECNOW_EINVAL;
+    if (head && (!head->w || !head->scores)) return RECNOW_EINVAL;
     if (saved_bytes < recnow_dcn_mix_saved_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
     if (ws_bytes < recnow_dcn_mix_workspace_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const MixDims m = mix_dims(B, D, S, N, L);
+    if (head && !mix_head_ok(m)) return RECNOW_EUNSUPPORTED;
     RnCarver c(ws, ws_bytes);
     float* Wc1 = c.take<float>((size_t)D * m.LDT);
     float* Wc2 = c.take<float>((size_t)m.LDT * D);
     c.take<float>((size_t)D * m.LDT);
     c.take<float>((size_t)m.LDT * D);
-    c.take<float>(3 * act_block(m) / sizeof(float));
+    float* hp = c.take<float>(3 * act_block(m) / sizeof(float));      // forward: free -> the head's row-dot partials (B x 2D/128)
     c.take<float>(2 * xbuf(m) / sizeof(float));
     const bool pack_once = m.exact && L <= MIX_PACK_MAX_L;          // all layers' packed weights in one launch
     float* Wc1_all = pack_once ? c.take<float>((size_t)L * D * m.LDT) : nullptr;
@@ -368,7 +463,16 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
                 d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
                 if (need_dx) { d.C2 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.ldc2 = D; d.c2_mode = 1; }     // O_l only feeds dx
+                if (head && l == L - 1) {       // the layer output only feeds the scoring head: row-dot partials instead of y
+                    d.c2_mode = 3; d.ldc2 = D;
+                    d.C = omid + (size_t)l * (xbuf(m) / sizeof(float));      // not written (c2_mode 3); a valid aligned address for the checks
+                    d.hv = head->w; d.hp = hp; d.hp_ld = 2 * (D / 128);
+                }
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+                if (head && l == L - 1) {
+                    hipLaunchKernelGGL(k_head_scores, ew_grid(B), 256, 0, st, hp, 2 * (D / 128), head->b, B, head->scores);
+                    RN_LAUNCH_CHECK();
+                }
             }
             xl = out;
             continue;
@@ -396,6 +500,30 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
         xl = out;
     }
     return RECNOW_OK;
+}
+
+extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, const float* const* V_host,
+                                  const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
+                                  int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* y, void* saved,
+                                  size_t saved_bytes, void* ws, size_t ws_bytes, void* stream, int need_dx) {
+    return dcnmix_fwd_impl(x, U_host, V_host, W_host, bias_host, gate_host, B, D, S, N, L, act_inner, act_outer, y, saved, saved_bytes,
+                           ws, ws_bytes, stream, need_dx, nullptr);
+}
+
+extern "C" int recnow_dcn_mix_score_supported(int64_t B, int D, int S, int N, int L) {
+    if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
+    return mix_head_ok(mix_dims(B, D, S, N, L)) ? 1 : 0;
+}
+
+extern "C" int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_host, const float* const* V_host,
+                                        const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
+                                        const float* head_w, const float* head_b, int64_t B, int D, int S, int N, int L, int act_inner,
+                                        int act_outer, float* scores, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                                        void* stream, int need_dx) {
+    MixHead head;
+    head.w = head_w; head.b = head_b; head.scores = scores;
+    return dcnmix_fwd_impl(x, U_host, V_host, W_host, bias_host, gate_host, B, D, S, N, L, act_inner, act_outer, nullptr, saved,
+                           saved_bytes, ws, ws_bytes, stream, need_dx, &head);
 }
 
 
@@ -430,7 +558,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
                             const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
                             const float* dy, const char* sv, int act_inner, int act_outer, float* dx, float* const* dU_host,
                             float* const* dV_host, float* const* dW_host, float* const* dbias_host, float* const* dgate_host,
-                            void* ws, size_t ws_bytes, hipStream_t st, hipStream_t st2) {
+                            void* ws, size_t ws_bytes, hipStream_t st, hipStream_t st2, const MixHeadGrad* hd = nullptr,
+                            void* const* layer_events = nullptr) {
     const int64_t B = m.B;
     const int D = m.D, S = m.S, N = m.N, L = m.L;
     const bool two = st2 != nullptr && st2 != st;
@@ -463,6 +592,20 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             RN_LAUNCH_CHECK();
         }
     }
+    float* Wh = dWc1;                  // fused head: [W * w_head; bias * w_head] of the top layer ((NS+N) x D <= D x LDT floats), consumed
+                                       // by the top dT2g product before this layer's dU product overwrites the buffer
+    float* T2g_ds = dC;                // fused head: dscore * T2g of the top layer (dC is scratch of the unfused sub-space route only)
+    if (hd) {
+        const float* T2g_top = (const float*)(sv + (size_t)(3 * (L - 1) + 2) * act_block(m));
+        hipLaunchKernelGGL(k_head_scale_w, ew_grid((int64_t)m.KC * D), 256, 0, st, W_host[L - 1], bias_host[L - 1], hd->w, m.NS, N, D, Wh);
+        hipLaunchKernelGGL(k_row_scale, ew_grid(B * (m.LDT / 4)), 256, 0, st, T2g_top, hd->dscores, B, m.LDT, T2g_ds);
+        RN_LAUNCH_CHECK();
+        if (hd->db && (rc = rn_colsum(hd->dscores, nullptr, 0, 0, B, 1, 1, hd->db, 0, gws, gemm_ws, st))) return rc;
+        if (dx && L == 1) {            // a single cross layer: its dx product accumulates on top of the head's term
+            hipLaunchKernelGGL(k_head_dx_top, ew_grid(B * (D / 4)), 256, 0, st, omid, hd->dscores, hd->w, B, D, dx);
+            RN_LAUNCH_CHECK();
+        }
+    }
     hipEvent_t e_g = nullptr;        // "g of this layer (and the packs) are ready" -> side stream may start the layer
     MIX_SIGNAL(e_g, st);
     hipEvent_t e_side_prev = nullptr;   // side stream finished the previous (higher) layer: dT1/dC/g buffers reusable
@@ -480,13 +623,22 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         MIX_WAIT(e_g, st2);
         {   // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
+            const bool top_head = hd && l == L - 1;
             d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 1;
             d.B = T2g; d.ldb = m.LDT; d.b_trans = 0;
+            if (top_head) {      // M^T = (x^T (dscore * T2g))^T: the rank-one head gradient reduced to a row scale of the small operand
+                d.A = x; d.A2 = nullptr; d.a_mode = RECNOW_OPMODE_NONE;
+                d.B = T2g_ds;
+            }
             d.C = dW_host[l]; d.ldc = D; d.c_trans = 1;
             d.M = D; d.N = m.NS; d.K = (int)B;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
-            d.sp_bx = T2g + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
+            d.sp_bx = d.B + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
             if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
+            if (top_head) {      // dW = w_head * M^T, dbias likewise, d w_head = sum_k [W; b] * M^T
+                hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 256), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw);
+                RN_LAUNCH_CHECK();
+            }
         }
         // ---------------- chain stream
         {   // dT2g[:, :NS] = (x*g) W^T;  gate columns dT2g[:, NS+n] = (x*g) . bias_n as the side product
@@ -497,7 +649,11 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = (int)B; d.N = m.NS; d.K = D;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.sp_bx = bias_host[l]; d.sp_bx_ks = 1; d.sp_bx_rs = D; d.sp_cx = dT2g + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
-            if (l == L - 1 && dx) {      // top layer: this product streams g = dy anyway -> dx = dy * O_{L-1} written on the way
+            if (hd && l == L - 1) {      // x (W * w_head)^T and x (bias * w_head)^T; the rows are scaled by dscore when dT2g is read
+                d.A = x; d.A2 = nullptr; d.a_mode = RECNOW_OPMODE_NONE;
+                d.B = Wh;
+                d.sp_bx = Wh + (size_t)m.NS * D;
+            } else if (l == L - 1 && dx) {      // top layer: this product streams g = dy anyway -> dx = dy * O_{L-1} written on the way
                 d.as_in = omid + (size_t)l * (xbuf(m) / sizeof(float));
                 d.as_out = dx;
             }
@@ -505,7 +661,10 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         }
         MIX_WAIT(e_side_prev, st);          // dT1 (and the g buffer about to be rewritten) are free again
         // gate backward, dA_n = (dC_n V_n^T) * act_inner'(H1_n) and dV_n = H1_n^T dC_n
-        if ((rc = mix_mid_bwd(m, dT2g, T2, T1, V_host[l], dC, dT1, dV_host[l], act_inner, act_outer, mid_ws, mid_ws_bytes, gws, gemm_ws, st)))
+        if (hd && l == L - 1) {
+            if ((rc = rn_mix_mid_bwd(dT2g, T2, T1, V_host[l], dT1, dV_host[l], B, S, N, m.LDT, act_inner, act_outer, mid_ws, mid_ws_bytes, st, hd->dscores)))
+                return rc;
+        } else if ((rc = mix_mid_bwd(m, dT2g, T2, T1, V_host[l], dC, dT1, dV_host[l], act_inner, act_outer, mid_ws, mid_ws_bytes, gws, gemm_ws, st)))
             return rc;
         hipEvent_t e_dT1 = nullptr;
         MIX_SIGNAL(e_dT1, st);
@@ -519,6 +678,10 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.accumulate = (l == 0) ? 1 : 0;
             if (l > 0 && dx) { d.C2 = dx; d.ldc2 = D; d.E2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.lde2 = D; d.c2_mode = 2; }
+            if (hd && l == L - 1 && l > 0 && dx) {       // first write of dx: g_{l-1} * O_{l-1} + dscore (x) w_head * O_{L-1}
+                d.c2_mode = 4;
+                d.E3 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.lde3 = D; d.rv = hd->dscores; d.cv = hd->w;
+            }
             if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
         }
         if (l > 0) MIX_SIGNAL(e_g, st);
@@ -537,6 +700,9 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             RN_LAUNCH_CHECK();
         }
         MIX_SIGNAL(e_side_prev, st2);
+        // every weight gradient of layer l has been issued (dW, dbias above; dV in the sub-space kernel; dU, dgate just now): a
+        // caller-owned event lets the all-reduce of this layer start while the lower layers' backward still runs
+        if (layer_events && layer_events[l]) RN_HIP(hipEventRecord((hipEvent_t)layer_events[l], two ? st2 : st));
         g = gprev;
     }
     MIX_WAIT(e_side_prev, st);              // join: everything the side stream produced is ordered before later work on st
@@ -653,4 +819,44 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
         g = gprev;
     }
     return RECNOW_OK;
+}
+
+
+// Backward of recnow_dcn_mix_score_fwd.  dscores (B) = d loss / d scores.  layer_events_host: optional HOST array of L hipEvent_t
+// (entries may be NULL); event l is recorded once every weight gradient of layer l has been issued, the head's gradients are
+// complete at event L-1.
+extern "C" int recnow_dcn_mix_score_bwd(const float* x, const float* const* U_host, const float* const* V_host,
+                                        const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
+                                        const float* head_w, const float* dscores, const void* saved, size_t saved_bytes, int64_t B,
+                                        int D, int S, int N, int L, int act_inner, int act_outer, float* dx, float* const* dU_host,
+                                        float* const* dV_host, float* const* dW_host, float* const* dbias_host,
+                                        float* const* dgate_host, float* dhead_w, float* dhead_b, void* ws, size_t ws_bytes,
+                                        void* stream, void* stream2, void* const* layer_events_host) {
+    if (B < 0 || D < 1 || S < 1 || N < 1 || L < 1 || B > 0x7fffffffll) return RECNOW_EINVAL;
+    if (N > 64) return RECNOW_EUNSUPPORTED;
+    if (!dU_host || !dV_host || !dW_host || !dbias_host || !dgate_host || !dhead_w) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        for (int l = 0; l < L; ++l) {
+            RN_HIP(hipMemsetAsync(dU_host[l], 0, (size_t)N * D * S * sizeof(float), st));
+            RN_HIP(hipMemsetAsync(dV_host[l], 0, (size_t)N * S * S * sizeof(float), st));
+            RN_HIP(hipMemsetAsync(dW_host[l], 0, (size_t)N * S * D * sizeof(float), st));
+            RN_HIP(hipMemsetAsync(dbias_host[l], 0, (size_t)N * D * sizeof(float), st));
+            RN_HIP(hipMemsetAsync(dgate_host[l], 0, (size_t)D * N * sizeof(float), st));
+            if (layer_events_host && layer_events_host[l]) RN_HIP(hipEventRecord((hipEvent_t)layer_events_host[l], st));
+        }
+        RN_HIP(hipMemsetAsync(dhead_w, 0, (size_t)D * sizeof(float), st));
+        if (dhead_b) RN_HIP(hipMemsetAsync(dhead_b, 0, sizeof(float), st));
+        return RECNOW_OK;
+    }
+    if (!x || !U_host || !V_host || !W_host || !bias_host || !gate_host || !head_w || !dscores || !saved || !ws) return RECNOW_EINVAL;
+    if (saved_bytes < recnow_dcn_mix_saved_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
+    if (ws_bytes < recnow_dcn_mix_workspace_bytes(B, D, S, N, L)) return RECNOW_EWORKSPACE;
+    const MixDims m = mix_dims(B, D, S, N, L);
+    if (!mix_head_ok(m)) return RECNOW_EUNSUPPORTED;
+    MixHeadGrad hd;
+    hd.w = head_w; hd.dscores = dscores; hd.dw = dhead_w; hd.db = dhead_b;
+    return dcnmix_bwd_exact(m, x, U_host, V_host, W_host, bias_host, gate_host, nullptr, (const char*)saved, act_inner, act_outer, dx,
+                            dU_host, dV_host, dW_host, dbias_host, dgate_host, ws, ws_bytes, st, (hipStream_t)stream2, &hd,
+                            layer_events_host);
 }

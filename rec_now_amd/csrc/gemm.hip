@@ -157,7 +157,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     k.C2 = d->C2; k.E2 = d->E2; k.ldc2 = d->ldc2; k.lde2 = d->lde2;
     k.as_in = d->as_in; k.as_out = d->as_out;
     if ((d->as_in != nullptr) != (d->as_out != nullptr)) return RECNOW_EINVAL;
-    if (d->c2_mode < 0 || d->c2_mode > 4 || (d->c2_mode && !d->C2) || ((d->c2_mode == 2 || d->c2_mode == 4) && !d->E2)) return RECNOW_EINVAL;
+    if (d->c2_mode < 0 || d->c2_mode > 4 || (d->c2_mode && d->c2_mode != 3 && !d->C2) || ((d->c2_mode == 2 || d->c2_mode == 4) && !d->E2)) return RECNOW_EINVAL;
     if (d->c2_mode == 3 && (!d->hv || !d->hp || !d->emul || d->hp_ld < d->N / 64 || ((uintptr_t)d->hv & 15))) return RECNOW_EINVAL;
     if (d->c2_mode == 4 && (!d->E3 || !d->rv || !d->cv || ((uintptr_t)d->cv & 15) || !host_aligned(d->E3, d->lde3, 0))) return RECNOW_EINVAL;
     k.E3 = d->E3; k.lde3 = d->lde3; k.rv = d->rv; k.cv = d->cv; k.hv = d->hv; k.hp = d->hp; k.hp_ld = d->hp_ld;
@@ -215,7 +215,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
         if (rc) return rc;
     } else if (use_shortk) {
         // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)
-        if (d->c2_mode && (!host_aligned(d->C2, d->ldc2, 0) || ((d->c2_mode == 2 || d->c2_mode == 4) && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
+        if (d->c2_mode && ((d->C2 && !host_aligned(d->C2, d->ldc2, 0)) || ((d->c2_mode == 2 || d->c2_mode == 4) && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
         rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, st);
         if (rc) return rc;
     } else if (d->c2_mode) {

@@ -21,8 +21,12 @@
 // 3 (scoring head folded into the last cross layer): C2 = acc, C = acc * emul is NOT stored, its row-dot with hv leaves as
 //   partials hp[m][2 * column tile + wave column] (fixed order, summed by the consumer);
 // 4 (first dx write of the backward): C = acc, C2 = acc * E2 + rv[m] * cv[n] * E3[m][n] (C2 is written, never read).
+// Workgroups per CU (= waves per SIMD): the epilogue's operand registers set it.  These products are HBM-bound, three or two
+// co-resident workgroups still cover each other's epilogues; spilling the epilogue operands to scratch does not.
+__host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL) { return DUAL == 4 ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3) ? 3 : 4; }
+
 template <bool B_KC, int EP, int DUAL>
-__global__ void __launch_bounds__(GEMM_THREADS, ((EP == 3 || DUAL == 2 || DUAL == 4) ? 3 : 4))
+__global__ void __launch_bounds__(GEMM_THREADS, sk_wg_per_cu(EP, DUAL))
 k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
@@ -195,7 +199,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                     if (EP & 1) v = v * ev[buf][2 * h + q];
                     if (EP & 2) v = v + cv[buf][2 * h + q];
                     if (DUAL != 3) *reinterpret_cast<f32x4*>(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane) = v;
-                    if (DUAL == 1 || DUAL == 3) *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) = a;
+                    if (DUAL == 1 || (DUAL == 3 && p.C2 != nullptr)) *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) = a;
                     if (DUAL == 2)
                         *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) =
                             dv[buf][2 * h + q] + a * fv[buf][2 * h + q];
@@ -238,7 +242,7 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
     using TB = Tile<SK_BN, SK_BK, B_KC>;
     constexpr size_t lds = 2 * SK_BK * (size_t)(TA::LD + TB::LD) * sizeof(float);
     const int rt = k.M / SK_BM, ct = k.N / SK_BN;
-    const int resident = 256 * ((EP == 3 || DUAL == 2 || DUAL == 4) ? 3 : 4);
+    const int resident = 256 * sk_wg_per_cu(EP, DUAL);
     int grid = rt * ct < resident ? rt * ct : resident;
     const int xcd = (rt % 8 == 0 && grid % 8 == 0) ? 1 : 0;
     hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL>), grid, GEMM_THREADS, lds, st, k, rt, ct, xcd);

@@ -74,3 +74,27 @@ extern "C" int recnow_prof_collect(int* count_host, double* ms_host, double* flo
     g_used = 0;
     return RECNOW_OK;
 }
+
+
+// ---- events owned through the C ABI (the per-layer "gradients issued" events of recnow_dcn_mix_score_bwd) -----------------
+extern "C" int recnow_event_create(void** event_out) {
+    if (!event_out) return RECNOW_EINVAL;
+    hipEvent_t e = nullptr;
+    RN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event_out = (void*)e;
+    return RECNOW_OK;
+}
+extern "C" int recnow_event_destroy(void* event) {
+    if (event) RN_HIP(hipEventDestroy((hipEvent_t)event));
+    return RECNOW_OK;
+}
+extern "C" int recnow_event_record(void* event, void* stream) {
+    if (!event) return RECNOW_EINVAL;
+    RN_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return RECNOW_OK;
+}
+extern "C" int recnow_stream_wait_event(void* stream, void* event) {
+    if (!event) return RECNOW_EINVAL;
+    RN_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return RECNOW_OK;
+}

@@ -144,3 +144,73 @@ class GradientAllReducer(object):
                 off += k
             if dst:
                 torch._foreach_copy_(dst, src)
+
+
+class LayerwiseReducer(object):
+    """Gradient all-reduce overlapped with the backward pass, one bucket per cross layer.
+
+    `stages`: parameter lists in the order their gradients become final in the backward pass (for the north-star model: the
+    top cross layer + the scoring head first, layer 0 last).  `events[i]` (fused.GpuEvent) is recorded by
+    `recnow_dcn_mix_score_bwd` once every gradient of stage i has been issued.  After `loss_sum.backward()` has returned (all
+    kernels are enqueued, none need have run), `reduce(loss_sum, count)` makes a side stream wait for event i, all-reduce
+    bucket i and scale it -- while the main stream is still executing the backward of the stages below.  The two loss
+    statistics ride in the FIRST bucket (they are known before the backward pass starts), so every later bucket can be
+    multiplied by 1 / (P_global + eps) as soon as its own collective has finished.  Works without a process group (scaling
+    only).  Returns (global mean loss, P_global) as 0-dim tensors."""
+
+    def __init__(self, stages, events, device):
+        self.stages = [[p for p in stage if p.requires_grad] for stage in stages]
+        self.events = list(events)
+        if len(self.events) != len(self.stages):
+            raise ValueError('one event per stage')
+        self.comm = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None      # CPU (gloo tests): in order
+        self._flat = [None] * len(self.stages)
+
+    def reduce(self, local_loss_sum, local_count, eps=SMALL_POSIVITE_FLOAT):
+        import contextlib
+        main = torch.cuda.current_stream() if self.comm is not None else None
+        stats = torch.stack([local_loss_sum.detach().to(torch.float32), local_count.detach().to(torch.float32)])
+        if not is_dist():
+            inv = 1.0 / (stats[1] + eps)
+            grads = [p.grad for stage in self.stages for p in stage if p.grad is not None]
+            if grads:
+                torch._foreach_mul_(grads, inv)
+            return stats[0] * inv, stats[1]
+        if self.comm is not None:
+            self.comm.wait_stream(main)                 # the statistics (and, without events, everything) are ordered before the side stream
+        out_stats = None
+        inv = None
+        with (torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()):
+            for i, stage in enumerate(self.stages):
+                if self.events[i] is not None and self.comm is not None:
+                    self.events[i].wait(self.comm)
+                parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in stage]
+                if i == 0:
+                    parts.append(stats)
+                total = sum(t.numel() for t in parts)
+                flat = self._flat[i]
+                if flat is None or flat.numel() != total:
+                    flat = self._flat[i] = torch.empty(total, dtype=torch.float32, device=stats.device)
+                torch.cat(parts, out=flat)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                if i == 0:
+                    out_stats = flat[-2:].clone()
+                    inv = 1.0 / (out_stats[1] + eps)
+                flat.mul_(inv)
+                off, dst, src = 0, [], []
+                for p in stage:
+                    k = p.numel()
+                    view = flat[off:off + k].reshape(p.shape)
+                    if p.grad is None:
+                        p.grad = view.clone()
+                    else:
+                        if self.comm is not None:
+                            p.grad.record_stream(self.comm)
+                        dst.append(p.grad)
+                        src.append(view)
+                    off += k
+                if dst:
+                    torch._foreach_copy_(dst, src)
+        if self.comm is not None:
+            main.wait_stream(self.comm)                 # the gradients are final for whatever the main stream does next
+        return out_stats[0] * inv, out_stats[1]

@@ -156,6 +156,20 @@ def _worker4(rank, world, port, out, empty_rank):
     lw_bw.backward()
     red2 = dp.GradientAllReducer([wl])
     red2.all_reduce()
+    # layer-wise (overlapped) form: two stages, the statistics ride in the first bucket, every bucket scaled after its collective
+    wc = torch.from_numpy(w[:2].copy()).requires_grad_(True)
+    wd = torch.from_numpy(w[2:3].copy()).requires_grad_(True)
+    sc3 = torch.from_numpy(s[mine]) * wc[0] + wc[1] + wd[0] * torch.from_numpy(s[mine]) ** 2
+    if mine.sum() > 0:
+        local_sum3, n_pair3 = R.pairwise_loss(sc3, yl, gl, f, return_num_pair=True)
+    else:
+        local_sum3, n_pair3 = sc3.sum() * 0.0, 0.0
+    local_sum3.backward()
+    lw_red = dp.LayerwiseReducer([[wd], [wc]], [None, None], 'cpu')
+    loss_val3, p_glob3 = lw_red.reduce(local_sum3, torch.tensor(float(n_pair3)))
+    assert abs(float(loss_val3) - float(loss_val)) <= 2e-6 * max(1.0, abs(float(loss_val))) and float(p_glob3) == float(p_glob)
+    assert np.abs(wc.grad.numpy() - wa.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wa.grad.numpy()).max())
+    assert np.abs(wd.grad.numpy() - wb.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wb.grad.numpy()).max())
     out[rank] = (float(loss_val), float(p_glob), wa.grad.numpy().copy(), wb.grad.numpy().copy(), int(mine.sum()),
                  float(lw_val), float(nv_glob), wl.grad.numpy().copy())
     dist.barrier()

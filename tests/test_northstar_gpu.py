@@ -63,10 +63,12 @@ def test_dcn_mix_config3_every_gradient_vs_oracle(dev):
         close(p.grad, rgrads[name], what=name)
 
 
-@pytest.mark.parametrize('B', [32768, 65536])
-def test_config3_model_drop_in_signature(dev, B):
+@pytest.mark.parametrize('B,route', [(32768, 'layers'), (65536, 'layers'), (32768, 'fused'), (65536, 'fused')])
+def test_config3_model_drop_in_signature(dev, B, route):
     """configs[2] end to end through the drop-in signatures: DCNMixLayer -> MultiDenseLayer(1,1) -> pairwise_loss(outputs, labels,
-    groups): loss, pair count, d loss / d x and every weight gradient (cross layers and head) vs the oracle."""
+    groups): loss, pair count, d loss / d x and every weight gradient (cross layers and head) vs the oracle.
+    route 'fused': the same two layers evaluated by the model-level fused node (rec_now_amd/fused.py)."""
+    from rec_now_amd.fused import dcn_mix_score, fused_route_available
     from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
     from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
     from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
@@ -82,7 +84,11 @@ def test_config3_model_drop_in_signature(dev, B):
     with torch.no_grad():
         head.kernel.mul_(40.0)          # scores of O(1): pair terms away from the softplus(0) = ln 2 plateau
         head.bias.fill_(0.3)
-    scores = head(cross(xd)).reshape(-1)
+    if route == 'fused':
+        assert fused_route_available(cross, head, xd)
+        scores = dcn_mix_score(cross, head, xd)
+    else:
+        scores = head(cross(xd)).reshape(-1)
     loss, n_pair = pairwise_loss(scores, torch.from_numpy(labels).to(dev), torch.from_numpy(groups).to(dev), return_num_pair=True)
     loss.backward()
     named = dict(cross.named_weights())
