@@ -241,13 +241,15 @@ def main():
     from rec_now_amd.fused import GpuEvent, dcn_mix_score, fused_route_available
     from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
     fused = not args.unfused and fused_route_available(model.cross, model.head, xd)
-    events, layerwise = None, None
+    events, layerwise, grad_buffers = None, None, None
     if fused and use_dist:
         events = [GpuEvent() for _ in range(LAYERS)]
         per_layer = lambda l: [model.cross.origin_to_sub_kernels[l], model.cross.sub_to_sub_kernels[l], model.cross.sub_to_origin_kernels[l],     # noqa: E731
                                model.cross.biases[l], model.cross.gate_layers[l].kernel]
         stages = [per_layer(LAYERS - 1) + [model.head.kernel, model.head.bias]] + [per_layer(l) for l in range(LAYERS - 2, -1, -1)]
         layerwise = dp.LayerwiseReducer(stages, [events[l] for l in range(LAYERS - 1, -1, -1)], dev)
+        from rec_now_amd.fused import score_params
+        grad_buffers = [layerwise.buffer_of(p) for p in score_params(model.cross, model.head)]     # gradients are written into the buckets
 
     side = torch.cuda.Stream(device=dev)
     last = {}
@@ -273,7 +275,7 @@ def main():
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 seg = group_rows(gd)
-            scores = dcn_mix_score(model.cross, model.head, xin, layer_events=events) if fused else model(xin)
+            scores = dcn_mix_score(model.cross, model.head, xin, layer_events=events, grad_buffers=grad_buffers) if fused else model(xin)
             main.wait_stream(side)
             local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False, segments=seg)
         if layerwise is not None:
@@ -374,6 +376,8 @@ def main():
         named_np = {k: v.detach().cpu().numpy() for k, v in named.items()}
         xq_np = x * np.float32(CHECK_SCALE)
         sc_gpu, dx_gpu = last['scores'].detach().cpu().numpy(), xq.grad.cpu().numpy()
+        if use_dist:          # the one-collective form runs the backward pass on the unnormalised loss sum: weight gradients are scaled
+            dx_gpu = dx_gpu / (np.float32(last['n_pair'].item()) + np.float32(1e-10))      # in the reducer, dx (not a parameter) here
         parity = {'inputs': 'x * %g' % CHECK_SCALE, 'loss': float(loss_q.item()), 'tolerance': PARITY_TOL}
         if True:
             parity['subset_fp64'] = subset_parity(xq_np, groups, labels, named_np, sc_gpu, dx_gpu, int(last['n_pair'].item()))

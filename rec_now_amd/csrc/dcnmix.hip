@@ -186,6 +186,7 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
     s += 2 * rn_align(mix_gemm_ws(m));                       // split-K slabs: chain stream + side stream
     s += rn_mix_mid_bwd_ws_bytes(B, S, N);                   // per-workgroup dV partials of the fused sub-space backward
     s += (size_t)L * (rn_align((size_t)D * m.LDT * sizeof(float)) + rn_align((size_t)m.LDT * D * sizeof(float)));   // per-layer packs
+    s += rn_align(rn_colsum_ws_bytes(B, 1));                 // fused scoring head: d bias = sum of dscores
     return s + 4096;
 }
 
@@ -577,6 +578,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     void* gws2 = c.take<char>(gemm_ws);                             // ... and of the side stream
     const size_t mid_ws_bytes = rn_mix_mid_bwd_ws_bytes(B, S, N);
     void* mid_ws = c.take<char>(mid_ws_bytes);
+    const size_t cs_ws_bytes = rn_colsum_ws_bytes(B, 1);
+    void* cs_ws = c.take<char>(cs_ws_bytes);
     if (!c.ok()) return RECNOW_EWORKSPACE;
     const float* xmid = (const float*)(sv + (size_t)L * 3 * act_block(m));
     const float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));
@@ -600,7 +603,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         hipLaunchKernelGGL(k_head_scale_w, ew_grid((int64_t)m.KC * D), 256, 0, st, W_host[L - 1], bias_host[L - 1], hd->w, m.NS, N, D, Wh);
         hipLaunchKernelGGL(k_row_scale, ew_grid(B * (m.LDT / 4)), 256, 0, st, T2g_top, hd->dscores, B, m.LDT, T2g_ds);
         RN_LAUNCH_CHECK();
-        if (hd->db && (rc = rn_colsum(hd->dscores, nullptr, 0, 0, B, 1, 1, hd->db, 0, gws, gemm_ws, st))) return rc;
+        if (hd->db && (rc = rn_colsum(hd->dscores, nullptr, 0, 0, B, 1, 1, hd->db, 0, cs_ws, cs_ws_bytes, st))) return rc;
         if (dx && L == 1) {            // a single cross layer: its dx product accumulates on top of the head's term
             hipLaunchKernelGGL(k_head_dx_top, ew_grid(B * (D / 4)), 256, 0, st, omid, hd->dscores, hd->w, B, D, dx);
             RN_LAUNCH_CHECK();

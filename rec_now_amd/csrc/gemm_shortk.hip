@@ -23,11 +23,16 @@
 // 4 (first dx write of the backward): C = acc, C2 = acc * E2 + rv[m] * cv[n] * E3[m][n] (C2 is written, never read).
 // Workgroups per CU (= waves per SIMD): the epilogue's operand registers set it.  These products are HBM-bound, three or two
 // co-resident workgroups still cover each other's epilogues; spilling the epilogue operands to scratch does not.
-__host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL) { return DUAL == 4 ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3) ? 3 : 4; }
+// PRE: the whole tile of `emul` (64 registers per lane) is requested BEFORE the tile's k-loop, so it lands under the MFMAs and the
+// epilogue never waits for a load (EP == 1 products: y = x * (T2g [W; b]) streams x).
+__host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL, bool PRE) {
+    return (DUAL == 4 || PRE) ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3) ? 3 : 4;
+}
 
-template <bool B_KC, int EP, int DUAL>
-__global__ void __launch_bounds__(GEMM_THREADS, sk_wg_per_cu(EP, DUAL))
+template <bool B_KC, int EP, int DUAL, bool PRE = false>
+__global__ void __launch_bounds__(GEMM_THREADS, sk_wg_per_cu(EP, DUAL, PRE))
 k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
+    static_assert(!PRE || (EP == 1 && DUAL != 2 && DUAL != 4), "whole-tile prefetch: emul only");
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
     constexpr int A_SZ = SK_BK * TA::LD, B_SZ = SK_BK * TB::LD, BUF = A_SZ + B_SZ;
@@ -100,6 +105,15 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        f32x4 evt[PRE ? 4 : 1][4];
+        if (PRE) {
+            const float* Etp = p.emul + (int64_t)m0 * p.lde + n0;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    evt[PRE ? s2 : 0][q] = *reinterpret_cast<const f32x4*>(Etp + (int64_t)((s2 >> 1) * 32 + q * 8) * p.lde + (s2 & 1) * 32 + e_lane);
+        }
         for (int t = 0; t < nk; ++t) {
             const int cur = (f + t) & 1;
             const bool more = t + 1 < nk;
@@ -171,7 +185,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
             const int i = s2 >> 1, j = s2 & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (EP & 1) ev[buf][q] = *reinterpret_cast<const f32x4*>(Et + (int64_t)(i * 32 + q * 8) * p.lde + j * 32 + e_lane);
+                if ((EP & 1) && !PRE) ev[buf][q] = *reinterpret_cast<const f32x4*>(Et + (int64_t)(i * 32 + q * 8) * p.lde + j * 32 + e_lane);
                 if (EP & 2) cv[buf][q] = *reinterpret_cast<const f32x4*>(Ct + (int64_t)(i * 32 + q * 8) * p.ldc + j * 32 + c_lane);
                 if (DUAL == 2 || DUAL == 4) fv[buf][q] = *reinterpret_cast<const f32x4*>(Ft + (int64_t)(i * 32 + q * 8) * p.lde2 + j * 32 + f_lane);
                 if (DUAL == 2) dv[buf][q] = *reinterpret_cast<const f32x4*>(Dt + (int64_t)(i * 32 + q * 8) * p.ldc2 + j * 32 + d_lane);
@@ -181,11 +195,11 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 }
             }
         };
-        if (EP || DUAL == 2 || DUAL == 4) issue(0, 0);
+        if ((EP && !PRE) || DUAL == 2 || DUAL == 4) issue(0, 0);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
             const int i = s2 >> 1, j = s2 & 1, buf = s2 & 1;
-            if ((EP || DUAL == 2 || DUAL == 4) && s2 + 1 < 4) issue(s2 + 1, buf ^ 1);
+            if (((EP && !PRE) || DUAL == 2 || DUAL == 4) && s2 + 1 < 4) issue(s2 + 1, buf ^ 1);
             if (DUAL == 3 && j == 0) hs[0] = hs[1] = hs[2] = hs[3] = 0.f;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {          // accumulator registers 8h..8h+7 hold rows 16h..16h+15 of the sub-tile
@@ -196,7 +210,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rr0) * 36 + cc);
                     f32x4 v = a;
-                    if (EP & 1) v = v * ev[buf][2 * h + q];
+                    if (EP & 1) v = v * (PRE ? evt[PRE ? s2 : 0][2 * h + q] : ev[buf][2 * h + q]);
                     if (EP & 2) v = v + cv[buf][2 * h + q];
                     if (DUAL != 3) *reinterpret_cast<f32x4*>(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane) = v;
                     if (DUAL == 1 || (DUAL == 3 && p.C2 != nullptr)) *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) = a;
@@ -236,16 +250,16 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     }
 }
 
-template <bool B_KC, int EP, int DUAL>
+template <bool B_KC, int EP, int DUAL, bool PRE = false>
 static int launch_sk(const GemmK& k, hipStream_t st) {
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
     constexpr size_t lds = 2 * SK_BK * (size_t)(TA::LD + TB::LD) * sizeof(float);
     const int rt = k.M / SK_BM, ct = k.N / SK_BN;
-    const int resident = 256 * sk_wg_per_cu(EP, DUAL);
+    const int resident = 256 * sk_wg_per_cu(EP, DUAL, PRE);
     int grid = rt * ct < resident ? rt * ct : resident;
     const int xcd = (rt % 8 == 0 && grid % 8 == 0) ? 1 : 0;
-    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL>), grid, GEMM_THREADS, lds, st, k, rt, ct, xcd);
+    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL, PRE>), grid, GEMM_THREADS, lds, st, k, rt, ct, xcd);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -254,6 +268,12 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
 // guarantees: M, N multiples of 128, K a multiple of 16, A k-contiguous, every operand 16-byte aligned, batch == 1, no
 // bias / activation / transposed store.  Second outputs are instantiated for the two products DCN-v2 uses them in.
 int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st) {
+    static const bool pre = []() { const char* e = getenv("RECNOW_SK_PRE"); return !e || e[0] != '0'; }();     // A/B switch of the whole-tile emul prefetch
+    if (pre && !b_kc && ep == 1) {
+        if (c2_mode == 1) return launch_sk<false, 1, 1, true>(k, st);
+        if (c2_mode == 3) return launch_sk<false, 1, 3, true>(k, st);
+        if (c2_mode == 0) return launch_sk<false, 1, 0, true>(k, st);
+    }
     if (c2_mode == 1) return (!b_kc && ep == 1) ? launch_sk<false, 1, 1>(k, st) : RECNOW_EUNSUPPORTED;
     if (c2_mode == 2) return (b_kc && ep == 0) ? launch_sk<true, 0, 2>(k, st) : RECNOW_EUNSUPPORTED;
     if (c2_mode == 3) return (!b_kc && ep == 1) ? launch_sk<false, 1, 3>(k, st) : RECNOW_EUNSUPPORTED;

@@ -151,20 +151,36 @@ class LayerwiseReducer(object):
 
     `stages`: parameter lists in the order their gradients become final in the backward pass (for the north-star model: the
     top cross layer + the scoring head first, layer 0 last).  `events[i]` (fused.GpuEvent) is recorded by
-    `recnow_dcn_mix_score_bwd` once every gradient of stage i has been issued.  After `loss_sum.backward()` has returned (all
-    kernels are enqueued, none need have run), `reduce(loss_sum, count)` makes a side stream wait for event i, all-reduce
-    bucket i and scale it -- while the main stream is still executing the backward of the stages below.  The two loss
-    statistics ride in the FIRST bucket (they are known before the backward pass starts), so every later bucket can be
-    multiplied by 1 / (P_global + eps) as soon as its own collective has finished.  Works without a process group (scaling
-    only).  Returns (global mean loss, P_global) as 0-dim tensors."""
+    `recnow_dcn_mix_score_bwd` once every gradient of stage i has been issued.  Every stage owns ONE flat fp32 bucket;
+    `buffer_of(param)` is that parameter's slice of it, to be handed to the backward pass as gradient storage
+    (`fused.dcn_mix_score(..., grad_buffers=...)`), so the collective runs in place: nothing is packed before and nothing is
+    copied after it (a gradient that was produced elsewhere is copied in and out, as a fallback).
+    After `loss_sum.backward()` has returned (all kernels are enqueued, none need have run), `reduce(loss_sum, count)` makes a
+    side stream wait for event i, all-reduce bucket i and scale it -- while the main stream is still executing the backward of
+    the stages below.  The two loss statistics ride in the FIRST bucket (they are known before the backward pass starts), so
+    every later bucket is multiplied by 1 / (P_global + eps) as soon as its own collective has finished.  Works without a
+    process group (scaling only).  Returns (global mean loss, P_global) as 0-dim tensors."""
 
     def __init__(self, stages, events, device):
         self.stages = [[p for p in stage if p.requires_grad] for stage in stages]
         self.events = list(events)
         if len(self.events) != len(self.stages):
             raise ValueError('one event per stage')
-        self.comm = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None      # CPU (gloo tests): in order
-        self._flat = [None] * len(self.stages)
+        dev = torch.device(device)
+        self.comm = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None      # CPU (gloo tests): in order
+        self._flat, self._view = [], {}
+        for i, stage in enumerate(self.stages):
+            n = sum(p.numel() for p in stage) + (2 if i == 0 else 0)
+            flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            off = 0
+            for p in stage:
+                self._view[id(p)] = flat[off:off + p.numel()]
+                off += p.numel()
+            self._flat.append(flat)
+
+    def buffer_of(self, param):
+        """The slice of its stage's flat bucket that holds `param`'s gradient (1-D view), or None for a foreign parameter."""
+        return self._view.get(id(param))
 
     def reduce(self, local_loss_sum, local_count, eps=SMALL_POSIVITE_FLOAT):
         import contextlib
@@ -184,33 +200,27 @@ class LayerwiseReducer(object):
             for i, stage in enumerate(self.stages):
                 if self.events[i] is not None and self.comm is not None:
                     self.events[i].wait(self.comm)
-                parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in stage]
-                if i == 0:
-                    parts.append(stats)
-                total = sum(t.numel() for t in parts)
                 flat = self._flat[i]
-                if flat is None or flat.numel() != total:
-                    flat = self._flat[i] = torch.empty(total, dtype=torch.float32, device=stats.device)
-                torch.cat(parts, out=flat)
+                foreign = []                            # gradients that were not written into the bucket by the backward pass
+                for p in stage:
+                    view = self._view[id(p)]
+                    if p.grad is None:
+                        view.zero_()
+                        p.grad = view.view(p.shape)
+                    elif p.grad.data_ptr() != view.data_ptr():
+                        view.copy_(p.grad.reshape(-1))
+                        foreign.append((p, view))
+                if i == 0:
+                    flat[-2:].copy_(stats)
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)
                 if i == 0:
                     out_stats = flat[-2:].clone()
                     inv = 1.0 / (out_stats[1] + eps)
                 flat.mul_(inv)
-                off, dst, src = 0, [], []
-                for p in stage:
-                    k = p.numel()
-                    view = flat[off:off + k].reshape(p.shape)
-                    if p.grad is None:
-                        p.grad = view.clone()
-                    else:
-                        if self.comm is not None:
-                            p.grad.record_stream(self.comm)
-                        dst.append(p.grad)
-                        src.append(view)
-                    off += k
-                if dst:
-                    torch._foreach_copy_(dst, src)
+                for p, view in foreign:
+                    if self.comm is not None:
+                        p.grad.record_stream(self.comm)
+                    p.grad.copy_(view.view(p.shape))
         if self.comm is not None:
             main.wait_stream(self.comm)                 # the gradients are final for whatever the main stream does next
         return out_stats[0] * inv, out_stats[1]

@@ -45,7 +45,7 @@ class DCNMixScoreFunction(torch.autograd.Function):
     """params = U_0..U_{L-1}, V_0.., W_0.., bias_0.., gate_0.. (5*L tensors), as DCNMixFunction."""
 
     @staticmethod
-    def forward(ctx, x, head_w, head_b, L, act_inner, act_outer, events, *params):
+    def forward(ctx, x, head_w, head_b, L, act_inner, act_outer, events, grad_buffers, *params):
         x = _lib.f32c(x, 'inputs')
         hw = _lib.f32c(head_w, 'head kernel').reshape(-1)
         hb = _lib.f32c(head_b, 'head bias').reshape(-1) if head_b is not None else None
@@ -62,20 +62,26 @@ class DCNMixScoreFunction(torch.autograd.Function):
                   _host_ptr_array(bias), _host_ptr_array(gate), _lib.ptr(hw), _lib.ptr(hb), B, D, S, N, L, act_inner, act_outer,
                   _lib.ptr(scores), _lib.ptr(saved), saved.numel(), _lib.ptr(ws), ws.numel(), _lib.stream(), int(need_dx))
         ctx.save_for_backward(x, saved, hw, *ps)
-        ctx.meta = (B, D, S, N, L, act_inner, act_outer, need_dx, head_w.shape, None if head_b is None else head_b.shape, events)
+        ctx.meta = (B, D, S, N, L, act_inner, act_outer, need_dx, head_w.shape, None if head_b is None else head_b.shape, events,
+                    grad_buffers)
         return scores
 
     @staticmethod
     def backward(ctx, dscores):
         x, saved, hw, *ps = ctx.saved_tensors
-        B, D, S, N, L, act_inner, act_outer, need_dx, hw_shape, hb_shape, events = ctx.meta
+        B, D, S, N, L, act_inner, act_outer, need_dx, hw_shape, hb_shape, events, gbuf = ctx.meta
         U, V, W, bias, gate = (ps[i * L:(i + 1) * L] for i in range(5))
         ds = _lib.f32c(dscores, 'grad').reshape(-1)
         dx = torch.empty_like(x) if need_dx else None
-        grads = [torch.empty_like(p) for p in ps]
+        # gradient storage: fresh tensors, or the caller's buffers (dp.LayerwiseReducer hands out views of one flat bucket per
+        # layer, so the all-reduce runs in place: no packing before and no copy after the collective)
+        out = lambda i, like: (gbuf[i].view(like.shape) if gbuf is not None and gbuf[i] is not None else torch.empty_like(like))    # noqa: E731
+        grads = [out(2 + i, p) for i, p in enumerate(ps)]
         dU, dV, dW, dbias, dgate = (grads[i * L:(i + 1) * L] for i in range(5))
-        dhw = torch.empty(D, dtype=torch.float32, device=x.device)
-        dhb = torch.empty(1, dtype=torch.float32, device=x.device) if hb_shape is not None else None
+        dhw = out(0, hw)
+        dhb = None
+        if hb_shape is not None:
+            dhb = gbuf[1].view(1) if gbuf is not None and gbuf[1] is not None else torch.empty(1, dtype=torch.float32, device=x.device)
         lib = _lib.load()
         ws = _lib.workspace(lib.recnow_dcn_mix_workspace_bytes(B, D, S, N, L), x.device)
         ev = None
@@ -88,7 +94,7 @@ class DCNMixScoreFunction(torch.autograd.Function):
                   act_inner, act_outer, _lib.ptr(dx) if need_dx else None, _host_ptr_array(dU), _host_ptr_array(dV),
                   _host_ptr_array(dW), _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(dhw), _lib.ptr(dhb), _lib.ptr(ws),
                   ws.numel(), _lib.stream(), None, ev)
-        return (dx, dhw.reshape(hw_shape), None if dhb is None else dhb.reshape(hb_shape), None, None, None, None) + tuple(grads)
+        return (dx, dhw.view(hw_shape), None if dhb is None else dhb.view(hb_shape), None, None, None, None, None) + tuple(grads)
 
 
 def fused_route_available(cross, head, x):
@@ -105,8 +111,15 @@ def fused_route_available(cross, head, x):
     return bool(_lib.load().recnow_dcn_mix_score_supported(x.shape[0], D, S, N, cross.num_layer))
 
 
-def dcn_mix_score(cross, head, x, layer_events=None):
-    """scores (B,) = head(cross(x)).reshape(-1) for a DCNMixLayer `cross` and a MultiDenseLayer(1, 1) `head` (linear)."""
+def score_params(cross, head):
+    """The node's parameters in the order of its gradient buffers: head kernel, head bias, then U_0.., V_0.., W_0.., bias_0.., gate_0.."""
+    return ([head.kernel, head.bias] + list(cross.origin_to_sub_kernels) + list(cross.sub_to_sub_kernels)
+            + list(cross.sub_to_origin_kernels) + list(cross.biases) + [g.kernel for g in cross.gate_layers])
+
+
+def dcn_mix_score(cross, head, x, layer_events=None, grad_buffers=None):
+    """scores (B,) = head(cross(x)).reshape(-1) for a DCNMixLayer `cross` and a MultiDenseLayer(1, 1) `head` (linear).
+    grad_buffers: optional list aligned with `score_params(cross, head)` of preallocated gradient tensors (or None entries)."""
     if not (cross.built and head.built):
         return head(cross(x)).reshape(-1)            # builds both (Keras-style lazy build); the next call takes the fused route
     if not fused_route_available(cross, head, x):
@@ -114,4 +127,4 @@ def dcn_mix_score(cross, head, x, layer_events=None):
     params = (list(cross.origin_to_sub_kernels) + list(cross.sub_to_sub_kernels) + list(cross.sub_to_origin_kernels)
               + list(cross.biases) + [g.kernel for g in cross.gate_layers])
     return DCNMixScoreFunction.apply(x, head.kernel, head.bias, cross.num_layer, cross._act_inner, cross._act_outer, layer_events,
-                                     *params)
+                                     grad_buffers, *params)
