@@ -281,6 +281,7 @@ def main():
         if layerwise is not None:
             # backward on the unnormalised local sum; each layer's bucket is all-reduced behind its event while the layers below
             # are still in their backward pass; (loss sum, P) ride in the first bucket
+            layerwise.prepare(local_sum, n_pair)
             local_sum.backward()
             loss_val, _ = layerwise.reduce(local_sum, n_pair)
         elif use_dist:

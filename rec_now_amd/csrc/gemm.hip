@@ -154,6 +154,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     if (d->eu_r > 0 && (!d->eu_p || !d->eu_q || d->batch != 1)) return RECNOW_EINVAL;
     pick_split(d, c, &k.splitk, &k.kchunk);
     k.trace = nullptr;
+    k.cu_slots = nullptr; k.stagger_ticks = 0;
     k.C2 = d->C2; k.E2 = d->E2; k.ldc2 = d->ldc2; k.lde2 = d->lde2;
     k.as_in = d->as_in; k.as_out = d->as_out;
     if ((d->as_in != nullptr) != (d->as_out != nullptr)) return RECNOW_EINVAL;

@@ -16,6 +16,7 @@
 #define SK_BM 128
 #define SK_BN 128
 #define SK_BK 16
+#define SK_STAGGER_US_DEFAULT 0      // phase stagger of the co-resident workgroups of a CU (see the kernel); 0 = off
 
 // EP: bit 0 = C *= emul, bit 1 = C += C_old.   DUAL: 0 none, 1: C2 = acc, 2: C2 += acc * E2,
 // 3 (scoring head folded into the last cross layer): C2 = acc, C = acc * emul is NOT stored, its row-dot with hv leaves as
@@ -74,6 +75,24 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     tb.init(p.ldb);
     int slot = blockIdx.x;
     if (slot >= ntiles) return;
+    // Phase stagger.  The co-resident workgroups of a CU run identical work, so without it they move in lockstep: all of them in
+    // the k-loop (sharing the MFMA pipe), then all of them in the epilogue (the pipe idle, HBM hit by every CU at once).  Each
+    // workgroup takes an arrival number on its CU (XCC id + SE/SH/CU id of HW_ID) and starts that many delay units late; the
+    // counter is given back at exit, so the buffer stays zero between launches.  Every wave leaves the bounded wait loop.
+    int cu_key = -1;
+    if (p.cu_slots != nullptr && p.stagger_ticks > 0) {
+        __shared__ int s_arrival;
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));        // HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));       // XCC_ID
+            cu_key = (int)(((xcc & 15u) << 8) | ((hw >> 8) & 255u));                                 // CU_ID[11:8], SH_ID[12], SE_ID[15:13]
+            s_arrival = atomicAdd(&p.cu_slots[cu_key], 1);
+        }
+        __syncthreads();
+        const int arrival = s_arrival & 7;
+        const long long t0 = wall_clock64(), wait = (long long)arrival * p.stagger_ticks;
+        while (wall_clock64() - t0 < wait && wall_clock64() - t0 < 20000) __builtin_amdgcn_s_sleep(16);     // <= 200 us, always ends
+    }
     int m0, n0;
     tile_of(slot, m0, n0);
     ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0, 0);
@@ -248,6 +267,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
         m0 = m0n;
         n0 = n0n;
     }
+    if (cu_key >= 0) atomicSub(&p.cu_slots[cu_key], 1);          // thread 0 only (cu_key stays -1 elsewhere)
 }
 
 template <bool B_KC, int EP, int DUAL, bool PRE = false>
@@ -259,7 +279,21 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
     const int resident = 256 * sk_wg_per_cu(EP, DUAL, PRE);
     int grid = rt * ct < resident ? rt * ct : resident;
     const int xcd = (rt % 8 == 0 && grid % 8 == 0) ? 1 : 0;
-    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL, PRE>), grid, GEMM_THREADS, lds, st, k, rt, ct, xcd);
+    GemmK kk = k;
+    // stagger unit (microseconds, RECNOW_SK_STAGGER_US; 0 = off) and the per-CU arrival counters (allocated once, zero between launches)
+    static const int stagger_us = []() { const char* e = getenv("RECNOW_SK_STAGGER_US"); return e ? atoi(e) : SK_STAGGER_US_DEFAULT; }();
+    static int* cu_slots = nullptr;
+    kk.cu_slots = nullptr;
+    kk.stagger_ticks = 0;
+    if (stagger_us > 0 && grid >= 512) {
+        if (!cu_slots) {
+            if (hipMalloc((void**)&cu_slots, 4096 * sizeof(int)) != hipSuccess) return RECNOW_EINVAL;
+            RN_HIP(hipMemset(cu_slots, 0, 4096 * sizeof(int)));
+        }
+        kk.cu_slots = cu_slots;
+        kk.stagger_ticks = stagger_us * 100;
+    }
+    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL, PRE>), grid, GEMM_THREADS, lds, st, kk, rt, ct, xcd);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

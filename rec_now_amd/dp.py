@@ -182,10 +182,23 @@ class LayerwiseReducer(object):
         """The slice of its stage's flat bucket that holds `param`'s gradient (1-D view), or None for a foreign parameter."""
         return self._view.get(id(param))
 
+    def prepare(self, local_loss_sum, local_count):
+        """Call BEFORE `local_loss_sum.backward()`: packs the two loss statistics on the current stream and marks that point, so
+        that `reduce` has nothing to wait for on the main stream but the per-stage events (waiting for the main stream itself
+        would wait for the whole backward pass, i.e. no overlap)."""
+        self._stats = torch.stack([local_loss_sum.detach().to(torch.float32), local_count.detach().to(torch.float32)])
+        self._stats_ready = None
+        if self.comm is not None:
+            self._stats_ready = torch.cuda.Event()
+            self._stats_ready.record(torch.cuda.current_stream())
+
     def reduce(self, local_loss_sum, local_count, eps=SMALL_POSIVITE_FLOAT):
         import contextlib
         main = torch.cuda.current_stream() if self.comm is not None else None
-        stats = torch.stack([local_loss_sum.detach().to(torch.float32), local_count.detach().to(torch.float32)])
+        prepared = getattr(self, '_stats', None) is not None
+        stats = self._stats if prepared else torch.stack([local_loss_sum.detach().to(torch.float32), local_count.detach().to(torch.float32)])
+        stats_ready = self._stats_ready if prepared else None
+        self._stats = None
         if not is_dist():
             inv = 1.0 / (stats[1] + eps)
             grads = [p.grad for stage in self.stages for p in stage if p.grad is not None]
@@ -193,7 +206,10 @@ class LayerwiseReducer(object):
                 torch._foreach_mul_(grads, inv)
             return stats[0] * inv, stats[1]
         if self.comm is not None:
-            self.comm.wait_stream(main)                 # the statistics (and, without events, everything) are ordered before the side stream
+            if stats_ready is not None and all(e is not None for e in self.events):
+                self.comm.wait_event(stats_ready)       # only the statistics; the gradients are ordered by the per-stage events
+            else:
+                self.comm.wait_stream(main)             # no events / no prepare(): everything enqueued so far, i.e. after the backward pass
         out_stats = None
         inv = None
         with (torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()):
