@@ -119,6 +119,16 @@ int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, const uint8
                            float power, int reduce_mean, float* loss, float* dscores, void* ws, size_t ws_bytes,
                            void* stream);
 
+/* The same loss for a SMALL batch in one launch (BASELINE config 2: pairwise_loss_from_batch at B = 8192): grouping of ONE
+ * float32 / int32 group tensor (key_dtype RECNOW_KEY_F32 / RECNOW_KEY_I32), pair counts, loss and d loss / d scores by a single
+ * 1024-thread workgroup on LDS-resident data, B <= 8192 (recnow_pairwise_small_supported).  Same predicates, pair set, occurrence
+ * weights and normalisation as recnow_group_keys + recnow_group_segments + recnow_pair_count + recnow_pair_bpr_fwdbwd; no
+ * workspace.  n_pair: [1] int64. */
+int recnow_pairwise_small_supported(int64_t B, int key_dtype);
+int recnow_pairwise_small_fwdbwd(const void* groups, int key_dtype, const float* labels, const float* scores, const uint8_t* mask,
+                                 int64_t B, int flags, float factor, float power, int reduce_mean, float* loss, float* dscores,
+                                 int64_t* n_pair, void* stream);
+
 /* bpr_loss_func on explicit (P,) vectors (pairwise_loss_from_batch.py:96-127).  weights may be NULL.
  * dpos = d loss/d outputs_pos, dneg = -dpos.  P may be 0 (loss = 0). */
 int recnow_bpr_loss_fwdbwd(const float* pos, const float* neg, const float* weights, int64_t P, float factor,

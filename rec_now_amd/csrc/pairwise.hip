@@ -8,6 +8,7 @@
 // same time (wave-uniform broadcast loads served by L1), work is sum_g n_g^2 candidate compares.
 #include "common.hpp"
 #include "scan.hpp"
+#include "group_small.hpp"
 
 struct __attribute__((aligned(16))) Member {   // one sorted row
     float label;
@@ -336,6 +337,218 @@ __global__ void k_occ_weight(const int32_t* __restrict__ order, const int32_t* _
     w[order[k]] = (power == 1.f) ? c : powf(c, power);
 }
 
+
+// ---- small batches: the WHOLE loss in one launch ----------------------------------------------------------------------
+// B <= 8192 rows with one float32 / int32 group tensor (BASELINE config 2: pairwise_loss_from_batch at B = 8192, ~128 user groups).
+// The general path is a chain of eight launches of a few microseconds each (keys, grouping, pack, two counting kernels, two
+// loss kernels, finalize) whose wall time is launch latency.  Here ONE 1024-thread workgroup does all of it on LDS-resident data:
+//   canonical keys -> stable LSD radix sort (group_small.hpp) -> segment bounds per sorted row -> members (label, score, valid)
+//   -> pair counts per group (LDS integer atomics) -> P -> BPR terms per row -> loss (double, fixed order) and d loss / d scores.
+// A thread owns 8 consecutive sorted rows and walks each row's segment; rows of segments longer than PS_LONG are walked by a whole
+// wave instead (lanes stride over the members, fixed butterfly sums), so one huge group does not serialise on a few threads.
+// Same predicates, order-independent integer counts and per-row sums as the general kernels above: bitwise reproducible.
+#define PS_LONG 256
+template <int FLAGS>
+__global__ void __launch_bounds__(GS_T)
+k_pairwise_small(const void* __restrict__ groups, int key_dtype, const float* __restrict__ labels, const float* __restrict__ scores,
+                 const uint8_t* __restrict__ mask, int B, float factor, float power, int reduce_mean, float* __restrict__ loss_out,
+                 float* __restrict__ dscores, long long* __restrict__ n_pair_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gs_lds[];
+    uint32_t* key0 = reinterpret_cast<uint32_t*>(gs_lds);
+    uint32_t* key1 = key0 + GS_MAXB;
+    uint16_t* idx0 = reinterpret_cast<uint16_t*>(key1 + GS_MAXB);
+    uint16_t* idx1 = idx0 + GS_MAXB;
+    uint16_t* cnt = idx1 + GS_MAXB;                                   // [16][GS_T] u16 = 32 KB
+    unsigned* wsum = reinterpret_cast<unsigned*>(cnt + 16 * GS_T);    // 34 words
+    __shared__ double dred[16];
+    __shared__ long long lred[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned SOLO = 0x80000000u;                                // marks NaN / inf ids in the index word (B <= 8192 < 2^15)
+    unsigned vor = 0, vand = 0xffffffffu;
+    // canonical keys (recnow_group_keys): -0.0 == +0.0; NaN and +-inf equal nothing, themselves included
+    uint8_t* solo = reinterpret_cast<uint8_t*>(wsum + 34);            // [B] flags by ORIGINAL row (dead once the heads are known)
+    for (int i = tid; i < B; i += GS_T) {
+        uint32_t k;
+        bool so = false;
+        if (key_dtype == RECNOW_KEY_F32) {
+            const float v = reinterpret_cast<const float*>(groups)[i];
+            k = __float_as_uint(v);
+            if (v == 0.0f) k = 0u;
+            so = !(fabsf(v) < INFINITY);
+        } else {
+            k = (uint32_t)reinterpret_cast<const int32_t*>(groups)[i];
+        }
+        key0[i] = k;
+        idx0[i] = (uint16_t)i;
+        solo[i] = so ? 1 : 0;
+        vor |= k;
+        vand &= k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vor |= __shfl_xor(vor, o, 64);
+        vand &= __shfl_xor(vand, o, 64);
+    }
+    if (lane == 0) { wsum[wv] = vor; wsum[16 + wv] = vand; }
+    __syncthreads();
+    vor = 0; vand = 0xffffffffu;
+    for (int i = 0; i < 16; ++i) { vor |= wsum[i]; vand &= wsum[16 + i]; }
+    const unsigned varying = vor ^ vand;
+    __syncthreads();
+    uint32_t* ka = key0; uint32_t* kb = key1;
+    uint16_t* ia = idx0; uint16_t* ib = idx1;
+    gs_radix_sort_lds(ka, kb, ia, ib, cnt, wsum, B, varying);
+    const int lo = tid * GS_KPT, hi = min(B, lo + GS_KPT);
+    // segment bounds of every sorted row: begin = last head at or before it, end = first head after it
+    unsigned heads = 0;
+    int last_head = -1;
+    for (int i = lo; i < hi; ++i) {
+        bool h = true;
+        if (i > 0) h = (ka[i] != ka[i - 1]) || solo[ia[i]] || solo[ia[i - 1]];
+        if (h) { heads |= 1u << (i - lo); last_head = i; }
+    }
+    __syncthreads();                                                  // every thread has read the keys / solo flags it needs
+    // inclusive max-scan of last_head over threads (carry-in for rows before this thread's first head)
+    int inc = last_head;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc = max(inc, t);
+    }
+    int* iw = reinterpret_cast<int*>(wsum);
+    if (lane == 63) iw[wv] = inc;
+    __syncthreads();
+    int carry = -1;
+    for (int i = 0; i < wv; ++i) carry = max(carry, iw[i]);
+    const int prev_incl = __shfl_up(inc, 1, 64);
+    int begin_carry = max(carry, lane > 0 ? prev_incl : -1);         // last head strictly before this thread's rows
+    __syncthreads();
+    // first head at or after the thread's LAST row + 1, i.e. exclusive min-scan from the right of "first head of thread"
+    int first_head = B;
+    for (int i = hi - 1; i >= lo; --i)
+        if ((heads >> (i - lo)) & 1u) first_head = i;
+    int dec = first_head;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_down(dec, o, 64);
+        if (lane + o < 64) dec = min(dec, t);
+    }
+    if (lane == 0) iw[wv] = dec;
+    __syncthreads();
+    int rcarry = B;
+    for (int i = 15; i > wv; --i) rcarry = min(rcarry, iw[i]);
+    const int next_incl = __shfl_down(dec, 1, 64);
+    const int end_carry = min(rcarry, lane < 63 ? next_incl : B);    // first head strictly after this thread's rows
+    __syncthreads();
+    // members in sorted order.  Everything of the sort is dead after the barrier below (the values live in registers across it),
+    // so the arena is laid out afresh: labels, scores, segment bounds, (valid, row), pairs per segment = 144 KB
+    float* lab = reinterpret_cast<float*>(gs_lds);
+    float* sc = lab + GS_MAXB;
+    uint16_t* sbeg = reinterpret_cast<uint16_t*>(sc + GS_MAXB);
+    uint16_t* send = sbeg + GS_MAXB;
+    uint16_t* vrow = send + GS_MAXB;                                  // valid flag << 15 | original row
+    unsigned* gcount = reinterpret_cast<unsigned*>(vrow + GS_MAXB);   // [GS_MAXB] pairs per segment, indexed by the segment's first row
+    {
+        int bcur = begin_carry;
+        uint16_t bb[GS_KPT], ee[GS_KPT];
+        for (int i = lo; i < hi; ++i) {
+            if ((heads >> (i - lo)) & 1u) bcur = i;
+            bb[i - lo] = (uint16_t)bcur;
+        }
+        int ecur = end_carry;
+        for (int i = hi - 1; i >= lo; --i) {
+            ee[i - lo] = (uint16_t)ecur;
+            if ((heads >> (i - lo)) & 1u) ecur = i;
+        }
+        float l8[GS_KPT], s8[GS_KPT];
+        uint16_t v8[GS_KPT];
+        for (int i = lo; i < hi; ++i) {
+            const int row = ia[i];
+            l8[i - lo] = labels[row];
+            s8[i - lo] = scores[row];
+            v8[i - lo] = (uint16_t)(row | ((mask ? (mask[row] != 0) : 1) ? 0x8000 : 0));
+        }
+        __syncthreads();                                              // the sort's buffers are dead for everybody
+        for (int i = lo; i < hi; ++i) {
+            sbeg[i] = bb[i - lo]; send[i] = ee[i - lo];
+            lab[i] = l8[i - lo]; sc[i] = s8[i - lo]; vrow[i] = v8[i - lo];
+        }
+    }
+    for (int i = tid; i < B; i += GS_T) gcount[i] = 0u;
+    __syncthreads();
+    auto member = [&](int j) {
+        Member m;
+        const unsigned v = vrow[j];
+        m.label = lab[j]; m.score = sc[j]; m.row = (int)(v & 0x7fffu); m.valid = (int)(v >> 15);
+        return m;
+    };
+    // ---- pass 1: pairs per segment ---------------------------------------------------------------------------------
+    for (int i = wv; i < B; i += 16) {                                // long segments: a wave per row
+        const int s = sbeg[i], e = send[i];
+        if (e - s <= PS_LONG) continue;                               // wave-uniform
+        const Member me = member(i);
+        int cc = 0;
+        for (int j = s + lane; j < e; j += 64) cc += (j != i && pair_ok<FLAGS>(me, member(j))) ? 1 : 0;
+        cc = wave_sum(cc);
+        if (lane == 0 && cc) atomicAdd(&gcount[s], (unsigned)cc);
+    }
+    for (int i = lo; i < hi; ++i) {
+        const int s = sbeg[i], e = send[i];
+        if (e - s > PS_LONG) continue;
+        const Member me = member(i);
+        int cc = 0;
+        for (int j = s; j < e; ++j) cc += (j != i && pair_ok<FLAGS>(me, member(j))) ? 1 : 0;
+        if (cc) atomicAdd(&gcount[s], (unsigned)cc);                  // integer atomics in LDS: order-independent
+    }
+    __syncthreads();
+    long long pl = 0;
+    for (int i = tid; i < B; i += GS_T) pl += gcount[i];
+    const long long P = block_sum<long long>(pl, lred);
+    const float denom = reduce_mean ? ((float)P + 1.0e-10f) : 1.f;
+    // ---- pass 2: BPR terms ----------------------------------------------------------------------------------------------
+    auto weight = [&](int s) {
+        if (power == 0.f) return 1.f;
+        const float c = (float)gcount[s];
+        return (c == 0.f) ? 1.f : ((power == 1.f) ? c : powf(c, power));
+    };
+    double lsum = 0.0;
+    for (int i = wv; i < B; i += 16) {
+        const int s = sbeg[i], e = send[i];
+        if (e - s <= PS_LONG) continue;
+        const Member me = member(i);
+        float la = 0.f, ga = 0.f;
+        for (int j = s + lane; j < e; j += 64) bpr_term<FLAGS>(me, member(j), j != i, factor, la, ga);
+        la = wave_sum(la);
+        ga = wave_sum(ga);
+        if (lane == 0) {
+            const float w = weight(s);
+            dscores[me.row] = w * factor * ga / denom;
+            lsum += (double)(w * la);
+        }
+    }
+    for (int i = lo; i < hi; ++i) {
+        const int s = sbeg[i], e = send[i];
+        if (e - s > PS_LONG) continue;
+        const Member me = member(i);
+        float la = 0.f, ga = 0.f;
+        for (int j = s; j < e; ++j) bpr_term<FLAGS>(me, member(j), j != i, factor, la, ga);
+        const float w = weight(s);
+        dscores[me.row] = w * factor * ga / denom;
+        lsum += (double)(w * la);
+    }
+    lsum = block_sum<double>(lsum, dred);
+    if (tid == 0) {
+        float v = (float)lsum;
+        if (reduce_mean) v = v / ((float)P + 1.0e-10f);
+        *loss_out = v;
+        *n_pair_out = P;
+    }
+}
+static inline size_t ps_lds_bytes() {          // max(sort arena + solo flags, members arena)
+    const size_t a = gs_lds_bytes() + GS_MAXB, b = (size_t)GS_MAXB * (4 + 4 + 2 + 2 + 2 + 4);
+    return a > b ? a : b;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 #define RN_PW_T 256
 #define RN_VEC_BLOCKS 1024
@@ -515,6 +728,43 @@ extern "C" int recnow_occurance_power_weight(const int32_t* order, const int32_t
     if (B == 0) return RECNOW_OK;
     if (!order || !seg_id || !seg_first || !w_out) return RECNOW_EINVAL;
     hipLaunchKernelGGL(k_occ_weight, rn_cdiv(B, 256), 256, 0, (hipStream_t)stream, order, seg_id, seg_first, B, power, w_out);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+
+// The whole BPR pairwise loss of a small batch (B <= 8192, ONE float32 or int32 group tensor) in one launch:
+// grouping, pair counts, loss and d loss / d scores.  Same results as recnow_group_keys + recnow_group_segments +
+// recnow_pair_count + recnow_pair_bpr_fwdbwd on the same inputs.
+extern "C" int recnow_pairwise_small_supported(int64_t B, int key_dtype) {
+    return (B >= 0 && B <= GS_MAXB && (key_dtype == RECNOW_KEY_F32 || key_dtype == RECNOW_KEY_I32)) ? 1 : 0;
+}
+extern "C" int recnow_pairwise_small_fwdbwd(const void* groups, int key_dtype, const float* labels, const float* scores,
+                                            const uint8_t* mask, int64_t B, int flags, float factor, float power, int reduce_mean,
+                                            float* loss, float* dscores, int64_t* n_pair, void* stream) {
+    if (B < 0 || !loss || !n_pair) return RECNOW_EINVAL;
+    if (!recnow_pairwise_small_supported(B, key_dtype)) return RECNOW_EUNSUPPORTED;
+    if ((flags & (RECNOW_PAIR_LABEL_GT | RECNOW_PAIR_WRONG_ORDER)) == 0) return RECNOW_EINVAL;      // see recnow_pair_bpr_fwdbwd
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        RN_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+        RN_HIP(hipMemsetAsync(n_pair, 0, sizeof(int64_t), st));
+        return RECNOW_OK;
+    }
+    if (!groups || !labels || !scores || !dscores) return RECNOW_EINVAL;
+    const size_t lds = ps_lds_bytes();
+#define PS_LAUNCH(F)                                                                                                              \
+    do {                                                                                                                          \
+        RN_HIP(hipFuncSetAttribute((const void*)k_pairwise_small<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(k_pairwise_small<F>, 1, GS_T, lds, st, groups, key_dtype, labels, scores, mask, (int)B, factor, power, \
+                           reduce_mean, loss, dscores, (long long*)n_pair);                                                      \
+    } while (0)
+    switch (flags & 3) {
+        case 1: PS_LAUNCH(1); break;
+        case 2: PS_LAUNCH(2); break;
+        default: PS_LAUNCH(3); break;
+    }
+#undef PS_LAUNCH
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

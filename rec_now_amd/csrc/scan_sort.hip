@@ -7,6 +7,7 @@
 // LDS-resident counters, not MFMA.
 #include "common.hpp"
 #include "scan.hpp"
+#include "group_small.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // keys
@@ -334,32 +335,6 @@ __global__ void k_seg_empty(int32_t* seg_first, int32_t* n_seg) {
 //   4-bit digits: a thread's 16 digit counters (each <= 8) pack into one 64-bit register; passes whose digit is constant
 //   over the batch are skipped (OR/AND of all keys); counters [16][1024] u16 are scanned block-wide in digit-major order.
 // ------------------------------------------------------------------------------------------------
-#define GS_T 1024
-#define GS_KPT 8
-#define GS_MAXB (GS_T * GS_KPT)
-
-__device__ __forceinline__ unsigned gs_block_exclusive_scan(unsigned v, unsigned* wsum /* [16] */, unsigned* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    __syncthreads();
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    unsigned off = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const unsigned x = wsum[i];
-        if (i < w) off += x;
-        tot += x;
-    }
-    if (total) *total = tot;
-    return off + inc - v;
-}
-
 __global__ void __launch_bounds__(GS_T)
 k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int B, int32_t* __restrict__ order,
               int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
@@ -393,36 +368,7 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
     uint32_t* ka = key0; uint32_t* kb = key1;
     uint16_t* ia = idx0; uint16_t* ib = idx1;
     const int lo = tid * GS_KPT, hi = min(B, lo + GS_KPT);
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 4 * pass;
-        if (((varying >> shift) & 15u) == 0) continue;    // block-uniform: this digit is the same for every key
-        unsigned long long c64 = 0;
-        for (int i = lo; i < hi; ++i) c64 += 1ull << (4 * ((ka[i] >> shift) & 15u));
-#pragma unroll
-        for (int d = 0; d < 16; ++d) cnt[d * GS_T + tid] = (uint16_t)((c64 >> (4 * d)) & 15u);
-        __syncthreads();
-        // exclusive scan of the flattened [digit][thread] counters: thread t owns entries [16t, 16t + 16)
-        unsigned loc[16], sum = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { loc[j] = cnt[tid * 16 + j]; sum += loc[j]; }
-        unsigned run = gs_block_exclusive_scan(sum, wsum, nullptr);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { cnt[tid * 16 + j] = (uint16_t)run; run += loc[j]; }
-        __syncthreads();
-        unsigned long long r64 = 0;                       // running per-digit rank inside this thread's chunk
-        for (int i = lo; i < hi; ++i) {
-            const uint32_t k = ka[i];
-            const unsigned d = (k >> shift) & 15u;
-            const unsigned dst = cnt[d * GS_T + tid] + (unsigned)((r64 >> (4 * d)) & 15u);
-            r64 += 1ull << (4 * d);
-            kb[dst] = k;
-            ib[dst] = ia[i];
-        }
-        __syncthreads();
-        uint32_t* tk = ka; ka = kb; kb = tk;
-        uint16_t* ti = ia; ia = ib; ib = ti;
-    }
+    gs_radix_sort_lds(ka, kb, ia, ib, cnt, wsum, B, varying);
     // segment heads over the sorted order; solo rows (NaN / inf ids) are segments of their own
     unsigned heads = 0, nh = 0;
     for (int i = lo; i < hi; ++i) {
@@ -446,7 +392,6 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
         n_seg[1] = (int32_t)total;
     }
 }
-static inline size_t gs_lds_bytes() { return (size_t)GS_MAXB * (4 + 4 + 2 + 2) + (size_t)16 * GS_T * 2 + 34 * sizeof(unsigned); }
 
 extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) {
     if (B < 0 || n_words < 1 || n_words > RN_MAX_WORDS) return 0;

@@ -16,7 +16,7 @@ Two execution paths:
 import torch
 
 from .. import _lib
-from ._segments import build_segments
+from ._segments import _as_key_tensor, build_segments
 
 SMALL_POSIVITE_FLOAT = 1.0E-10   # reference :13 (spelling kept)
 
@@ -172,6 +172,51 @@ class _PairBprFused(torch.autograd.Function):
         return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None
 
 
+class _PairBprSmall(torch.autograd.Function):
+    """B <= 8192 rows, one float32 / int32 group tensor: grouping, pair counts, loss and gradient in ONE launch
+    (recnow_pairwise_small_fwdbwd) instead of the chain of eight few-microsecond launches of the general route."""
+
+    @staticmethod
+    def forward(ctx, outputs, labels, mask, gkey, gdt, flags, factor, power, reduce_mean):
+        B = gkey.numel()
+        scores = _flat_f32(outputs, B, 'outputs')
+        labs = _flat_f32(labels, B, 'labels')
+        m = _flat_mask(mask, B)
+        dev = gkey.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dscores = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
+        n_pair = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.call('recnow_pairwise_small_fwdbwd', _lib.ptr(gkey), gdt, _lib.ptr(labs), _lib.ptr(scores), _lib.ptr(m), B, flags,
+                  float(factor), float(power), 1 if reduce_mean else 0, _lib.ptr(loss), _lib.ptr(dscores), _lib.ptr(n_pair), _lib.stream())
+        ctx.save_for_backward(dscores[:B])
+        ctx.shape = outputs.shape
+        n_pair_f = n_pair.to(torch.float32).reshape(())
+        ctx.mark_non_differentiable(n_pair_f)
+        return loss, n_pair_f
+
+    @staticmethod
+    def backward(ctx, g, _g_np):
+        (dscores,) = ctx.saved_tensors
+        return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None, None
+
+
+def _small_route(groups):
+    """(key tensor, dtype code) when the single-launch route applies: one group tensor of B <= 8192 float / int32-able ids."""
+    if isinstance(groups, (list, tuple)):
+        if len(groups) != 1:
+            return None
+        groups = groups[0]
+    if not isinstance(groups, torch.Tensor) or not groups.is_cuda or groups.dtype in (torch.float64, torch.int64):
+        return None
+    try:
+        key, dt = _as_key_tensor(groups)
+    except TypeError:
+        return None
+    if not _lib.load().recnow_pairwise_small_supported(key.numel(), dt):
+        return None
+    return key, dt
+
+
 def group_rows(groups):
     """The score-independent half of the loss: canonical keys -> radix sort -> segments of `groups` (tensor or list of
     tensors, as `pairwise_loss` takes them).  The result can be handed to `pairwise_loss_fused(..., segments=...)`, so a
@@ -184,8 +229,12 @@ def pairwise_loss_fused(outputs, labels, groups, only_use_wrong_order_pair=False
     """Fused BPR pairwise loss; returns (loss, n_pair) as 0-dim tensors, no host sync.  `pairwise_loss` routes here
     whenever the defaults make it possible; exposed because it also accepts `factor` / `reduce_mean` and a precomputed
     `segments=group_rows(groups)` (then `groups` is not looked at again)."""
-    seg = segments if segments is not None else build_segments(groups)
     flags = _FLAG_LABEL_GT | (_FLAG_WRONG_ORDER if only_use_wrong_order_pair else 0)
+    if segments is None:
+        small = _small_route(groups)
+        if small is not None:
+            return _PairBprSmall.apply(outputs, labels, mask, small[0], small[1], flags, factor, click_occurance_power, reduce_mean)
+    seg = segments if segments is not None else build_segments(groups)
     return _PairBprFused.apply(outputs, labels, mask, seg, flags, factor, click_occurance_power, reduce_mean)
 
 

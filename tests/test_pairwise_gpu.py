@@ -363,3 +363,79 @@ def test_groups_beyond_the_lds_staging_size(dev, seed):
         pos, neg = M.pair_indices(sd.detach(), yd, gd, mask=md)
         cpos, cneg = C.pair_indices(g, y, s, m)
         assert np.array_equal(pos.cpu().numpy(), cpos) and np.array_equal(neg.cpu().numpy(), cneg)
+
+
+# ---- the single-launch route for small batches (recnow_pairwise_small_fwdbwd) -----------------------------------------------
+def _zipf_groups(rng, B, cap):
+    sizes = []
+    while sum(sizes) < B:
+        sizes.append(int(min(cap, rng.zipf(1.3))))
+    g = np.repeat(np.arange(len(sizes)), sizes)[:B]
+    return rng.permutation(g).astype(np.float32)
+
+
+@pytest.mark.parametrize('B,kind,seed', [(8192, 'uniform128', 0), (8192, 'zipf2048', 1), (8192, 'one_group', 2), (8192, 'singletons', 3),
+                                          (5000, 'special_ids', 4), (1, 'uniform128', 5), (777, 'two_groups', 6), (8191, 'zipf300', 7)])
+@pytest.mark.parametrize('wrong,power,use_mask', [(False, 0.0, False), (True, -0.5, True), (False, 1.0, True)])
+def test_small_route_equals_general_route_and_c_oracle(dev, B, kind, seed, wrong, power, use_mask):
+    """One launch (B <= 8192, one group tensor) against (a) the general multi-launch route on the same inputs (segments handed
+    in explicitly), (b) the plain-C restatement of the reference formulation (oracle/pairs_oracle.c)."""
+    import pairs_oracle as PO
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import _small_route, group_rows, pairwise_loss_fused
+    rng = np.random.default_rng(100 + seed)
+    if kind == 'uniform128':
+        g = rng.integers(0, 128, B).astype(np.float32)
+    elif kind.startswith('zipf'):
+        g = _zipf_groups(rng, B, int(kind[4:]))
+    elif kind == 'one_group':
+        g = np.full(B, 3.0, np.float32)
+    elif kind == 'singletons':
+        g = rng.permutation(B).astype(np.float32)
+    elif kind == 'two_groups':
+        g = (rng.random(B) < 0.9).astype(np.float32)
+    else:       # NaN / inf ids pair with nobody; -0.0 and +0.0 are one group; negative and fractional ids
+        g = rng.choice(np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, -1.5, 2.25, 1e30, -7.0], np.float32), B)
+    y = rng.integers(0, 3, B).astype(np.float32)
+    s = rng.normal(size=B).astype(np.float32)
+    m = (rng.random(B) < 0.85) if use_mask else None
+    gd, yd = torch.from_numpy(g).to(dev), torch.from_numpy(y).to(dev)
+    md = None if m is None else torch.from_numpy(m).to(dev)
+    assert _small_route(gd) is not None
+    outs = []
+    for route in ('small', 'general'):
+        sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+        seg = group_rows(gd) if route == 'general' else None
+        loss, n_pair = pairwise_loss_fused(sd, yd, gd, only_use_wrong_order_pair=wrong, click_occurance_power=power, mask=md,
+                                           factor=1.3, segments=seg)
+        loss.backward()
+        outs.append((float(loss), int(n_pair.item()), sd.grad.cpu().numpy()))
+    (l1, p1, d1), (l2, p2, d2) = outs
+    assert p1 == p2
+    assert abs(l1 - l2) <= 2e-6 * max(1.0, abs(l2))
+    assert np.abs(d1 - d2).max() <= 2e-6 * max(np.abs(d2).max(), 1e-30)
+    flags = 1 | (2 if wrong else 0)
+    rl, rd, rp = PO.pairwise_bpr(g, y, s, None if m is None else m.astype(np.uint8), flags, 1.3, power)
+    assert p1 == rp
+    assert abs(l1 - rl) <= 1e-5 * max(1.0, abs(rl))
+    assert np.abs(d1 - rd).max() <= 1e-5 * max(np.abs(rd).max(), 1e-30)
+
+
+def test_small_route_int_ids_determinism_and_routing(dev):
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import _small_route, pairwise_loss
+    rng = np.random.default_rng(9)
+    B = 6000
+    gi = torch.from_numpy(rng.integers(-5, 60, B).astype(np.int32)).to(dev)
+    y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).to(dev)
+    s0 = rng.normal(size=B).astype(np.float32)
+    res = []
+    for g in (gi, gi.to(torch.float32), gi.to(torch.int16)):
+        assert _small_route(g) is not None
+        sd = torch.from_numpy(s0).to(dev).requires_grad_(True)
+        loss = pairwise_loss(sd, y, g)
+        loss.backward()
+        res.append((loss.detach().clone(), sd.grad.clone()))
+    for l, d in res[1:]:
+        assert torch.equal(l, res[0][0]) and torch.equal(d, res[0][1])            # same groups whatever the id dtype; bitwise reproducible
+    # not this route: two group tensors, 64-bit ids, more than 8192 rows
+    assert _small_route([gi, gi]) is None and _small_route(gi.to(torch.int64)) is None
+    assert _small_route(torch.zeros(8193, device=dev)) is None
