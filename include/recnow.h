@@ -46,7 +46,7 @@ extern "C" {
 /* pair predicate flags */
 #define RECNOW_PAIR_LABEL_GT 1    /* keep (i,j) only if label_i > label_j   (pairwise_loss_from_batch.py:189)     */
 #define RECNOW_PAIR_WRONG_ORDER 2 /* keep (i,j) only if score_i < score_j   (pairwise_loss_from_batch.py:197-203) */
-#define RECNOW_PAIR_MEMBERS_PACKED 256 /* recnow_pair_bpr_fwdbwd only: the workspace is the one recnow_pair_count just
+#define RECNOW_PAIR_MEMBERS_PACKED 256 /* recnow_pair_bpr_fwdbwd (and recnow_pair_count after recnow_group_pack_small): the workspace is the one recnow_pair_count just
                                           used with the same scores / labels / mask / order -- its packed rows are reused */
 
 int recnow_abi_version(void);
@@ -119,15 +119,16 @@ int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, const uint8
                            float power, int reduce_mean, float* loss, float* dscores, void* ws, size_t ws_bytes,
                            void* stream);
 
-/* The same loss for a SMALL batch in one launch (BASELINE config 2: pairwise_loss_from_batch at B = 8192): grouping of ONE
- * float32 / int32 group tensor (key_dtype RECNOW_KEY_F32 / RECNOW_KEY_I32), pair counts, loss and d loss / d scores by a single
- * 1024-thread workgroup on LDS-resident data, B <= 8192 (recnow_pairwise_small_supported).  Same predicates, pair set, occurrence
- * weights and normalisation as recnow_group_keys + recnow_group_segments + recnow_pair_count + recnow_pair_bpr_fwdbwd; no
- * workspace.  n_pair: [1] int64. */
+/* Front end of the loss for a SMALL batch in one launch (BASELINE config 2: pairwise_loss_from_batch at B = 8192): canonical keys
+ * of ONE float32 / int32 group tensor (key_dtype RECNOW_KEY_F32 / RECNOW_KEY_I32), stable sort and segments by a single
+ * 1024-thread workgroup on LDS-resident keys, B <= 8192 (recnow_pairwise_small_supported), plus what recnow_pair_count would do
+ * first: the packed member records in `ws` (recnow_pairwise_workspace_bytes) and cleared cnt_super[0..B) / *n_pair.  Follow with
+ * recnow_pair_count and recnow_pair_bpr_fwdbwd on the SAME ws with RECNOW_PAIR_MEMBERS_PACKED in flags.  Same outputs as
+ * recnow_group_keys + recnow_group_segments on these ids. */
 int recnow_pairwise_small_supported(int64_t B, int key_dtype);
-int recnow_pairwise_small_fwdbwd(const void* groups, int key_dtype, const float* labels, const float* scores, const uint8_t* mask,
-                                 int64_t B, int flags, float factor, float power, int reduce_mean, float* loss, float* dscores,
-                                 int64_t* n_pair, void* stream);
+int recnow_group_pack_small(const void* groups, int key_dtype, const float* labels, const float* scores, const uint8_t* mask,
+                            int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id, int32_t* n_seg,
+                            int64_t* cnt_super, int64_t* n_pair, void* ws, size_t ws_bytes, void* stream);
 
 /* bpr_loss_func on explicit (P,) vectors (pairwise_loss_from_batch.py:96-127).  weights may be NULL.
  * dpos = d loss/d outputs_pos, dneg = -dpos.  P may be 0 (loss = 0). */

@@ -338,21 +338,18 @@ __global__ void k_occ_weight(const int32_t* __restrict__ order, const int32_t* _
 }
 
 
-// ---- small batches: the WHOLE loss in one launch ----------------------------------------------------------------------
+// ---- small batches: grouping + member packing in ONE launch ---------------------------------------------------------
 // B <= 8192 rows with one float32 / int32 group tensor (BASELINE config 2: pairwise_loss_from_batch at B = 8192, ~128 user groups).
-// The general path is a chain of eight launches of a few microseconds each (keys, grouping, pack, two counting kernels, two
-// loss kernels, finalize) whose wall time is launch latency.  Here ONE 1024-thread workgroup does all of it on LDS-resident data:
-//   canonical keys -> stable LSD radix sort (group_small.hpp) -> segment bounds per sorted row -> members (label, score, valid)
-//   -> pair counts per group (LDS integer atomics) -> P -> BPR terms per row -> loss (double, fixed order) and d loss / d scores.
-// A thread owns 8 consecutive sorted rows and walks each row's segment; rows of segments longer than PS_LONG are walked by a whole
-// wave instead (lanes stride over the members, fixed butterfly sums), so one huge group does not serialise on a few threads.
-// Same predicates, order-independent integer counts and per-row sums as the general kernels above: bitwise reproducible.
-#define PS_LONG 256
-template <int FLAGS>
+// The general front end is a chain of launches of a few microseconds each (keys, solo memset, grouping, pack) whose wall time is
+// launch latency.  Here ONE 1024-thread workgroup (group_small.hpp) forms the canonical keys, sorts them in LDS, derives the
+// segments and writes, besides order / seg_id / seg_first, the packed member records (label, score, row, valid) that the counting
+// and loss kernels walk, and clears their counters.  (Doing the pair walks in this workgroup too was tried: one CU is 1/256 of
+// the chip, the loss took 0.3 ms instead of 0.08.)
 __global__ void __launch_bounds__(GS_T)
-k_pairwise_small(const void* __restrict__ groups, int key_dtype, const float* __restrict__ labels, const float* __restrict__ scores,
-                 const uint8_t* __restrict__ mask, int B, float factor, float power, int reduce_mean, float* __restrict__ loss_out,
-                 float* __restrict__ dscores, long long* __restrict__ n_pair_out) {
+k_group_pack_small(const void* __restrict__ groups, int key_dtype, const float* __restrict__ labels, const float* __restrict__ scores,
+                   const uint8_t* __restrict__ mask, int B, int32_t* __restrict__ order, int32_t* __restrict__ seg_id,
+                   int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg,
+                   Member* __restrict__ mem, unsigned long long* __restrict__ cnt_super, unsigned long long* __restrict__ n_pair) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gs_lds[];
     uint32_t* key0 = reinterpret_cast<uint32_t*>(gs_lds);
     uint32_t* key1 = key0 + GS_MAXB;
@@ -360,13 +357,10 @@ k_pairwise_small(const void* __restrict__ groups, int key_dtype, const float* __
     uint16_t* idx1 = idx0 + GS_MAXB;
     uint16_t* cnt = idx1 + GS_MAXB;                                   // [16][GS_T] u16 = 32 KB
     unsigned* wsum = reinterpret_cast<unsigned*>(cnt + 16 * GS_T);    // 34 words
-    __shared__ double dred[16];
-    __shared__ long long lred[16];
+    uint8_t* solo = reinterpret_cast<uint8_t*>(wsum + 34);            // [B] NaN / inf flags by ORIGINAL row
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const unsigned SOLO = 0x80000000u;                                // marks NaN / inf ids in the index word (B <= 8192 < 2^15)
     unsigned vor = 0, vand = 0xffffffffu;
     // canonical keys (recnow_group_keys): -0.0 == +0.0; NaN and +-inf equal nothing, themselves included
-    uint8_t* solo = reinterpret_cast<uint8_t*>(wsum + 34);            // [B] flags by ORIGINAL row (dead once the heads are known)
     for (int i = tid; i < B; i += GS_T) {
         uint32_t k;
         bool so = false;
@@ -383,7 +377,9 @@ k_pairwise_small(const void* __restrict__ groups, int key_dtype, const float* __
         solo[i] = so ? 1 : 0;
         vor |= k;
         vand &= k;
+        if (cnt_super) cnt_super[i] = 0ull;
     }
+    if (tid == 0 && n_pair) *n_pair = 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         vor |= __shfl_xor(vor, o, 64);
@@ -399,154 +395,41 @@ k_pairwise_small(const void* __restrict__ groups, int key_dtype, const float* __
     uint16_t* ia = idx0; uint16_t* ib = idx1;
     gs_radix_sort_lds(ka, kb, ia, ib, cnt, wsum, B, varying);
     const int lo = tid * GS_KPT, hi = min(B, lo + GS_KPT);
-    // segment bounds of every sorted row: begin = last head at or before it, end = first head after it
-    unsigned heads = 0;
-    int last_head = -1;
+    unsigned heads = 0, nh = 0;
     for (int i = lo; i < hi; ++i) {
         bool h = true;
         if (i > 0) h = (ka[i] != ka[i - 1]) || solo[ia[i]] || solo[ia[i - 1]];
-        if (h) { heads |= 1u << (i - lo); last_head = i; }
+        heads |= (h ? 1u : 0u) << (i - lo);
+        nh += h ? 1u : 0u;
     }
-    __syncthreads();                                                  // every thread has read the keys / solo flags it needs
-    // inclusive max-scan of last_head over threads (carry-in for rows before this thread's first head)
-    int inc = last_head;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc = max(inc, t);
-    }
-    int* iw = reinterpret_cast<int*>(wsum);
-    if (lane == 63) iw[wv] = inc;
-    __syncthreads();
-    int carry = -1;
-    for (int i = 0; i < wv; ++i) carry = max(carry, iw[i]);
-    const int prev_incl = __shfl_up(inc, 1, 64);
-    int begin_carry = max(carry, lane > 0 ? prev_incl : -1);         // last head strictly before this thread's rows
-    __syncthreads();
-    // first head at or after the thread's LAST row + 1, i.e. exclusive min-scan from the right of "first head of thread"
-    int first_head = B;
-    for (int i = hi - 1; i >= lo; --i)
-        if ((heads >> (i - lo)) & 1u) first_head = i;
-    int dec = first_head;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_down(dec, o, 64);
-        if (lane + o < 64) dec = min(dec, t);
-    }
-    if (lane == 0) iw[wv] = dec;
-    __syncthreads();
-    int rcarry = B;
-    for (int i = 15; i > wv; --i) rcarry = min(rcarry, iw[i]);
-    const int next_incl = __shfl_down(dec, 1, 64);
-    const int end_carry = min(rcarry, lane < 63 ? next_incl : B);    // first head strictly after this thread's rows
-    __syncthreads();
-    // members in sorted order.  Everything of the sort is dead after the barrier below (the values live in registers across it),
-    // so the arena is laid out afresh: labels, scores, segment bounds, (valid, row), pairs per segment = 144 KB
-    float* lab = reinterpret_cast<float*>(gs_lds);
-    float* sc = lab + GS_MAXB;
-    uint16_t* sbeg = reinterpret_cast<uint16_t*>(sc + GS_MAXB);
-    uint16_t* send = sbeg + GS_MAXB;
-    uint16_t* vrow = send + GS_MAXB;                                  // valid flag << 15 | original row
-    unsigned* gcount = reinterpret_cast<unsigned*>(vrow + GS_MAXB);   // [GS_MAXB] pairs per segment, indexed by the segment's first row
-    {
-        int bcur = begin_carry;
-        uint16_t bb[GS_KPT], ee[GS_KPT];
-        for (int i = lo; i < hi; ++i) {
-            if ((heads >> (i - lo)) & 1u) bcur = i;
-            bb[i - lo] = (uint16_t)bcur;
-        }
-        int ecur = end_carry;
-        for (int i = hi - 1; i >= lo; --i) {
-            ee[i - lo] = (uint16_t)ecur;
-            if ((heads >> (i - lo)) & 1u) ecur = i;
-        }
-        float l8[GS_KPT], s8[GS_KPT];
-        uint16_t v8[GS_KPT];
-        for (int i = lo; i < hi; ++i) {
-            const int row = ia[i];
-            l8[i - lo] = labels[row];
-            s8[i - lo] = scores[row];
-            v8[i - lo] = (uint16_t)(row | ((mask ? (mask[row] != 0) : 1) ? 0x8000 : 0));
-        }
-        __syncthreads();                                              // the sort's buffers are dead for everybody
-        for (int i = lo; i < hi; ++i) {
-            sbeg[i] = bb[i - lo]; send[i] = ee[i - lo];
-            lab[i] = l8[i - lo]; sc[i] = s8[i - lo]; vrow[i] = v8[i - lo];
-        }
-    }
-    for (int i = tid; i < B; i += GS_T) gcount[i] = 0u;
-    __syncthreads();
-    auto member = [&](int j) {
+    unsigned total = 0;
+    unsigned g = gs_block_exclusive_scan(nh, wsum, &total);
+    for (int i = lo; i < hi; ++i) {
+        const bool h = (heads >> (i - lo)) & 1u;
+        if (h) { seg_first[g] = i; ++g; }
+        const int row = ia[i];
+        order[i] = row;
+        seg_id[i] = (int32_t)g - 1;
+        super_id[i] = (int32_t)g - 1;
         Member m;
-        const unsigned v = vrow[j];
-        m.label = lab[j]; m.score = sc[j]; m.row = (int)(v & 0x7fffu); m.valid = (int)(v >> 15);
-        return m;
-    };
-    // ---- pass 1: pairs per segment ---------------------------------------------------------------------------------
-    for (int i = wv; i < B; i += 16) {                                // long segments: a wave per row
-        const int s = sbeg[i], e = send[i];
-        if (e - s <= PS_LONG) continue;                               // wave-uniform
-        const Member me = member(i);
-        int cc = 0;
-        for (int j = s + lane; j < e; j += 64) cc += (j != i && pair_ok<FLAGS>(me, member(j))) ? 1 : 0;
-        cc = wave_sum(cc);
-        if (lane == 0 && cc) atomicAdd(&gcount[s], (unsigned)cc);
+        m.row = row;
+        m.label = labels[row];
+        m.score = scores[row];
+        m.valid = mask ? (mask[row] != 0) : 1;
+        mem[i] = m;
     }
-    for (int i = lo; i < hi; ++i) {
-        const int s = sbeg[i], e = send[i];
-        if (e - s > PS_LONG) continue;
-        const Member me = member(i);
-        int cc = 0;
-        for (int j = s; j < e; ++j) cc += (j != i && pair_ok<FLAGS>(me, member(j))) ? 1 : 0;
-        if (cc) atomicAdd(&gcount[s], (unsigned)cc);                  // integer atomics in LDS: order-independent
-    }
-    __syncthreads();
-    long long pl = 0;
-    for (int i = tid; i < B; i += GS_T) pl += gcount[i];
-    const long long P = block_sum<long long>(pl, lred);
-    const float denom = reduce_mean ? ((float)P + 1.0e-10f) : 1.f;
-    // ---- pass 2: BPR terms ----------------------------------------------------------------------------------------------
-    auto weight = [&](int s) {
-        if (power == 0.f) return 1.f;
-        const float c = (float)gcount[s];
-        return (c == 0.f) ? 1.f : ((power == 1.f) ? c : powf(c, power));
-    };
-    double lsum = 0.0;
-    for (int i = wv; i < B; i += 16) {
-        const int s = sbeg[i], e = send[i];
-        if (e - s <= PS_LONG) continue;
-        const Member me = member(i);
-        float la = 0.f, ga = 0.f;
-        for (int j = s + lane; j < e; j += 64) bpr_term<FLAGS>(me, member(j), j != i, factor, la, ga);
-        la = wave_sum(la);
-        ga = wave_sum(ga);
-        if (lane == 0) {
-            const float w = weight(s);
-            dscores[me.row] = w * factor * ga / denom;
-            lsum += (double)(w * la);
-        }
-    }
-    for (int i = lo; i < hi; ++i) {
-        const int s = sbeg[i], e = send[i];
-        if (e - s > PS_LONG) continue;
-        const Member me = member(i);
-        float la = 0.f, ga = 0.f;
-        for (int j = s; j < e; ++j) bpr_term<FLAGS>(me, member(j), j != i, factor, la, ga);
-        const float w = weight(s);
-        dscores[me.row] = w * factor * ga / denom;
-        lsum += (double)(w * la);
-    }
-    lsum = block_sum<double>(lsum, dred);
     if (tid == 0) {
-        float v = (float)lsum;
-        if (reduce_mean) v = v / ((float)P + 1.0e-10f);
-        *loss_out = v;
-        *n_pair_out = P;
+        seg_first[total] = B;
+        n_seg[0] = (int32_t)total;
+        n_seg[1] = (int32_t)total;
     }
 }
-static inline size_t ps_lds_bytes() {          // max(sort arena + solo flags, members arena)
-    const size_t a = gs_lds_bytes() + GS_MAXB, b = (size_t)GS_MAXB * (4 + 4 + 2 + 2 + 2 + 4);
-    return a > b ? a : b;
+static inline size_t ps_lds_bytes() { return gs_lds_bytes() + GS_MAXB; }
+__global__ void k_seg_empty2(int32_t* seg_first, int32_t* n_seg, unsigned long long* n_pair) {
+    seg_first[0] = 0;
+    n_seg[0] = 0;
+    n_seg[1] = 0;
+    *n_pair = 0ull;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -622,7 +505,8 @@ extern "C" int recnow_pair_count(const float* scores, const float* labels, const
     if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
     const PairWs pw = pair_ws(ws, ws_bytes, B);
     Member* mem = pw.mem;
-    int rc = pack_members(scores, labels, mask, order, B, mem, st, cnt_super, n_pair);      // also clears cnt_super[0..B) and *n_pair
+    // RECNOW_PAIR_MEMBERS_PACKED: recnow_group_pack_small has packed the members into `ws` and cleared the counters
+    int rc = (flags & RECNOW_PAIR_MEMBERS_PACKED) ? RECNOW_OK : pack_members(scores, labels, mask, order, B, mem, st, cnt_super, n_pair);      // also clears cnt_super[0..B) and *n_pair
     if (rc) return rc;
     const int G = rn_cdiv(B, RN_PW_T);
     RN_DISPATCH_LONG(0, mem, seg_id, seg_first, B, 1.f, pw.long_cnt, pw.long_la, pw.long_ga);
@@ -733,38 +617,32 @@ extern "C" int recnow_occurance_power_weight(const int32_t* order, const int32_t
 }
 
 
-// The whole BPR pairwise loss of a small batch (B <= 8192, ONE float32 or int32 group tensor) in one launch:
-// grouping, pair counts, loss and d loss / d scores.  Same results as recnow_group_keys + recnow_group_segments +
-// recnow_pair_count + recnow_pair_bpr_fwdbwd on the same inputs.
+// Front end of the pairwise loss for a small batch (B <= 8192, ONE float32 or int32 group tensor) in one launch: canonical keys,
+// stable sort, segments AND the packed member records + cleared counters that recnow_pair_count / recnow_pair_bpr_fwdbwd expect
+// when called with RECNOW_PAIR_MEMBERS_PACKED on the same workspace.  Equivalent to recnow_group_keys + recnow_group_segments +
+// the packing pass of recnow_pair_count.
 extern "C" int recnow_pairwise_small_supported(int64_t B, int key_dtype) {
     return (B >= 0 && B <= GS_MAXB && (key_dtype == RECNOW_KEY_F32 || key_dtype == RECNOW_KEY_I32)) ? 1 : 0;
 }
-extern "C" int recnow_pairwise_small_fwdbwd(const void* groups, int key_dtype, const float* labels, const float* scores,
-                                            const uint8_t* mask, int64_t B, int flags, float factor, float power, int reduce_mean,
-                                            float* loss, float* dscores, int64_t* n_pair, void* stream) {
-    if (B < 0 || !loss || !n_pair) return RECNOW_EINVAL;
+extern "C" int recnow_group_pack_small(const void* groups, int key_dtype, const float* labels, const float* scores,
+                                       const uint8_t* mask, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first,
+                                       int32_t* super_id, int32_t* n_seg, int64_t* cnt_super, int64_t* n_pair, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    if (B < 0 || !seg_first || !n_seg || !n_pair) return RECNOW_EINVAL;
     if (!recnow_pairwise_small_supported(B, key_dtype)) return RECNOW_EUNSUPPORTED;
-    if ((flags & (RECNOW_PAIR_LABEL_GT | RECNOW_PAIR_WRONG_ORDER)) == 0) return RECNOW_EINVAL;      // see recnow_pair_bpr_fwdbwd
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) {
-        RN_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
-        RN_HIP(hipMemsetAsync(n_pair, 0, sizeof(int64_t), st));
+        hipLaunchKernelGGL(k_seg_empty2, 1, 1, 0, st, seg_first, n_seg, (unsigned long long*)n_pair);
+        RN_LAUNCH_CHECK();
         return RECNOW_OK;
     }
-    if (!groups || !labels || !scores || !dscores) return RECNOW_EINVAL;
+    if (!groups || !labels || !scores || !order || !seg_id || !super_id || !cnt_super || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
+    const PairWs pw = pair_ws(ws, ws_bytes, B);
     const size_t lds = ps_lds_bytes();
-#define PS_LAUNCH(F)                                                                                                              \
-    do {                                                                                                                          \
-        RN_HIP(hipFuncSetAttribute((const void*)k_pairwise_small<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL(k_pairwise_small<F>, 1, GS_T, lds, st, groups, key_dtype, labels, scores, mask, (int)B, factor, power, \
-                           reduce_mean, loss, dscores, (long long*)n_pair);                                                      \
-    } while (0)
-    switch (flags & 3) {
-        case 1: PS_LAUNCH(1); break;
-        case 2: PS_LAUNCH(2); break;
-        default: PS_LAUNCH(3); break;
-    }
-#undef PS_LAUNCH
+    RN_HIP(hipFuncSetAttribute((const void*)k_group_pack_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_group_pack_small, 1, GS_T, lds, st, groups, key_dtype, labels, scores, mask, (int)B, order, seg_id, seg_first,
+                       super_id, n_seg, pw.mem, (unsigned long long*)cnt_super, (unsigned long long*)n_pair);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

@@ -173,8 +173,8 @@ class _PairBprFused(torch.autograd.Function):
 
 
 class _PairBprSmall(torch.autograd.Function):
-    """B <= 8192 rows, one float32 / int32 group tensor: grouping, pair counts, loss and gradient in ONE launch
-    (recnow_pairwise_small_fwdbwd) instead of the chain of eight few-microsecond launches of the general route."""
+    """B <= 8192 rows, one float32 / int32 group tensor: keys, grouping and member packing in ONE launch
+    (recnow_group_pack_small), then the counting and loss kernels of the general route on the packed members."""
 
     @staticmethod
     def forward(ctx, outputs, labels, mask, gkey, gdt, flags, factor, power, reduce_mean):
@@ -183,11 +183,24 @@ class _PairBprSmall(torch.autograd.Function):
         labs = _flat_f32(labels, B, 'labels')
         m = _flat_mask(mask, B)
         dev = gkey.device
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)      # noqa: E731
+        order, seg_id, seg_first, super_id, n_seg = i32(max(B, 1)), i32(max(B, 1)), i32(B + 1), i32(max(B, 1)), i32(2)
+        cnt_row = i32(max(B, 1))
+        cnt_super = torch.empty(max(B, 1), dtype=torch.int64, device=dev)
+        n_pair = torch.empty(1, dtype=torch.int64, device=dev)
+        ws = _lib.workspace(_lib.load().recnow_pairwise_workspace_bytes(B), dev)
+        st = _lib.stream()
+        _lib.call('recnow_group_pack_small', _lib.ptr(gkey), gdt, _lib.ptr(labs), _lib.ptr(scores), _lib.ptr(m), B, _lib.ptr(order),
+                  _lib.ptr(seg_id), _lib.ptr(seg_first), _lib.ptr(super_id), _lib.ptr(n_seg), _lib.ptr(cnt_super), _lib.ptr(n_pair),
+                  _lib.ptr(ws), ws.numel(), st)
+        _lib.call('recnow_pair_count', _lib.ptr(scores), _lib.ptr(labs), _lib.ptr(m), _lib.ptr(order), _lib.ptr(seg_id),
+                  _lib.ptr(seg_first), _lib.ptr(super_id), B, flags | _FLAG_MEMBERS_PACKED, _lib.ptr(cnt_row), _lib.ptr(cnt_super),
+                  _lib.ptr(n_pair), _lib.ptr(ws), ws.numel(), st)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         dscores = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
-        n_pair = torch.empty(1, dtype=torch.int64, device=dev)
-        _lib.call('recnow_pairwise_small_fwdbwd', _lib.ptr(gkey), gdt, _lib.ptr(labs), _lib.ptr(scores), _lib.ptr(m), B, flags,
-                  float(factor), float(power), 1 if reduce_mean else 0, _lib.ptr(loss), _lib.ptr(dscores), _lib.ptr(n_pair), _lib.stream())
+        _lib.call('recnow_pair_bpr_fwdbwd', _lib.ptr(scores), _lib.ptr(labs), _lib.ptr(m), _lib.ptr(order), _lib.ptr(seg_id),
+                  _lib.ptr(seg_first), _lib.ptr(super_id), _lib.ptr(cnt_super), _lib.ptr(n_pair), B, flags | _FLAG_MEMBERS_PACKED,
+                  float(factor), float(power), 1 if reduce_mean else 0, _lib.ptr(loss), _lib.ptr(dscores), _lib.ptr(ws), ws.numel(), st)
         ctx.save_for_backward(dscores[:B])
         ctx.shape = outputs.shape
         n_pair_f = n_pair.to(torch.float32).reshape(())

@@ -365,8 +365,8 @@ def test_groups_beyond_the_lds_staging_size(dev, seed):
         assert np.array_equal(pos.cpu().numpy(), cpos) and np.array_equal(neg.cpu().numpy(), cneg)
 
 
-# ---- the single-launch route for small batches (recnow_pairwise_small_fwdbwd) -----------------------------------------------
-def _zipf_groups(rng, B, cap):
+# ---- the one-launch front end for small batches (recnow_group_pack_small) -----------------------------------------------
+def _zipf_groups_cap(rng, B, cap):
     sizes = []
     while sum(sizes) < B:
         sizes.append(int(min(cap, rng.zipf(1.3))))
@@ -378,15 +378,15 @@ def _zipf_groups(rng, B, cap):
                                           (5000, 'special_ids', 4), (1, 'uniform128', 5), (777, 'two_groups', 6), (8191, 'zipf300', 7)])
 @pytest.mark.parametrize('wrong,power,use_mask', [(False, 0.0, False), (True, -0.5, True), (False, 1.0, True)])
 def test_small_route_equals_general_route_and_c_oracle(dev, B, kind, seed, wrong, power, use_mask):
-    """One launch (B <= 8192, one group tensor) against (a) the general multi-launch route on the same inputs (segments handed
-    in explicitly), (b) the plain-C restatement of the reference formulation (oracle/pairs_oracle.c)."""
+    """The one-launch front end (keys + grouping + member packing, B <= 8192, one group tensor) against (a) the general route on
+    the same inputs (segments handed in explicitly), (b) the plain-C restatement of the reference formulation (pairs_oracle.c)."""
     import pairs_oracle as PO
     from rec_now_amd.rec_block.pairwise_loss_from_batch import _small_route, group_rows, pairwise_loss_fused
     rng = np.random.default_rng(100 + seed)
     if kind == 'uniform128':
         g = rng.integers(0, 128, B).astype(np.float32)
     elif kind.startswith('zipf'):
-        g = _zipf_groups(rng, B, int(kind[4:]))
+        g = _zipf_groups_cap(rng, B, int(kind[4:]))
     elif kind == 'one_group':
         g = np.full(B, 3.0, np.float32)
     elif kind == 'singletons':
