@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librecnow_hip.so')
+LIB_PATH = os.environ.get('RECNOW_LIB_PATH') or os.path.join(_HERE, 'librecnow_hip.so')      # override: A/B runs of two builds (tools/)
 
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t

@@ -565,6 +565,9 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     const int D = m.D, S = m.S, N = m.N, L = m.L;
     const bool two = st2 != nullptr && st2 != st;
     if (!two) st2 = st;
+    // RECNOW_TWO_STREAMS=2 ("paired"): BOTH weight-gradient products of a layer (MFMA-bound) are held back until the sub-space
+    // backward is done, so that they run beside the layer's dx product (HBM-bound) instead of beside the MFMA-bound dT2g product
+    static const bool paired = []() { const char* e = getenv("RECNOW_TWO_STREAMS"); return e && e[0] == '2'; }();
     RnCarver c(ws, ws_bytes);
     float* Wc1_all = c.take<float>((size_t)L * D * m.LDT);        // per-layer packs: the side stream reads them later
     float* dWc1 = c.take<float>((size_t)D * m.LDT);
@@ -623,8 +626,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         float* gprev = (l == 0) ? nullptr : ((l & 1) ? gbuf0 : gbuf1);
         const float* Wc1 = Wc1_all + (size_t)l * D * m.LDT;
         // ---------------- side stream, part 1: needs only g_l and saved activations
-        MIX_WAIT(e_g, st2);
-        {   // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
+        auto side_dw = [&]() -> int {
+            // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
             const bool top_head = hd && l == L - 1;
             d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 1;
@@ -642,6 +645,11 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
                 hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 256), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw);
                 RN_LAUNCH_CHECK();
             }
+            return RECNOW_OK;
+        };
+        if (!(two && paired)) {
+            MIX_WAIT(e_g, st2);
+            if ((rc = side_dw())) return rc;
         }
         // ---------------- chain stream
         {   // dT2g[:, :NS] = (x*g) W^T;  gate columns dT2g[:, NS+n] = (x*g) . bias_n as the side product
@@ -690,6 +698,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         if (l > 0) MIX_SIGNAL(e_g, st);
         // ---------------- side stream, part 2: needs dC / dT1 of this layer
         MIX_WAIT(e_dT1, st2);
+        if (two && paired && (rc = side_dw())) return rc;           // (e_dT1 is later than e_g of this layer)
         {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = xl; d.lda = D; d.a_trans = 1;

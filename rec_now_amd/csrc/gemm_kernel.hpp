@@ -270,13 +270,7 @@ k_gemm(const GemmK p) {
     float* const Bxs = smem + 2 * A_SZ + 2 * B_SZ;     // XF & 1: two buffers of BK x 4 side-product weights
     // (sp_on / side output use blockIdx.y directly: those launches are never remapped in y, see rn_gemm)
     const bool sp_on = (XF & 1) && blockIdx.y == 0;    // one column-tile computes the side product of a row-tile
-    // Side product off the MFMA fragments: a wave already holds A'[m][k] for its 64 rows in the fragment registers of every k-step
-    // (lanes 0-31: even k of the pair, lanes 32-63: odd k), so side column r costs one FMA per fragment and one broadcast LDS read
-    // of Bx[k][r] -- no second pass over the A tile in LDS.  The two waves of a row panel (wave column wn = 0 / 1) share the rows:
-    // wn takes the side columns r = wn and wn + 2.
-    float spv[XF & 1 ? (BM / (WAVES_M * 32)) : 1][2];
-#pragma unroll
-    for (int i = 0; i < ((XF & 1) ? (BM / (WAVES_M * 32)) : 1); ++i) spv[i][0] = spv[i][1] = 0.f;
+    f32x4 spacc = mk4(0.f, 0.f, 0.f, 0.f);
     float bxr[4] = {0.f, 0.f, 0.f, 0.f};
 
 #ifdef RN_GEMM_TRACE      // per-workgroup phase timestamps for tools/gemm_trace.py (build with RECNOW_TRACE=1)
@@ -380,7 +374,10 @@ k_gemm(const GemmK p) {
                 *reinterpret_cast<f32x4*>(Bxs + (cur ^ 1) * BK * 4 + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
             if (t + 2 < ntile) issue_loads(t + 2);
         }
-        const float* bxs = Bxs + cur * BK * 4 + (lane >> 5) * 4 + wn;      // Bx[k of this lane's half][r = wn], r + 2 at +2
+        // VALU side product off the A tile in LDS: thread = (row m, half of the tile's k range); its 2*(BK/4) k's are
+        // spread over the MFMA loop below (2 per iteration) so the FMAs run in the shadow of in-flight MFMAs.
+        const float* asx = As + cur * A_SZ + (threadIdx.x & 127) + (threadIdx.x >> 7) * (BK / 2) * TA::LD;
+        const float* bxs = Bxs + cur * BK * 4 + (threadIdx.x >> 7) * (BK / 2) * 4;
         const float* as = As + cur * A_SZ + a_off;
         const float* bs = Bs + cur * B_SZ + b_off;
         // ONE loop form for full and tail tiles (two forms make the compiler shuffle every accumulator between them):
@@ -399,12 +396,10 @@ k_gemm(const GemmK p) {
             for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
-            float bx00 = 0.f, bx01 = 0.f, bx10 = 0.f, bx11 = 0.f;
-            if constexpr ((XF & 1) != 0) {          // Bx of this lane's k (steps kk and kk + 2), side columns wn and wn + 2
-                bx00 = bxs[kk * 4];
-                bx01 = bxs[kk * 4 + 2];
-                bx10 = bxs[(kk + 2) * 4];
-                bx11 = bxs[(kk + 2) * 4 + 2];
+            if constexpr ((XF & 1) != 0) {
+                const int kq = kk >> 1;        // this iteration's two k's of the thread's half-range
+                spacc += asx[kq * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + kq * 4);
+                spacc += asx[(kq + 1) * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + (kq + 1) * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -412,13 +407,6 @@ k_gemm(const GemmK p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((XF & 1) != 0) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    spv[i][0] += a0[i] * bx00 + a1[i] * bx10;
-                    spv[i][1] += a0[i] * bx01 + a1[i] * bx11;
-                }
-            }
             const int kn = min(kk + 4, BK - 2);     // stays inside this buffer on the last iteration (value unused then)
 #pragma unroll
             for (int i = 0; i < TM; ++i) a0[i] = as[kn * TA::LD + i * 32];
@@ -434,19 +422,19 @@ k_gemm(const GemmK p) {
         __syncthreads();
     }
     if constexpr ((XF & 1) != 0) {
-        // lanes l and l + 32 hold the even-k / odd-k halves of the same row's sums
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float tot = spv[i][q] + __shfl_xor(spv[i][q], 32, 64);
-                const int r = wn + 2 * q;
-                if (sp_on && lane < 32 && r < p.sp_r) {
-                    const int m = m0 + wm * TM * 32 + i * 32 + lane;
-                    if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = tot;
-                    else p.cx[(int64_t)m * p.cx_ms + r * p.cx_rs] = tot;
-                }
+        // combine the two k-halves through LDS (free now) and write the side columns
+        if (sp_on && threadIdx.x >= 128) *reinterpret_cast<f32x4*>(smem + (threadIdx.x - 128) * 4) = spacc;
+        __syncthreads();
+        if (sp_on && threadIdx.x < 128) {
+            const f32x4 o = spacc + *reinterpret_cast<const f32x4*>(smem + threadIdx.x * 4);
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+            const int m = m0 + threadIdx.x;
+            for (int r = 0; r < p.sp_r; ++r) {
+                if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = ov[r];
+                else p.cx[(int64_t)m * p.cx_ms + r * p.cx_rs] = ov[r];
             }
+        }
+        __syncthreads();
     }
 
     RN_TR(2);

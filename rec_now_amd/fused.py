@@ -17,7 +17,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .layers._ops import _host_ptr_array
+from .layers._ops import DCN_MIX_TWO_STREAMS, _host_ptr_array
 
 
 class GpuEvent(object):
@@ -93,7 +93,7 @@ class DCNMixScoreFunction(torch.autograd.Function):
                   _host_ptr_array(bias), _host_ptr_array(gate), _lib.ptr(hw), _lib.ptr(ds), _lib.ptr(saved), saved.numel(), B, D, S, N, L,
                   act_inner, act_outer, _lib.ptr(dx) if need_dx else None, _host_ptr_array(dU), _host_ptr_array(dV),
                   _host_ptr_array(dW), _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(dhw), _lib.ptr(dhb), _lib.ptr(ws),
-                  ws.numel(), _lib.stream(), None, ev)
+                  ws.numel(), _lib.stream(), _lib.side_stream(x.device) if DCN_MIX_TWO_STREAMS else None, ev)
         return (dx, dhw.view(hw_shape), None if dhb is None else dhb.view(hb_shape), None, None, None, None, None) + tuple(grads)
 
 

@@ -174,7 +174,7 @@ import os
 # Opt-in: run the weight-gradient products of the DCN-v2 backward on a second HIP stream (recnow_dcn_mix_bwd's stream2).
 # Measured on MI355X at the north-star shape: 5.43 vs 5.54 ms/step (-2 %), every GEMM already fills all 256 CUs, so the
 # default stays single-stream (per-launch timings then remain meaningful for the roofline hook).
-DCN_MIX_TWO_STREAMS = os.environ.get('RECNOW_TWO_STREAMS', '0') == '1'
+DCN_MIX_TWO_STREAMS = os.environ.get('RECNOW_TWO_STREAMS', '0') in ('1', '2')
 
 
 # ---- DCN-v2 mix ---------------------------------------------------------------------------------------------------
