@@ -325,6 +325,12 @@ def main():
         loss = run_step()
     sync()
     elapsed = time.perf_counter() - t0
+    # diagnostic: host time to ENQUEUE a step (no synchronisation inside): well below ms_per_step = the step is GPU-bound
+    h0 = time.perf_counter()
+    for _ in range(5):
+        run_step()
+    host_ms = (time.perf_counter() - h0) * 1e3 / 5
+    sync()
     roofline = None
     if prof:
         cnt = (ctypes.c_int * 8)()
@@ -419,7 +425,8 @@ def main():
                                    'in-batch pairwise (logistic), B=65536 rows per GPU, 64 fields x 16-dim, ~64 rows/group',
                        'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(args.graph), 'parallelism': 'dp%d' % world,
                        'route': 'fused node dcn_mix_score + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
-                       'loss': float(loss.item())},
+                       'loss': float(loss.item()), 'host_enqueue_ms_per_step': host_ms,
+                       'grads_copied_into_buckets': getattr(layerwise, 'last_foreign', None) if layerwise is not None else None},
             'roofline': roofline,
             'parity': parity,
             'parity_max_rel': parity.get('parity_max_rel') if parity else None,

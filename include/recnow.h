@@ -250,6 +250,9 @@ typedef struct recnow_gemm_desc {
      *              Dense(1) head folded into the epilogue of the product that forms its input.
      *   c2_mode 4 (b_trans 1, no emul): C = acc; C2[m][n] = acc * E2[m][n] + rv[m] * cv[n] * E3[m][n] (written, not read). */
     const float* E3; int64_t lde3; const float* rv; const float* cv; const float* hv; float* hp; int hp_ld; int hp_pad;
+    /* k_valid (0 = K): the caller guarantees that A's columns / B's rows k_valid .. K-1 are ZERO (a depth padded to the k-tile);
+     * the short-K kernel then skips the MFMA steps of the padding (DCN-v2: 130 of 144). */
+    int k_valid; int k_pad;
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;
@@ -509,6 +512,9 @@ int recnow_event_create(void** event_out);
 int recnow_event_destroy(void* event);
 int recnow_event_record(void* event, void* stream);
 int recnow_stream_wait_event(void* stream, void* event);
+/* x[0..n) *= 1 / (count[0] + eps), count a DEVICE scalar: the in-place normalisation of a reduced gradient bucket by the global
+ * pair count (pairwise_loss_from_batch.py:125-126, P + 1e-10) without a host round trip.  x 16-byte aligned. */
+int recnow_scale_by_inv_count(float* x, int64_t n, const float* count, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -356,25 +356,32 @@ k_row_scale(const float* __restrict__ in, const float* __restrict__ rs, int64_t 
     }
 }
 // in place: Mw (NS x D) and Mb (N x D) hold M^T = (x^T (dscore * T2g))^T;  dwh[c] = sum_k W[k][c] Mw[k][c] + sum_n bias[n][c] Mb[n][c];
-// then Mw *= wh[c] (= dW) and Mb *= wh[c] (= dbias).  One thread per column, rows walked in order.
+// then Mw *= wh[c] (= dW) and Mb *= wh[c] (= dbias).  A workgroup owns 32 columns; its 8 row groups walk the NS + N rows with a
+// stride of 8 (coalesced 128-byte row pieces) and their partial sums are added in a fixed order.
 __global__ void __launch_bounds__(256)
 k_head_post(float* __restrict__ Mw, float* __restrict__ Mb, const float* __restrict__ W, const float* __restrict__ bias,
             const float* __restrict__ wh, int NS, int N, int D, float* __restrict__ dwh) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
-    const float w = wh[c];
+    __shared__ float part[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
     float s = 0.f;
-    for (int k = 0; k < NS; ++k) {
-        const float m = Mw[(int64_t)k * D + c];
-        s += W[(int64_t)k * D + c] * m;
-        Mw[(int64_t)k * D + c] = m * w;
+    if (c < D) {
+        const float w = wh[c];
+        for (int k = rg; k < NS + N; k += 8) {
+            float* mp = k < NS ? Mw + (int64_t)k * D + c : Mb + (int64_t)(k - NS) * D + c;
+            const float wk = k < NS ? W[(int64_t)k * D + c] : bias[(int64_t)(k - NS) * D + c];
+            const float m = *mp;
+            s += wk * m;
+            *mp = m * w;
+        }
     }
-    for (int n = 0; n < N; ++n) {
-        const float m = Mb[(int64_t)n * D + c];
-        s += bias[(int64_t)n * D + c] * m;
-        Mb[(int64_t)n * D + c] = m * w;
+    part[rg][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (rg == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += part[r][threadIdx.x & 31];
+        dwh[c] = t;
     }
-    dwh[c] = s;
 }
 // dx[m][c] = ds[m] * wh[c] * O[m][c]   (single cross layer under a fused head: the only term that is not a product)
 __global__ void __launch_bounds__(256)
@@ -460,7 +467,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
                 d.B = Wc2; d.ldb = D; d.b_trans = 0;
                 d.C = out; d.ldc = D;
-                d.M = (int)B; d.N = D; d.K = m.KP;
+                d.M = (int)B; d.N = D; d.K = m.KP; d.k_valid = m.KC;
                 d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
                 if (need_dx) { d.C2 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.ldc2 = D; d.c2_mode = 1; }     // O_l only feeds dx
@@ -494,7 +501,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc2; d.ldb = D; d.b_trans = 0;
             d.C = out; d.ldc = D;
-            d.M = (int)B; d.N = D; d.K = m.KP;
+            d.M = (int)B; d.N = D; d.K = m.KP; d.k_valid = m.KC;
             d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
         }
@@ -642,7 +649,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.sp_bx = d.B + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
             if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
             if (top_head) {      // dW = w_head * M^T, dbias likewise, d w_head = sum_k [W; b] * M^T
-                hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 256), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw);
+                hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw);
                 RN_LAUNCH_CHECK();
             }
             return RECNOW_OK;
@@ -685,7 +692,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
             d.C = (l == 0) ? dx : gprev; d.ldc = D;
-            d.M = (int)B; d.N = D; d.K = m.KP;
+            d.M = (int)B; d.N = D; d.K = m.KP; d.k_valid = m.KC;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.accumulate = (l == 0) ? 1 : 0;
             if (l > 0 && dx) { d.C2 = dx; d.ldc2 = D; d.E2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.lde2 = D; d.c2_mode = 2; }
@@ -799,7 +806,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             d.A = T2g; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc2; d.ldb = D; d.b_trans = 0;
             d.C = dx; d.ldc = D;
-            d.M = (int)B; d.N = D; d.K = m.KP;
+            d.M = (int)B; d.N = D; d.K = m.KP; d.k_valid = m.KC;
             d.emul = g; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
             d.accumulate = dx_started ? 1 : 0;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
@@ -824,7 +831,7 @@ extern "C" int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, co
             d.A = dT1; d.lda = m.LDT; d.a_trans = 0;
             d.B = Wc1; d.ldb = m.LDT; d.b_trans = 1;
             d.C = (l == 0) ? dx : gprev; d.ldc = D;
-            d.M = (int)B; d.N = D; d.K = m.KP;
+            d.M = (int)B; d.N = D; d.K = m.KP; d.k_valid = m.KC;
             d.accumulate = (l == 0) ? 1 : 0;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
         }

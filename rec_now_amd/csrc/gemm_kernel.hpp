@@ -44,6 +44,7 @@ struct GemmK {
     const float* hv;           // c2_mode 3: column vector of the fused row-dot (the scoring head's kernel)
     float* hp;                 // c2_mode 3: partials hp[m][hp_ld], entry 2 * column tile + wave column
     int hp_ld;
+    int tail_pairs;            // short-K kernel: k-pairs of the LAST k-tile that hold data (8 = all; fewer: a zero-padded depth)
     int* cu_slots;             // short-K kernel: per-CU arrival counters of the phase stagger (NULL: no stagger)
     int stagger_ticks;         // delay per arrival slot, in 10 ns ticks of the constant 100 MHz clock
     long long* trace;          // RN_GEMM_TRACE builds only: 8 int64 per workgroup (phase timestamps, HW id)

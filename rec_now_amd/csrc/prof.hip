@@ -98,3 +98,27 @@ extern "C" int recnow_stream_wait_event(void* stream, void* event) {
     RN_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
     return RECNOW_OK;
 }
+
+
+// x[i] *= 1 / (count[0] + eps)  (the gradient buckets of dp.LayerwiseReducer: count = the global pair count, a device scalar)
+__global__ void __launch_bounds__(256) k_scale_by_inv_count(float* __restrict__ x, int64_t n, const float* __restrict__ count, float eps) {
+    const float inv = 1.f / (count[0] + eps);
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[n4 * 4 + threadIdx.x] *= inv;
+}
+extern "C" int recnow_scale_by_inv_count(float* x, int64_t n, const float* count, float eps, void* stream) {
+    if (n < 0) return RECNOW_EINVAL;
+    if (n == 0) return RECNOW_OK;
+    if (!x || !count || ((uintptr_t)x & 15)) return RECNOW_EINVAL;
+    int64_t g = (n / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_scale_by_inv_count, (int)g, 256, 0, (hipStream_t)stream, x, n, count, eps);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}

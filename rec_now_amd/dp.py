@@ -15,6 +15,8 @@ import torch.distributed as dist
 SMALL_POSIVITE_FLOAT = 1.0e-10
 
 
+import os as _os
+_SKIP_COLLECTIVE = _os.environ.get('RECNOW_DP_SKIP_COLLECTIVE') == '1'      # diagnostics only: price the path around the collective
 FORCE_COLLECTIVES = False      # diagnostics: run the collectives even in a 1-rank process group (bench.py --force-dist)
 
 
@@ -212,6 +214,7 @@ class LayerwiseReducer(object):
                 self.comm.wait_stream(main)             # no events / no prepare(): everything enqueued so far, i.e. after the backward pass
         out_stats = None
         inv = None
+        self.last_foreign = 0                           # diagnostics: gradients that had to be copied into their bucket
         with (torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()):
             for i, stage in enumerate(self.stages):
                 if self.events[i] is not None and self.comm is not None:
@@ -226,13 +229,20 @@ class LayerwiseReducer(object):
                     elif p.grad.data_ptr() != view.data_ptr():
                         view.copy_(p.grad.reshape(-1))
                         foreign.append((p, view))
+                        self.last_foreign += 1
                 if i == 0:
                     flat[-2:].copy_(stats)
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                if not _SKIP_COLLECTIVE:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
                 if i == 0:
                     out_stats = flat[-2:].clone()
                     inv = 1.0 / (out_stats[1] + eps)
-                flat.mul_(inv)
+                if flat.is_cuda:            # one small launch (torch's broadcast multiply by a 0-dim tensor takes ~30 us per bucket)
+                    from . import _lib
+                    _lib.call('recnow_scale_by_inv_count', _lib.ptr(flat), flat.numel(), _lib.ptr(out_stats[1:]), float(eps),
+                              _lib._P(torch.cuda.current_stream().cuda_stream))
+                else:
+                    flat.mul_(inv)
                 for p, view in foreign:
                     if self.comm is not None:
                         p.grad.record_stream(self.comm)
