@@ -157,7 +157,8 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     k.cu_slots = nullptr; k.stagger_ticks = 0;
     k.tail_pairs = 8;
     if (d->k_valid < 0 || d->k_valid > d->K) return RECNOW_EINVAL;
-    if (d->k_valid > 0 && d->K % 16 == 0 && d->k_valid > d->K - 16) k.tail_pairs = (d->k_valid - (d->K - 16) + 1) / 2;      // pairs of the last 16-deep tile
+    static const bool sk_tail = []() { const char* e = getenv("RECNOW_SK_TAIL"); return !e || e[0] != '0'; }();      // A/B switch
+    if (sk_tail && d->k_valid > 0 && d->K % 16 == 0 && d->k_valid > d->K - 16) k.tail_pairs = (d->k_valid - (d->K - 16) + 1) / 2;      // pairs of the last 16-deep tile
     k.C2 = d->C2; k.E2 = d->E2; k.ldc2 = d->ldc2; k.lde2 = d->lde2;
     k.as_in = d->as_in; k.as_out = d->as_out;
     if ((d->as_in != nullptr) != (d->as_out != nullptr)) return RECNOW_EINVAL;

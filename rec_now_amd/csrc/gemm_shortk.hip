@@ -145,21 +145,10 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
             }
             const float* as = smem + cur * BUF + a_off;
             const float* bs = smem + cur * BUF + A_SZ + b_off;
-            if (t == nk - 1 && p.tail_pairs < SK_BK / 2) {
-                // The last k-tile of a zero-padded depth (DCN-v2: K = N*S + N = 130 stored as 144): only its first tail_pairs
-                // k-pairs hold data, the rest of the tile is zeros -- one MFMA step instead of eight (10 % of the tile's MFMAs).
-                for (int pr = 0; pr < p.tail_pairs; ++pr) {
-                    float ta0[2], tb0[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) ta0[i] = as[(2 * pr) * TA::LD + i * 32];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tb0[j] = bs[(2 * pr) * TB::LD + j * 32];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta0[i], tb0[j], acc[i][j], 0, 0, 0);
-                }
-            } else {
+            // k-pairs of this k-tile that hold data: all 8, except in the last k-tile of a zero-padded depth (DCN-v2: K = N*S + N = 130
+            // stored as 144 -> 1 pair): the MFMA groups of the padding are skipped behind a scalar branch each (10 % of a tile's MFMAs).
+            // The loads, the fragment reads and the schedule of the groups stay as they are.
+            const int npairs = (t == nk - 1) ? p.tail_pairs : SK_BK / 2;
             float a0[2], b0[2], a1[2], b1[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a0[i] = as[i * 32];
@@ -172,10 +161,12 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
                 __builtin_amdgcn_sched_barrier(0);
+                if (kk / 2 < npairs) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 4 < SK_BK) {
 #pragma unroll
@@ -184,12 +175,13 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                     for (int j = 0; j < 2; ++j) b0[j] = bs[(kk + 4) * TB::LD + j * 32];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (kk / 2 + 1 < npairs) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-            }
             }
             if (more || has_next) {
                 ta.store(smem + (cur ^ 1) * BUF);

@@ -393,6 +393,280 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Mid-size batches (8192 < B <= 524288, or several key words): the whole grouping in ONE cooperative launch.
+// The general path above is a chain of ~35 launches (per digit: histogram, scan, scatter; then heads, two device-wide scans,
+// finish) of a few microseconds of work each -- at BASELINE config 3 (B = 65536) 0.38 ms of kernel time stretched over the side
+// stream.  Here G = ceil(B / 2048) <= 256 workgroups (all co-resident: at most one per CU) walk the same phases separated by a
+// grid barrier: identity order + varying-bit words | per digit: local histogram | offsets + stable scatter | segment heads + local
+// counts | ids.  2 + 2 * (non-trivial digits) barriers of ~5 us each (MI355X_MICROARCH.md, barrier-counter row).
+// Barrier = the guide's R1 hand-off: every wave drains its stores, workgroup barrier, lane 0: agent-scope release, arrive on one
+// monotonic counter, relaxed agent-scope poll, agent-scope acquire, workgroup barrier, plain loads.  The poll is bounded (2 s):
+// on a timeout the error word is set, every later barrier returns at once and the host reports RECNOW_EINVAL -- the grid always
+// drains.
+// ------------------------------------------------------------------------------------------------
+#define GM_MAXG 256
+struct GroupMidCtl {          // zeroed by the host before the launch
+    unsigned bar;
+    int err;
+    unsigned mix[2 * RN_MAX_WORDS];
+    unsigned pad[14];
+};
+
+__device__ __forceinline__ void gm_barrier(GroupMidCtl* ctl, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&ctl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&ctl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (wall_clock64() - t0 > 200000000LL) {          // 2 s of the 100 MHz clock
+                __hip_atomic_store(&ctl->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
+            GroupMidCtl* __restrict__ ctl, int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, uint32_t* __restrict__ key0,
+            uint32_t* __restrict__ key1, unsigned* __restrict__ blockhist, int* __restrict__ headcnt, int32_t* __restrict__ order,
+            int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
+    __shared__ unsigned h[256];
+    __shared__ unsigned wcnt[4][256];
+    __shared__ unsigned boff[256];
+    __shared__ unsigned wtot[4];
+    __shared__ unsigned part[4][2 * RN_MAX_WORDS];
+    __shared__ int s_triv[RN_MAX_PASS], s_src[RN_MAX_PASS], s_carried[RN_MAX_PASS], s_wconst[RN_MAX_WORDS], s_final[2];
+    __shared__ int s_cnt[4][2];
+    const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t base = (int64_t)g * RN_TILE;
+    unsigned nbar = 0;
+    // ---- phase 0: identity order, bits that vary over the batch ----------------------------------------------------------
+    {
+        unsigned o[RN_MAX_WORDS], z[RN_MAX_WORDS];
+#pragma unroll
+        for (int w = 0; w < RN_MAX_WORDS; ++w) o[w] = z[w] = 0u;
+        for (int r = 0; r < RN_TILE / 256; ++r) {
+            const int64_t i = base + r * 256 + tid;
+            if (i < B) {
+                idx0[i] = (int32_t)i;
+#pragma unroll
+                for (int w = 0; w < RN_MAX_WORDS; ++w)
+                    if (w < n_words) {
+                        const uint32_t k = words[(int64_t)w * B + i];
+                        o[w] |= k;
+                        z[w] |= ~k;
+                    }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < RN_MAX_WORDS; ++w)
+            if (w < n_words) {
+                unsigned a = o[w], c = z[w];
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) {
+                    a |= __shfl_xor(a, sft, 64);
+                    c |= __shfl_xor(c, sft, 64);
+                }
+                if (lane == 0) { part[wv][w] = a; part[wv][RN_MAX_WORDS + w] = c; }
+            }
+        __syncthreads();
+        if (tid < 2 * n_words) {
+            const int w = tid % n_words, half = tid / n_words, col = half * RN_MAX_WORDS + w;
+            atomicOr(&ctl->mix[half * n_words + w], part[0][col] | part[1][col] | part[2][col] | part[3][col]);
+        }
+    }
+    gm_barrier(ctl, (++nbar) * G);
+    const int np = n_words * 4;
+    if (tid == 0) {          // the pass plan, as k_sort_plan builds it (every workgroup derives the same one)
+        int cur = 0, word_in_buf = -1;
+        for (int p = 0; p < np; ++p) {
+            const int w = n_words - 1 - p / 4, d = p % 4;
+            const unsigned both = __hip_atomic_load(&ctl->mix[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                                  __hip_atomic_load(&ctl->mix[n_words + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int tv = ((both >> (8 * d)) & 255u) == 0u;
+            s_triv[p] = tv;
+            s_src[p] = cur;
+            s_carried[p] = word_in_buf == w;
+            if (!tv) { cur ^= 1; word_in_buf = w; }
+        }
+        s_final[0] = cur;
+        s_final[1] = word_in_buf;
+        for (int w = 0; w < n_words; ++w) {
+            int c = 1;
+            for (int d = 0; d < 4; ++d) c &= s_triv[(n_words - 1 - w) * 4 + d];
+            s_wconst[w] = c;
+        }
+    }
+    __syncthreads();
+    // ---- digits ---------------------------------------------------------------------------------------------------------------
+    for (int p = 0; p < np; ++p) {
+        if (s_triv[p]) continue;                              // block-uniform (and the same in every workgroup)
+        const int sb = s_src[p];
+        const int32_t* src = sb ? idx1 : idx0;
+        int32_t* dst = sb ? idx0 : idx1;
+        const uint32_t* ksrc = sb ? key1 : key0;
+        uint32_t* kdst = sb ? key0 : key1;
+        const bool carried = s_carried[p];
+        const uint32_t* wk = words + (int64_t)(n_words - 1 - p / 4) * B;
+        const int shift = 8 * (p % 4);
+        // this tile's keys (kept in registers for the scatter) and its digit histogram
+        int32_t my_idx[RN_TILE / 256];
+        uint32_t my_key[RN_TILE / 256];
+        h[tid] = 0;
+        for (int t = tid; t < 1024; t += 256) (&wcnt[0][0])[t] = 0;
+        __syncthreads();
+        const int64_t wbase = base + wv * (RN_TILE / 4);
+#pragma unroll
+        for (int r = 0; r < RN_TILE / 256; ++r) {
+            const int64_t e = wbase + r * 64 + lane;
+            const bool ok = e < B;
+            const int32_t id = ok ? src[e] : 0;
+            const uint32_t kv = ok ? (carried ? ksrc[e] : wk[id]) : 0u;
+            my_idx[r] = id;
+            my_key[r] = kv;
+            if (ok) atomicAdd(&h[(kv >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        blockhist[(int64_t)tid * G + g] = h[tid];             // digit-major
+        gm_barrier(ctl, (++nbar) * G);
+        {   // first output position of every digit for this workgroup: counts of the workgroups before it + the digits below
+            const unsigned* row = blockhist + (int64_t)tid * G;
+            unsigned before = 0, total = 0;
+            for (int b = 0; b < G; ++b) {
+                const unsigned v = row[b];
+                before += b < g ? v : 0u;
+                total += v;
+            }
+            unsigned inc = total;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            if (lane == 63) wtot[wv] = inc;
+            __syncthreads();
+            unsigned woff = 0;
+            for (int i = 0; i < wv; ++i) woff += wtot[i];
+            boff[tid] = woff + inc - total + before;
+        }
+        __syncthreads();
+        // stable ranks: wave w owns RN_TILE / 4 consecutive keys, 8 rounds of 64 consecutive keys (as k_sort_scatter)
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        unsigned my_dr[RN_TILE / 256];
+#pragma unroll
+        for (int r = 0; r < RN_TILE / 256; ++r) {
+            const int64_t e = wbase + r * 64 + lane;
+            const bool ok = e < B;
+            const unsigned d = (my_key[r] >> shift) & 255u;
+            unsigned long long peers = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const unsigned prior = ok ? wcnt[wv][d] : 0u;
+            const unsigned rank = prior + (unsigned)__popcll(peers & lt);
+            if (ok && (peers & lt) == 0ull) wcnt[wv][d] = prior + (unsigned)__popcll(peers);
+            my_dr[r] = d | (rank << 8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RN_TILE / 256; ++r) {
+            const int64_t e = wbase + r * 64 + lane;
+            if (e < B) {
+                const unsigned d = my_dr[r] & 255u, rank = my_dr[r] >> 8;
+                unsigned off = boff[d] + rank;
+                for (int pw = 0; pw < wv; ++pw) off += wcnt[pw][d];
+                dst[off] = my_idx[r];
+                kdst[off] = my_key[r];
+            }
+        }
+        gm_barrier(ctl, (++nbar) * G);
+    }
+    // ---- segments: heads of this tile's 2048 sorted positions, 8 consecutive positions per thread ---------------------------------
+    const int32_t* fin = s_final[0] ? idx1 : idx0;
+    const uint32_t* kfin = s_final[0] ? key1 : key0;
+    const int final_word = s_final[1];
+    const int64_t k0 = base + (int64_t)tid * 8;
+    unsigned hb = 0, sb8 = 0;
+    int nh = 0, ns = 0;
+    for (int q = 0; q < 8; ++q) {
+        const int64_t k = k0 + q;
+        if (k >= B) break;
+        const int32_t i = fin[k];
+        int hd = 1, sh = 1;
+        if (k > 0) {
+            const int32_t j = fin[k - 1];
+            const bool so = solo[i] | solo[j];
+            bool diff_first = false, diff_any = false;
+            for (int w = 0; w < n_words; ++w) {
+                if (s_wconst[w]) continue;
+                const bool df = w == final_word ? kfin[k] != kfin[k - 1] : words[(int64_t)w * B + i] != words[(int64_t)w * B + j];
+                diff_any |= df;
+                if (w < n_words_first) diff_first |= df;
+            }
+            hd = (so || diff_any) ? 1 : 0;
+            sh = (so || diff_first) ? 1 : 0;
+        }
+        hb |= (unsigned)hd << q;
+        sb8 |= (unsigned)sh << q;
+        nh += hd;
+        ns += sh;
+        order[k] = i;
+    }
+    // exclusive prefix of (nh, ns) inside the workgroup
+    int inh = nh, ins = ns;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t1 = __shfl_up(inh, o, 64), t2 = __shfl_up(ins, o, 64);
+        if (lane >= o) { inh += t1; ins += t2; }
+    }
+    if (lane == 63) { s_cnt[wv][0] = inh; s_cnt[wv][1] = ins; }
+    __syncthreads();
+    int offh = inh - nh, offs = ins - ns, toth = 0, tots = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < wv) { offh += s_cnt[i][0]; offs += s_cnt[i][1]; }
+        toth += s_cnt[i][0];
+        tots += s_cnt[i][1];
+    }
+    if (tid == 0) { headcnt[2 * g] = toth; headcnt[2 * g + 1] = tots; }
+    gm_barrier(ctl, (++nbar) * G);
+    int preh = 0, pres = 0, allh = 0, alls = 0;              // heads in the workgroups before this one / in all of them
+    for (int b = 0; b < G; ++b) {
+        const int a = headcnt[2 * b], c = headcnt[2 * b + 1];
+        if (b < g) { preh += a; pres += c; }
+        allh += a;
+        alls += c;
+    }
+    int sid = preh + offh, sup = pres + offs;                 // ids of the LAST head before this thread's first position, + 1
+    for (int q = 0; q < 8; ++q) {
+        const int64_t k = k0 + q;
+        if (k >= B) break;
+        if ((hb >> q) & 1u) { seg_first[sid] = (int32_t)k; ++sid; }
+        if ((sb8 >> q) & 1u) ++sup;
+        seg_id[k] = sid - 1;
+        super_id[k] = sup - 1;
+    }
+    if (g == 0 && tid == 0) {
+        const bool bad = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;       // a barrier timed out
+        seg_first[allh] = (int32_t)B;
+        n_seg[0] = bad ? -1 : allh;
+        n_seg[1] = bad ? -1 : alls;
+    }
+}
+
 extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) {
     if (B < 0 || n_words < 1 || n_words > RN_MAX_WORDS) return 0;
     const int nblk = rn_cdiv(B > 0 ? B : 1, RN_TILE);
@@ -403,6 +677,7 @@ extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) 
     s += rn_align((size_t)256 * nblk * sizeof(unsigned));           // blockhist
     s += 4 * rn_align((size_t)(B + 1) * sizeof(int32_t));           // head, shead, seg_incl, super_incl
     s += rn_scan_ws_bytes(B);
+    s += rn_align(sizeof(GroupMidCtl)) + rn_align((size_t)2 * GM_MAXG * sizeof(int));      // cooperative mid-size path
     return s;
 }
 
@@ -429,6 +704,7 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     const int nblk = rn_cdiv(B, RN_TILE);
     RnCarver c(ws, ws_bytes);
     SortPlan* plan = c.take<SortPlan>(1);
+    static const bool coop = []() { const char* e = getenv("RECNOW_GROUP_COOP"); return !e || e[0] != '0'; }();      // A/B switch
     unsigned* ghist = c.take<unsigned>((size_t)n_words * 4 * 256);
     int32_t* idx0 = c.take<int32_t>(B + 1);
     int32_t* idx1 = c.take<int32_t>(B + 1);
@@ -439,6 +715,17 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     int32_t* shead = c.take<int32_t>(B + 1);
     int32_t* seg_incl = c.take<int32_t>(B + 1);
     int32_t* super_incl = c.take<int32_t>(B + 1);
+    if (coop && nblk <= GM_MAXG) {                // one cooperative launch: all nblk workgroups are co-resident (<= one per CU)
+        const size_t scan_bytes = rn_scan_ws_bytes(B);
+        char* tail = c.base + c.off + scan_bytes;
+        GroupMidCtl* ctl = (GroupMidCtl*)tail;
+        int* headcnt = (int*)(tail + rn_align(sizeof(GroupMidCtl)));
+        RN_HIP(hipMemsetAsync(ctl, 0, sizeof(GroupMidCtl), st));
+        hipLaunchKernelGGL(k_group_mid, nblk, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
+                           headcnt, order, seg_id, seg_first, super_id, n_seg);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
     void* scan_ws = (void*)(c.base + c.off);
     size_t scan_ws_bytes = ws_bytes - c.off;
 
