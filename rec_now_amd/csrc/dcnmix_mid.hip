@@ -44,7 +44,7 @@ static inline int mid_fwd_grid(int64_t B, size_t lds) {
     const int64_t tiles = (B + MID_ROWS - 1) / MID_ROWS;
     int per_cu = (int)((160 * 1024) / (lds + 1024));
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;            // registers: two tiles in flight per workgroup cost 219 VGPRs = 2 waves per SIMD
+    if (per_cu > 4) per_cu = 4;
     const int64_t cap = 256 * per_cu;
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
@@ -65,11 +65,10 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
     const int64_t ntiles = (B + MID_ROWS - 1) / MID_ROWS;
     const int cpr = NS / 4;
     const int nch = MID_ROWS * cpr / 256;          // float4 chunks per thread and tile (NS % 32 == 0)
-    // TWO tiles ahead are in flight in registers (sets 0 / 1): with one, a CU had ~24 KB of loads outstanding on average and the
-    // kernel sat at Little's law (2.9 TB/s); the HBM latency now hides under two tiles' work.
-    float4 pv0[MID_PRE], pv1[MID_PRE];
-    float plg0[MID_NMAX], plg1[MID_NMAX];
-    auto prefetch = [&](float4 (&pv)[MID_PRE], float (&plg)[MID_NMAX], int64_t r0) {
+    // The next tile's rows are fetched into registers before this tile's MFMA phase: HBM latency hides under it.
+    float4 pv[MID_PRE];
+    float plg[MID_NMAX];
+    auto prefetch = [&](int64_t r0) {
 #pragma unroll
         for (int i = 0; i < MID_PRE; ++i) {
             pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -83,9 +82,8 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
             for (int n = 0; n < MID_NMAX; ++n) plg[n] = (n < N && r0 + tid < B) ? T1[(r0 + tid) * LDT + NS + n] : -INFINITY;
         }
     };
-    prefetch(pv0, plg0, (int64_t)blockIdx.x * MID_ROWS);
-    if ((int64_t)blockIdx.x + gridDim.x < ntiles) prefetch(pv1, plg1, ((int64_t)blockIdx.x + gridDim.x) * MID_ROWS);
-    auto body = [&](float4 (&pv)[MID_PRE], float (&plg)[MID_NMAX], int64_t tile) {
+    prefetch((int64_t)blockIdx.x * MID_ROWS);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * MID_ROWS;
         __syncthreads();
 #pragma unroll
@@ -129,7 +127,7 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
             }
         }
         __syncthreads();
-        if (tile + 2 * (int64_t)gridDim.x < ntiles) prefetch(pv, plg, (tile + 2 * (int64_t)gridDim.x) * MID_ROWS);     // this set is free again
+        if (tile + gridDim.x < ntiles) prefetch((tile + gridDim.x) * MID_ROWS);
         const int nitems = N * (S / 32);
         for (int item = w; item < nitems; item += 4) {                    // wave-uniform
             const int n = item / (S / 32), cb = item - n * (S / 32);
@@ -152,10 +150,6 @@ k_mix_mid_fwd(const float* __restrict__ T1, const float* __restrict__ V, float* 
                 }
             }
         }
-    };
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += 2 * (int64_t)gridDim.x) {
-        body(pv0, plg0, tile);
-        if (tile + gridDim.x < ntiles) body(pv1, plg1, tile + gridDim.x);
     }
 }
 

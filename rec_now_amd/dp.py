@@ -188,7 +188,8 @@ class LayerwiseReducer(object):
         """Call BEFORE `local_loss_sum.backward()`: packs the two loss statistics on the current stream and marks that point, so
         that `reduce` has nothing to wait for on the main stream but the per-stage events (waiting for the main stream itself
         would wait for the whole backward pass, i.e. no overlap)."""
-        self._stats = torch.stack([local_loss_sum.detach().to(torch.float32), local_count.detach().to(torch.float32)])
+        # straight into the tail of the first bucket (one small kernel on the main stream, before the backward pass)
+        self._stats = torch.stack([local_loss_sum.detach().to(torch.float32), local_count.detach().to(torch.float32)], out=self._flat[0][-2:])
         self._stats_ready = None
         if self.comm is not None:
             self._stats_ready = torch.cuda.Event()
@@ -213,7 +214,6 @@ class LayerwiseReducer(object):
             else:
                 self.comm.wait_stream(main)             # no events / no prepare(): everything enqueued so far, i.e. after the backward pass
         out_stats = None
-        inv = None
         self.last_foreign = 0                           # diagnostics: gradients that had to be copied into their bucket
         with (torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()):
             for i, stage in enumerate(self.stages):
@@ -230,23 +230,23 @@ class LayerwiseReducer(object):
                         view.copy_(p.grad.reshape(-1))
                         foreign.append((p, view))
                         self.last_foreign += 1
-                if i == 0:
+                if i == 0 and not prepared:
                     flat[-2:].copy_(stats)
                 if not _SKIP_COLLECTIVE:
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                n_grad = flat.numel() - (2 if i == 0 else 0)        # the statistics themselves stay unscaled in the first bucket's tail
                 if i == 0:
-                    out_stats = flat[-2:].clone()
-                    inv = 1.0 / (out_stats[1] + eps)
+                    out_stats = flat[-2:]
                 if flat.is_cuda:            # one small launch (torch's broadcast multiply by a 0-dim tensor takes ~30 us per bucket)
                     from . import _lib
-                    _lib.call('recnow_scale_by_inv_count', _lib.ptr(flat), flat.numel(), _lib.ptr(out_stats[1:]), float(eps),
+                    _lib.call('recnow_scale_by_inv_count', _lib.ptr(flat), n_grad, _lib.ptr(out_stats[1:]), float(eps),
                               _lib._P(torch.cuda.current_stream().cuda_stream))
                 else:
-                    flat.mul_(inv)
+                    flat[:n_grad].mul_(1.0 / (out_stats[1] + eps))
                 for p, view in foreign:
                     if self.comm is not None:
                         p.grad.record_stream(self.comm)
                     p.grad.copy_(view.view(p.shape))
         if self.comm is not None:
             main.wait_stream(self.comm)                 # the gradients are final for whatever the main stream does next
-        return out_stats[0] * inv, out_stats[1]
+        return out_stats[0] / (out_stats[1] + eps), out_stats[1].clone()

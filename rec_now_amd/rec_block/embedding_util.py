@@ -64,9 +64,14 @@ class EmbeddingTable(torch.nn.Module):
     `tf.nn.embedding_lookup(params, ids)`).  Passing an instance to embedding_using_sparse_batch_segment_ids selects the
     fused path: the pooled rows are gathered straight from the table, no unique/gather round trip."""
 
-    def __init__(self, params):
+    def __init__(self, params, sparse_grad=False):
+        """sparse_grad: hand the table's gradient back as a torch.sparse_coo_tensor of the rows that were looked up (what the
+        reference path yields: tf.IndexedSlices) instead of a dense, zero-filled (V, D) tensor -- for large tables the dense form is
+        hundreds of MB of memset and optimizer traffic per step.  Costs one host sync per backward (the number of distinct ids is
+        data-dependent); use with an optimizer that accepts sparse gradients (torch.optim.SparseAdam, SGD)."""
         super().__init__()
         self.weight = params if isinstance(params, torch.nn.Parameter) else torch.nn.Parameter(torch.as_tensor(params, dtype=torch.float32))
+        self.sparse_grad = bool(sparse_grad)
 
     def forward(self, ids):
         _lib.require_gpu(ids, 'ids')
@@ -129,7 +134,12 @@ class _PoolFunction(torch.autograd.Function):
         _lib.call('recnow_embed_rows_bwd', _lib.ptr(srt.key), _lib.ptr(s.order), _lib.ptr(s.seg_id), _lib.ptr(s.seg_first),
                   _lib.ptr(s.n_seg), _lib.ptr(seg), _lib.ptr(weights), _lib.ptr(cnt), _lib.ptr(dout), N, C, T, D, 1 if mean else 0,
                   _lib.ptr(drows), _lib.ptr(row_ids), _lib.ptr(ws), ws.numel(), _lib.stream())
-        if dense_scatter:
+        if dense_scatter == 'sparse':
+            n_used = int(s.n_seg[0].item())                    # distinct keys (incl. the one "not pooled" key, which sorts last)
+            ids = row_ids[:n_used]
+            keep = (ids >= 0) & (ids < V)                       # drops the not-pooled key and ids outside the table
+            dtable = torch.sparse_coo_tensor(ids[keep].unsqueeze(0), drows[:n_used][keep], (V, D))
+        elif dense_scatter:
             dtable = torch.zeros((V, D), dtype=torch.float32, device=dev)
             _lib.call('recnow_embed_scatter_rows', _lib.ptr(drows), _lib.ptr(row_ids), N, D, V, _lib.ptr(dtable), _lib.stream())
         else:
@@ -177,7 +187,7 @@ def embedding_using_sparse_batch_segment_ids(embedding_func, slots, target_slots
     srt = _Sorted(key)
     mean = method == 'mean'
     if isinstance(embedding_func, EmbeddingTable):
-        return _PoolFunction.apply(embedding_func.weight, ids, seg, weights, T, mean, srt, True)
+        return _PoolFunction.apply(embedding_func.weight, ids, seg, weights, T, mean, srt, 'sparse' if embedding_func.sparse_grad else True)
     B, C = ids.shape
     N = B * C
     dev = ids.device

@@ -202,3 +202,27 @@ def test_embedding_ids_outside_the_table_read_as_zero_rows(dev):
     # plain lookup through EmbeddingTable(ids)
     got = EmbeddingTable(T_(params).to(dev))(torch.tensor([2, 9, -1], device=dev))
     assert torch.equal(got[0].cpu(), T_(params[2])) and float(got[1:].abs().sum()) == 0.0
+
+
+def test_embedding_table_sparse_gradient(dev):
+    """EmbeddingTable(sparse_grad=True): the table gradient as a sparse COO tensor of the looked-up rows equals the dense one."""
+    from rec_now_amd.rec_block.embedding_util import EmbeddingTable, embedding_using_sparse_batch_segment_ids
+    rng = np.random.default_rng(21)
+    B, C, T, D, V = 200, 30, 6, 16, 500
+    slots = T_(rng.integers(0, T + 2, (B, C)).astype(np.int32)).to(dev)
+    ids = rng.integers(0, V, (B, C)).astype(np.int64)
+    ids[3, 4], ids[7, 1] = V + 5, -2                                   # ids outside the table are dropped
+    ids = T_(ids).to(dev)
+    w = T_(rng.uniform(0.5, 1.5, (B, C)).astype(np.float32)).to(dev)
+    gy = T_(rng.normal(size=(B, T, D)).astype(np.float32)).to(dev)
+    params = T_(rng.normal(size=(V, D)).astype(np.float32)).to(dev)
+    grads = []
+    for sparse in (False, True):
+        table = EmbeddingTable(torch.nn.Parameter(params.clone()), sparse_grad=sparse)
+        out = embedding_using_sparse_batch_segment_ids(table, slots, list(range(T)), ids, weights=w, method='mean')
+        out.backward(gy)
+        g = table.weight.grad
+        assert g.is_sparse == sparse
+        grads.append(g.to_dense() if sparse else g)
+    assert torch.equal(grads[0], grads[1])
+    assert grads[1].abs().sum() > 0

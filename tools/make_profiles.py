@@ -9,7 +9,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 
@@ -55,12 +55,12 @@ json.dump({'kernel_source_sha256': kernel_source_hash(),
                      'WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section (FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950); '
                      'launch-weighted mean over the instantiations of each tile family',
            'hbm_bytes_per_launch': traffic}, open('profiles/traffic.json', 'w'), indent=1)
-steps = 13
+steps = 19      # 3 warm-up + 10 timed + 5 host-enqueue diagnostic + 1 parity step
 with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
     fo.write('# Round %s -- rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline` (1x MI355X)\n\n' % tag[1:])
     fo.write('Raw per-kernel CSV: `%s_bench_kernel_stats.csv`; HBM counters (separate --pmc passes): `%s_bench_pmc_hbm.csv`; bench line of the '
              'same build: `%s_bench.json`; GEMM microbenchmark (`tools/gemm_bench.py`): `%s_gemm_bench.txt`.\n\n' % (tag, tag, tag, tag))
-    fo.write('Sum of kernel durations: %.1f ms over %d steps (3 warm-up + 10 timed) = %.3f ms/step.  The batch-grouping kernels (sort, scans, '
+    fo.write('Sum of kernel durations: %.1f ms over %d steps (3 warm-up + 10 timed + 5 untimed host-enqueue diagnostic + 1 parity step) = %.3f ms/step.  The batch-grouping kernels (sort, scans, '
              'segments) run on a side stream under the forward pass and are stretched by the GEMMs they share the chip with, so this sum is '
              'larger than the wall time per step (see `%s_bench.json`).\n\n' % (tot / 1e6, steps, tot / 1e6 / steps, tag))
     fo.write('| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n')
@@ -68,6 +68,11 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
         fo.write('| `%s` | %s | %.2f | %.1f | %s |\n' % (r['Name'][:100].replace('|', '/'), r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                    float(r['AverageNs']) / 1e3, r['Percentage']))
 shutil.copy('gpurun_out/%s_bench.json' % tag, 'profiles/%s_bench.json' % tag)
+for extra in ('bench_unfused', 'bench_forcedist', 'layer_bench'):
+    for ext in ('json', 'txt'):
+        src = 'gpurun_out/%s_%s.%s' % (tag, extra, ext)
+        if os.path.exists(src):
+            shutil.copy(src, 'profiles/%s_%s.%s' % (tag, extra, ext))
 if os.path.exists('gpurun_out/%s_gemm_bench.txt' % tag):
     lines = [l for l in open('gpurun_out/%s_gemm_bench.txt' % tag) if 'TFLOP' in l]
     open('profiles/%s_gemm_bench.txt' % tag, 'w').writelines(lines)

@@ -2,10 +2,12 @@
 # Run on the GPU box from the repository root (gpurun -- 'bash tools/refresh_profiles.sh r01'): writes the raw material of
 # profiles/ into gpurun_out/; tools/make_profiles.py then turns it into the committed summaries.
 # Every rocprofv3 line starts the program itself (python3), counters are collected in their own passes.
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 mkdir -p $R/gpurun_out
 python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
+python3 $R/bench.py --steps 20 --warmup 5 --unfused --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_unfused.json 2>> $R/gpurun_out/${TAG}_bench.err
+python3 $R/bench.py --steps 20 --warmup 5 --force-dist --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_forcedist.json 2>> $R/gpurun_out/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${TAG}_stats $R/gpurun_out/${TAG}_pmc_fetch $R/gpurun_out/${TAG}_pmc_write
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats.log 2>&1
