@@ -136,8 +136,8 @@ def test_ple_config5_per_rank_size(dev):
     souts = layer(xs)
     sum((o * gy[sub].to(dev)).sum() for o, gy in zip(souts, gys)).backward()
     for o, so in zip(outs, souts):
-        close(so, o[sub], rtol=2e-6)
-    close(xs.grad, xd.grad[sub], rtol=2e-6)
+        close(so, o[sub], rtol=5e-6)           # different batch sizes take different tile paths (summation order); tanh via exp2 / rcp
+    close(xs.grad, xd.grad[sub], rtol=5e-6)
     halves = []
     for lo, hi in ((0, B // 2), (B // 2, B)):
         _zero(layer)
