@@ -253,6 +253,10 @@ typedef struct recnow_gemm_desc {
     /* k_valid (0 = K): the caller guarantees that A's columns / B's rows k_valid .. K-1 are ZERO (a depth padded to the k-tile);
      * the short-K kernel then skips the MFMA steps of the padding (DCN-v2: 130 of 144). */
     int k_valid; int k_pad;
+    /* c_perm_s > 0 (split-K products only, batch 1, no transposed store / accumulate; else RECNOW_EINVAL / EUNSUPPORTED): the result
+     * is stored as [N / c_perm_s][M][c_perm_s] instead of [M][N], C[((n / s) * M + m) * s + n % s] -- DCN-v2's dU (N, D, S) straight
+     * from the product x_l^T dA (D x N*S), without an unpack pass. */
+    int c_perm_s; int c_perm_pad;
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;

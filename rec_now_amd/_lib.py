@@ -112,7 +112,7 @@ class GemmDesc(ctypes.Structure):
         ('sp_bx', _P), ('sp_cx', _P), ('sp_bx_ks', _L), ('sp_bx_rs', _L), ('sp_cx_ms', _L), ('sp_cx_rs', _L), ('sp_r', _I), ('sp_pad', _I),
         ('eu_p', _P), ('eu_q', _P), ('eu_pms', _L), ('eu_qrs', _L), ('eu_qns', _L), ('eu_r', _I), ('eu_pad', _I), ('prof_flops', ctypes.c_double),
         ('C2', _P), ('ldc2', _L), ('E2', _P), ('lde2', _L), ('c2_mode', _I), ('c2_pad', _I), ('as_in', _P), ('as_out', _P),
-        ('E3', _P), ('lde3', _L), ('rv', _P), ('cv', _P), ('hv', _P), ('hp', _P), ('hp_ld', _I), ('hp_pad', _I), ('k_valid', _I), ('k_pad', _I),
+        ('E3', _P), ('lde3', _L), ('rv', _P), ('cv', _P), ('hv', _P), ('hp', _P), ('hp_ld', _I), ('hp_pad', _I), ('k_valid', _I), ('k_pad', _I), ('c_perm_s', _I), ('c_perm_pad', _I),
     ]
 
 _ERR = {-1: 'RECNOW_EINVAL', -2: 'RECNOW_EWORKSPACE', -3: 'RECNOW_EUNSUPPORTED'}

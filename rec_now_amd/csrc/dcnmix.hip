@@ -714,9 +714,17 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = D; d.N = m.NS; d.K = (int)B;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.sp_bx = dT1 + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dgate_host[l]; d.sp_cx_ms = N; d.sp_cx_rs = 1; d.sp_r = N;
-            if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
-            hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st2, dWc1, D, S, N, dU_host[l]);
-            RN_LAUNCH_CHECK();
+            // K = B is always split at these sizes: the slab reduce stores dU (N, D, S) directly; without a split, unpack afterwards
+            recnow_gemm_desc dq = d;
+            dq.C = dU_host[l]; dq.c_perm_s = S;
+            rc = rn_gemm(&dq, gws2, gemm_ws, st2);
+            if (rc == RECNOW_EUNSUPPORTED) {
+                if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
+                hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st2, dWc1, D, S, N, dU_host[l]);
+                RN_LAUNCH_CHECK();
+            } else if (rc) {
+                return rc;
+            }
         }
         MIX_SIGNAL(e_side_prev, st2);
         // every weight gradient of layer l has been issued (dW, dbias above; dV in the sub-space kernel; dU, dgate just now): a

@@ -64,6 +64,7 @@ k_gemm_splitk_reduce(const GemmK p) {
                 v *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(ev, p.e_act) : ev;
             }
             float* dst = p.C + (int64_t)b * p.sC + (p.c_trans ? ((int64_t)c * p.ldc + row) : ((int64_t)row * p.ldc + c));
+            if (p.perm_s > 0) dst = p.C + ((int64_t)(c / p.perm_s) * p.M + row) * p.perm_s + (c % p.perm_s);      // [N/s][M][s] layout
             if (p.accumulate) v += *dst;
             *dst = v;
         }
@@ -153,9 +154,15 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     if (d->sp_r > 0 && (!d->sp_bx || !d->sp_cx || d->batch != 1)) return RECNOW_EINVAL;
     if (d->eu_r > 0 && (!d->eu_p || !d->eu_q || d->batch != 1)) return RECNOW_EINVAL;
     pick_split(d, c, &k.splitk, &k.kchunk);
+    if (d->c_perm_s > 0) {
+        if (k.splitk <= 1) return RECNOW_EUNSUPPORTED;       // the permuted store lives in the split-K reduce
+        k.perm_s = d->c_perm_s;
+    }
     k.trace = nullptr;
     k.cu_slots = nullptr; k.stagger_ticks = 0;
     k.tail_pairs = 8;
+    k.perm_s = 0;
+    if (d->c_perm_s < 0 || (d->c_perm_s > 0 && (d->N % d->c_perm_s || d->batch != 1 || d->c_trans || d->accumulate))) return RECNOW_EINVAL;
     if (d->k_valid < 0 || d->k_valid > d->K) return RECNOW_EINVAL;
     static const bool sk_tail = []() { const char* e = getenv("RECNOW_SK_TAIL"); return !e || e[0] != '0'; }();      // A/B switch
     if (sk_tail && d->k_valid > 0 && d->K % 16 == 0 && d->k_valid > d->K - 16) k.tail_pairs = (d->k_valid - (d->K - 16) + 1) / 2;      // pairs of the last 16-deep tile

@@ -44,6 +44,7 @@ struct GemmK {
     const float* hv;           // c2_mode 3: column vector of the fused row-dot (the scoring head's kernel)
     float* hp;                 // c2_mode 3: partials hp[m][hp_ld], entry 2 * column tile + wave column
     int hp_ld;
+    int perm_s;                // split-K reduce: > 0 stores C[row][c] at C[((c / perm_s) * M + row) * perm_s + c % perm_s] (see recnow_gemm_desc.c_perm_s)
     int tail_pairs;            // short-K kernel: k-pairs of the LAST k-tile that hold data (8 = all; fewer: a zero-padded depth)
     int* cu_slots;             // short-K kernel: per-CU arrival counters of the phase stagger (NULL: no stagger)
     int stagger_ticks;         // delay per arrival slot, in 10 ns ticks of the constant 100 MHz clock

@@ -439,3 +439,61 @@ def test_small_route_int_ids_determinism_and_routing(dev):
     # not this route: two group tensors, 64-bit ids, more than 8192 rows
     assert _small_route([gi, gi]) is None and _small_route(gi.to(torch.int64)) is None
     assert _small_route(torch.zeros(8193, device=dev)) is None
+
+
+# ---- grouping machinery at mid sizes: the cooperative single-launch path (k_group_mid), several key words ----------------------------
+@pytest.mark.parametrize('B,kind', [(30000, 'f32'), (30000, 'pair_f32'), (70000, 'i64'), (9000, 'f64'), (300000, 'f32_wide'),
+                                    (524288, 'pair_mixed'), (12345, 'all_equal')])
+def test_build_segments_invariants_mid_sizes(dev, B, kind):
+    """Segments of 8192 < B <= 524288 rows (one cooperative launch) and of multi-word keys: the order is a permutation, rows of a
+    segment are ascending (stable sort), rows share a segment iff every key word matches (NaN / inf ids are segments of their own),
+    seg_first / n_seg are consistent, and the super segments follow the FIRST group tensor only."""
+    from rec_now_amd.rec_block._segments import build_segments
+    rng = np.random.default_rng(B % 1000 + len(kind))
+    if kind == 'f32':
+        gs = [rng.integers(0, 500, B).astype(np.float32)]
+        gs[0][::1013] = np.nan
+        gs[0][5::2027] = np.inf
+    elif kind == 'pair_f32':
+        gs = [rng.integers(0, 40, B).astype(np.float32), rng.integers(0, 7, B).astype(np.float32)]
+    elif kind == 'i64':
+        gs = [rng.integers(-2 ** 40, 2 ** 40, 300)[rng.integers(0, 300, B)].astype(np.int64)]
+    elif kind == 'f64':
+        gs = [rng.normal(size=200)[rng.integers(0, 200, B)].astype(np.float64)]
+    elif kind == 'f32_wide':
+        gs = [rng.normal(size=5000).astype(np.float32)[rng.integers(0, 5000, B)]]
+    elif kind == 'pair_mixed':
+        gs = [rng.integers(0, 3000, B).astype(np.int32), rng.integers(0, 3, B).astype(np.float32)]
+    else:
+        gs = [np.full(B, -0.0, np.float32)]
+        gs[0][::2] = 0.0                                            # -0.0 and +0.0 are one group
+    seg = build_segments([torch.from_numpy(g).to(dev) for g in gs])
+    order, seg_id, super_id = (t.cpu().numpy()[:B] for t in (seg.order, seg.seg_id, seg.super_id))
+    n_seg, n_super = (int(v) for v in seg.n_seg.cpu().numpy())
+    seg_first = seg.seg_first.cpu().numpy()[:n_seg + 1]
+    assert n_seg >= 1 and np.array_equal(np.sort(order), np.arange(B))
+    assert seg_first[0] == 0 and seg_first[-1] == B and np.all(np.diff(seg_first) > 0)
+    assert np.array_equal(seg_id, np.repeat(np.arange(n_seg), np.diff(seg_first)))
+    same_seg = seg_id[1:] == seg_id[:-1]
+    assert np.all(order[1:][same_seg] > order[:-1][same_seg])                       # stable: ascending rows inside a segment
+
+    def canon(g):
+        g = g[order]
+        solo = ~np.isfinite(g) if g.dtype.kind == 'f' else np.zeros(B, bool)
+        return np.where(g == 0, 0, g) if g.dtype.kind == 'f' else g, solo
+
+    keys = [canon(g) for g in gs]
+    solo = np.zeros(B, bool)
+    for _, so in keys:
+        solo |= so
+    eq_all = np.ones(B - 1, bool)
+    for k, _ in keys:
+        eq_all &= k[1:] == k[:-1]
+    eq_all &= ~(solo[1:] | solo[:-1])
+    assert np.array_equal(same_seg, eq_all)                                           # neighbours share a segment iff all words match
+    # globally: the number of segments = distinct composite keys among the finite rows + one per solo row
+    fin = ~solo
+    comp = np.stack([k[fin].astype(np.float64) if k.dtype.kind == 'f' else k[fin] for k, _ in keys], 1)
+    assert n_seg == len(np.unique(comp, axis=0)) + int(solo.sum())
+    eq_first = (keys[0][0][1:] == keys[0][0][:-1]) & ~(solo[1:] | solo[:-1])
+    assert np.array_equal(super_id[1:] == super_id[:-1], eq_first) and n_super == super_id[-1] + 1
