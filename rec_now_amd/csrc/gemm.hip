@@ -154,6 +154,7 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     if (d->sp_r > 0 && (!d->sp_bx || !d->sp_cx || d->batch != 1)) return RECNOW_EINVAL;
     if (d->eu_r > 0 && (!d->eu_p || !d->eu_q || d->batch != 1)) return RECNOW_EINVAL;
     pick_split(d, c, &k.splitk, &k.kchunk);
+    k.perm_s = 0;
     if (d->c_perm_s > 0) {
         if (k.splitk <= 1) return RECNOW_EUNSUPPORTED;       // the permuted store lives in the split-K reduce
         k.perm_s = d->c_perm_s;
@@ -161,7 +162,8 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     k.trace = nullptr;
     k.cu_slots = nullptr; k.stagger_ticks = 0;
     k.tail_pairs = 8;
-    k.perm_s = 0;
+    static const int gemm_prio = []() { const char* e = getenv("RECNOW_GEMM_PRIO"); return e ? atoi(e) : 0; }();     // A/B switch
+    k.prio = gemm_prio;
     if (d->c_perm_s < 0 || (d->c_perm_s > 0 && (d->N % d->c_perm_s || d->batch != 1 || d->c_trans || d->accumulate))) return RECNOW_EINVAL;
     if (d->k_valid < 0 || d->k_valid > d->K) return RECNOW_EINVAL;
     static const bool sk_tail = []() { const char* e = getenv("RECNOW_SK_TAIL"); return !e || e[0] != '0'; }();      // A/B switch

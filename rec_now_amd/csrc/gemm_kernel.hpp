@@ -44,6 +44,7 @@ struct GemmK {
     const float* hv;           // c2_mode 3: column vector of the fused row-dot (the scoring head's kernel)
     float* hp;                 // c2_mode 3: partials hp[m][hp_ld], entry 2 * column tile + wave column
     int hp_ld;
+    int prio;                  // short-K kernel: raise the wave priority inside the k-loop (experiment)
     int perm_s;                // split-K reduce: > 0 stores C[row][c] at C[((c / perm_s) * M + row) * perm_s + c % perm_s] (see recnow_gemm_desc.c_perm_s)
     int tail_pairs;            // short-K kernel: k-pairs of the LAST k-tile that hold data (8 = all; fewer: a zero-padded depth)
     int* cu_slots;             // short-K kernel: per-CU arrival counters of the phase stagger (NULL: no stagger)
@@ -367,6 +368,9 @@ k_gemm(const GemmK p) {
     if (ntile > 1) issue_loads(1);
     __syncthreads();
     RN_TR(1);
+    if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntile) {                      // k-tile t+1: registers -> the buffer k-tile t-1 was read from
@@ -439,6 +443,7 @@ k_gemm(const GemmK p) {
         __syncthreads();
     }
 
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
     RN_TR(2);
     // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);

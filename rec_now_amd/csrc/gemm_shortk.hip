@@ -117,6 +117,11 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
 #define SK_TR(i) do { } while (0)
 #endif
         SK_TR(0); SK_TR(1);
+        // k-loop: its fragment reads and MFMAs go ahead of the co-resident workgroups' epilogue instructions (issue is arbitrated by
+        // priority, then age: MI355X_MICROARCH.md, 'Two waves per SIMD'); measured 227 -> 214 us per launch
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -190,6 +195,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
             __syncthreads();
         }
         SK_TR(2);
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
         // buffer `fr` was consumed by the last k-tile and is free: staging space of the epilogue (16 rows x 36 per wave)
         const int fr = (f + nk - 1) & 1;
         float* stg = smem + fr * BUF + wave * (16 * 36);
@@ -293,6 +299,8 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
     static int* cu_slots = nullptr;
     kk.cu_slots = nullptr;
     kk.stagger_ticks = 0;
+    static const int prio = []() { const char* e = getenv("RECNOW_SK_PRIO"); return e ? atoi(e) : 1; }();     // 0 = off (A/B switch)
+    kk.prio = prio;
     if (stagger_us > 0 && grid >= 512) {
         if (!cu_slots) {
             if (hipMalloc((void**)&cu_slots, 4096 * sizeof(int)) != hipSuccess) return RECNOW_EINVAL;
