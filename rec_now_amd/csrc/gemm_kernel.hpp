@@ -389,6 +389,7 @@ k_gemm(const GemmK p) {
         // ONE loop form for full and tail tiles (two forms make the compiler shuffle every accumulator between them):
         // kv = valid k of this tile; rows beyond it are zero in LDS, so the (at most one) surplus k-step adds zeros.
         const int kv = EDGE ? min(BK, k_end - (k_begin + t * BK)) : BK;
+        if (p.prio == 4) __builtin_amdgcn_s_setprio(1);       // experiment: the MFMA loop above the other workgroup's staging section
         float a0[TM], b0[TN], a1[TM], b1[TN];      // explicit fragment double buffer: step kk+2 loads under step kk's MFMAs
 #pragma unroll
         for (int i = 0; i < TM; ++i) a0[i] = as[i * 32];
@@ -425,6 +426,7 @@ k_gemm(const GemmK p) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (p.prio == 4) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
     if constexpr ((XF & 1) != 0) {

@@ -116,3 +116,85 @@ def test_fused_score_falls_back_for_other_shapes(dev):
     head2(cross2(xd2[:256]))
     assert not fused_route_available(cross2, head2, xd2)
     assert dcn_mix_score(cross2, head2, xd2).shape == (512,)
+
+
+def test_one_rank_rccl_group_equals_plain_path(dev):
+    """The N > 1 path of bench.py on ONE GPU: a 1-rank RCCL group with every collective forced on (`dp.FORCE_COLLECTIVES`, what
+    `bench.py --force-dist` sets) -- the layer-wise in-place all-reduce behind the per-layer events and the one-bucket form after
+    the backward pass -- gives the loss and every gradient of the plain single-process path."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from rec_now_amd import dp
+    from rec_now_amd.fused import GpuEvent, dcn_mix_score, score_params
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss_fused
+    B, D, S, N, L = 2048, 256, 64, 2, 3
+    x, xd, cross, head, w, hk, hb = _build(dev, B, D, S, N, L, 21)
+    rng = np.random.default_rng(4)
+    gd = torch.from_numpy(rng.integers(0, 40, B).astype(np.int64)).to(dev)
+    yd = torch.from_numpy(rng.integers(0, 2, B).astype(np.float32)).to(dev)
+    params = score_params(cross, head)
+
+    def clear():
+        for p in params:
+            p.grad = None
+        xd.grad = None
+
+    def snap():
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in params] + [xd.grad.detach().clone()]
+
+    # the head-bias gradient is sum(d loss / d score) = 0 up to rounding: compare it on the scale of its terms (sum |ds| <= 1)
+    scale_of = lambda r, p: 1.0 if p is head.bias else float(r.abs().max())     # noqa: E731
+
+    # plain: normalise, then backward
+    clear()
+    ls, npair = pairwise_loss_fused(dcn_mix_score(cross, head, xd), yd, gd, reduce_mean=False)
+    loss_bw, loss_plain, _ = dp.global_pairwise_loss(ls, npair)
+    loss_bw.backward()
+    plain = snap()
+    assert float(npair) > 0 and abs(float(loss_plain) - np.log(2.0)) > 1e-3
+
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', device_id=dev)
+    dp.FORCE_COLLECTIVES = True
+    try:
+        assert dp.is_dist()
+        inv = 1.0 / (float(npair) + 1e-10)
+        # (a) layer-wise: gradients written into per-layer buckets, all-reduced in place behind the layer's event
+        events = [GpuEvent() for _ in range(L)]
+        per_layer = lambda l: [cross.origin_to_sub_kernels[l], cross.sub_to_sub_kernels[l], cross.sub_to_origin_kernels[l],     # noqa: E731
+                               cross.biases[l], cross.gate_layers[l].kernel]
+        stages = [per_layer(L - 1) + [head.kernel, head.bias]] + [per_layer(l) for l in range(L - 2, -1, -1)]
+        lw = dp.LayerwiseReducer(stages, [events[l] for l in range(L - 1, -1, -1)], dev)
+        gbuf = [lw.buffer_of(p) for p in params]
+        for rep in range(2):                           # twice: the buckets are reused step after step
+            clear()
+            ls, npair2 = pairwise_loss_fused(dcn_mix_score(cross, head, xd, layer_events=events, grad_buffers=gbuf), yd, gd,
+                                             reduce_mean=False)
+            lw.prepare(ls, npair2)
+            ls.backward()
+            loss_lw, p_glob = lw.reduce(ls, npair2)
+            got = snap()
+            assert lw.last_foreign == 0                # every gradient was produced inside its bucket
+            assert float(p_glob) == float(npair)
+            close(loss_lw, loss_plain, rtol=1e-6, what='loss (layer-wise reducer)')
+            for g, r, p in zip(got[:-1], plain[:-1], params):
+                close(g.reshape(-1), r.reshape(-1), rtol=2e-6, what='layer-wise reducer gradient', scale=scale_of(r, p))
+            close(got[-1] * inv, plain[-1], rtol=2e-6, what='dx (unnormalised backward x 1/P)')
+        # (b) one bucket after the backward pass
+        clear()
+        ls, npair3 = pairwise_loss_fused(dcn_mix_score(cross, head, xd), yd, gd, reduce_mean=False)
+        ls.backward()
+        loss_one, _ = dp.GradientAllReducer(params).all_reduce_with_loss(ls, npair3)
+        got = snap()
+        close(loss_one, loss_plain, rtol=1e-6, what='loss (one bucket)')
+        for g, r, p in zip(got[:-1], plain[:-1], params):
+            close(g.reshape(-1), r.reshape(-1), rtol=2e-6, what='one-bucket gradient', scale=scale_of(r, p))
+    finally:
+        dp.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()
