@@ -80,6 +80,7 @@ struct Tile {
     static constexpr bool RAGGED = (NF4 % GEMM_THREADS) != 0;                   // last slot only for some threads
     static constexpr int LD = KC ? ROWS + 1 : ROWS;
     f32x4 v[NV];
+    f32x4 y[NV];          // sliced schedule only: second operand (MUL / ACTGRAD) or OUTER scale (.x), combined at commit time
     unsigned off[NV];     // element offset of this thread's float4 inside a tile; tile-invariant (set once by init)
 
     // A tile's addresses are (block-uniform tile base) + off[i]: the base lives in SGPRs and advances per k-tile, the
@@ -232,22 +233,50 @@ struct Tile {
         }
     }
 
+    __device__ __forceinline__ void store_slot(int i, float* __restrict__ S) const {
+        int r, k;
+        coords(threadIdx.x + i * GEMM_THREADS, r, k);
+        if (!has(i)) return;
+        if (KC) {
+            float* s = S + k * LD + r;
+            s[0] = v[i].x;
+            s[LD] = v[i].y;
+            s[2 * LD] = v[i].z;
+            s[3 * LD] = v[i].w;
+        } else {
+            *reinterpret_cast<f32x4*>(S + k * LD + r) = v[i];
+        }
+    }
     __device__ __forceinline__ void store(float* __restrict__ S) const {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = 0; i < NV; ++i) store_slot(i, S);
+    }
+
+    // Sliced schedule of the lean kernels (fast tiles only): slot i of the NEXT-BUT-ONE k-tile is requested with issue()
+    // and nothing waits for it; commit() -- one k-tile of MFMAs later -- combines it with its second operand and writes it
+    // to LDS.  (Combining at load time put an `s_waitcnt vmcnt` right behind the loads: the MUL / ACTGRAD / OUTER kernels
+    // sat out the HBM latency of every k-tile in front of their MFMA loop.)
+    template <int K2>
+    __device__ __forceinline__ void issue(int i, const float* __restrict__ p, const float* __restrict__ p2, int64_t ld,
+                                          int r0, int k0, int64_t ld2, int hq) {
+        if (!has(i)) return;
+        if (K2 == RECNOW_OPMODE_OUTER) {
             int r, k;
             coords(threadIdx.x + i * GEMM_THREADS, r, k);
-            if (!has(i)) continue;
-            if (KC) {
-                float* s = S + k * LD + r;
-                s[0] = v[i].x;
-                s[LD] = v[i].y;
-                s[2 * LD] = v[i].z;
-                s[3 * LD] = v[i].w;
-            } else {
-                *reinterpret_cast<f32x4*>(S + k * LD + r) = v[i];
-            }
+            const int row = KC ? r0 + r : k0 + k, col = KC ? k0 + k : r0 + r;
+            v[i] = *reinterpret_cast<const f32x4*>(p + (int64_t)row * ld + (col % hq));
+            y[i].x = p2[(int64_t)row * ld2 + (col / hq)];
+        } else {
+            const int64_t base = tile_base(ld, r0, k0);
+            v[i] = *reinterpret_cast<const f32x4*>(p + base + off[i]);
+            if (K2 != RECNOW_OPMODE_NONE) y[i] = *reinterpret_cast<const f32x4*>(p2 + base + off[i]);
         }
+    }
+    template <int K2>
+    __device__ __forceinline__ void commit(int i, float* __restrict__ S, int act) {
+        if (K2 == RECNOW_OPMODE_OUTER) v[i] = mk4(v[i].x * y[i].x, v[i].y * y[i].x, v[i].z * y[i].x, v[i].w * y[i].x);
+        else if (K2 != RECNOW_OPMODE_NONE) v[i] = gemm_combine(v[i], y[i], K2, act);
+        store_slot(i, S);
     }
 };
 
@@ -335,6 +364,41 @@ k_gemm(const GemmK p) {
     ta.init(p.lda);
     tb.init(p.ldb);
     const int ntile = (k_end - k_begin + BK - 1) / BK;
+    // SLICED (lean kernels with compile-time operand kinds): the LDS writes of k-tile t+1 and the loads of k-tile t+2 are cut
+    // into per-slot slices that sit BETWEEN the MFMA groups of k-tile t (each slice issues while the last MFMA of its group
+    // executes), instead of in a staging section between the barrier and the MFMA loop where -- the two workgroups of a CU
+    // run in lockstep -- no wave of the CU had an MFMA to issue (counters: pipe idle 30 % of the kernel).
+    constexpr bool SLICED = !EDGE && A2K >= 0 && B2K >= 0 && (XF & 4) == 0;
+    constexpr int NSL = TA::NV + TB::NV;
+    auto a_issue = [&](int i, int k0) { ta.template issue<A2K>(i, Ab, A2b, p.lda, m0, k0, p.a_ld2, p.a_hq); };
+    auto b_issue = [&](int i, int k0) { tb.template issue<B2K>(i, Bb, B2b, p.ldb, n0, k0, p.b_ld2, p.b_hq); };
+    if constexpr (SLICED) {
+        if (ntile > 0) {
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) a_issue(i, k_begin);
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) b_issue(i, k_begin);
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) ta.template commit<A2K>(i, As, p.a_act);
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) tb.template commit<B2K>(i, Bs, p.b_act);
+            if ((XF & 1) && threadIdx.x < BK) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    bxr[r] = r < p.sp_r ? p.bx[(int64_t)(k_begin + threadIdx.x) * p.bx_ks + r * p.bx_rs] : 0.f;
+                *reinterpret_cast<f32x4*>(Bxs + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
+            }
+            const int k1 = k_begin + min(1, ntile - 1) * BK;
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) a_issue(i, k1);
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) b_issue(i, k1);
+            if ((XF & 1) && threadIdx.x < BK) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bxr[r] = r < p.sp_r ? p.bx[(int64_t)(k1 + threadIdx.x) * p.bx_ks + r * p.bx_rs] : 0.f;
+            }
+        }
+    } else
     if (ntile > 0) {
         const bool kf = !EDGE || (k_begin + BK <= k_end);
         if ((XF & 4) != 0 && blockIdx.y == 0) ta.load_fast_side(Ab, A2b, p.as_in, p.as_out, p.lda, m0, k_begin);      // one column tile writes the side output
@@ -365,7 +429,7 @@ k_gemm(const GemmK p) {
             for (int r = 0; r < 4; ++r) bxr[r] = r < p.sp_r ? p.bx[(int64_t)kx * p.bx_ks + r * p.bx_rs] : 0.f;
         }
     };
-    if (ntile > 1) issue_loads(1);
+    if (!SLICED && ntile > 1) issue_loads(1);
     __syncthreads();
     RN_TR(1);
     if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -373,6 +437,14 @@ k_gemm(const GemmK p) {
     else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
+        if constexpr (SLICED) {
+            if ((XF & 1) && threadIdx.x < BK) {   // side-product weights: k-tile t+1 to LDS, t+2 requested (clamped: unconditional)
+                *reinterpret_cast<f32x4*>(Bxs + (cur ^ 1) * BK * 4 + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
+                const int kx = k_begin + min(t + 2, ntile - 1) * BK + threadIdx.x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bxr[r] = r < p.sp_r ? p.bx[(int64_t)kx * p.bx_ks + r * p.bx_rs] : 0.f;
+            }
+        } else
         if (t + 1 < ntile) {                      // k-tile t+1: registers -> the buffer k-tile t-1 was read from
             ta.store(As + (cur ^ 1) * A_SZ);
             tb.store(Bs + (cur ^ 1) * B_SZ);
@@ -398,6 +470,54 @@ k_gemm(const GemmK p) {
         // sched_barrier(0) pins "issue the NEXT step's ds_reads, then this step's MFMAs": without it hipcc sinks the
         // reads below the MFMAs and waits lgkmcnt(0) right in front of their first use (seen in the .s).  An fp32
         // 32x32x2 MFMA group is >= 256 cycles, far longer than the LDS latency, so nothing finer is needed.
+        if constexpr (SLICED) {
+            // slot s of k-tile t+1 goes registers -> the LDS buffer k-tile t-1 was read from (free since the barrier that
+            // opened this iteration), then the same registers request slot s of k-tile t+2 (index clamped to the last tile, so
+            // neither half is under a branch: the surplus stores land in a buffer nobody reads, the surplus loads hit L2)
+            constexpr int NG = BK / 2;             // MFMA groups per k-tile
+            const int k2 = k_begin + min(t + 2, ntile - 1) * BK;
+            float* const As_n = As + (cur ^ 1) * A_SZ;
+            float* const Bs_n = Bs + (cur ^ 1) * B_SZ;
+            auto stage = [&](int g) {
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) {
+                    if (sl * NG / NSL != g) continue;
+                    if (sl < TA::NV) { ta.template commit<A2K>(sl, As_n, p.a_act); a_issue(sl, k2); }
+                    else { tb.template commit<B2K>(sl - TA::NV, Bs_n, p.b_act); b_issue(sl - TA::NV, k2); }
+                }
+            };
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
+                if constexpr ((XF & 1) != 0) {
+                    const int kq = kk >> 1;
+                    spacc += asx[kq * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + kq * 4);
+                    spacc += asx[(kq + 1) * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + (kq + 1) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                stage(kk / 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const int kn = kk + 4 < BK ? kk + 4 : BK - 2;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[i] = as[kn * TA::LD + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b0[j] = bs[kn * TB::LD + j * 32];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                stage(kk / 2 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         for (int kk = 0; kk < kv; kk += 4) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
