@@ -435,6 +435,12 @@ k_gemm(const GemmK p) {
     if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (p.prio == 5) {
+        // asymmetric: the workgroup in the even wave slot of its SIMDs runs above its co-resident twin.  Two equal workgroups that
+        // share the MFMA pipe fairly finish every k-tile together, sit in their barriers together and leave the pipe idle
+        // together; with a strict order the favoured one runs as if alone and the other fills its gaps.
+        if ((__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11)) & 1) == 0) __builtin_amdgcn_s_setprio(2);
+    }
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1;
         if constexpr (SLICED) {
@@ -486,16 +492,33 @@ k_gemm(const GemmK p) {
                     else { tb.template commit<B2K>(sl - TA::NV, Bs_n, p.b_act); b_issue(sl - TA::NV, k2); }
                 }
             };
+            // side product: the operands of iteration kk are read one iteration ahead and the FMAs are pinned behind the first
+            // MFMA group (an empty volatile asm on the accumulator: hipcc otherwise sinks all 32 packed FMAs of the k-tile to the
+            // end of the tile, a serial VALU tail in front of every barrier with 80 registers held for it)
+            float sa0 = 0.f, sa1 = 0.f;
+            f32x4 sb0 = mk4(0.f, 0.f, 0.f, 0.f), sb1 = sb0;
+            if constexpr ((XF & 1) != 0) {
+                sa0 = asx[0];
+                sa1 = asx[TA::LD];
+                sb0 = *reinterpret_cast<const f32x4*>(bxs);
+                sb1 = *reinterpret_cast<const f32x4*>(bxs + 4);
+            }
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
+                float na0 = 0.f, na1 = 0.f;
+                f32x4 nb0 = sb0, nb1 = sb1;
                 if constexpr ((XF & 1) != 0) {
-                    const int kq = kk >> 1;
-                    spacc += asx[kq * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + kq * 4);
-                    spacc += asx[(kq + 1) * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + (kq + 1) * 4);
+                    if (kk + 4 < BK) {
+                        const int kq = (kk >> 1) + 2;
+                        na0 = asx[kq * TA::LD];
+                        na1 = asx[(kq + 1) * TA::LD];
+                        nb0 = *reinterpret_cast<const f32x4*>(bxs + kq * 4);
+                        nb1 = *reinterpret_cast<const f32x4*>(bxs + (kq + 1) * 4);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -503,6 +526,11 @@ k_gemm(const GemmK p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
                 stage(kk / 2);
+                if constexpr ((XF & 1) != 0) {
+                    spacc += sa0 * sb0;
+                    spacc += sa1 * sb1;
+                    asm volatile("" : "+v"(spacc));
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const int kn = kk + 4 < BK ? kk + 4 : BK - 2;
 #pragma unroll
@@ -516,6 +544,7 @@ k_gemm(const GemmK p) {
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
                 stage(kk / 2 + 1);
                 __builtin_amdgcn_sched_barrier(0);
+                sa0 = na0; sa1 = na1; sb0 = nb0; sb1 = nb1;
             }
         } else
         for (int kk = 0; kk < kv; kk += 4) {
@@ -547,7 +576,16 @@ k_gemm(const GemmK p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (p.prio == 4) __builtin_amdgcn_s_setprio(0);
+#ifdef RN_GEMM_TRACE      // per-wave barrier arrival / departure of the first 64 workgroups (tools/gemm_trace.py, second table)
+        const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        long long* const tr2 = (p.trace && wg_lin < 64 && t < 64 && lane == 0)
+                                   ? p.trace + 8ll * gridDim.x * gridDim.y * gridDim.z + ((wg_lin * 4 + wave) * 64 + t) * 2 : nullptr;
+        if (tr2) tr2[0] = clock64();
         __syncthreads();
+        if (tr2) tr2[1] = clock64();
+#else
+        __syncthreads();
+#endif
     }
     if constexpr ((XF & 1) != 0) {
         // combine the two k-halves through LDS (free now) and write the side columns

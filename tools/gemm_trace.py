@@ -8,14 +8,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = [sys.argv[0], '1', sys.argv[1]] if len(sys.argv) > 1 else [sys.argv[0], '1', '7']
 dev = torch.device('cuda:0')
-tr = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+tr = torch.zeros(8192 * 8 + 64 * 4 * 64 * 2, dtype=torch.int64, device=dev)
 import tools.gemm_bench as gb   # runs once untraced (argv -> reps=1, one shape)
 os.environ['RECNOW_GEMM_TRACE'] = str(tr.data_ptr())
 gb.reps = 1
 s = gb.SHAPES[int(sys.argv[2])]
 gb.run(*s)
 torch.cuda.synchronize()
-t = tr.cpu().numpy().reshape(-1, 8)
+raw = tr.cpu().numpy()
+t = raw[:8192 * 8].reshape(-1, 8)
 t = t[t[:, 0] != 0]
 t0 = t[:, 0].min()
 st, pro, ml, end = [(t[:, i] - t0) / 100.0 for i in range(4)]     # us (100 MHz)
@@ -38,3 +39,26 @@ order = sel[np.argsort(st[sel])]
 print('timeline of one CU (start, prologue_done, mainloop_done, end) us; wave slot:')
 for i in order[:24]:
     print('  blk %5d  %7.2f %7.2f %7.2f %7.2f  slot %d simd %d' % (i, st[i], pro[i], ml[i], end[i], hw[i] & 0xf, (hw[i] >> 4) & 3))
+
+# second table (trace build): per-wave barrier arrival / departure per k-tile of the first 64 workgroups, in shader cycles
+M, N = s[1], s[2]
+nwg = len(t)
+bar = raw[8 * nwg: 8 * nwg + 64 * 4 * 64 * 2].reshape(64, 4, 64, 2)
+ok = bar[:, :, :, 1] != 0
+if ok.any():
+    nt = int(ok[0, 0].sum())
+    arr, dep = bar[:, :, :nt, 0], bar[:, :, :nt, 1]
+    wait = dep - arr                                   # cycles a wave sat in the barrier
+    period = np.diff(dep, axis=2)                      # cycles between consecutive barrier departures = one k-tile
+    print('k-tiles traced per workgroup:', nt)
+    print('barrier wait per wave and k-tile, cycles: mean %.0f p50 %.0f p90 %.0f max %.0f' % (
+        wait.mean(), np.median(wait), np.percentile(wait, 90), wait.max()))
+    print('k-tile period, cycles: mean %.0f p50 %.0f p10 %.0f p90 %.0f' % (
+        period.mean(), np.median(period), np.percentile(period, 10), np.percentile(period, 90)))
+    skew = arr.max(axis=1) - arr.min(axis=1)           # first-to-last arrival inside a workgroup
+    print('arrival skew inside a workgroup, cycles: mean %.0f p90 %.0f' % (skew.mean(), np.percentile(skew, 90)))
+    w0 = 0
+    print('workgroup 0, first 12 k-tiles: per wave (arrive - tile start, wait):')
+    for k in range(1, min(nt, 13)):
+        base = dep[w0, :, k - 1].min()
+        print('  tile %2d ' % k + '  '.join('%6d/%5d' % (arr[w0, w, k] - base, wait[w0, w, k]) for w in range(4)))
