@@ -203,6 +203,11 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
     args = ap.parse_args()
 
+    # The N > 1 step uses four streams (main, grouping, gradient all-reduce, RCCL's own).  With HIP's default of 4 hardware queues
+    # two of them shared a queue: either the grouping ran in front of the forward pass instead of under it, or the all-reduce
+    # stream sat behind the whole backward pass (kernel trace, +0.09 ms per step).  The HIP runtime reads this when it
+    # initialises, i.e. at the first device call below.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -277,6 +282,13 @@ def main():
                 seg = group_rows(gd)
             scores = dcn_mix_score(model.cross, model.head, xin, layer_events=events, grad_buffers=grad_buffers) if fused else model(xin)
             main.wait_stream(side)
+            if not use_dist:
+                # one process: the reference's own normalisation (pairwise_loss_from_batch.py:279, mean over the pairs) inside the
+                # loss kernel, as `pairwise_loss` returns it -- no statistics to combine
+                loss_val, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=True, segments=seg)
+                loss_val.backward()
+                last['scores'], last['n_pair'] = scores, n_pair
+                return loss_val.detach()
             local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False, segments=seg)
         if layerwise is not None:
             # backward on the unnormalised local sum; each layer's bucket is all-reduced behind its event while the layers below
@@ -289,7 +301,7 @@ def main():
             # the gradients are divided by P_global afterwards (the loss is linear in 1/P) -- no sync between fwd and bwd
             local_sum.backward()
             loss_val, _ = reducer.all_reduce_with_loss(local_sum, n_pair)
-        else:
+        else:                 # N > 1 without the gradient reducers (not reached by the flags of this script; kept as the two-collective form)
             loss_bw, loss_val, _ = dp.global_pairwise_loss(local_sum, n_pair)
             loss_bw.backward()
         last['scores'], last['n_pair'] = scores, n_pair

@@ -517,8 +517,11 @@ int recnow_event_destroy(void* event);
 int recnow_event_record(void* event, void* stream);
 int recnow_stream_wait_event(void* stream, void* event);
 /* x[0..n) *= 1 / (count[0] + eps), count a DEVICE scalar: the in-place normalisation of a reduced gradient bucket by the global
- * pair count (pairwise_loss_from_batch.py:125-126, P + 1e-10) without a host round trip.  x 16-byte aligned. */
-int recnow_scale_by_inv_count(float* x, int64_t n, const float* count, float eps, void* stream);
+ * pair count (pairwise_loss_from_batch.py:125-126, P + 1e-10) without a host round trip.  x 16-byte aligned.
+ * stats_out (optional, 2 floats): receives (loss_sum[0] / (count[0] + eps), count[0]) = the mean loss the reference returns
+ * (pairwise_loss_from_batch.py:279) and the pair count, from the same launch. */
+int recnow_scale_by_inv_count(float* x, int64_t n, const float* count, float eps, const float* loss_sum, float* stats_out,
+                              void* stream);
 
 #ifdef __cplusplus
 }

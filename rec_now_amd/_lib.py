@@ -95,7 +95,7 @@ SIGNATURES = {
     'recnow_event_destroy': (_I, [_P]),
     'recnow_event_record': (_I, [_P, _P]),
     'recnow_stream_wait_event': (_I, [_P, _P]),
-    'recnow_scale_by_inv_count': (_I, [_P, _L, _P, _F, _P]),
+    'recnow_scale_by_inv_count': (_I, [_P, _L, _P, _F, _P, _P, _P]),
 }
 
 

@@ -101,8 +101,13 @@ extern "C" int recnow_stream_wait_event(void* stream, void* event) {
 
 
 // x[i] *= 1 / (count[0] + eps)  (the gradient buckets of dp.LayerwiseReducer: count = the global pair count, a device scalar)
-__global__ void __launch_bounds__(256) k_scale_by_inv_count(float* __restrict__ x, int64_t n, const float* __restrict__ count, float eps) {
+__global__ void __launch_bounds__(256) k_scale_by_inv_count(float* __restrict__ x, int64_t n, const float* __restrict__ count, float eps,
+                                                            const float* __restrict__ loss_sum, float* __restrict__ stats_out) {
     const float inv = 1.f / (count[0] + eps);
+    if (stats_out && blockIdx.x == 0 && threadIdx.x == 0) {      // (global mean loss, global count): what the step returns
+        stats_out[0] = loss_sum[0] * inv;
+        stats_out[1] = count[0];
+    }
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 v = reinterpret_cast<float4*>(x)[i];
@@ -111,14 +116,15 @@ __global__ void __launch_bounds__(256) k_scale_by_inv_count(float* __restrict__ 
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[n4 * 4 + threadIdx.x] *= inv;
 }
-extern "C" int recnow_scale_by_inv_count(float* x, int64_t n, const float* count, float eps, void* stream) {
-    if (n < 0) return RECNOW_EINVAL;
-    if (n == 0) return RECNOW_OK;
+extern "C" int recnow_scale_by_inv_count(float* x, int64_t n, const float* count, float eps, const float* loss_sum, float* stats_out,
+                                         void* stream) {
+    if (n < 0 || (stats_out && !loss_sum)) return RECNOW_EINVAL;
+    if (n == 0 && !stats_out) return RECNOW_OK;
     if (!x || !count || ((uintptr_t)x & 15)) return RECNOW_EINVAL;
     int64_t g = (n / 4 + 255) / 256;
     if (g > 2048) g = 2048;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_scale_by_inv_count, (int)g, 256, 0, (hipStream_t)stream, x, n, count, eps);
+    hipLaunchKernelGGL(k_scale_by_inv_count, (int)g, 256, 0, (hipStream_t)stream, x, n, count, eps, loss_sum, stats_out);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

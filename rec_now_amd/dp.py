@@ -237,16 +237,22 @@ class LayerwiseReducer(object):
                 n_grad = flat.numel() - (2 if i == 0 else 0)        # the statistics themselves stay unscaled in the first bucket's tail
                 if i == 0:
                     out_stats = flat[-2:]
-                if flat.is_cuda:            # one small launch (torch's broadcast multiply by a 0-dim tensor takes ~30 us per bucket)
-                    from . import _lib
+                if flat.is_cuda:            # one small launch (torch's broadcast multiply by a 0-dim tensor takes ~30 us per bucket);
+                    from . import _lib      # the first bucket's launch also leaves (mean loss, P) = what reduce() returns
+                    if i == 0:
+                        result = torch.empty(2, dtype=torch.float32, device=flat.device)
                     _lib.call('recnow_scale_by_inv_count', _lib.ptr(flat), n_grad, _lib.ptr(out_stats[1:]), float(eps),
+                              _lib.ptr(out_stats) if i == 0 else None, _lib.ptr(result) if i == 0 else None,
                               _lib._P(torch.cuda.current_stream().cuda_stream))
                 else:
                     flat[:n_grad].mul_(1.0 / (out_stats[1] + eps))
+                    if i == 0:
+                        result = torch.stack([out_stats[0] / (out_stats[1] + eps), out_stats[1]])
                 for p, view in foreign:
                     if self.comm is not None:
                         p.grad.record_stream(self.comm)
                     p.grad.copy_(view.view(p.shape))
         if self.comm is not None:
             main.wait_stream(self.comm)                 # the gradients are final for whatever the main stream does next
-        return out_stats[0] / (out_stats[1] + eps), out_stats[1].clone()
+            result.record_stream(main)
+        return result[0], result[1]
