@@ -51,10 +51,11 @@ D = N_FIELD * EMB_DIM
 SUB, LAYERS, EXPERTS = 64, 3, 2
 ROWS_PER_GROUP = 64
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 16 * 157.3     # same guide: the fp32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
 PEAK_HBM_GBS = 8000.0                 # same guide, "HBM3E peak BW" (spec; 6.29 TB/s is the measured copy ceiling)
 PROF_EVERY = 5                        # time every 5th hooked launch (24 per step: every launch position gets sampled)
 GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>',
-             5: 'k_gemm_shortk'}          # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
+             5: 'k_gemm_shortk', 8: 'k_gemm_split'}          # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
 HBM_TAGS = {5: 'k_gemm_shortk', 6: 'k_mix_mid_fwd', 7: 'k_mix_mid_bwd'}
 CHECK_SCALE = 120.0                   # the parity step's inputs: x * 120 (std 6) -> scores of O(0.3), loss != ln 2
 PARITY_TOL = 1e-4                     # GPU fp32 vs CPU-port fp32 at B = 65536 (the fp64 subset check uses 1e-5, north_star)
@@ -200,6 +201,9 @@ def main():
     ap.add_argument('--rows', type=int, default=B_PER_GPU, help='rows per GPU (diagnostics; the metric is defined at 65536)')
     ap.add_argument('--unfused', action='store_true', help='diagnostic: the drop-in composition head(cross(x)) and pairwise_loss(outputs, labels, groups) '
                     'instead of the model-level fused node (rec_now_amd/fused.py) with grouping on a side stream')
+    ap.add_argument('--gemm-precision', choices=['f32', 'bf16x3'], default='f32',
+                    help="arithmetic of the long-K products: 'f32' exact fp32 MFMA (the headline), 'bf16x3' the opt-in split-precision kernels "
+                         '(fp32 operands as three bf16 pieces, six bf16 MFMA terms, fp32 accumulation; same 1e-5 parity bound, not bit-identical)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
     args = ap.parse_args()
 
@@ -229,6 +233,7 @@ def main():
     from rec_now_amd.rec_block.pairwise_loss_from_batch import group_rows, pairwise_loss_fused
     lib = _lib.load()
     dp.FORCE_COLLECTIVES = bool(args.force_dist)
+    _lib.call('recnow_set_gemm_precision', 1 if args.gemm_precision == 'bf16x3' else 0)
 
     torch.manual_seed(3)                      # identical replicated weights on every rank
     model = Model()
@@ -345,10 +350,10 @@ def main():
     sync()
     roofline = None
     if prof:
-        cnt = (ctypes.c_int * 8)()
-        ms = (ctypes.c_double * 8)()
-        fl = (ctypes.c_double * 8)()
-        by = (ctypes.c_double * 8)()
+        cnt = (ctypes.c_int * 16)()          # the library fills RN_TAG_MAX (= 9) entries
+        ms = (ctypes.c_double * 16)()
+        fl = (ctypes.c_double * 16)()
+        by = (ctypes.c_double * 16)()
         _lib.check(lib.recnow_prof_collect(cnt, ms, fl, by), 'recnow_prof_collect')
         lib.recnow_prof_enable(0)
         traffic_tab, stale = {}, None
@@ -363,8 +368,10 @@ def main():
         tag = max(GEMM_TAGS, key=lambda t: ms[t])
         if cnt[tag] > 0:
             achieved = fl[tag] / (ms[tag] * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic_tab.get(GEMM_TAGS[tag]), 'traffic_stale': stale,
+            # k_gemm_split executes every algorithmic fp32 multiply-add as six bf16 MFMA terms: its ceiling is the dense bf16 peak / 6
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if tag == 8 else PEAK_F32_MFMA_TFLOPS
+            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': achieved / peak, 'traffic': traffic_tab.get(GEMM_TAGS[tag]), 'traffic_stale': stale,
                         'kernel': GEMM_TAGS[tag],
                         'launches': cnt[tag], 'sampled': 'every %dth hooked launch of the timed region' % PROF_EVERY, 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
                         'algorithmic_flops_per_launch': fl[tag] / cnt[tag], 'algorithmic_bytes_per_launch': by[tag] / cnt[tag],
@@ -431,7 +438,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'f32' if args.gemm_precision == 'f32' else 'f32 operands as 3 x bf16, bf16 MFMA, f32 accumulate (opt-in, --gemm-precision bf16x3)',
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
                                    'in-batch pairwise (logistic), B=65536 rows per GPU, 64 fields x 16-dim, ~64 rows/group',

@@ -263,6 +263,13 @@ typedef struct recnow_gemm_desc {
 
 size_t recnow_gemm_workspace_bytes(const recnow_gemm_desc* desc_host);
 int recnow_gemm(const recnow_gemm_desc* desc_host, void* ws, size_t ws_bytes, void* stream);
+/* Process-wide arithmetic of the long-K 128-column products with a side product (the K = 1024 / K = B products of DCNMixLayer):
+ *   0 (default) exact fp32 MFMA -- an fp32 fma chain, what TF's fp32 matmul computes up to summation order;
+ *   1 "bf16x3": every fp32 operand element split into three bf16 pieces, six bf16 MFMA terms per product, fp32 accumulation:
+ *     relative error of a product <= 2^-25, results within the 1e-5 parity bound but NOT bit-identical to mode 0 (opt-in).
+ * Also read once from the environment (RECNOW_GEMM_PRECISION=bf16x3).  Shapes without a split kernel run mode 0 regardless. */
+int recnow_set_gemm_precision(int mode);
+int recnow_get_gemm_precision(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * MultiDenseLayer: rec_now/layers/multi_dense_layer.py:80-94.   y[n] = act(x[n] @ kernel[n] + bias[n])
@@ -499,8 +506,8 @@ int recnow_embed_scatter_rows(const float* drows, const int64_t* row_ids, int64_
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the GEMM kernels on the launch stream.
  * recnow_prof_enable(capacity > 0) arms `capacity` launch slots, (0) disables.  recnow_prof_collect synchronises and
- * returns per-kernel-family totals in HOST arrays of 8 entries indexed by tag: 1 = k_gemm<128,128>, 2 = k_gemm<128,160>,
- * 3 = k_gemm<256,64>, 4 = k_gemm<256,32>, 5 = k_gemm_shortk, 6 = k_mix_mid_fwd, 7 = k_mix_mid_bwd: launches, total
+ * returns per-kernel-family totals in HOST arrays of 9 entries indexed by tag: 1 = k_gemm<128,128>, 2 = k_gemm<128,160>,
+ * 3 = k_gemm<256,64>, 4 = k_gemm<256,32>, 5 = k_gemm_shortk, 6 = k_mix_mid_fwd, 7 = k_mix_mid_bwd, 8 = k_gemm_split: launches, total
  * milliseconds, total algorithmic flops (2*M*N*K*batch) and (bytes_host, may be NULL) total algorithmic HBM bytes: every
  * operand read once, every output written once, read-modify-write outputs twice.
  * ---------------------------------------------------------------------------------------------------------- */

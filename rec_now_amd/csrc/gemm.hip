@@ -100,6 +100,17 @@ static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* 
     *kchunk = kc;
 }
 
+static int g_gemm_precision = []() {
+    const char* e = getenv("RECNOW_GEMM_PRECISION");
+    return (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? 1 : 0;
+}();
+int rn_gemm_precision() { return g_gemm_precision; }
+int rn_gemm_set_precision(int mode) {
+    if (mode != 0 && mode != 1) return RECNOW_EINVAL;
+    g_gemm_precision = mode;
+    return RECNOW_OK;
+}
+
 size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return 0;
     const GemmCfg c = pick_cfg(d->N);
@@ -207,6 +218,10 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
                             d->b_mode == 0 && !d->bias && d->act == RECNOW_ACT_LINEAR && !d->c_trans &&
                             (!d->emul || d->e_mode == RECNOW_OPMODE_MUL);
     if (use_shortk) tag = RN_TAG_GEMM_SHORTK;
+    const bool split_ok = g_gemm_precision == 1 && xf == 1 && !d->as_out && !edge && !bk16 && c.BM == 128 && c.BN == 128 && d->b_mode == 0 &&
+                          (d->a_mode == RECNOW_OPMODE_NONE || d->a_mode == RECNOW_OPMODE_MUL) &&
+                          ((a_kc && !b_kc && d->a_mode == 0) || (a_kc && b_kc) || (!a_kc && !b_kc));
+    if (split_ok) tag = RN_TAG_GEMM_SPLIT;
     RnProfRecord* pr = nullptr;
     if (rn_prof_on()) {
         // algorithmic HBM bytes: every operand read once, every output written once (read-modify-write outputs count twice)
@@ -225,7 +240,10 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     }
     if (xf) {        // side product / rank-R update exist only in the lean 128x128 kernels: the caller guarantees the shape
         if (edge || c.BM != 128 || c.BN != 128 || d->c2_mode) return RECNOW_EUNSUPPORTED;
-        rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
+        rc = RECNOW_EUNSUPPORTED;
+        // opt-in split precision: the long-K products with a side product (every k_gemm launch of the DCN-v2 step)
+        if (split_ok) rc = rn_gemm_launch_split(k, a_kc, b_kc, d->a_mode, true, grid, st);
+        if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
     } else if (use_shortk) {
         // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)
@@ -383,6 +401,8 @@ int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int
     return RECNOW_OK;
 }
 
+extern "C" int recnow_set_gemm_precision(int mode) { return rn_gemm_set_precision(mode); }
+extern "C" int recnow_get_gemm_precision(void) { return rn_gemm_precision(); }
 extern "C" size_t recnow_gemm_workspace_bytes(const recnow_gemm_desc* desc_host) {
     return desc_host ? rn_gemm_ws_bytes(desc_host) : 0;
 }

@@ -6,6 +6,9 @@
 // C[b] = epilogue( opA(A[b]) * opB(B[b]) ), b = 0..batch-1, see recnow_gemm_desc in include/recnow.h
 int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d);
+// 0 = exact fp32 MFMA (default), 1 = bf16x3 split for the products that have a split kernel (gemm_split.hip)
+int rn_gemm_precision();
+int rn_gemm_set_precision(int mode);
 
 static inline recnow_gemm_desc rn_gemm_desc_zero() {
     recnow_gemm_desc d;

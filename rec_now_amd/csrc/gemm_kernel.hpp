@@ -284,6 +284,104 @@ __device__ __forceinline__ bool gemm_aligned(const void* p, int64_t ld, int64_t 
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0) && (sb % 4 == 0);
 }
 
+// Lean epilogue (every tile in bounds, 16-byte aligned): shared by the fp32 kernels below and the split-precision kernel
+// (gemm_split.hip) -- both leave the 32x32 MFMA accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+template <int TM, int TN, int XF>
+__device__ __forceinline__ void gemm_lean_epilogue(const GemmK& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0, int wm, int wn,
+                                                   int lane, int wave, int z, int bidx) {
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    // Lean epilogue: each 32x32 accumulator sub-tile goes through a wave-private LDS buffer (36-float rows) so that
+    // global traffic is float4 per lane (8 lanes = one 128-B row segment) with every epilogue operand of the
+    // sub-tile in flight at once -- 4 wide loads/stores instead of 16 + 16 dependent dword round trips.
+    float* stg = smem + wave * (32 * 36);          // the k-loop's last barrier has retired every As/Bs read
+    const int rr0 = lane >> 3, cc = (lane & 7) * 4;
+    float* Cb = p.splitk > 1 ? p.partial + ((int64_t)z * p.M) * p.npart : p.C + (int64_t)bidx * p.sC;
+    const int64_t ldc = p.splitk > 1 ? p.npart : p.ldc;
+    const bool plain = p.splitk > 1;
+    const float* biasb = (!plain && p.bias) ? p.bias + (int64_t)bidx * p.sBias : nullptr;
+    const float* Eb = (!plain && p.emul) ? p.emul + (int64_t)bidx * p.sE : nullptr;
+    const bool accum = !plain && p.accumulate;
+    // rank-R update operands: Q[r][col] depends only on the column sub-tile j, P[row][r] only on the row sub-tile i.
+    // Loads are unconditional (r clamped to the last valid one, its weight zeroed): no per-load branches.
+    float euq[TN][4][4], eup[4][4];
+    if ((XF & 2) && !plain) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rc = min(r, p.eu_r - 1);
+                const float on = r < p.eu_r ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    euq[j][r][e] = on * p.eu_q[(int64_t)rc * p.eu_qrs + (int64_t)(n0 + wn * TN * 32 + j * 32 + cc + e) * p.eu_qns];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if ((XF & 2) && !plain) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    eup[q][r] = p.eu_p[(int64_t)(m0 + wm * TM * 32 + i * 32 + q * 8 + rr0) * p.eu_pms + min(r, p.eu_r - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row0 = m0 + wm * TM * 32 + i * 32, col0 = n0 + wn * TN * 32 + j * 32 + cc;
+            float4 ev[4], cv[4];
+            if (Eb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const float4*>(Eb + (int64_t)(row0 + q * 8 + rr0) * p.lde + col0);
+            }
+            const bool ctr = !plain && p.c_trans;      // transposed store C[n][m]: scalar accesses (block-uniform, rare)
+            if (accum) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t rw = row0 + q * 8 + rr0;
+                    if (!ctr) cv[q] = *reinterpret_cast<const float4*>(Cb + rw * ldc + col0);
+                    else cv[q] = make_float4(Cb[(int64_t)col0 * ldc + rw], Cb[(int64_t)(col0 + 1) * ldc + rw],
+                                             Cb[(int64_t)(col0 + 2) * ldc + rw], Cb[(int64_t)(col0 + 3) * ldc + rw]);
+                }
+            }
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (biasb) bv = *reinterpret_cast<const float4*>(biasb + col0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + row_l) * 36 + col_l] = acc[i][j][r];
+            RN_LDS_WAVE_SYNC();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 a = *reinterpret_cast<const float4*>(stg + (q * 8 + rr0) * 36 + cc);
+                float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+                if ((XF & 2) && !plain) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += eup[q][r] * euq[j][r][e];
+                }
+                if (!plain && p.act != RECNOW_ACT_LINEAR) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col0 + e < p.act_cols) v[e] = rn_act(v[e], p.act);
+                }
+                if (Eb) {
+                    const float ee[4] = {ev[q].x, ev[q].y, ev[q].z, ev[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(ee[e], p.e_act) : ee[e];
+                }
+                if (accum) { v[0] += cv[q].x; v[1] += cv[q].y; v[2] += cv[q].z; v[3] += cv[q].w; }
+                const int64_t rw = row0 + q * 8 + rr0;
+                if (!ctr) *reinterpret_cast<float4*>(Cb + rw * ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Cb[(int64_t)(col0 + e) * ldc + rw] = v[e];
+                }
+            }
+            RN_LDS_WAVE_SYNC();
+        }
+    }
+}
+
 // EDGE = false: every tile of the launch is in bounds and 16-byte aligned (checked on the host) -> no bounds code at
 // all (lean: no spills under the 256-register cap).  EDGE = true: general shapes, clamped loads and predicated stores.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, bool EDGE, int A2K, int B2K, int XF = 0>
@@ -608,96 +706,7 @@ k_gemm(const GemmK p) {
     // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     if constexpr (!EDGE) {
-        // Lean epilogue: each 32x32 accumulator sub-tile goes through a wave-private LDS buffer (36-float rows) so that
-        // global traffic is float4 per lane (8 lanes = one 128-B row segment) with every epilogue operand of the
-        // sub-tile in flight at once -- 4 wide loads/stores instead of 16 + 16 dependent dword round trips.
-        float* stg = smem + wave * (32 * 36);          // the k-loop's last barrier has retired every As/Bs read
-        const int rr0 = lane >> 3, cc = (lane & 7) * 4;
-        float* Cb = p.splitk > 1 ? p.partial + ((int64_t)z * p.M) * p.npart : p.C + (int64_t)bidx * p.sC;
-        const int64_t ldc = p.splitk > 1 ? p.npart : p.ldc;
-        const bool plain = p.splitk > 1;
-        const float* biasb = (!plain && p.bias) ? p.bias + (int64_t)bidx * p.sBias : nullptr;
-        const float* Eb = (!plain && p.emul) ? p.emul + (int64_t)bidx * p.sE : nullptr;
-        const bool accum = !plain && p.accumulate;
-        // rank-R update operands: Q[r][col] depends only on the column sub-tile j, P[row][r] only on the row sub-tile i.
-        // Loads are unconditional (r clamped to the last valid one, its weight zeroed): no per-load branches.
-        float euq[TN][4][4], eup[4][4];
-        if ((XF & 2) && !plain) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rc = min(r, p.eu_r - 1);
-                    const float on = r < p.eu_r ? 1.f : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        euq[j][r][e] = on * p.eu_q[(int64_t)rc * p.eu_qrs + (int64_t)(n0 + wn * TN * 32 + j * 32 + cc + e) * p.eu_qns];
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if ((XF & 2) && !plain) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        eup[q][r] = p.eu_p[(int64_t)(m0 + wm * TM * 32 + i * 32 + q * 8 + rr0) * p.eu_pms + min(r, p.eu_r - 1)];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row0 = m0 + wm * TM * 32 + i * 32, col0 = n0 + wn * TN * 32 + j * 32 + cc;
-                float4 ev[4], cv[4];
-                if (Eb) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ev[q] = *reinterpret_cast<const float4*>(Eb + (int64_t)(row0 + q * 8 + rr0) * p.lde + col0);
-                }
-                const bool ctr = !plain && p.c_trans;      // transposed store C[n][m]: scalar accesses (block-uniform, rare)
-                if (accum) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int64_t rw = row0 + q * 8 + rr0;
-                        if (!ctr) cv[q] = *reinterpret_cast<const float4*>(Cb + rw * ldc + col0);
-                        else cv[q] = make_float4(Cb[(int64_t)col0 * ldc + rw], Cb[(int64_t)(col0 + 1) * ldc + rw],
-                                                 Cb[(int64_t)(col0 + 2) * ldc + rw], Cb[(int64_t)(col0 + 3) * ldc + rw]);
-                    }
-                }
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (biasb) bv = *reinterpret_cast<const float4*>(biasb + col0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + row_l) * 36 + col_l] = acc[i][j][r];
-                RN_LDS_WAVE_SYNC();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 a = *reinterpret_cast<const float4*>(stg + (q * 8 + rr0) * 36 + cc);
-                    float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
-                    if ((XF & 2) && !plain) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += eup[q][r] * euq[j][r][e];
-                    }
-                    if (!plain && p.act != RECNOW_ACT_LINEAR) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (col0 + e < p.act_cols) v[e] = rn_act(v[e], p.act);
-                    }
-                    if (Eb) {
-                        const float ee[4] = {ev[q].x, ev[q].y, ev[q].z, ev[q].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] *= (p.e_mode == RECNOW_OPMODE_ACTGRAD) ? rn_act_grad_from_out(ee[e], p.e_act) : ee[e];
-                    }
-                    if (accum) { v[0] += cv[q].x; v[1] += cv[q].y; v[2] += cv[q].z; v[3] += cv[q].w; }
-                    const int64_t rw = row0 + q * 8 + rr0;
-                    if (!ctr) *reinterpret_cast<float4*>(Cb + rw * ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) Cb[(int64_t)(col0 + e) * ldc + rw] = v[e];
-                    }
-                }
-                RN_LDS_WAVE_SYNC();
-            }
-        }
+        gemm_lean_epilogue<TM, TN, XF>(p, acc, smem, m0, n0, wm, wn, lane, wave, z, bidx);
         RN_TR(3);
 #ifdef RN_GEMM_TRACE
         if (p.trace && threadIdx.x == 0) p.trace[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8ll + 6] = clock64();
@@ -779,5 +788,7 @@ static inline void rn_gemm_launch_one(const GemmK& k, dim3 grid, hipStream_t st)
     hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, EDGE, A2K, B2K, XF>), grid, GEMM_THREADS, lds, st, k);
 }
 int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k, int b2k, int xf, dim3 grid, hipStream_t st);
+// split-precision (bf16x3) 128x128 kernel, k-tiles of 16 (gemm_split.hip)
+int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, bool sp, dim3 grid, hipStream_t st);
 // persistent short-K kernel (gemm_shortk.hip): ep = (emul ? 1 : 0) | (accumulate ? 2 : 0)
 int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st);

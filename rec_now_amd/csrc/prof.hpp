@@ -16,7 +16,8 @@ struct RnProfRecord {
 #define RN_TAG_GEMM_SHORTK 5        // k_gemm_shortk (persistent, K <= 512): a kernel of its own in rocprof, a family of its own here
 #define RN_TAG_MIX_MID_FWD 6        // k_mix_mid_fwd (DCN-v2 sub-space stage, HBM-bound)
 #define RN_TAG_MIX_MID_BWD 7        // k_mix_mid_bwd
-#define RN_TAG_MAX 8
+#define RN_TAG_GEMM_SPLIT 8         // k_gemm_split (bf16x3 split-precision 128x128 products, opt-in)
+#define RN_TAG_MAX 9
 
 bool rn_prof_on();
 // returns a slot (or nullptr when profiling is off / the pool is full) and records e0 on st
