@@ -166,8 +166,11 @@ static size_t mix_gemm_ws(const MixDims& m) {
         if (s > best) best = s;
     }
     if (m.exact) {           // exact-path split-K products carry 4 side columns per slab row
-        d.M = m.D; d.N = m.NS; d.K = (int)m.B; d.batch = 1; d.sp_r = m.N;
-        const size_t s = rn_gemm_ws_bytes(&d);
+        d.M = m.D; d.N = m.NS; d.K = (int)m.B; d.batch = 1; d.sp_r = m.N; d.a_trans = 1;
+        size_t s = rn_gemm_ws_bytes(&d);
+        if (s > best) best = s;
+        d.M = (int)m.B; d.N = m.NS; d.K = m.D; d.a_trans = 0;       // x_l U / (x*g) W^T: room for the split-precision planes of the weights
+        s = rn_gemm_ws_bytes(&d);
         if (s > best) best = s;
     }
     return best;

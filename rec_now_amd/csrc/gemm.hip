@@ -111,12 +111,19 @@ int rn_gemm_set_precision(int mode) {
     return RECNOW_OK;
 }
 
+// products whose B operand the split-precision kernel splits once per launch into global planes (weights: small, L2-resident)
+static inline bool split_planes_shape(const recnow_gemm_desc* d) {
+    return d->sp_r > 0 && d->N == 128 && d->K <= 4096 && d->K % 16 == 0 && d->batch == 1 && !d->a_trans;
+}
+
 size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return 0;
     const GemmCfg c = pick_cfg(d->N);
     int s, kc;
     pick_split(d, c, &s, &kc);
-    return s > 1 ? rn_align((size_t)s * d->batch * d->M * (d->N + (d->sp_r > 0 ? 4 : 0)) * sizeof(float)) : 0;
+    size_t b = s > 1 ? rn_align((size_t)s * d->batch * d->M * (d->N + (d->sp_r > 0 ? 4 : 0)) * sizeof(float)) : 0;
+    if (split_planes_shape(d)) b += rn_gemm_split_planes_bytes(d->K, d->N);      // whatever the precision mode is when the product runs
+    return b;
 }
 
 static inline bool host_aligned(const void* p, int64_t ld, int64_t sb) {
@@ -242,7 +249,14 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
         if (edge || c.BM != 128 || c.BN != 128 || d->c2_mode) return RECNOW_EUNSUPPORTED;
         rc = RECNOW_EUNSUPPORTED;
         // opt-in split precision: the long-K products with a side product (every k_gemm launch of the DCN-v2 step)
-        if (split_ok) rc = rn_gemm_launch_split(k, a_kc, b_kc, d->a_mode, true, grid, st);
+        if (split_ok) {
+            void* planes = nullptr;
+            if (split_planes_shape(d)) {
+                const size_t used = k.splitk > 1 ? rn_align((size_t)k.splitk * d->batch * d->M * k.npart * sizeof(float)) : 0;
+                if (ws && ws_bytes >= used + rn_gemm_split_planes_bytes(d->K, d->N)) planes = (char*)ws + used;
+            }
+            rc = rn_gemm_launch_split(k, a_kc, b_kc, d->a_mode, planes, grid, st);
+        }
         if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
     } else if (use_shortk) {

@@ -6,26 +6,33 @@
 // work of eight 16-pass fp32 MFMAs: 2.67x the fp32-MFMA rate.  OPT-IN (recnow_set_gemm_precision / RECNOW_GEMM_PRECISION=bf16x3):
 // results are not bit-identical to the fp32 kernels; parity (1e-5 relative, north_star) is held by the same tests.
 //
-// Structure follows the sliced fp32 kernel (gemm_kernel.hpp): 256 threads = 2 x 2 waves of 64 x 64, k-tiles of 16 (= one MFMA
-// k-step), two LDS stages, the registers hold k-tile t+1 while k-tile t is computed, its split + LDS writes and the loads of
-// k-tile t+2 sit between the MFMA groups.  LDS image per operand and stage: 3 planes (pieces) x 2 k-halves x 136 units of 16 B
-// (unit = 8 consecutive k of one row: exactly what a lane feeds to the MFMA; rows padded by one unit per 16 so that the writes of
-// the [k][row]-contiguous loaders spread over the banks).  Side product (sp_r <= 4 extra columns): fp32 FMAs on the operand
-// registers at LDS-write time, reduced across the threads that share a row at the end (no fp32 image in LDS to read it from).
+// Structure: 256 threads = 2 x 2 waves of 64 x 64, k-tiles of 16 (= one MFMA k-step), two LDS stages.  The A operand is
+// requested TWO k-tiles ahead (register ring of two: an iteration is ~1 us, shorter than an HBM round trip under load), the B
+// operand one (weights: L2) or two (activations) ahead; the split + LDS writes of k-tile t+1 and the loads sit between the six
+// MFMA groups of k-tile t.  LDS image per operand and stage: 3 planes (pieces) x 2 k-halves x 136 units of 16 B (unit = 8
+// consecutive k of one row: exactly what a lane feeds to the MFMA; rows padded by one unit per 16 so that the writes of the
+// [k][row]-contiguous loaders spread over the banks).  A small B operand (weights, K <= 4096) is split ONCE per launch into
+// global planes of the same units by k_split_planes (every one of the 512 workgroups would otherwise split the same tile), the
+// loader then copies units.  Side product (sp_r <= 4 extra columns): fp32 FMAs on the A staging registers at LDS-write time,
+// reduced across the threads that share a row at the end (there is no fp32 image in LDS to read it from).
 #include "gemm_kernel.hpp"
 #include "prof.hpp"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((__vector_size__(16)));
 typedef __bf16 bf16x2 __attribute__((__vector_size__(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define SPL_BK 16
 #define SPL_PLANE_H 136                                  // 16-byte units per k-half: 128 rows + 1 pad per 16 rows
 #define SPL_PLANE (2 * SPL_PLANE_H * 16)                 // bytes per piece plane
 #define SPL_OPER (3 * SPL_PLANE)                         // bytes per operand and stage
 #define SPL_STAGE (2 * SPL_OPER)
-#define SPL_BX_OFF (2 * SPL_STAGE)                       // side-product weights: ring of 3 k-tiles x 16 k x 4 floats
-#define SPL_LDS (SPL_BX_OFF + 3 * SPL_BK * 4 * 4)
+#define SPL_BX_OFF (2 * SPL_STAGE)                       // side-product weights: ring of 4 k-tiles x 16 k x 4 floats
+#define SPL_BX_RING 4
+#define SPL_LDS (SPL_BX_OFF + SPL_BX_RING * SPL_BK * 4 * 4)
 
 __device__ __forceinline__ int spl_pos(int r) { return r + (r >> 4); }
 
@@ -33,29 +40,52 @@ __device__ __forceinline__ int spl_pos(int r) { return r + (r >> 4); }
 __device__ __forceinline__ void spl_split2(float u, float v, unsigned& p1, unsigned& p2, unsigned& p3) {
     bf16x2 h = {(__bf16)u, (__bf16)v};
     p1 = __builtin_bit_cast(unsigned, h);
-    float ru = u - __builtin_bit_cast(float, p1 << 16), rv = v - __builtin_bit_cast(float, p1 & 0xffff0000u);
-    bf16x2 g = {(__bf16)ru, (__bf16)rv};
+    f32x2 r = {u - __builtin_bit_cast(float, p1 << 16), v - __builtin_bit_cast(float, p1 & 0xffff0000u)};
+    bf16x2 g = {(__bf16)r.x, (__bf16)r.y};
     p2 = __builtin_bit_cast(unsigned, g);
-    ru -= __builtin_bit_cast(float, p2 << 16);
-    rv -= __builtin_bit_cast(float, p2 & 0xffff0000u);
-    bf16x2 f = {(__bf16)ru, (__bf16)rv};
+    r.x -= __builtin_bit_cast(float, p2 << 16);
+    r.y -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+    bf16x2 f = {(__bf16)r.x, (__bf16)r.y};
     p3 = __builtin_bit_cast(unsigned, f);
 }
 
-// One operand's staging registers: two float4 per thread and k-tile.
+// B (K x N; [K][N] rows of ldb floats, or [N][K] when b_kc) -> planes[s][K/8][N] units of 8 bf16 (16 B): unit (o, n) of piece s
+// holds piece s of B[8 o .. 8 o + 7][n].  One thread per unit.
+__global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ B, int64_t ldb, int b_kc, int K, int N, char* __restrict__ planes) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)(K / 8) * N;
+    if (u >= total) return;
+    const int n = (int)(u % N), o = (int)(u / N);
+    float x[8];
+    if (b_kc) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(B + (int64_t)n * ldb + 8 * o), b = *reinterpret_cast<const f32x4*>(B + (int64_t)n * ldb + 8 * o + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = B[(int64_t)(8 * o + e) * ldb + n];
+    }
+    u32x4 w[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned p1, p2, p3;
+        spl_split2(x[2 * e], x[2 * e + 1], p1, p2, p3);
+        w[0][e] = p1; w[1][e] = p2; w[2][e] = p3;
+    }
+    const int64_t ps = total * 16;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(planes + s * ps + u * 16) = w[s];
+}
+
+// One fp32 operand's staging registers for ONE k-tile: two float4 per thread.
 //   KC  ([row][k], k contiguous): slot i = rows (tid >> 2) + 64 i, k = 4 (tid & 3) .. +3
 //   !KC ([k][row], row contiguous): slot i = k 2 (tid >> 5) + i, rows 4 (tid & 31) .. +3   (the two slots pair up along k)
 template <bool KC, int K2>
 struct SplTile {
     f32x4 v[2], y[2];
-    __device__ __forceinline__ void issue(const float* __restrict__ p, const float* __restrict__ p2, int64_t ld, int r0, int k0) {
-        const int t = threadIdx.x;
+    __device__ __forceinline__ void issue(const float* __restrict__ p, const float* __restrict__ p2, int64_t tile_off, const unsigned (&off)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int64_t off = KC ? (int64_t)(r0 + (t >> 2) + 64 * i) * ld + k0 + 4 * (t & 3)
-                                   : (int64_t)(k0 + 2 * (t >> 5) + i) * ld + r0 + 4 * (t & 31);
-            v[i] = *reinterpret_cast<const f32x4*>(p + off);
-            if (K2 != RECNOW_OPMODE_NONE) y[i] = *reinterpret_cast<const f32x4*>(p2 + off);
+            v[i] = *reinterpret_cast<const f32x4*>(p + tile_off + off[i]);
+            if (K2 != RECNOW_OPMODE_NONE) y[i] = *reinterpret_cast<const f32x4*>(p2 + tile_off + off[i]);
         }
     }
     __device__ __forceinline__ void combine(int act) {
@@ -64,48 +94,37 @@ struct SplTile {
             v[1] = gemm_combine(v[1], y[1], K2, act);
         }
     }
-    // split and write to the three planes at `S` (byte address of the operand's stage image)
-    __device__ __forceinline__ void store(char* __restrict__ S) const {
-        const int t = threadIdx.x;
-        if (KC) {
-            const int k4 = 4 * (t & 3);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                char* d = S + (((k4 >> 3) * SPL_PLANE_H + spl_pos((t >> 2) + 64 * i)) * 16 + ((k4 >> 2) & 1) * 8);
-                unsigned a1, a2, a3, b1, b2, b3;
-                spl_split2(v[i].x, v[i].y, a1, a2, a3);
-                spl_split2(v[i].z, v[i].w, b1, b2, b3);
-                u32x2 w;
-                w.x = a1; w.y = b1;
-                *reinterpret_cast<u32x2*>(d) = w;
-                w.x = a2; w.y = b2;
-                *reinterpret_cast<u32x2*>(d + SPL_PLANE) = w;
-                w.x = a3; w.y = b3;
-                *reinterpret_cast<u32x2*>(d + 2 * SPL_PLANE) = w;
-            }
-        } else {
-            const int k = 2 * (t >> 5), r4 = 4 * (t & 31);
-            char* d = S + ((k >> 3) * SPL_PLANE_H * 16 + (k & 7) * 2);
-            const float lo[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, hi[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned p1, p2, p3;
-                spl_split2(lo[e], hi[e], p1, p2, p3);
-                char* de = d + spl_pos(r4 + e) * 16;
-                *reinterpret_cast<unsigned*>(de) = p1;
-                *reinterpret_cast<unsigned*>(de + SPL_PLANE) = p2;
-                *reinterpret_cast<unsigned*>(de + 2 * SPL_PLANE) = p3;
-            }
-        }
+    // split and write to the three planes at `S` (byte address of the operand's stage image + this thread's offset)
+    __device__ __forceinline__ void store(char* __restrict__ S, int i) const {      // KC: one slot
+        unsigned a1, a2, a3, b1, b2, b3;
+        spl_split2(v[i].x, v[i].y, a1, a2, a3);
+        spl_split2(v[i].z, v[i].w, b1, b2, b3);
+        u32x2 w;
+        w.x = a1; w.y = b1;
+        *reinterpret_cast<u32x2*>(S) = w;
+        w.x = a2; w.y = b2;
+        *reinterpret_cast<u32x2*>(S + SPL_PLANE) = w;
+        w.x = a3; w.y = b3;
+        *reinterpret_cast<u32x2*>(S + 2 * SPL_PLANE) = w;
+    }
+    __device__ __forceinline__ void store_pair(char* __restrict__ S, int e) const {  // !KC: row e of the four, k pair
+        unsigned p1, p2, p3;
+        spl_split2(v[0][e], v[1][e], p1, p2, p3);
+        *reinterpret_cast<unsigned*>(S) = p1;
+        *reinterpret_cast<unsigned*>(S + SPL_PLANE) = p2;
+        *reinterpret_cast<unsigned*>(S + 2 * SPL_PLANE) = p3;
     }
 };
 
-template <bool A_KC, bool B_KC, int A2K, bool SP>
+// BSRC: 0 = fp32 [K][N] split in the kernel, 1 = fp32 [N][K] split in the kernel, 2 = planes of k_split_planes
+template <bool A_KC, int A2K, int BSRC>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
-k_gemm_split(const GemmK p) {
+k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_bytes) {
+    constexpr bool B_KC = BSRC == 1;
+    constexpr bool BPRE = BSRC == 2;
     extern __shared__ __attribute__((aligned(16))) char spl_smem[];
     float* const Bxs = reinterpret_cast<float*>(spl_smem + SPL_BX_OFF);
-    int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+    int bx = blockIdx.x, z = blockIdx.z;
     if (p.xcd_remap == 1) {       // as k_gemm: the row tiles of one k-slab become consecutive workgroups of one XCD
         const int gx = gridDim.x, lin = bx + gx * z, xcd = lin & 7, i = lin >> 3;
         z = xcd * ((int)gridDim.z >> 3) + i / gx;
@@ -114,14 +133,13 @@ k_gemm_split(const GemmK p) {
     const int bidx = z / p.splitk, ks = z % p.splitk;
     const int k_begin = ks * p.kchunk;
     const int k_end = min(p.K, k_begin + p.kchunk);
-    const int m0 = bx * 128, n0 = by * 128;
+    const int m0 = bx * 128, n0 = blockIdx.y * 128;
     const float* Ab = p.A + (int64_t)bidx * p.sA;
     const float* A2b = p.A2 ? p.A2 + (int64_t)bidx * p.sA : nullptr;
     const float* Bb = p.B + (int64_t)bidx * p.sB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntile = (k_end - k_begin) / SPL_BK;
-    const bool sp_on = SP && by == 0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -137,52 +155,116 @@ k_gemm_split(const GemmK p) {
     for (int e = 0; e < 4; ++e) spacc[e] = mk4(0.f, 0.f, 0.f, 0.f);
     float bxr[4] = {0.f, 0.f, 0.f, 0.f};
 
-    SplTile<A_KC, A2K> ta;
-    SplTile<B_KC, RECNOW_OPMODE_NONE> tb;
+    // thread-invariant element offsets inside a k-tile (the tile base is block-uniform and lives in SGPRs) and LDS write offsets
+    unsigned a_goff[2], b_goff[2];
+    int a_soff[4], b_soff[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_goff[i] = A_KC ? (unsigned)(((tid >> 2) + 64 * i) * p.lda + 4 * (tid & 3)) : (unsigned)((2 * (tid >> 5) + i) * p.lda + 4 * (tid & 31));
+        b_goff[i] = B_KC ? (unsigned)(((tid >> 2) + 64 * i) * p.ldb + 4 * (tid & 3)) : (unsigned)((2 * (tid >> 5) + i) * p.ldb + 4 * (tid & 31));
+    }
+    {
+        const int k4 = 4 * (tid & 3), kp = 2 * (tid >> 5);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // KC uses entries 0, 1 (its two slots); !KC entries 0..3 (the four rows of its k pair)
+            const int kc_off = ((k4 >> 3) * SPL_PLANE_H + spl_pos((tid >> 2) + 64 * (e & 1))) * 16 + ((k4 >> 2) & 1) * 8;
+            const int rc_off = ((kp >> 3) * SPL_PLANE_H + spl_pos(4 * (tid & 31) + e)) * 16 + (kp & 7) * 2;
+            a_soff[e] = A_KC ? kc_off : rc_off;
+            b_soff[e] = SPL_OPER + (B_KC ? kc_off : rc_off);
+        }
+    }
+    // planes: thread copies unit (k-half tid >> 7, column tid & 127) of each piece
+    const int64_t bp_goff = BPRE ? ((int64_t)(tid >> 7) * p.N + n0 + (tid & 127)) * 16 : 0;
+    const int bp_soff = SPL_OPER + ((tid >> 7) * SPL_PLANE_H + spl_pos(tid & 127)) * 16;
+
+    SplTile<A_KC, A2K> ta[2];                      // ring of two k-tiles in flight
+    SplTile<B_KC, RECNOW_OPMODE_NONE> tb[2];       // in-kernel split of B: ring of two as well
+    u32x4 bpl[3];                                  // planes: one k-tile in flight (L2-resident weights)
+    auto a_base = [&](int tile) { return A_KC ? (int64_t)m0 * p.lda + k_begin + tile * SPL_BK : (int64_t)(k_begin + tile * SPL_BK) * p.lda + m0; };
+    auto b_base = [&](int tile) { return B_KC ? (int64_t)n0 * p.ldb + k_begin + tile * SPL_BK : (int64_t)(k_begin + tile * SPL_BK) * p.ldb + n0; };
+    auto b_issue = [&](int slot, int tile) {
+        if (BPRE) {
+            const char* src = b_planes + (int64_t)((k_begin + tile * SPL_BK) >> 3) * p.N * 16 + bp_goff;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bpl[s] = *reinterpret_cast<const u32x4*>(src + s * b_plane_bytes);
+        } else {
+            tb[slot].issue(Bb, nullptr, b_base(tile), b_goff);
+        }
+    };
+    auto b_store = [&](int slot, char* S) {
+        if (BPRE) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(S + bp_soff + s * SPL_PLANE) = bpl[s];
+        } else if (B_KC) {
+            tb[slot].store(S + b_soff[0], 0);
+            tb[slot].store(S + b_soff[1], 1);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tb[slot].store_pair(S + b_soff[e], e);
+        }
+    };
+    auto a_store = [&](int slot, char* S) {
+        if (A_KC) {
+            ta[slot].store(S + a_soff[0], 0);
+            ta[slot].store(S + a_soff[1], 1);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ta[slot].store_pair(S + a_soff[e], e);
+        }
+    };
     auto load_bx = [&](int tile) {      // threads < 16: the side-product weights of k-tile `tile` (one k each)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            bxr[r] = r < p.sp_r ? p.bx[(int64_t)(k_begin + tile * SPL_BK + threadIdx.x) * p.bx_ks + r * p.bx_rs] : 0.f;
+            bxr[r] = r < p.sp_r ? p.bx[(int64_t)(k_begin + tile * SPL_BK + tid) * p.bx_ks + r * p.bx_rs] : 0.f;
     };
-    auto store_bx = [&](int tile) { *reinterpret_cast<f32x4*>(Bxs + (tile % 3) * SPL_BK * 4 + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]); };
+    auto store_bx = [&](int tile) { *reinterpret_cast<f32x4*>(Bxs + (tile % SPL_BX_RING) * SPL_BK * 4 + tid * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]); };
     // side product of the A registers with the weights of k-tile `tile` (scaled by w: 0 for a surplus commit)
-    auto sp_fma = [&](int tile, float w) {
-        const float* bt = Bxs + (tile % 3) * SPL_BK * 4;
-        const int t = threadIdx.x;
+    auto sp_fma = [&](int slot, int tile, float w) {
+        const float* bt = Bxs + (tile % SPL_BX_RING) * SPL_BK * 4;
         if (A_KC) {
-            const int k4 = 4 * (t & 3);
+            const int k4 = 4 * (tid & 3);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(bt + k4 * 4) * w, b1 = *reinterpret_cast<const f32x4*>(bt + k4 * 4 + 4) * w,
                         b2 = *reinterpret_cast<const f32x4*>(bt + k4 * 4 + 8) * w, b3 = *reinterpret_cast<const f32x4*>(bt + k4 * 4 + 12) * w;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) spacc[i] += ta.v[i].x * b0 + ta.v[i].y * b1 + ta.v[i].z * b2 + ta.v[i].w * b3;
+            for (int i = 0; i < 2; ++i) spacc[i] += ta[slot].v[i].x * b0 + ta[slot].v[i].y * b1 + ta[slot].v[i].z * b2 + ta[slot].v[i].w * b3;
         } else {
-            const int k = 2 * (t >> 5);
+            const int k = 2 * (tid >> 5);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(bt + k * 4) * w, b1 = *reinterpret_cast<const f32x4*>(bt + k * 4 + 4) * w;
-            spacc[0] += ta.v[0].x * b0 + ta.v[1].x * b1;
-            spacc[1] += ta.v[0].y * b0 + ta.v[1].y * b1;
-            spacc[2] += ta.v[0].z * b0 + ta.v[1].z * b1;
-            spacc[3] += ta.v[0].w * b0 + ta.v[1].w * b1;
+            spacc[0] += ta[slot].v[0].x * b0 + ta[slot].v[1].x * b1;
+            spacc[1] += ta[slot].v[0].y * b0 + ta[slot].v[1].y * b1;
+            spacc[2] += ta[slot].v[0].z * b0 + ta[slot].v[1].z * b1;
+            spacc[3] += ta[slot].v[0].w * b0 + ta[slot].v[1].w * b1;
         }
     };
+    auto clampt = [&](int tile) { return min(tile, ntile - 1); };
 
     if (ntile > 0) {
-        ta.issue(Ab, A2b, p.lda, m0, k_begin);
-        tb.issue(Bb, nullptr, p.ldb, n0, k_begin);
-        if (SP && threadIdx.x < SPL_BK) {
+        // k-tile 0 -> stage 0; k-tiles 1 (ring slot 1) and 2 (slot 0) requested; side-product weights of k-tiles 0..2 staged, 3 requested
+        ta[0].issue(Ab, A2b, a_base(0), a_goff);
+        b_issue(0, 0);
+        if (tid < SPL_BK) {
             load_bx(0);
             store_bx(0);
-            load_bx(min(1, ntile - 1));
+            load_bx(clampt(1));
             store_bx(1);
-            load_bx(min(2, ntile - 1));
+            load_bx(clampt(2));
+            store_bx(2);
+            load_bx(clampt(3));
         }
+        ta[1].issue(Ab, A2b, a_base(clampt(1)), a_goff);
         __syncthreads();
-        ta.combine(p.a_act);
-        if (sp_on) sp_fma(0, 1.f);
-        ta.store(spl_smem);
-        tb.store(spl_smem + SPL_OPER);
-        const int k1 = k_begin + min(1, ntile - 1) * SPL_BK;
-        ta.issue(Ab, A2b, p.lda, m0, k1);
-        tb.issue(Bb, nullptr, p.ldb, n0, k1);
+        ta[0].combine(p.a_act);
+        sp_fma(0, 0, 1.f);
+        a_store(0, spl_smem);
+        b_store(0, spl_smem);
+        ta[0].issue(Ab, A2b, a_base(clampt(2)), a_goff);
+        if (BPRE) {
+            b_issue(0, clampt(1));
+        } else {
+            b_issue(1, clampt(1));
+            b_issue(0, clampt(2));
+        }
     }
     __syncthreads();
 
@@ -193,15 +275,16 @@ k_gemm_split(const GemmK p) {
         a_off[i] = ((lane >> 5) * SPL_PLANE_H + spl_pos(wm * 64 + i * 32 + (lane & 31))) * 16;
         b_off[i] = SPL_OPER + ((lane >> 5) * SPL_PLANE_H + spl_pos(wn * 64 + i * 32 + (lane & 31))) * 16;
     }
-    for (int t = 0; t < ntile; ++t) {
+    // one k-tile: t = its index, SLOT = the ring slot that holds k-tile t+1 (compile-time: the loop below is unrolled by two)
+    auto ktile = [&](int t, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
         const int cur = t & 1;
         const char* S = spl_smem + cur * SPL_STAGE;
         char* Sn = spl_smem + (cur ^ 1) * SPL_STAGE;
-        const int k2 = k_begin + min(t + 2, ntile - 1) * SPL_BK;
         const float spw = t + 1 < ntile ? 1.f : 0.f;           // the last iteration's commit is surplus (nobody reads it)
-        if (SP && threadIdx.x < SPL_BK) {                      // weights of k-tile t+2 to the ring, t+3 requested
-            store_bx(t + 2);
-            load_bx(min(t + 3, ntile - 1));
+        if (tid < SPL_BK) {                                    // weights of k-tile t+3 to the ring, t+4 requested
+            store_bx(t + 3);
+            load_bx(clampt(t + 4));
         }
         bf16x8 af[3][2], bf[3][2];
 #pragma unroll
@@ -212,79 +295,118 @@ k_gemm_split(const GemmK p) {
                 bf[s][i] = *reinterpret_cast<const bf16x8*>(S + s * SPL_PLANE + b_off[i]);
             }
         __builtin_amdgcn_sched_barrier(0);
-        // the six terms, smallest first; the A slice after the first eight MFMAs, the B slice after the next eight
+        // the six terms, smallest first; the staging work of k-tile t+1 is cut into pieces that follow the MFMA groups
 #define SPL_TERM(SA, SB)                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SA][i], bf[SB][j], acc[i][j], 0, 0, 0);
         SPL_TERM(2, 0)
+        ta[SLOT].combine(p.a_act);
+        sp_fma(SLOT, t + 1, spw);
+        __builtin_amdgcn_sched_barrier(0);
         SPL_TERM(0, 2)
-        ta.combine(p.a_act);
-        if (sp_on) sp_fma(t + 1, spw);
-        ta.store(Sn);
-        ta.issue(Ab, A2b, p.lda, m0, k2);
+        if (A_KC) ta[SLOT].store(Sn + a_soff[0], 0);
+        else { ta[SLOT].store_pair(Sn + a_soff[0], 0); ta[SLOT].store_pair(Sn + a_soff[1], 1); }
         __builtin_amdgcn_sched_barrier(0);
         SPL_TERM(1, 1)
+        if (A_KC) ta[SLOT].store(Sn + a_soff[1], 1);
+        else { ta[SLOT].store_pair(Sn + a_soff[2], 2); ta[SLOT].store_pair(Sn + a_soff[3], 3); }
+        ta[SLOT].issue(Ab, A2b, a_base(clampt(t + 3)), a_goff);
+        __builtin_amdgcn_sched_barrier(0);
         SPL_TERM(1, 0)
-        tb.store(Sn + SPL_OPER);
-        tb.issue(Bb, nullptr, p.ldb, n0, k2);
+        if (BPRE) {
+            b_store(0, Sn);
+            b_issue(0, clampt(t + 2));
+        } else if (B_KC) {
+            tb[SLOT].store(Sn + b_soff[0], 0);
+        } else {
+            tb[SLOT].store_pair(Sn + b_soff[0], 0);
+            tb[SLOT].store_pair(Sn + b_soff[1], 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         SPL_TERM(0, 1)
+        if (!BPRE) {
+            if (B_KC) tb[SLOT].store(Sn + b_soff[1], 1);
+            else { tb[SLOT].store_pair(Sn + b_soff[2], 2); tb[SLOT].store_pair(Sn + b_soff[3], 3); }
+            tb[SLOT].issue(Bb, nullptr, b_base(clampt(t + 3)), b_goff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         SPL_TERM(0, 0)
 #undef SPL_TERM
         __syncthreads();
+    };
+    // k-tile t+1 sits in ring slot (t + 1) & 1
+    int t = 0;
+    for (; t + 1 < ntile; t += 2) {
+        ktile(t, std::integral_constant<int, 1>());
+        ktile(t + 1, std::integral_constant<int, 0>());
     }
+    if (t < ntile) ktile(t, std::integral_constant<int, 1>());
 
     float* smem = reinterpret_cast<float*>(spl_smem);
-    if (SP) {
-        if (A_KC) {
-            // the four threads of a row (adjacent lanes) hold its four k-chunks
+    if (A_KC) {
+        // the four threads of a row (adjacent lanes) hold its four k-chunks
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x4 s = spacc[i];
+        for (int i = 0; i < 2; ++i) {
+            f32x4 s = spacc[i];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float x = s[c];
-                    x += __shfl_xor(x, 1);
-                    x += __shfl_xor(x, 2);
-                    s[c] = x;
-                }
-                if (sp_on && (threadIdx.x & 3) == 0) {
-                    const int m = m0 + (threadIdx.x >> 2) + 64 * i;
-                    for (int r = 0; r < p.sp_r; ++r) {
-                        if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = s[r];
-                        else p.cx[(int64_t)m * p.cx_ms + r * p.cx_rs] = s[r];
-                    }
-                }
+            for (int c = 0; c < 4; ++c) {
+                float x = s[c];
+                x += __shfl_xor(x, 1);
+                x += __shfl_xor(x, 2);
+                s[c] = x;
             }
-        } else {
-            // eight thread groups (tid >> 5) hold the k-pairs of the same four rows: fixed-order sum through LDS
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                *reinterpret_cast<f32x4*>(smem + (((threadIdx.x >> 5) * 128) + 4 * (threadIdx.x & 31) + e) * 4) = spacc[e];
-            __syncthreads();
-            if (sp_on && threadIdx.x < 128) {
-                f32x4 s = *reinterpret_cast<const f32x4*>(smem + threadIdx.x * 4);
-#pragma unroll
-                for (int g = 1; g < 8; ++g) s += *reinterpret_cast<const f32x4*>(smem + (g * 128 + threadIdx.x) * 4);
-                const int m = m0 + threadIdx.x;
+            if ((tid & 3) == 0) {
+                const int m = m0 + (tid >> 2) + 64 * i;
                 for (int r = 0; r < p.sp_r; ++r) {
                     if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = s[r];
                     else p.cx[(int64_t)m * p.cx_ms + r * p.cx_rs] = s[r];
                 }
             }
-            __syncthreads();
         }
+    } else {
+        // eight thread groups (tid >> 5) hold the k-pairs of the same four rows: fixed-order sum through LDS
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(smem + (((tid >> 5) * 128) + 4 * (tid & 31) + e) * 4) = spacc[e];
+        __syncthreads();
+        if (tid < 128) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(smem + tid * 4);
+#pragma unroll
+            for (int g = 1; g < 8; ++g) s += *reinterpret_cast<const f32x4*>(smem + (g * 128 + tid) * 4);
+            const int m = m0 + tid;
+            for (int r = 0; r < p.sp_r; ++r) {
+                if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = s[r];
+                else p.cx[(int64_t)m * p.cx_ms + r * p.cx_rs] = s[r];
+            }
+        }
+        __syncthreads();
     }
     gemm_lean_epilogue<2, 2, 0>(p, acc, smem, m0, n0, wm, wn, lane, wave, z, bidx);
 }
 
-// Launcher: the (layout, operand kind) combinations of the DCN-v2 step.  RECNOW_EUNSUPPORTED -> the caller runs the fp32 kernel.
-int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, bool sp, dim3 grid, hipStream_t st) {
+size_t rn_gemm_split_planes_bytes(int K, int N) { return rn_align((size_t)(K / 8) * N * 16 * 3); }
+
+// Launcher: the (layout, operand kind) combinations of the DCN-v2 step, N = 128 (one column tile: the side product belongs to
+// it).  `planes` != NULL: B is split once into planes there (rn_gemm_split_planes_bytes(K, N) bytes) before the product.
+// RECNOW_EUNSUPPORTED -> the caller runs the fp32 kernel.
+int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* planes, dim3 grid, hipStream_t st) {
+    if (grid.y != 1 || k.K % SPL_BK || k.kchunk % SPL_BK || k.sp_r <= 0) return RECNOW_EUNSUPPORTED;
+    // element offsets inside a tile are 32-bit
+    if ((int64_t)128 * k.lda >= (1ll << 31) || (int64_t)128 * k.ldb >= (1ll << 31)) return RECNOW_EUNSUPPORTED;
+    const int64_t pb = (int64_t)(k.K / 8) * k.N * 16;
+    if (planes && k.batch == 1 && a_kc) {
+        const int64_t units = (int64_t)(k.K / 8) * k.N;
+        hipLaunchKernelGGL(k_split_planes, (unsigned)((units + 255) / 256), 256, 0, st, k.B, k.ldb, b_kc ? 1 : 0, k.K, k.N, (char*)planes);
+        RN_LAUNCH_CHECK();
+        if (a2k == 0) hipLaunchKernelGGL((k_gemm_split<true, 0, 2>), grid, GEMM_THREADS, SPL_LDS, st, k, (const char*)planes, pb);
+        else if (a2k == 1) hipLaunchKernelGGL((k_gemm_split<true, 1, 2>), grid, GEMM_THREADS, SPL_LDS, st, k, (const char*)planes, pb);
+        else return RECNOW_EUNSUPPORTED;
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
 #define X(AKC, BKC, A2)                                                                                               \
     if (a_kc == AKC && b_kc == BKC && a2k == A2) {                                                                    \
-        if (sp) hipLaunchKernelGGL((k_gemm_split<AKC, BKC, A2, true>), grid, GEMM_THREADS, SPL_LDS, st, k);            \
-        else hipLaunchKernelGGL((k_gemm_split<AKC, BKC, A2, false>), grid, GEMM_THREADS, SPL_LDS, st, k);              \
+        hipLaunchKernelGGL((k_gemm_split<AKC, A2, BKC ? 1 : 0>), grid, GEMM_THREADS, SPL_LDS, st, k, (const char*)nullptr, (int64_t)0);  \
         RN_LAUNCH_CHECK();                                                                                            \
         return RECNOW_OK;                                                                                             \
     }
