@@ -26,15 +26,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define SPL_BK 16
-#define SPL_PLANE_H 136                                  // 16-byte units per k-half: 128 rows + 1 pad per 16 rows
+#define SPL_PLANE_H 132                                  // 16-byte units per k-half: 128 rows + 4 (the second half starts 64 B
+                                                         //   into the 128-B bank row of the stores: 8-lane store groups of 4 rows x 2 halves tile it)
 #define SPL_PLANE (2 * SPL_PLANE_H * 16)                 // bytes per piece plane
 #define SPL_OPER (3 * SPL_PLANE)                         // bytes per operand and stage
 #define SPL_STAGE (2 * SPL_OPER)
 #define SPL_BX_OFF (2 * SPL_STAGE)                       // side-product weights: ring of 4 k-tiles x 16 k x 4 floats
 #define SPL_BX_RING 4
 #define SPL_LDS (SPL_BX_OFF + SPL_BX_RING * SPL_BK * 4 * 4)
-
-__device__ __forceinline__ int spl_pos(int r) { return r + (r >> 4); }
 
 // (u, v) -> three packed bf16 pairs (low half = piece of u, high half = piece of v)
 __device__ __forceinline__ void spl_split2(float u, float v, unsigned& p1, unsigned& p2, unsigned& p3) {
@@ -47,6 +46,15 @@ __device__ __forceinline__ void spl_split2(float u, float v, unsigned& p1, unsig
     r.y -= __builtin_bit_cast(float, p2 & 0xffff0000u);
     bf16x2 f = {(__bf16)r.x, (__bf16)r.y};
     p3 = __builtin_bit_cast(unsigned, f);
+}
+// eight consecutive k of one row -> one 16-byte unit per piece
+__device__ __forceinline__ void spl_split8(const float (&x)[8], u32x4 (&w)[3]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned p1, p2, p3;
+        spl_split2(x[2 * e], x[2 * e + 1], p1, p2, p3);
+        w[0][e] = p1; w[1][e] = p2; w[2][e] = p3;
+    }
 }
 
 // B (K x N; [K][N] rows of ldb floats, or [N][K] when b_kc) -> planes[s][K/8][N] units of 8 bf16 (16 B): unit (o, n) of piece s
@@ -64,55 +72,50 @@ __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ 
         for (int e = 0; e < 8; ++e) x[e] = B[(int64_t)(8 * o + e) * ldb + n];
     }
     u32x4 w[3];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        unsigned p1, p2, p3;
-        spl_split2(x[2 * e], x[2 * e + 1], p1, p2, p3);
-        w[0][e] = p1; w[1][e] = p2; w[2][e] = p3;
-    }
+    spl_split8(x, w);
     const int64_t ps = total * 16;
 #pragma unroll
     for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(planes + s * ps + u * 16) = w[s];
 }
 
-// One fp32 operand's staging registers for ONE k-tile: two float4 per thread.
-//   KC  ([row][k], k contiguous): slot i = rows (tid >> 2) + 64 i, k = 4 (tid & 3) .. +3
-//   !KC ([k][row], row contiguous): slot i = k 2 (tid >> 5) + i, rows 4 (tid & 31) .. +3   (the two slots pair up along k)
+// One fp32 operand's staging registers for ONE k-tile.  Every thread owns exactly one unit = 8 consecutive k (k-half h) of one
+// tile row, so that the split pieces leave as three conflict-free ds_write_b128:
+//   KC  ([row][k], k contiguous): row = tid >> 1, h = tid & 1: two float4 (32 contiguous bytes)
+//   !KC ([k][row], row contiguous): row = tid & 127, h = tid >> 7: eight dword loads, one per k row (a wave reads 256 contiguous
+//        bytes of each: float4 loads here would leave every thread with 4 rows x 2 k, i.e. 2-byte scatters into LDS)
 template <bool KC, int K2>
 struct SplTile {
-    f32x4 v[2], y[2];
-    __device__ __forceinline__ void issue(const float* __restrict__ p, const float* __restrict__ p2, int64_t tile_off, const unsigned (&off)[2]) {
+    float v[8], y[8];
+    __device__ __forceinline__ void issue(const float* __restrict__ p, const float* __restrict__ p2, int64_t tile_off, unsigned off, int64_t ld) {
+        if (KC) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + tile_off + off), b = *reinterpret_cast<const f32x4*>(p + tile_off + off + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            if (K2 != RECNOW_OPMODE_NONE) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p2 + tile_off + off), d = *reinterpret_cast<const f32x4*>(p2 + tile_off + off + 4);
+                y[0] = c.x; y[1] = c.y; y[2] = c.z; y[3] = c.w; y[4] = d.x; y[5] = d.y; y[6] = d.z; y[7] = d.w;
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            v[i] = *reinterpret_cast<const f32x4*>(p + tile_off + off[i]);
-            if (K2 != RECNOW_OPMODE_NONE) y[i] = *reinterpret_cast<const f32x4*>(p2 + tile_off + off[i]);
+            for (int e = 0; e < 8; ++e) {
+                v[e] = p[tile_off + e * ld + off];
+                if (K2 != RECNOW_OPMODE_NONE) y[e] = p2[tile_off + e * ld + off];
+            }
         }
     }
     __device__ __forceinline__ void combine(int act) {
-        if (K2 != RECNOW_OPMODE_NONE) {
-            v[0] = gemm_combine(v[0], y[0], K2, act);
-            v[1] = gemm_combine(v[1], y[1], K2, act);
+        if (K2 == RECNOW_OPMODE_MUL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= y[e];
+        } else if (K2 != RECNOW_OPMODE_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= rn_act_grad_from_out(y[e], act);
         }
     }
-    // split and write to the three planes at `S` (byte address of the operand's stage image + this thread's offset)
-    __device__ __forceinline__ void store(char* __restrict__ S, int i) const {      // KC: one slot
-        unsigned a1, a2, a3, b1, b2, b3;
-        spl_split2(v[i].x, v[i].y, a1, a2, a3);
-        spl_split2(v[i].z, v[i].w, b1, b2, b3);
-        u32x2 w;
-        w.x = a1; w.y = b1;
-        *reinterpret_cast<u32x2*>(S) = w;
-        w.x = a2; w.y = b2;
-        *reinterpret_cast<u32x2*>(S + SPL_PLANE) = w;
-        w.x = a3; w.y = b3;
-        *reinterpret_cast<u32x2*>(S + 2 * SPL_PLANE) = w;
-    }
-    __device__ __forceinline__ void store_pair(char* __restrict__ S, int e) const {  // !KC: row e of the four, k pair
-        unsigned p1, p2, p3;
-        spl_split2(v[0][e], v[1][e], p1, p2, p3);
-        *reinterpret_cast<unsigned*>(S) = p1;
-        *reinterpret_cast<unsigned*>(S + SPL_PLANE) = p2;
-        *reinterpret_cast<unsigned*>(S + 2 * SPL_PLANE) = p3;
+    __device__ __forceinline__ void store(char* __restrict__ S) const {      // S: this thread's unit in piece plane 0
+        u32x4 w[3];
+        spl_split8(v, w);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(S + s * SPL_PLANE) = w[s];
     }
 };
 
@@ -148,35 +151,17 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // side product accumulators: KC -> spacc[i] = the 4 columns of row (tid >> 2) + 64 i, partial over this thread's 4 k;
-    //                            !KC -> spacc[e] = the 4 columns of row 4 (tid & 31) + e, partial over this thread's k pairs
-    f32x4 spacc[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) spacc[e] = mk4(0.f, 0.f, 0.f, 0.f);
+    f32x4 spacc = mk4(0.f, 0.f, 0.f, 0.f);       // side product: the 4 columns of this thread's A row, partial over its k-half
     float bxr[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // thread-invariant element offsets inside a k-tile (the tile base is block-uniform and lives in SGPRs) and LDS write offsets
-    unsigned a_goff[2], b_goff[2];
-    int a_soff[4], b_soff[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a_goff[i] = A_KC ? (unsigned)(((tid >> 2) + 64 * i) * p.lda + 4 * (tid & 3)) : (unsigned)((2 * (tid >> 5) + i) * p.lda + 4 * (tid & 31));
-        b_goff[i] = B_KC ? (unsigned)(((tid >> 2) + 64 * i) * p.ldb + 4 * (tid & 3)) : (unsigned)((2 * (tid >> 5) + i) * p.ldb + 4 * (tid & 31));
-    }
-    {
-        const int k4 = 4 * (tid & 3), kp = 2 * (tid >> 5);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // KC uses entries 0, 1 (its two slots); !KC entries 0..3 (the four rows of its k pair)
-            const int kc_off = ((k4 >> 3) * SPL_PLANE_H + spl_pos((tid >> 2) + 64 * (e & 1))) * 16 + ((k4 >> 2) & 1) * 8;
-            const int rc_off = ((kp >> 3) * SPL_PLANE_H + spl_pos(4 * (tid & 31) + e)) * 16 + (kp & 7) * 2;
-            a_soff[e] = A_KC ? kc_off : rc_off;
-            b_soff[e] = SPL_OPER + (B_KC ? kc_off : rc_off);
-        }
-    }
-    // planes: thread copies unit (k-half tid >> 7, column tid & 127) of each piece
-    const int64_t bp_goff = BPRE ? ((int64_t)(tid >> 7) * p.N + n0 + (tid & 127)) * 16 : 0;
-    const int bp_soff = SPL_OPER + ((tid >> 7) * SPL_PLANE_H + spl_pos(tid & 127)) * 16;
+    // this thread's unit (row, k-half) per operand: element offset inside a k-tile (the tile base is block-uniform) and LDS offset
+    const int a_row = A_KC ? tid >> 1 : tid & 127, a_h = A_KC ? tid & 1 : tid >> 7;
+    const int b_row = B_KC ? tid >> 1 : tid & 127, b_h = B_KC ? tid & 1 : tid >> 7;      // planes: as !KC
+    const unsigned a_goff = A_KC ? (unsigned)(a_row * p.lda + 8 * a_h) : (unsigned)(8 * a_h * p.lda + a_row);
+    const unsigned b_goff = B_KC ? (unsigned)(b_row * p.ldb + 8 * b_h) : (unsigned)(8 * b_h * p.ldb + b_row);
+    const int a_soff = (a_h * SPL_PLANE_H + a_row) * 16;
+    const int b_soff = SPL_OPER + (b_h * SPL_PLANE_H + b_row) * 16;
+    const int64_t bp_goff = BPRE ? ((int64_t)b_h * p.N + n0 + b_row) * 16 : 0;
 
     SplTile<A_KC, A2K> ta[2];                      // ring of two k-tiles in flight
     SplTile<B_KC, RECNOW_OPMODE_NONE> tb[2];       // in-kernel split of B: ring of two as well
@@ -189,28 +174,15 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
 #pragma unroll
             for (int s = 0; s < 3; ++s) bpl[s] = *reinterpret_cast<const u32x4*>(src + s * b_plane_bytes);
         } else {
-            tb[slot].issue(Bb, nullptr, b_base(tile), b_goff);
+            tb[slot].issue(Bb, nullptr, b_base(tile), b_goff, p.ldb);
         }
     };
     auto b_store = [&](int slot, char* S) {
         if (BPRE) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(S + bp_soff + s * SPL_PLANE) = bpl[s];
-        } else if (B_KC) {
-            tb[slot].store(S + b_soff[0], 0);
-            tb[slot].store(S + b_soff[1], 1);
+            for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(S + b_soff + s * SPL_PLANE) = bpl[s];
         } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tb[slot].store_pair(S + b_soff[e], e);
-        }
-    };
-    auto a_store = [&](int slot, char* S) {
-        if (A_KC) {
-            ta[slot].store(S + a_soff[0], 0);
-            ta[slot].store(S + a_soff[1], 1);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ta[slot].store_pair(S + a_soff[e], e);
+            tb[slot].store(S + b_soff);
         }
     };
     auto load_bx = [&](int tile) {      // threads < 16: the side-product weights of k-tile `tile` (one k each)
@@ -219,29 +191,19 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
             bxr[r] = r < p.sp_r ? p.bx[(int64_t)(k_begin + tile * SPL_BK + tid) * p.bx_ks + r * p.bx_rs] : 0.f;
     };
     auto store_bx = [&](int tile) { *reinterpret_cast<f32x4*>(Bxs + (tile % SPL_BX_RING) * SPL_BK * 4 + tid * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]); };
-    // side product of the A registers with the weights of k-tile `tile` (scaled by w: 0 for a surplus commit)
+    // side product of the A registers with the weights of k-tile `tile` (times w: 0 for a surplus commit)
     auto sp_fma = [&](int slot, int tile, float w) {
-        const float* bt = Bxs + (tile % SPL_BX_RING) * SPL_BK * 4;
-        if (A_KC) {
-            const int k4 = 4 * (tid & 3);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bt + k4 * 4) * w, b1 = *reinterpret_cast<const f32x4*>(bt + k4 * 4 + 4) * w,
-                        b2 = *reinterpret_cast<const f32x4*>(bt + k4 * 4 + 8) * w, b3 = *reinterpret_cast<const f32x4*>(bt + k4 * 4 + 12) * w;
+        const float* bt = Bxs + (tile % SPL_BX_RING) * SPL_BK * 4 + a_h * 32;
+        f32x4 s = ta[slot].v[0] * *reinterpret_cast<const f32x4*>(bt);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) spacc[i] += ta[slot].v[i].x * b0 + ta[slot].v[i].y * b1 + ta[slot].v[i].z * b2 + ta[slot].v[i].w * b3;
-        } else {
-            const int k = 2 * (tid >> 5);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bt + k * 4) * w, b1 = *reinterpret_cast<const f32x4*>(bt + k * 4 + 4) * w;
-            spacc[0] += ta[slot].v[0].x * b0 + ta[slot].v[1].x * b1;
-            spacc[1] += ta[slot].v[0].y * b0 + ta[slot].v[1].y * b1;
-            spacc[2] += ta[slot].v[0].z * b0 + ta[slot].v[1].z * b1;
-            spacc[3] += ta[slot].v[0].w * b0 + ta[slot].v[1].w * b1;
-        }
+        for (int e = 1; e < 8; ++e) s += ta[slot].v[e] * *reinterpret_cast<const f32x4*>(bt + 4 * e);
+        spacc += w * s;
     };
     auto clampt = [&](int tile) { return min(tile, ntile - 1); };
 
     if (ntile > 0) {
         // k-tile 0 -> stage 0; k-tiles 1 (ring slot 1) and 2 (slot 0) requested; side-product weights of k-tiles 0..2 staged, 3 requested
-        ta[0].issue(Ab, A2b, a_base(0), a_goff);
+        ta[0].issue(Ab, A2b, a_base(0), a_goff, p.lda);
         b_issue(0, 0);
         if (tid < SPL_BK) {
             load_bx(0);
@@ -252,13 +214,13 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
             store_bx(2);
             load_bx(clampt(3));
         }
-        ta[1].issue(Ab, A2b, a_base(clampt(1)), a_goff);
+        ta[1].issue(Ab, A2b, a_base(clampt(1)), a_goff, p.lda);
         __syncthreads();
         ta[0].combine(p.a_act);
         sp_fma(0, 0, 1.f);
-        a_store(0, spl_smem);
+        ta[0].store(spl_smem + a_soff);
         b_store(0, spl_smem);
-        ta[0].issue(Ab, A2b, a_base(clampt(2)), a_goff);
+        ta[0].issue(Ab, A2b, a_base(clampt(2)), a_goff, p.lda);
         if (BPRE) {
             b_issue(0, clampt(1));
         } else {
@@ -268,12 +230,13 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
     }
     __syncthreads();
 
-    // fragment addresses: lane (row l & 31 of the 32-row MFMA tile, k-half l >> 5) reads one 16-byte unit per piece
+    // fragment addresses: lane (row l & 31 of the 32-row MFMA tile, k-half l >> 5) reads one 16-byte unit per piece (consecutive
+    // units per half: conflict-free for the 16-lane groups of ds_read_b128)
     int a_off[2], b_off[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        a_off[i] = ((lane >> 5) * SPL_PLANE_H + spl_pos(wm * 64 + i * 32 + (lane & 31))) * 16;
-        b_off[i] = SPL_OPER + ((lane >> 5) * SPL_PLANE_H + spl_pos(wn * 64 + i * 32 + (lane & 31))) * 16;
+        a_off[i] = ((lane >> 5) * SPL_PLANE_H + wm * 64 + i * 32 + (lane & 31)) * 16;
+        b_off[i] = SPL_OPER + ((lane >> 5) * SPL_PLANE_H + wn * 64 + i * 32 + (lane & 31)) * 16;
     }
     // one k-tile: t = its index, SLOT = the ring slot that holds k-tile t+1 (compile-time: the loop below is unrolled by two)
     auto ktile = [&](int t, auto slot_c) {
@@ -295,43 +258,30 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
                 bf[s][i] = *reinterpret_cast<const bf16x8*>(S + s * SPL_PLANE + b_off[i]);
             }
         __builtin_amdgcn_sched_barrier(0);
-        // the six terms, smallest first; the staging work of k-tile t+1 is cut into pieces that follow the MFMA groups
+        // the six terms in the order their fragments were requested (pieces 0, then 1, then 2: the first group waits for four
+        // reads, not twelve); the staging work of k-tile t+1 is cut into pieces that follow the MFMA groups
 #define SPL_TERM(SA, SB)                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SA][i], bf[SB][j], acc[i][j], 0, 0, 0);
-        SPL_TERM(2, 0)
+        SPL_TERM(0, 0)
         ta[SLOT].combine(p.a_act);
         sp_fma(SLOT, t + 1, spw);
         __builtin_amdgcn_sched_barrier(0);
-        SPL_TERM(0, 2)
-        if (A_KC) ta[SLOT].store(Sn + a_soff[0], 0);
-        else { ta[SLOT].store_pair(Sn + a_soff[0], 0); ta[SLOT].store_pair(Sn + a_soff[1], 1); }
-        __builtin_amdgcn_sched_barrier(0);
-        SPL_TERM(1, 1)
-        if (A_KC) ta[SLOT].store(Sn + a_soff[1], 1);
-        else { ta[SLOT].store_pair(Sn + a_soff[2], 2); ta[SLOT].store_pair(Sn + a_soff[3], 3); }
-        ta[SLOT].issue(Ab, A2b, a_base(clampt(t + 3)), a_goff);
+        SPL_TERM(0, 1)
+        ta[SLOT].store(Sn + a_soff);
         __builtin_amdgcn_sched_barrier(0);
         SPL_TERM(1, 0)
-        if (BPRE) {
-            b_store(0, Sn);
-            b_issue(0, clampt(t + 2));
-        } else if (B_KC) {
-            tb[SLOT].store(Sn + b_soff[0], 0);
-        } else {
-            tb[SLOT].store_pair(Sn + b_soff[0], 0);
-            tb[SLOT].store_pair(Sn + b_soff[1], 1);
-        }
+        ta[SLOT].issue(Ab, A2b, a_base(clampt(t + 3)), a_goff, p.lda);
         __builtin_amdgcn_sched_barrier(0);
-        SPL_TERM(0, 1)
-        if (!BPRE) {
-            if (B_KC) tb[SLOT].store(Sn + b_soff[1], 1);
-            else { tb[SLOT].store_pair(Sn + b_soff[2], 2); tb[SLOT].store_pair(Sn + b_soff[3], 3); }
-            tb[SLOT].issue(Bb, nullptr, b_base(clampt(t + 3)), b_goff);
-        }
+        SPL_TERM(1, 1)
+        b_store(SLOT, Sn);
         __builtin_amdgcn_sched_barrier(0);
-        SPL_TERM(0, 0)
+        SPL_TERM(0, 2)
+        if (BPRE) b_issue(0, clampt(t + 2));
+        else b_issue(SLOT, clampt(t + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        SPL_TERM(2, 0)
 #undef SPL_TERM
         __syncthreads();
     };
@@ -343,36 +293,24 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
     }
     if (t < ntile) ktile(t, std::integral_constant<int, 1>());
 
+    // the two threads of a row (its two k-halves): adjacent lanes (KC) or 128 threads apart (!KC, through LDS)
     float* smem = reinterpret_cast<float*>(spl_smem);
     if (A_KC) {
-        // the four threads of a row (adjacent lanes) hold its four k-chunks
+        f32x4 s = spacc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4 s = spacc[i];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float x = s[c];
-                x += __shfl_xor(x, 1);
-                x += __shfl_xor(x, 2);
-                s[c] = x;
-            }
-            if ((tid & 3) == 0) {
-                const int m = m0 + (tid >> 2) + 64 * i;
-                for (int r = 0; r < p.sp_r; ++r) {
-                    if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = s[r];
-                    else p.cx[(int64_t)m * p.cx_ms + r * p.cx_rs] = s[r];
-                }
+        for (int c = 0; c < 4; ++c) s[c] += __shfl_xor(s[c], 1);
+        if ((tid & 1) == 0) {
+            const int m = m0 + a_row;
+            for (int r = 0; r < p.sp_r; ++r) {
+                if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = s[r];
+                else p.cx[(int64_t)m * p.cx_ms + r * p.cx_rs] = s[r];
             }
         }
     } else {
-        // eight thread groups (tid >> 5) hold the k-pairs of the same four rows: fixed-order sum through LDS
-#pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(smem + (((tid >> 5) * 128) + 4 * (tid & 31) + e) * 4) = spacc[e];
+        if (tid >= 128) *reinterpret_cast<f32x4*>(smem + (tid - 128) * 4) = spacc;
         __syncthreads();
         if (tid < 128) {
-            f32x4 s = *reinterpret_cast<const f32x4*>(smem + tid * 4);
-#pragma unroll
-            for (int g = 1; g < 8; ++g) s += *reinterpret_cast<const f32x4*>(smem + (g * 128 + tid) * 4);
+            const f32x4 s = spacc + *reinterpret_cast<const f32x4*>(smem + tid * 4);
             const int m = m0 + tid;
             for (int r = 0; r < p.sp_r; ++r) {
                 if (p.splitk > 1) p.partial[((int64_t)z * p.M + m) * p.npart + p.N + r] = s[r];
