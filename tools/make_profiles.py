@@ -68,11 +68,15 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
         fo.write('| `%s` | %s | %.2f | %.1f | %s |\n' % (r['Name'][:100].replace('|', '/'), r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                    float(r['AverageNs']) / 1e3, r['Percentage']))
 shutil.copy('gpurun_out/%s_bench.json' % tag, 'profiles/%s_bench.json' % tag)
-for extra in ('bench_unfused', 'bench_forcedist', 'layer_bench'):
+for extra in ('bench_unfused', 'bench_forcedist', 'bench_bf16x3', 'layer_bench'):
     for ext in ('json', 'txt'):
         src = 'gpurun_out/%s_%s.%s' % (tag, extra, ext)
         if os.path.exists(src):
             shutil.copy(src, 'profiles/%s_%s.%s' % (tag, extra, ext))
+try:
+    shutil.copy(newest('gpurun_out/%s_stats_bf16x3/*/*_kernel_stats.csv' % tag), 'profiles/%s_bench_bf16x3_kernel_stats.csv' % tag)
+except IndexError:
+    pass
 if os.path.exists('gpurun_out/%s_gemm_bench.txt' % tag):
     lines = [l for l in open('gpurun_out/%s_gemm_bench.txt' % tag) if 'TFLOP' in l]
     open('profiles/%s_gemm_bench.txt' % tag, 'w').writelines(lines)
