@@ -62,7 +62,8 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
              'same build: `%s_bench.json`; GEMM microbenchmark (`tools/gemm_bench.py`): `%s_gemm_bench.txt`.\n\n' % (tag, tag, tag, tag))
     fo.write('Sum of kernel durations: %.1f ms over %d steps (3 warm-up + 10 timed + 5 untimed host-enqueue diagnostic + 1 parity step) = %.3f ms/step.  The batch-grouping kernels (sort, scans, '
              'segments) run on a side stream under the forward pass and are stretched by the GEMMs they share the chip with, so this sum is '
-             'larger than the wall time per step (see `%s_bench.json`).\n\n' % (tot / 1e6, steps, tot / 1e6 / steps, tag))
+             'larger than the wall time per step (see `%s_bench.json`); `__amd_rocclr_copyBuffer` is the parity step copying d loss / d x and the '
+             'gradients to the host, outside the timed region.\n\n' % (tot / 1e6, steps, tot / 1e6 / steps, tag))
     fo.write('| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n')
     for r in rows[:24]:
         fo.write('| `%s` | %s | %.2f | %.1f | %s |\n' % (r['Name'][:100].replace('|', '/'), r['Calls'], float(r['TotalDurationNs']) / 1e6,
