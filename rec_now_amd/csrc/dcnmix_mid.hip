@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline size_t mid_fwd_lds(int S, int N) { return ((size_t)N * S * S + (size_t)MID_ROWS * (N * S + 1) + (size_t)MID_ROWS * N) * sizeof(float); }
 static inline size_t mid_bwd_lds(int S, int N) {
-    return ((size_t)N * S * S + 2 * (size_t)MID_ROWS * (N * S + 1) + 2 * (size_t)MID_ROWS * N) * sizeof(float);
+    return ((size_t)N * S * S + 2 * (size_t)MID_ROWS * (N * S + 1) + 3 * (size_t)MID_ROWS * N) * sizeof(float);      // + Ds of the fast variant
 }
 
 bool rn_mix_mid_supported(int S, int N, int LDT) {
@@ -303,6 +303,268 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
     }
 }
 
+// ---- fast variants: every tile full (B % 32 == 0), N a template parameter with N * S = 128 (four 32 x 32 output blocks: one
+// per wave), LDT = N * S + 16 -----------------------------------------------------------------------------------------------
+// Same arithmetic, same order of operations as the general kernels above (results equal up to fma contraction), restructured around what their
+// ISA showed: (1) every `if (row < B)` / `if (i < nch)` around a load became a branch with an `s_waitcnt vmcnt(0)` at its merge, so
+// the prefetch loads of a tile were issued one HBM round trip after the other (~10 us per 32-row tile); (2) vmcnt counts loads and
+// stores in order, and a wait for the prefetched tile is `vmcnt(number of stores issued since)` only if that number is the same on
+// every path -- so no store sits under a lane or wave condition here: the gate columns (computed by 32 lanes) go through LDS and
+// are stored by all 256 threads, one float4 each, and every wave owns exactly one output block.
+template <int S, int N, int AO>
+__device__ __forceinline__ void mid_fwd_fast_body(const float* __restrict__ T1, const float* __restrict__ V, float* __restrict__ T2,
+                                                  float* __restrict__ T2g, int64_t B, int LDT, int act_outer_rt) {
+    const int act_outer = AO >= 0 ? AO : act_outer_rt;       // compile-time activation: no per-element switch in the store loop
+    extern __shared__ float lds[];
+    constexpr int NS = N * S, LDA = NS + 1, CPR = NS / 4, NCH = MID_ROWS * CPR / 256;
+    static_assert(NS == 128 && NCH == 4 && N * (S / 32) == 4, "N * S = 128");
+    float* Vs = lds;                       // [n][k][col]
+    float* As = Vs + N * S * S;            // [row][NS] stride LDA
+    float* Gs = As + MID_ROWS * LDA;       // [row][n]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid * 4; i < N * S * S; i += 1024) *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(V + i);
+    const int64_t ntiles = B / MID_ROWS;
+    float4 pv[NCH];
+    float plg[N];
+    auto prefetch = [&](int64_t r0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, r = c / CPR, k4 = (c - r * CPR) * 4;
+            pv[i] = *reinterpret_cast<const float4*>(T1 + (r0 + r) * LDT + k4);
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) plg[n] = T1[(r0 + (tid & 31)) * LDT + NS + n];      // every thread (no branch); threads < 32 use it
+    };
+    auto stage = [&]() {                       // prefetched tile -> LDS; softmax of its logits -> LDS
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, r = c / CPR, k4 = (c - r * CPR) * 4;
+            float* d = As + r * LDA + k4;
+            d[0] = pv[i].x; d[1] = pv[i].y; d[2] = pv[i].z; d[3] = pv[i].w;
+        }
+        if (tid < MID_ROWS) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int n = 0; n < N; ++n) mx = plg[n] > mx ? plg[n] : mx;
+            float lg[N];
+            float sum = 0.f;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                lg[n] = expf(plg[n] - mx);
+                sum += lg[n];
+            }
+#pragma unroll
+            for (int n = 0; n < N; ++n) Gs[tid * N + n] = lg[n] / sum;
+        }
+    };
+    // Loop shape: [stage tile] B [request next tile; gate columns + output block stored] B [stage next tile] ...: the wait for the
+    // requested tile sits in the stage at the bottom, behind a fixed number of stores (the stage after the last tile stages the
+    // re-read last tile, which nobody uses).
+    prefetch((int64_t)blockIdx.x * MID_ROWS);
+    stage();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * MID_ROWS;
+        __syncthreads();
+        {
+            const int64_t nt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+            prefetch(nt * MID_ROWS);
+        }
+        {   // columns NS .. NS + 15 of T2 and T2g: [G | 0]; thread = (row, tensor, float4)
+            const int row = tid >> 3, q = tid & 3;
+            float g4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g4[e] = 4 * q + e < N ? Gs[row * N + ((4 * q + e) < N ? 4 * q + e : 0)] : 0.f;
+            float* dst = ((tid & 4) ? T2g : T2) + (r0 + row) * LDT + NS + 4 * q;
+            *reinterpret_cast<float4*>(dst) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        }
+        {
+            const int n = w / (S / 32), cb = w - n * (S / 32);              // one output block per wave
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = As + (lane & 31) * LDA + n * S + (lane >> 5);
+            const float* bp = Vs + n * S * S + (lane >> 5) * S + cb * 32 + (lane & 31);
+#pragma unroll 8
+            for (int st = 0; st < S / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], bp[2 * st * S], acc, 0, 0, 0);
+            const int col = n * S + cb * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t row = r0 + rr;
+                const float h2 = rn_act(acc[r], act_outer);
+                T2[row * LDT + col] = h2;
+                T2g[row * LDT + col] = Gs[rr * N + n] * h2;
+            }
+        }
+        __syncthreads();
+        stage();
+    }
+}
+
+template <int S, int N>
+__global__ void __launch_bounds__(256, 2)
+k_mix_mid_fwd_fast(const float* __restrict__ T1, const float* __restrict__ V, float* __restrict__ T2, float* __restrict__ T2g, int64_t B,
+                   int LDT, int act_outer) {
+    if (act_outer == RECNOW_ACT_TANH) mid_fwd_fast_body<S, N, RECNOW_ACT_TANH>(T1, V, T2, T2g, B, LDT, act_outer);
+    else mid_fwd_fast_body<S, N, -1>(T1, V, T2, T2g, B, LDT, act_outer);
+}
+
+template <int S, int N, bool RS, int AI, int AO>
+__device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1,
+                                                  const float* __restrict__ V, float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B,
+                                                  int LDT, int act_inner_rt, int act_outer_rt, const float* __restrict__ rscale) {
+    const int act_inner = AI >= 0 ? AI : act_inner_rt, act_outer = AO >= 0 ? AO : act_outer_rt;
+    extern __shared__ float lds[];
+    constexpr int NS = N * S, LDA = NS + 1, CPR = NS / 4, NCH = MID_ROWS * CPR / 256, GL = S / 4;
+    constexpr int nvitems = N * (S / 32) * (S / 32), VI = (nvitems + 3) / 4;
+    static_assert(NS == 128 && NCH == 4 && N * (S / 32) == 4, "N * S = 128");
+    float* VTs = lds;                      // [n][t][s] = V[n][s][t]
+    float* Cs = VTs + N * S * S;           // dC tile
+    float* Hs = Cs + MID_ROWS * LDA;       // H1 tile
+    float* Ps = Hs + MID_ROWS * LDA;       // [row][n]  <dT2g_n, H2_n>
+    float* Ds = Ps + MID_ROWS * N;         // [row][n]  dlogits of the tile (stored by all threads after the next barrier)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < N * S * S; i += 256) {
+        const int n = i / (S * S), rem = i - n * S * S, s = rem / S, t = rem - s * S;
+        VTs[n * S * S + t * S + s] = V[i];
+    }
+    f32x16 accV[VI];
+#pragma unroll
+    for (int j = 0; j < VI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accV[j][r] = 0.f;
+    const int64_t ntiles = B / MID_ROWS;
+    float4 pd[NCH], ph[NCH], pa[NCH];
+    float pg[NCH], psc[NCH];
+    float pgg[N], pdg[N], psg = 1.f;           // gate row (tid & 31): used by threads < 32
+    auto prefetch = [&](int64_t r0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, r = c / CPR, k4 = (c - r * CPR) * 4, n = k4 / S;
+            const int64_t row = r0 + r;
+            pd[i] = *reinterpret_cast<const float4*>(dT2g + row * LDT + k4);
+            ph[i] = *reinterpret_cast<const float4*>(T2 + row * LDT + k4);
+            pa[i] = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
+            pg[i] = T2[row * LDT + NS + n];
+            psc[i] = RS ? rscale[row] : 1.f;
+        }
+        const int64_t grow = r0 + (tid & 31);
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            pgg[n] = T2[grow * LDT + NS + n];
+            pdg[n] = dT2g[grow * LDT + NS + n];
+        }
+        if (RS) psg = rscale[grow];
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, r = c / CPR, k4 = (c - r * CPR) * 4, n = k4 / S;
+            float4 d = pd[i];
+            if (RS) { d.x *= psc[i]; d.y *= psc[i]; d.z *= psc[i]; d.w *= psc[i]; }
+            const float4 h = ph[i], a = pa[i];
+            const float g = pg[i];
+            float* cd = Cs + r * LDA + k4;
+            cd[0] = g * d.x * rn_act_grad_from_out(h.x, act_outer);
+            cd[1] = g * d.y * rn_act_grad_from_out(h.y, act_outer);
+            cd[2] = g * d.z * rn_act_grad_from_out(h.z, act_outer);
+            cd[3] = g * d.w * rn_act_grad_from_out(h.w, act_outer);
+            float* hd = Hs + r * LDA + k4;
+            hd[0] = a.x; hd[1] = a.y; hd[2] = a.z; hd[3] = a.w;
+            float pp = d.x * h.x + d.y * h.y + d.z * h.z + d.w * h.w;
+#pragma unroll
+            for (int o = GL / 2; o > 0; o >>= 1) pp += __shfl_xor(pp, o, 64);
+            if ((c & (GL - 1)) == 0) Ps[r * N + n] = pp;
+        }
+    };
+    // Loop shape: [stage tile] B [gate math -> LDS; request next tile; dA block + stores; dV blocks] B [gate columns stored by all
+    // threads; stage next tile] ...: the stage at the bottom belongs to the next iteration (after the last tile it stages the
+    // re-read last tile again, which nobody uses).
+    prefetch((int64_t)blockIdx.x * MID_ROWS);
+    __syncthreads();                       // VTs complete
+    stage();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * MID_ROWS;
+        __syncthreads();
+        if (tid < MID_ROWS) {
+            float dg[N];
+            float dot = 0.f;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                dg[n] = Ps[tid * N + n] + pdg[n] * psg;
+                dot += pgg[n] * dg[n];
+            }
+#pragma unroll
+            for (int n = 0; n < N; ++n) Ds[tid * N + n] = pgg[n] * (dg[n] - dot);
+        }
+        {
+            const int64_t nt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+            prefetch(nt * MID_ROWS);
+        }
+        {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n): one 32x32 output block (n, cb) per wave
+            const int n = w / (S / 32), cb = w - n * (S / 32);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = Cs + (lane & 31) * LDA + n * S + (lane >> 5);
+            const float* bp = VTs + n * S * S + (lane >> 5) * S + cb * 32 + (lane & 31);
+#pragma unroll 8
+            for (int st = 0; st < S / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], bp[2 * st * S], acc, 0, 0, 0);
+            const int col = n * S + cb * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                dT1[(r0 + rr) * LDT + col] = acc[r] * rn_act_grad_from_out(Hs[rr * LDA + col], act_inner);
+            }
+        }
+        // dV_n += H1_n^T dC_n over this tile's 32 rows: output blocks (n, mb, cb) stay in registers across tiles
+#pragma unroll
+        for (int j = 0; j < VI; ++j) {
+            const int item = w + 4 * j;
+            if (item < nvitems) {
+                const int n = item / ((S / 32) * (S / 32)), rem = item - n * (S / 32) * (S / 32), mb = rem / (S / 32), cb = rem - mb * (S / 32);
+                const float* ap = Hs + (lane >> 5) * LDA + n * S + mb * 32 + (lane & 31);
+                const float* bp = Cs + (lane >> 5) * LDA + n * S + cb * 32 + (lane & 31);
+#pragma unroll 8
+                for (int st = 0; st < MID_ROWS / 2; ++st)
+                    accV[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st * LDA], bp[2 * st * LDA], accV[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        {   // columns NS .. NS + 15 of dT1: [dlogits | 0]; thread = (row, float4), two threads write each float4 (same values)
+            const int row = tid >> 3, q = tid & 3;
+            float g4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g4[e] = 4 * q + e < N ? Ds[row * N + ((4 * q + e) < N ? 4 * q + e : 0)] : 0.f;
+            *reinterpret_cast<float4*>(dT1 + (r0 + row) * LDT + NS + 4 * q) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        }
+        stage();
+    }
+    float* P = dVpart + (int64_t)blockIdx.x * N * S * S;
+#pragma unroll
+    for (int j = 0; j < VI; ++j) {
+        const int item = w + 4 * j;
+        if (item < nvitems) {
+            const int n = item / ((S / 32) * (S / 32)), rem = item - n * (S / 32) * (S / 32), mb = rem / (S / 32), cb = rem - mb * (S / 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                P[n * S * S + (mb * 32 + rr) * S + cb * 32 + (lane & 31)] = accV[j][r];
+            }
+        }
+    }
+}
+
+template <int S, int N, bool RS>
+__global__ void __launch_bounds__(256, 2)
+k_mix_mid_bwd_fast(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1, const float* __restrict__ V,
+                   float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B, int LDT, int act_inner, int act_outer,
+                   const float* __restrict__ rscale) {
+    if (act_inner == RECNOW_ACT_TANH && act_outer == RECNOW_ACT_TANH)
+        mid_bwd_fast_body<S, N, RS, RECNOW_ACT_TANH, RECNOW_ACT_TANH>(dT2g, T2, T1, V, dT1, dVpart, B, LDT, act_inner, act_outer, rscale);
+    else mid_bwd_fast_body<S, N, RS, -1, -1>(dT2g, T2, T1, V, dT1, dVpart, B, LDT, act_inner, act_outer, rscale);
+}
+
 // dV[i] = sum over workgroup partials, fixed order: 64 elements x 16 strided part groups per block, then a 16-term LDS sum.
 __global__ void __launch_bounds__(1024) k_mix_dv_reduce(const float* __restrict__ part, int nparts, int total, float* __restrict__ dV) {
     __shared__ float red[16][64];
@@ -341,6 +603,18 @@ int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64
     int rc;
     // measurement hook: read T1, write T2 and T2g (12 * B * LDT bytes)
     RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_MIX_MID_FWD, 4.0 * B * N * S * S, 12.0 * B * LDT, st) : nullptr;
+    static const bool mid_fast = []() { const char* e = getenv("RECNOW_MID_FAST"); return !e || e[0] != '0'; }();      // A/B switch
+#define MID_FWD_FAST(SS, NN)                                                                                                  \
+    if (mid_fast && B % MID_ROWS == 0 && S == SS && N == NN && LDT == SS * NN + 16) {                                         \
+        if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN>, lds))) return rc;                                                 \
+        hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer); \
+        rn_prof_end(pr, st);                                                                                                  \
+        RN_LAUNCH_CHECK();                                                                                                    \
+        return RECNOW_OK;                                                                                                     \
+    }
+    MID_FWD_FAST(64, 2)
+    MID_FWD_FAST(32, 4)
+#undef MID_FWD_FAST
     if (S == 32) {
         if ((rc = mid_allow_lds(k_mix_mid_fwd<32>, lds))) return rc;
         hipLaunchKernelGGL(k_mix_mid_fwd<32>, mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, N, LDT, act_outer);
@@ -369,7 +643,24 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
         if ((rc = mid_allow_lds(k_mix_mid_bwd<SS, VV>, lds))) return rc;                                                      \
         hipLaunchKernelGGL((k_mix_mid_bwd<SS, VV>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer, rscale); \
     } while (0)
-    if (S == 32) {
+    static const bool mid_fast = []() { const char* e = getenv("RECNOW_MID_FAST"); return !e || e[0] != '0'; }();      // A/B switch
+    bool done = false;
+#define MID_BWD_FAST(SS, NN)                                                                                                  \
+    if (!done && mid_fast && B % MID_ROWS == 0 && S == SS && N == NN && LDT == SS * NN + 16) {                                                    \
+        if (rscale) {                                                                                                         \
+            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true>, lds))) return rc;                                       \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale); \
+        } else {                                                                                                              \
+            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false>, lds))) return rc;                                      \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale); \
+        }                                                                                                                     \
+        done = true;                                                                                                          \
+    }
+    MID_BWD_FAST(64, 2)
+    MID_BWD_FAST(32, 4)
+#undef MID_BWD_FAST
+    if (done) {
+    } else if (S == 32) {
         if (vi <= 1) MID_BWD(32, 1);
         else MID_BWD(32, 2);
     } else {
