@@ -411,6 +411,174 @@ k_dcn_bwd_saved_wl(const float* __restrict__ x, const float* __restrict__ kernel
 }
 
 
+// ---- fast variants: D = TPR * 4 * NV exactly, 16-byte aligned, B a multiple of the rows per workgroup, L and the activation
+// compile-time ------------------------------------------------------------------------------------------------------------------
+// Same math as k_dcn_fwd / dcn_bwd_saved_body.  What their ISA showed: every `d < D ? load : 0`, `if (ok) store`, `if (l < L)`,
+// `if (biases)` and the per-element activation switch is a branch; vmcnt counts loads and stores in order, so the wait for the
+// prefetched next row is `vmcnt(stores issued since)` only when that number is the same on every path -- with the branches it
+// became `vmcnt(0)`: every row waited for its own stores to be acknowledged before the next row's arithmetic started.  Here nothing
+// that touches memory sits under a condition: kernels and biases of all layers live in LDS (a missing bias = zeros), the next
+// row is always requested (the last request re-reads the own row), the per-row scalars are stored by every lane of the row.
+template <int TPR, int NV>
+__device__ __forceinline__ void row_load_full(float (&r)[NV][4], const float* __restrict__ p, int t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 q = *reinterpret_cast<const float4*>(p + (i * TPR + t) * 4);
+        r[i][0] = q.x; r[i][1] = q.y; r[i][2] = q.z; r[i][3] = q.w;
+    }
+}
+template <int TPR, int NV>
+__device__ __forceinline__ void row_store_full(const float (&r)[NV][4], float* __restrict__ p, int t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(p + (i * TPR + t) * 4) = make_float4(r[i][0], r[i][1], r[i][2], r[i][3]);
+}
+
+template <int NV, int L, int ACT, bool CS>
+__global__ void __launch_bounds__(256)
+k_dcn_fwd_fast(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases, int64_t B, int act_rt,
+               float* __restrict__ y, float* __restrict__ csave) {
+    constexpr int TPR = 64, D = TPR * 4 * NV;          // a wave per row: reductions are shuffles only
+    const int act = ACT >= 0 ? ACT : act_rt;
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [L][D] kernels, [L][D] biases
+    for (int i = threadIdx.x; i < L * D; i += 256) {
+        wl[i] = kernels[i];
+        wl[L * D + i] = biases ? biases[i] : 0.f;
+    }
+    __syncthreads();
+    const int t = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    float xn[NV][4];
+    row_load_full<TPR, NV>(xn, x + ((int64_t)blockIdx.x * 4 + rsub) * D, t);
+    for (int64_t row0 = (int64_t)blockIdx.x * 4; row0 < B; row0 += stride) {
+        const int64_t row = row0 + rsub;
+        float x0[NV][4], xl[NV][4];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xl[i][e] = x0[i][e] = xn[i][e];
+        row_load_full<TPR, NV>(xn, x + (row0 + stride < B ? row + stride : row) * D, t);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            float w[NV][4], bb[NV][4];
+            row_load_full<TPR, NV>(w, wl + l * D, t);
+            row_load_full<TPR, NV>(bb, wl + (L + l) * D, t);
+            const float c = wave_sum(row_dot<4, NV>(xl, w));
+            if (CS) csave[row * L + l] = c;                  // every lane of the row (same value, same address: one transaction)
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xl[i][e] = rn_act(x0[i][e] * c + bb[i][e], act);
+        }
+        row_store_full<TPR, NV>(xl, y + row * D, t);
+    }
+}
+
+// TPR = 64 (a wave per row, D <= 512) or 128 (two waves per row, D = 1024: half the accumulator registers per lane)
+template <int TPR, int NV, int L, int ACT>
+__global__ void __launch_bounds__(256)
+k_dcn_bwd_fast(const float* __restrict__ x, const float* __restrict__ kernels, const float* __restrict__ biases, const float* __restrict__ dy,
+               const float* __restrict__ csave, int64_t B, int act_rt, float* __restrict__ dx, float* __restrict__ part) {
+    constexpr int D = TPR * 4 * NV, RPB = 256 / TPR;
+    const int act = ACT >= 0 ? ACT : act_rt;
+    __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) float comb[];    // [RPB][D] combine rows, then [L][D] kernels, [L][D] biases
+    float* wl = comb + RPB * D;
+    for (int i = threadIdx.x; i < L * D; i += 256) {
+        wl[i] = kernels[i];
+        wl[L * D + i] = biases ? biases[i] : 0.f;
+    }
+    __syncthreads();
+    const int t = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
+    float dw[L][NV][4], db[L][NV][4];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dw[l][i][e] = db[l][i][e] = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * RPB;
+    float xn[NV][4], gn[NV][4], csn[L];
+    {
+        const int64_t row = (int64_t)blockIdx.x * RPB + rsub;
+        row_load_full<TPR, NV>(xn, x + row * D, t);
+        row_load_full<TPR, NV>(gn, dy + row * D, t);
+#pragma unroll
+        for (int l = 0; l < L; ++l) csn[l] = csave[row * L + l];
+    }
+    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < B; row0 += stride) {
+        const int64_t row = row0 + rsub;
+        float x0[NV][4], g[NV][4], dx0[NV][4], tmp[NV][4];
+        float cs[L];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x0[i][e] = xn[i][e]; g[i][e] = gn[i][e]; dx0[i][e] = 0.f; }
+#pragma unroll
+        for (int l = 0; l < L; ++l) cs[l] = csn[l];
+        {
+            const int64_t nrow = row0 + stride < B ? row + stride : row;
+            row_load_full<TPR, NV>(xn, x + nrow * D, t);
+            row_load_full<TPR, NV>(gn, dy + nrow * D, t);
+#pragma unroll
+            for (int l = 0; l < L; ++l) csn[l] = csave[nrow * L + l];
+        }
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            const float c = cs[l];
+            // dz = g * act'(out_l),  out_l = act(x0 * c_l + b_l)   (kept in g's registers)
+            row_load_full<TPR, NV>(tmp, wl + (L + l) * D, t);
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float out = rn_act(x0[i][e] * c + tmp[i][e], act);
+                    g[i][e] *= rn_act_grad_from_out(out, act);
+                    p += g[i][e] * x0[i][e];
+                }
+            const float dc = row_sum<TPR>(p, red);
+            if (l > 0) row_load_full<TPR, NV>(tmp, wl + (L + l - 1) * D, t);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xl = l == 0 ? x0[i][e] : rn_act(x0[i][e] * cs[l > 0 ? l - 1 : 0] + tmp[i][e], act);
+                    db[l][i][e] += g[i][e];
+                    dx0[i][e] += g[i][e] * c;
+                    dw[l][i][e] += xl * dc;
+                }
+            row_load_full<TPR, NV>(tmp, wl + l * D, t);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[i][e] = dc * tmp[i][e];       // gradient w.r.t. x_l
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dx0[i][e] += g[i][e];             // x_0 is x0 itself
+        row_store_full<TPR, NV>(dx0, dx + row * D, t);
+    }
+    // per-workgroup combine (rows of the workgroup summed in a fixed order), then one slab per workgroup: as dcn_bwd_saved_body
+    float* slab = part + (int64_t)blockIdx.x * 2 * L * D;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float* dst = slab + (int64_t)(which * L + l) * D;
+            __syncthreads();
+            row_store_full<TPR, NV>(which ? db[l] : dw[l], comb + rsub * D, t);
+            __syncthreads();
+            for (int d = threadIdx.x; d < D; d += 256) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPB; ++r) s += comb[r * D + d];
+                dst[d] = s;
+            }
+        }
+    }
+}
+
 // ---- general shapes: any degree_of_cross, any D, any alignment ------------------------------------------------------------
 // The fused kernels above keep a row (and 2 L accumulator rows in the backward) in registers: L <= 4, D <= 4096.  Beyond
 // that the same math runs as three streaming kernels built on the per-row scalars c_l = x_l . w_l (reference
@@ -588,6 +756,26 @@ extern "C" int recnow_dcn_fwd(const float* x, const float* kernels, const float*
         RN_LAUNCH_CHECK();
         return RECNOW_OK;
     }
+    static const bool dcn_fast = []() { const char* e = getenv("RECNOW_DCN_FAST"); return !e || e[0] != '0'; }();      // A/B switch
+    if (dcn_fast && cfg.vec == 4 && cfg.tpr == 64 && D == 256 * cfg.nv && B % 4 == 0 && L <= DCN_MAX_L && (size_t)2 * L * D * sizeof(float) <= 48 * 1024) {
+        const int G = dcn_grid(B, 64);
+        const size_t shm = (size_t)2 * L * D * sizeof(float);
+#define FWD_FAST(NV_, L_)                                                                                                          \
+        if (cfg.nv == NV_ && L == L_) {                                                                                            \
+            if (act == RECNOW_ACT_LINEAR) {                                                                                        \
+                if (csave) hipLaunchKernelGGL((k_dcn_fwd_fast<NV_, L_, RECNOW_ACT_LINEAR, true>), G, 256, shm, st, x, kernels, biases, B, act, y, csave);  \
+                else hipLaunchKernelGGL((k_dcn_fwd_fast<NV_, L_, RECNOW_ACT_LINEAR, false>), G, 256, shm, st, x, kernels, biases, B, act, y, csave);      \
+            } else {                                                                                                               \
+                if (csave) hipLaunchKernelGGL((k_dcn_fwd_fast<NV_, L_, -1, true>), G, 256, shm, st, x, kernels, biases, B, act, y, csave);                 \
+                else hipLaunchKernelGGL((k_dcn_fwd_fast<NV_, L_, -1, false>), G, 256, shm, st, x, kernels, biases, B, act, y, csave);                     \
+            }                                                                                                                      \
+            RN_LAUNCH_CHECK();                                                                                                     \
+            return RECNOW_OK;                                                                                                      \
+        }
+        FWD_FAST(1, 1) FWD_FAST(1, 2) FWD_FAST(1, 3) FWD_FAST(1, 4)
+        FWD_FAST(4, 1) FWD_FAST(4, 2) FWD_FAST(4, 3) FWD_FAST(4, 4)
+#undef FWD_FAST
+    }
     const int G = dcn_grid(B, cfg.tpr);
     DCN_DISPATCH(k_dcn_fwd, 0, x, kernels, biases, B, D, L, act, y, csave);
     RN_LAUNCH_CHECK();
@@ -638,10 +826,25 @@ extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float*
         return RECNOW_OK;
     }
     if (csave && cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4) cfg = {128, 4, 2};     // 2 waves per wide row: half the registers per lane
-    const int G = dcn_grid(B, cfg.tpr);
+    static const bool dcn_fast = []() { const char* e = getenv("RECNOW_DCN_FAST"); return !e || e[0] != '0'; }();      // A/B switch
+    bool fast_done = false;
+    int G = dcn_grid(B, cfg.tpr);
+    if (dcn_fast && csave && cfg.vec == 4 && D == cfg.tpr * 4 * cfg.nv && B % (256 / cfg.tpr) == 0 && (cfg.tpr == 64 || cfg.tpr == 128)) {
+        const size_t shm = ((size_t)(256 / cfg.tpr) * D + (size_t)2 * L * D) * sizeof(float);
+#define BWD_FAST(TPR_, NV_, L_)                                                                                                    \
+        if (!fast_done && shm <= 48 * 1024 && cfg.tpr == TPR_ && cfg.nv == NV_ && L == L_) {                                       \
+            if (act == RECNOW_ACT_LINEAR) hipLaunchKernelGGL((k_dcn_bwd_fast<TPR_, NV_, L_, RECNOW_ACT_LINEAR>), G, 256, shm, st, x, kernels, biases, dy, csave, B, act, dx, part); \
+            else hipLaunchKernelGGL((k_dcn_bwd_fast<TPR_, NV_, L_, -1>), G, 256, shm, st, x, kernels, biases, dy, csave, B, act, dx, part);  \
+            fast_done = true;                                                                                                      \
+        }
+        BWD_FAST(64, 1, 1) BWD_FAST(64, 1, 2) BWD_FAST(64, 1, 3) BWD_FAST(64, 1, 4)
+        BWD_FAST(128, 2, 1) BWD_FAST(128, 2, 2) BWD_FAST(128, 2, 3) BWD_FAST(128, 2, 4)
+#undef BWD_FAST
+    }
     const size_t shmem = cfg.tpr < 256 ? (size_t)(256 / cfg.tpr) * D * sizeof(float) : 0;
     const size_t wl_bytes = (size_t)2 * L * D * sizeof(float);            // kernels + biases of every layer, staged in LDS when they fit
-    if (csave && shmem + wl_bytes <= 48 * 1024) DCN_DISPATCH(k_dcn_bwd_saved_wl, shmem + wl_bytes, x, kernels, biases, dy, csave, B, D, L, act, dx, part);
+    if (fast_done) {
+    } else if (csave && shmem + wl_bytes <= 48 * 1024) DCN_DISPATCH(k_dcn_bwd_saved_wl, shmem + wl_bytes, x, kernels, biases, dy, csave, B, D, L, act, dx, part);
     else if (csave) DCN_DISPATCH(k_dcn_bwd_saved, shmem, x, kernels, biases, dy, csave, B, D, L, act, dx, part);
     else DCN_DISPATCH(k_dcn_bwd, shmem, x, kernels, biases, dy, B, D, L, act, dx, part);
     RN_LAUNCH_CHECK();
