@@ -42,7 +42,7 @@ with open('profiles/%s_bench_pmc_hbm.csv' % tag, 'w') as fo:
         b = (2 * fv + wv) * 1024
         w.writerow([k, n, '%.1f' % fv, '%.1f' % wv, '%.0f' % b])
         m = re.match(r'void k_gemm<(\d+), (\d+), (\d+), (\d+),', k)
-        other = [f for f in ('k_gemm_shortk', 'k_mix_mid_fwd', 'k_mix_mid_bwd') if k.startswith('void %s<' % f)]
+        other = [f for f in ('k_gemm_shortk', 'k_mix_mid_fwd', 'k_mix_mid_bwd', 'k_gemm_split') if k.startswith('void %s<' % f) or k.startswith('void %s_fast<' % f)]
         if m or other:      # the persistent short-K kernel and the sub-space kernels are families of their own (bench.py *_TAGS)
             key = 'k_gemm<%s,%s,%s,%s>' % m.groups() if m else other[0]
             fam[key][0] += n
