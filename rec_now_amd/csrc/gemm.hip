@@ -17,13 +17,21 @@
 
 // sum the split-K slabs in slice order (deterministic) and apply the epilogue.  float4 per thread along N (the slabs
 // are [M][N] with N % 4 == 0 whenever VEC), four slabs in flight per thread.
-template <bool VEC>
+// Deterministic slab reduction of the split-K products.  QUAD: four adjacent lanes share one float4 of the output, each sums a
+// quarter of the slabs (a contiguous range, in order), and the four partial sums are combined as (q0 + q1) + (q2 + q3): four times
+// the threads and loads in flight -- an output of 1024 x 132 floats is 33 792 float4, i.e. 132 workgroups of threads that each walk
+// 64 slabs with four loads in flight (10.5 us for 35 MB that the product has just left in the memory-side cache).
+template <bool VEC, bool QUAD>
 __global__ void __launch_bounds__(256)
 k_gemm_splitk_reduce(const GemmK p) {
     constexpr int W = VEC ? 4 : 1;
+    constexpr int NQ = QUAD ? 4 : 1;
     const int64_t MN = (int64_t)p.M * p.npart;          // one slab
     const int64_t total = MN * p.batch / W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = QUAD ? (threadIdx.x & 3) : 0;
+    const int per = (p.splitk + NQ - 1) / NQ, k_lo = q * per, k_hi = min(p.splitk, k_lo + per);
+    // QUAD: every lane of a quad runs the loop for the quad's element (whole quads are in or out: total is rounded up by the caller's grid)
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / NQ; i < total; i += (int64_t)gridDim.x * blockDim.x / NQ) {
         const int64_t e0 = i * W;
         const int b = (int)(e0 / MN);
         const int64_t mn = e0 % MN;
@@ -32,9 +40,9 @@ k_gemm_splitk_reduce(const GemmK p) {
         float s[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) s[e] = 0.f;
-        int k = 0;
+        int k = k_lo;
         if (VEC) {
-            for (; k + 4 <= p.splitk; k += 4) {
+            for (; k + 4 <= k_hi; k += 4) {
                 const float4 a0 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 0) * MN);
                 const float4 a1 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 1) * MN);
                 const float4 a2 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 2) * MN);
@@ -45,9 +53,17 @@ k_gemm_splitk_reduce(const GemmK p) {
                 s[3 % W] = (((s[3 % W] + a0.w) + a1.w) + a2.w) + a3.w;
             }
         }
-        for (; k < p.splitk; ++k) {
+        for (; k < k_hi; ++k) {
 #pragma unroll
             for (int e = 0; e < W; ++e) s[e] += P[(int64_t)k * MN + e];
+        }
+        if (QUAD) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                s[e] += __shfl_xor(s[e], 1, 64);         // q0 + q1 | q2 + q3 (both lanes of a pair hold the same sum)
+                s[e] += __shfl_xor(s[e], 2, 64);         // (q0 + q1) + (q2 + q3)
+            }
+            if (q != 0) continue;
         }
 #pragma unroll
         for (int e = 0; e < W; ++e) {
@@ -279,8 +295,11 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
         const int64_t total = (int64_t)d->M * k.npart * d->batch;
         int g = rn_cdiv(total, 256);
         if (g > 2048) g = 2048;
-        if (d->N % 4 == 0) hipLaunchKernelGGL(k_gemm_splitk_reduce<true>, rn_cdiv(total / 4, 256) > 2048 ? 2048 : rn_cdiv(total / 4, 256), 256, 0, st, k);
-        else hipLaunchKernelGGL(k_gemm_splitk_reduce<false>, g, 256, 0, st, k);
+        static const bool quad_reduce = []() { const char* e = getenv("RECNOW_REDUCE_QUAD"); return !e || e[0] != '0'; }();      // A/B switch
+        if (d->N % 4 == 0 && quad_reduce && k.splitk >= 16 && (total / 4) % 64 == 0)      // whole quads per wave: the shuffles need all four lanes in the loop
+            hipLaunchKernelGGL((k_gemm_splitk_reduce<true, true>), rn_cdiv(total, 256) > 4096 ? 4096 : rn_cdiv(total, 256), 256, 0, st, k);
+        else if (d->N % 4 == 0) hipLaunchKernelGGL((k_gemm_splitk_reduce<true, false>), rn_cdiv(total / 4, 256) > 2048 ? 2048 : rn_cdiv(total / 4, 256), 256, 0, st, k);
+        else hipLaunchKernelGGL((k_gemm_splitk_reduce<false, false>), g, 256, 0, st, k);
         RN_LAUNCH_CHECK();
     }
     return RECNOW_OK;
