@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline size_t mid_fwd_lds(int S, int N) { return ((size_t)N * S * S + (size_t)MID_ROWS * (N * S + 1) + (size_t)MID_ROWS * N) * sizeof(float); }
 static inline size_t mid_bwd_lds(int S, int N) {
-    return ((size_t)N * S * S + 2 * (size_t)MID_ROWS * (N * S + 1) + 3 * (size_t)MID_ROWS * N) * sizeof(float);      // + Ds of the fast variant
+    return ((size_t)N * S * (S + 1) + 2 * (size_t)MID_ROWS * (N * S + 1) + 3 * (size_t)MID_ROWS * N) * sizeof(float);      // + Ds and the padded V^T rows of the fast variant
 }
 
 bool rn_mix_mid_supported(int S, int N, int LDT) {
@@ -35,8 +35,9 @@ bool rn_mix_mid_supported(int S, int N, int LDT) {
 }
 
 static inline int mid_grid(int64_t B) {
+    static const int cap = []() { const char* e = getenv("RECNOW_MID_BWD_GRID"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 512 ? v : 512; }();      // experiments: <= 512 (the workspace is sized for 512 partials)
     const int64_t tiles = (B + MID_ROWS - 1) / MID_ROWS;
-    return (int)(tiles < 512 ? (tiles > 0 ? tiles : 1) : 512);
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 
 // forward: as many workgroups as the LDS footprint lets a CU hold (the kernel is latency-bound per workgroup)
@@ -418,15 +419,18 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
     constexpr int NS = N * S, LDA = NS + 1, CPR = NS / 4, NCH = MID_ROWS * CPR / 256, GL = S / 4;
     constexpr int nvitems = N * (S / 32) * (S / 32), VI = (nvitems + 3) / 4;
     static_assert(NS == 128 && NCH == 4 && N * (S / 32) == 4, "N * S = 128");
-    float* VTs = lds;                      // [n][t][s] = V[n][s][t]
-    float* Cs = VTs + N * S * S;           // dC tile
+    constexpr int LV = S + 1;              // row stride of the transposed matrices: the transposing writes (lane = t) walk a stride of LV
+                                           // floats, i.e. 32 banks; with a stride of S = 64 every lane hit ONE bank (32-way conflict,
+                                           // ~8 us of the kernel per CU for the 2 x 8192 elements, counters)
+    float* VTs = lds;                      // [n][t][s] = V[n][s][t], rows of LV floats
+    float* Cs = VTs + N * S * LV;          // dC tile
     float* Hs = Cs + MID_ROWS * LDA;       // H1 tile
     float* Ps = Hs + MID_ROWS * LDA;       // [row][n]  <dT2g_n, H2_n>
     float* Ds = Ps + MID_ROWS * N;         // [row][n]  dlogits of the tile (stored by all threads after the next barrier)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < N * S * S; i += 256) {
         const int n = i / (S * S), rem = i - n * S * S, s = rem / S, t = rem - s * S;
-        VTs[n * S * S + t * S + s] = V[i];
+        VTs[(n * S + t) * LV + s] = V[i];
     }
     f32x16 accV[VI];
 #pragma unroll
@@ -507,9 +511,9 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const float* ap = Cs + (lane & 31) * LDA + n * S + (lane >> 5);
-            const float* bp = VTs + n * S * S + (lane >> 5) * S + cb * 32 + (lane & 31);
+            const float* bp = VTs + (n * S + (lane >> 5)) * LV + cb * 32 + (lane & 31);
 #pragma unroll 8
-            for (int st = 0; st < S / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], bp[2 * st * S], acc, 0, 0, 0);
+            for (int st = 0; st < S / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], bp[2 * st * LV], acc, 0, 0, 0);
             const int col = n * S + cb * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
