@@ -119,6 +119,18 @@ int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, const uint8
                            float power, int reduce_mean, float* loss, float* dscores, void* ws, size_t ws_bytes,
                            void* stream);
 
+/* The same loss WITHOUT occurrence weights (click_occurance_power == 0, the reference's default) in one walk per row: pair counts and
+ * BPR terms come out of the same pass (no recnow_pair_count before it).  n_pair (out, [1]) = P; loss = sum / (P + 1e-10) or the raw
+ * sum; dscores_unnorm[k] = d(SUM of pair losses) / d scores[k], i.e. NOT divided by P: multiply the incoming gradient in with
+ * recnow_pair_scale_grad, which applies 1 / (P + eps) as well (n_pair = NULL there for the raw sum).  flags as recnow_pair_bpr_fwdbwd
+ * (RECNOW_PAIR_MEMBERS_PACKED after recnow_group_pack_small on the same ws). */
+int recnow_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
+                            const int32_t* seg_id, const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean,
+                            float* loss, float* dscores_unnorm, int64_t* n_pair, void* ws, size_t ws_bytes, void* stream);
+/* out[i] = dscores_unnorm[i] * g[0] / (float(*n_pair) + eps); g a DEVICE scalar (the gradient of the loss); n_pair == NULL: no division. */
+int recnow_pair_scale_grad(const float* dscores_unnorm, const float* g, const int64_t* n_pair, float eps, int64_t B, float* out,
+                           void* stream);
+
 /* Front end of the loss for a SMALL batch in one launch (BASELINE config 2: pairwise_loss_from_batch at B = 8192): canonical keys
  * of ONE float32 / int32 group tensor (key_dtype RECNOW_KEY_F32 / RECNOW_KEY_I32), stable sort and segments by a single
  * 1024-thread workgroup on LDS-resident keys, B <= 8192 (recnow_pairwise_small_supported), plus what recnow_pair_count would do

@@ -37,9 +37,12 @@ k_gemm_splitk_reduce(const GemmK p) {
         const int64_t mn = e0 % MN;
         const int row = (int)(mn / p.npart), col = (int)(mn % p.npart);
         const float* P = p.partial + ((int64_t)b * p.splitk) * MN + mn;
-        float s[W];
+        // the slabs are summed in fp64 (the kernel is bound by reading them; 64 double adds per output are free): the K = B weight
+        // gradients then carry only the fp32 accumulation INSIDE a slab (K / splitk deep), not another 64-term fp32 sum on top --
+        // at K = 32 768 the full-size PLE parity test sat at 1.0e-5 of its bound with fp32 slab sums
+        double s[W];
 #pragma unroll
-        for (int e = 0; e < W; ++e) s[e] = 0.f;
+        for (int e = 0; e < W; ++e) s[e] = 0.0;
         int k = k_lo;
         if (VEC) {
             for (; k + 4 <= k_hi; k += 4) {
@@ -67,7 +70,7 @@ k_gemm_splitk_reduce(const GemmK p) {
         }
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-            float v = s[e];
+            float v = (float)s[e];
             const int c = col + e;
             if (c >= p.N) {                      // side-product columns ride behind the N main columns of a slab row
                 if (c - p.N < p.sp_r) p.cx[(int64_t)row * p.cx_ms + (int64_t)(c - p.N) * p.cx_rs] = v;

@@ -131,7 +131,7 @@ __device__ __forceinline__ void bpr_term(const Member& me, const Member& o, bool
 // lying strictly inside them is shorter than 64 rows, so only the first and the last row's segment can be long, and looking at
 // those two decides block-uniformly whether there is anything to do: batches without long groups pay one empty launch.
 #define PW_LONG 512
-template <int FLAGS, int MODE>                     // MODE 0: pair counts;  1: BPR loss and gradient terms
+template <int FLAGS, int MODE>                     // MODE 0: pair counts;  1: BPR loss and gradient terms;  2: both in one walk
 __global__ void __launch_bounds__(256)
 k_pair_long(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B,
             float factor, int32_t* __restrict__ long_cnt, float* __restrict__ long_la, float* __restrict__ long_ga) {
@@ -163,13 +163,14 @@ k_pair_long(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, 
             int cc = 0;
             float la = 0.f, ga = 0.f;
             PW_WALK_STRIDED(in_lds, staged, s, mem, s + lane, e, j, o, {
-                if (MODE == 0) cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
-                else bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
+                if (MODE != 1) cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
+                if (MODE != 0) bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
             });
-            if (MODE == 0) {
+            if (MODE != 1) {
                 cc = wave_sum(cc);
                 if (lane == 0) long_cnt[k] = cc;
-            } else {
+            }
+            if (MODE != 0) {
                 la = wave_sum(la);
                 ga = wave_sum(ga);
                 if (lane == 0) {
@@ -277,6 +278,59 @@ k_pair_bpr(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, c
     }
     lsum = block_sum<double>(lsum, red);
     if (threadIdx.x == 0) block_loss[blockIdx.x] = lsum;
+}
+
+// One pass for the loss without occurrence weights (click_occurance_power == 0, the default): the pair count of a row and its BPR
+// terms come out of the SAME walk, so counting and loss are one launch each for the long and the short rows instead of two.  The
+// gradient is left unnormalised (d sum / d score); the 1 / (P + 1e-10) of the mean is applied where the incoming gradient is
+// multiplied in (k_pair_scale_grad), because P is complete only when this kernel is.
+template <int FLAGS>
+__global__ void __launch_bounds__(256)
+k_pair_one(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
+           const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la, const float* __restrict__ long_ga,
+           double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair, float* __restrict__ dscores) {
+    __shared__ double red[16];
+    __shared__ long long redc[16];
+    __shared__ Member staged[PW_STAGE];
+    int sbase;
+    const bool in_lds = stage_members(mem, seg_id, seg_first, B, staged, &sbase);
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double lsum = 0.0;
+    long long c = 0;
+    if (k < B) {
+        const Member me = mem[k];
+        const int g = seg_id[k];
+        const int s = seg_first[g], e = seg_first[g + 1];
+        const bool is_long = e - s > PW_LONG;       // walked by k_pair_long
+        int cc = 0;
+        float la = 0.f, ga = 0.f;
+        PW_WALK(in_lds, staged, sbase, mem, (is_long ? e : s), e, j, o, {
+            cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
+            bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
+        });
+        if (is_long) {
+            cc = long_cnt[k];
+            la = long_la[k];
+            ga = long_ga[k];
+        }
+        dscores[me.row] = factor * ga;
+        lsum = (double)la;
+        c = cc;
+    }
+    lsum = block_sum<double>(lsum, red);
+    c = block_sum<long long>(c, redc);
+    if (threadIdx.x == 0) {
+        block_loss[blockIdx.x] = lsum;
+        if (c) atomicAdd(n_pair, (unsigned long long)c);      // integer atomics: order-independent
+    }
+}
+
+// out[i] = d[i] * g[0] / (P + eps)   (P = *n_pair; n_pair == NULL: no division)
+__global__ void __launch_bounds__(256)
+k_pair_scale_grad(const float* __restrict__ d, const float* __restrict__ g, const unsigned long long* __restrict__ n_pair, float eps, int64_t B,
+                  float* __restrict__ out) {
+    const float sc = n_pair ? g[0] / ((float)(*n_pair) + eps) : g[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) out[i] = d[i] * sc;
 }
 
 __global__ void __launch_bounds__(1024)
@@ -572,6 +626,44 @@ extern "C" int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, 
     RN_DISPATCH_FLAGS(k_pair_bpr, mem, seg_id, seg_first, super_id, (const unsigned long long*)cnt_super,
                       (const unsigned long long*)n_pair, B, factor, power, reduce_mean, pw.long_la, pw.long_ga, part, dscores);
     hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, part, G, (const unsigned long long*)n_pair, (int64_t)0, reduce_mean, loss);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
+                                      const int32_t* seg_id, const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean,
+                                      float* loss, float* dscores_unnorm, int64_t* n_pair, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || !loss || !n_pair) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        RN_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+        RN_HIP(hipMemsetAsync(n_pair, 0, sizeof(int64_t), st));
+        return RECNOW_OK;
+    }
+    if (!scores || !labels || !order || !seg_id || !seg_first || !dscores_unnorm || !ws) return RECNOW_EINVAL;
+    if ((flags & (RECNOW_PAIR_LABEL_GT | RECNOW_PAIR_WRONG_ORDER)) == 0) return RECNOW_EINVAL;      // as recnow_pair_bpr_fwdbwd
+    if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
+    const PairWs pw = pair_ws(ws, ws_bytes, B);
+    const int G = rn_cdiv(B, RN_PW_T);
+    // RECNOW_PAIR_MEMBERS_PACKED: recnow_group_pack_small has packed the members into `ws` and cleared *n_pair
+    int rc = (flags & RECNOW_PAIR_MEMBERS_PACKED) ? RECNOW_OK : pack_members(scores, labels, mask, order, B, pw.mem, st, nullptr, n_pair);
+    if (rc) return rc;
+    RN_DISPATCH_LONG(2, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga);
+    RN_DISPATCH_FLAGS(k_pair_one, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
+                      (unsigned long long*)n_pair, dscores_unnorm);
+    hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, pw.part, G, (const unsigned long long*)n_pair, (int64_t)0, reduce_mean, loss);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+extern "C" int recnow_pair_scale_grad(const float* dscores_unnorm, const float* g, const int64_t* n_pair, float eps, int64_t B, float* out,
+                                      void* stream) {
+    if (B < 0) return RECNOW_EINVAL;
+    if (B == 0) return RECNOW_OK;
+    if (!dscores_unnorm || !g || !out) return RECNOW_EINVAL;
+    int G = rn_cdiv(B, 256);
+    if (G > 2048) G = 2048;
+    hipLaunchKernelGGL(k_pair_scale_grad, G, 256, 0, (hipStream_t)stream, dscores_unnorm, g, (const unsigned long long*)n_pair, eps, B, out);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

@@ -146,6 +146,32 @@ def pair_indices(outputs, labels, groups, only_use_wrong_order_pair=False, mask=
     return pos[:P], neg[:P]
 
 
+def _onepass(ctx, outputs, scores, labs, m, order, seg_id, seg_first, B, dev, flags, factor, reduce_mean, ws, n_pair):
+    """Loss without occurrence weights (click_occurance_power == 0): counts and BPR terms from ONE walk per row
+    (recnow_pair_bpr_onepass); the gradient stays unnormalised until the incoming gradient is multiplied in (backward)."""
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dscores = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
+    _lib.call('recnow_pair_bpr_onepass', _lib.ptr(scores), _lib.ptr(labs), _lib.ptr(m), _lib.ptr(order), _lib.ptr(seg_id),
+              _lib.ptr(seg_first), B, flags, float(factor), 1 if reduce_mean else 0, _lib.ptr(loss), _lib.ptr(dscores), _lib.ptr(n_pair),
+              _lib.ptr(ws), ws.numel(), _lib.stream())
+    ctx.save_for_backward(dscores[:B], n_pair)
+    ctx.shape = outputs.shape
+    ctx.onepass = True
+    ctx.reduce_mean = bool(reduce_mean)
+    n_pair_f = n_pair.to(torch.float32).reshape(())
+    ctx.mark_non_differentiable(n_pair_f)
+    return loss, n_pair_f
+
+
+def _onepass_backward(ctx, g):
+    dscores, n_pair = ctx.saved_tensors
+    gd = g.detach().to(torch.float32).reshape(1).contiguous()
+    out = torch.empty_like(dscores)
+    _lib.call('recnow_pair_scale_grad', _lib.ptr(dscores), _lib.ptr(gd), _lib.ptr(n_pair) if ctx.reduce_mean else None, 1.0e-10,
+              dscores.numel(), _lib.ptr(out), _lib.stream())
+    return out.reshape(ctx.shape)
+
+
 class _PairBprFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, outputs, labels, mask, seg, flags, factor, power, reduce_mean):
@@ -153,6 +179,12 @@ class _PairBprFused(torch.autograd.Function):
         scores = _flat_f32(outputs, B, 'outputs')
         labs = _flat_f32(labels, B, 'labels')
         m = _flat_mask(mask, B)
+        ctx.onepass = False
+        if float(power) == 0.0:
+            n_pair = torch.empty(1, dtype=torch.int64, device=seg.device)
+            ws = _lib.workspace(_lib.load().recnow_pairwise_workspace_bytes(B), seg.device)
+            return _onepass(ctx, outputs, scores, labs, m, seg.order, seg.seg_id, seg.seg_first, B, seg.device, flags, factor,
+                            reduce_mean, ws, n_pair)
         cnt_row, cnt_super, n_pair, ws = _count(scores, labs, m, seg, flags)
         loss = torch.empty((), dtype=torch.float32, device=seg.device)
         dscores = torch.empty(max(B, 1), dtype=torch.float32, device=seg.device)
@@ -168,6 +200,8 @@ class _PairBprFused(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_np):
+        if ctx.onepass:
+            return _onepass_backward(ctx, g), None, None, None, None, None, None, None
         (dscores,) = ctx.saved_tensors
         return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None
 
@@ -193,6 +227,10 @@ class _PairBprSmall(torch.autograd.Function):
         _lib.call('recnow_group_pack_small', _lib.ptr(gkey), gdt, _lib.ptr(labs), _lib.ptr(scores), _lib.ptr(m), B, _lib.ptr(order),
                   _lib.ptr(seg_id), _lib.ptr(seg_first), _lib.ptr(super_id), _lib.ptr(n_seg), _lib.ptr(cnt_super), _lib.ptr(n_pair),
                   _lib.ptr(ws), ws.numel(), st)
+        ctx.onepass = False
+        if float(power) == 0.0:
+            return _onepass(ctx, outputs, scores, labs, m, order, seg_id, seg_first, B, dev, flags | _FLAG_MEMBERS_PACKED, factor,
+                            reduce_mean, ws, n_pair)
         _lib.call('recnow_pair_count', _lib.ptr(scores), _lib.ptr(labs), _lib.ptr(m), _lib.ptr(order), _lib.ptr(seg_id),
                   _lib.ptr(seg_first), _lib.ptr(super_id), B, flags | _FLAG_MEMBERS_PACKED, _lib.ptr(cnt_row), _lib.ptr(cnt_super),
                   _lib.ptr(n_pair), _lib.ptr(ws), ws.numel(), st)
@@ -209,6 +247,8 @@ class _PairBprSmall(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_np):
+        if ctx.onepass:
+            return _onepass_backward(ctx, g), None, None, None, None, None, None, None, None
         (dscores,) = ctx.saved_tensors
         return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None, None
 
