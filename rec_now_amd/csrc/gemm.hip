@@ -111,6 +111,9 @@ static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* 
         if (s > maxs) s = maxs;
         if (s < 1) s = 1;
     }
+    // accuracy, not occupancy: an fp32 accumulator that walks K >= 16384 terms in sequence carries ~sqrt(K) roundings (the K = 32768
+    // weight gradients of PLE sat at 0.95 of the 1e-5 parity bound); slabs of <= 8192 terms, summed in fp64 by the reduce, halve that
+    if (s == 1 && d->K >= 16384 && !d->as_out && !d->c2_mode && d->c_perm_s == 0) s = d->K / 8192;
     int kc = rn_cdiv(rn_cdiv(d->K, s), 32) * 32;
     if (kc < 32) kc = 32;
     s = rn_cdiv(d->K, kc);

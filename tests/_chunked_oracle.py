@@ -3,6 +3,8 @@
 The interaction layers are row-separable: outputs and input gradients of a row depend on that row only, and every weight
 gradient is a plain sum over rows.  So the oracle at BASELINE.json's sizes (B = 65536 x D = 1024, where one fp64 autograd
 graph of the whole batch would need tens of GB) is the chunk-wise oracle with the weight gradients accumulated in fp64."""
+import os
+
 import numpy as np
 import torch
 
@@ -50,4 +52,7 @@ def close(a, b, rtol=1e-5, scale=None, what=''):
     assert a.shape == b.shape, (what, a.shape, b.shape)
     s = max(np.abs(b).max() if scale is None else scale, 1e-30)
     err = np.abs(a - b).max()
+    if os.environ.get('RECNOW_TEST_MARGIN_LOG') and err > 0.3 * rtol * s:      # diagnostics: comparisons that use more than 30 % of their bound
+        with open(os.environ['RECNOW_TEST_MARGIN_LOG'], 'a') as fh:
+            fh.write('%.3f of the bound  %s  %s\n' % (err / (rtol * s), os.environ.get('PYTEST_CURRENT_TEST', ''), what))
     assert err <= rtol * s, '%s: max err %.3g vs scale %.3g (rel %.3g > %.1g)' % (what, err, s, err / s, rtol)

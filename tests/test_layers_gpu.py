@@ -4,6 +4,8 @@ Each layer is checked (a) against the reference's own golden (fixtures regenerat
 Tolerance: 1e-5 relative to the largest magnitude of the compared tensor (north_star: 1e-5 rel fp32)."""
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -21,6 +23,9 @@ def close(a, b, rtol=RTOL):
     assert a.shape == b.shape, (a.shape, b.shape)
     scale = max(np.abs(b).max(), 1e-30)
     err = np.abs(a - b).max()
+    if os.environ.get('RECNOW_TEST_MARGIN_LOG') and err > 0.3 * rtol * scale:      # diagnostics: comparisons that use more than 30 % of their bound
+        with open(os.environ['RECNOW_TEST_MARGIN_LOG'], 'a') as fh:
+            fh.write('%.3f of the bound  %s\n' % (err / (rtol * scale), os.environ.get('PYTEST_CURRENT_TEST', '')))
     assert err <= rtol * scale, 'max err %.3g vs scale %.3g (rel %.3g)' % (err, scale, err / scale)
 
 

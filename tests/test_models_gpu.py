@@ -3,6 +3,8 @@ autograd node) against the oracle:
   configs[3]: embeddings -> CINLayer || FMLayer -> Dense head -> pairwise_loss
   configs[4]: x -> PLELayer (3 tasks) -> per-task heads -> listwise loss on task 0 (+ the other heads summed, so every
               weight gets a gradient)"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -19,6 +21,9 @@ def close(a, b, rtol=RTOL, scale=None):
     assert a.shape == b.shape, (a.shape, b.shape)
     s = max(np.abs(b).max() if scale is None else scale, 1e-30)
     err = np.abs(a - b).max()
+    if os.environ.get('RECNOW_TEST_MARGIN_LOG') and err > 0.3 * rtol * s:      # diagnostics: comparisons that use more than 30 % of their bound
+        with open(os.environ['RECNOW_TEST_MARGIN_LOG'], 'a') as fh:
+            fh.write('%.3f of the bound  %s  %s\n' % (err / (rtol * s), os.environ.get('PYTEST_CURRENT_TEST', ''), ''))
     assert err <= rtol * s, 'max err %.3g vs scale %.3g (rel %.3g)' % (err, s, err / s)
 
 
