@@ -105,8 +105,8 @@ static inline GemmCfg pick_cfg(int N) {
 static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* splitk, int* kchunk) {
     const long long tiles = (long long)rn_cdiv(d->M, c.BM) * rn_cdiv(d->N, c.BN) * d->batch;
     int s = 1;
-    if (tiles < 256 && !d->as_out && !d->c2_mode) {      // fused side / second outputs need the whole K in one workgroup
-        s = (int)(512 / tiles);          // 256 CUs x 2 resident workgroups
+    if (tiles < 512 && !d->as_out && !d->c2_mode) {      // fused side / second outputs need the whole K in one workgroup
+        s = (int)((512 + tiles - 1) / tiles);          // 256 CUs x 2 resident workgroups (256..511 tiles left half the slots empty until round 2)
         const int maxs = d->K / (8 * 32);      // at least 8 k-tiles per slice
         if (s > maxs) s = maxs;
         if (s < 1) s = 1;
