@@ -497,3 +497,38 @@ def test_build_segments_invariants_mid_sizes(dev, B, kind):
     assert n_seg == len(np.unique(comp, axis=0)) + int(solo.sum())
     eq_first = (keys[0][0][1:] == keys[0][0][:-1]) & ~(solo[1:] | solo[:-1])
     assert np.array_equal(super_id[1:] == super_id[:-1], eq_first) and n_super == super_id[-1] + 1
+
+
+@pytest.mark.parametrize('reduce_mean', [True, False])
+def test_one_pass_route_equals_two_pass_route(dev, reduce_mean):
+    """click_occurance_power == 0 takes the one-walk route (recnow_pair_bpr_onepass + recnow_pair_scale_grad); a power of 1e-30
+    gives weights cnt ** 1e-30 = 1 to fp32 precision but takes the count-then-loss route: same loss, same pair count, same gradient,
+    also under a non-unit incoming gradient (the 1 / (P + 1e-10) of the mean is applied where it is multiplied in)."""
+    from rec_now_amd import _lib
+    M = _mod()
+    rng = np.random.default_rng(12)
+    B = 20000
+    s = rng.normal(size=B).astype(np.float32)
+    y = rng.integers(0, 3, B).astype(np.float32)
+    g = np.concatenate([rng.integers(0, 300, B - 3000), np.full(3000, 999)]).astype(np.int64)       # one 3000-row group: the wave-per-row walks
+    rng.shuffle(g)
+    mask = rng.random(B) < 0.9
+    res = []
+    for power in (0.0, 1e-30):
+        sd = torch.from_numpy(s).to(dev).requires_grad_(True)
+        loss, n_pair = M.pairwise_loss_fused(sd, torch.from_numpy(y).to(dev), torch.from_numpy(g).to(dev), click_occurance_power=power,
+                                             mask=torch.from_numpy(mask).to(dev), reduce_mean=reduce_mean)
+        (loss * 2.5).backward()
+        res.append((float(loss), float(n_pair), sd.grad.detach().cpu().numpy()))
+    (l0, p0, g0), (l1, p1, g1) = res
+    assert p0 == p1 and p0 > 0
+    assert abs(l0 - l1) <= 2e-6 * abs(l1)
+    assert np.abs(g0 - g1).max() <= 2e-6 * np.abs(g1).max()
+    # the C entry point refuses a pair set without the label / wrong-order predicate, as recnow_pair_bpr_fwdbwd does
+    z = torch.zeros(8, device=dev)
+    zi = torch.zeros(9, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(_lib.load().recnow_pairwise_workspace_bytes(8), dev)
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    rc = _lib.load().recnow_pair_bpr_onepass(_lib.ptr(z), _lib.ptr(z), None, _lib.ptr(zi), _lib.ptr(zi), _lib.ptr(zi), 8, 0, 1.0, 1,
+                                             _lib.ptr(z), _lib.ptr(z), _lib.ptr(n), _lib.ptr(ws), ws.numel(), _lib.stream())
+    assert rc != 0
