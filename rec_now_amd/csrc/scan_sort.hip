@@ -456,18 +456,30 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         unsigned o[RN_MAX_WORDS], z[RN_MAX_WORDS];
 #pragma unroll
         for (int w = 0; w < RN_MAX_WORDS; ++w) o[w] = z[w] = 0u;
+        // loads from clamped indices, masked afterwards: no load sits under a lane condition (each would end in an `s_waitcnt vmcnt(0)`
+        // at its merge, i.e. the eight rounds of a thread would be eight round trips in series)
+        for (int w = 0; w < n_words; ++w) {                   // block-uniform trip count
+            uint32_t kk[RN_TILE / 256];
+#pragma unroll
+            for (int r = 0; r < RN_TILE / 256; ++r) {
+                const int64_t i = base + r * 256 + tid;
+                kk[r] = words[(int64_t)w * B + (i < B ? i : B - 1)];
+            }
+            unsigned oo = 0u, zz = 0u;
+#pragma unroll
+            for (int r = 0; r < RN_TILE / 256; ++r) {
+                const bool ok = base + r * 256 + tid < B;
+                oo |= ok ? kk[r] : 0u;
+                zz |= ok ? ~kk[r] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < RN_MAX_WORDS; ++q)
+                if (q == w) { o[q] = oo; z[q] = zz; }
+        }
+#pragma unroll
         for (int r = 0; r < RN_TILE / 256; ++r) {
             const int64_t i = base + r * 256 + tid;
-            if (i < B) {
-                idx0[i] = (int32_t)i;
-#pragma unroll
-                for (int w = 0; w < RN_MAX_WORDS; ++w)
-                    if (w < n_words) {
-                        const uint32_t k = words[(int64_t)w * B + i];
-                        o[w] |= k;
-                        z[w] |= ~k;
-                    }
-            }
+            if (i < B) idx0[i] = (int32_t)i;
         }
 #pragma unroll
         for (int w = 0; w < RN_MAX_WORDS; ++w)
@@ -527,15 +539,30 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         for (int t = tid; t < 1024; t += 256) (&wcnt[0][0])[t] = 0;
         __syncthreads();
         const int64_t wbase = base + wv * (RN_TILE / 4);
+        // all eight rounds' loads in flight together (clamped indices; the block-uniform `carried` chooses between two straight-line
+        // load sequences instead of sitting inside every round): two dependent round trips per pass, not sixteen
+        if (carried) {
+#pragma unroll
+            for (int r = 0; r < RN_TILE / 256; ++r) {
+                const int64_t e = wbase + r * 64 + lane, ec = e < B ? e : B - 1;
+                my_idx[r] = src[ec];
+                my_key[r] = ksrc[ec];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RN_TILE / 256; ++r) {
+                const int64_t e = wbase + r * 64 + lane;
+                my_idx[r] = src[e < B ? e : B - 1];
+            }
+#pragma unroll
+            for (int r = 0; r < RN_TILE / 256; ++r) my_key[r] = wk[my_idx[r]];
+        }
 #pragma unroll
         for (int r = 0; r < RN_TILE / 256; ++r) {
-            const int64_t e = wbase + r * 64 + lane;
-            const bool ok = e < B;
-            const int32_t id = ok ? src[e] : 0;
-            const uint32_t kv = ok ? (carried ? ksrc[e] : wk[id]) : 0u;
-            my_idx[r] = id;
-            my_key[r] = kv;
-            if (ok) atomicAdd(&h[(kv >> shift) & 255u], 1u);
+            const bool ok = wbase + r * 64 + lane < B;
+            my_idx[r] = ok ? my_idx[r] : 0;
+            my_key[r] = ok ? my_key[r] : 0u;
+            if (ok) atomicAdd(&h[(my_key[r] >> shift) & 255u], 1u);
         }
         __syncthreads();
         blockhist[(int64_t)tid * G + g] = h[tid];             // digit-major
@@ -602,29 +629,58 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
     const int64_t k0 = base + (int64_t)tid * 8;
     unsigned hb = 0, sb8 = 0;
     int nh = 0, ns = 0;
-    for (int q = 0; q < 8; ++q) {
-        const int64_t k = k0 + q;
-        if (k >= B) break;
-        const int32_t i = fin[k];
-        int hd = 1, sh = 1;
-        if (k > 0) {
-            const int32_t j = fin[k - 1];
-            const bool so = solo[i] | solo[j];
-            bool diff_first = false, diff_any = false;
-            for (int w = 0; w < n_words; ++w) {
-                if (s_wconst[w]) continue;
-                const bool df = w == final_word ? kfin[k] != kfin[k - 1] : words[(int64_t)w * B + i] != words[(int64_t)w * B + j];
-                diff_any |= df;
-                if (w < n_words_first) diff_first |= df;
-            }
-            hd = (so || diff_any) ? 1 : 0;
-            sh = (so || diff_first) ? 1 : 0;
+    {
+        // the nine sorted rows k0 - 1 .. k0 + 7 of this thread, then their solo flags and key words: every load unconditional (clamped
+        // positions), a word's nine loads in flight together
+        int32_t f[9];
+        bool so9[9];
+        unsigned dany = 0u, dfirst = 0u;                     // bit q: rows k0 + q - 1 and k0 + q differ in some / in a groups[0] word
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            int64_t kq = k0 - 1 + q;
+            kq = kq < 0 ? 0 : (kq < B ? kq : B - 1);
+            f[q] = fin[kq];
         }
-        hb |= (unsigned)hd << q;
-        sb8 |= (unsigned)sh << q;
-        nh += hd;
-        ns += sh;
-        order[k] = i;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) so9[q] = solo[f[q]] != 0;
+        for (int w = 0; w < n_words; ++w) {                  // block-uniform
+            if (s_wconst[w]) continue;
+            uint32_t v[9];
+            if (w == final_word) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    int64_t kq = k0 - 1 + q;
+                    kq = kq < 0 ? 0 : (kq < B ? kq : B - 1);
+                    v[q] = kfin[kq];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = words[(int64_t)w * B + f[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned df = v[q + 1] != v[q] ? 1u : 0u;
+                dany |= df << q;
+                if (w < n_words_first) dfirst |= df << q;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t k = k0 + q;
+            if (k < B) {
+                int hd = 1, sh = 1;
+                if (k > 0) {
+                    const bool so = so9[q + 1] | so9[q];
+                    hd = (so || ((dany >> q) & 1u)) ? 1 : 0;
+                    sh = (so || ((dfirst >> q) & 1u)) ? 1 : 0;
+                }
+                hb |= (unsigned)hd << q;
+                sb8 |= (unsigned)sh << q;
+                nh += hd;
+                ns += sh;
+                order[k] = f[q + 1];
+            }
+        }
     }
     // exclusive prefix of (nh, ns) inside the workgroup
     int inh = nh, ins = ns;
