@@ -279,6 +279,9 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
             }
             rc = rn_gemm_launch_split(k, a_kc, b_kc, d->a_mode, planes, grid, st);
         }
+        static const bool sp_narrow = []() { const char* e = getenv("RECNOW_SP_NARROW"); return !e || e[0] != '0'; }();      // A/B switch
+        if (rc == RECNOW_EUNSUPPORTED && sp_narrow && xf == 1 && d->sp_r <= 2 && !bk16)
+            rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, d->a_mode, d->b_mode, 9, grid, st);
         if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
     } else if (use_shortk) {

@@ -11,6 +11,11 @@ int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2
         return RECNOW_OK;                                                                                            \
     }
     X(true, false, 0, 0, 1)     // GEMM1:   x_l U           + gate logits as side product
+    X(true, false, 0, 0, 9)     //          ... XF | 8: at most two side columns (two experts), two-wide side product
+    X(true, true, 1, 0, 9)
+    X(true, true, 0, 0, 9)
+    X(false, false, 0, 0, 9)
+    X(false, false, 1, 0, 9)
     X(true, false, 0, 0, 2)     // GEMM3:   T2g W           + gate-weighted bias as rank-2 update
     X(true, true, 1, 0, 1)      // dT2g:    (x*g) W^T       + bias columns as side product
     X(true, true, 1, 0, 5)      //          ... and dx = g * O written from the A stream (top layer)

@@ -3,6 +3,7 @@
 #pragma once
 #include "gemm.hpp"
 #include <string.h>
+#include <type_traits>
 
 #define GEMM_THREADS 256
 
@@ -10,6 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // native 4-wide vector for the staging registers: HIP's float4 is a STRUCT, and whole-struct copies (global -> regs -> LDS)
 // are lowered to llvm.memcpy through a private alloca that SROA cannot promote -> the tile would live in scratch.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
 struct GemmK {
@@ -401,6 +403,10 @@ k_gemm(const GemmK p) {
     // (sp_on / side output use blockIdx.y directly: those launches are never remapped in y, see rn_gemm)
     const bool sp_on = (XF & 1) && blockIdx.y == 0;    // one column-tile computes the side product of a row-tile
     f32x4 spacc = mk4(0.f, 0.f, 0.f, 0.f);
+    // XF & 8 (sliced kernels): the side product has at most two columns (DCN-v2 with two experts): two-wide weights and accumulator --
+    // half the FMAs and half the LDS bytes of the weights; the side product costs 15 us of a 180 us launch in its four-wide form
+    using SPV = std::conditional_t<(XF & 8) != 0, f32x2, f32x4>;
+    SPV spn = SPV(0.f);
     float bxr[4] = {0.f, 0.f, 0.f, 0.f};
 
 #ifdef RN_GEMM_TRACE      // per-workgroup phase timestamps for tools/gemm_trace.py (build with RECNOW_TRACE=1)
@@ -594,12 +600,12 @@ k_gemm(const GemmK p) {
             // MFMA group (an empty volatile asm on the accumulator: hipcc otherwise sinks all 32 packed FMAs of the k-tile to the
             // end of the tile, a serial VALU tail in front of every barrier with 80 registers held for it)
             float sa0 = 0.f, sa1 = 0.f;
-            f32x4 sb0 = mk4(0.f, 0.f, 0.f, 0.f), sb1 = sb0;
+            SPV sb0 = SPV(0.f), sb1 = SPV(0.f);
             if constexpr ((XF & 1) != 0) {
                 sa0 = asx[0];
                 sa1 = asx[TA::LD];
-                sb0 = *reinterpret_cast<const f32x4*>(bxs);
-                sb1 = *reinterpret_cast<const f32x4*>(bxs + 4);
+                sb0 = *reinterpret_cast<const SPV*>(bxs);
+                sb1 = *reinterpret_cast<const SPV*>(bxs + 4);
             }
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
@@ -608,14 +614,14 @@ k_gemm(const GemmK p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
                 float na0 = 0.f, na1 = 0.f;
-                f32x4 nb0 = sb0, nb1 = sb1;
+                SPV nb0 = sb0, nb1 = sb1;
                 if constexpr ((XF & 1) != 0) {
                     if (kk + 4 < BK) {
                         const int kq = (kk >> 1) + 2;
                         na0 = asx[kq * TA::LD];
                         na1 = asx[(kq + 1) * TA::LD];
-                        nb0 = *reinterpret_cast<const f32x4*>(bxs + kq * 4);
-                        nb1 = *reinterpret_cast<const f32x4*>(bxs + (kq + 1) * 4);
+                        nb0 = *reinterpret_cast<const SPV*>(bxs + kq * 4);
+                        nb1 = *reinterpret_cast<const SPV*>(bxs + (kq + 1) * 4);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -625,9 +631,9 @@ k_gemm(const GemmK p) {
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
                 stage(kk / 2);
                 if constexpr ((XF & 1) != 0) {
-                    spacc += sa0 * sb0;
-                    spacc += sa1 * sb1;
-                    asm volatile("" : "+v"(spacc));
+                    spn += sa0 * sb0;
+                    spn += sa1 * sb1;
+                    asm volatile("" : "+v"(spn));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int kn = kk + 4 < BK ? kk + 4 : BK - 2;
@@ -684,6 +690,10 @@ k_gemm(const GemmK p) {
 #else
         __syncthreads();
 #endif
+    }
+    if constexpr ((XF & 1) != 0 && SLICED) {
+        if constexpr ((XF & 8) != 0) spacc = mk4(spn.x, spn.y, 0.f, 0.f);
+        else spacc = spn;
     }
     if constexpr ((XF & 1) != 0) {
         // combine the two k-halves through LDS (free now) and write the side columns

@@ -23,7 +23,6 @@ typedef __bf16 bf16x8 __attribute__((__vector_size__(16)));
 typedef __bf16 bf16x2 __attribute__((__vector_size__(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define SPL_BK 16
 #define SPL_PLANE_H 132                                  // 16-byte units per k-half: 128 rows + 4 (the second half starts 64 B
