@@ -26,14 +26,24 @@
 // co-resident workgroups still cover each other's epilogues; spilling the epilogue operands to scratch does not.
 // PRE: the whole tile of `emul` (64 registers per lane) is requested BEFORE the tile's k-loop, so it lands under the MFMAs and the
 // epilogue never waits for a load (EP == 1 products: y = x * (T2g [W; b]) streams x).
-__host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL, bool PRE) {
-    return (DUAL == 4 || PRE) ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3) ? 3 : 4;
+__host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL, bool PRE, int NK = 0) {
+    return (DUAL == 4 || PRE || (NK > 0 && DUAL == 2)) ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3 || NK > 0) ? 3 : 4;      // ring schedule: 32 more operand registers
 }
 
-template <bool B_KC, int EP, int DUAL, bool PRE = false>
-__global__ void __launch_bounds__(GEMM_THREADS, sk_wg_per_cu(EP, DUAL, PRE))
+// NK > 0 (the depth in k-tiles as a template parameter, NK % 3 == 0): the RING schedule.  Per-workgroup timestamps (tools/gemm_trace.py)
+// showed the k-loop of the NK = 0 schedule latency-bound: operands of k-tile t+1 are requested at the top of k-tile t and needed 32
+// MFMAs (0.9 us) later, while a load takes 2-3 us next to the epilogues' HBM streams -- the MFMA pipe of a CU was 58 % busy with two
+// workgroups in their k-loops.  Here three register sets rotate (set = k-tile % 3): k-tile t+2 is requested at the top of k-tile t, so a
+// load has two k-tiles to land; the sets carry on across tiles (the last two k-tiles of a tile request k-tiles 0 and 1 of the next
+// one), every load and LDS write is unconditional (a workgroup without a next tile re-reads its own), and the k-loop is unrolled, so
+// every `s_waitcnt vmcnt` is an exact count.  PRE: the tile of `emul` is requested in four groups at k-tiles 0, 2, 4, 6,
+// each behind that k-tile's ring loads, so no ring wait stands behind a load younger than two k-tiles.
+template <bool B_KC, int EP, int DUAL, bool PRE = false, int NK = 0>
+__global__ void __launch_bounds__(GEMM_THREADS, sk_wg_per_cu(EP, DUAL, PRE, NK))
 k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
-    static_assert(!PRE || (EP == 1 && DUAL != 2 && DUAL != 4), "whole-tile prefetch: emul only");
+    static_assert(!PRE || ((EP == 1 || EP == 2) && DUAL != 2 && DUAL != 4), "whole-tile prefetch: emul (EP 1) or the old C (EP 2)");
+    static_assert(NK % 3 == 0, "ring schedule: three register sets, the same set holds k-tile 0 of every tile");
+    static_assert(!PRE || NK == 0 || NK >= 7, "ring schedule: the four groups of the emul tile go out at k-tiles 0, 2, 4, 6");
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
     constexpr int A_SZ = SK_BK * TA::LD, B_SZ = SK_BK * TB::LD, BUF = A_SZ + B_SZ;
@@ -52,6 +62,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     const unsigned g_lane = (unsigned)((wm * 64 + rr0) * p.lde3 + wn * 64 + cc);
     const int nk = p.K / SK_BK;
     const int ntiles = row_tiles * col_tiles;
+    constexpr bool EARLY = NK >= 3 && ((EP && !PRE) || DUAL == 2 || DUAL == 4);       // ring schedule with epilogue loads
 
     // slot (= workgroup index + round * grid) -> tile.  XCD-aware: slots of one XCD enumerate (row tile, column tile) with
     // the column tile fastest; row tiles are dealt round-robin to the 8 XCDs.
@@ -95,16 +106,38 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     }
     int m0, n0;
     tile_of(slot, m0, n0);
-    ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0, 0);
-    tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0, 0);
-    ta.store(smem);
-    tb.store(smem + A_SZ);
+    // ring schedule: operand registers of the three sets (set s = k-tile % 3)
+    f32x4 ra[NK ? 3 : 1][TA::NV], rb[NK ? 3 : 1][TB::NV];
+    auto ring_load = [&](int set, int mm, int nn, int k0) {
+        const float* __restrict__ pa = p.A + TA::tile_base(p.lda, mm, k0);
+        const float* __restrict__ pb = p.B + TB::tile_base(p.ldb, nn, k0);
+#pragma unroll
+        for (int i = 0; i < TA::NV; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(pa + ta.off[i]);
+#pragma unroll
+        for (int i = 0; i < TB::NV; ++i) rb[set][i] = *reinterpret_cast<const f32x4*>(pb + tb.off[i]);
+    };
+    auto ring_store = [&](int set, float* S) {
+#pragma unroll
+        for (int i = 0; i < TA::NV; ++i) { ta.v[i] = ra[set][i]; ta.store_slot(i, S); }
+#pragma unroll
+        for (int i = 0; i < TB::NV; ++i) { tb.v[i] = rb[set][i]; tb.store_slot(i, S + A_SZ); }
+    };
+    if (NK) {
+        ring_load(0, m0, n0, 0);
+        ring_load(1, m0, n0, SK_BK);
+        ring_store(0, smem);
+    } else {
+        ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0, 0);
+        tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0, 0);
+        ta.store(smem);
+        tb.store(smem + A_SZ);
+    }
     __syncthreads();
     int f = 0;                                     // buffer holding k-tile 0 of the current tile
     for (; slot < ntiles; slot += gridDim.x) {
         const int nslot = slot + gridDim.x;
         const bool has_next = nslot < ntiles;
-        int m0n = 0, n0n = 0;
+        int m0n = NK ? m0 : 0, n0n = NK ? n0 : 0;       // ring: a workgroup without a next tile re-reads its own (loads stay unconditional)
         if (has_next) tile_of(nslot, m0n, n0n);
 #ifdef RN_GEMM_TRACE
 #define SK_TR(i) do { if (p.trace && threadIdx.x == 0) p.trace[(long long)slot * 8 + (i)] = wall_clock64(); } while (0)
@@ -130,30 +163,19 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         f32x4 evt[PRE ? 4 : 1][4];
-        if (PRE) {
-            const float* Etp = p.emul + (int64_t)m0 * p.lde + n0;
+        const float* Etp = !PRE ? nullptr : EP == 1 ? p.emul + (int64_t)m0 * p.lde + n0 : p.C + (int64_t)m0 * p.ldc + n0;
+        const int64_t ldp = EP == 1 ? p.lde : p.ldc;
+        auto pre_load = [&](int s2) {
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    evt[PRE ? s2 : 0][q] = *reinterpret_cast<const f32x4*>(Etp + (int64_t)((s2 >> 1) * 32 + q * 8) * p.lde + (s2 & 1) * 32 + e_lane);
-        }
-        for (int t = 0; t < nk; ++t) {
-            const int cur = (f + t) & 1;
-            const bool more = t + 1 < nk;
-            if (more) {
-                ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0, (t + 1) * SK_BK);
-                tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0, (t + 1) * SK_BK);
-            } else if (has_next) {                 // next tile's first k-tile flies under this tile's last MFMAs
-                ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0n, 0);
-                tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0n, 0);
-            }
+            for (int q = 0; q < 4; ++q)
+                evt[PRE ? s2 : 0][q] = *reinterpret_cast<const f32x4*>(Etp + (int64_t)((s2 >> 1) * 32 + q * 8) * ldp + (s2 & 1) * 32 + (EP == 1 ? e_lane : c_lane));
+        };
+        // fragment reads and MFMAs of one k-tile in LDS buffer `cur`.  npairs = k-pairs of this k-tile that hold data: all 8, except in
+        // the last k-tile of a zero-padded depth (DCN-v2: K = N*S + N = 130 stored as 144 -> 1 pair): the MFMA groups of the padding are
+        // skipped behind a scalar branch each (10 % of a tile's MFMAs).  The fragment reads and the schedule of the groups stay as they are.
+        auto ktile = [&](int cur, int npairs) {
             const float* as = smem + cur * BUF + a_off;
             const float* bs = smem + cur * BUF + A_SZ + b_off;
-            // k-pairs of this k-tile that hold data: all 8, except in the last k-tile of a zero-padded depth (DCN-v2: K = N*S + N = 130
-            // stored as 144 -> 1 pair): the MFMA groups of the padding are skipped behind a scalar branch each (10 % of a tile's MFMAs).
-            // The loads, the fragment reads and the schedule of the groups stay as they are.
-            const int npairs = (t == nk - 1) ? p.tail_pairs : SK_BK / 2;
             float a0[2], b0[2], a1[2], b1[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a0[i] = as[i * 32];
@@ -188,17 +210,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more || has_next) {
-                ta.store(smem + (cur ^ 1) * BUF);
-                tb.store(smem + (cur ^ 1) * BUF + A_SZ);
-            }
-            __syncthreads();
-        }
-        SK_TR(2);
-        if (p.prio) __builtin_amdgcn_s_setprio(0);
-        // buffer `fr` was consumed by the last k-tile and is free: staging space of the epilogue (16 rows x 36 per wave)
-        const int fr = (f + nk - 1) & 1;
-        float* stg = smem + fr * BUF + wave * (16 * 36);
+        };
         // Epilogue addresses = (tile- and sub-tile-uniform 64-bit base, kept in SGPRs) + (lane offset, 32-bit, tile-invariant).
         f32x4 ev[2][4], cv[2][4], fv[2][4], dv[2][4];
         float rs[2][4];                     // DUAL 4: the rank-one factor's row values of the sub-tile's four row groups
@@ -209,17 +221,12 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
         const float* Ft = (DUAL == 2 || DUAL == 4) ? p.E2 + (int64_t)m0 * p.lde2 + n0 : nullptr;
         const float* Gt = (DUAL == 4) ? p.E3 + (int64_t)m0 * p.lde3 + n0 : nullptr;
         float* Dt = DUAL ? p.C2 + (int64_t)m0 * p.ldc2 + n0 : nullptr;
-        if (DUAL == 3 || DUAL == 4) {
-            const float* colv = (DUAL == 3 ? p.hv : p.cv) + n0 + wn * 64 + cc;
-            hv4[0] = *reinterpret_cast<const f32x4*>(colv);
-            hv4[1] = *reinterpret_cast<const f32x4*>(colv + 32);
-        }
         auto issue = [&](int s2, int buf) {
             const int i = s2 >> 1, j = s2 & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if ((EP & 1) && !PRE) ev[buf][q] = *reinterpret_cast<const f32x4*>(Et + (int64_t)(i * 32 + q * 8) * p.lde + j * 32 + e_lane);
-                if (EP & 2) cv[buf][q] = *reinterpret_cast<const f32x4*>(Ct + (int64_t)(i * 32 + q * 8) * p.ldc + j * 32 + c_lane);
+                if ((EP & 2) && !PRE) cv[buf][q] = *reinterpret_cast<const f32x4*>(Ct + (int64_t)(i * 32 + q * 8) * p.ldc + j * 32 + c_lane);
                 if (DUAL == 2 || DUAL == 4) fv[buf][q] = *reinterpret_cast<const f32x4*>(Ft + (int64_t)(i * 32 + q * 8) * p.lde2 + j * 32 + f_lane);
                 if (DUAL == 2) dv[buf][q] = *reinterpret_cast<const f32x4*>(Dt + (int64_t)(i * 32 + q * 8) * p.ldc2 + j * 32 + d_lane);
                 if (DUAL == 4) {
@@ -228,7 +235,56 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 }
             }
         };
-        if ((EP && !PRE) || DUAL == 2 || DUAL == 4) issue(0, 0);
+        if (NK) {
+#pragma unroll
+            for (int t = 0; t < (NK ? NK : 1); ++t) {
+                const int cur = (f + t) & 1;
+                // k-tile t+2 of this tile, or k-tile 0 / 1 of the next one, into the set that k-tile t left free
+                if (t + 2 < NK) ring_load((t + 2) % 3, m0, n0, (t + 2) * SK_BK);
+                else ring_load((t + 2) % 3, m0n, n0n, (t + 2 - NK) * SK_BK);
+                if (PRE && (t & 1) == 0 && t < 8) pre_load(t >> 1);
+                // epilogue operands of sub-tile 0: requested three k-tiles early (behind this k-tile's ring loads: the ring wait two k-tiles on
+                // is the first one that stands behind them), so the epilogue starts on landed data
+                if (EARLY && t == NK - 3) issue(0, 0);
+                if (t == NK - 1) ktile(cur, p.tail_pairs);
+                else ktile(cur, SK_BK / 2);
+                ring_store((t + 1) % 3, smem + (cur ^ 1) * BUF);
+                __syncthreads();
+            }
+        } else {
+            if (PRE) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) pre_load(s2);
+            }
+            for (int t = 0; t < nk; ++t) {
+                const int cur = (f + t) & 1;
+                const bool more = t + 1 < nk;
+                if (more) {
+                    ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0, (t + 1) * SK_BK);
+                    tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0, (t + 1) * SK_BK);
+                } else if (has_next) {                 // next tile's first k-tile flies under this tile's last MFMAs
+                    ta.template load_fast<false>(p.A, nullptr, 0, 0, p.lda, m0n, 0);
+                    tb.template load_fast<false>(p.B, nullptr, 0, 0, p.ldb, n0n, 0);
+                }
+                ktile(cur, (t == nk - 1) ? p.tail_pairs : SK_BK / 2);
+                if (more || has_next) {
+                    ta.store(smem + (cur ^ 1) * BUF);
+                    tb.store(smem + (cur ^ 1) * BUF + A_SZ);
+                }
+                __syncthreads();
+            }
+        }
+        SK_TR(2);
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
+        // buffer `fr` was consumed by the last k-tile and is free: staging space of the epilogue (16 rows x 36 per wave)
+        const int fr = (f + nk - 1) & 1;
+        float* stg = smem + fr * BUF + wave * (16 * 36);
+        if (DUAL == 3 || DUAL == 4) {
+            const float* colv = (DUAL == 3 ? p.hv : p.cv) + n0 + wn * 64 + cc;
+            hv4[0] = *reinterpret_cast<const f32x4*>(colv);
+            hv4[1] = *reinterpret_cast<const f32x4*>(colv + 32);
+        }
+        if (((EP && !PRE) || DUAL == 2 || DUAL == 4) && !EARLY) issue(0, 0);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
             const int i = s2 >> 1, j = s2 & 1, buf = s2 & 1;
@@ -244,7 +300,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rr0) * 36 + cc);
                     f32x4 v = a;
                     if (EP & 1) v = v * (PRE ? evt[PRE ? s2 : 0][2 * h + q] : ev[buf][2 * h + q]);
-                    if (EP & 2) v = v + cv[buf][2 * h + q];
+                    if (EP & 2) v = v + (PRE ? evt[PRE ? s2 : 0][2 * h + q] : cv[buf][2 * h + q]);
                     if (DUAL != 3) *reinterpret_cast<f32x4*>(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane) = v;
                     if (DUAL == 1 || (DUAL == 3 && p.C2 != nullptr)) *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) = a;
                     if (DUAL == 2)
@@ -284,13 +340,13 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     if (cu_key >= 0) atomicSub(&p.cu_slots[cu_key], 1);          // thread 0 only (cu_key stays -1 elsewhere)
 }
 
-template <bool B_KC, int EP, int DUAL, bool PRE = false>
+template <bool B_KC, int EP, int DUAL, bool PRE = false, int NK = 0>
 static int launch_sk(const GemmK& k, hipStream_t st) {
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
     constexpr size_t lds = 2 * SK_BK * (size_t)(TA::LD + TB::LD) * sizeof(float);
     const int rt = k.M / SK_BM, ct = k.N / SK_BN;
-    const int resident = 256 * sk_wg_per_cu(EP, DUAL, PRE);
+    const int resident = 256 * sk_wg_per_cu(EP, DUAL, PRE, NK);
     int grid = rt * ct < resident ? rt * ct : resident;
     const int xcd = (rt % 8 == 0 && grid % 8 == 0) ? 1 : 0;
     GemmK kk = k;
@@ -309,7 +365,7 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
         kk.cu_slots = cu_slots;
         kk.stagger_ticks = stagger_us * 100;
     }
-    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL, PRE>), grid, GEMM_THREADS, lds, st, kk, rt, ct, xcd);
+    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL, PRE, NK>), grid, GEMM_THREADS, lds, st, kk, rt, ct, xcd);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -319,6 +375,18 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
 // bias / activation / transposed store.  Second outputs are instantiated for the two products DCN-v2 uses them in.
 int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st) {
     static const bool pre = []() { const char* e = getenv("RECNOW_SK_PRE"); return !e || e[0] != '0'; }();     // A/B switch of the whole-tile emul prefetch
+    // nine k-tiles (DCN-v2: K = N*S + N = 130 stored as 144): the ring schedule; RECNOW_SK_RING=0 is the A/B switch
+    static const int ring = []() { const char* e = getenv("RECNOW_SK_RING"); return e ? atoi(e) : 15; }();
+    if (k.K == 9 * SK_BK && (ring & 1) && pre && !b_kc && ep == 1) {
+        if (c2_mode == 1) return launch_sk<false, 1, 1, true, 9>(k, st);
+        if (c2_mode == 3) return launch_sk<false, 1, 3, true, 9>(k, st);
+        if (c2_mode == 0) return launch_sk<false, 1, 0, true, 9>(k, st);
+    }
+    if (k.K == 9 * SK_BK && (ring & 4) && b_kc && ep == 2 && c2_mode == 0) return launch_sk<true, 2, 0, true, 9>(k, st);
+    if (k.K == 9 * SK_BK && b_kc && ep == 0) {
+        if (c2_mode == 2 && (ring & 2)) return launch_sk<true, 0, 2, false, 9>(k, st);
+        if (c2_mode == 4 && (ring & 8)) return launch_sk<true, 0, 4, false, 9>(k, st);
+    }
     if (pre && !b_kc && ep == 1) {
         if (c2_mode == 1) return launch_sk<false, 1, 1, true>(k, st);
         if (c2_mode == 3) return launch_sk<false, 1, 3, true>(k, st);

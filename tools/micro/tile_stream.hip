@@ -32,6 +32,29 @@ __global__ void __launch_bounds__(256) k_tiled(const float* __restrict__ x, floa
     }
 }
 
+// the epilogue's own pattern: wave w owns the 64 x 64 quadrant (w >> 1, w & 1) of the tile and moves 32 x 32 sub-tiles, one instruction
+// = 8 rows x 128 B (lane >> 3 = row, (lane & 7) * 16 B)
+__global__ void __launch_bounds__(256) k_quad(const float* __restrict__ x, float* __restrict__ y1, float* __restrict__ y2, int B, int D) {
+    const int ntile = (B / 128) * (D / 128);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rr0 = lane >> 3, cc = (lane & 7) * 4;
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const long base = (long)(t / (D / 128)) * 128 * D + (long)(t % (D / 128)) * 128 + (long)((wave >> 1) * 64 + rr0) * D + (wave & 1) * 64 + cc;
+        f32x4 v[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[s2 * 4 + q] = *reinterpret_cast<const f32x4*>(x + base + (long)((s2 >> 1) * 32 + q * 8) * D + (s2 & 1) * 32);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<f32x4*>(y1 + base + (long)((s2 >> 1) * 32 + q * 8) * D + (s2 & 1) * 32) = v[s2 * 4 + q] * 1.5f;
+                *reinterpret_cast<f32x4*>(y2 + base + (long)((s2 >> 1) * 32 + q * 8) * D + (s2 & 1) * 32) = v[s2 * 4 + q] * 0.5f;
+            }
+    }
+}
+
 int main() {
     const int B = 65536, D = 1024;
     const long n = (long)B * D;
@@ -54,6 +77,9 @@ int main() {
     for (int g : {512, 1024, 2048})
         time(g == 512 ? "tiles 128x128, 1 read + 2 writes, 512 workgroups" : g == 1024 ? "tiles 128x128, 1 read + 2 writes, 1024 workgroups" : "tiles 128x128, 1 read + 2 writes, 2048 workgroups",
              3.0 * n * 4, [&]() { hipLaunchKernelGGL(k_tiled<2>, g, 256, 0, 0, x, y1, y2, B, D); });
+    for (int g : {512, 768, 1024})
+        time(g == 512 ? "quadrant pattern (8 rows x 128 B per instruction), 512 wg" : g == 768 ? "quadrant pattern, 768 wg" : "quadrant pattern, 1024 wg",
+             3.0 * n * 4, [&]() { hipLaunchKernelGGL(k_quad, g, 256, 0, 0, x, y1, y2, B, D); });
     time("tiles 128x128, 1 read + 1 write, 1024 workgroups", 2.0 * n * 4, [&]() { hipLaunchKernelGGL(k_tiled<1>, 1024, 256, 0, 0, x, y1, y2, B, D); });
     return 0;
 }
