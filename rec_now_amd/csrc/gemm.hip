@@ -154,6 +154,7 @@ static inline bool host_aligned(const void* p, int64_t ld, int64_t sb) {
 // the lean (EDGE = false) kernel needs every tile in bounds and every float4 aligned
 static bool gemm_interior(const recnow_gemm_desc* d, const GemmCfg& c, int bk, int kchunk, bool split) {
     if (d->M % c.BM || d->N % c.BN || d->K % bk || kchunk % bk) return false;
+    if ((int64_t)256 * d->lda >= (1ll << 30) || (int64_t)256 * d->ldb >= (1ll << 30)) return false;      // 32-bit byte offsets inside a tile
     if (!host_aligned(d->A, d->lda, d->a_batch_stride) || !host_aligned(d->B, d->ldb, d->b_batch_stride)) return false;
     if (d->a_mode == RECNOW_OPMODE_OUTER) { if (d->a_hq % 4) return false; }
     else if (d->a_mode != RECNOW_OPMODE_NONE && !host_aligned(d->A2, d->lda, d->a_batch_stride)) return false;

@@ -75,6 +75,13 @@ __device__ __forceinline__ f32x4 gemm_combine(f32x4 x, f32x4 y, int mode, int ac
 // (a branch around each load makes hipcc drain vmcnt at every merge and serialises the tile's loads):
 //   load_fast: whole tile in bounds and 16-B aligned -> unconditional float4 loads, all in flight together;
 //   load_safe: edge tiles -> unconditional scalar loads from CLAMPED (always valid) addresses + select to zero.
+// LDS access that stays ONE ds_read_b32 / ds_write_b32 with a 16-bit immediate offset.  hipcc pairs plain accesses into ds_read2_b32 /
+// ds_write2_b32, whose 8-bit offsets (1020 B) do not span the k-rows of a tile (516 B apart): every pair then needs a VALU add to rebase
+// its address, and in the MFMA loop every VALU instruction both takes an issue slot from the MFMAs and sits between a fragment and its
+// read (measured: 30 adds per k-tile gone = 4-5 % per launch of the K = 1024 products).
+#define FR(ptr) (*(const volatile __attribute__((address_space(3))) float*)(ptr))
+#define FW(ptr) (*(volatile __attribute__((address_space(3))) float*)(ptr))
+
 template <int ROWS, int BK, bool KC>
 struct Tile {
     static constexpr int NF4 = ROWS * BK / 4;                                   // float4 slots in the tile
@@ -84,6 +91,7 @@ struct Tile {
     f32x4 v[NV];
     f32x4 y[NV];          // sliced schedule only: second operand (MUL / ACTGRAD) or OUTER scale (.x), combined at commit time
     unsigned off[NV];     // element offset of this thread's float4 inside a tile; tile-invariant (set once by init)
+    unsigned boff[NV];    // the same in bytes (sliced schedule: `global_load v, voff, s[base]` addressing; the host checks the range)
 
     // A tile's addresses are (block-uniform tile base) + off[i]: the base lives in SGPRs and advances per k-tile, the
     // offsets are loop-invariant 32-bit VGPRs.  (Per-load 64-bit addresses recomputed every tile cost ~10 VALU each and,
@@ -94,6 +102,7 @@ struct Tile {
             int r, k;
             coords(threadIdx.x + i * GEMM_THREADS, r, k);
             off[i] = KC ? (unsigned)(r * ld + k) : (unsigned)(k * ld + r);
+            boff[i] = off[i] << 2;
         }
     }
     __device__ __forceinline__ static int64_t tile_base(int64_t ld, int r0, int k0) {
@@ -241,10 +250,10 @@ struct Tile {
         if (!has(i)) return;
         if (KC) {
             float* s = S + k * LD + r;
-            s[0] = v[i].x;
-            s[LD] = v[i].y;
-            s[2 * LD] = v[i].z;
-            s[3 * LD] = v[i].w;
+            FW(s) = v[i].x;
+            FW(s + LD) = v[i].y;
+            FW(s + 2 * LD) = v[i].z;
+            FW(s + 3 * LD) = v[i].w;
         } else {
             *reinterpret_cast<f32x4*>(S + k * LD + r) = v[i];
         }
@@ -269,9 +278,14 @@ struct Tile {
             v[i] = *reinterpret_cast<const f32x4*>(p + (int64_t)row * ld + (col % hq));
             y[i].x = p2[(int64_t)row * ld2 + (col / hq)];
         } else {
+            // (block-uniform base in SGPRs) + (32-bit byte offset of the thread) = the `global_load v, voff, s[base]` form: no VALU address
+            // arithmetic per load.  The empty asm keeps the offset opaque inside the loop body: seen as loop-invariant, its zero-extension
+            // is hoisted out, instruction selection then meets a 64-bit VGPR offset and emits a 64-bit VALU add per load.
             const int64_t base = tile_base(ld, r0, k0);
-            v[i] = *reinterpret_cast<const f32x4*>(p + base + off[i]);
-            if (K2 != RECNOW_OPMODE_NONE) y[i] = *reinterpret_cast<const f32x4*>(p2 + base + off[i]);
+            asm volatile("" : "+v"(boff[i]));
+            const unsigned bo = boff[i];
+            v[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p + base) + bo);
+            if (K2 != RECNOW_OPMODE_NONE) y[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p2 + base) + bo);
         }
     }
     template <int K2>
@@ -574,9 +588,9 @@ k_gemm(const GemmK p) {
         if (p.prio == 4) __builtin_amdgcn_s_setprio(1);       // experiment: the MFMA loop above the other workgroup's staging section
         float a0[TM], b0[TN], a1[TM], b1[TN];      // explicit fragment double buffer: step kk+2 loads under step kk's MFMAs
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a0[i] = as[i * 32];
+        for (int i = 0; i < TM; ++i) a0[i] = FR(as + i * 32);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b0[j] = bs[j * 32];
+        for (int j = 0; j < TN; ++j) b0[j] = FR(bs + j * 32);
         // sched_barrier(0) pins "issue the NEXT step's ds_reads, then this step's MFMAs": without it hipcc sinks the
         // reads below the MFMAs and waits lgkmcnt(0) right in front of their first use (seen in the .s).  An fp32
         // 32x32x2 MFMA group is >= 256 cycles, far longer than the LDS latency, so nothing finer is needed.
@@ -602,24 +616,24 @@ k_gemm(const GemmK p) {
             float sa0 = 0.f, sa1 = 0.f;
             SPV sb0 = SPV(0.f), sb1 = SPV(0.f);
             if constexpr ((XF & 1) != 0) {
-                sa0 = asx[0];
-                sa1 = asx[TA::LD];
+                sa0 = FR(asx);
+                sa1 = FR(asx + TA::LD);
                 sb0 = *reinterpret_cast<const SPV*>(bxs);
                 sb1 = *reinterpret_cast<const SPV*>(bxs + 4);
             }
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
+                for (int i = 0; i < TM; ++i) a1[i] = FR(as + (kk + 2) * TA::LD + i * 32);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
+                for (int j = 0; j < TN; ++j) b1[j] = FR(bs + (kk + 2) * TB::LD + j * 32);
                 float na0 = 0.f, na1 = 0.f;
                 SPV nb0 = sb0, nb1 = sb1;
                 if constexpr ((XF & 1) != 0) {
                     if (kk + 4 < BK) {
                         const int kq = (kk >> 1) + 2;
-                        na0 = asx[kq * TA::LD];
-                        na1 = asx[(kq + 1) * TA::LD];
+                        na0 = FR(asx + kq * TA::LD);
+                        na1 = FR(asx + (kq + 1) * TA::LD);
                         nb0 = *reinterpret_cast<const SPV*>(bxs + kq * 4);
                         nb1 = *reinterpret_cast<const SPV*>(bxs + (kq + 1) * 4);
                     }
@@ -638,9 +652,9 @@ k_gemm(const GemmK p) {
                 __builtin_amdgcn_sched_barrier(0);
                 const int kn = kk + 4 < BK ? kk + 4 : BK - 2;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a0[i] = as[kn * TA::LD + i * 32];
+                for (int i = 0; i < TM; ++i) a0[i] = FR(as + kn * TA::LD + i * 32);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b0[j] = bs[kn * TB::LD + j * 32];
+                for (int j = 0; j < TN; ++j) b0[j] = FR(bs + kn * TB::LD + j * 32);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -653,9 +667,9 @@ k_gemm(const GemmK p) {
         } else
         for (int kk = 0; kk < kv; kk += 4) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
+            for (int i = 0; i < TM; ++i) a1[i] = FR(as + (kk + 2) * TA::LD + i * 32);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
+            for (int j = 0; j < TN; ++j) b1[j] = FR(bs + (kk + 2) * TB::LD + j * 32);
             if constexpr ((XF & 1) != 0) {
                 const int kq = kk >> 1;        // this iteration's two k's of the thread's half-range
                 spacc += asx[kq * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + kq * 4);
@@ -669,9 +683,9 @@ k_gemm(const GemmK p) {
             __builtin_amdgcn_sched_barrier(0);
             const int kn = min(kk + 4, BK - 2);     // stays inside this buffer on the last iteration (value unused then)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a0[i] = as[kn * TA::LD + i * 32];
+            for (int i = 0; i < TM; ++i) a0[i] = FR(as + kn * TA::LD + i * 32);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b0[j] = bs[kn * TB::LD + j * 32];
+            for (int j = 0; j < TN; ++j) b0[j] = FR(bs + kn * TB::LD + j * 32);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)

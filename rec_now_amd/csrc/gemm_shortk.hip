@@ -109,12 +109,18 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     // ring schedule: operand registers of the three sets (set s = k-tile % 3)
     f32x4 ra[NK ? 3 : 1][TA::NV], rb[NK ? 3 : 1][TB::NV];
     auto ring_load = [&](int set, int mm, int nn, int k0) {
-        const float* __restrict__ pa = p.A + TA::tile_base(p.lda, mm, k0);
-        const float* __restrict__ pb = p.B + TB::tile_base(p.ldb, nn, k0);
+        const char* __restrict__ pa = reinterpret_cast<const char*>(p.A + TA::tile_base(p.lda, mm, k0));
+        const char* __restrict__ pb = reinterpret_cast<const char*>(p.B + TB::tile_base(p.ldb, nn, k0));
 #pragma unroll
-        for (int i = 0; i < TA::NV; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(pa + ta.off[i]);
+        for (int i = 0; i < TA::NV; ++i) {           // SGPR base + opaque 32-bit byte offset: see Tile::issue
+            asm volatile("" : "+v"(ta.boff[i]));
+            ra[set][i] = *reinterpret_cast<const f32x4*>(pa + ta.boff[i]);
+        }
 #pragma unroll
-        for (int i = 0; i < TB::NV; ++i) rb[set][i] = *reinterpret_cast<const f32x4*>(pb + tb.off[i]);
+        for (int i = 0; i < TB::NV; ++i) {
+            asm volatile("" : "+v"(tb.boff[i]));
+            rb[set][i] = *reinterpret_cast<const f32x4*>(pb + tb.boff[i]);
+        }
     };
     auto ring_store = [&](int set, float* S) {
 #pragma unroll
@@ -178,15 +184,15 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
             const float* bs = smem + cur * BUF + A_SZ + b_off;
             float a0[2], b0[2], a1[2], b1[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a0[i] = as[i * 32];
+            for (int i = 0; i < 2; ++i) a0[i] = FR(as + i * 32);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b0[j] = bs[j * 32];
+            for (int j = 0; j < 2; ++j) b0[j] = FR(bs + j * 32);
 #pragma unroll
             for (int kk = 0; kk < SK_BK; kk += 4) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a1[i] = as[(kk + 2) * TA::LD + i * 32];
+                for (int i = 0; i < 2; ++i) a1[i] = FR(as + (kk + 2) * TA::LD + i * 32);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b1[j] = bs[(kk + 2) * TB::LD + j * 32];
+                for (int j = 0; j < 2; ++j) b1[j] = FR(bs + (kk + 2) * TB::LD + j * 32);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk / 2 < npairs) {
 #pragma unroll
@@ -197,9 +203,9 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 4 < SK_BK) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) a0[i] = as[(kk + 4) * TA::LD + i * 32];
+                    for (int i = 0; i < 2; ++i) a0[i] = FR(as + (kk + 4) * TA::LD + i * 32);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) b0[j] = bs[(kk + 4) * TB::LD + j * 32];
+                    for (int j = 0; j < 2; ++j) b0[j] = FR(bs + (kk + 4) * TB::LD + j * 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk / 2 + 1 < npairs) {
