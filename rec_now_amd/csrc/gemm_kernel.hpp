@@ -559,8 +559,7 @@ k_gemm(const GemmK p) {
         // together; with a strict order the favoured one runs as if alone and the other fills its gaps.
         if ((__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11)) & 1) == 0) __builtin_amdgcn_s_setprio(2);
     }
-    for (int t = 0; t < ntile; ++t) {
-        const int cur = t & 1;
+    auto ktile_body = [&](const int t, const int cur) __attribute__((always_inline)) {
         if constexpr (SLICED) {
             if ((XF & 1) && threadIdx.x < BK) {   // side-product weights: k-tile t+1 to LDS, t+2 requested (clamped: unconditional)
                 *reinterpret_cast<f32x4*>(Bxs + (cur ^ 1) * BK * 4 + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
@@ -645,9 +644,22 @@ k_gemm(const GemmK p) {
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
                 stage(kk / 2);
                 if constexpr ((XF & 1) != 0) {
-                    spn += sa0 * sb0;
-                    spn += sa1 * sb1;
-                    asm volatile("" : "+v"(spn));
+                    // packed FMAs (two fp32 FMAs per VALU issue), the A value broadcast to both halves by op_sel: hipcc scalarises
+                    // `scalar * f32x2`.  Same operations in the same order per component as `spn += sa0 * sb0; spn += sa1 * sb1`.
+                    // Being volatile they also stay here, behind the first MFMA group (otherwise all FMAs of a k-tile sink to its end).
+                    const f32x2 sa = {sa0, sa1};
+                    if constexpr ((XF & 8) != 0) {
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(spn) : "v"(sa), "v"(sb0));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(spn) : "v"(sa), "v"(sb1));
+                    } else {
+                        f32x2 lo = {spn.x, spn.y}, hi = {spn.z, spn.w};
+                        const f32x2 b0l = {sb0.x, sb0.y}, b0h = {sb0.z, sb0.w}, b1l = {sb1.x, sb1.y}, b1h = {sb1.z, sb1.w};
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(lo) : "v"(sa), "v"(b0l));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(hi) : "v"(sa), "v"(b0h));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(lo) : "v"(sa), "v"(b1l));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(hi) : "v"(sa), "v"(b1h));
+                        spn = mk4(lo.x, lo.y, hi.x, hi.y);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int kn = kk + 4 < BK ? kk + 4 : BK - 2;
@@ -704,6 +716,17 @@ k_gemm(const GemmK p) {
 #else
         __syncthreads();
 #endif
+    };
+    if constexpr (SLICED) {
+        // two copies of the body, the LDS buffer index a compile-time constant in each: every LDS address of the loop is then (a
+        // loop-invariant register) + (an immediate offset), no per-k-tile VALU address arithmetic
+        for (int t = 0; t < ntile; t += 2) {
+            ktile_body(t, 0);
+            if (t + 1 >= ntile) break;
+            ktile_body(t + 1, 1);
+        }
+    } else {
+        for (int t = 0; t < ntile; ++t) ktile_body(t, t & 1);
     }
     if constexpr ((XF & 1) != 0 && SLICED) {
         if constexpr ((XF & 8) != 0) spacc = mk4(spn.x, spn.y, 0.f, 0.f);
