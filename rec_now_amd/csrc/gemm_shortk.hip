@@ -11,6 +11,8 @@
 //   * the epilogue requests the operands of sub-tile s+1 before it stages and stores sub-tile s, and never waits on a store;
 //   * tiles are handed out XCD-aware: workgroup b runs on XCD b % 8 (round-robin dispatch), and the 8 column tiles of one
 //     row tile go to consecutive workgroups of the SAME XCD, so the A row-panel is fetched into one L2 instead of eight.
+//   * nine-k-tile products (K = 144, DCN-v2) run the RING schedule (NK = 9 below): operands two k-tiles ahead in three rotating
+//     register sets, the k-loop unrolled, every wait an exact count.
 #include "gemm_kernel.hpp"
 
 #define SK_BM 128
