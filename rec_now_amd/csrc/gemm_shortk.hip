@@ -390,7 +390,13 @@ int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStr
         if (c2_mode == 3) return launch_sk<false, 1, 3, true, 9>(k, st);
         if (c2_mode == 0) return launch_sk<false, 1, 0, true, 9>(k, st);
     }
-    if (k.K == 9 * SK_BK && (ring & 4) && b_kc && ep == 2 && c2_mode == 0) return launch_sk<true, 2, 0, true, 9>(k, st);
+    if (k.K == 9 * SK_BK && (ring & 1) && !pre && !b_kc && ep == 1) {      // RECNOW_SK_PRE=0: the ring without the whole-tile prefetch, 3 workgroups per CU
+        if (c2_mode == 1) return launch_sk<false, 1, 1, false, 9>(k, st);
+        if (c2_mode == 3) return launch_sk<false, 1, 3, false, 9>(k, st);
+        if (c2_mode == 0) return launch_sk<false, 1, 0, false, 9>(k, st);
+    }
+    if (k.K == 9 * SK_BK && (ring & 4) && b_kc && ep == 2 && c2_mode == 0)
+        return pre ? launch_sk<true, 2, 0, true, 9>(k, st) : launch_sk<true, 2, 0, false, 9>(k, st);
     if (k.K == 9 * SK_BK && b_kc && ep == 0) {
         if (c2_mode == 2 && (ring & 2)) return launch_sk<true, 0, 2, false, 9>(k, st);
         if (c2_mode == 4 && (ring & 8)) return launch_sk<true, 0, 4, false, 9>(k, st);
