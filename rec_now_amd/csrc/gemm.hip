@@ -203,6 +203,8 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
     k.trace = nullptr;
     k.cu_slots = nullptr; k.stagger_ticks = 0;
     k.tail_pairs = 8;
+    static const int direct = []() { const char* e = getenv("RECNOW_GEMM_DIRECT"); return e ? atoi(e) : 1; }();      // A/B switch
+    k.direct_store = direct;
     static const int gemm_prio = []() { const char* e = getenv("RECNOW_GEMM_PRIO"); return e ? atoi(e) : 0; }();     // A/B switch
     k.prio = gemm_prio;
     if (d->c_perm_s < 0 || (d->c_perm_s > 0 && (d->N % d->c_perm_s || d->batch != 1 || d->c_trans || d->accumulate))) return RECNOW_EINVAL;

@@ -47,6 +47,7 @@ struct GemmK {
     float* hp;                 // c2_mode 3: partials hp[m][hp_ld], entry 2 * column tile + wave column
     int hp_ld;
     int prio;                  // short-K kernel: raise the wave priority inside the k-loop (experiment)
+    int direct_store;          // lean epilogue: plain outputs straight from the accumulators (RECNOW_GEMM_DIRECT=0: staged through LDS)
     int perm_s;                // split-K reduce: > 0 stores C[row][c] at C[((c / perm_s) * M + row) * perm_s + c % perm_s] (see recnow_gemm_desc.c_perm_s)
     int tail_pairs;            // short-K kernel: k-pairs of the LAST k-tile that hold data (8 = all; fewer: a zero-padded depth)
     int* cu_slots;             // short-K kernel: per-CU arrival counters of the phase stagger (NULL: no stagger)
@@ -317,6 +318,20 @@ __device__ __forceinline__ void gemm_lean_epilogue(const GemmK& p, f32x16 (&acc)
     const float* biasb = (!plain && p.bias) ? p.bias + (int64_t)bidx * p.sBias : nullptr;
     const float* Eb = (!plain && p.emul) ? p.emul + (int64_t)bidx * p.sE : nullptr;
     const bool accum = !plain && p.accumulate;
+    // Nothing to apply (split-K slabs, and plain products such as the K = 1024 ones of DCN-v2): the accumulators go out as they lie --
+    // one dword per lane, a store instruction = two rows x 128 B, 16 per sub-tile, no LDS round trip and nothing to wait for.  The
+    // epilogue of these launches runs with the MFMA pipe idle (every workgroup of the one round reaches it at the same time).
+    if (p.direct_store && (plain || (!biasb && !Eb && !accum && !p.c_trans && p.act == RECNOW_ACT_LINEAR && (XF & 2) == 0))) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float* cp = Cb + (int64_t)(m0 + wm * TM * 32 + i * 32 + row_l) * ldc + n0 + wn * TN * 32 + j * 32 + col_l;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r];
+            }
+        return;
+    }
     // rank-R update operands: Q[r][col] depends only on the column sub-tile j, P[row][r] only on the row sub-tile i.
     // Loads are unconditional (r clamped to the last valid one, its weight zeroed): no per-load branches.
     float euq[TN][4][4], eup[4][4];
