@@ -487,7 +487,10 @@ def test_dcn_mix_input_without_gradient(dev, B, D, S, N, L):
 
 
 # ---- persistent short-K kernel: every epilogue form, tile counts above and below one resident wave of workgroups -------------
-@pytest.mark.parametrize('M,N,K,tb', [(256, 256, 144, 0), (1024, 1024, 48, 1), (16384, 1024, 144, 0), (384, 128, 16, 1)])
+# K = 144 = nine k-tiles runs the ring schedule (operands two k-tiles ahead, carried across tiles): 8576 x 1024 = 536 tiles is a ragged
+# second round on 512 resident workgroups without the XCD-aware order (67 row tiles), 9216 x 1024 = 576 tiles the same with it
+@pytest.mark.parametrize('M,N,K,tb', [(256, 256, 144, 0), (1024, 1024, 48, 1), (16384, 1024, 144, 0), (384, 128, 16, 1),
+                                      (8576, 1024, 144, 0), (9216, 1024, 144, 1), (8576, 1024, 144, 1)])
 @pytest.mark.parametrize('form', ['plain', 'emul', 'accum', 'emul_accum', 'dual_raw', 'dual_fma'])
 def test_gemm_short_k_persistent_kernel(dev, M, N, K, tb, form):
     from rec_now_amd import _lib
