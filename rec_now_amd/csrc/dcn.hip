@@ -718,6 +718,12 @@ static bool dcn_pick_bwd(int D, const void* a, const void* b, const void* c, Dcn
     return true;
 }
 
+static int dcn_occupancy(const void* kernel, size_t shm) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, shm) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
 static inline int dcn_grid(int64_t B, int tpr) {
     const int64_t rpb = 256 / tpr;
     int64_t g = (B + rpb - 1) / rpb;
@@ -825,20 +831,35 @@ extern "C" int recnow_dcn_bwd(const float* x, const float* kernels, const float*
         if (dbiases) RN_HIP(hipMemcpyAsync(dbiases, sums + (size_t)L * D, (size_t)L * D * sizeof(float), hipMemcpyDeviceToDevice, st));
         return RECNOW_OK;
     }
-    if (csave && cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4) cfg = {128, 4, 2};     // 2 waves per wide row: half the registers per lane
+    // D = 1024: a wave per row up to three cross layers (row sums are shuffles, no barrier in the row loop: the two-waves-per-row form
+    // waits on a workgroup barrier per layer and row: 176 vs 166 us at B = 65 536, L = 3, both on one resident wave of workgroups); deeper: 2 waves per row, half the
+    // accumulator registers per lane.  RECNOW_DCN_WAVE_ROW=0 is the A/B switch.
+    static const bool wave_row = []() { const char* e = getenv("RECNOW_DCN_WAVE_ROW"); return !e || e[0] != '0'; }();
+    if (csave && cfg.tpr == 64 && cfg.vec == 4 && cfg.nv == 4 && !(wave_row && L <= 3)) cfg = {128, 4, 2};
     static const bool dcn_fast = []() { const char* e = getenv("RECNOW_DCN_FAST"); return !e || e[0] != '0'; }();      // A/B switch
+    static const bool dcn_resident = []() { const char* e = getenv("RECNOW_DCN_RESIDENT"); return !e || e[0] != '0'; }();      // A/B switch
     bool fast_done = false;
     int G = dcn_grid(B, cfg.tpr);
     if (dcn_fast && csave && cfg.vec == 4 && D == cfg.tpr * 4 * cfg.nv && B % (256 / cfg.tpr) == 0 && (cfg.tpr == 64 || cfg.tpr == 128)) {
         const size_t shm = ((size_t)(256 / cfg.tpr) * D + (size_t)2 * L * D) * sizeof(float);
 #define BWD_FAST(TPR_, NV_, L_)                                                                                                    \
         if (!fast_done && shm <= 48 * 1024 && cfg.tpr == TPR_ && cfg.nv == NV_ && L == L_) {                                       \
-            if (act == RECNOW_ACT_LINEAR) hipLaunchKernelGGL((k_dcn_bwd_fast<TPR_, NV_, L_, RECNOW_ACT_LINEAR>), G, 256, shm, st, x, kernels, biases, dy, csave, B, act, dx, part); \
-            else hipLaunchKernelGGL((k_dcn_bwd_fast<TPR_, NV_, L_, -1>), G, 256, shm, st, x, kernels, biases, dy, csave, B, act, dx, part);  \
+            /* one resident wave of workgroups (rows are grid-strided): every workgroup beyond it costs a weight fill, a combine  \
+               and a 2*L*D slab that the column sum reads back (2048 slabs = 50 MB at D = 1024, L = 3) */                        \
+            if (act == RECNOW_ACT_LINEAR) {                                                                                        \
+                static const int occ = dcn_occupancy((const void*)k_dcn_bwd_fast<TPR_, NV_, L_, RECNOW_ACT_LINEAR>, shm);          \
+                if (dcn_resident && G > 256 * occ) G = 256 * occ;                                                                  \
+                hipLaunchKernelGGL((k_dcn_bwd_fast<TPR_, NV_, L_, RECNOW_ACT_LINEAR>), G, 256, shm, st, x, kernels, biases, dy, csave, B, act, dx, part); \
+            } else {                                                                                                               \
+                static const int occ = dcn_occupancy((const void*)k_dcn_bwd_fast<TPR_, NV_, L_, -1>, shm);                         \
+                if (dcn_resident && G > 256 * occ) G = 256 * occ;                                                                  \
+                hipLaunchKernelGGL((k_dcn_bwd_fast<TPR_, NV_, L_, -1>), G, 256, shm, st, x, kernels, biases, dy, csave, B, act, dx, part);  \
+            }                                                                                                                      \
             fast_done = true;                                                                                                      \
         }
         BWD_FAST(64, 1, 1) BWD_FAST(64, 1, 2) BWD_FAST(64, 1, 3) BWD_FAST(64, 1, 4)
         BWD_FAST(128, 2, 1) BWD_FAST(128, 2, 2) BWD_FAST(128, 2, 3) BWD_FAST(128, 2, 4)
+        BWD_FAST(64, 4, 1) BWD_FAST(64, 4, 2) BWD_FAST(64, 4, 3)
 #undef BWD_FAST
     }
     const size_t shmem = cfg.tpr < 256 ? (size_t)(256 / cfg.tpr) * D * sizeof(float) : 0;

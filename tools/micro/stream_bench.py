@@ -1,5 +1,5 @@
 """Kernel-only timings (HIP events, 50 launches) of the streaming kernels whose bound is the HBM read rate:
-FM forward / backward at BASELINE config 4 and the scoring head of the north-star step.  GPU only.
+FM forward / backward at BASELINE config 4, DCNLayer forward / backward at config 3's shape and the scoring head of the north-star step.  GPU only.
 usage: python tools/micro/stream_bench.py"""
 import os
 import sys
@@ -60,6 +60,24 @@ def head():
     print('head fwd+bwd : %.1f us wall per step  %.2f TB/s of 12*B*D bytes (x | x, dx)' % (t, 12.0 * B * D / t / 1e6))
 
 
+def dcn():
+    B, D, L = 65536, 1024, 3                 # BASELINE config 3 shape, DCNLayer (rec_now/layers/dcn_layer.py:91-103)
+    x = torch.randn(B, D, device=dev)
+    k = torch.randn(L, D, device=dev) * 0.03
+    b = torch.randn(L, D, device=dev) * 0.03
+    y, dy, dx = torch.empty_like(x), torch.randn(B, D, device=dev), torch.empty_like(x)
+    cs = torch.empty(B, L, device=dev)
+    dk, db = torch.empty_like(k), torch.empty_like(b)
+    ws = _lib.workspace(lib.recnow_dcn_workspace_bytes(B, D, L), dev)
+    st = _lib.stream()
+    tf = timeit(lambda: _lib.call('recnow_dcn_fwd', _lib.ptr(x), _lib.ptr(k), _lib.ptr(b), B, D, L, 0, _lib.ptr(y), _lib.ptr(cs), st))
+    tb = timeit(lambda: _lib.call('recnow_dcn_bwd', _lib.ptr(x), _lib.ptr(k), _lib.ptr(b), _lib.ptr(dy), _lib.ptr(cs), B, D, L, 0, _lib.ptr(dx),
+                                  _lib.ptr(dk), _lib.ptr(db), _lib.ptr(ws), ws.numel(), st))
+    print('DCN fwd  B=%d D=%d L=%d : %.1f us  %.2f TB/s of 8*B*D bytes' % (B, D, L, tf, 8.0 * B * D / tf / 1e6))
+    print('DCN bwd  B=%d D=%d L=%d : %.1f us  %.2f TB/s of 12*B*D bytes (all launches of the call)' % (B, D, L, tb, 12.0 * B * D / tb / 1e6))
+
+
 if __name__ == '__main__':
+    dcn()
     fm()
     head()
