@@ -173,7 +173,15 @@ def ptr(t):
     return _P(t.data_ptr())
 
 
+# torch.cuda.current_stream() resolves its device through torch.cuda.is_available() (an os.getenv and a Stream object per call): 20-70 us
+# of host time on every entry point.  The raw accessors return the same hipStream_t of the current device in well under a microsecond.
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_RAW_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream():
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return _P(_RAW_STREAM(_RAW_DEVICE()))
     return _P(torch.cuda.current_stream().cuda_stream)
 
 
