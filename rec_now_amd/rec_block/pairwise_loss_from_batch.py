@@ -158,9 +158,17 @@ def _onepass(ctx, outputs, scores, labs, m, order, seg_id, seg_first, B, dev, fl
     ctx.shape = outputs.shape
     ctx.onepass = True
     ctx.reduce_mean = bool(reduce_mean)
+    return loss, _n_pair_out(ctx, n_pair)
+
+
+def _n_pair_out(ctx, n_pair):
+    """The pair count as the float32 0-dim tensor the reference returns -- only when the caller asked for it (one conversion kernel
+    and its host time less on the default `pairwise_loss(...)` path)."""
+    if not ctx.want_np:
+        return None
     n_pair_f = n_pair.to(torch.float32).reshape(())
     ctx.mark_non_differentiable(n_pair_f)
-    return loss, n_pair_f
+    return n_pair_f
 
 
 def _onepass_backward(ctx, g):
@@ -174,8 +182,9 @@ def _onepass_backward(ctx, g):
 
 class _PairBprFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, outputs, labels, mask, seg, flags, factor, power, reduce_mean):
+    def forward(ctx, outputs, labels, mask, seg, flags, factor, power, reduce_mean, want_np=True):
         B = seg.B
+        ctx.want_np = bool(want_np)
         scores = _flat_f32(outputs, B, 'outputs')
         labs = _flat_f32(labels, B, 'labels')
         m = _flat_mask(mask, B)
@@ -194,16 +203,14 @@ class _PairBprFused(torch.autograd.Function):
                   _lib.ptr(dscores), _lib.ptr(ws), ws.numel(), _lib.stream())
         ctx.save_for_backward(dscores[:B])
         ctx.shape = outputs.shape
-        n_pair_f = n_pair.to(torch.float32).reshape(())
-        ctx.mark_non_differentiable(n_pair_f)
-        return loss, n_pair_f
+        return loss, _n_pair_out(ctx, n_pair)
 
     @staticmethod
     def backward(ctx, g, _g_np):
         if ctx.onepass:
-            return _onepass_backward(ctx, g), None, None, None, None, None, None, None
+            return _onepass_backward(ctx, g), None, None, None, None, None, None, None, None
         (dscores,) = ctx.saved_tensors
-        return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None
+        return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None, None
 
 
 class _PairBprSmall(torch.autograd.Function):
@@ -211,8 +218,9 @@ class _PairBprSmall(torch.autograd.Function):
     (recnow_group_pack_small), then the counting and loss kernels of the general route on the packed members."""
 
     @staticmethod
-    def forward(ctx, outputs, labels, mask, gkey, gdt, flags, factor, power, reduce_mean):
+    def forward(ctx, outputs, labels, mask, gkey, gdt, flags, factor, power, reduce_mean, want_np=True):
         B = gkey.numel()
+        ctx.want_np = bool(want_np)
         scores = _flat_f32(outputs, B, 'outputs')
         labs = _flat_f32(labels, B, 'labels')
         m = _flat_mask(mask, B)
@@ -241,16 +249,14 @@ class _PairBprSmall(torch.autograd.Function):
                   float(factor), float(power), 1 if reduce_mean else 0, _lib.ptr(loss), _lib.ptr(dscores), _lib.ptr(ws), ws.numel(), st)
         ctx.save_for_backward(dscores[:B])
         ctx.shape = outputs.shape
-        n_pair_f = n_pair.to(torch.float32).reshape(())
-        ctx.mark_non_differentiable(n_pair_f)
-        return loss, n_pair_f
+        return loss, _n_pair_out(ctx, n_pair)
 
     @staticmethod
     def backward(ctx, g, _g_np):
         if ctx.onepass:
-            return _onepass_backward(ctx, g), None, None, None, None, None, None, None, None
+            return _onepass_backward(ctx, g), None, None, None, None, None, None, None, None, None
         (dscores,) = ctx.saved_tensors
-        return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None, None
+        return (dscores * g).reshape(ctx.shape), None, None, None, None, None, None, None, None, None
 
 
 def _small_route(groups):
@@ -278,17 +284,19 @@ def group_rows(groups):
 
 
 def pairwise_loss_fused(outputs, labels, groups, only_use_wrong_order_pair=False, click_occurance_power=0.0, mask=None,
-                        factor=1.0, reduce_mean=True, segments=None):
+                        factor=1.0, reduce_mean=True, segments=None, return_num_pair=True):
     """Fused BPR pairwise loss; returns (loss, n_pair) as 0-dim tensors, no host sync.  `pairwise_loss` routes here
     whenever the defaults make it possible; exposed because it also accepts `factor` / `reduce_mean` and a precomputed
-    `segments=group_rows(groups)` (then `groups` is not looked at again)."""
+    `segments=group_rows(groups)` (then `groups` is not looked at again).  return_num_pair=False: the second value is None (the
+    float32 conversion of the pair count is a kernel of its own)."""
     flags = _FLAG_LABEL_GT | (_FLAG_WRONG_ORDER if only_use_wrong_order_pair else 0)
     if segments is None:
         small = _small_route(groups)
         if small is not None:
-            return _PairBprSmall.apply(outputs, labels, mask, small[0], small[1], flags, factor, click_occurance_power, reduce_mean)
+            return _PairBprSmall.apply(outputs, labels, mask, small[0], small[1], flags, factor, click_occurance_power, reduce_mean,
+                                       return_num_pair)
     seg = segments if segments is not None else build_segments(groups)
-    return _PairBprFused.apply(outputs, labels, mask, seg, flags, factor, click_occurance_power, reduce_mean)
+    return _PairBprFused.apply(outputs, labels, mask, seg, flags, factor, click_occurance_power, reduce_mean, return_num_pair)
 
 
 def _merge_weights_by_mul(weights1, weights2):
@@ -317,7 +325,8 @@ def pairwise_loss(outputs, labels, groups,
     Returns: loss, or (loss, n_pair as float32 tensor) when return_num_pair.
     """
     if pairloss_func is bpr_loss_func and label_pair_to_weight_func is None:
-        loss, n_pair = pairwise_loss_fused(outputs, labels, groups, only_use_wrong_order_pair, click_occurance_power, mask)
+        loss, n_pair = pairwise_loss_fused(outputs, labels, groups, only_use_wrong_order_pair, click_occurance_power, mask,
+                                           return_num_pair=return_num_pair)
         return (loss, n_pair) if return_num_pair else loss
 
     # general path: materialise the pair list, then run the user's callables on (P,) vectors
