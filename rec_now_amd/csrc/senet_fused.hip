@@ -280,7 +280,7 @@ extern "C" int recnow_senet_fused_bwd(const float* const* fields, float* const* 
     }
     if (!fields || !dfields || !W1 || !W2 || !dout || !sq_save || !h_save || !w_save || !dW1 || !dW2 || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_senet_fused_workspace_bytes(B, F, M)) return RECNOW_EWORKSPACE;
-    const int nb = sf_grid(B);
+    int nb = sf_grid(B);
     RnCarver c(ws, ws_bytes);
     float* part = c.take<float>((size_t)nb * nout);
     float* sums = c.take<float>((size_t)nout);
@@ -289,7 +289,17 @@ extern "C" int recnow_senet_fused_bwd(const float* const* fields, float* const* 
     const SfDims dm = {F, D, M, act1, act2, 0};
     const size_t lds = ((size_t)F * (M + 1) + (size_t)M * (F + 1) + 7 * SF_R * SF_RS) * sizeof(float);
     const int nacc = (nout + 255) / 256;
-#define SF_BWD(NA) hipLaunchKernelGGL(k_senet_fused_bwd<NA>, nb, 256, lds, st, fields, dfields, dm, B, W1, W2, dout, sq_save, h_save, w_save, part)
+    // one resident wave of workgroups (rows are grid-strided): every further workgroup costs a weight fill and a slab of partial sums that
+    // the column sum reads back (as the DCNLayer backward); RECNOW_SENET_RESIDENT=0 is the A/B switch: 0.85 -> 0.78 ms for the layer's step at B = 131 072; the forward measured the same either way
+    static const bool resident = []() { const char* e = getenv("RECNOW_SENET_RESIDENT"); return !e || e[0] != '0'; }();
+#define SF_BWD(NA) do {                                                                                                            \
+        if (resident) {                                                                                                            \
+            int occ = 0;                                                                                                           \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_senet_fused_bwd<NA>, 256, lds) != hipSuccess || occ < 1) occ = 1; \
+            if (nb > 256 * occ) nb = 256 * occ;                                                                                    \
+        }                                                                                                                          \
+        hipLaunchKernelGGL(k_senet_fused_bwd<NA>, nb, 256, lds, st, fields, dfields, dm, B, W1, W2, dout, sq_save, h_save, w_save, part); \
+    } while (0)
     if (nacc <= 3) SF_BWD(3);
     else if (nacc <= 5) SF_BWD(5);
     else if (nacc <= 9) SF_BWD(9);
