@@ -317,20 +317,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
     graph = None
-    if args.graph:
+    if not args.graph:
+        for _ in range(args.warmup):
+            step()
+    else:
         if use_dist:
             raise SystemExit('--graph is a single-GPU diagnostic')
+        # every warm-up step on a non-default stream (torch.cuda.graph's own recipe), and no reference to an earlier step's autograd graph
+        # left: the AccumulateGrad nodes of the parameters then belong to a capturable stream -- created under the legacy default stream
+        # (and kept alive through last['scores']) they make hipStreamEndCapture fail
+        cap_warm = torch.cuda.Stream()
+        cap_warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap_warm):
+            for _ in range(max(args.warmup, 3)):
+                step()
+        torch.cuda.current_stream().wait_stream(cap_warm)
         torch.cuda.synchronize()
+        last.clear()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             graph_loss = step()
         run_step = lambda: (graph.replay(), graph_loss)[1]     # noqa: E731
         for _ in range(2):
             run_step()
-    else:
+    if graph is None:
         run_step = step
     prof = not args.no_prof and graph is None
     if prof:
