@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Headline benchmark (BASELINE.json): samples/sec, forward+backward, in-batch pairwise loss + 3-layer DCN-v2
-(DCNMixLayer, low-rank 64, 2 experts), B = 65536 rows per GPU, 64 fields x 16-dim = 1024 features, on N MI355X.
+(DCNMixLayer, low-rank 64, 2 experts), global batch B = 65536, 64 fields x 16-dim = 1024 features, on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
@@ -8,8 +8,9 @@
 A step = one forward + backward pass of the hot path over one resident batch (inputs already in HBM):
     x (B,1024) -> DCNMixLayer(dim_sub_space=64, num_layer=3, num_expert=2) -> MultiDenseLayer(1,1) head -> (B,) scores
       -> pairwise_loss(scores, labels, group_id) -> backward to every weight (+ SUM all-reduce of weight grads, N > 1).
-Data-parallel (weak scaling): every rank owns whole groups, the loss is combined with one 2-float all-reduce
-(rec_now_amd/dp.py).  Prints ONE JSON line on rank 0.
+Data-parallel: STRONG scaling by default -- the metric's B = 65536 is the global batch, every rank owns 65536 / N rows of whole
+groups (`--scaling weak`: 65536 rows per rank); the loss statistics ride in the first gradient bucket (rec_now_amd/dp.py), no
+data-path collective.  `--rows R --force-dist` runs the per-rank shard of an N-GPU row on one GPU.  Prints ONE JSON line on rank 0.
 
 roofline:     the dominant kernel is the exact-fp32 MFMA GEMM `k_gemm<128,128,..>` (the K = 1024 and K = B products of the
               step); `achieved` = algorithmic flops (2*M*N*K per launch) / HIP-event time of its launches during the timed
@@ -45,7 +46,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_PER_GPU = 65536
+GLOBAL_BATCH = 65536                  # BASELINE.json metric: B = 65536 at 1/2/4/8 GPUs (strong scaling: 65536 / N rows per rank)
+B_PER_GPU = 65536                     # --scaling weak: rows per rank
 N_FIELD, EMB_DIM = 64, 16
 D = N_FIELD * EMB_DIM
 SUB, LAYERS, EXPERTS = 64, 3, 2
@@ -73,7 +75,10 @@ def kernel_source_hash():
 def synth_batch(B, seed, rank=0):
     rng = np.random.default_rng(seed + 1000 * rank)
     x = rng.normal(0.0, 0.05, (B, D)).astype(np.float32)
-    groups = rng.integers(0, B // ROWS_PER_GROUP, B).astype(np.float32)      # ids are rank-local -> whole groups per rank
+    # every rank draws its own B // 64 group ids and shifts them by rank * (B // 64): whole groups per rank, ids distinct across
+    # ranks, so the ranks' shards concatenate to ONE global batch whose loss the N-rank step reproduces (rec_now_amd/dp.py)
+    n_groups = max(B // ROWS_PER_GROUP, 1)
+    groups = (rng.integers(0, n_groups, B) + rank * n_groups).astype(np.float32)
     labels = (rng.random(B) < 0.25).astype(np.float32)
     return x, groups, labels
 
@@ -198,7 +203,13 @@ def main():
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events in the timed region')
     ap.add_argument('--graph', action='store_true', help='capture the step into a HIP graph and replay it (SURVEY 8f.1; launch-bound small batches)')
     ap.add_argument('--no-input-grad', action='store_true', help='diagnostic: x is data without a gradient (the metric keeps d loss / d x: in a model x is the embedding output)')
-    ap.add_argument('--rows', type=int, default=B_PER_GPU, help='rows per GPU (diagnostics; the metric is defined at 65536)')
+    ap.add_argument('--scaling', choices=['strong', 'weak'], default='strong',
+                    help="'strong' (default, the metric: B = 65536 is the GLOBAL batch, every rank owns 65536 / N rows of whole groups); "
+                         "'weak': 65536 rows per GPU")
+    ap.add_argument('--rows', type=int, default=None, help='rows per GPU (diagnostics: the per-rank shard of the 2/4/8-GPU rows on one GPU, '
+                    'e.g. --rows 8192 --force-dist; default 65536 / N under strong scaling, 65536 under weak scaling)')
+    ap.add_argument('--group-inline', action='store_true', help='diagnostic: the grouping of the batch on the main stream instead of a side stream under the forward pass')
+    ap.add_argument('--hostprof', default=None, help='diagnostic: cProfile the host side of 20 extra (untimed) steps into this file')
     ap.add_argument('--unfused', action='store_true', help='diagnostic: the drop-in composition head(cross(x)) and pairwise_loss(outputs, labels, groups) '
                     'instead of the model-level fused node (rec_now_amd/fused.py) with grouping on a side stream')
     ap.add_argument('--gemm-precision', choices=['f32', 'bf16x3'], default='f32',
@@ -237,7 +248,12 @@ def main():
 
     torch.manual_seed(3)                      # identical replicated weights on every rank
     model = Model()
-    rows = args.rows
+    if args.rows is None:
+        if args.scaling == 'strong' and GLOBAL_BATCH % world:
+            raise SystemExit('strong scaling shards B = %d over %d ranks: not divisible' % (GLOBAL_BATCH, world))
+        rows = GLOBAL_BATCH // world if args.scaling == 'strong' else B_PER_GPU
+    else:
+        rows = args.rows
     x, groups, labels = synth_batch(rows, 3, rank)
     xd, gd, yd = (torch.from_numpy(v).to(dev) for v in (x, groups, labels))
     model(xd[:256])                           # lazy build on the device
@@ -281,12 +297,16 @@ def main():
                 return loss_val.detach()
             local_sum, n_pair = pairwise_loss_fused(scores, yd, gd, reduce_mean=False)
         else:
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+            if args.group_inline:
                 seg = group_rows(gd)
-            scores = dcn_mix_score(model.cross, model.head, xin, layer_events=events, grad_buffers=grad_buffers) if fused else model(xin)
-            main.wait_stream(side)
+                scores = dcn_mix_score(model.cross, model.head, xin, layer_events=events, grad_buffers=grad_buffers) if fused else model(xin)
+            else:
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    seg = group_rows(gd)
+                scores = dcn_mix_score(model.cross, model.head, xin, layer_events=events, grad_buffers=grad_buffers) if fused else model(xin)
+                main.wait_stream(side)
             if not use_dist:
                 # one process: the reference's own normalisation (pairwise_loss_from_batch.py:279, mean over the pairs) inside the
                 # loss kernel, as `pairwise_loss` returns it -- no statistics to combine
@@ -353,20 +373,32 @@ def main():
         loss = run_step()
     sync()
     elapsed = time.perf_counter() - t0
-    # diagnostic: host time to ENQUEUE a step (no synchronisation inside): well below ms_per_step = the step is GPU-bound
-    h0 = time.perf_counter()
-    for _ in range(5):
-        run_step()
-    host_ms = (time.perf_counter() - h0) * 1e3 / 5
-    sync()
     roofline = None
-    if prof:
+    if prof:                                 # collected and switched off HERE: the samples are launches of the timed steps only
         cnt = (ctypes.c_int * 16)()          # the library fills RN_TAG_MAX (= 9) entries
         ms = (ctypes.c_double * 16)()
         fl = (ctypes.c_double * 16)()
         by = (ctypes.c_double * 16)()
         _lib.check(lib.recnow_prof_collect(cnt, ms, fl, by), 'recnow_prof_collect')
         lib.recnow_prof_enable(0)
+    # diagnostic: host time to ENQUEUE a step (no synchronisation inside): well below ms_per_step = the step is GPU-bound
+    h0 = time.perf_counter()
+    for _ in range(5):
+        run_step()
+    host_ms = (time.perf_counter() - h0) * 1e3 / 5
+    sync()
+    if args.hostprof:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(20):
+            run_step()
+        pr.disable()
+        sync()
+        with open(args.hostprof, 'w') as fh:
+            pstats.Stats(pr, stream=fh).sort_stats('cumulative').print_stats(45)
+    if prof:
         traffic_tab, stale = {}, None
         try:
             with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as fh:
@@ -447,12 +479,13 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': elapsed * 1e3 / args.steps,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling if args.rows is None else 'weak',
             'vs_baseline': None,
             'dtype': 'f32' if args.gemm_precision == 'f32' else 'f32 operands as 3 x bf16, bf16 MFMA, f32 accumulate (opt-in, --gemm-precision bf16x3)',
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
-                                   'in-batch pairwise (logistic), B=65536 rows per GPU, 64 fields x 16-dim, ~64 rows/group',
+                                   'in-batch pairwise (logistic), global B=%d = %d rows on each of %d GPU(s), 64 fields x 16-dim, ~64 rows/group' % (rows * world, rows, world),
+                       'rows_per_gpu': rows,
                        'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(args.graph), 'parallelism': 'dp%d' % world,
                        'route': 'fused node dcn_mix_score + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
                        'loss': float(loss.item()), 'host_enqueue_ms_per_step': host_ms,
