@@ -201,7 +201,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events in the timed region')
-    ap.add_argument('--graph', action='store_true', help='capture the step into a HIP graph and replay it (SURVEY 8f.1; launch-bound small batches)')
+    ap.add_argument('--graph', action='store_true', help='replay the step from captured HIP graphs (SURVEY 8f.1); the default under a process group '
+                    '(N > 1 or --force-dist), where a shard of 8192-32768 rows is shorter on the GPU than its launches are on the host')
+    ap.add_argument('--eager', action='store_true', help='never replay graphs (diagnostic for the N > 1 path)')
+    ap.add_argument('--route', choices=['step', 'autograd'], default='step',
+                    help="'step' (default): the whole step through recnow_dcn_mix_step (rec_now_amd/step.py: one C call per phase, buffers allocated "
+                         "once); 'autograd': the model-level fused node dcn_mix_score + pairwise_loss_fused through torch.autograd")
     ap.add_argument('--no-input-grad', action='store_true', help='diagnostic: x is data without a gradient (the metric keeps d loss / d x: in a model x is the embedding output)')
     ap.add_argument('--scaling', choices=['strong', 'weak'], default='strong',
                     help="'strong' (default, the metric: B = 65536 is the GLOBAL batch, every rank owns 65536 / N rows of whole groups); "
@@ -267,8 +272,18 @@ def main():
     from rec_now_amd.fused import GpuEvent, dcn_mix_score, fused_route_available
     from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
     fused = not args.unfused and fused_route_available(model.cross, model.head, xd)
-    events, layerwise, grad_buffers = None, None, None
-    if fused and use_dist:
+    use_step = fused and args.route == 'step'
+    use_graph = (args.graph or (use_dist and use_step)) and not args.eager
+    events, layerwise, grad_buffers, pstep = None, None, None, None
+    if use_step:
+        # whole-step entry: one C call per phase on buffers allocated once; under a process group the gradients are produced inside the
+        # reducer's per-layer buckets and every bucket's all-reduce is enqueued as soon as its piece of the backward pass is
+        from rec_now_amd.step import DCNMixPairwiseStep
+        if use_dist:
+            stages = DCNMixPairwiseStep.stages_for(model.cross, model.head)
+            layerwise = dp.LayerwiseReducer(stages, [GpuEvent() for _ in stages], dev)
+        pstep = DCNMixPairwiseStep(model.cross, model.head, xd.detach(), yd, gd, need_dx=not args.no_input_grad, reducer=layerwise)
+    elif fused and use_dist:
         events = [GpuEvent() for _ in range(LAYERS)]
         per_layer = lambda l: [model.cross.origin_to_sub_kernels[l], model.cross.sub_to_sub_kernels[l], model.cross.sub_to_origin_kernels[l],     # noqa: E731
                                model.cross.biases[l], model.cross.gate_layers[l].kernel]
@@ -281,6 +296,12 @@ def main():
     last = {}
 
     def step(xin=None):
+        if pstep is not None:
+            if xin is not None:
+                pstep.x.copy_(xin.detach())       # the parity step's inputs (the step object owns its input storage)
+            loss_val, n_pair = pstep.run()
+            last['scores'], last['n_pair'], last['dx'] = pstep.scores, n_pair, pstep.dx
+            return loss_val
         xin = xd if xin is None else xin
         for p in params:
             p.grad = None
@@ -338,12 +359,21 @@ def main():
         torch.cuda.synchronize()
 
     graph = None
-    if not args.graph:
+    if pstep is not None:
+        for _ in range(max(args.warmup, 1 if use_graph else 0)):
+            step()
+        if use_graph:
+            pstep.capture()
+            graph = pstep
+            run_step = lambda: pstep.replay()[0]      # noqa: E731
+            for _ in range(2):
+                run_step()
+    elif not use_graph:
         for _ in range(args.warmup):
             step()
     else:
         if use_dist:
-            raise SystemExit('--graph is a single-GPU diagnostic')
+            raise SystemExit('--graph with --route autograd / --unfused is a single-GPU diagnostic')
         # every warm-up step on a non-default stream (torch.cuda.graph's own recipe), and no reference to an earlier step's autograd graph
         # left: the AccumulateGrad nodes of the parameters then belong to a capturable stream -- created under the legacy default stream
         # (and kept alive through last['scores']) they make hipStreamEndCapture fail
@@ -374,6 +404,17 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     roofline = None
+    prof_note = 'every %dth hooked launch of the timed region' % PROF_EVERY
+    if not prof and not args.no_prof and pstep is not None:
+        # the timed steps replayed HIP graphs, whose kernel nodes the event hook cannot bracket: the same step runs eagerly a few more
+        # times (untimed) with the hook on -- same kernels, same launch order, same buffers
+        prof = True
+        prof_note = 'every %dth hooked launch of 10 EAGER steps run right after the timed region (the timed steps replay HIP graphs)' % PROF_EVERY
+        _lib.check(lib.recnow_prof_enable(64 * 12), 'recnow_prof_enable')
+        _lib.check(lib.recnow_prof_sample_every(PROF_EVERY), 'recnow_prof_sample_every')
+        for _ in range(10):
+            step()
+        sync()
     if prof:                                 # collected and switched off HERE: the samples are launches of the timed steps only
         cnt = (ctypes.c_int * 16)()          # the library fills RN_TAG_MAX (= 9) entries
         ms = (ctypes.c_double * 16)()
@@ -416,7 +457,7 @@ def main():
             roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                         'frac': achieved / peak, 'traffic': traffic_tab.get(GEMM_TAGS[tag]), 'traffic_stale': stale,
                         'kernel': GEMM_TAGS[tag],
-                        'launches': cnt[tag], 'sampled': 'every %dth hooked launch of the timed region' % PROF_EVERY, 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
+                        'launches': cnt[tag], 'sampled': prof_note, 'avg_launch_us': ms[tag] * 1e3 / cnt[tag],
                         'algorithmic_flops_per_launch': fl[tag] / cnt[tag], 'algorithmic_bytes_per_launch': by[tag] / cnt[tag],
                         'all_gemm': {GEMM_TAGS[t]: {'launches': cnt[t], 'ms': ms[t],
                                                     'tflops': (fl[t] / (ms[t] * 1e-3) / 1e12) if ms[t] > 0 else None}
@@ -436,7 +477,7 @@ def main():
     # ---- parity step (untimed): same shapes and kernels, inputs scaled so that the scores are of O(1) ----------------------
     parity = None
     cpu = None
-    if world == 1 and graph is None and not args.no_input_grad:      # N > 1: the same kernels run, checked at N = 1
+    if world == 1 and (graph is None or pstep is not None) and not args.no_input_grad:      # N > 1: the same kernels run, checked at N = 1
         xq = (xd.detach() * CHECK_SCALE).requires_grad_(True)
         loss_q = step(xq)
         torch.cuda.synchronize()
@@ -444,7 +485,7 @@ def main():
         named['head.kernel'], named['head.bias'] = model.head.kernel, model.head.bias
         named_np = {k: v.detach().cpu().numpy() for k, v in named.items()}
         xq_np = x * np.float32(CHECK_SCALE)
-        sc_gpu, dx_gpu = last['scores'].detach().cpu().numpy(), xq.grad.cpu().numpy()
+        sc_gpu, dx_gpu = last['scores'].detach().cpu().numpy(), (last['dx'] if pstep is not None else xq.grad).cpu().numpy()
         if use_dist:          # the one-collective form runs the backward pass on the unnormalised loss sum: weight gradients are scaled
             dx_gpu = dx_gpu / (np.float32(last['n_pair'].item()) + np.float32(1e-10))      # in the reducer, dx (not a parameter) here
         parity = {'inputs': 'x * %g' % CHECK_SCALE, 'loss': float(loss_q.item()), 'tolerance': PARITY_TOL}
@@ -486,8 +527,9 @@ def main():
             'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
                                    'in-batch pairwise (logistic), global B=%d = %d rows on each of %d GPU(s), 64 fields x 16-dim, ~64 rows/group' % (rows * world, rows, world),
                        'rows_per_gpu': rows,
-                       'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(args.graph), 'parallelism': 'dp%d' % world,
-                       'route': 'fused node dcn_mix_score + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
+                       'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(use_graph), 'parallelism': 'dp%d' % world,
+                       'route': ('whole-step entry recnow_dcn_mix_step (one C call per phase, grouping on a side stream)' + (', replayed from HIP graphs' if use_graph else '')) if use_step else
+                                'fused node dcn_mix_score through autograd + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
                        'loss': float(loss.item()), 'host_enqueue_ms_per_step': host_ms,
                        'grads_copied_into_buckets': getattr(layerwise, 'last_foreign', None) if layerwise is not None else None},
             'roofline': roofline,

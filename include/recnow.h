@@ -393,6 +393,63 @@ int recnow_dcn_mix_score_bwd(const float* x, const float* const* U_host, const f
  * the dx recompute run on it concurrently with the data-gradient chain on `stream`, ordered by events created and
  * destroyed inside the call; on return all of stream2's work is ordered before later work submitted to `stream`. */
 
+/* The whole north-star step -- x -> L cross layers -> Dense(1) head -> in-batch pairwise (BPR) loss -> every gradient -- enqueued by
+ * ONE call per phase, on buffers the caller allocates once (at 8192 rows per GPU, the 8-GPU shard of the metric's batch,
+ * the ~60 launches of a step take less GPU time than a host framework needs to enqueue them one by one; a phase is one call, and,
+ * because nothing is allocated and no event of the library is recorded inside, each phase can be captured into a HIP graph and
+ * replayed).  Reference path: rec_now/layers/dcn_mix_layer.py:114-151 -> multi_dense_layer.py:80-94 ->
+ * rec_block/pairwise_loss_from_batch.py:228-279 (pairloss_func = bpr_loss_func, no occurrence weights, optional mask).
+ *
+ * phases (bit mask, executed in this order within one call):
+ *   RECNOW_STEP_GROUP     canonical keys + radix sort + segments of `groups` (score independent: may run on another stream,
+ *                         under the forward pass; order it before RECNOW_STEP_LOSS with an event);
+ *   RECNOW_STEP_FORWARD   recnow_dcn_mix_score_fwd -> scores;
+ *   RECNOW_STEP_LOSS      loss, n_pair, stats, d loss / d scores (normalised by 1 / (P + 1e-10) when reduce_mean, else the
+ *                         gradient of the loss SUM: a data-parallel caller divides by the global pair count after its all-reduce);
+ *   RECNOW_STEP_BACKWARD  recnow_dcn_mix_score_bwd for the cross layers layer_hi .. layer_lo (descending; the head's gradients
+ *                         belong to layer L-1).  A caller that all-reduces per layer issues one call (one graph) per layer.
+ * All of a step's phases must use the same descriptor contents and workspace.  Shapes: recnow_dcn_mix_score_supported. */
+#define RECNOW_STEP_GROUP 1
+#define RECNOW_STEP_FORWARD 2
+#define RECNOW_STEP_LOSS 4
+#define RECNOW_STEP_BACKWARD 8
+typedef struct recnow_dcn_mix_step_desc {
+    int64_t B;
+    int D, S, N, L;
+    int act_inner, act_outer;           /* RECNOW_ACT_* of the cross layers */
+    int group_dtype;                    /* RECNOW_KEY_* of `groups` */
+    int only_use_wrong_order_pair;      /* pairwise_loss(only_use_wrong_order_pair=...) */
+    int reduce_mean;                    /* 1: loss = sum / (P + 1e-10) (the reference's), 0: the sum */
+    float factor;                       /* bpr_loss_func(factor=...) */
+    const float* x;                     /* (B, D) */
+    const float* labels;                /* (B) */
+    const void* groups;                 /* (B) ids */
+    const uint8_t* mask;                /* (B) or NULL */
+    const float* const* U_host;         /* HOST arrays of L DEVICE pointers, as recnow_dcn_mix_fwd */
+    const float* const* V_host;
+    const float* const* W_host;
+    const float* const* bias_host;
+    const float* const* gate_host;
+    const float* head_w;                /* (D) */
+    const float* head_b;                /* (1) or NULL */
+    float* scores;                      /* out (B) */
+    float* loss;                        /* out (1) */
+    int64_t* n_pair;                    /* out (1) */
+    float* stats;                       /* out (2) or NULL: {loss as stored, (float) n_pair}, e.g. the tail of a gradient bucket */
+    float* dx;                          /* out (B, D) or NULL: x is data */
+    float* const* dU_host;              /* HOST arrays of L DEVICE pointers: the gradients */
+    float* const* dV_host;
+    float* const* dW_host;
+    float* const* dbias_host;
+    float* const* dgate_host;
+    float* dhead_w;                     /* out (D) */
+    float* dhead_b;                     /* out (1) or NULL */
+    void* ws;                           /* recnow_dcn_mix_step_workspace_bytes; holds the step's state between the phases */
+    size_t ws_bytes;
+} recnow_dcn_mix_step_desc;
+size_t recnow_dcn_mix_step_workspace_bytes(int64_t B, int D, int S, int N, int L, int group_dtype);
+int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* desc_host, int phases, int layer_hi, int layer_lo, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * CINLayer (xDeepFM Compressed Interaction Network): rec_now/layers/cin_layer.py:72-122
  *   X_k[b,d,c] = sum_{f,h} W_k[c, f*H_{k-1}+h] * x0[b,d,f] * X_{k-1}[b,d,h]   (X_0 = x0, H_0 = F)          (:103-109)

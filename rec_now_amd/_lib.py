@@ -66,6 +66,8 @@ SIGNATURES = {
     'recnow_dcn_mix_score_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P, _I]),
     'recnow_dcn_mix_score_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                                        _P, _P, _Z, _P, _P, _P]),
+    'recnow_dcn_mix_step_workspace_bytes': (_Z, [_L, _I, _I, _I, _I, _I]),
+    'recnow_dcn_mix_step': (_I, [_P, _I, _I, _I, _P]),
     'recnow_cin_saved_bytes': (_Z, [_L, _I, _I, _P, _I]),
     'recnow_cin_workspace_bytes': (_Z, [_L, _I, _I, _P, _I]),
     'recnow_cin_fwd': (_I, [_P, _P, _L, _I, _I, _P, _I, _I, _I, _P, _P, _Z, _P, _Z, _P]),
@@ -119,6 +121,21 @@ class GemmDesc(ctypes.Structure):
         ('E3', _P), ('lde3', _L), ('rv', _P), ('cv', _P), ('hv', _P), ('hp', _P), ('hp_ld', _I), ('hp_pad', _I), ('k_valid', _I), ('k_pad', _I), ('c_perm_s', _I), ('c_perm_pad', _I),
     ]
 
+ABI_VERSION = 3      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)
+
+class StepDesc(ctypes.Structure):
+    """recnow_dcn_mix_step_desc of include/recnow.h."""
+    _fields_ = [
+        ('B', _L), ('D', _I), ('S', _I), ('N', _I), ('L', _I), ('act_inner', _I), ('act_outer', _I), ('group_dtype', _I),
+        ('only_use_wrong_order_pair', _I), ('reduce_mean', _I), ('factor', _F),
+        ('x', _P), ('labels', _P), ('groups', _P), ('mask', _P),
+        ('U_host', _P), ('V_host', _P), ('W_host', _P), ('bias_host', _P), ('gate_host', _P), ('head_w', _P), ('head_b', _P),
+        ('scores', _P), ('loss', _P), ('n_pair', _P), ('stats', _P), ('dx', _P),
+        ('dU_host', _P), ('dV_host', _P), ('dW_host', _P), ('dbias_host', _P), ('dgate_host', _P), ('dhead_w', _P), ('dhead_b', _P),
+        ('ws', _P), ('ws_bytes', _Z),
+    ]
+
+
 _ERR = {-1: 'RECNOW_EINVAL', -2: 'RECNOW_EWORKSPACE', -3: 'RECNOW_EUNSUPPORTED'}
 _lib = None
 
@@ -132,6 +149,11 @@ def load():
                 'rec_now_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
+        lib.recnow_abi_version.restype = _I
+        have = lib.recnow_abi_version()
+        if have != ABI_VERSION:      # a stale build (or a foreign one through RECNOW_LIB_PATH) would take shifted arguments silently
+            raise RuntimeError('rec_now_amd: %s exports C ABI version %d, these bindings were written for version %d; rebuild it with '
+                               '`python -c "import __graft_entry__ as g; g.build()"`' % (LIB_PATH, have, ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError here = symbol missing from the .so
             fn.restype = res

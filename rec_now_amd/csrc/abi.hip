@@ -1,2 +1,5 @@
 #include "common.hpp"
-extern "C" int recnow_abi_version(void) { return 1; }
+// Bumped whenever an exported signature or recnow_gemm_desc changes incompatibly; rec_now_amd/_lib.py refuses a library whose
+// version differs from the one its SIGNATURES table was written for.  2: recnow_prof_collect (4 arrays), recnow_embed_pool_fwd
+// (V), recnow_gemm_desc (second outputs, side products); 3: recnow_dcn_mix_step, recnow_group_segments_status (round 3).
+extern "C" int recnow_abi_version(void) { return 3; }

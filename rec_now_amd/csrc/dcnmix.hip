@@ -144,6 +144,15 @@ static inline MixDims mix_dims(int64_t B, int D, int S, int N, int L) {
 }
 static inline size_t act_block(const MixDims& m) { return rn_align((size_t)m.B * m.LDT * sizeof(float)); }
 static inline size_t xbuf(const MixDims& m) { return rn_align((size_t)m.B * m.D * sizeof(float)); }
+#define MIX_PACK_MAX_L 8
+// exact path, L <= MIX_PACK_MAX_L: the packed weights of every layer -- Wc1_l = [U_l | K_l | 0] (D x LDT), Wc2_l = [W_l; b_l; 0]
+// (LDT x D) and one (LDT x D) block for the fused head's pre-scaled top-layer weights -- live at the end of `saved`: the forward
+// packs them ONCE per step (one launch) and the backward reads them there instead of packing again.
+static inline size_t mix_pack_one(const MixDims& m) { return rn_align((size_t)m.D * m.LDT * sizeof(float)); }
+static inline size_t mix_pack_bytes(const MixDims& m) { return (m.exact && m.L <= MIX_PACK_MAX_L) ? (size_t)(2 * m.L + 1) * mix_pack_one(m) : 0; }
+static inline size_t mix_pack_off(const MixDims& m) {       // byte offset of the pack region inside `saved`
+    return (size_t)m.L * 3 * act_block(m) + (size_t)(m.L - 1) * xbuf(m) + (m.exact ? (size_t)m.L * xbuf(m) : 0);
+}
 
 // saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D);
 // exact path: then O_0..O_{L-1} (B x D)
@@ -152,7 +161,7 @@ extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int
     const MixDims m = mix_dims(B, D, S, N, L);
     // exact path: O_l = T2g_l [W; b] of every layer is kept next to x_{l+1} = x * O_l (second output of GEMM3), so the
     // backward forms dx = sum_l g_l * O_l inside kernels that stream g_l anyway instead of recomputing the products.
-    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + 256;
+    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + mix_pack_bytes(m) + 256;
 }
 
 static size_t mix_gemm_ws(const MixDims& m) {
@@ -196,7 +205,6 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
 
 // One launch packs the weights of ALL layers (exact path): Wc1_l = [U_l | K_l | 0] (D x LDT) and, when Wc2 != NULL,
 // Wc2_l = [W_l; b_l; 0] (LDT x D).  Replaces 4 tiny launches per layer in front of every product.
-#define MIX_PACK_MAX_L 8
 struct MixPackPtrs {
     const float* U[MIX_PACK_MAX_L];
     const float* K[MIX_PACK_MAX_L];
@@ -204,10 +212,17 @@ struct MixPackPtrs {
     const float* b[MIX_PACK_MAX_L];
 };
 __global__ void __launch_bounds__(256)
-k_pack_all(MixPackPtrs p, int L, int D, int S, int N, int LDT, float* __restrict__ Wc1, float* __restrict__ Wc2) {
+k_pack_all(MixPackPtrs p, int L, int D, int S, int N, int LDT, float* __restrict__ Wc1, float* __restrict__ Wc2,
+           const float* __restrict__ wh, float* __restrict__ Wh) {
     const int NS = N * S, KC = NS + N;
-    const int64_t per = (int64_t)D * LDT, total = (int64_t)L * per * (Wc2 ? 2 : 1);
+    const int64_t per = (int64_t)D * LDT, packs = (int64_t)L * per * (Wc2 ? 2 : 1), total = packs + (Wh ? (int64_t)KC * D : 0);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i >= packs) {                                // fused scoring head: Wh[k][c] = [W; b]_{L-1}[k][c] * w_head[c]
+            const int64_t e = i - packs;
+            const int k = (int)(e / D), c = (int)(e % D);
+            Wh[e] = (k < NS ? p.W[L - 1][e] : p.b[L - 1][(int64_t)(k - NS) * D + c]) * wh[c];
+            continue;
+        }
         const int64_t j = i % ((int64_t)L * per);
         const int l = (int)(j / per);
         const int64_t e = j - (int64_t)l * per;
@@ -227,15 +242,15 @@ k_pack_all(MixPackPtrs p, int L, int D, int S, int N, int LDT, float* __restrict
     }
 }
 static int pack_all(const MixDims& m, const float* const* U_host, const float* const* W_host, const float* const* bias_host,
-                    const float* const* gate_host, float* Wc1_all, float* Wc2_all, hipStream_t st) {
+                    const float* const* gate_host, float* Wc1_all, float* Wc2_all, const float* head_w, float* Wh, hipStream_t st) {
     MixPackPtrs p;
     for (int l = 0; l < m.L; ++l) {
         p.U[l] = U_host[l]; p.K[l] = gate_host[l]; p.W[l] = W_host[l]; p.b[l] = bias_host[l];
     }
-    const int64_t total = (int64_t)m.L * m.D * m.LDT * (Wc2_all ? 2 : 1);
+    const int64_t total = (int64_t)m.L * m.D * m.LDT * (Wc2_all ? 2 : 1) + (Wh ? (int64_t)m.KC * m.D : 0);
     int g = rn_cdiv(total, 256);
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_pack_all, g, 256, 0, st, p, m.L, m.D, m.S, m.N, m.LDT, Wc1_all, Wc2_all);
+    hipLaunchKernelGGL(k_pack_all, g, 256, 0, st, p, m.L, m.D, m.S, m.N, m.LDT, Wc1_all, Wc2_all, head_w, head_w ? Wh : nullptr);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -337,16 +352,6 @@ k_head_scores(const float* __restrict__ hp, int np, const float* __restrict__ bi
         scores[m] = s;
     }
 }
-// Wh[k][c] = W[k][c] * wh[c] (k < NS), Wh[NS + n][c] = bias[n][c] * wh[c]
-__global__ void __launch_bounds__(256)
-k_head_scale_w(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ wh, int NS, int N, int D,
-               float* __restrict__ Wh) {
-    const int64_t total = (int64_t)(NS + N) * D;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int k = (int)(i / D), c = (int)(i % D);
-        Wh[i] = (k < NS ? W[i] : bias[(int64_t)(k - NS) * D + c]) * wh[c];
-    }
-}
 // out[m][:] = rs[m] * in[m][:]   (B x LD, float4)
 __global__ void __launch_bounds__(256)
 k_row_scale(const float* __restrict__ in, const float* __restrict__ rs, int64_t B, int LD, float* __restrict__ out) {
@@ -363,7 +368,8 @@ k_row_scale(const float* __restrict__ in, const float* __restrict__ rs, int64_t 
 // stride of 8 (coalesced 128-byte row pieces) and their partial sums are added in a fixed order.
 __global__ void __launch_bounds__(256)
 k_head_post(float* __restrict__ Mw, float* __restrict__ Mb, const float* __restrict__ W, const float* __restrict__ bias,
-            const float* __restrict__ wh, int NS, int N, int D, float* __restrict__ dwh) {
+            const float* __restrict__ wh, int NS, int N, int D, float* __restrict__ dwh, const float* __restrict__ ds_part, int n_part,
+            float* __restrict__ dhb) {
     __shared__ float part[8][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
     float s = 0.f;
@@ -384,6 +390,15 @@ k_head_post(float* __restrict__ Mw, float* __restrict__ Mb, const float* __restr
 #pragma unroll
         for (int r = 0; r < 8; ++r) t += part[r][threadIdx.x & 31];
         dwh[c] = t;
+    }
+    // recnow_dcn_mix_step: d head bias = sum of dscores, from the per-workgroup partial sums its loss stage left (fixed order: thread
+    // t sums partials t, t + 256, ..; then a fixed tree)
+    if (dhb && blockIdx.x == 0) {
+        __shared__ float red[16];
+        float t = 0.f;
+        for (int i = threadIdx.x; i < n_part; i += 256) t += ds_part[i];
+        t = block_sum<float>(t, red);
+        if (threadIdx.x == 0) dhb[0] = t;
     }
 }
 // dx[m][c] = ds[m] * wh[c] * O[m][c]   (single cross layer under a fused head: the only term that is not a product)
@@ -429,16 +444,17 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     c.take<float>((size_t)m.LDT * D);
     float* hp = c.take<float>(3 * act_block(m) / sizeof(float));      // forward: free -> the head's row-dot partials (B x 2D/128)
     c.take<float>(2 * xbuf(m) / sizeof(float));
-    const bool pack_once = m.exact && L <= MIX_PACK_MAX_L;          // all layers' packed weights in one launch
-    float* Wc1_all = pack_once ? c.take<float>((size_t)L * D * m.LDT) : nullptr;
-    float* Wc2_all = pack_once ? c.take<float>((size_t)L * m.LDT * D) : nullptr;
+    const bool pack_once = m.exact && L <= MIX_PACK_MAX_L;          // all layers' packed weights in one launch, kept in `saved` for the backward
+    char* sv = (char*)saved;
+    float* Wc1_all = pack_once ? (float*)(sv + mix_pack_off(m)) : nullptr;
+    float* Wc2_all = pack_once ? Wc1_all + (size_t)L * D * m.LDT : nullptr;
+    float* Wh_saved = pack_once ? Wc2_all + (size_t)L * m.LDT * D : nullptr;      // fused head: [W; b]_{L-1} * w_head for the backward
     void* gws = c.base + c.off;
     const size_t gws_bytes = ws_bytes - c.off;
-    char* sv = (char*)saved;
     float* xmid = (float*)(sv + (size_t)L * 3 * act_block(m));
     float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));        // exact path only
     int rc;
-    if (pack_once && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, st))) return rc;
+    if (pack_once && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st))) return rc;
     const float* xl = x;
     for (int l = 0; l < L; ++l) {
         float* T1 = (float*)(sv + (size_t)(3 * l) * act_block(m));
@@ -570,16 +586,23 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
                             const float* dy, const char* sv, int act_inner, int act_outer, float* dx, float* const* dU_host,
                             float* const* dV_host, float* const* dW_host, float* const* dbias_host, float* const* dgate_host,
                             void* ws, size_t ws_bytes, hipStream_t st, hipStream_t st2, const MixHeadGrad* hd = nullptr,
-                            void* const* layer_events = nullptr) {
+                            void* const* layer_events = nullptr, int l_hi = -1, int l_lo = 0, const float* T2g_ds_ready = nullptr,
+                            const float* ds_part = nullptr, int ds_nparts = 0) {
+    // l_hi .. l_lo (descending, default: all layers): the backward of a sub-range of the layers, so that a caller can cut the pass
+    // into pieces (one HIP graph per piece, a gradient all-reduce launched in between).  The pieces share `ws`: the gradient that
+    // flows from layer l + 1 into layer l sits in the ping-pong buffer the full pass would have used.
     const int64_t B = m.B;
     const int D = m.D, S = m.S, N = m.N, L = m.L;
+    if (l_hi < 0) l_hi = L - 1;
+    if (l_lo < 0 || l_lo > l_hi || l_hi > L - 1) return RECNOW_EINVAL;
+    const bool top = l_hi == L - 1;
     const bool two = st2 != nullptr && st2 != st;
     if (!two) st2 = st;
     // RECNOW_TWO_STREAMS=2 ("paired"): BOTH weight-gradient products of a layer (MFMA-bound) are held back until the sub-space
     // backward is done, so that they run beside the layer's dx product (HBM-bound) instead of beside the MFMA-bound dT2g product
     static const bool paired = []() { const char* e = getenv("RECNOW_TWO_STREAMS"); return e && e[0] == '2'; }();
     RnCarver c(ws, ws_bytes);
-    float* Wc1_all = c.take<float>((size_t)L * D * m.LDT);        // per-layer packs: the side stream reads them later
+    float* Wc1_all = c.take<float>((size_t)L * D * m.LDT);        // per-layer packs (L > MIX_PACK_MAX_L only: otherwise the forward's, in `saved`)
     float* dWc1 = c.take<float>((size_t)D * m.LDT);
     float* dT2g = c.take<float>(act_block(m) / sizeof(float));
     float* dC = c.take<float>(act_block(m) / sizeof(float));
@@ -598,9 +621,11 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     const float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));
     MixEvents evs;
     int rc;
-    if (L <= MIX_PACK_MAX_L) {             // [U | K | 0] of every layer in one launch (W and bias are used in place)
-        if ((rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, nullptr, st))) return rc;
-    } else {
+    const float* Wh = nullptr;         // fused head: [W * w_head; bias * w_head] of the top layer, packed by the forward
+    if (L <= MIX_PACK_MAX_L) {         // [U | K | 0] of every layer: packed ONCE per step by the forward, kept behind the activations in `saved`
+        Wc1_all = (float*)(sv + mix_pack_off(m));
+        Wh = Wc1_all + (size_t)2 * L * D * m.LDT;
+    } else if (top) {
         int pgw = rn_cdiv((int64_t)D * m.LDT, 256);
         if (pgw > 2048) pgw = 2048;
         for (int l = 0; l < L; ++l) {
@@ -608,15 +633,16 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             RN_LAUNCH_CHECK();
         }
     }
-    float* Wh = dWc1;                  // fused head: [W * w_head; bias * w_head] of the top layer ((NS+N) x D <= D x LDT floats), consumed
-                                       // by the top dT2g product before this layer's dU product overwrites the buffer
-    float* T2g_ds = dC;                // fused head: dscore * T2g of the top layer (dC is scratch of the unfused sub-space route only)
-    if (hd) {
+    const float* T2g_ds = dC;          // fused head: dscore * T2g of the top layer (dC is scratch of the unfused sub-space route only)
+    if (hd && top) {
         const float* T2g_top = (const float*)(sv + (size_t)(3 * (L - 1) + 2) * act_block(m));
-        hipLaunchKernelGGL(k_head_scale_w, ew_grid((int64_t)m.KC * D), 256, 0, st, W_host[L - 1], bias_host[L - 1], hd->w, m.NS, N, D, Wh);
-        hipLaunchKernelGGL(k_row_scale, ew_grid(B * (m.LDT / 4)), 256, 0, st, T2g_top, hd->dscores, B, m.LDT, T2g_ds);
-        RN_LAUNCH_CHECK();
-        if (hd->db && (rc = rn_colsum(hd->dscores, nullptr, 0, 0, B, 1, 1, hd->db, 0, cs_ws, cs_ws_bytes, st))) return rc;
+        if (T2g_ds_ready) {            // the caller's loss stage has already formed dscore * T2g_top and d bias = sum of dscores (recnow_dcn_mix_step)
+            T2g_ds = T2g_ds_ready;
+        } else {
+            hipLaunchKernelGGL(k_row_scale, ew_grid(B * (m.LDT / 4)), 256, 0, st, T2g_top, hd->dscores, B, m.LDT, dC);
+            RN_LAUNCH_CHECK();
+            if (hd->db && (rc = rn_colsum(hd->dscores, nullptr, 0, 0, B, 1, 1, hd->db, 0, cs_ws, cs_ws_bytes, st))) return rc;
+        }
         if (dx && L == 1) {            // a single cross layer: its dx product accumulates on top of the head's term
             hipLaunchKernelGGL(k_head_dx_top, ew_grid(B * (D / 4)), 256, 0, st, omid, hd->dscores, hd->w, B, D, dx);
             RN_LAUNCH_CHECK();
@@ -625,10 +651,10 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     hipEvent_t e_g = nullptr;        // "g of this layer (and the packs) are ready" -> side stream may start the layer
     MIX_SIGNAL(e_g, st);
     hipEvent_t e_side_prev = nullptr;   // side stream finished the previous (higher) layer: dT1/dC/g buffers reusable
-    const float* g = dy;
+    const float* g = top ? dy : (((l_hi + 1) & 1) ? gbuf0 : gbuf1);      // a lower piece starts from the buffer layer l_hi + 1 wrote
     int pg = rn_cdiv((int64_t)D * m.NS, 256);
     if (pg > 2048) pg = 2048;
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = l_hi; l >= l_lo; --l) {
         const float* T1 = (const float*)(sv + (size_t)(3 * l) * act_block(m));
         const float* T2 = (const float*)(sv + (size_t)(3 * l + 1) * act_block(m));
         const float* T2g = (const float*)(sv + (size_t)(3 * l + 2) * act_block(m));
@@ -652,7 +678,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.sp_bx = d.B + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
             if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
             if (top_head) {      // dW = w_head * M^T, dbias likewise, d w_head = sum_k [W; b] * M^T
-                hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw);
+                hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw,
+                                   ds_part, ds_nparts, ds_part ? hd->db : nullptr);
                 RN_LAUNCH_CHECK();
             }
             return RECNOW_OK;
@@ -889,4 +916,140 @@ extern "C" int recnow_dcn_mix_score_bwd(const float* x, const float* const* U_ho
     return dcnmix_bwd_exact(m, x, U_host, V_host, W_host, bias_host, gate_host, nullptr, (const char*)saved, act_inner, act_outer, dx,
                             dU_host, dV_host, dW_host, dbias_host, dgate_host, ws, ws_bytes, st, (hipStream_t)stream2, &hd,
                             layer_events_host);
+}
+
+
+// ---- the north-star step, one call per phase (include/recnow.h: recnow_dcn_mix_step) -------------------------------------------
+#define STEP_ROWS 64          // rows per workgroup of the loss stage's gradient kernel
+struct StepWs {
+    void* saved; size_t saved_bytes;
+    void* mix; size_t mix_bytes;
+    uint32_t* words; uint8_t* solo;
+    int32_t *order, *seg_id, *seg_first, *super_id, *n_seg;
+    void* grp; size_t grp_bytes;
+    void* pair; size_t pair_bytes;
+    float *dsu, *ds, *T2g_ds, *ds_part;
+    int n_words;
+    size_t total;
+    bool ok;
+};
+static StepWs step_carve(void* ws, size_t ws_bytes, int64_t B, int D, int S, int N, int L, int group_dtype) {
+    StepWs w;
+    const MixDims m = mix_dims(B, D, S, N, L);
+    RnCarver c(ws, ws_bytes);
+    w.n_words = recnow_key_words(group_dtype);
+    if (w.n_words < 1) w.n_words = 1;
+    w.saved_bytes = recnow_dcn_mix_saved_bytes(B, D, S, N, L);
+    w.saved = c.take<char>(w.saved_bytes);
+    w.mix_bytes = recnow_dcn_mix_workspace_bytes(B, D, S, N, L);
+    w.mix = c.take<char>(w.mix_bytes);
+    w.words = c.take<uint32_t>((size_t)w.n_words * B);
+    w.solo = c.take<uint8_t>(B);
+    w.order = c.take<int32_t>(B);
+    w.seg_id = c.take<int32_t>(B);
+    w.seg_first = c.take<int32_t>(B + 1);
+    w.super_id = c.take<int32_t>(B);
+    w.n_seg = c.take<int32_t>(2);
+    w.grp_bytes = recnow_group_segments_workspace_bytes(B, w.n_words);
+    w.grp = c.take<char>(w.grp_bytes);
+    w.pair_bytes = recnow_pairwise_workspace_bytes(B);
+    w.pair = c.take<char>(w.pair_bytes);
+    w.dsu = c.take<float>(B);
+    w.ds = c.take<float>(B);
+    w.T2g_ds = c.take<float>(act_block(m) / sizeof(float));
+    w.ds_part = c.take<float>(rn_cdiv(B, STEP_ROWS));
+    w.total = c.off;
+    w.ok = c.ok();
+    return w;
+}
+extern "C" size_t recnow_dcn_mix_step_workspace_bytes(int64_t B, int D, int S, int N, int L, int group_dtype) {
+    if (B <= 0 || D <= 0 || S <= 0 || N <= 0 || L <= 0) return 256;
+    return step_carve(nullptr, 0, B, D, S, N, L, group_dtype).total + 256;      // a carve of a null base only adds up the sizes
+}
+
+// Loss stage, last kernel: ds = d(loss)/d(scores) from the unnormalised pair gradients (x 1 / (P + eps) when the loss is the mean);
+// the top layer's dscore * T2g (the row-scaled small operand of the fused head's weight gradient) for the same rows; the
+// workgroup's partial sum of ds (d head bias, joined by k_head_post); {loss, (float) P} for the caller's statistics.
+__global__ void __launch_bounds__(256)
+k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restrict__ n_pair, int reduce_mean, float eps, int64_t B,
+              const float* __restrict__ T2g_top, int LDT, float* __restrict__ ds, float* __restrict__ T2g_ds, float* __restrict__ ds_part,
+              const float* __restrict__ loss, float* __restrict__ stats) {
+    __shared__ float sds[STEP_ROWS];
+    const float P = (float)(*n_pair);
+    const float sc = reduce_mean ? 1.f / (P + eps) : 1.f;
+    const int64_t r0 = (int64_t)blockIdx.x * STEP_ROWS;
+    if (threadIdx.x < STEP_ROWS) {            // one wave
+        const int64_t r = r0 + threadIdx.x;
+        const float v = r < B ? dsu[r] * sc : 0.f;
+        if (r < B) ds[r] = v;
+        sds[threadIdx.x] = v;
+        const float t = wave_sum(v);
+        if (threadIdx.x == 0) ds_part[blockIdx.x] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) { stats[0] = loss[0]; stats[1] = P; }
+    __syncthreads();
+    const int q = LDT / 4;
+    for (int i = threadIdx.x; i < STEP_ROWS * q; i += 256) {
+        const int rl = i / q, c4 = i % q;
+        const int64_t r = r0 + rl;
+        if (r < B) {
+            float4 v = reinterpret_cast<const float4*>(T2g_top + r * LDT)[c4];
+            const float s = sds[rl];
+            v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+            reinterpret_cast<float4*>(T2g_ds + r * LDT)[c4] = v;
+        }
+    }
+}
+
+extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases, int layer_hi, int layer_lo, void* stream) {
+    if (!d || d->B < 0 || d->D < 1 || d->S < 1 || d->N < 1 || d->L < 1 || d->B > 0x7fffffffll) return RECNOW_EINVAL;
+    if (phases & ~(RECNOW_STEP_GROUP | RECNOW_STEP_FORWARD | RECNOW_STEP_LOSS | RECNOW_STEP_BACKWARD)) return RECNOW_EINVAL;
+    if (d->B == 0 || !recnow_dcn_mix_score_supported(d->B, d->D, d->S, d->N, d->L)) return RECNOW_EUNSUPPORTED;
+    if (recnow_key_words(d->group_dtype) < 1) return RECNOW_EINVAL;
+    if (!d->ws || d->ws_bytes < recnow_dcn_mix_step_workspace_bytes(d->B, d->D, d->S, d->N, d->L, d->group_dtype)) return RECNOW_EWORKSPACE;
+    const int64_t B = d->B;
+    const int D = d->D, S = d->S, N = d->N, L = d->L;
+    const StepWs w = step_carve(d->ws, d->ws_bytes, B, D, S, N, L, d->group_dtype);
+    if (!w.ok) return RECNOW_EWORKSPACE;
+    const MixDims m = mix_dims(B, D, S, N, L);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (phases & RECNOW_STEP_GROUP) {
+        if (!d->groups) return RECNOW_EINVAL;
+        RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
+        if ((rc = recnow_group_keys(d->groups, d->group_dtype, B, w.words, w.solo, stream))) return rc;
+        if ((rc = recnow_group_segments(w.words, w.solo, B, w.n_words, w.n_words, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp,
+                                        w.grp_bytes, stream)))
+            return rc;
+    }
+    if (phases & RECNOW_STEP_FORWARD) {
+        if (!d->scores) return RECNOW_EINVAL;
+        if ((rc = recnow_dcn_mix_score_fwd(d->x, d->U_host, d->V_host, d->W_host, d->bias_host, d->gate_host, d->head_w, d->head_b, B, D, S, N, L,
+                                           d->act_inner, d->act_outer, d->scores, w.saved, w.saved_bytes, w.mix, w.mix_bytes, stream,
+                                           d->dx ? 1 : 0)))
+            return rc;
+    }
+    if (phases & RECNOW_STEP_LOSS) {
+        if (!d->scores || !d->labels || !d->loss || !d->n_pair) return RECNOW_EINVAL;
+        const int flags = RECNOW_PAIR_LABEL_GT | (d->only_use_wrong_order_pair ? RECNOW_PAIR_WRONG_ORDER : 0);
+        if ((rc = recnow_pair_bpr_onepass(d->scores, d->labels, d->mask, w.order, w.seg_id, w.seg_first, B, flags, d->factor, d->reduce_mean,
+                                          d->loss, w.dsu, d->n_pair, w.pair, w.pair_bytes, stream)))
+            return rc;
+        const float* T2g_top = (const float*)((const char*)w.saved + (size_t)(3 * (L - 1) + 2) * act_block(m));
+        hipLaunchKernelGGL(k_step_dscore, rn_cdiv(B, STEP_ROWS), 256, 0, st, w.dsu, (const unsigned long long*)d->n_pair, d->reduce_mean, 1.0e-10f, B,
+                           T2g_top, m.LDT, w.ds, w.T2g_ds, w.ds_part, d->loss, d->stats);
+        RN_LAUNCH_CHECK();
+    }
+    if (phases & RECNOW_STEP_BACKWARD) {
+        if (!d->x || !d->U_host || !d->V_host || !d->W_host || !d->bias_host || !d->gate_host || !d->head_w || !d->dU_host || !d->dV_host ||
+            !d->dW_host || !d->dbias_host || !d->dgate_host || !d->dhead_w)
+            return RECNOW_EINVAL;
+        MixHeadGrad hd;
+        hd.w = d->head_w; hd.dscores = w.ds; hd.dw = d->dhead_w; hd.db = d->dhead_b;
+        if ((rc = dcnmix_bwd_exact(m, d->x, d->U_host, d->V_host, d->W_host, d->bias_host, d->gate_host, nullptr, (const char*)w.saved,
+                                   d->act_inner, d->act_outer, d->dx, d->dU_host, d->dV_host, d->dW_host, d->dbias_host, d->dgate_host, w.mix,
+                                   w.mix_bytes, st, nullptr, &hd, nullptr, layer_hi, layer_lo, w.T2g_ds, w.ds_part, rn_cdiv(B, STEP_ROWS))))
+            return rc;
+    }
+    return RECNOW_OK;
 }

@@ -713,8 +713,24 @@ extern "C" int recnow_occurance_power_weight(const int32_t* order, const int32_t
 // stable sort, segments AND the packed member records + cleared counters that recnow_pair_count / recnow_pair_bpr_fwdbwd expect
 // when called with RECNOW_PAIR_MEMBERS_PACKED on the same workspace.  Equivalent to recnow_group_keys + recnow_group_segments +
 // the packing pass of recnow_pair_count.
+// The single workgroup needs ps_lds_bytes() (~139 KB) of dynamic LDS: asked of the device once (a partition or a part with less LDS
+// per workgroup answers 0 here and the callers take the general route), and the kernel's LDS limit is raised once, not per call.
+static bool pack_small_lds_ok() {
+    static int cached[64];      // 0 = not asked, 1 = fits, 2 = does not
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!cached[dev]) {
+        // raising the kernel's dynamic-LDS limit IS the query: the runtime refuses a size above what a workgroup of this device
+        // may own (the device attribute only reports the 64 KB default limit)
+        const bool ok = hipFuncSetAttribute((const void*)k_group_pack_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps_lds_bytes()) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        cached[dev] = ok ? 1 : 2;
+    }
+    return cached[dev] == 1;
+}
 extern "C" int recnow_pairwise_small_supported(int64_t B, int key_dtype) {
-    return (B >= 0 && B <= GS_MAXB && (key_dtype == RECNOW_KEY_F32 || key_dtype == RECNOW_KEY_I32)) ? 1 : 0;
+    if (!(B >= 0 && B <= GS_MAXB && (key_dtype == RECNOW_KEY_F32 || key_dtype == RECNOW_KEY_I32))) return 0;
+    return (B == 0 || pack_small_lds_ok()) ? 1 : 0;
 }
 extern "C" int recnow_group_pack_small(const void* groups, int key_dtype, const float* labels, const float* scores,
                                        const uint8_t* mask, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first,
@@ -731,8 +747,7 @@ extern "C" int recnow_group_pack_small(const void* groups, int key_dtype, const 
     if (!groups || !labels || !scores || !order || !seg_id || !super_id || !cnt_super || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
     const PairWs pw = pair_ws(ws, ws_bytes, B);
-    const size_t lds = ps_lds_bytes();
-    RN_HIP(hipFuncSetAttribute((const void*)k_group_pack_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = ps_lds_bytes();            // the limit was raised by recnow_pairwise_small_supported above
     hipLaunchKernelGGL(k_group_pack_small, 1, GS_T, lds, st, groups, key_dtype, labels, scores, mask, (int)B, order, seg_id, seg_first,
                        super_id, n_seg, pw.mem, (unsigned long long*)cnt_super, (unsigned long long*)n_pair);
     RN_LAUNCH_CHECK();

@@ -403,8 +403,9 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
 // counts | ids.  2 + 2 * (non-trivial digits) barriers of ~5 us each (MI355X_MICROARCH.md, barrier-counter row).
 // Barrier = the guide's R1 hand-off: every wave drains its stores, workgroup barrier, lane 0: agent-scope release, arrive on one
 // monotonic counter, relaxed agent-scope poll, agent-scope acquire, workgroup barrier, plain loads.  The poll is bounded (2 s):
-// on a timeout the error word is set, every later barrier returns at once and the host reports RECNOW_EINVAL -- the grid always
-// drains.
+// on a timeout the error word is set, every later barrier returns at once, the kernel leaves the identity grouping (every row
+// its own group: consumers stay in bounds) and n_seg = -1 -- the grid always drains.  The host only takes this route when
+// `gm_max_coresident()` says all workgroups fit on the device at once.
 // ------------------------------------------------------------------------------------------------
 #define GM_MAXG 256
 struct GroupMidCtl {          // zeroed by the host before the launch
@@ -706,6 +707,20 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         allh += a;
         alls += c;
     }
+    // a barrier timed out (the workgroups were not co-resident: the host gates this route on the occupancy query, so this is a
+    // last line of defence): every workgroup sees the error word behind the last barrier and leaves a SAFE grouping instead of
+    // half-written arrays -- every row its own group (no pairs, in-bounds walks for every consumer) -- and n_seg = -1, which
+    // `Segments.num_segments()` and `recnow_group_segments_status` report.
+    const bool bad = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (bad) {
+        for (int q = 0; q < 8; ++q) {
+            const int64_t k = k0 + q;
+            if (k >= B) break;
+            order[k] = (int32_t)k; seg_id[k] = (int32_t)k; seg_first[k] = (int32_t)k; super_id[k] = (int32_t)k;
+        }
+        if (g == 0 && tid == 0) { seg_first[B] = (int32_t)B; n_seg[0] = -1; n_seg[1] = -1; }
+        return;
+    }
     int sid = preh + offh, sup = pres + offs;                 // ids of the LAST head before this thread's first position, + 1
     for (int q = 0; q < 8; ++q) {
         const int64_t k = k0 + q;
@@ -716,11 +731,29 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         super_id[k] = sup - 1;
     }
     if (g == 0 && tid == 0) {
-        const bool bad = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;       // a barrier timed out
         seg_first[allh] = (int32_t)B;
-        n_seg[0] = bad ? -1 : allh;
-        n_seg[1] = bad ? -1 : alls;
+        n_seg[0] = allh;
+        n_seg[1] = alls;
     }
+}
+
+// Largest grid of k_group_mid whose workgroups are all resident at once on the CURRENT device: occupancy x compute units, queried
+// once per device (a CU mask, a smaller partition (CPX) or a register-hungrier build all show up here).  The hand-rolled grid
+// barrier is only correct below it; anything larger takes the multi-launch chain.
+static int gm_max_coresident() {
+    static int cached[64];
+    static bool have[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!have[dev]) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_group_mid, 256, 0) != hipSuccess) per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        // one workgroup per CU is what the route counts on (the step's GEMMs hold the other slots)
+        cached[dev] = per_cu > 0 ? cus : 0;
+        have[dev] = true;
+    }
+    return cached[dev];
 }
 
 extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) {
@@ -752,7 +785,13 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     if (!words || !solo || !order || !seg_id || !super_id || !ws) return RECNOW_EINVAL;
     if (ws_bytes < recnow_group_segments_workspace_bytes(B, n_words)) return RECNOW_EWORKSPACE;
     if (B <= GS_MAXB && n_words == 1) {           // small batch, one key word: everything in one workgroup
-        RN_HIP(hipFuncSetAttribute((const void*)k_group_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+        static bool lds_raised[64];      // per device, once (not a stream operation: kept out of every later call and of stream captures)
+        int dev = 0;
+        RN_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !lds_raised[dev]) {
+            RN_HIP(hipFuncSetAttribute((const void*)k_group_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+            if (dev >= 0 && dev < 64) lds_raised[dev] = true;
+        }
         hipLaunchKernelGGL(k_group_small, 1, GS_T, gs_lds_bytes(), st, words, solo, (int)B, order, seg_id, seg_first, super_id, n_seg);
         RN_LAUNCH_CHECK();
         return RECNOW_OK;
@@ -771,7 +810,7 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     int32_t* shead = c.take<int32_t>(B + 1);
     int32_t* seg_incl = c.take<int32_t>(B + 1);
     int32_t* super_incl = c.take<int32_t>(B + 1);
-    if (coop && nblk <= GM_MAXG) {                // one cooperative launch: all nblk workgroups are co-resident (<= one per CU)
+    if (coop && nblk <= GM_MAXG && nblk <= gm_max_coresident()) {      // one cooperative launch: all nblk workgroups are co-resident (<= one per CU)
         const size_t scan_bytes = rn_scan_ws_bytes(B);
         char* tail = c.base + c.off + scan_bytes;
         GroupMidCtl* ctl = (GroupMidCtl*)tail;

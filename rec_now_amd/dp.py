@@ -161,7 +161,13 @@ class LayerwiseReducer(object):
     side stream wait for event i, all-reduce bucket i and scale it -- while the main stream is still executing the backward of
     the stages below.  The two loss statistics ride in the FIRST bucket (they are known before the backward pass starts), so
     every later bucket is multiplied by 1 / (P_global + eps) as soon as its own collective has finished.  Works without a
-    process group (scaling only).  Returns (global mean loss, P_global) as 0-dim tensors."""
+    process group (scaling only).  Returns (global mean loss, P_global) as 0-dim tensors.
+
+    Gradient contract: after a step `p.grad` IS a view of the bucket.  The usual loop (`p.grad = None` / `zero_grad(set_to_none=
+    True)` before the next backward) lets the next backward write the bucket in place.  When a gradient is still alive at the next
+    forward (gradient accumulation), `fused.dcn_mix_score` gives that parameter a fresh gradient tensor instead, autograd adds it
+    to the live `p.grad` (= the bucket view), and `reduce` all-reduces the accumulated sum -- note that `reduce` scales the whole
+    bucket by 1 / (P_global + eps) each time it runs, so accumulate with ONE `reduce` at the end of the accumulation window."""
 
     def __init__(self, stages, events, device):
         self.stages = [[p for p in stage if p.requires_grad] for stage in stages]
@@ -183,6 +189,49 @@ class LayerwiseReducer(object):
     def buffer_of(self, param):
         """The slice of its stage's flat bucket that holds `param`'s gradient (1-D view), or None for a foreign parameter."""
         return self._view.get(id(param))
+
+    # ---- in-place protocol of step.DCNMixPairwiseStep: gradients AND statistics are produced inside the buckets ---------------
+    def stats_slot(self):
+        """The two floats behind the first bucket's gradients: {local loss sum, local pair count} are written there by the step's
+        loss stage (`recnow_dcn_mix_step_desc.stats`), so they ride in the first collective without a packing kernel."""
+        return self._flat[0][-2:]
+
+    def stage_done(self, i, eps=SMALL_POSIVITE_FLOAT):
+        """Every gradient of stage i (and, for i == 0, the statistics) has been ENQUEUED on the current stream: mark that point and
+        enqueue the stage's all-reduce + 1 / (P_global + eps) scaling on the communication stream.  The current stream is not made to
+        wait: the backward of the stages below keeps running under the collective."""
+        flat = self._flat[i]
+        n_grad = flat.numel() - (2 if i == 0 else 0)
+        stats = self._flat[0][-2:]
+        if self.comm is None:                       # CPU tensors (gloo tests): in order on the host
+            if is_dist() and not _SKIP_COLLECTIVE:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat[:n_grad].mul_(1.0 / (stats[1] + eps))
+            if i == 0:
+                self._result = torch.stack([stats[0] / (stats[1] + eps), stats[1]])
+            return
+        from . import _lib
+        main = torch.cuda.current_stream()
+        ev = self.events[i]
+        _lib.call('recnow_event_record', ev.handle, _lib._P(main.cuda_stream))
+        ev.wait(self.comm)
+        if getattr(self, '_result', None) is None or not self._result.is_cuda:
+            self._result = torch.empty(2, dtype=torch.float32, device=flat.device)
+        if is_dist() and not _SKIP_COLLECTIVE:
+            torch.cuda.set_stream(self.comm)        # (the context manager costs ~40 us of host time per use)
+            try:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            finally:
+                torch.cuda.set_stream(main)
+        _lib.call('recnow_scale_by_inv_count', _lib.ptr(flat), n_grad, _lib.ptr(stats[1:]), float(eps), _lib.ptr(stats) if i == 0 else None,
+                  _lib.ptr(self._result) if i == 0 else None, _lib._P(self.comm.cuda_stream))
+
+    def reduce_in_place(self):
+        """After the last `stage_done`: the current stream waits for the communication stream (the gradients are final for whatever
+        comes next).  Returns (global mean loss, P_global) as 0-dim device tensors."""
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        return self._result[0], self._result[1]
 
     def prepare(self, local_loss_sum, local_count):
         """Call BEFORE `local_loss_sum.backward()`: packs the two loss statistics on the current stream and marks that point, so

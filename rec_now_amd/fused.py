@@ -126,5 +126,12 @@ def dcn_mix_score(cross, head, x, layer_events=None, grad_buffers=None):
         return head(cross(x)).reshape(-1)
     params = (list(cross.origin_to_sub_kernels) + list(cross.sub_to_sub_kernels) + list(cross.sub_to_origin_kernels)
               + list(cross.biases) + [g.kernel for g in cross.gate_layers])
+    if grad_buffers is not None:
+        # A parameter whose .grad still IS its buffer (gradient accumulation: a second backward without `p.grad = None` in between)
+        # must not have that storage overwritten by this pass before autograd adds the new gradient to it: such a parameter gets a
+        # fresh gradient tensor (autograd then accumulates into the bucket view, dp.LayerwiseReducer.reduce sees it as in place).
+        owners = [head.kernel, head.bias] + params
+        grad_buffers = [None if (b is not None and p is not None and p.grad is not None and p.grad.data_ptr() == b.data_ptr()) else b
+                        for p, b in zip(owners, grad_buffers)]
     return DCNMixScoreFunction.apply(x, head.kernel, head.bias, cross.num_layer, cross._act_inner, cross._act_outer, layer_events,
                                      grad_buffers, *params)

@@ -37,8 +37,13 @@ class Segments(object):
     __slots__ = ('B', 'device', 'order', 'seg_id', 'seg_first', 'super_id', 'n_seg')
 
     def num_segments(self):
-        """Host-synchronising read of the number of groups."""
-        return int(self.n_seg[0].item())
+        """Host-synchronising read of the number of groups.  Raises if the single-launch grouping kernel reported a grid-barrier
+        time-out (n_seg = -1; it leaves the identity grouping behind, so nothing downstream walks out of bounds)."""
+        n = int(self.n_seg[0].item())
+        if n < 0:
+            raise RuntimeError('rec_now_amd: the cooperative grouping kernel timed out at a grid barrier (workgroups not co-resident); '
+                               'set RECNOW_GROUP_COOP=0 to use the multi-launch route')
+        return n
 
 
 def build_segments(groups):

@@ -1,0 +1,168 @@
+"""The north-star training step as phases of ONE C entry point (`recnow_dcn_mix_step`, include/recnow.h):
+
+    x -> DCNMixLayer -> MultiDenseLayer(1, 1) head -> pairwise_loss(scores, labels, groups) -> every gradient
+
+i.e. /root/reference/rec_now/layers/dcn_mix_layer.py:114-151 -> multi_dense_layer.py:80-94 ->
+rec_block/pairwise_loss_from_batch.py:228-279 and their backward, on buffers that are allocated ONCE.  Why it exists: under
+strong scaling the metric's batch of 65 536 rows leaves 8192 rows per GPU at 8 GPUs, a step of ~0.5 ms of GPU time made of ~60
+launches -- less than the host needs to enqueue them through autograd (0.6-0.9 ms).  Here a phase is one ctypes call, nothing is
+allocated and no library event is recorded inside a phase, so each phase is also capturable into a HIP graph
+(`capture()` / `replay()`): the host side of a step is then a handful of graph launches.
+
+The two drop-in layers keep holding the weights (reference names); gradients land in `p.grad` exactly as after
+`pairwise_loss(head(cross(x)), labels, groups).backward()` (same kernels; tests/test_step_gpu.py holds the two routes together).
+
+Data parallel (rec_now_amd/dp.py): pass the `LayerwiseReducer`; the gradients are then written straight into its per-layer
+buckets, the loss statistics into the first bucket's tail, the backward pass is cut into one piece per cross layer and each
+bucket's all-reduce is launched as soon as its piece has been enqueued (the collectives are NOT captured: RCCL launches stay
+ordinary stream work between the graph launches).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .fused import GpuEvent, fused_route_available, score_params
+from .layers._ops import _host_ptr_array
+from .rec_block._segments import _as_key_tensor
+
+_GROUP, _FORWARD, _LOSS, _BACKWARD = 1, 2, 4, 8
+
+
+class DCNMixPairwiseStep(object):
+    """cross: DCNMixLayer (built), head: MultiDenseLayer(1, 1) (built, linear), both on the GPU.
+
+    x (B, D) float32, labels (B,), groups (B,) float32 / int32 / float64 / int64 ids, optional mask (B,) bool: device tensors
+    whose STORAGE is reused by every step (copy new batches into them) -- a captured graph replays addresses.
+    reduce_mean: the reference's mean over the pairs (`loss` = sum / (P + 1e-10)); False: the loss sum and its gradient (the
+    data-parallel form: the reducer divides by the global pair count).  need_dx: also d loss / d x (`self.dx`).
+    reducer: optional dp.LayerwiseReducer built over `stages_for(cross, head)`.
+    """
+
+    def __init__(self, cross, head, x, labels, groups, mask=None, reduce_mean=True, need_dx=True, factor=1.0,
+                 only_use_wrong_order_pair=False, reducer=None):
+        if not fused_route_available(cross, head, x):
+            raise ValueError('DCNMixPairwiseStep needs the fused north-star shape (recnow_dcn_mix_score_supported): N*S and D multiples '
+                             'of 128, B a multiple of 256, built-in activations, a linear MultiDenseLayer(1, 1) head')
+        self.cross, self.head, self.reducer = cross, head, reducer
+        if reducer is not None:
+            reduce_mean = False        # the data-parallel form: loss SUM and its gradient, divided by the GLOBAL pair count by the reducer
+        dev = x.device
+        self.device = dev
+        N, D, S = cross.origin_to_sub_kernels[0].shape
+        L = cross.num_layer
+        B = x.shape[0]
+        self.B, self.D, self.L = B, D, L
+        self.x = _lib.f32c(x, 'inputs')
+        self.labels = _lib.f32c(labels, 'labels').reshape(-1)
+        self.groups, gdt = _as_key_tensor(groups)
+        self.mask = None if mask is None else (mask.reshape(-1) != 0).to(torch.uint8).contiguous()
+        if self.labels.numel() != B or self.groups.numel() != B or (self.mask is not None and self.mask.numel() != B):
+            raise ValueError('labels / groups / mask must have %d elements' % B)
+        lib = _lib.load()
+        self.scores = torch.empty(B, dtype=torch.float32, device=dev)
+        self.loss = torch.empty((), dtype=torch.float32, device=dev)
+        self.n_pair = torch.empty(1, dtype=torch.int64, device=dev)
+        self.dx = torch.empty_like(self.x) if need_dx else None
+        self.ws = _lib.workspace(lib.recnow_dcn_mix_step_workspace_bytes(B, D, S, N, L, gdt), dev)
+        # parameters in the order of fused.score_params: head kernel, head bias, U_0.., V_0.., W_0.., bias_0.., gate_0..
+        self.params = score_params(cross, head)
+        self.grads = []
+        for p in self.params:
+            buf = reducer.buffer_of(p) if reducer is not None else None
+            self.grads.append(torch.empty(p.numel(), dtype=torch.float32, device=dev) if buf is None else buf)
+        self.stats = reducer.stats_slot() if reducer is not None else torch.empty(2, dtype=torch.float32, device=dev)
+        ps = [_lib.f32c(p.detach(), 'weight') for p in self.params]
+        for p, q in zip(self.params, ps):
+            if p.data_ptr() != q.data_ptr():
+                raise ValueError('the weights must be contiguous float32 tensors (the step reads them in place)')
+        g5 = lambda i: self.grads[2 + i * L:2 + (i + 1) * L]        # noqa: E731
+        w5 = lambda i: ps[2 + i * L:2 + (i + 1) * L]                # noqa: E731
+        self._keep = [_host_ptr_array(w5(i)) for i in range(5)] + [_host_ptr_array(g5(i)) for i in range(5)]      # host pointer arrays: alive as long as the descriptor
+        d = _lib.StepDesc()
+        d.B, d.D, d.S, d.N, d.L = B, D, S, N, L
+        d.act_inner, d.act_outer, d.group_dtype = cross._act_inner, cross._act_outer, gdt
+        d.only_use_wrong_order_pair, d.reduce_mean, d.factor = int(bool(only_use_wrong_order_pair)), int(bool(reduce_mean)), float(factor)
+        P = lambda t: None if t is None else t.data_ptr()           # noqa: E731
+        d.x, d.labels, d.groups, d.mask = P(self.x), P(self.labels), P(self.groups), P(self.mask)
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)            # noqa: E731
+        d.U_host, d.V_host, d.W_host, d.bias_host, d.gate_host = (cast(a) for a in self._keep[:5])
+        d.dU_host, d.dV_host, d.dW_host, d.dbias_host, d.dgate_host = (cast(a) for a in self._keep[5:])
+        d.head_w, d.head_b = P(ps[0]), P(ps[1])
+        d.dhead_w, d.dhead_b = P(self.grads[0]), P(self.grads[1])
+        d.scores, d.loss, d.n_pair, d.stats, d.dx = P(self.scores), P(self.loss), P(self.n_pair), P(self.stats), P(self.dx)
+        d.ws, d.ws_bytes = P(self.ws), self.ws.numel()
+        self.desc = d
+        self.reduce_mean = bool(reduce_mean)
+        self.side = torch.cuda.Stream(device=dev)
+        self._grouped = GpuEvent()
+        self._fork = GpuEvent()
+        self._graphs = None
+        # the layer pieces of the backward pass: one per reducer stage (top layer + head first), or the whole pass
+        self.pieces = [(L - 1 - i, L - 1 - i) for i in range(L)] if reducer is not None else [(L - 1, 0)]
+        for p, g in zip(self.params, self.grads):
+            p.grad = g.view(p.shape)           # written in place by every step
+
+    @staticmethod
+    def stages_for(cross, head):
+        """Parameter stages for dp.LayerwiseReducer, in the order their gradients become final (top cross layer + head first)."""
+        L = cross.num_layer
+        per = lambda l: [cross.origin_to_sub_kernels[l], cross.sub_to_sub_kernels[l], cross.sub_to_origin_kernels[l], cross.biases[l],      # noqa: E731
+                         cross.gate_layers[l].kernel]
+        return [per(L - 1) + [head.kernel, head.bias]] + [per(l) for l in range(L - 2, -1, -1)]
+
+    # ---- phases -------------------------------------------------------------------------------------------------------
+    def _call(self, phases, hi=-1, lo=0, stream=None):
+        _lib.call('recnow_dcn_mix_step', ctypes.byref(self.desc), phases, hi, lo, _lib.stream() if stream is None else _lib._P(stream.cuda_stream))
+
+    def _enqueue(self, launch):
+        """One step on the current stream (+ the side stream for the grouping).  `launch(key, fn)` runs piece `key` (eager: calls fn;
+        replay: launches its graph).  Returns after everything is enqueued."""
+        main = torch.cuda.current_stream()
+        # grouping (sort by group id, segments) does not depend on the scores: on a side stream, under the forward pass
+        _lib.call('recnow_event_record', self._fork.handle, _lib._P(main.cuda_stream))
+        self._fork.wait(self.side)
+        torch.cuda.set_stream(self.side)           # (the `with torch.cuda.stream(..)` form costs ~40 us of host time)
+        try:
+            launch('group', lambda: self._call(_GROUP))
+        finally:
+            torch.cuda.set_stream(main)
+        _lib.call('recnow_event_record', self._grouped.handle, _lib._P(self.side.cuda_stream))
+        launch('forward', lambda: self._call(_FORWARD))
+        self._grouped.wait(main)
+        for i, (hi, lo) in enumerate(self.pieces):
+            launch('bwd%d' % i, lambda hi=hi, lo=lo, i=i: self._call((_LOSS if i == 0 else 0) | _BACKWARD, hi, lo))
+            if self.reducer is not None:
+                self.reducer.stage_done(i)
+        if self.reducer is not None:
+            return self.reducer.reduce_in_place()
+        return self.loss, self.n_pair
+
+    def run(self):
+        """One eager step.  Returns (loss, n_pair): 0-dim / 1-element device tensors (global mean loss and pair count under a
+        reducer).  Gradients are in `p.grad` of every parameter, d loss / d x in `self.dx`."""
+        return self._enqueue(lambda key, fn: fn())
+
+    def capture(self):
+        """Capture every piece of the step into its own HIP graph (single-stream graphs: a forked capture replays with a host-side
+        join between the branches, +1.5 ms per step measured).  Call once, after a warm-up `run()`."""
+        torch.cuda.synchronize(self.device)
+        self._graphs = {}
+        cap = torch.cuda.Stream(device=self.device)
+        keys = [('group', lambda: self._call(_GROUP)), ('forward', lambda: self._call(_FORWARD))]
+        for i, (hi, lo) in enumerate(self.pieces):
+            keys.append(('bwd%d' % i, lambda hi=hi, lo=lo, i=i: self._call((_LOSS if i == 0 else 0) | _BACKWARD, hi, lo)))
+        with torch.cuda.stream(cap):
+            for key, fn in keys:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap):
+                    fn()
+                self._graphs[key] = g
+        torch.cuda.synchronize(self.device)
+        return self
+
+    def replay(self):
+        """One step from the captured graphs (same results as `run()`, bit for bit)."""
+        if self._graphs is None:
+            raise RuntimeError('capture() first')
+        return self._enqueue(lambda key, fn: self._graphs[key].replay())

@@ -22,7 +22,7 @@ def test_header_symbols_exported_and_bound():
         assert n in _lib.SIGNATURES, '%s is not bound in rec_now_amd/_lib.py' % n
     for n in _lib.SIGNATURES:
         assert n in names, '%s is bound but not declared in include/recnow.h' % n
-    assert lib.recnow_abi_version() >= 1
+    assert lib.recnow_abi_version() == _lib.ABI_VERSION
 
 
 def test_cpu_tensor_is_refused_loudly():

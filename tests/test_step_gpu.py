@@ -1,0 +1,181 @@
+"""GPU parity of the whole-step entry `recnow_dcn_mix_step` (rec_now_amd/step.py): x -> DCNMixLayer ->
+MultiDenseLayer(1,1) -> pairwise_loss and every gradient, enqueued phase by phase from C on buffers allocated once.
+
+  * against the drop-in autograd route (same kernels: loss, scores and every gradient but the head bias bit for bit);
+  * at the PER-RANK shard sizes of the metric's 4- and 8-GPU rows (16 384 and 8192 rows x 1024: the dispatcher splits K of the
+    M = B products there) against the fp64 chunked oracle + the C pair oracle, through the data-parallel form: a 1-rank RCCL
+    group with the collectives forced on, gradients written into the LayerwiseReducer's buckets, statistics in the first
+    bucket's tail, one backward piece per cross layer;
+  * captured into HIP graphs and replayed: the same bits as the eager step.
+Reference: /root/reference/rec_now/layers/dcn_mix_layer.py:114-151, multi_dense_layer.py:80-94,
+rec_block/pairwise_loss_from_batch.py:228-279."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import pairs_oracle as PO
+from _chunked_oracle import close, run_chunked, weights64
+from test_northstar_gpu import _mix_fwd, _randomise
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev, B, D, S, N, L, seed, head_gain=40.0):
+    from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
+    from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0.0, 0.7, (B, D)).astype(np.float32)
+    groups = rng.integers(0, max(B // 64, 2), B).astype(np.float32)
+    labels = (rng.random(B) < 0.25).astype(np.float32)
+    cross, head = DCNMixLayer(S, num_layer=L, num_expert=N), MultiDenseLayer(1, 1)
+    xd = torch.from_numpy(x).to(dev)
+    head(cross(xd[:256]))
+    _randomise(cross, seed + 1)
+    with torch.no_grad():
+        head.kernel.mul_(head_gain * (1024.0 / D) ** 0.5)      # scores of O(1): away from the softplus(0) = ln 2 plateau
+        head.bias.fill_(0.3)
+    return x, groups, labels, xd, torch.from_numpy(labels).to(dev), torch.from_numpy(groups).to(dev), cross, head
+
+
+def _autograd_route(cross, head, xd, yd, gd, params):
+    from rec_now_amd.fused import dcn_mix_score
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+    for p in params:
+        p.grad = None
+    xr = xd.detach().clone().requires_grad_(True)
+    scores = dcn_mix_score(cross, head, xr)
+    loss, n_pair = pairwise_loss(scores, yd, gd, return_num_pair=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    return (loss.detach().clone(), int(n_pair.item()), scores.detach().clone(), xr.grad.clone(), [p.grad.detach().clone() for p in params])
+
+
+@pytest.mark.parametrize('B,D,S,N,L', [(2048, 256, 64, 2, 3), (512, 1024, 64, 2, 2), (1024, 128, 32, 4, 1)])
+def test_step_equals_autograd_route_and_graph_replay(dev, B, D, S, N, L):
+    from rec_now_amd.fused import score_params
+    from rec_now_amd.step import DCNMixPairwiseStep
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 7 + B)
+    params = score_params(cross, head)
+    loss_a, np_a, sc_a, dx_a, g_a = _autograd_route(cross, head, xd, yd, gd, params)
+    assert np_a > 0 and abs(float(loss_a) - np.log(2.0)) > 1e-3
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd)
+    for mode in ('eager', 'graph'):
+        if mode == 'graph':
+            step.capture()
+        for p in step.grads:
+            p.fill_(float('nan'))
+        step.dx.fill_(float('nan'))
+        loss, n_pair = step.run() if mode == 'eager' else step.replay()
+        torch.cuda.synchronize()
+        assert int(n_pair.item()) == np_a, mode
+        assert torch.equal(loss, loss_a) and torch.equal(step.scores, sc_a), mode
+        assert torch.equal(step.dx, dx_a), mode
+        for p, ga in zip(params, g_a):
+            if p is head.bias:        # sum of dscores (0 in exact arithmetic): another summation order than the autograd route's column sum
+                assert abs(float(p.grad) - float(ga)) <= 1e-5, (mode, float(p.grad), float(ga))
+            else:
+                assert torch.equal(p.grad, ga), (mode, tuple(p.shape))
+
+
+def test_step_with_mask_and_wrong_order_pairs(dev):
+    """mask and only_use_wrong_order_pair reach the loss stage as `pairwise_loss` passes them."""
+    from rec_now_amd.fused import dcn_mix_score, score_params
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+    from rec_now_amd.step import DCNMixPairwiseStep
+    B, D, S, N, L = 1024, 256, 64, 2, 2
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 3)
+    mask = torch.from_numpy(np.random.default_rng(5).random(B) < 0.8).to(dev)
+    params = score_params(cross, head)
+    for p in params:
+        p.grad = None
+    xr = xd.detach().clone().requires_grad_(True)
+    loss_a = pairwise_loss(dcn_mix_score(cross, head, xr), yd, gd, only_use_wrong_order_pair=True, mask=mask)
+    loss_a.backward()
+    ref = [p.grad.detach().clone() for p in params]
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd, mask=mask, only_use_wrong_order_pair=True)
+    loss, _ = step.run()
+    torch.cuda.synchronize()
+    assert torch.equal(loss, loss_a.detach()) and torch.equal(step.dx, xr.grad)
+    for p, g in zip(params, ref):
+        if p is not head.bias:
+            assert torch.equal(p.grad, g)
+
+
+@pytest.fixture(scope='module')
+def one_rank_rccl(dev):
+    import torch.distributed as dist
+    from rec_now_amd import dp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', device_id=dev)
+    dp.FORCE_COLLECTIVES = True
+    yield dist
+    dp.FORCE_COLLECTIVES = False
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('B', [8192, 16384])
+def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B):
+    """(8192, 1024) and (16 384, 1024): the 8- and 4-GPU shards of the metric's batch, step route + LayerwiseReducer over a 1-rank
+    RCCL group (every collective runs), eager and replayed from graphs, against the fp64 oracle: loss, pair count, scores,
+    d loss / d x and all 17 weight gradients."""
+    from rec_now_amd import dp
+    from rec_now_amd.fused import GpuEvent
+    from rec_now_amd.step import DCNMixPairwiseStep
+    D, S, N, L = 1024, 64, 2, 3
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 100 + B)
+    stages = DCNMixPairwiseStep.stages_for(cross, head)
+    reducer = dp.LayerwiseReducer(stages, [GpuEvent() for _ in stages], dev)
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd, reducer=reducer)
+    named = dict(cross.named_weights())
+    named['head/kernel'], named['head/bias'] = head.kernel, head.bias
+    w64 = weights64(named)
+    fwd = _mix_fwd(w64, L, head=True)
+    (rs,), _, _ = run_chunked(fwd, torch.from_numpy(x), None, w64, chunk=4096, want_dx=False)
+    rloss, rds, rP = PO.pairwise_bpr(groups, labels, rs.astype(np.float32))
+    assert rP > B and abs(rloss - np.log(2.0)) > 1e-3
+    _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), torch.from_numpy(rds), w64, chunk=4096)
+    for mode in ('eager', 'graph'):
+        if mode == 'graph':
+            step.capture()
+        for f in reducer._flat:
+            f.fill_(float('nan'))
+        loss, p_glob = step.run() if mode == 'eager' else step.replay()
+        torch.cuda.synchronize()
+        assert int(p_glob.item()) == rP and int(step.n_pair.item()) == rP, mode
+        close(step.scores, rs, what='scores ' + mode)
+        close(loss, np.float64(rloss), what='loss ' + mode)
+        # d loss / d x is not a parameter: the reducer does not scale it (the loss SUM's gradient; bench.py does the same division)
+        close(step.dx / (np.float32(rP) + np.float32(1e-10)), rdx, what='dx ' + mode)
+        for name, p in named.items():
+            close(p.grad, rgrads[name], what=name + ' ' + mode, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+
+
+def test_gradient_accumulation_onto_bucket_views(dev):
+    """dp.LayerwiseReducer + fused.dcn_mix_score(grad_buffers=...): a second backward without clearing the gradients must ADD to
+    p.grad (= the bucket view), not overwrite it."""
+    from rec_now_amd import dp
+    from rec_now_amd.fused import GpuEvent, dcn_mix_score, score_params
+    B, D, S, N, L = 512, 256, 64, 2, 2
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 11)
+    params = score_params(cross, head)
+    stages = [[p for p in params]]
+    lw = dp.LayerwiseReducer(stages, [None], dev)
+    gbuf = [lw.buffer_of(p) for p in params]
+    gs = torch.randn(B, device=dev)
+    for p in params:
+        p.grad = None
+    dcn_mix_score(cross, head, xd, grad_buffers=gbuf).backward(gs)
+    torch.cuda.synchronize()
+    once = [p.grad.detach().clone() for p in params]
+    assert all(p.grad.data_ptr() == b.data_ptr() for p, b in zip(params, gbuf))
+    dcn_mix_score(cross, head, xd, grad_buffers=gbuf).backward(gs)          # no clearing in between
+    torch.cuda.synchronize()
+    for p, g1 in zip(params, once):
+        close(p.grad, 2.0 * g1, rtol=1e-6, what='accumulated gradient')
