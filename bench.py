@@ -39,6 +39,14 @@ import os
 import sys
 import time
 
+# HIP graphs on ROCm 7.0: the runtime's graph AQL-packet capture (pre-built dispatch packets replayed straight into the queue) faults --
+# "Memory access fault ... write access to a read-only page" -- when a step that was captured as SEVERAL graphs (one per backward piece,
+# the N > 1 path) is replayed after the same kernels were launched eagerly in between (reproduced in tools/graph_dist_probe.py: clean with
+# the switch below, faults without it; single-graph steps were never affected).  The runtime reads the switch when it is loaded, i.e. at
+# `import torch`: INTEGRATION.md tells trainers that replay rec_now_amd.step graphs to export it as well.
+import os as _os
+_os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -358,16 +366,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace_on = os.environ.get('RECNOW_BENCH_TRACE') in ('1', '2')
+
+    def mark(what):          # diagnostic: phase markers on stderr (RECNOW_BENCH_TRACE=1: behind a device synchronisation; =2: host progress only)
+        if trace_on:
+            if os.environ.get('RECNOW_BENCH_TRACE') == '1':
+                torch.cuda.synchronize()
+            print('[bench] %s' % what, file=sys.stderr, flush=True)
+    if trace_on and pstep is not None:
+        print('[bench] ws %x +%d  x %x  dx %x  scores %x  buckets %s' % (pstep.ws.data_ptr(), pstep.ws.numel(), pstep.x.data_ptr(), pstep.dx.data_ptr() if pstep.dx is not None else 0,
+              pstep.scores.data_ptr(), [(hex(f.data_ptr()), f.numel() * 4) for f in (layerwise._flat if layerwise is not None else [])]), file=sys.stderr, flush=True)
+
     graph = None
+    hook_pre = None
     if pstep is not None:
         for _ in range(max(args.warmup, 1 if use_graph else 0)):
             step()
+        mark('eager warm-up done')
+        if use_graph and not args.no_prof:
+            # the event hook cannot bracket the kernel nodes of a replayed graph: the roofline samples of a graph run come from 10 more
+            # EAGER steps here, before anything is captured -- same kernels, same launch order, same buffers as the timed replays
+            _lib.check(lib.recnow_prof_enable(64 * 12), 'recnow_prof_enable')
+            _lib.check(lib.recnow_prof_sample_every(PROF_EVERY), 'recnow_prof_sample_every')
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            hook_pre = tuple((ctypes.c_int * 16)() if i == 0 else (ctypes.c_double * 16)() for i in range(4))
+            _lib.check(lib.recnow_prof_collect(*hook_pre), 'recnow_prof_collect')
+            lib.recnow_prof_enable(0)
+            mark('eager hook steps done')
         if use_graph:
             pstep.capture()
+            mark('captured')
             graph = pstep
             run_step = lambda: pstep.replay()[0]      # noqa: E731
             for _ in range(2):
                 run_step()
+                mark('replayed once')
     elif not use_graph:
         for _ in range(args.warmup):
             step()
@@ -403,19 +438,15 @@ def main():
         loss = run_step()
     sync()
     elapsed = time.perf_counter() - t0
+    mark('timed region done')
     roofline = None
     prof_note = 'every %dth hooked launch of the timed region' % PROF_EVERY
-    if not prof and not args.no_prof and pstep is not None:
-        # the timed steps replayed HIP graphs, whose kernel nodes the event hook cannot bracket: the same step runs eagerly a few more
-        # times (untimed) with the hook on -- same kernels, same launch order, same buffers
-        prof = True
-        prof_note = 'every %dth hooked launch of 10 EAGER steps run right after the timed region (the timed steps replay HIP graphs)' % PROF_EVERY
-        _lib.check(lib.recnow_prof_enable(64 * 12), 'recnow_prof_enable')
-        _lib.check(lib.recnow_prof_sample_every(PROF_EVERY), 'recnow_prof_sample_every')
-        for _ in range(10):
-            step()
-        sync()
-    if prof:                                 # collected and switched off HERE: the samples are launches of the timed steps only
+    hook_done = False
+    if not prof and hook_pre is not None:
+        prof, hook_done = True, True
+        prof_note = 'every %dth hooked launch of 10 EAGER steps run before the graphs were captured (the timed steps replay HIP graphs)' % PROF_EVERY
+        cnt, ms, fl, by = hook_pre
+    if prof and not hook_done:               # collected and switched off HERE: the samples are launches of the timed steps only
         cnt = (ctypes.c_int * 16)()          # the library fills RN_TAG_MAX (= 9) entries
         ms = (ctypes.c_double * 16)()
         fl = (ctypes.c_double * 16)()
@@ -428,6 +459,7 @@ def main():
         run_step()
     host_ms = (time.perf_counter() - h0) * 1e3 / 5
     sync()
+    mark('host enqueue loop done')
     if args.hostprof:
         import cProfile
         import pstats
