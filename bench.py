@@ -209,9 +209,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events in the timed region')
-    ap.add_argument('--graph', action='store_true', help='replay the step from captured HIP graphs (SURVEY 8f.1); the default under a process group '
-                    '(N > 1 or --force-dist), where a shard of 8192-32768 rows is shorter on the GPU than its launches are on the host')
-    ap.add_argument('--eager', action='store_true', help='never replay graphs (diagnostic for the N > 1 path)')
+    ap.add_argument('--graph', action='store_true', help='replay the step from captured HIP graphs (SURVEY 8f.1; one graph per phase / backward piece) '
+                    'instead of enqueueing it eagerly')
+    ap.add_argument('--eager', action='store_true', help='never replay graphs (overrides --graph)')
     ap.add_argument('--route', choices=['step', 'autograd'], default='step',
                     help="'step' (default): the whole step through recnow_dcn_mix_step (rec_now_amd/step.py: one C call per phase, buffers allocated "
                          "once); 'autograd': the model-level fused node dcn_mix_score + pairwise_loss_fused through torch.autograd")
@@ -281,7 +281,11 @@ def main():
     from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
     fused = not args.unfused and fused_route_available(model.cross, model.head, xd)
     use_step = fused and args.route == 'step'
-    use_graph = (args.graph or (use_dist and use_step)) and not args.eager
+    # under a process group the step stays EAGER by default: the whole-step entry leaves the host at 0.3-0.4 ms per step, below the GPU
+    # time of even the 8192-row shard, and an eager backward pass can run its weight-gradient products on a second stream across the
+    # layers (measured: 0.82 vs 0.83 ms replayed at 8192 rows, 1.22 vs 1.27 at 16 384); --graph replays per-piece graphs instead
+    use_graph = args.graph and not args.eager
+    two_streams = os.environ.get('RECNOW_STEP_TWO_STREAMS', '1' if (use_dist and not use_graph) else '0') == '1'
     events, layerwise, grad_buffers, pstep = None, None, None, None
     if use_step:
         # whole-step entry: one C call per phase on buffers allocated once; under a process group the gradients are produced inside the
@@ -290,7 +294,8 @@ def main():
         if use_dist:
             stages = DCNMixPairwiseStep.stages_for(model.cross, model.head)
             layerwise = dp.LayerwiseReducer(stages, [GpuEvent() for _ in stages], dev)
-        pstep = DCNMixPairwiseStep(model.cross, model.head, xd.detach(), yd, gd, need_dx=not args.no_input_grad, reducer=layerwise)
+        pstep = DCNMixPairwiseStep(model.cross, model.head, xd.detach(), yd, gd, need_dx=not args.no_input_grad, reducer=layerwise,
+                                   two_streams=two_streams)
     elif fused and use_dist:
         events = [GpuEvent() for _ in range(LAYERS)]
         per_layer = lambda l: [model.cross.origin_to_sub_kernels[l], model.cross.sub_to_sub_kernels[l], model.cross.sub_to_origin_kernels[l],     # noqa: E731
@@ -560,7 +565,7 @@ def main():
                                    'in-batch pairwise (logistic), global B=%d = %d rows on each of %d GPU(s), 64 fields x 16-dim, ~64 rows/group' % (rows * world, rows, world),
                        'rows_per_gpu': rows,
                        'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(use_graph), 'parallelism': 'dp%d' % world,
-                       'route': ('whole-step entry recnow_dcn_mix_step (one C call per phase, grouping on a side stream)' + (', replayed from HIP graphs' if use_graph else '')) if use_step else
+                       'route': ('whole-step entry recnow_dcn_mix_step (one C call per phase, grouping on a side stream)' + (', replayed from HIP graphs' if use_graph else '') + (', weight-gradient products on a second stream' if two_streams else '')) if use_step else
                                 'fused node dcn_mix_score through autograd + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
                        'loss': float(loss.item()), 'host_enqueue_ms_per_step': host_ms,
                        'grads_copied_into_buckets': getattr(layerwise, 'last_foreign', None) if layerwise is not None else None},

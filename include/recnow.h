@@ -446,6 +446,11 @@ typedef struct recnow_dcn_mix_step_desc {
     float* dhead_b;                     /* out (1) or NULL */
     void* ws;                           /* recnow_dcn_mix_step_workspace_bytes; holds the step's state between the phases */
     size_t ws_bytes;
+    void* stream2;                      /* optional second hipStream_t of RECNOW_STEP_BACKWARD (as recnow_dcn_mix_score_bwd's stream2): the
+                                           weight-gradient products run on it beside the data-gradient chain; NULL: one stream */
+    void* const* layer_events_host;     /* optional HOST array of L hipEvent_t (entries may be NULL), as recnow_dcn_mix_score_bwd: event l is
+                                           recorded once every weight gradient of layer l has been issued.  Must be NULL while the call
+                                           is being captured into a graph (an event recorded inside a capture belongs to the graph). */
 } recnow_dcn_mix_step_desc;
 size_t recnow_dcn_mix_step_workspace_bytes(int64_t B, int D, int S, int N, int L, int group_dtype);
 int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* desc_host, int phases, int layer_hi, int layer_lo, void* stream);

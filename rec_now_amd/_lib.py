@@ -132,7 +132,7 @@ class StepDesc(ctypes.Structure):
         ('U_host', _P), ('V_host', _P), ('W_host', _P), ('bias_host', _P), ('gate_host', _P), ('head_w', _P), ('head_b', _P),
         ('scores', _P), ('loss', _P), ('n_pair', _P), ('stats', _P), ('dx', _P),
         ('dU_host', _P), ('dV_host', _P), ('dW_host', _P), ('dbias_host', _P), ('dgate_host', _P), ('dhead_w', _P), ('dhead_b', _P),
-        ('ws', _P), ('ws_bytes', _Z),
+        ('ws', _P), ('ws_bytes', _Z), ('stream2', _P), ('layer_events_host', _P),
     ]
 
 

@@ -560,16 +560,21 @@ extern "C" int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_ho
 // epilogue and all workgroups of one launch run in phase, so a single stream leaves ~40 % of the MFMA pipe idle.  With a
 // second stream (st2 != st) the side products run concurrently with the chain and fill those phases.  Ordering is by
 // events only; results are identical to the single-stream order (dx is accumulated by the side stream, then joined).
+// Events of the two-stream ordering: taken from a process-wide pool that only grows (hipEventCreate / Destroy per call cost up to a
+// millisecond of host time on a busy runtime).  An event may be recorded again while an earlier wait on it is still queued: a wait
+// refers to the record that preceded it.
 struct MixEvents {
-    hipEvent_t e[64];
     int n = 0;
     hipEvent_t make() {
-        hipEvent_t ev = nullptr;
-        if (n < 64 && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) e[n++] = ev;
-        return ev;
-    }
-    ~MixEvents() {
-        for (int i = 0; i < n; ++i) (void)hipEventDestroy(e[i]);
+        static hipEvent_t pool[64];
+        static int have = 0;
+        if (n >= 64) return nullptr;
+        if (n >= have) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+            pool[have++] = ev;
+        }
+        return pool[n++];
     }
 };
 #define MIX_SIGNAL(ev, from)                                  \
@@ -1048,7 +1053,7 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
         hd.w = d->head_w; hd.dscores = w.ds; hd.dw = d->dhead_w; hd.db = d->dhead_b;
         if ((rc = dcnmix_bwd_exact(m, d->x, d->U_host, d->V_host, d->W_host, d->bias_host, d->gate_host, nullptr, (const char*)w.saved,
                                    d->act_inner, d->act_outer, d->dx, d->dU_host, d->dV_host, d->dW_host, d->dbias_host, d->dgate_host, w.mix,
-                                   w.mix_bytes, st, nullptr, &hd, nullptr, layer_hi, layer_lo, w.T2g_ds, w.ds_part, rn_cdiv(B, STEP_ROWS))))
+                                   w.mix_bytes, st, (hipStream_t)d->stream2, &hd, d->layer_events_host, layer_hi, layer_lo, w.T2g_ds, w.ds_part, rn_cdiv(B, STEP_ROWS))))
             return rc;
     }
     return RECNOW_OK;

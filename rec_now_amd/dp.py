@@ -196,10 +196,12 @@ class LayerwiseReducer(object):
         loss stage (`recnow_dcn_mix_step_desc.stats`), so they ride in the first collective without a packing kernel."""
         return self._flat[0][-2:]
 
-    def stage_done(self, i, eps=SMALL_POSIVITE_FLOAT):
+    def stage_done(self, i, eps=SMALL_POSIVITE_FLOAT, recorded=False):
         """Every gradient of stage i (and, for i == 0, the statistics) has been ENQUEUED on the current stream: mark that point and
         enqueue the stage's all-reduce + 1 / (P_global + eps) scaling on the communication stream.  The current stream is not made to
-        wait: the backward of the stages below keeps running under the collective."""
+        wait: the backward of the stages below keeps running under the collective.
+        recorded=True: the library has already recorded the stage's event where the stage's last gradient was issued (the
+        `layer_events_host` of recnow_dcn_mix_step / recnow_dcn_mix_score_bwd): only the wait and the collective are enqueued."""
         flat = self._flat[i]
         n_grad = flat.numel() - (2 if i == 0 else 0)
         stats = self._flat[0][-2:]
@@ -213,7 +215,8 @@ class LayerwiseReducer(object):
         from . import _lib
         main = torch.cuda.current_stream()
         ev = self.events[i]
-        _lib.call('recnow_event_record', ev.handle, _lib._P(main.cuda_stream))
+        if not recorded:
+            _lib.call('recnow_event_record', ev.handle, _lib._P(main.cuda_stream))
         ev.wait(self.comm)
         if getattr(self, '_result', None) is None or not self._result.is_cuda:
             self._result = torch.empty(2, dtype=torch.float32, device=flat.device)

@@ -40,7 +40,7 @@ class DCNMixPairwiseStep(object):
     """
 
     def __init__(self, cross, head, x, labels, groups, mask=None, reduce_mean=True, need_dx=True, factor=1.0,
-                 only_use_wrong_order_pair=False, reducer=None):
+                 only_use_wrong_order_pair=False, reducer=None, two_streams=False):
         if not fused_route_available(cross, head, x):
             raise ValueError('DCNMixPairwiseStep needs the fused north-star shape (recnow_dcn_mix_score_supported): N*S and D multiples '
                              'of 128, B a multiple of 256, built-in activations, a linear MultiDenseLayer(1, 1) head')
@@ -92,6 +92,10 @@ class DCNMixPairwiseStep(object):
         d.dhead_w, d.dhead_b = P(self.grads[0]), P(self.grads[1])
         d.scores, d.loss, d.n_pair, d.stats, d.dx = P(self.scores), P(self.loss), P(self.n_pair), P(self.stats), P(self.dx)
         d.ws, d.ws_bytes = P(self.ws), self.ws.numel()
+        # optional second stream of the backward pass (weight-gradient products beside the data-gradient chain): pays at small
+        # shards, where a single product leaves most of the chip idle (8192 rows: -12 % per step, eager); neutral at 65 536 rows
+        self.side2 = torch.cuda.Stream(device=dev) if two_streams else None
+        d.stream2 = None if self.side2 is None else self.side2.cuda_stream
         self.desc = d
         self.reduce_mean = bool(reduce_mean)
         self.side = torch.cuda.Stream(device=dev)
@@ -100,6 +104,10 @@ class DCNMixPairwiseStep(object):
         self._graphs = None
         # the layer pieces of the backward pass: one per reducer stage (top layer + head first), or the whole pass
         self.pieces = [(L - 1 - i, L - 1 - i) for i in range(L)] if reducer is not None else [(L - 1, 0)]
+        # stage i of the reducer = cross layer L-1-i: its event is what the library records for that layer (eager steps)
+        self._layer_events = None
+        if reducer is not None:
+            self._layer_events = (ctypes.c_void_p * L)(*[reducer.events[L - 1 - l].handle for l in range(L)])
         for p, g in zip(self.params, self.grads):
             p.grad = g.view(p.shape)           # written in place by every step
 
@@ -115,7 +123,7 @@ class DCNMixPairwiseStep(object):
     def _call(self, phases, hi=-1, lo=0, stream=None):
         _lib.call('recnow_dcn_mix_step', ctypes.byref(self.desc), phases, hi, lo, _lib.stream() if stream is None else _lib._P(stream.cuda_stream))
 
-    def _enqueue(self, launch):
+    def _enqueue(self, launch, whole_backward=False):
         """One step on the current stream (+ the side stream for the grouping).  `launch(key, fn)` runs piece `key` (eager: calls fn;
         replay: launches its graph).  Returns after everything is enqueued."""
         main = torch.cuda.current_stream()
@@ -130,6 +138,17 @@ class DCNMixPairwiseStep(object):
         _lib.call('recnow_event_record', self._grouped.handle, _lib._P(self.side.cuda_stream))
         launch('forward', lambda: self._call(_FORWARD))
         self._grouped.wait(main)
+        if whole_backward:
+            # eager under a reducer: ONE call walks all layers (the weight-gradient products of a layer run on the second stream beside
+            # the chain of the layers below) and records the stages' events itself where each stage's last gradient is issued
+            self.desc.layer_events_host = ctypes.cast(self._layer_events, ctypes.c_void_p)
+            try:
+                self._call(_LOSS | _BACKWARD, self.L - 1, 0)
+            finally:
+                self.desc.layer_events_host = None
+            for i in range(len(self.pieces)):
+                self.reducer.stage_done(i, recorded=True)
+            return self.reducer.reduce_in_place()
         for i, (hi, lo) in enumerate(self.pieces):
             launch('bwd%d' % i, lambda hi=hi, lo=lo, i=i: self._call((_LOSS if i == 0 else 0) | _BACKWARD, hi, lo))
             if self.reducer is not None:
@@ -141,7 +160,7 @@ class DCNMixPairwiseStep(object):
     def run(self):
         """One eager step.  Returns (loss, n_pair): 0-dim / 1-element device tensors (global mean loss and pair count under a
         reducer).  Gradients are in `p.grad` of every parameter, d loss / d x in `self.dx`."""
-        return self._enqueue(lambda key, fn: fn())
+        return self._enqueue(lambda key, fn: fn(), whole_backward=self.reducer is not None)
 
     def capture(self):
         """Capture every piece of the step into its own HIP graph (single-stream graphs: a forked capture replays with a host-side
@@ -152,12 +171,16 @@ class DCNMixPairwiseStep(object):
         keys = [('group', lambda: self._call(_GROUP)), ('forward', lambda: self._call(_FORWARD))]
         for i, (hi, lo) in enumerate(self.pieces):
             keys.append(('bwd%d' % i, lambda hi=hi, lo=lo, i=i: self._call((_LOSS if i == 0 else 0) | _BACKWARD, hi, lo)))
-        with torch.cuda.stream(cap):
-            for key, fn in keys:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap):
-                    fn()
-                self._graphs[key] = g
+        stream2, self.desc.stream2 = self.desc.stream2, None      # captured pieces are single-stream (a forked capture replays slowly)
+        try:
+            with torch.cuda.stream(cap):
+                for key, fn in keys:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=cap):
+                        fn()
+                    self._graphs[key] = g
+        finally:
+            self.desc.stream2 = stream2
         torch.cuda.synchronize(self.device)
         return self
 

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# before anything imports torch (the HIP runtime reads it when it is loaded): ROCm 7.0's graph AQL-packet capture faults when kernels
+# of a captured graph are also launched eagerly between replays (bench.py, tools/graph_dist_probe.py)
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 import numpy as np
 import pytest
 

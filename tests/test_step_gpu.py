@@ -120,8 +120,8 @@ def one_rank_rccl(dev):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('B', [8192, 16384])
-def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B):
+@pytest.mark.parametrize('B,two_streams', [(8192, False), (8192, True), (16384, True)])
+def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B, two_streams):
     """(8192, 1024) and (16 384, 1024): the 8- and 4-GPU shards of the metric's batch, step route + LayerwiseReducer over a 1-rank
     RCCL group (every collective runs), eager and replayed from graphs, against the fp64 oracle: loss, pair count, scores,
     d loss / d x and all 17 weight gradients."""
@@ -132,7 +132,9 @@ def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B):
     x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 100 + B)
     stages = DCNMixPairwiseStep.stages_for(cross, head)
     reducer = dp.LayerwiseReducer(stages, [GpuEvent() for _ in stages], dev)
-    step = DCNMixPairwiseStep(cross, head, xd, yd, gd, reducer=reducer)
+    # two_streams: the eager step walks all layers in one call, weight-gradient products on a second stream, the library records the
+    # stages' events (what bench.py runs under a process group); the replayed graphs are single-stream pieces either way
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd, reducer=reducer, two_streams=two_streams)
     named = dict(cross.named_weights())
     named['head/kernel'], named['head/bias'] = head.kernel, head.bias
     w64 = weights64(named)
