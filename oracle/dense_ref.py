@@ -238,6 +238,31 @@ def cin_layer(inputs, weights, num_field, embedding_dim, output_input=True, sum_
     return out.reshape(out.shape[0], -1)                                          # :120-121
 
 
+def cin_layer_gemm_form(inputs, weights, num_field, embedding_dim, output_input=True, sum_channel=True):
+    """layers/cin_layer.py:72-122 once more, for FULL-SIZE use by the chunked oracle (tests/_chunked_oracle.py): the per-(b, d)
+    matrix-vector product of :108-109, `matmul(w (1,1,H_k,H_{k-1}*F), hidden (B,D,H_{k-1}*F,1))`, written as ONE matrix product
+    `hidden.reshape(B*D, H_{k-1}*F) @ w^T` -- the same contraction over the column index f*H_{k-1}+h, term by term, but a GEMM
+    instead of B*D mat-vecs that each re-read the weight (at B = 16 384, F = 64, H = 128 the line-by-line form moves terabytes).
+    tests/test_oracle_golden.py holds it to `cin_layer` (and through it to the reference's golden)."""
+    emb = torch.cat(inputs, dim=1) if isinstance(inputs, list) else inputs        # :88-91
+    layer0 = emb.reshape(-1, num_field, embedding_dim).permute(0, 2, 1)           # :96-97 (B,D,F)
+    B = layer0.shape[0]
+    layers = [layer0]
+    for w in weights:                                                             # :101-110
+        prev = layers[-1]
+        hidden = torch.einsum('bdf,bdh->bdfh', layer0, prev)                      # :103
+        hidden = hidden.reshape(B * embedding_dim, -1)                            # :105-106 (B*D, F*H_{k-1})
+        hk = w.shape[2]
+        layers.append((hidden @ w.reshape(hk, -1).t()).reshape(B, embedding_dim, hk))      # :108-109
+    if not output_input:
+        layers = layers[1:]                                                       # :112-113
+    out = torch.cat(layers, dim=-1)                                               # :115
+    if sum_channel:
+        return out.sum(-1)                                                        # :116-117
+    out = out.permute(0, 2, 1)                                                    # :119
+    return out.reshape(out.shape[0], -1)                                          # :120-121
+
+
 def dcn_layer(inputs, kernels, biases=None, activation=None):
     """layers/dcn_layer.py:79-103. kernels[l] (D,1), biases[l] (1,D). No residual term."""
     act = _act(activation)

@@ -69,33 +69,26 @@ def test_dcn_mix_config3_full_size(dev):
 
 
 def test_cin_config4_per_rank_size(dev):
-    """configs[3] per-rank share: B = 16384, F = 64, D = 16, H = [128, 128, 128]."""
+    """configs[3] per-rank share: B = 16384, F = 64, D = 16, H = [128, 128, 128]: the output, d / d x on ALL rows and ALL THREE
+    weight gradients against the fp64 oracle evaluated chunk-wise over the whole batch (oracle/dense_ref.cin_layer_gemm_form,
+    reference /root/reference/rec_now/layers/cin_layer.py:101-110; weight gradients summed over the chunks in fp64)."""
+    from _chunked_oracle import run_chunked
     from rec_now_amd.layers.cin_layer import CINLayer
     B, F, D, Hs = 16384, 64, 16, [128, 128, 128]
     g = torch.Generator(device='cpu').manual_seed(12)
-    xs = [torch.randn(B, D, generator=g) * 0.3 for _ in range(F)]
+    x = torch.randn(B, F * D, generator=g) * 0.3
     gy = torch.randn(B, D, generator=g)
     layer = CINLayer(Hs)
-    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    xd = [x[:, f * D:(f + 1) * D].contiguous().to(dev).requires_grad_(True) for f in range(F)]
     y = layer(xd)
     y.backward(gy.to(dev))
-    full = _weight_grads(layer)
-    rows = torch.from_numpy(np.random.default_rng(2).choice(B, 96, replace=False))
-    w64 = [layer.idx2weight[k].detach().cpu().double().requires_grad_(True) for k in range(1, len(Hs) + 1)]
-    x64 = [x[rows].double().requires_grad_(True) for x in xs]
-    ry = R.cin_layer(x64, w64, F, D, True, True)
-    ry.backward(gy[rows].double())
-    close(y[rows.to(dev)], ry)
-    gs = max(float(v.grad.abs().max()) for v in x64)
-    for a, b in zip(xd, x64):
-        close(a.grad[rows.to(dev)], b.grad, scale=gs)
-    halves = []
-    for lo, hi in ((0, B // 2), (B // 2, B)):
-        _zero(layer)
-        layer([x[lo:hi].to(dev) for x in xs]).backward(gy[lo:hi].to(dev))
-        halves.append(_weight_grads(layer))
-    for k in full:
-        close(halves[0][k] + halves[1][k], full[k], rtol=3e-5)
+    w64 = {k: layer.idx2weight[k].detach().cpu().double().requires_grad_(True) for k in range(1, len(Hs) + 1)}
+    fwd = lambda xc: R.cin_layer_gemm_form(xc, [w64[k] for k in range(1, len(Hs) + 1)], F, D, True, True)      # noqa: E731
+    (ry,), rdx, rgrads = run_chunked(fwd, x, gy, w64, chunk=512)
+    close(y, ry)
+    close(torch.cat([a.grad for a in xd], dim=1), rdx)
+    for k in range(1, len(Hs) + 1):
+        close(layer.idx2weight[k].grad, rgrads[k])
 
 
 def test_fm_config4_full_size(dev):

@@ -60,6 +60,58 @@ def test_config4_cin_fm_pairwise(dev):
     close(head.kernel.grad, hk.grad)
 
 
+def test_config4_model_per_rank_size_vs_oracle(dev):
+    """configs[3] at its PER-RANK size (global B = 131072 over 8 ranks): B = 16384, F = 64, D = 16, CINLayer([128, 128, 128]) || FMLayer
+    -> MultiDenseLayer(1, 1) head on the (B, 17) features -> pairwise_loss with integers(0, 2048) groups: loss, pair count, scores,
+    d loss / d x (all rows, all fields) and every weight gradient against the fp64 oracle evaluated chunk-wise
+    (tests/_chunked_oracle.py; layers: /root/reference/rec_now/layers/cin_layer.py:101-110, fm_layer.py:36-42,
+    multi_dense_layer.py:88-94) with the O(B^2) pair part in oracle/pairs_oracle.c (rec_block/pairwise_loss_from_batch.py:254-279)."""
+    import pairs_oracle as PO
+    from _chunked_oracle import run_chunked
+    from rec_now_amd.layers.cin_layer import CINLayer
+    from rec_now_amd.layers.fm_layer import FMLayer
+    from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+    rng = np.random.default_rng(44)
+    B, F, D, Hs = 16384, 64, 16, [128, 128, 128]
+    x = rng.normal(0, 0.3, (B, F * D)).astype(np.float32)
+    groups = rng.integers(0, 2048, B).astype(np.float32)
+    labels = (rng.random(B) < 0.25).astype(np.float32)
+    cin, fm, head = CINLayer(Hs), FMLayer(), MultiDenseLayer(1, 1)
+    xd = [torch.from_numpy(np.ascontiguousarray(x[:, f * D:(f + 1) * D])).to(dev).requires_grad_(True) for f in range(F)]
+    feat = torch.cat([cin(xd), fm(xd)], dim=1)                        # (B, D + 1)
+    head(feat[:8])
+    with torch.no_grad():
+        head.kernel.mul_(0.05)          # scores of O(1) (the FM term of 64 fields is O(10)): pair terms off the softplus(0) plateau, no saturation
+        head.bias.fill_(0.2)
+    scores = head(feat).reshape(-1)
+    loss, n_pair = pairwise_loss(scores, torch.from_numpy(labels).to(dev), torch.from_numpy(groups).to(dev), return_num_pair=True)
+    loss.backward()
+    w64 = {k: cin.idx2weight[k].detach().cpu().double().requires_grad_(True) for k in range(1, len(Hs) + 1)}
+    w64['hk'] = head.kernel.detach().cpu().double().requires_grad_(True)
+    w64['hb'] = head.bias.detach().cpu().double().requires_grad_(True)
+
+    def fwd(xc):
+        fields = [xc[:, f * D:(f + 1) * D] for f in range(F)]
+        rfeat = torch.cat([R.cin_layer_gemm_form(xc, [w64[k] for k in range(1, len(Hs) + 1)], F, D, True, True), R.fm_layer(fields)], dim=1)
+        return R.multi_dense_layer(rfeat, w64['hk'], w64['hb']).reshape(-1)
+
+    xt = torch.from_numpy(x)
+    (rs,), _, _ = run_chunked(fwd, xt, None, w64, chunk=512, want_dx=False)
+    close(scores, torch.from_numpy(rs))
+    assert np.abs(rs).std() > 0.05
+    rloss, rds, rP = PO.pairwise_bpr(groups, labels, rs.astype(np.float32))
+    assert int(n_pair.item()) == rP and rP > B // 2
+    assert abs(rloss - np.log(2.0)) > 1e-3
+    close(loss, torch.tensor(rloss, dtype=torch.float64))
+    _, rdx, rgrads = run_chunked(fwd, xt, torch.from_numpy(rds), w64, chunk=512)
+    close(torch.cat([a.grad for a in xd], dim=1), torch.from_numpy(rdx))
+    for k in range(1, len(Hs) + 1):
+        close(cin.idx2weight[k].grad, torch.from_numpy(rgrads[k]))
+    close(head.kernel.grad, torch.from_numpy(rgrads['hk']))
+    close(head.bias.grad, torch.from_numpy(rgrads['hb']), scale=float(np.abs(rds).sum()))      # a sum that cancels to ~0: on the scale of its terms
+
+
 def test_config5_ple_listwise(dev, golden):
     from rec_now_amd.layers.ple_layer import PLELayer
     from rec_now_amd.rec_block.listwise_loss_from_batch import listwise_loss_from_batch

@@ -59,6 +59,33 @@ def test_cin(golden):
     assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
 
 
+def test_cin_gemm_form_equals_line_by_line_form(golden):
+    """oracle/dense_ref.cin_layer_gemm_form (what the full-size chunked oracle evaluates) against the line-by-line restatement:
+    the reference's golden, every output mode, and fp64 gradients on a random case."""
+    import torch
+    g = golden('cin')
+    ws = [T(g['weight_of_layer1']), T(g['weight_of_layer2'])]
+    out = R.cin_layer_gemm_form([T(x) for x in g['inputs']], ws, 10, 3)
+    assert R.calc_sum_of_abs_diff(out.numpy(), g['golden']) < TOL
+    gen = torch.Generator().manual_seed(3)
+    F, D, Hs, B = 5, 4, [6, 3, 7], 9
+    xs = [torch.randn(B, D, generator=gen, dtype=torch.float64) for _ in range(F)]
+    hp = [F] + Hs
+    for oi in (True, False):
+        for sc in (True, False):
+            w_a = [torch.randn(1, 1, hp[k + 1], hp[k] * F, generator=gen, dtype=torch.float64).requires_grad_(True) for k in range(len(Hs))]
+            w_b = [w.detach().clone().requires_grad_(True) for w in w_a]
+            xa = [x.clone().requires_grad_(True) for x in xs]
+            xb = [x.clone().requires_grad_(True) for x in xs]
+            ya, yb = R.cin_layer(xa, w_a, F, D, oi, sc), R.cin_layer_gemm_form(xb, w_b, F, D, oi, sc)
+            assert ya.shape == yb.shape and float((ya - yb).abs().max()) < 1e-12
+            gy = torch.randn(ya.shape, generator=gen, dtype=torch.float64)
+            ya.backward(gy)
+            yb.backward(gy)
+            for a, b in zip(xa + w_a, xb + w_b):
+                assert float((a.grad - b.grad).abs().max()) < 1e-11
+
+
 def ple_layers_from_fixture(g, to=T):
     layers = []
     for li in range(3):
