@@ -56,6 +56,52 @@ def global_listwise_loss(local_loss_sum, local_n_valid):
     return local_loss_sum / denom, stats[0] / denom, stats[1]
 
 
+def gathered_pairwise_loss(outputs, labels, groups, loss_fn=None, **kwargs):
+    """The EXACT in-batch pairwise loss for rows that arrive ARBITRARILY sharded (groups split across ranks), SURVEY.md section 8e
+    variant C3: one all-gather of the (score, label, group) triples (12 bytes per row: 0.8 MB at B = 65 536), then every rank
+    evaluates the loss of the GLOBAL batch on the gathered data -- the pair stage is ~0.1 ms at 65 536 rows, cheaper than any
+    exchange of partial results -- and keeps the gradient of ITS OWN rows: no return exchange.  The pairs are exactly those of
+    /root/reference/rec_now/rec_block/pairwise_loss_from_batch.py:254-274 on the concatenated batch.
+
+    outputs (B_local,) with grad; labels, groups (B_local,).  loss_fn(outputs, labels, groups, **kwargs) -> scalar loss: default
+    `rec_block.pairwise_loss_from_batch.pairwise_loss` (GPU kernels); the CPU tests pass the oracle's.  Shards may be uneven or empty.
+    Returns the global mean loss (identical on every rank); its backward gives d loss_global / d outputs for the local rows, so
+    weight gradients only need the usual SUM all-reduce (`GradientAllReducer.all_reduce()`, no 1/P scaling afterwards).
+    Without a process group this is `loss_fn(outputs, labels, groups)`."""
+    if loss_fn is None:
+        from .rec_block.pairwise_loss_from_batch import pairwise_loss as loss_fn
+    flat = outputs.reshape(-1)
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)):
+        return loss_fn(flat, labels.reshape(-1), groups.reshape(-1), **kwargs)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n_local = flat.numel()
+    counts = torch.zeros(world, dtype=torch.int64, device=flat.device)
+    counts[rank] = n_local
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    counts = [int(c) for c in counts.tolist()]
+    n_max = max(max(counts), 1)
+    # one gather of a (3, n_max) block per rank: scores, labels, group ids (ids as float64 would lose nothing for int64 ids < 2^53;
+    # float32 ids are gathered as they are -- the comparison `g_i - g_j == 0.0` of the reference is on float32)
+    gdt = torch.float64 if groups.dtype in (torch.int64, torch.float64) else torch.float32
+    block = torch.zeros(3, n_max, dtype=gdt, device=flat.device)
+    block[0, :n_local] = flat.detach().to(gdt)
+    block[1, :n_local] = labels.reshape(-1).to(gdt)
+    block[2, :n_local] = groups.reshape(-1).to(gdt)
+    parts = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(parts, block)
+    cat = lambda row: torch.cat([parts[r][row, :counts[r]] for r in range(world)])      # noqa: E731
+    s_all = cat(0).to(flat.dtype).requires_grad_(True)
+    y_all = cat(1).to(labels.dtype)
+    g_all = cat(2).to(groups.dtype)
+    with torch.enable_grad():
+        loss_all = loss_fn(s_all, y_all, g_all, **kwargs)
+        (ds_all,) = torch.autograd.grad(loss_all, s_all, allow_unused=True)
+    lo = sum(counts[:rank])
+    ds_mine = (torch.zeros(n_local, dtype=flat.dtype, device=flat.device) if ds_all is None else ds_all[lo:lo + n_local]).detach()
+    # value = the global loss; gradient w.r.t. the local outputs = this rank's rows of d loss_global / d scores
+    return loss_all.detach() + ((flat - flat.detach()) * ds_mine).sum()
+
+
 class GradientAllReducer(object):
     """SUM-all-reduce of the weight gradients in a few large flat buckets (xGMI is point-to-point: 7 links x ~153 GB/s
     per GPU, ring collectives are per-link bound, so fewer/larger messages win; the hot path's gradients are 3-80 MB)."""

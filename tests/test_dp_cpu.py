@@ -214,3 +214,90 @@ def test_four_ranks_uneven_shards():
 
 def test_four_ranks_with_an_empty_rank():
     _run4(2)
+
+
+# ---- C3 exact variant: arbitrarily sharded rows, one all-gather of (score, label, group) triples -----------------------------
+def _worker_gather(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rec_now_amd import dp
+    g, s, y, w = _make_batch(seed=11, B=700, G=17)
+    owner = np.random.default_rng(5).integers(0, world + 1, len(g)) % world      # rows dealt WITHOUT regard to their group, unevenly
+    owner[owner == world - 1] = 0 if world > 2 else owner[owner == world - 1]
+    mine = owner == rank
+    wt = torch.from_numpy(w.copy()).requires_grad_(True)
+    sc = torch.from_numpy(s[mine]) * wt[0] + wt[1] + wt[2] * torch.from_numpy(s[mine]) ** 2
+    loss = dp.gathered_pairwise_loss(sc, torch.from_numpy(y[mine]), torch.from_numpy(g[mine].astype(np.float32)), loss_fn=R.pairwise_loss)
+    loss.backward()
+    dp.GradientAllReducer([wt]).all_reduce()
+    out[rank] = (float(loss), wt.grad.numpy().copy(), int(mine.sum()), len(np.intersect1d(g[mine], g[~mine])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_arbitrarily_sharded_rows_equal_single_process_through_all_gather():
+    """dp.gathered_pairwise_loss (variant C3): groups are SPLIT across the ranks, yet the loss and the weight gradients
+    equal the single-process ones on the whole batch (rec_block/pairwise_loss_from_batch.py:254-274 on the concatenation)."""
+    for world in (2, 3):
+        port = _free_port()
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker_gather, args=(world, port, out), nprocs=world, join=True)
+        g, s, y, w = _make_batch(seed=11, B=700, G=17)
+        wt = torch.from_numpy(w.copy()).requires_grad_(True)
+        sc = torch.from_numpy(s) * wt[0] + wt[1] + wt[2] * torch.from_numpy(s) ** 2
+        loss = R.pairwise_loss(sc, torch.from_numpy(y), torch.from_numpy(g.astype(np.float32)))
+        loss.backward()
+        assert sum(out[r][2] for r in range(world)) == len(g)
+        assert out[0][3] > 5                                      # groups really are shared between ranks
+        for r in range(world):
+            assert abs(out[r][0] - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))
+            assert np.abs(out[r][1] - wt.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wt.grad.numpy()).max())
+
+
+# ---- in-place protocol of step.DCNMixPairwiseStep: gradients and statistics produced inside the buckets ---------------------
+def _worker_inplace(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rec_now_amd import dp
+    g, s, y, w = _make_batch(seed=13, B=600, G=29)
+    mine = dp.shard_rows_by_group(g, world).numpy() == rank
+    wa = torch.from_numpy(w[:2].copy()).requires_grad_(True)
+    wb = torch.from_numpy(w[2:3].copy()).requires_grad_(True)
+    sc = torch.from_numpy(s[mine]) * wa[0] + wa[1] + wb[0] * torch.from_numpy(s[mine]) ** 2
+    f = lambda p, n, wgt: R.bpr_loss_func(p, n, wgt, 1.0, reduce_mean=False)      # noqa: E731
+    local_sum, n_pair = R.pairwise_loss(sc, torch.from_numpy(y[mine]), torch.from_numpy(g[mine].astype(np.float32)), f, return_num_pair=True)
+    ga, gb = torch.autograd.grad(local_sum, [wa, wb])
+    red = dp.LayerwiseReducer([[wb], [wa]], [None, None], 'cpu')
+    # what the step's kernels do on the GPU: gradients written into the bucket slices, {loss sum, pair count} into the slot
+    red.buffer_of(wb).copy_(gb.reshape(-1))
+    red.buffer_of(wa).copy_(ga.reshape(-1))
+    red.stats_slot().copy_(torch.tensor([float(local_sum), float(n_pair)]))
+    wa.grad, wb.grad = red.buffer_of(wa).view(wa.shape), red.buffer_of(wb).view(wb.shape)
+    red.stage_done(0)
+    red.stage_done(1)
+    loss_val, p_glob = red.reduce_in_place()
+    out[rank] = (float(loss_val), float(p_glob), wa.grad.numpy().copy(), wb.grad.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_in_place_reducer_protocol_equals_single_process():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_inplace, args=(world, port, out), nprocs=world, join=True)
+    g, s, y, w = _make_batch(seed=13, B=600, G=29)
+    wa = torch.from_numpy(w[:2].copy()).requires_grad_(True)
+    wb = torch.from_numpy(w[2:3].copy()).requires_grad_(True)
+    sc = torch.from_numpy(s) * wa[0] + wa[1] + wb[0] * torch.from_numpy(s) ** 2
+    loss, n_pair = R.pairwise_loss(sc, torch.from_numpy(y), torch.from_numpy(g.astype(np.float32)), return_num_pair=True)
+    loss.backward()
+    for r in range(world):
+        lv, pg, ga, gb = out[r]
+        assert pg == n_pair and abs(lv - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))
+        assert np.abs(ga - wa.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wa.grad.numpy()).max())
+        assert np.abs(gb - wb.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wb.grad.numpy()).max())

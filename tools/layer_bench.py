@@ -4,6 +4,8 @@ rows/s and pairs/s for the ranking losses, TFLOP/s for CIN / MMoE / PLE.   usage
 import os
 import sys
 
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')      # see bench.py: ROCm 7.0 graph packet capture + eager launches of the same kernels
+
 import numpy as np
 import torch
 
@@ -28,6 +30,8 @@ def timeit(fn, n=reps, warm=10):
 def timeit_graph(fn, n=reps):
     """The same step replayed from a captured HIP graph: no Python or launch overhead between kernels, i.e. the GPU time of
     the step.  Returns None when the step cannot be captured (data-dependent host work)."""
+    if os.environ.get('RECNOW_LB_NOGRAPH') == '1':      # under rocprofv3: the eager launches are what gets traced
+        return None
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
