@@ -195,7 +195,7 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
     s += rn_align((size_t)m.LDT * D * sizeof(float));        // dWc2
     s += 3 * act_block(m);                                   // dT2g, dC, dT1
     s += 2 * xbuf(m);                                        // inter-layer gradient ping-pong
-    s += 2 * rn_align(mix_gemm_ws(m));                       // split-K slabs: chain stream + side stream
+    s += 3 * rn_align(mix_gemm_ws(m));                       // split-K slabs: chain stream, dU and dW (the last two are reduced together at the layer's end)
     s += rn_mix_mid_bwd_ws_bytes(B, S, N);                   // per-workgroup dV partials of the fused sub-space backward
     s += (size_t)L * (rn_align((size_t)D * m.LDT * sizeof(float)) + rn_align((size_t)m.LDT * D * sizeof(float)));   // per-layer packs
     s += rn_align(rn_colsum_ws_bytes(B, 1));                 // fused scoring head: d bias = sum of dscores
@@ -278,8 +278,9 @@ static inline int gate_grid(int64_t B) {
 
 // Sub-space stage: the fused streaming kernels of dcnmix_mid.hip when the shape fits them, else batched GEMMs + gate kernels.
 static int mix_mid_fwd(const MixDims& m, const float* T1, const float* V, float* T2, float* T2g, int act_outer, void* gws,
-                       size_t gws_bytes, hipStream_t st) {
-    if (rn_mix_mid_supported(m.S, m.N, m.LDT)) return rn_mix_mid_fwd(T1, V, T2, T2g, m.B, m.S, m.N, m.LDT, act_outer, st);
+                       size_t gws_bytes, hipStream_t st, const RnSlabs* slabs = nullptr, int act_inner = 0) {
+    if (rn_mix_mid_supported(m.S, m.N, m.LDT)) return rn_mix_mid_fwd(T1, V, T2, T2g, m.B, m.S, m.N, m.LDT, act_outer, st, slabs, act_inner);
+    if (slabs) return RECNOW_EUNSUPPORTED;
     int rc;
     {   // GEMM2: H2_n = act_outer(H1_n V_n), batched over the N experts
         recnow_gemm_desc d = rn_gemm_desc_zero();
@@ -468,6 +469,9 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             } else if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) {
                 return rc;
             }
+            RnDeferredReduce red1;
+            red1.valid = 0;
+            const bool absorb = rn_mix_mid_absorbs_slabs(B, S, N, m.LDT);
             {   // GEMM1: T1[:, :NS] = act_inner(x_l U);  gate logits T1[:, NS:NS+N] = x_l K as the VALU side product
                 recnow_gemm_desc d = rn_gemm_desc_zero();
                 d.A = xl; d.lda = D; d.a_trans = 0;
@@ -477,9 +481,17 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.act = act_inner;
                 d.sp_bx = gate_host[l]; d.sp_bx_ks = N; d.sp_bx_rs = 1; d.sp_cx = T1 + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
-                if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+                // a shard small enough for this product to be split over K: the sub-space kernel sums the slabs (and applies act_inner)
+                // on its way in -- no reduction launch
+                if (absorb) rc = rn_gemm_deferred(&d, gws, gws_bytes, st, &red1);
+                else rc = rn_gemm(&d, gws, gws_bytes, st);
+                if (rc) return rc;
             }
-            if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
+            if (absorb && red1.valid) {
+                RnSlabs sl;
+                rn_deferred_slabs(&red1, &sl.p, &sl.n, &sl.ld, &sl.stride);
+                if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st, &sl, act_inner))) return rc;
+            } else if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
             {   // GEMM3: out = x * ([G*H2 | G | 0] [W; b; 0]): K zero-padded NS+N -> KP (a 16-deep k-tile more is cheaper
                 // than a rank-N epilogue update: 215 vs 233 us measured)
                 recnow_gemm_desc d = rn_gemm_desc_zero();
@@ -601,6 +613,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     if (l_hi < 0) l_hi = L - 1;
     if (l_lo < 0 || l_lo > l_hi || l_hi > L - 1) return RECNOW_EINVAL;
     const bool top = l_hi == L - 1;
+    const bool defer_dv = rn_mix_mid_supported(S, N, m.LDT);      // the fused sub-space kernel leaves its dV partials for the layer-end reduction
     const bool two = st2 != nullptr && st2 != st;
     if (!two) st2 = st;
     // RECNOW_TWO_STREAMS=2 ("paired"): BOTH weight-gradient products of a layer (MFMA-bound) are held back until the sub-space
@@ -616,7 +629,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     float* gbuf1 = c.take<float>(xbuf(m) / sizeof(float));
     const size_t gemm_ws = mix_gemm_ws(m);
     void* gws = c.take<char>(gemm_ws);                              // split-K slabs of the chain stream
-    void* gws2 = c.take<char>(gemm_ws);                             // ... and of the side stream
+    void* gws2 = c.take<char>(gemm_ws);                             // ... of the dU product
+    void* gws3 = c.take<char>(gemm_ws);                             // ... of the dW product (kept until the layer-end reduction)
     const size_t mid_ws_bytes = rn_mix_mid_bwd_ws_bytes(B, S, N);
     void* mid_ws = c.take<char>(mid_ws_bytes);
     const size_t cs_ws_bytes = rn_colsum_ws_bytes(B, 1);
@@ -666,6 +680,9 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));
         float* gprev = (l == 0) ? nullptr : ((l & 1) ? gbuf0 : gbuf1);
         const float* Wc1 = Wc1_all + (size_t)l * D * m.LDT;
+        RnDeferredReduce red_dw, red_du, red_t2g;
+        red_dw.valid = red_du.valid = red_t2g.valid = 0;
+        const bool absorb_bwd = defer_dv && rn_mix_mid_absorbs_slabs(B, S, N, m.LDT);
         // ---------------- side stream, part 1: needs only g_l and saved activations
         auto side_dw = [&]() -> int {
             // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
@@ -681,12 +698,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = D; d.N = m.NS; d.K = (int)B;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.sp_bx = d.B + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
-            if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
-            if (top_head) {      // dW = w_head * M^T, dbias likewise, d w_head = sum_k [W; b] * M^T
-                hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw,
-                                   ds_part, ds_nparts, ds_part ? hd->db : nullptr);
-                RN_LAUNCH_CHECK();
-            }
+            // the slab reduction waits for the layer's end (one launch with dU's and the dV partial sum)
+            if ((rc = rn_gemm_deferred(&d, gws3, gemm_ws, st2, &red_dw))) return rc;
             return RECNOW_OK;
         };
         if (!(two && paired)) {
@@ -710,12 +723,26 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
                 d.as_in = omid + (size_t)l * (xbuf(m) / sizeof(float));
                 d.as_out = dx;
             }
-            if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
+            // split over K at small shards: the sub-space kernel sums the slabs on its way in (no reduction launch)
+            if (absorb_bwd) rc = rn_gemm_deferred(&d, gws, gemm_ws, st, &red_t2g);
+            else rc = rn_gemm(&d, gws, gemm_ws, st);
+            if (rc) return rc;
+        }
+        RnSlabs sl_t2g;
+        const RnSlabs* slp = nullptr;
+        if (absorb_bwd && red_t2g.valid) {
+            rn_deferred_slabs(&red_t2g, &sl_t2g.p, &sl_t2g.n, &sl_t2g.ld, &sl_t2g.stride);
+            slp = &sl_t2g;
         }
         MIX_WAIT(e_side_prev, st);          // dT1 (and the g buffer about to be rewritten) are free again
         // gate backward, dA_n = (dC_n V_n^T) * act_inner'(H1_n) and dV_n = H1_n^T dC_n
         if (hd && l == L - 1) {
-            if ((rc = rn_mix_mid_bwd(dT2g, T2, T1, V_host[l], dT1, dV_host[l], B, S, N, m.LDT, act_inner, act_outer, mid_ws, mid_ws_bytes, st, hd->dscores)))
+            if ((rc = rn_mix_mid_bwd(dT2g, T2, T1, V_host[l], dT1, dV_host[l], B, S, N, m.LDT, act_inner, act_outer, mid_ws, mid_ws_bytes, st, hd->dscores,
+                                     defer_dv, slp)))
+                return rc;
+        } else if (defer_dv) {
+            if ((rc = rn_mix_mid_bwd(dT2g, T2, T1, V_host[l], dT1, dV_host[l], B, S, N, m.LDT, act_inner, act_outer, mid_ws, mid_ws_bytes, st, nullptr, true,
+                                     slp)))
                 return rc;
         } else if ((rc = mix_mid_bwd(m, dT2g, T2, T1, V_host[l], dC, dT1, dV_host[l], act_inner, act_outer, mid_ws, mid_ws_bytes, gws, gemm_ws, st)))
             return rc;
@@ -752,7 +779,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             // K = B is always split at these sizes: the slab reduce stores dU (N, D, S) directly; without a split, unpack afterwards
             recnow_gemm_desc dq = d;
             dq.C = dU_host[l]; dq.c_perm_s = S;
-            rc = rn_gemm(&dq, gws2, gemm_ws, st2);
+            rc = rn_gemm_deferred(&dq, gws2, gemm_ws, st2, &red_du);
             if (rc == RECNOW_EUNSUPPORTED) {
                 if ((rc = rn_gemm(&d, gws2, gemm_ws, st2))) return rc;
                 hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st2, dWc1, D, S, N, dU_host[l]);
@@ -760,6 +787,14 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             } else if (rc) {
                 return rc;
             }
+        }
+        // the layer's end: slab reductions of dW (+ dbias) and dU (+ dgate) and the dV partial sum in ONE launch
+        if ((rc = rn_layer_end_reduce(&red_dw, &red_du, defer_dv ? (const float*)mid_ws : nullptr, rn_mix_mid_bwd_nparts(B), N * S * S, dV_host[l], st2)))
+            return rc;
+        if (hd && l == L - 1) {      // dW = w_head * M^T, dbias likewise, d w_head = sum_k [W; b] * M^T (on the reduced M^T)
+            hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw,
+                               ds_part, ds_nparts, ds_part ? hd->db : nullptr);
+            RN_LAUNCH_CHECK();
         }
         MIX_SIGNAL(e_side_prev, st2);
         // every weight gradient of layer l has been issued (dW, dbias above; dV in the sub-space kernel; dU, dgate just now): a

@@ -316,10 +316,12 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
 // of a row, and the transposing LDS writes of a 32-lane group go to rows r .. r + 3 x chunks 0 .. 7, i.e. 32 distinct banks (row
 // stride 129 floats); with 32 lanes on ONE row (chunks 0 .. 31) lanes l and l + 8 shared a bank: 4-way conflicts on every staging
 // write (counters: 36 % / 60 % of the LDS cycles of the forward / backward kernel were conflicts).
-template <int S, int N, int AO>
+template <int S, int N, int AO, bool SL>
 __device__ __forceinline__ void mid_fwd_fast_body(const float* __restrict__ T1, const float* __restrict__ V, float* __restrict__ T2,
-                                                  float* __restrict__ T2g, int64_t B, int LDT, int act_outer_rt) {
+                                                  float* __restrict__ T2g, int64_t B, int LDT, int act_outer_rt, const RnSlabs sl, int act_inner) {
     const int act_outer = AO >= 0 ? AO : act_outer_rt;       // compile-time activation: no per-element switch in the store loop
+    float* const T1out = const_cast<float*>(T1);             // SL: T1 is written (the backward pass reads it), not read
+    int64_t pr0 = 0;                                         // SL: first row of the prefetched tile
     extern __shared__ float lds[];
     constexpr int NS = N * S, LDA = NS + 1, CPR = NS / 4, NCH = MID_ROWS * CPR / 256;
     static_assert(NS == 128 && NCH == 4 && N * (S / 32) == 4, "N * S = 128");
@@ -332,6 +334,27 @@ __device__ __forceinline__ void mid_fwd_fast_body(const float* __restrict__ T1, 
     float4 pv[NCH];
     float plg[N];
     auto prefetch = [&](int64_t r0) {
+        if constexpr (SL) {
+            // the product that feeds this kernel was split over K: its slabs are summed here (slab order, fp32: at most K / 256 = 4 terms
+            // of a K = 1024 product) and the activation of the product's epilogue is applied when the tile is staged
+            pr0 = r0;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < N; ++n) plg[n] = 0.f;
+            for (int s = 0; s < sl.n; ++s) {            // block-uniform trip count, every load unconditional
+                const float* __restrict__ P = sl.p + (int64_t)s * sl.stride;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int r = 4 * (tid >> 5) + ((tid >> 3) & 3), k4 = ((tid & 7) + 8 * i) * 4;
+                    const float4 t = *reinterpret_cast<const float4*>(P + (r0 + r) * sl.ld + k4);
+                    pv[i].x += t.x; pv[i].y += t.y; pv[i].z += t.z; pv[i].w += t.w;
+                }
+#pragma unroll
+                for (int n = 0; n < N; ++n) plg[n] += P[(r0 + (tid & 31)) * sl.ld + NS + n];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int r = 4 * (tid >> 5) + ((tid >> 3) & 3), k4 = ((tid & 7) + 8 * i) * 4;      // see the note on the chunk mapping above
@@ -344,8 +367,16 @@ __device__ __forceinline__ void mid_fwd_fast_body(const float* __restrict__ T1, 
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int r = 4 * (tid >> 5) + ((tid >> 3) & 3), k4 = ((tid & 7) + 8 * i) * 4;      // see the note on the chunk mapping above
+            if constexpr (SL) {                // H1 = act_inner(x_l U) leaves for the backward pass from here; logits by every thread of the row
+                pv[i] = make_float4(rn_act(pv[i].x, act_inner), rn_act(pv[i].y, act_inner), rn_act(pv[i].z, act_inner), rn_act(pv[i].w, act_inner));
+                *reinterpret_cast<float4*>(T1out + (pr0 + r) * LDT + k4) = pv[i];
+            }
             float* d = As + r * LDA + k4;
             d[0] = pv[i].x; d[1] = pv[i].y; d[2] = pv[i].z; d[3] = pv[i].w;
+        }
+        if constexpr (SL) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) T1out[(pr0 + (tid & 31)) * LDT + NS + n] = plg[n];
         }
         if (tid < MID_ROWS) {
             float mx = -INFINITY;
@@ -406,18 +437,18 @@ __device__ __forceinline__ void mid_fwd_fast_body(const float* __restrict__ T1, 
     }
 }
 
-template <int S, int N>
+template <int S, int N, bool SL = false>
 __global__ void __launch_bounds__(256, 2)
 k_mix_mid_fwd_fast(const float* __restrict__ T1, const float* __restrict__ V, float* __restrict__ T2, float* __restrict__ T2g, int64_t B,
-                   int LDT, int act_outer) {
-    if (act_outer == RECNOW_ACT_TANH) mid_fwd_fast_body<S, N, RECNOW_ACT_TANH>(T1, V, T2, T2g, B, LDT, act_outer);
-    else mid_fwd_fast_body<S, N, -1>(T1, V, T2, T2g, B, LDT, act_outer);
+                   int LDT, int act_outer, const RnSlabs sl, int act_inner) {
+    if (act_outer == RECNOW_ACT_TANH) mid_fwd_fast_body<S, N, RECNOW_ACT_TANH, SL>(T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner);
+    else mid_fwd_fast_body<S, N, -1, SL>(T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner);
 }
 
-template <int S, int N, bool RS, int AI, int AO>
+template <int S, int N, bool RS, int AI, int AO, bool SL>
 __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1,
                                                   const float* __restrict__ V, float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B,
-                                                  int LDT, int act_inner_rt, int act_outer_rt, const float* __restrict__ rscale) {
+                                                  int LDT, int act_inner_rt, int act_outer_rt, const float* __restrict__ rscale, const RnSlabs sl) {
     const int act_inner = AI >= 0 ? AI : act_inner_rt, act_outer = AO >= 0 ? AO : act_outer_rt;
     extern __shared__ float lds[];
     constexpr int NS = N * S, LDA = NS + 1, CPR = NS / 4, NCH = MID_ROWS * CPR / 256, GL = S / 4;
@@ -450,7 +481,7 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
         for (int i = 0; i < NCH; ++i) {
             const int r = 4 * (tid >> 5) + ((tid >> 3) & 3), k4 = ((tid & 7) + 8 * i) * 4, n = k4 / S;
             const int64_t row = r0 + r;
-            pd[i] = *reinterpret_cast<const float4*>(dT2g + row * LDT + k4);
+            if constexpr (!SL) pd[i] = *reinterpret_cast<const float4*>(dT2g + row * LDT + k4);
             ph[i] = *reinterpret_cast<const float4*>(T2 + row * LDT + k4);
             pa[i] = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
             pg[i] = T2[row * LDT + NS + n];
@@ -460,9 +491,26 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
 #pragma unroll
         for (int n = 0; n < N; ++n) {
             pgg[n] = T2[grow * LDT + NS + n];
-            pdg[n] = dT2g[grow * LDT + NS + n];
+            if constexpr (!SL) pdg[n] = dT2g[grow * LDT + NS + n];
         }
         if (RS) psg = rscale[grow];
+        if constexpr (SL) {       // the dT2g product was split over K: its slabs are summed here (slab order, fp32, at most 4 terms)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < N; ++n) pdg[n] = 0.f;
+            for (int sb = 0; sb < sl.n; ++sb) {          // block-uniform trip count, every load unconditional
+                const float* __restrict__ P = sl.p + (int64_t)sb * sl.stride;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int r = 4 * (tid >> 5) + ((tid >> 3) & 3), k4 = ((tid & 7) + 8 * i) * 4;
+                    const float4 t = *reinterpret_cast<const float4*>(P + (r0 + r) * sl.ld + k4);
+                    pd[i].x += t.x; pd[i].y += t.y; pd[i].z += t.z; pd[i].w += t.w;
+                }
+#pragma unroll
+                for (int n = 0; n < N; ++n) pdg[n] += P[grow * sl.ld + NS + n];
+            }
+        }
     };
     auto stage = [&]() {
         float ppv[NCH];
@@ -572,14 +620,14 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
     }
 }
 
-template <int S, int N, bool RS>
+template <int S, int N, bool RS, bool SL = false>
 __global__ void __launch_bounds__(256, 2)
 k_mix_mid_bwd_fast(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1, const float* __restrict__ V,
                    float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B, int LDT, int act_inner, int act_outer,
-                   const float* __restrict__ rscale) {
+                   const float* __restrict__ rscale, const RnSlabs sl) {
     if (act_inner == RECNOW_ACT_TANH && act_outer == RECNOW_ACT_TANH)
-        mid_bwd_fast_body<S, N, RS, RECNOW_ACT_TANH, RECNOW_ACT_TANH>(dT2g, T2, T1, V, dT1, dVpart, B, LDT, act_inner, act_outer, rscale);
-    else mid_bwd_fast_body<S, N, RS, -1, -1>(dT2g, T2, T1, V, dT1, dVpart, B, LDT, act_inner, act_outer, rscale);
+        mid_bwd_fast_body<S, N, RS, RECNOW_ACT_TANH, RECNOW_ACT_TANH, SL>(dT2g, T2, T1, V, dT1, dVpart, B, LDT, act_inner, act_outer, rscale, sl);
+    else mid_bwd_fast_body<S, N, RS, -1, -1, SL>(dT2g, T2, T1, V, dT1, dVpart, B, LDT, act_inner, act_outer, rscale, sl);
 }
 
 // dV[i] = sum over workgroup partials, fixed order: 64 elements x 16 strided part groups per block, then a 16-term LDS sum.
@@ -614,17 +662,32 @@ static int mid_allow_lds(K kernel, size_t bytes) {
     return RECNOW_OK;
 }
 
-int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64_t B, int S, int N, int LDT, int act_outer, hipStream_t st) {
+static const bool g_mid_fast = []() { const char* e = getenv("RECNOW_MID_FAST"); return !e || e[0] != '0'; }();      // A/B switch
+bool rn_mix_mid_absorbs_slabs(int64_t B, int S, int N, int LDT) {
+    static const bool on = []() { const char* e = getenv("RECNOW_MID_SLABS"); return !e || e[0] != '0'; }();            // A/B switch
+    return on && g_mid_fast && B % MID_ROWS == 0 && ((S == 64 && N == 2) || (S == 32 && N == 4)) && LDT == S * N + 16;
+}
+int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64_t B, int S, int N, int LDT, int act_outer, hipStream_t st,
+                   const RnSlabs* slabs, int act_inner) {
     if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
+    if (slabs && !rn_mix_mid_absorbs_slabs(B, S, N, LDT)) return RECNOW_EUNSUPPORTED;
+    RnSlabs sl;
+    sl.p = nullptr; sl.n = 0; sl.ld = 0; sl.stride = 0;
+    if (slabs) sl = *slabs;
     const size_t lds = mid_fwd_lds(S, N);
     int rc;
     // measurement hook: read T1, write T2 and T2g (12 * B * LDT bytes)
     RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_MIX_MID_FWD, 4.0 * B * N * S * S, 12.0 * B * LDT, st) : nullptr;
-    static const bool mid_fast = []() { const char* e = getenv("RECNOW_MID_FAST"); return !e || e[0] != '0'; }();      // A/B switch
+    const bool mid_fast = g_mid_fast;
 #define MID_FWD_FAST(SS, NN)                                                                                                  \
     if (mid_fast && B % MID_ROWS == 0 && S == SS && N == NN && LDT == SS * NN + 16) {                                         \
-        if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN>, lds))) return rc;                                                 \
-        hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer); \
+        if (slabs) {                                                                                                          \
+            if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN, true>, lds))) return rc;                                       \
+            hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN, true>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner); \
+        } else {                                                                                                              \
+            if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN, false>, lds))) return rc;                                      \
+            hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN, false>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner); \
+        }                                                                                                                     \
         rn_prof_end(pr, st);                                                                                                  \
         RN_LAUNCH_CHECK();                                                                                                    \
         return RECNOW_OK;                                                                                                     \
@@ -645,8 +708,13 @@ int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64
 }
 
 int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const float* V, float* dT1, float* dV, int64_t B, int S, int N,
-                   int LDT, int act_inner, int act_outer, void* ws, size_t ws_bytes, hipStream_t st, const float* rscale) {
+                   int LDT, int act_inner, int act_outer, void* ws, size_t ws_bytes, hipStream_t st, const float* rscale, bool defer_dv,
+                   const RnSlabs* slabs) {
     if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
+    if (slabs && !rn_mix_mid_absorbs_slabs(B, S, N, LDT)) return RECNOW_EUNSUPPORTED;
+    RnSlabs sl;
+    sl.p = nullptr; sl.n = 0; sl.ld = 0; sl.stride = 0;
+    if (slabs) sl = *slabs;
     if (ws_bytes < rn_mix_mid_bwd_ws_bytes(B, S, N)) return RECNOW_EWORKSPACE;
     const size_t lds = mid_bwd_lds(S, N);
     const int grid = mid_grid(B);
@@ -660,16 +728,22 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
         if ((rc = mid_allow_lds(k_mix_mid_bwd<SS, VV>, lds))) return rc;                                                      \
         hipLaunchKernelGGL((k_mix_mid_bwd<SS, VV>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, N, LDT, act_inner, act_outer, rscale); \
     } while (0)
-    static const bool mid_fast = []() { const char* e = getenv("RECNOW_MID_FAST"); return !e || e[0] != '0'; }();      // A/B switch
+    const bool mid_fast = g_mid_fast;
     bool done = false;
 #define MID_BWD_FAST(SS, NN)                                                                                                  \
     if (!done && mid_fast && B % MID_ROWS == 0 && S == SS && N == NN && LDT == SS * NN + 16) {                                                    \
-        if (rscale) {                                                                                                         \
-            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true>, lds))) return rc;                                       \
-            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale); \
+        if (rscale && slabs) {                                                                                                \
+            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true, true>, lds))) return rc;                                 \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true, true>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); \
+        } else if (rscale) {                                                                                                  \
+            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true, false>, lds))) return rc;                                \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true, false>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); \
+        } else if (slabs) {                                                                                                   \
+            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false, true>, lds))) return rc;                                \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false, true>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); \
         } else {                                                                                                              \
-            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false>, lds))) return rc;                                      \
-            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale); \
+            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false, false>, lds))) return rc;                               \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false, false>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); \
         }                                                                                                                     \
         done = true;                                                                                                          \
     }
@@ -688,8 +762,10 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
 #undef MID_BWD
     rn_prof_end(pr, st);
     RN_LAUNCH_CHECK();
+    if (defer_dv) return RECNOW_OK;
     const int total = N * S * S;
     hipLaunchKernelGGL(k_mix_dv_reduce, rn_cdiv(total, 64), 1024, 0, st, part, grid, total, dV);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
+int rn_mix_mid_bwd_nparts(int64_t B) { return mid_grid(B); }

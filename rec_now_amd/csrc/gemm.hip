@@ -22,8 +22,7 @@
 // the threads and loads in flight -- an output of 1024 x 132 floats is 33 792 float4, i.e. 132 workgroups of threads that each walk
 // 64 slabs with four loads in flight (10.5 us for 35 MB that the product has just left in the memory-side cache).
 template <bool VEC, bool QUAD>
-__global__ void __launch_bounds__(256)
-k_gemm_splitk_reduce(const GemmK p) {
+__device__ __forceinline__ void splitk_reduce_body(const GemmK& p, const int bid, const int nblk) {
     constexpr int W = VEC ? 4 : 1;
     constexpr int NQ = QUAD ? 4 : 1;
     const int64_t MN = (int64_t)p.M * p.npart;          // one slab
@@ -31,7 +30,7 @@ k_gemm_splitk_reduce(const GemmK p) {
     const int q = QUAD ? (threadIdx.x & 3) : 0;
     const int per = (p.splitk + NQ - 1) / NQ, k_lo = q * per, k_hi = min(p.splitk, k_lo + per);
     // QUAD: every lane of a quad runs the loop for the quad's element (whole quads are in or out: total is rounded up by the caller's grid)
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / NQ; i < total; i += (int64_t)gridDim.x * blockDim.x / NQ) {
+    for (int64_t i = ((int64_t)bid * 256 + threadIdx.x) / NQ; i < total; i += (int64_t)nblk * 256 / NQ) {
         const int64_t e0 = i * W;
         const int b = (int)(e0 / MN);
         const int64_t mn = e0 % MN;
@@ -88,6 +87,45 @@ k_gemm_splitk_reduce(const GemmK p) {
             *dst = v;
         }
     }
+}
+template <bool VEC, bool QUAD>
+__global__ void __launch_bounds__(256)
+k_gemm_splitk_reduce(const GemmK p) {
+    splitk_reduce_body<VEC, QUAD>(p, blockIdx.x, gridDim.x);
+}
+
+// One launch at the end of a DCN-v2 cross layer's backward: the slab reductions of its two K = B weight-gradient products (dW with
+// dbias riding as side columns, dU with dgate) and the sum of the sub-space kernel's per-workgroup dV partials -- three launches of a
+// few microseconds each otherwise.  Blocks [0, na) run reduction a, [na, na + nb) reduction b, the rest the dV sum (64 columns per
+// block: 4 strided groups of partials, fixed order, then a 4-term LDS sum).
+__device__ __forceinline__ void reduce_variant(const GemmK& p, int variant, int bid, int nblk) {
+    if (variant == 2) splitk_reduce_body<true, true>(p, bid, nblk);
+    else if (variant == 1) splitk_reduce_body<true, false>(p, bid, nblk);
+    else splitk_reduce_body<false, false>(p, bid, nblk);
+}
+__global__ void __launch_bounds__(256)
+k_layer_end_reduce(const GemmK pa, int va, int na, const GemmK pb, int vb, int nb, const float* __restrict__ dv_part, int dv_nparts, int dv_total,
+                   float* __restrict__ dV) {
+    const int bid = blockIdx.x;
+    if (bid < na) { reduce_variant(pa, va, bid, na); return; }
+    if (bid < na + nb) { reduce_variant(pb, vb, bid - na, nb); return; }
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = (bid - na - nb) * 64 + e;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    if (i < dv_total) {
+        int g = q;
+        for (; g + 4 * 7 < dv_nparts; g += 4 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += dv_part[(int64_t)(g + 4 * u) * dv_total + i];
+        }
+        for (; g < dv_nparts; g += 4) s[0] += dv_part[(int64_t)g * dv_total + i];
+    }
+    red[q][e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (q == 0 && i < dv_total) dV[i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // ---- host dispatch -------------------------------------------------------------------------------------
@@ -169,7 +207,9 @@ static bool gemm_interior(const recnow_gemm_desc* d, const GemmCfg& c, int bk, i
     return true;
 }
 
-int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
+static_assert(sizeof(GemmK) <= sizeof(((RnDeferredReduce*)nullptr)->k), "RnDeferredReduce::k holds a GemmK");
+static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st, RnDeferredReduce* defer) {
+    if (defer) defer->valid = 0;
     if (!d || d->M < 0 || d->N < 0 || d->K < 0 || d->batch < 0) return RECNOW_EINVAL;
     if (d->M == 0 || d->N == 0 || d->batch == 0) return RECNOW_OK;
     if (!d->A || !d->B || !d->C) return RECNOW_EINVAL;
@@ -308,12 +348,54 @@ int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st
         int g = rn_cdiv(total, 256);
         if (g > 2048) g = 2048;
         static const bool quad_reduce = []() { const char* e = getenv("RECNOW_REDUCE_QUAD"); return !e || e[0] != '0'; }();      // A/B switch
-        if (d->N % 4 == 0 && quad_reduce && k.splitk >= 16 && (total / 4) % 64 == 0)      // whole quads per wave: the shuffles need all four lanes in the loop
-            hipLaunchKernelGGL((k_gemm_splitk_reduce<true, true>), rn_cdiv(total, 256) > 4096 ? 4096 : rn_cdiv(total, 256), 256, 0, st, k);
-        else if (d->N % 4 == 0) hipLaunchKernelGGL((k_gemm_splitk_reduce<true, false>), rn_cdiv(total / 4, 256) > 2048 ? 2048 : rn_cdiv(total / 4, 256), 256, 0, st, k);
-        else hipLaunchKernelGGL((k_gemm_splitk_reduce<false, false>), g, 256, 0, st, k);
+        int variant = 0, blocks = g;
+        if (d->N % 4 == 0 && quad_reduce && k.splitk >= 16 && (total / 4) % 64 == 0) {      // whole quads per wave: the shuffles need all four lanes in the loop
+            variant = 2;
+            blocks = rn_cdiv(total, 256) > 4096 ? 4096 : rn_cdiv(total, 256);
+        } else if (d->N % 4 == 0) {
+            variant = 1;
+            blocks = rn_cdiv(total / 4, 256) > 2048 ? 2048 : rn_cdiv(total / 4, 256);
+        }
+        if (defer) {             // the caller runs the reduction (rn_layer_end_reduce)
+            memcpy(defer->k, &k, sizeof(GemmK));
+            defer->variant = variant;
+            defer->blocks = blocks;
+            defer->valid = 1;
+            return RECNOW_OK;
+        }
+        if (variant == 2) hipLaunchKernelGGL((k_gemm_splitk_reduce<true, true>), blocks, 256, 0, st, k);
+        else if (variant == 1) hipLaunchKernelGGL((k_gemm_splitk_reduce<true, false>), blocks, 256, 0, st, k);
+        else hipLaunchKernelGGL((k_gemm_splitk_reduce<false, false>), blocks, 256, 0, st, k);
         RN_LAUNCH_CHECK();
     }
+    return RECNOW_OK;
+}
+int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st) { return rn_gemm_impl(d, ws, ws_bytes, st, nullptr); }
+int rn_gemm_deferred(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st, RnDeferredReduce* out) {
+    if (!out) return RECNOW_EINVAL;
+    return rn_gemm_impl(d, ws, ws_bytes, st, out);
+}
+void rn_deferred_slabs(const RnDeferredReduce* r, const float** partial, int* nsplit, int* ld, int64_t* stride) {
+    GemmK k;
+    memcpy(&k, r->k, sizeof(GemmK));
+    *partial = k.partial;
+    *nsplit = k.splitk;
+    *ld = k.npart;
+    *stride = (int64_t)k.M * k.npart;
+}
+int rn_layer_end_reduce(const RnDeferredReduce* a, const RnDeferredReduce* b, const float* dv_part, int dv_nparts, int dv_total, float* dV,
+                        hipStream_t st) {
+    GemmK ka, kb;
+    memset(&ka, 0, sizeof(ka));
+    memset(&kb, 0, sizeof(kb));
+    const int na = (a && a->valid) ? a->blocks : 0, nb = (b && b->valid) ? b->blocks : 0;
+    if (na) memcpy(&ka, a->k, sizeof(GemmK));
+    if (nb) memcpy(&kb, b->k, sizeof(GemmK));
+    const int nv = (dv_part && dV && dv_nparts > 0 && dv_total > 0) ? rn_cdiv(dv_total, 64) : 0;
+    if (na + nb + nv == 0) return RECNOW_OK;
+    hipLaunchKernelGGL(k_layer_end_reduce, na + nb + nv, 256, 0, st, ka, na ? a->variant : 0, na, kb, nb ? b->variant : 0, nb, dv_part, dv_nparts,
+                       dv_total, dV);
+    RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
 

@@ -6,6 +6,21 @@
 // C[b] = epilogue( opA(A[b]) * opB(B[b]) ), b = 0..batch-1, see recnow_gemm_desc in include/recnow.h
 int rn_gemm(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d);
+// A split-K product whose slab reduction is left to the caller: rn_gemm_deferred launches the product only and describes the
+// reduction; rn_layer_end_reduce then runs up to two such reductions and the dV partial sum of the sub-space backward kernel as ONE
+// launch (DCN-v2: the dW, dU and dV of a cross layer end in one launch instead of three).  `valid == 0`: the product was not
+// split, its output is final.  The slabs (`ws`) must stay untouched until the reduction has run.
+struct RnDeferredReduce {
+    alignas(16) char k[1024];      // the launch's GemmK
+    int variant;                   // k_gemm_splitk_reduce<VEC, QUAD>: 0 <false,false>, 1 <true,false>, 2 <true,true>
+    int blocks;
+    int valid;
+};
+int rn_gemm_deferred(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st, RnDeferredReduce* out);
+// the slabs of a deferred (valid) product: slab s, row m, column c at partial[s * stride + m * ld + c]; side columns behind the N main ones
+void rn_deferred_slabs(const RnDeferredReduce* r, const float** partial, int* nsplit, int* ld, int64_t* stride);
+int rn_layer_end_reduce(const RnDeferredReduce* a, const RnDeferredReduce* b, const float* dv_part, int dv_nparts, int dv_total, float* dV,
+                        hipStream_t st);
 // 0 = exact fp32 MFMA (default), 1 = bf16x3 split for the products that have a split kernel (gemm_split.hip)
 int rn_gemm_precision();
 int rn_gemm_set_precision(int mode);

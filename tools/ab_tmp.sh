@@ -7,5 +7,6 @@ r=d.get('roofline') or {}
 print(sys.argv[1].split('/')[-1], 'ms %.3f'%d['ms_per_step'], 'host %.3f'%d['config']['host_enqueue_ms_per_step'], 'graph', d['config']['hip_graph'], 'par', d['parity_max_rel'], 'gemm us %.1f'%(r.get('avg_launch_us') or 0))
 PY
 }
-for rows in 8192 16384 32768 65536; do
-for ts in 0 1; do RECNOW_STEP_TWO_STREAMS=$ts run efd_ts${ts}_$rows --rows $rows --force-dist --eager || exit 1; done; done
+run plain_65536 || exit 1
+for rows in 65536 32768 16384 8192; do run efd_$rows --rows $rows --force-dist || exit 1; done
+run plain_8192 --rows 8192 || exit 1
