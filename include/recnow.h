@@ -131,6 +131,18 @@ int recnow_pair_bpr_onepass(const float* scores, const float* labels, const uint
 int recnow_pair_scale_grad(const float* dscores_unnorm, const float* g, const int64_t* n_pair, float eps, int64_t B, float* out,
                            void* stream);
 
+/* pairwise_loss(outputs, labels, groups) with the reference's defaults (pairloss_func = bpr_loss_func, click_occurance_power = 0,
+ * one group tensor; rec_block/pairwise_loss_from_batch.py:228-279) as ONE call: grouping (the single-launch front end when
+ * recnow_pairwise_small_supported, else keys + radix sort + segments), the one-walk loss and the gradient
+ *   dscores[k] = d loss / d scores[k]   (already divided by P + 1e-10 when reduce_mean),
+ * so that a host framework's backward is one multiply by the incoming gradient.  One workspace holds every intermediate
+ * (recnow_pairwise_loss_workspace_bytes); out2 (2 floats, optional) receives {loss, (float) P} beside loss / n_pair.
+ * flags: RECNOW_PAIR_LABEL_GT [| RECNOW_PAIR_WRONG_ORDER].  mask may be NULL. */
+size_t recnow_pairwise_loss_workspace_bytes(int64_t B, int key_dtype);
+int recnow_pairwise_loss(const void* groups, int key_dtype, const float* labels, const float* scores, const uint8_t* mask, int64_t B,
+                         int flags, float factor, int reduce_mean, float* loss, int64_t* n_pair, float* out2, float* dscores, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* Front end of the loss for a SMALL batch in one launch (BASELINE config 2: pairwise_loss_from_batch at B = 8192): canonical keys
  * of ONE float32 / int32 group tensor (key_dtype RECNOW_KEY_F32 / RECNOW_KEY_I32), stable sort and segments by a single
  * 1024-thread workgroup on LDS-resident keys, B <= 8192 (recnow_pairwise_small_supported), plus what recnow_pair_count would do

@@ -28,6 +28,8 @@ SIGNATURES = {
     'recnow_pair_bpr_fwdbwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _P, _P, _P, _Z, _P]),
     'recnow_pair_bpr_onepass': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
     'recnow_pair_scale_grad': (_I, [_P, _P, _P, _F, _L, _P, _P]),
+    'recnow_pairwise_loss_workspace_bytes': (_Z, [_L, _I]),
+    'recnow_pairwise_loss': (_I, [_P, _I, _P, _P, _P, _L, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'recnow_pairwise_small_supported': (_I, [_L, _I]),
     'recnow_group_pack_small': (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'recnow_bpr_loss_fwdbwd': (_I, [_P, _P, _P, _L, _F, _I, _P, _P, _P, _Z, _P]),

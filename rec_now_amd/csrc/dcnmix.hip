@@ -487,9 +487,16 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 else rc = rn_gemm(&d, gws, gws_bytes, st);
                 if (rc) return rc;
             }
+            RnSlabs sl;
+            sl.n = 0;
             if (absorb && red1.valid) {
-                RnSlabs sl;
                 rn_deferred_slabs(&red1, &sl.p, &sl.n, &sl.ld, &sl.stride);
+                if (sl.n != 2 && sl.n != 4) {      // a split the sub-space kernel has no variant for: reduce as usual
+                    if ((rc = rn_layer_end_reduce(&red1, nullptr, nullptr, 0, 0, nullptr, st))) return rc;
+                    sl.n = 0;
+                }
+            }
+            if (sl.n) {
                 if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st, &sl, act_inner))) return rc;
             } else if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
             {   // GEMM3: out = x * ([G*H2 | G | 0] [W; b; 0]): K zero-padded NS+N -> KP (a 16-deep k-tile more is cheaper
@@ -732,7 +739,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         const RnSlabs* slp = nullptr;
         if (absorb_bwd && red_t2g.valid) {
             rn_deferred_slabs(&red_t2g, &sl_t2g.p, &sl_t2g.n, &sl_t2g.ld, &sl_t2g.stride);
-            slp = &sl_t2g;
+            if (sl_t2g.n == 2 || sl_t2g.n == 4) slp = &sl_t2g;
+            else if ((rc = rn_layer_end_reduce(&red_t2g, nullptr, nullptr, 0, 0, nullptr, st))) return rc;      // no variant: reduce as usual
         }
         MIX_WAIT(e_side_prev, st);          // dT1 (and the g buffer about to be rewritten) are free again
         // gate backward, dA_n = (dC_n V_n^T) * act_inner'(H1_n) and dV_n = H1_n^T dC_n

@@ -316,10 +316,11 @@ k_mix_mid_bwd(const float* __restrict__ dT2g, const float* __restrict__ T2, cons
 // of a row, and the transposing LDS writes of a 32-lane group go to rows r .. r + 3 x chunks 0 .. 7, i.e. 32 distinct banks (row
 // stride 129 floats); with 32 lanes on ONE row (chunks 0 .. 31) lanes l and l + 8 shared a bank: 4-way conflicts on every staging
 // write (counters: 36 % / 60 % of the LDS cycles of the forward / backward kernel were conflicts).
-template <int S, int N, int AO, bool SL>
+template <int S, int N, int AO, int NSL>
 __device__ __forceinline__ void mid_fwd_fast_body(const float* __restrict__ T1, const float* __restrict__ V, float* __restrict__ T2,
                                                   float* __restrict__ T2g, int64_t B, int LDT, int act_outer_rt, const RnSlabs sl, int act_inner) {
     const int act_outer = AO >= 0 ? AO : act_outer_rt;       // compile-time activation: no per-element switch in the store loop
+    constexpr bool SL = NSL > 0;
     float* const T1out = const_cast<float*>(T1);             // SL: T1 is written (the backward pass reads it), not read
     int64_t pr0 = 0;                                         // SL: first row of the prefetched tile
     extern __shared__ float lds[];
@@ -335,23 +336,34 @@ __device__ __forceinline__ void mid_fwd_fast_body(const float* __restrict__ T1, 
     float plg[N];
     auto prefetch = [&](int64_t r0) {
         if constexpr (SL) {
-            // the product that feeds this kernel was split over K: its slabs are summed here (slab order, fp32: at most K / 256 = 4 terms
-            // of a K = 1024 product) and the activation of the product's epilogue is applied when the tile is staged
+            // the product that feeds this kernel was split over K into NSL slabs: all NSL x NCH loads of the tile go out together and
+            // are summed in slab order (fp32; NSL <= 4 terms of a K = 1024 product); the activation of the product's epilogue is
+            // applied when the tile is staged
             pr0 = r0;
+            float4 t[NSL][NCH];
+            float tg[NSL][N];
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int n = 0; n < N; ++n) plg[n] = 0.f;
-            for (int s = 0; s < sl.n; ++s) {            // block-uniform trip count, every load unconditional
+            for (int s = 0; s < NSL; ++s) {
                 const float* __restrict__ P = sl.p + (int64_t)s * sl.stride;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) {
                     const int r = 4 * (tid >> 5) + ((tid >> 3) & 3), k4 = ((tid & 7) + 8 * i) * 4;
-                    const float4 t = *reinterpret_cast<const float4*>(P + (r0 + r) * sl.ld + k4);
-                    pv[i].x += t.x; pv[i].y += t.y; pv[i].z += t.z; pv[i].w += t.w;
+                    t[s][i] = *reinterpret_cast<const float4*>(P + (r0 + r) * sl.ld + k4);
                 }
 #pragma unroll
-                for (int n = 0; n < N; ++n) plg[n] += P[(r0 + (tid & 31)) * sl.ld + NS + n];
+                for (int n = 0; n < N; ++n) tg[s][n] = P[(r0 + (tid & 31)) * sl.ld + NS + n];
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                pv[i] = t[0][i];
+#pragma unroll
+                for (int s = 1; s < NSL; ++s) { pv[i].x += t[s][i].x; pv[i].y += t[s][i].y; pv[i].z += t[s][i].z; pv[i].w += t[s][i].w; }
+            }
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                plg[n] = tg[0][n];
+#pragma unroll
+                for (int s = 1; s < NSL; ++s) plg[n] += tg[s][n];
             }
             return;
         }
@@ -437,7 +449,7 @@ __device__ __forceinline__ void mid_fwd_fast_body(const float* __restrict__ T1, 
     }
 }
 
-template <int S, int N, bool SL = false>
+template <int S, int N, int SL = 0>
 __global__ void __launch_bounds__(256, 2)
 k_mix_mid_fwd_fast(const float* __restrict__ T1, const float* __restrict__ V, float* __restrict__ T2, float* __restrict__ T2g, int64_t B,
                    int LDT, int act_outer, const RnSlabs sl, int act_inner) {
@@ -445,11 +457,12 @@ k_mix_mid_fwd_fast(const float* __restrict__ T1, const float* __restrict__ V, fl
     else mid_fwd_fast_body<S, N, -1, SL>(T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner);
 }
 
-template <int S, int N, bool RS, int AI, int AO, bool SL>
+template <int S, int N, bool RS, int AI, int AO, int NSL>
 __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1,
                                                   const float* __restrict__ V, float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B,
                                                   int LDT, int act_inner_rt, int act_outer_rt, const float* __restrict__ rscale, const RnSlabs sl) {
     const int act_inner = AI >= 0 ? AI : act_inner_rt, act_outer = AO >= 0 ? AO : act_outer_rt;
+    constexpr bool SL = NSL > 0;
     extern __shared__ float lds[];
     constexpr int NS = N * S, LDA = NS + 1, CPR = NS / 4, NCH = MID_ROWS * CPR / 256, GL = S / 4;
     constexpr int nvitems = N * (S / 32) * (S / 32), VI = (nvitems + 3) / 4;
@@ -494,21 +507,31 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
             if constexpr (!SL) pdg[n] = dT2g[grow * LDT + NS + n];
         }
         if (RS) psg = rscale[grow];
-        if constexpr (SL) {       // the dT2g product was split over K: its slabs are summed here (slab order, fp32, at most 4 terms)
+        if constexpr (SL) {       // the dT2g product was split over K into NSL slabs: loaded together, summed in slab order (fp32, <= 4 terms)
+            float4 t[NSL][NCH];
+            float tg[NSL][N];
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int n = 0; n < N; ++n) pdg[n] = 0.f;
-            for (int sb = 0; sb < sl.n; ++sb) {          // block-uniform trip count, every load unconditional
+            for (int sb = 0; sb < NSL; ++sb) {
                 const float* __restrict__ P = sl.p + (int64_t)sb * sl.stride;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) {
                     const int r = 4 * (tid >> 5) + ((tid >> 3) & 3), k4 = ((tid & 7) + 8 * i) * 4;
-                    const float4 t = *reinterpret_cast<const float4*>(P + (r0 + r) * sl.ld + k4);
-                    pd[i].x += t.x; pd[i].y += t.y; pd[i].z += t.z; pd[i].w += t.w;
+                    t[sb][i] = *reinterpret_cast<const float4*>(P + (r0 + r) * sl.ld + k4);
                 }
 #pragma unroll
-                for (int n = 0; n < N; ++n) pdg[n] += P[grow * sl.ld + NS + n];
+                for (int n = 0; n < N; ++n) tg[sb][n] = P[grow * sl.ld + NS + n];
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                pd[i] = t[0][i];
+#pragma unroll
+                for (int sb = 1; sb < NSL; ++sb) { pd[i].x += t[sb][i].x; pd[i].y += t[sb][i].y; pd[i].z += t[sb][i].z; pd[i].w += t[sb][i].w; }
+            }
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                pdg[n] = tg[0][n];
+#pragma unroll
+                for (int sb = 1; sb < NSL; ++sb) pdg[n] += tg[sb][n];
             }
         }
     };
@@ -620,7 +643,7 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
     }
 }
 
-template <int S, int N, bool RS, bool SL = false>
+template <int S, int N, bool RS, int SL = 0>
 __global__ void __launch_bounds__(256, 2)
 k_mix_mid_bwd_fast(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1, const float* __restrict__ V,
                    float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B, int LDT, int act_inner, int act_outer,
@@ -670,7 +693,7 @@ bool rn_mix_mid_absorbs_slabs(int64_t B, int S, int N, int LDT) {
 int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64_t B, int S, int N, int LDT, int act_outer, hipStream_t st,
                    const RnSlabs* slabs, int act_inner) {
     if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
-    if (slabs && !rn_mix_mid_absorbs_slabs(B, S, N, LDT)) return RECNOW_EUNSUPPORTED;
+    if (slabs && (!rn_mix_mid_absorbs_slabs(B, S, N, LDT) || (slabs->n != 2 && slabs->n != 4))) return RECNOW_EUNSUPPORTED;
     RnSlabs sl;
     sl.p = nullptr; sl.n = 0; sl.ld = 0; sl.stride = 0;
     if (slabs) sl = *slabs;
@@ -681,12 +704,15 @@ int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64
     const bool mid_fast = g_mid_fast;
 #define MID_FWD_FAST(SS, NN)                                                                                                  \
     if (mid_fast && B % MID_ROWS == 0 && S == SS && N == NN && LDT == SS * NN + 16) {                                         \
-        if (slabs) {                                                                                                          \
-            if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN, true>, lds))) return rc;                                       \
-            hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN, true>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner); \
+        if (slabs && sl.n == 4) {                                                                                             \
+            if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN, 4>, lds))) return rc;                                          \
+            hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN, 4>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner); \
+        } else if (slabs) {                                                                                                   \
+            if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN, 2>, lds))) return rc;                                          \
+            hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN, 2>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner); \
         } else {                                                                                                              \
-            if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN, false>, lds))) return rc;                                      \
-            hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN, false>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner); \
+            if ((rc = mid_allow_lds(k_mix_mid_fwd_fast<SS, NN, 0>, lds))) return rc;                                          \
+            hipLaunchKernelGGL((k_mix_mid_fwd_fast<SS, NN, 0>), mid_fwd_grid(B, lds), 256, lds, st, T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner); \
         }                                                                                                                     \
         rn_prof_end(pr, st);                                                                                                  \
         RN_LAUNCH_CHECK();                                                                                                    \
@@ -711,7 +737,7 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
                    int LDT, int act_inner, int act_outer, void* ws, size_t ws_bytes, hipStream_t st, const float* rscale, bool defer_dv,
                    const RnSlabs* slabs) {
     if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
-    if (slabs && !rn_mix_mid_absorbs_slabs(B, S, N, LDT)) return RECNOW_EUNSUPPORTED;
+    if (slabs && (!rn_mix_mid_absorbs_slabs(B, S, N, LDT) || (slabs->n != 2 && slabs->n != 4))) return RECNOW_EUNSUPPORTED;
     RnSlabs sl;
     sl.p = nullptr; sl.n = 0; sl.ld = 0; sl.stride = 0;
     if (slabs) sl = *slabs;
@@ -732,19 +758,19 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
     bool done = false;
 #define MID_BWD_FAST(SS, NN)                                                                                                  \
     if (!done && mid_fast && B % MID_ROWS == 0 && S == SS && N == NN && LDT == SS * NN + 16) {                                                    \
-        if (rscale && slabs) {                                                                                                \
-            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true, true>, lds))) return rc;                                 \
-            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true, true>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); \
-        } else if (rscale) {                                                                                                  \
-            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true, false>, lds))) return rc;                                \
-            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true, false>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); \
-        } else if (slabs) {                                                                                                   \
-            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false, true>, lds))) return rc;                                \
-            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false, true>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); \
-        } else {                                                                                                              \
-            if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false, false>, lds))) return rc;                               \
-            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false, false>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); \
-        }                                                                                                                     \
+        const int slv = slabs ? sl.n : 0;                                                                                     \
+        if (rscale && slv == 4) { if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true, 4>, lds))) return rc;               \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true, 4>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); } \
+        else if (rscale && slv == 2) { if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true, 2>, lds))) return rc;          \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true, 2>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); } \
+        else if (rscale) { if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, true, 0>, lds))) return rc;                      \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, true, 0>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); } \
+        else if (slv == 4) { if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false, 4>, lds))) return rc;                   \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false, 4>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); } \
+        else if (slv == 2) { if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false, 2>, lds))) return rc;                   \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false, 2>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); } \
+        else { if ((rc = mid_allow_lds(k_mix_mid_bwd_fast<SS, NN, false, 0>, lds))) return rc;                                 \
+            hipLaunchKernelGGL((k_mix_mid_bwd_fast<SS, NN, false, 0>), grid, 256, lds, st, dT2g, T2, T1, V, dT1, part, B, LDT, act_inner, act_outer, rscale, sl); } \
         done = true;                                                                                                          \
     }
     MID_BWD_FAST(64, 2)

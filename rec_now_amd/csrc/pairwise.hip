@@ -753,3 +753,91 @@ extern "C" int recnow_group_pack_small(const void* groups, int key_dtype, const 
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
+
+
+// ---- the default pairwise_loss in one call (include/recnow.h: recnow_pairwise_loss) ----------------------------------------------
+struct PairLossWs {
+    int32_t *order, *seg_id, *seg_first, *super_id, *n_seg;
+    int64_t* cnt_super;
+    uint32_t* words;
+    uint8_t* solo;
+    float* dsu;
+    void* grp; size_t grp_bytes;
+    void* pair; size_t pair_bytes;
+    int n_words;
+    size_t total;
+};
+static PairLossWs pair_loss_carve(void* ws, int64_t B, int key_dtype) {
+    PairLossWs w;
+    RnCarver c(ws, 0);
+    const int64_t Bp = B > 0 ? B : 1;
+    w.n_words = recnow_key_words(key_dtype);
+    if (w.n_words < 1) w.n_words = 1;
+    w.order = c.take<int32_t>(Bp);
+    w.seg_id = c.take<int32_t>(Bp);
+    w.seg_first = c.take<int32_t>(Bp + 1);
+    w.super_id = c.take<int32_t>(Bp);
+    w.n_seg = c.take<int32_t>(2);
+    w.cnt_super = c.take<int64_t>(Bp);
+    w.words = c.take<uint32_t>((size_t)w.n_words * Bp);
+    w.solo = c.take<uint8_t>(Bp);
+    w.dsu = c.take<float>(Bp);
+    w.grp_bytes = recnow_group_segments_workspace_bytes(B, w.n_words);
+    w.grp = c.take<char>(w.grp_bytes);
+    w.pair_bytes = recnow_pairwise_workspace_bytes(B);
+    w.pair = c.take<char>(w.pair_bytes);
+    w.total = c.off;
+    return w;
+}
+extern "C" size_t recnow_pairwise_loss_workspace_bytes(int64_t B, int key_dtype) {
+    if (B < 0) return 0;
+    return pair_loss_carve(nullptr, B, key_dtype).total + 256;
+}
+// dscores = unnormalised pair gradients x 1 / (P + eps) (mean) or as they are (sum); {loss, (float) P} for the caller
+__global__ void __launch_bounds__(256)
+k_pair_norm_grad(const float* __restrict__ d, const unsigned long long* __restrict__ n_pair, int reduce_mean, float eps, int64_t B,
+                 float* __restrict__ out, const float* __restrict__ loss, float* __restrict__ out2) {
+    const float P = (float)(*n_pair);
+    const float sc = reduce_mean ? 1.f / (P + eps) : 1.f;
+    if (out2 && blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = loss[0]; out2[1] = P; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) out[i] = d[i] * sc;
+}
+extern "C" int recnow_pairwise_loss(const void* groups, int key_dtype, const float* labels, const float* scores, const uint8_t* mask,
+                                    int64_t B, int flags, float factor, int reduce_mean, float* loss, int64_t* n_pair, float* out2,
+                                    float* dscores, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || !loss || !n_pair) return RECNOW_EINVAL;
+    if (recnow_key_words(key_dtype) < 1) return RECNOW_EINVAL;
+    if ((flags & (RECNOW_PAIR_LABEL_GT | RECNOW_PAIR_WRONG_ORDER)) == 0 || (flags & ~3)) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        RN_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+        RN_HIP(hipMemsetAsync(n_pair, 0, sizeof(int64_t), st));
+        if (out2) RN_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(float), st));
+        return RECNOW_OK;
+    }
+    if (!groups || !labels || !scores || !dscores || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_pairwise_loss_workspace_bytes(B, key_dtype)) return RECNOW_EWORKSPACE;
+    const PairLossWs w = pair_loss_carve(ws, B, key_dtype);
+    int rc;
+    int f = flags;
+    if (recnow_pairwise_small_supported(B, key_dtype)) {
+        if ((rc = recnow_group_pack_small(groups, key_dtype, labels, scores, mask, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.cnt_super,
+                                          n_pair, w.pair, w.pair_bytes, stream)))
+            return rc;
+        f |= RECNOW_PAIR_MEMBERS_PACKED;
+    } else {
+        RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
+        if ((rc = recnow_group_keys(groups, key_dtype, B, w.words, w.solo, stream))) return rc;
+        if ((rc = recnow_group_segments(w.words, w.solo, B, w.n_words, w.n_words, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes,
+                                        stream)))
+            return rc;
+    }
+    if ((rc = recnow_pair_bpr_onepass(scores, labels, mask, w.order, w.seg_id, w.seg_first, B, f, factor, reduce_mean, loss, w.dsu, n_pair, w.pair,
+                                      w.pair_bytes, stream)))
+        return rc;
+    int G = rn_cdiv(B, 256);
+    if (G > 2048) G = 2048;
+    hipLaunchKernelGGL(k_pair_norm_grad, G, 256, 0, st, w.dsu, (const unsigned long long*)n_pair, reduce_mean, 1.0e-10f, B, dscores, loss, out2);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
