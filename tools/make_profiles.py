@@ -9,7 +9,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 
@@ -19,9 +19,44 @@ def newest(pattern):
     return fs[-1]
 
 
-f = newest('gpurun_out/%s_stats/*/*_kernel_stats.csv' % tag)
-shutil.copy(f, 'profiles/%s_bench_kernel_stats.csv' % tag)
-rows = list(csv.DictReader(open(f)))
+import statistics
+
+
+def trace_stats(trace_csv, out_csv=None):
+    """Per-kernel statistics of the STEPS of a bench.py run from its rocprofv3 kernel trace: the dispatches before the first step's
+    grouping launch (the lazy build of the layers on 256 rows, initialisers) are dropped, so an average is an average over launches of
+    the benchmarked shape.  Returns rows sorted by total time: dicts Name, Calls, TotalDurationNs, AverageNs, MinNs, MaxNs, Percentage."""
+    ev = []
+    for r in csv.DictReader(open(trace_csv)):
+        ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+    ev.sort()
+    first = next((i for i, e in enumerate(ev) if e[2].startswith('k_keys_') or e[2].startswith('k_pack_all')), 0)
+    agg = collections.OrderedDict()
+    for s0, e0, n in ev[first:]:
+        agg.setdefault(n, []).append(e0 - s0)
+    tot = sum(sum(v) for v in agg.values())
+    rows = [{'Name': n, 'Calls': len(v), 'TotalDurationNs': sum(v), 'AverageNs': sum(v) / len(v), 'MinNs': min(v), 'MaxNs': max(v),
+             'Percentage': '%.2f' % (100.0 * sum(v) / tot)} for n, v in agg.items()]
+    rows.sort(key=lambda r: -r['TotalDurationNs'])
+    if out_csv:
+        with open(out_csv, 'w') as fo:
+            w = csv.writer(fo)
+            w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+            for r in rows:
+                w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], '%.1f' % r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+    return rows, len(ev) - first, first
+
+
+def bench_line(log):
+    """The JSON line a profiled bench.py run printed (its own event hook's figures of the same run)."""
+    for line in reversed(open(log, errors='replace').read().splitlines()):
+        if line.startswith('{"metric"'):
+            return json.loads(line)
+    return None
+
+
+f = newest('gpurun_out/%s_stats/*/*_kernel_trace.csv' % tag)
+rows, n_disp, n_dropped = trace_stats(f, 'profiles/%s_bench_kernel_stats.csv' % tag)
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 pmc = {}
 for name, cnt in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
@@ -55,29 +90,65 @@ json.dump({'kernel_source_sha256': kernel_source_hash(),
                      'WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section (FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950); '
                      'launch-weighted mean over the instantiations of each tile family',
            'hbm_bytes_per_launch': traffic}, open('profiles/traffic.json', 'w'), indent=1)
-steps = 19      # 3 warm-up + 10 timed + 5 host-enqueue diagnostic + 1 parity step
+steps = 19      # 3 warm-up + 10 timed + 5 untimed host-enqueue diagnostic + 1 parity step
+hook = bench_line('gpurun_out/%s_stats.log' % tag)
+clean = json.load(open('gpurun_out/%s_bench.json' % tag)) if os.path.exists('gpurun_out/%s_bench.json' % tag) else None
 with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
-    fo.write('# Round %s -- rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline` (1x MI355X)\n\n' % tag[1:])
-    fo.write('Raw per-kernel CSV: `%s_bench_kernel_stats.csv`; HBM counters (separate --pmc passes): `%s_bench_pmc_hbm.csv`; bench line of the '
-             'same build: `%s_bench.json`; GEMM microbenchmark (`tools/gemm_bench.py`): `%s_gemm_bench.txt`.\n\n' % (tag, tag, tag, tag))
-    fo.write('Sum of kernel durations: %.1f ms over %d steps (3 warm-up + 10 timed + 5 untimed host-enqueue diagnostic + 1 parity step) = %.3f ms/step.  The batch-grouping kernels (sort, scans, '
-             'segments) run on a side stream under the forward pass and are stretched by the GEMMs they share the chip with, so this sum is '
-             'larger than the wall time per step (see `%s_bench.json`); `__amd_rocclr_copyBuffer` is the parity step copying d loss / d x and the '
-             'gradients to the host, outside the timed region.\n\n' % (tot / 1e6, steps, tot / 1e6 / steps, tag))
-    fo.write('| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n')
-    for r in rows[:24]:
-        fo.write('| `%s` | %s | %.2f | %.1f | %s |\n' % (r['Name'][:100].replace('|', '/'), r['Calls'], float(r['TotalDurationNs']) / 1e6,
-                                                   float(r['AverageNs']) / 1e3, r['Percentage']))
+    fo.write('# Round %s -- rocprofv3 --kernel-trace of `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline` (1x MI355X)\n\n' % tag[1:])
+    fo.write('Per-kernel CSV (computed from the kernel trace; the %d dispatches in front of the first step -- the lazy build of the layers on 256 rows '
+             'and the initialisers -- are dropped, so every average is over launches of the benchmarked shape): `%s_bench_kernel_stats.csv`; HBM counters '
+             '(separate --pmc passes): `%s_bench_pmc_hbm.csv`; bench line of the same build WITHOUT the profiler: `%s_bench.json`; GEMM '
+             'microbenchmark (`tools/gemm_bench.py`): `%s_gemm_bench.txt`.\n\n' % (n_dropped, tag, tag, tag, tag))
+    fo.write('Sum of kernel durations: %.1f ms over %d steps (3 warm-up + 10 timed + 5 untimed host-enqueue diagnostic + 1 parity step) = %.3f ms/step; the '
+             'grouping kernels run on a side stream under the forward pass, so this sum exceeds the wall time per step; `__amd_rocclr_copyBuffer` is the '
+             'parity step copying results to the host, outside the timed region.\n\n' % (tot / 1e6, steps, tot / 1e6 / steps))
+    gem = [r for r in rows if 'k_gemm<128, 128' in r['Name']]
+    if gem:
+        gavg = sum(r['TotalDurationNs'] for r in gem) / sum(r['Calls'] for r in gem) / 1e3
+        fo.write('**`k_gemm<128,128,..>` (the dominant kernel), three figures of one build**: rocprofv3 average over its %d launches in this profiled run '
+                 '%.1f us = %.3f of the 157.3 TFLOP/s fp32 MFMA peak (17.45 GFLOP per launch)' % (sum(r['Calls'] for r in gem), gavg, 17.448 / gavg / 157.3 * 1e3))
+        if hook and hook.get('roofline'):
+            fo.write('; the library\'s own HIP-event hook INSIDE the same profiled run %.1f us = %.3f (the hook agrees with rocprofv3: the profiler slows the run, '
+                     'step %.3f ms here)' % (hook['roofline']['avg_launch_us'], hook['roofline']['frac'], hook['ms_per_step']))
+        if clean and clean.get('roofline'):
+            fo.write('; the hook in the UNPROFILED run of the same build (`%s_bench.json`, what `bench.py` reports) %.1f us = %.3f, step %.3f ms'
+                     % (tag, clean['roofline']['avg_launch_us'], clean['roofline']['frac'], clean['ms_per_step']))
+        fo.write('.\n\n')
+    fo.write('| kernel | calls | total ms | avg us | min us | %% |\n|---|---|---|---|---|---|\n')
+    for r in rows[:26]:
+        fo.write('| `%s` | %s | %.2f | %.1f | %.1f | %s |\n' % (r['Name'][:100].replace('|', '/'), r['Calls'], float(r['TotalDurationNs']) / 1e6,
+                                                        float(r['AverageNs']) / 1e3, r['MinNs'] / 1e3, r['Percentage']))
+    # per-rank shard sizes of the 2/4/8-GPU rows
+    fo.write('\n## The per-rank shards of the metric\'s 2 / 4 / 8-GPU rows on one GPU (`bench.py --rows R --force-dist`: every collective of the N > 1 path over a 1-rank RCCL group)\n\n')
+    fo.write('| rows per GPU (N) | ms/step unprofiled | ideal = 1-GPU step / N | strong-scaling efficiency of the shard | host enqueue ms | kernel stats |\n|---|---|---|---|---|---|\n')
+    base = None
+    for rws, n in ((65536, 1), (32768, 2), (16384, 4), (8192, 8)):
+        pth = 'gpurun_out/%s_bench_rows%d.json' % (tag, rws)
+        if not os.path.exists(pth):
+            continue
+        d = json.loads(open(pth).read().strip().splitlines()[-1])
+        shutil.copy(pth, 'profiles/%s_bench_rows%d.json' % (tag, rws))
+        if base is None:
+            base = d['ms_per_step']
+        ks = ''
+        try:
+            ft = newest('gpurun_out/%s_stats_rows%d/*/*_kernel_trace.csv' % (tag, rws))
+            trace_stats(ft, 'profiles/%s_bench_rows%d_kernel_stats.csv' % (tag, rws))
+            ks = '`%s_bench_rows%d_kernel_stats.csv`' % (tag, rws)
+        except (IndexError, StopIteration):
+            pass
+        fo.write('| %d (%d) | %.3f | %.3f | %.2f | %.3f | %s |\n' % (rws, n, d['ms_per_step'], base / n, base / n / d['ms_per_step'], d['config']['host_enqueue_ms_per_step'], ks))
+    pg = 'gpurun_out/%s_bench_rows8192_graph.json' % tag
+    if os.path.exists(pg):
+        d = json.loads(open(pg).read().strip().splitlines()[-1])
+        shutil.copy(pg, 'profiles/%s_bench_rows8192_graph.json' % tag)
+        fo.write('\n8192 rows replayed from per-piece HIP graphs (`--graph`): %.3f ms/step, host %.3f ms.\n' % (d['ms_per_step'], d['config']['host_enqueue_ms_per_step']))
 shutil.copy('gpurun_out/%s_bench.json' % tag, 'profiles/%s_bench.json' % tag)
-for extra in ('bench_unfused', 'bench_forcedist', 'bench_bf16x3', 'layer_bench'):
+for extra in ('bench_unfused', 'bench_autograd', 'bench_bf16x3', 'layer_bench'):
     for ext in ('json', 'txt'):
         src = 'gpurun_out/%s_%s.%s' % (tag, extra, ext)
         if os.path.exists(src):
             shutil.copy(src, 'profiles/%s_%s.%s' % (tag, extra, ext))
-try:
-    shutil.copy(newest('gpurun_out/%s_stats_bf16x3/*/*_kernel_stats.csv' % tag), 'profiles/%s_bench_bf16x3_kernel_stats.csv' % tag)
-except IndexError:
-    pass
 if os.path.exists('gpurun_out/%s_gemm_bench.txt' % tag):
     lines = [l for l in open('gpurun_out/%s_gemm_bench.txt' % tag) if 'TFLOP' in l]
     open('profiles/%s_gemm_bench.txt' % tag, 'w').writelines(lines)

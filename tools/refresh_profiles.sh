@@ -1,23 +1,32 @@
 #!/bin/bash
-# Run on the GPU box from the repository root (gpurun -- 'bash tools/refresh_profiles.sh r01'): writes the raw material of
+# Run on the GPU box from the repository root (gpurun -- 'bash tools/refresh_profiles.sh r03'): writes the raw material of
 # profiles/ into gpurun_out/; tools/make_profiles.py then turns it into the committed summaries.
 # Every rocprofv3 line starts the program itself (python3), counters are collected in their own passes.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
-mkdir -p $R/gpurun_out
-python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
-python3 $R/bench.py --steps 20 --warmup 5 --unfused --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_unfused.json 2>> $R/gpurun_out/${TAG}_bench.err
-python3 $R/bench.py --steps 20 --warmup 5 --force-dist --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_forcedist.json 2>> $R/gpurun_out/${TAG}_bench.err
-python3 $R/bench.py --steps 20 --warmup 5 --gemm-precision bf16x3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_bf16x3.json 2>> $R/gpurun_out/${TAG}_bench.err
+O=$R/gpurun_out
+mkdir -p $O
+python3 $R/bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || exit 1
+python3 $R/bench.py --steps 20 --warmup 5 --unfused --no-cpu-baseline > $O/${TAG}_bench_unfused.json 2>> $O/${TAG}_bench.err
+python3 $R/bench.py --steps 20 --warmup 5 --route autograd --no-cpu-baseline > $O/${TAG}_bench_autograd.json 2>> $O/${TAG}_bench.err
+python3 $R/bench.py --steps 20 --warmup 5 --gemm-precision bf16x3 --no-cpu-baseline > $O/${TAG}_bench_bf16x3.json 2>> $O/${TAG}_bench.err
+# the per-rank shards of the metric's 1/2/4/8-GPU rows on one GPU, every collective of the N > 1 path over a 1-rank RCCL group
+for rows in 65536 32768 16384 8192; do
+  python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --rows $rows --force-dist > $O/${TAG}_bench_rows${rows}.json 2>> $O/${TAG}_bench.err || exit 1
+done
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --rows 8192 --force-dist --graph > $O/${TAG}_bench_rows8192_graph.json 2>> $O/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/${TAG}_stats $R/gpurun_out/${TAG}_pmc_fetch $R/gpurun_out/${TAG}_pmc_write $R/gpurun_out/${TAG}_stats_bf16x3
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $R/gpurun_out/${TAG}_pmc_write.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_bf16x3 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --gemm-precision bf16x3 > $R/gpurun_out/${TAG}_stats_bf16x3.log 2>&1
+for d in stats pmc_fetch pmc_write stats_rows32768 stats_rows16384 stats_rows8192; do rm -rf $O/${TAG}_$d; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $O/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $O/${TAG}_pmc_write.log 2>&1
+for rows in 32768 16384 8192; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats_rows$rows -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --rows $rows --force-dist > $O/${TAG}_stats_rows$rows.log 2>&1
+done
 # keep only the small CSVs (the merge back is capped at 64 MiB)
-find $R/gpurun_out/${TAG}_stats $R/gpurun_out/${TAG}_pmc_fetch $R/gpurun_out/${TAG}_pmc_write $R/gpurun_out/${TAG}_stats_bf16x3 -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete
+find $O/${TAG}_stats $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_stats_rows* -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' ! -name '*kernel_trace.csv' -delete
+find $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write -name '*kernel_trace.csv' -delete
 cd $R
-python3 tools/gemm_bench.py > gpurun_out/${TAG}_gemm_bench.txt 2>&1
-python3 tools/layer_bench.py 10 > gpurun_out/${TAG}_layer_bench.txt 2>&1
-tail -c 600 gpurun_out/${TAG}_bench.json
+python3 tools/gemm_bench.py > $O/${TAG}_gemm_bench.txt 2>&1
+python3 tools/layer_bench.py 20 > $O/${TAG}_layer_bench.txt 2>&1
+tail -c 400 $O/${TAG}_bench.json
