@@ -858,3 +858,4 @@ int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* pl
 size_t rn_gemm_split_planes_bytes(int K, int N);
 // persistent short-K kernel (gemm_shortk.hip): ep = (emul ? 1 : 0) | (accumulate ? 2 : 0)
 int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st);
+
