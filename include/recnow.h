@@ -190,6 +190,15 @@ int recnow_listwise_loss_fwdbwd(const float* labels, const float* logits, const 
                                 const float* seg_ysum, const float* seg_psum, const float* seg_pdot,
                                 const int32_t* valid_rank, const int32_t* n_valid, const float* weights, int64_t B,
                                 float* loss, float* dbase, int32_t* row_rank, float* group_loss, void* stream);
+/* to_listwise_sample + listwise_loss_via_softmax_cross_entropy_with_logits(do_reduce=True) fused on sorted segments, as ONE call
+ * (rec_block/listwise_loss_from_batch.py:89-173): grouping of `groups` (one id tensor), the per-list statistics, the mean loss over
+ * the valid lists (0 when there is none: nan_to_zero) and  dlogits[i] = d loss / d logits[i]  (already divided by the number of valid
+ * lists), so that a host framework's backward is one multiply.  out2 (2 floats): {loss, (float) number of valid lists}.
+ * weights: [>= number of valid lists] in first-occurrence order of the valid groups, or NULL.  One workspace
+ * (recnow_listwise_loss_workspace_bytes) holds every intermediate. */
+size_t recnow_listwise_loss_workspace_bytes(int64_t B, int key_dtype);
+int recnow_listwise_loss(const void* groups, int key_dtype, const float* labels, const float* logits, const float* weights, int64_t B,
+                         float pos_neg_th, float pad_logit, float* out2, float* dlogits, void* ws, size_t ws_bytes, void* stream);
 /* Dense (n_valid,B) outputs of to_listwise_sample (:131-148) for API parity.  The caller pre-fills mask_out = 0,
  * labels_out = 0, logits_out = pad_logit; members of valid groups are scattered in. */
 int recnow_listwise_dense(const float* labels, const float* logits, const int32_t* order, const int32_t* seg_id,

@@ -38,6 +38,8 @@ SIGNATURES = {
     'recnow_listwise_workspace_bytes': (_Z, [_L]),
     'recnow_listwise_segments': (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'recnow_listwise_loss_fwdbwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
+    'recnow_listwise_loss_workspace_bytes': (_Z, [_L, _I]),
+    'recnow_listwise_loss': (_I, [_P, _I, _P, _P, _P, _L, _F, _F, _P, _P, _P, _Z, _P]),
     'recnow_listwise_dense': (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P]),
     'recnow_listwise_dense_bwd': (_I, [_P, _P, _L, _P, _P]),
     'recnow_softmax_ce_rows_fwd': (_I, [_P, _P, _L, _L, _P, _P, _P, _P]),

@@ -293,3 +293,79 @@ extern "C" int recnow_softmax_ce_rows_bwd(const float* labels, const float* logi
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
+
+
+// ---- the fused listwise loss in one call (include/recnow.h: recnow_listwise_loss) ----------------------------------------------
+struct LwLossWs {
+    int32_t *order, *seg_id, *seg_first, *super_id, *n_seg, *seg_valid, *valid_rank, *n_valid, *row_rank;
+    float *seg_lse, *seg_ysum, *seg_psum, *seg_pdot, *dbase, *group_loss, *loss;
+    uint32_t* words;
+    uint8_t* solo;
+    void* grp; size_t grp_bytes;
+    void* lw; size_t lw_bytes;
+    int n_words;
+    size_t total;
+};
+static LwLossWs lw_loss_carve(void* ws, int64_t B, int key_dtype) {
+    LwLossWs w;
+    RnCarver c(ws, 0);
+    const int64_t n = B > 0 ? B : 1;
+    w.n_words = recnow_key_words(key_dtype);
+    if (w.n_words < 1) w.n_words = 1;
+    w.order = c.take<int32_t>(n); w.seg_id = c.take<int32_t>(n); w.seg_first = c.take<int32_t>(n + 1); w.super_id = c.take<int32_t>(n);
+    w.n_seg = c.take<int32_t>(2); w.seg_valid = c.take<int32_t>(n); w.valid_rank = c.take<int32_t>(n); w.n_valid = c.take<int32_t>(1);
+    w.row_rank = c.take<int32_t>(n);
+    w.seg_lse = c.take<float>(n); w.seg_ysum = c.take<float>(n); w.seg_psum = c.take<float>(n); w.seg_pdot = c.take<float>(n);
+    w.dbase = c.take<float>(n); w.group_loss = c.take<float>(n); w.loss = c.take<float>(1);
+    w.words = c.take<uint32_t>((size_t)w.n_words * n);
+    w.solo = c.take<uint8_t>(n);
+    w.grp_bytes = recnow_group_segments_workspace_bytes(B, w.n_words);
+    w.grp = c.take<char>(w.grp_bytes);
+    w.lw_bytes = recnow_listwise_workspace_bytes(B);
+    w.lw = c.take<char>(w.lw_bytes);
+    w.total = c.off;
+    return w;
+}
+extern "C" size_t recnow_listwise_loss_workspace_bytes(int64_t B, int key_dtype) {
+    if (B < 0) return 0;
+    return lw_loss_carve(nullptr, B, key_dtype).total + 256;
+}
+// dlogits = dbase / (number of valid lists) (0 when there is none); {loss, (float) number of valid lists}
+__global__ void __launch_bounds__(256)
+k_lw_norm(const float* __restrict__ dbase, const int32_t* __restrict__ n_valid, int64_t B, float* __restrict__ out, const float* __restrict__ loss,
+          float* __restrict__ out2) {
+    const int nv = n_valid[0];
+    const float sc = nv > 0 ? 1.f / (float)nv : 0.f;
+    if (out2 && blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = loss[0]; out2[1] = (float)nv; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) out[i] = dbase[i] * sc;
+}
+extern "C" int recnow_listwise_loss(const void* groups, int key_dtype, const float* labels, const float* logits, const float* weights, int64_t B,
+                                    float pos_neg_th, float pad_logit, float* out2, float* dlogits, void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || !out2) return RECNOW_EINVAL;
+    if (recnow_key_words(key_dtype) < 1) return RECNOW_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        RN_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(float), st));
+        return RECNOW_OK;
+    }
+    if (!groups || !labels || !logits || !dlogits || !ws) return RECNOW_EINVAL;
+    if (ws_bytes < recnow_listwise_loss_workspace_bytes(B, key_dtype)) return RECNOW_EWORKSPACE;
+    const LwLossWs w = lw_loss_carve(ws, B, key_dtype);
+    int rc;
+    RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
+    if ((rc = recnow_group_keys(groups, key_dtype, B, w.words, w.solo, stream))) return rc;
+    if ((rc = recnow_group_segments(w.words, w.solo, B, w.n_words, w.n_words, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes,
+                                    stream)))
+        return rc;
+    if ((rc = recnow_listwise_segments(labels, logits, w.order, w.seg_first, w.n_seg, B, pos_neg_th, pad_logit, w.seg_valid, w.seg_lse, w.seg_ysum,
+                                       w.seg_psum, w.seg_pdot, w.valid_rank, w.n_valid, w.lw, w.lw_bytes, stream)))
+        return rc;
+    if ((rc = recnow_listwise_loss_fwdbwd(labels, logits, w.order, w.seg_id, w.seg_first, w.seg_valid, w.seg_lse, w.seg_ysum, w.seg_psum, w.seg_pdot,
+                                          w.valid_rank, w.n_valid, weights, B, w.loss, w.dbase, w.row_rank, w.group_loss, stream)))
+        return rc;
+    int G = rn_cdiv(B, 256);
+    if (G > 2048) G = 2048;
+    hipLaunchKernelGGL(k_lw_norm, G, 256, 0, st, w.dbase, w.n_valid, B, dlogits, w.loss, out2);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}

@@ -226,6 +226,43 @@ class _ListwiseFused(torch.autograd.Function):
         return d.reshape(ctx.shape), None, None, None, None, None, None, None
 
 
+class _ListwiseOneCall(torch.autograd.Function):
+    """do_reduce=True through ONE library call (recnow_listwise_loss): grouping, list statistics, mean loss and the gradient already
+    divided by the number of valid lists, on two allocations; the backward pass is one multiply."""
+
+    @staticmethod
+    def forward(ctx, logits, gkey, gdt, labels, weights, pad_logit, pos_neg_th):
+        B = gkey.numel()
+        lab = _lib.f32c(labels, 'labels').reshape(-1)
+        lg = _lib.f32c(logits, 'logits').reshape(-1)
+        if lab.numel() != B or lg.numel() != B:
+            raise ValueError('group_ids, labels and logits must have the same number of elements')
+        w = None
+        if weights is not None:
+            w = _lib.f32c(weights, 'weights').reshape(-1)
+            if w.numel() < B:          # the kernel reads weights[rank of a valid list] (<= B lists): never past the buffer's end
+                w = torch.cat([w, w.new_zeros(B - w.numel())])
+        dev = gkey.device
+        nws = _lib.load().recnow_listwise_loss_workspace_bytes(B, gdt)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        out = torch.empty(B + 2, dtype=torch.float32, device=dev)       # [d loss / d logits (B) | loss | number of valid lists]
+        _lib.call('recnow_listwise_loss', _lib.ptr(gkey), gdt, _lib.ptr(lab), _lib.ptr(lg), _lib.ptr(w), B, float(pos_neg_th), float(pad_logit),
+                  _lib._P(out.data_ptr() + 4 * B), _lib.ptr(out), _lib.ptr(ws), nws, _lib.stream())
+        ctx.save_for_backward(out)
+        ctx.B, ctx.shape = B, logits.shape
+        n_valid = out[B + 1].reshape(())
+        ctx.mark_non_differentiable(n_valid)
+        return out[B].reshape(()), n_valid
+
+    @staticmethod
+    def backward(ctx, g, _gn):
+        (out,) = ctx.saved_tensors
+        return (out[:ctx.B] * g).reshape(ctx.shape), None, None, None, None, None, None
+
+
+_LW_ONE_CALL = __import__('os').environ.get('RECNOW_LISTWISE_ONE_CALL', '1') != '0'      # A/B switch: '0' keeps the piecewise host route
+
+
 def listwise_loss_from_batch(group_ids, labels, logits, weights=None, do_reduce=True, do_mask_logits=True,
                              value_of_masked_logit=-1E9, pos_neg_th=0.5, return_num_list=False):
     """Fused equivalent of
@@ -233,6 +270,12 @@ def listwise_loss_from_batch(group_ids, labels, logits, weights=None, do_reduce=
         loss = listwise_loss_via_softmax_cross_entropy_with_logits(y, s, weights, do_reduce)
     without the (G,B) matrices and (for do_reduce=True) without a host sync.  `weights`: (num_valid_group,) in
     first-occurrence order of the valid groups.  Returns loss [, number of valid lists as a float tensor]."""
+    if do_reduce and _LW_ONE_CALL and isinstance(group_ids, torch.Tensor) and group_ids.is_cuda and group_ids.numel() > 0:
+        from ._segments import _as_key_tensor
+        gkey, gdt = _as_key_tensor(group_ids)
+        loss, n_valid = _ListwiseOneCall.apply(logits, gkey, gdt, labels, weights, float(value_of_masked_logit) if do_mask_logits else 0.0,
+                                               pos_neg_th)
+        return (loss, n_valid) if return_num_list else loss
     loss, n_valid = _ListwiseFused.apply(logits, group_ids, labels, weights, do_reduce, do_mask_logits, value_of_masked_logit,
                                          pos_neg_th)
     return (loss, n_valid) if return_num_list else loss
