@@ -1,5 +1,6 @@
 #include "common.hpp"
 // Bumped whenever an exported signature or recnow_gemm_desc changes incompatibly; rec_now_amd/_lib.py refuses a library whose
 // version differs from the one its SIGNATURES table was written for.  2: recnow_prof_collect (4 arrays), recnow_embed_pool_fwd
-// (V), recnow_gemm_desc (second outputs, side products); 3: recnow_dcn_mix_step, recnow_group_segments_status (round 3).
+// (V), recnow_gemm_desc (second outputs, side products); 3 (round 3): recnow_dcn_mix_step + its descriptor, recnow_pairwise_loss,
+// recnow_listwise_loss, the packed weights kept in recnow_dcn_mix_saved_bytes.
 extern "C" int recnow_abi_version(void) { return 3; }

@@ -585,15 +585,16 @@ extern "C" int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_ho
 struct MixEvents {
     int n = 0;
     hipEvent_t make() {
-        static hipEvent_t pool[64];
-        static int have = 0;
-        if (n >= 64) return nullptr;
-        if (n >= have) {
+        static hipEvent_t pool[16][64];          // per device (an event belongs to the device that was current when it was created)
+        static int have[16];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || n >= 64) return nullptr;
+        if (n >= have[dev]) {
             hipEvent_t ev = nullptr;
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-            pool[have++] = ev;
+            pool[dev][have[dev]++] = ev;
         }
-        return pool[n++];
+        return pool[dev][n++];
     }
 };
 #define MIX_SIGNAL(ev, from)                                  \

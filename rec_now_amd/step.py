@@ -108,8 +108,7 @@ class DCNMixPairwiseStep(object):
         self._layer_events = None
         if reducer is not None:
             self._layer_events = (ctypes.c_void_p * L)(*[reducer.events[L - 1 - l].handle for l in range(L)])
-        for p, g in zip(self.params, self.grads):
-            p.grad = g.view(p.shape)           # written in place by every step
+        self._bind_grads()                     # p.grad = the step's gradient storage, written in place by every step
 
     @staticmethod
     def stages_for(cross, head):
@@ -123,9 +122,16 @@ class DCNMixPairwiseStep(object):
     def _call(self, phases, hi=-1, lo=0, stream=None):
         _lib.call('recnow_dcn_mix_step', ctypes.byref(self.desc), phases, hi, lo, _lib.stream() if stream is None else _lib._P(stream.cuda_stream))
 
+    def _bind_grads(self):
+        """`p.grad` of every parameter is the step's gradient storage (re-bound after `zero_grad(set_to_none=True)` or `p.grad = None`)."""
+        for p, g in zip(self.params, self.grads):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g.view(p.shape)
+
     def _enqueue(self, launch, whole_backward=False):
         """One step on the current stream (+ the side stream for the grouping).  `launch(key, fn)` runs piece `key` (eager: calls fn;
         replay: launches its graph).  Returns after everything is enqueued."""
+        self._bind_grads()
         main = torch.cuda.current_stream()
         # grouping (sort by group id, segments) does not depend on the scores: on a side stream, under the forward pass
         _lib.call('recnow_event_record', self._fork.handle, _lib._P(main.cuda_stream))
