@@ -290,6 +290,13 @@ typedef struct recnow_gemm_desc {
      * is stored as [N / c_perm_s][M][c_perm_s] instead of [M][N], C[((n / s) * M + m) * s + n % s] -- DCN-v2's dU (N, D, S) straight
      * from the product x_l^T dA (D x N*S), without an unpack pass. */
     int c_perm_s; int c_perm_pad;
+    /* Fused sub-space forward of DCNMixLayer (rec_now/layers/dcn_mix_layer.py:135-138,146-147; lean 128x128 kernel, batch 1, no split-K):
+     * the product is formulated TRANSPOSED -- A = [U | K]^T stored [K][M] with M = N_e * S = 128 (a_trans 1), B = x_l^T stored [N][K]
+     * (b_trans 1), so "N" is the batch -- the side product (sp_bx = K, sp_r = 2) is taken from the B tile, and the epilogue continues
+     * from the accumulators: H1 = act(acc) -> mid_T1 [row][s]; per expert C = H1 V on the MFMA with the accumulator registers as the A
+     * fragments (k pairs (s, s + 4): no LDS round trip), H2 = mid_act_outer(C) -> mid_T2, G = softmax(logits), mid_T2g = [G * H2 | G | 0],
+     * logits -> mid_T1[:, 128 + e].  mid_V (2, 64, 64); mid_T1 / mid_T2 / mid_T2g (N x mid_ld).  C is not written. */
+    const float* mid_V; float* mid_T1; float* mid_T2; float* mid_T2g; int64_t mid_ld; int mid_act_outer; int mid_pad;
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;

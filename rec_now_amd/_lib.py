@@ -123,6 +123,7 @@ class GemmDesc(ctypes.Structure):
         ('eu_p', _P), ('eu_q', _P), ('eu_pms', _L), ('eu_qrs', _L), ('eu_qns', _L), ('eu_r', _I), ('eu_pad', _I), ('prof_flops', ctypes.c_double),
         ('C2', _P), ('ldc2', _L), ('E2', _P), ('lde2', _L), ('c2_mode', _I), ('c2_pad', _I), ('as_in', _P), ('as_out', _P),
         ('E3', _P), ('lde3', _L), ('rv', _P), ('cv', _P), ('hv', _P), ('hp', _P), ('hp_ld', _I), ('hp_pad', _I), ('k_valid', _I), ('k_pad', _I), ('c_perm_s', _I), ('c_perm_pad', _I),
+        ('mid_V', _P), ('mid_T1', _P), ('mid_T2', _P), ('mid_T2g', _P), ('mid_ld', _L), ('mid_act_outer', _I), ('mid_pad', _I),
     ]
 
 ABI_VERSION = 3      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)

@@ -472,6 +472,26 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             RnDeferredReduce red1;
             red1.valid = 0;
             const bool absorb = rn_mix_mid_absorbs_slabs(B, S, N, m.LDT);
+            // GEMM1 with the sub-space forward in its epilogue (recnow_gemm_desc.mid_V): two experts of 64, a batch large enough that the
+            // product is not split over K (512 batch tiles), exact-fp32 products; T1, T2 and T2g leave the one kernel, `k_mix_mid_fwd` is gone
+            static const int midf_on = []() { const char* e = getenv("RECNOW_MIDF"); return e ? atoi(e) : 1; }();      // A/B switch: 0 off, 2 any batch (tests)
+            if (midf_on && N == 2 && S == 64 && m.LDT == 144 && B % 128 == 0 && (B / 128 >= 512 || midf_on == 2) && rn_gemm_precision() == 0 &&
+                rn_mix_mid_supported(S, N, m.LDT)) {
+                recnow_gemm_desc d = rn_gemm_desc_zero();
+                d.A = Wc1; d.lda = m.LDT; d.a_trans = 1;             // [U | K]^T: stored [K = D][M = 128 (+ gate columns, unused here)]
+                d.B = xl; d.ldb = D; d.b_trans = 1;                  // x_l^T: stored [N = B][K = D]
+                d.C = T1; d.ldc = m.LDT;                             // (not written: the epilogue stores T1 / T2 / T2g itself)
+                d.M = m.NS; d.N = (int)B; d.K = D;
+                d.prof_flops = 2.0 * (double)B * D * m.KC;
+                d.act = act_inner;
+                d.sp_bx = gate_host[l]; d.sp_bx_ks = N; d.sp_bx_rs = 1; d.sp_cx = T1 + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
+                d.mid_V = V_host[l]; d.mid_T1 = T1; d.mid_T2 = T2; d.mid_T2g = T2g; d.mid_ld = m.LDT; d.mid_act_outer = act_outer;
+                rc = rn_gemm(&d, gws, gws_bytes, st);
+                if (rc && rc != RECNOW_EUNSUPPORTED) return rc;
+            } else {
+                rc = RECNOW_EUNSUPPORTED;
+            }
+            if (rc == RECNOW_EUNSUPPORTED) {
             {   // GEMM1: T1[:, :NS] = act_inner(x_l U);  gate logits T1[:, NS:NS+N] = x_l K as the VALU side product
                 recnow_gemm_desc d = rn_gemm_desc_zero();
                 d.A = xl; d.lda = D; d.a_trans = 0;
@@ -499,6 +519,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             if (sl.n) {
                 if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st, &sl, act_inner))) return rc;
             } else if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
+            }      // (not the fused GEMM1)
             {   // GEMM3: out = x * ([G*H2 | G | 0] [W; b; 0]): K zero-padded NS+N -> KP (a 16-deep k-tile more is cheaper
                 // than a rank-N epilogue update: 215 vs 233 us measured)
                 recnow_gemm_desc d = rn_gemm_desc_zero();

@@ -143,7 +143,7 @@ static inline GemmCfg pick_cfg(int N) {
 static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* splitk, int* kchunk) {
     const long long tiles = (long long)rn_cdiv(d->M, c.BM) * rn_cdiv(d->N, c.BN) * d->batch;
     int s = 1;
-    if (tiles < 512 && !d->as_out && !d->c2_mode) {      // fused side / second outputs need the whole K in one workgroup
+    if (tiles < 512 && !d->as_out && !d->c2_mode && !d->mid_V) {      // fused side / second outputs need the whole K in one workgroup
         s = (int)((512 + tiles - 1) / tiles);          // 256 CUs x 2 resident workgroups (256..511 tiles left half the slots empty until round 2)
         const int maxs = d->K / (8 * 32);      // at least 8 k-tiles per slice
         if (s > maxs) s = maxs;
@@ -151,7 +151,7 @@ static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* 
     }
     // accuracy, not occupancy: an fp32 accumulator that walks K >= 16384 terms in sequence carries ~sqrt(K) roundings (the K = 32768
     // weight gradients of PLE sat at 0.95 of the 1e-5 parity bound); slabs of <= 8192 terms, summed in fp64 by the reduce, halve that
-    if (s == 1 && d->K >= 16384 && !d->as_out && !d->c2_mode && d->c_perm_s == 0) s = d->K / 8192;
+    if (s == 1 && d->K >= 16384 && !d->as_out && !d->c2_mode && !d->mid_V && d->c_perm_s == 0) s = d->K / 8192;
     int kc = rn_cdiv(rn_cdiv(d->K, s), 32) * 32;
     if (kc < 32) kc = 32;
     s = rn_cdiv(d->K, kc);
@@ -258,6 +258,13 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     if (d->c2_mode == 3 && (!d->hv || !d->hp || !d->emul || d->hp_ld < d->N / 64 || ((uintptr_t)d->hv & 15))) return RECNOW_EINVAL;
     if (d->c2_mode == 4 && (!d->E3 || !d->rv || !d->cv || ((uintptr_t)d->cv & 15) || !host_aligned(d->E3, d->lde3, 0))) return RECNOW_EINVAL;
     k.E3 = d->E3; k.lde3 = d->lde3; k.rv = d->rv; k.cv = d->cv; k.hv = d->hv; k.hp = d->hp; k.hp_ld = d->hp_ld;
+    k.mid_V = d->mid_V; k.mid_T1 = d->mid_T1; k.mid_T2 = d->mid_T2; k.mid_T2g = d->mid_T2g; k.mid_ld = d->mid_ld; k.mid_act_outer = d->mid_act_outer;
+    if (d->mid_V) {      // fused sub-space forward: the transposed GEMM1 of DCNMixLayer with two experts of 64 (see recnow_gemm_desc)
+        if (!d->mid_T1 || !d->mid_T2 || !d->mid_T2g || d->M != 128 || d->N % 128 || d->sp_r != 2 || !d->a_trans || !d->b_trans || d->a_mode || d->b_mode ||
+            d->batch != 1 || d->bias || d->emul || d->accumulate || d->c_trans || d->mid_ld % 4 || d->mid_ld < 144 ||
+            (((uintptr_t)d->mid_T1 | (uintptr_t)d->mid_T2 | (uintptr_t)d->mid_T2g) & 15))
+            return RECNOW_EUNSUPPORTED;
+    }
     if (d->c2_mode && (d->K > 512 || d->K % 16 || d->batch != 1)) return RECNOW_EUNSUPPORTED;      // short-K kernel only
 #ifdef RN_GEMM_TRACE
     if (const char* t = getenv("RECNOW_GEMM_TRACE")) k.trace = (long long*)strtoull(t, nullptr, 10);
@@ -285,6 +292,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     // else (and every edge shape) runs the general kernel of the same tile family.
     rc = RECNOW_EUNSUPPORTED;
     int xf = (d->sp_r > 0 ? 1 : 0) | (d->eu_r > 0 ? 2 : 0);
+    if (d->mid_V && (edge || k.splitk != 1 || c.BM != 128 || c.BN != 128 || short_k)) return RECNOW_EUNSUPPORTED;
     // the persistent short-K kernel takes the plain products below (same condition as its branch)
     const bool use_shortk = !xf && !d->as_out && !edge && bk16 && c.BN == 128 && a_kc && k.splitk == 1 && d->batch == 1 && d->a_mode == 0 &&
                             d->b_mode == 0 && !d->bias && d->act == RECNOW_ACT_LINEAR && !d->c_trans &&
@@ -323,9 +331,10 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
             rc = rn_gemm_launch_split(k, a_kc, b_kc, d->a_mode, planes, grid, st);
         }
         static const bool sp_narrow = []() { const char* e = getenv("RECNOW_SP_NARROW"); return !e || e[0] != '0'; }();      // A/B switch
-        if (rc == RECNOW_EUNSUPPORTED && sp_narrow && xf == 1 && d->sp_r <= 2 && !bk16)
+        if (d->mid_V) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, 0, 0, 25, grid, st);      // XF 16 | 8 | 1: the fused sub-space forward
+        else if (rc == RECNOW_EUNSUPPORTED && sp_narrow && xf == 1 && d->sp_r <= 2 && !bk16)
             rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, d->a_mode, d->b_mode, 9, grid, st);
-        if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
+        if (!d->mid_V && rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
     } else if (use_shortk) {
         // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)

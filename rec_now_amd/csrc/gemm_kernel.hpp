@@ -53,6 +53,11 @@ struct GemmK {
     int* cu_slots;             // short-K kernel: per-CU arrival counters of the phase stagger (NULL: no stagger)
     int stagger_ticks;         // delay per arrival slot, in 10 ns ticks of the constant 100 MHz clock
     long long* trace;          // RN_GEMM_TRACE builds only: 8 int64 per workgroup (phase timestamps, HW id)
+    // XF & 16 -- fused sub-space forward of DCNMixLayer behind a TRANSPOSED GEMM1 (see recnow_gemm_desc.mid_V)
+    const float* mid_V;
+    float *mid_T1, *mid_T2, *mid_T2g;
+    int64_t mid_ld;
+    int mid_act_outer;
 };
 
 // Order one wave's LDS writes against its own later LDS reads (and reads against later overwrites).  DS instructions of a
@@ -413,6 +418,80 @@ __device__ __forceinline__ void gemm_lean_epilogue(const GemmK& p, f32x16 (&acc)
     }
 }
 
+// XF & 16: epilogue of the TRANSPOSED GEMM1 of DCNMixLayer (128 T1 columns x 128 batch rows per workgroup; wave (wm, wn): expert wm
+// (S = 64 columns of T1), batch rows wn * 64 .. + 63).  acc[i][j][r] = (x_l U)[row = n0 + wn * 64 + j * 32 + (lane & 31)][s = i * 32 + rmap(r) +
+// 4 * (lane >> 5)] of expert wm, rmap(r) = (r & 3) + 8 * (r >> 2): for the second product C = H1 V the register r of a lane IS the A
+// fragment of the k pair (s, s + 4) -- lanes 0-31 supply k = s, lanes 32-63 k = s + 4 -- so the S x S product runs straight off the
+// accumulators, its B fragments (V, 16 KB per expert, L2-resident) come from global memory.  smem: [0, 512) side-product combine,
+// [512, 768) the gate values G[row][2] (written by the caller before the barrier in front of this function), [1024, ..) staging.
+__device__ __forceinline__ void gemm_midf_epilogue(const GemmK& p, f32x16 (&acc)[2][2], float* smem, int n0, int wm, int wn, int lane, int wave) {
+    const float* Gs = smem + 512;
+    float* stg = smem + 1024 + wave * (32 * 36);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int rr0 = lane >> 3, cc = (lane & 7) * 4;
+    // the B fragments of the second product (this lane's 64 values of V_e) are requested first: they land under the activation and the T1 store
+    const float* Vn = p.mid_V + (int64_t)wm * 64 * 64 + (int64_t)(4 * h) * 64 + l31;
+    float bv[2][16][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s0 = i * 32 + (r & 3) + 8 * (r >> 2);
+            bv[i][r][0] = Vn[s0 * 64];
+            bv[i][r][1] = Vn[s0 * 64 + 32];
+        }
+    // 1 + 3. H1 = act_inner(x_l U) and C = H1 V_e, interleaved: the activation of a register (VALU, ~70 cycles with exp2 / rcp) runs in
+    // the shadow of the previous register's MFMAs; row block j = 0 first, so that its H2 / T2 / T2g epilogue (4.) can be spread over the
+    // MFMA steps of row block j = 1.  acc2[j][tb][r] = C[row = j * 32 + rmap(r) + 4 h][t = tb * 32 + (lane & 31)].
+    f32x16 acc2[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][tb][r] = 0.f;
+    auto finish = [&](int j, int tb, int r) {      // 4. one register of C: H2 = act_outer(C) -> T2, G_e * H2 -> T2g
+        const int rl = wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float g = Gs[rl * 2 + wm];
+        const int64_t ro = (int64_t)(n0 + rl) * p.mid_ld + wm * 64 + tb * 32 + l31;
+        const float h2 = rn_act(acc2[j][tb][r], p.mid_act_outer);
+        p.mid_T2[ro] = h2;
+        p.mid_T2g[ro] = g * h2;
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = rn_act(acc[i][j][r], p.act);
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc2[j][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[i][j][r], bv[i][r][tb], acc2[j][tb], 0, 0, 0);
+                if (j == 1) finish(0, i, r);       // the finished row block's epilogue, one register per MFMA step
+            }
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) finish(1, tb, r);
+    // 2. T1[row][expert * 64 + s] for the backward pass: transposed through a wave-private LDS tile, rows leave as float4
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stg[l31 * 36 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[i][j][r];
+            RN_LDS_WAVE_SYNC();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = q * 8 + rr0;
+                const float4 v = *reinterpret_cast<const float4*>(stg + row * 36 + cc);
+                *reinterpret_cast<float4*>(p.mid_T1 + (int64_t)(n0 + wn * 64 + j * 32 + row) * p.mid_ld + wm * 64 + i * 32 + cc) = v;
+            }
+            RN_LDS_WAVE_SYNC();
+        }
+}
+
 // EDGE = false: every tile of the launch is in bounds and 16-byte aligned (checked on the host) -> no bounds code at
 // all (lean: no spills under the 256-register cap).  EDGE = true: general shapes, clamped loads and predicated stores.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, bool EDGE, int A2K, int B2K, int XF = 0>
@@ -420,6 +499,9 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2)      // >= 2 waves/SIMD: VGPR
 k_gemm(const GemmK p) {
     static_assert(XF == 0 || (!EDGE && BM == 128), "side product / rank-R update: lean 128-row kernels only");
     static_assert((XF & 4) == 0 || (A_KC && A2K == RECNOW_OPMODE_MUL), "A-stream side output: A [M][K] in MUL mode");
+    static_assert((XF & 16) == 0 || ((XF & 9) == 9 && !A_KC && B_KC && BM == 128 && BN == 128 && WAVES_M == 2 && A2K == 0 && B2K == 0),
+                  "fused sub-space forward: transposed GEMM1, two-wide side product from the B tile");
+    constexpr bool MIDF = (XF & 16) != 0;
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
     using TA = Tile<BM, BK, A_KC>;
@@ -430,7 +512,7 @@ k_gemm(const GemmK p) {
     float* const Bs = smem + 2 * A_SZ;
     float* const Bxs = smem + 2 * A_SZ + 2 * B_SZ;     // XF & 1: two buffers of BK x 4 side-product weights
     // (sp_on / side output use blockIdx.y directly: those launches are never remapped in y, see rn_gemm)
-    const bool sp_on = (XF & 1) && blockIdx.y == 0;    // one column-tile computes the side product of a row-tile
+    const bool sp_on = (XF & 1) && (MIDF || blockIdx.y == 0);    // one column-tile computes the side product of a row-tile (MIDF: every workgroup, of its batch rows)
     f32x4 spacc = mk4(0.f, 0.f, 0.f, 0.f);
     // XF & 8 (sliced kernels): the side product has at most two columns (DCN-v2 with two experts): two-wide weights and accumulator --
     // half the FMAs and half the LDS bytes of the weights; the side product costs 15 us of a 180 us launch in its four-wide form
@@ -592,7 +674,9 @@ k_gemm(const GemmK p) {
         }
         // VALU side product off the A tile in LDS: thread = (row m, half of the tile's k range); its 2*(BK/4) k's are
         // spread over the MFMA loop below (2 per iteration) so the FMAs run in the shadow of in-flight MFMAs.
-        const float* asx = As + cur * A_SZ + (threadIdx.x & 127) + (threadIdx.x >> 7) * (BK / 2) * TA::LD;
+        // (MIDF: the product is transposed, the rows of the side product are the rows of the B tile)
+        constexpr int SP_LD = MIDF ? TB::LD : TA::LD;
+        const float* asx = (MIDF ? Bs + cur * B_SZ : As + cur * A_SZ) + (threadIdx.x & 127) + (threadIdx.x >> 7) * (BK / 2) * SP_LD;
         const float* bxs = Bxs + cur * BK * 4 + (threadIdx.x >> 7) * (BK / 2) * 4;
         const float* as = As + cur * A_SZ + a_off;
         const float* bs = Bs + cur * B_SZ + b_off;
@@ -631,7 +715,7 @@ k_gemm(const GemmK p) {
             SPV sb0 = SPV(0.f), sb1 = SPV(0.f);
             if constexpr ((XF & 1) != 0) {
                 sa0 = FR(asx);
-                sa1 = FR(asx + TA::LD);
+                sa1 = FR(asx + SP_LD);
                 sb0 = *reinterpret_cast<const SPV*>(bxs);
                 sb1 = *reinterpret_cast<const SPV*>(bxs + 4);
             }
@@ -646,8 +730,8 @@ k_gemm(const GemmK p) {
                 if constexpr ((XF & 1) != 0) {
                     if (kk + 4 < BK) {
                         const int kq = (kk >> 1) + 2;
-                        na0 = FR(asx + kq * TA::LD);
-                        na1 = FR(asx + (kq + 1) * TA::LD);
+                        na0 = FR(asx + kq * SP_LD);
+                        na1 = FR(asx + (kq + 1) * SP_LD);
                         nb0 = *reinterpret_cast<const SPV*>(bxs + kq * 4);
                         nb1 = *reinterpret_cast<const SPV*>(bxs + (kq + 1) * 4);
                     }
@@ -699,8 +783,8 @@ k_gemm(const GemmK p) {
             for (int j = 0; j < TN; ++j) b1[j] = FR(bs + (kk + 2) * TB::LD + j * 32);
             if constexpr ((XF & 1) != 0) {
                 const int kq = kk >> 1;        // this iteration's two k's of the thread's half-range
-                spacc += asx[kq * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + kq * 4);
-                spacc += asx[(kq + 1) * TA::LD] * *reinterpret_cast<const f32x4*>(bxs + (kq + 1) * 4);
+                spacc += asx[kq * SP_LD] * *reinterpret_cast<const f32x4*>(bxs + kq * 4);
+                spacc += asx[(kq + 1) * SP_LD] * *reinterpret_cast<const f32x4*>(bxs + (kq + 1) * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -754,6 +838,29 @@ k_gemm(const GemmK p) {
         // combine the two k-halves through LDS (free now) and write the side columns
         if (sp_on && threadIdx.x >= 128) *reinterpret_cast<f32x4*>(smem + (threadIdx.x - 128) * 4) = spacc;
         __syncthreads();
+        if constexpr (MIDF) {
+            // the two gate logits of batch row n0 + tid: softmax -> G (LDS, for the epilogue) and the gate columns [128, 144) of the three
+            // activation tensors: T1 keeps the logits, T2 and T2g [G | 0] (the zero padding is read by the K = 144 product that follows)
+            if (threadIdx.x < 128) {
+                const f32x4 o = spacc + *reinterpret_cast<const f32x4*>(smem + threadIdx.x * 4);
+                const float mx = fmaxf(o.x, o.y);
+                const float e0 = expf(o.x - mx), e1 = expf(o.y - mx), sum = e0 + e1;
+                const float g0 = e0 / sum, g1 = e1 / sum;
+                smem[512 + threadIdx.x * 2] = g0;
+                smem[512 + threadIdx.x * 2 + 1] = g1;
+                const int64_t ro = (int64_t)(n0 + threadIdx.x) * p.mid_ld + 128;
+                p.mid_T1[ro] = o.x;
+                p.mid_T1[ro + 1] = o.y;
+                const float4 gz = make_float4(g0, g1, 0.f, 0.f), zz = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(p.mid_T2 + ro) = gz;
+                *reinterpret_cast<float4*>(p.mid_T2g + ro) = gz;
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    *reinterpret_cast<float4*>(p.mid_T2 + ro + 4 * q) = zz;
+                    *reinterpret_cast<float4*>(p.mid_T2g + ro + 4 * q) = zz;
+                }
+            }
+        } else
         if (sp_on && threadIdx.x < 128) {
             const f32x4 o = spacc + *reinterpret_cast<const f32x4*>(smem + threadIdx.x * 4);
             const float ov[4] = {o.x, o.y, o.z, o.w};
@@ -770,6 +877,10 @@ k_gemm(const GemmK p) {
     RN_TR(2);
     // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    if constexpr (MIDF) {
+        gemm_midf_epilogue(p, acc, smem, n0, wm, wn, lane, wave);
+        return;
+    } else
     if constexpr (!EDGE) {
         gemm_lean_epilogue<TM, TN, XF>(p, acc, smem, m0, n0, wm, wn, lane, wave, z, bidx);
         RN_TR(3);

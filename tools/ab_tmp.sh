@@ -1,14 +1,17 @@
 R=$PWD; O=$R/gpurun_out
-run() { tag=$1; shift; timeout -k 10 200 python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" > $O/$tag.json 2> $O/$tag.err || { echo "$tag FAILED"; grep -i "fault" $O/$tag.err; tail -3 $O/$tag.err; exit 1; }
-python3 - $O/$tag.json <<'PY'
-import json,sys
-d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-r=d.get('roofline') or {}
-print(sys.argv[1].split('/')[-1], 'ms %.3f'%d['ms_per_step'], 'par', d['parity_max_rel'], 'gemm us %.1f'%(r.get('avg_launch_us') or 0), {k:round(v['avg_launch_us'],1) for k,v in (r.get('hbm_bound_kernels') or {}).items()})
+cd /tmp && export TMPDIR=/tmp
+for m in 0 1; do
+rm -rf $O/midf_stats$m
+RECNOW_MIDF=$m rocprofv3 --kernel-trace --stats --output-format csv -d $O/midf_stats$m -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > $O/midf_stats$m.log 2>&1
+find $O/midf_stats$m -type f ! -name '*kernel_stats.csv' -delete
+f=$(find $O/midf_stats$m -name '*kernel_stats.csv')
+echo "== MIDF=$m"; python3 - $f <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+tot=0
+for r in rows:
+    n=r['Name']
+    if 'k_gemm<' in n or 'mix_mid_fwd' in n:
+        print('%-90s %4s %8.1f'%(n[:90], r['Calls'], float(r['AverageNs'])/1e3))
 PY
-}
-for kt in 8 4; do
-RECNOW_GEMM_MINKT=$kt RECNOW_MID_SLABS=0 run minkt${kt}_8192 --rows 8192 || exit 1
-RECNOW_GEMM_MINKT=$kt RECNOW_MID_SLABS=0 run minkt${kt}_16384 --rows 16384 || exit 1
 done
-RECNOW_GEMM_MINKT=8 run slabs_8192 --rows 8192 || exit 1
