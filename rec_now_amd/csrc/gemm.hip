@@ -302,6 +302,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
                           (d->a_mode == RECNOW_OPMODE_NONE || d->a_mode == RECNOW_OPMODE_MUL) &&
                           ((a_kc && !b_kc && d->a_mode == 0) || (a_kc && b_kc) || (!a_kc && !b_kc));
     if (split_ok) tag = RN_TAG_GEMM_SPLIT;
+    if (d->mid_V) tag = RN_TAG_GEMM_MIDF;      // a kernel of its own: the product's flops + the whole sub-space forward in one launch
     RnProfRecord* pr = nullptr;
     if (rn_prof_on()) {
         // algorithmic HBM bytes: every operand read once, every output written once (read-modify-write outputs count twice)

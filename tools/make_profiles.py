@@ -105,7 +105,7 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
     fo.write('Sum of kernel durations: %.1f ms over %d steps (3 warm-up + 10 timed + 5 untimed host-enqueue diagnostic + 1 parity step) = %.3f ms/step; the '
              'grouping kernels run on a side stream under the forward pass, so this sum exceeds the wall time per step; `__amd_rocclr_copyBuffer` is the '
              'parity step copying results to the host, outside the timed region.\n\n' % (tot / 1e6, steps, tot / 1e6 / steps))
-    gem = [r for r in rows if 'k_gemm<128, 128' in r['Name']]
+    gem = [r for r in rows if 'k_gemm<128, 128' in r['Name'] and ', 25>' not in r['Name']]      # (the ', 25>' instantiation: GEMM1 + sub-space forward, listed on its own)
     if gem:
         gavg = sum(r['TotalDurationNs'] for r in gem) / sum(r['Calls'] for r in gem) / 1e3
         fo.write('**`k_gemm<128,128,..>` (the dominant kernel), three figures of one build**: rocprofv3 average over its %d launches in this profiled run '
@@ -117,6 +117,11 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
             fo.write('; the hook in the UNPROFILED run of the same build (`%s_bench.json`, what `bench.py` reports) %.1f us = %.3f, step %.3f ms'
                      % (tag, clean['roofline']['avg_launch_us'], clean['roofline']['frac'], clean['ms_per_step']))
         fo.write('.\n\n')
+        mf = [r for r in rows if 'k_gemm<128, 128' in r['Name'] and ', 25>' in r['Name']]
+        if mf:
+            fo.write('`k_gemm<128,128,..,25>` (the transposed GEMM1 with the sub-space forward in its epilogue, %d launches: its own kernel in these figures) %.1f us per '
+                     'launch, of which the product itself is ~%.0f us; it replaces `k_gemm<..true, false..9>` + `k_mix_mid_fwd`.\n\n'
+                     % (sum(r['Calls'] for r in mf), sum(r['TotalDurationNs'] for r in mf) / sum(r['Calls'] for r in mf) / 1e3, gavg))
     fo.write('| kernel | calls | total ms | avg us | min us | % |\n|---|---|---|---|---|---|\n')
     for r in rows[:26]:
         fo.write('| `%s` | %s | %.2f | %.1f | %.1f | %s |\n' % (r['Name'][:100].replace('|', '/'), r['Calls'], float(r['TotalDurationNs']) / 1e6,
