@@ -19,6 +19,7 @@
 // takes the lean interior kernel (no bounds code) whenever B is a multiple of 256.  Zero columns/rows are inert.
 #include "gemm.hpp"
 #include "dcnmix_mid.hpp"
+#include "dcnmix_chain.hpp"
 
 static inline int ldt_of(int S, int N) {
     const int kc = N * S + N;
@@ -457,6 +458,13 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     int rc;
     if (pack_once && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st))) return rc;
     const float* xl = x;
+    // chained products (csrc/dcnmix_chain.hip): the product that leaves layer l and GEMM1 of layer l + 1 in one kernel.  Measured slower
+    // than the two launches (the chip's clock drops when the HBM streams run beside the MFMAs: see the file's header): opt-in,
+    // RECNOW_CHAIN=1 from 512 row blocks on, 2 for any batch (tests)
+    static const int chain_on = []() { const char* e = getenv("RECNOW_CHAIN"); return e ? atoi(e) : 0; }();
+    const bool chain = chain_on && pack_once && rn_mix_chain_fwd_supported(B, D, S, N, m.LDT) && (B / 128 >= 512 || chain_on == 2) &&
+                       rn_gemm_precision() == 0 && rn_mix_mid_supported(S, N, m.LDT);
+    bool t1_ready = false;           // T1 of this layer was produced by the previous layer's chained kernel
     for (int l = 0; l < L; ++l) {
         float* T1 = (float*)(sv + (size_t)(3 * l) * act_block(m));
         float* T2 = (float*)(sv + (size_t)(3 * l + 1) * act_block(m));
@@ -469,6 +477,9 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             } else if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) {
                 return rc;
             }
+            if (t1_ready) {
+                if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
+            } else {
             RnDeferredReduce red1;
             red1.valid = 0;
             const bool absorb = rn_mix_mid_absorbs_slabs(B, S, N, m.LDT);
@@ -520,6 +531,17 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st, &sl, act_inner))) return rc;
             } else if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
             }      // (not the fused GEMM1)
+            }      // (T1 not already there)
+            t1_ready = false;
+            if (chain && l + 1 < L) {      // out = x * (T2g [W; b]) (+ O_l) and T1 of layer l + 1 in one kernel
+                if ((rc = rn_mix_chain_fwd(T2g, Wc2, x, out, need_dx ? omid + (size_t)l * (xbuf(m) / sizeof(float)) : nullptr,
+                                           Wc1_all + (size_t)(l + 1) * D * m.LDT, gate_host[l + 1],
+                                           (float*)(sv + (size_t)(3 * (l + 1)) * act_block(m)), B, D, m.LDT, act_inner, st)))
+                    return rc;
+                t1_ready = true;
+                xl = out;
+                continue;
+            }
             {   // GEMM3: out = x * ([G*H2 | G | 0] [W; b; 0]): K zero-padded NS+N -> KP (a 16-deep k-tile more is cheaper
                 // than a rank-N epilogue update: 215 vs 233 us measured)
                 recnow_gemm_desc d = rn_gemm_desc_zero();
