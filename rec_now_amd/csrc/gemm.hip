@@ -44,6 +44,20 @@ __device__ __forceinline__ void splitk_reduce_body(const GemmK& p, const int bid
         for (int e = 0; e < W; ++e) s[e] = 0.0;
         int k = k_lo;
         if (VEC) {
+            // eight slabs in flight per lane (the loop is bound by the latency of its loads: 4 in flight read 2.7 TB/s); the sums keep
+            // the sequential order
+            for (; k + 8 <= k_hi; k += 8) {
+                float4 a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const float4*>(P + (int64_t)(k + u) * MN);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s[0] += a[u].x;
+                    s[1 % W] += a[u].y;
+                    s[2 % W] += a[u].z;
+                    s[3 % W] += a[u].w;
+                }
+            }
             for (; k + 4 <= k_hi; k += 4) {
                 const float4 a0 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 0) * MN);
                 const float4 a1 = *reinterpret_cast<const float4*>(P + (int64_t)(k + 1) * MN);
