@@ -108,8 +108,12 @@ B, F, D, Hs = 16384, 64, 16, [128, 128, 128]
 ext = [F] + Hs
 fwd = 2.0 * D * F * sum(ext[k - 1] * ext[k] for k in range(1, len(ext))) * B
 steps = 13            # layer_bench: 10 warm-up + 3 timed steps (n = max(3, reps // 3)); the GEMM launch counts below divide evenly by it
+GEMM_MS_CIN = sum(float(r['TotalDurationNs']) for r in rows if 'k_gemm' in r['Name'] and 'reduce' not in r['Name']) / steps / 1e6
 gemm_table(rows, steps, 3 * fwd, '## CINLayer, configs[3] per-rank share: B = %d, F = %d, D = %d, H = %s  (bound: fp32 MFMA)\n' % (B, F, D, Hs),
-           'The backward recomputes the outer-product operand for dX and dx0 (4 x forward flops executed).')
+           'SURVEY 8d prices the backward at 2 x forward; the layer is TRILINEAR in (W, x0, X_{k-1}), so its backward is three contractions of the forward\'s size '
+           '(dW, dX_{k-1}, dx0: none of them can be derived from another), each a GEMM whose outer-product operand is generated in the operand load: 4 x forward = '
+           '%.2f TFLOP are necessary and executed per step, i.e. **%.1f TFLOP/s = %.2f of the fp32 MFMA peak inside the GEMM kernels** -- the rate of `k_gemm` in the c3 step.'
+           % (4 * fwd / 1e12, 4 * fwd / GEMM_MS_CIN / 1e9, 4 * fwd / GEMM_MS_CIN / 1e9 / PEAK_MFMA))
 
 # ---- PLE (c5 per rank) ------------------------------------------------------------------------------------------------------
 rows = stats('ple')
