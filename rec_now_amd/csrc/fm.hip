@@ -49,6 +49,60 @@ k_fm_fwd_vec4(const float* const* __restrict__ fields, int F, int64_t nchunk /* 
     }
 }
 
+// The same with CPL chunks per thread: a wave reads CPL x 1 KiB = 4 KiB CONTIGUOUS of every field (CPL coalesced instructions), FU
+// fields at a time -- FU * CPL loads in flight per lane.  One KiB per wave and field left the 64 field streams at 3.9 TB/s.
+template <bool SAVE_S, int CPL, int FU>
+__global__ void __launch_bounds__(256)
+k_fm_fwd_wide(const float* const* __restrict__ fields, int F, int64_t nchunk, int lanes_per_row, float* __restrict__ y, float* __restrict__ S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per_blk = 256 * CPL;
+    for (int64_t q0 = (int64_t)blockIdx.x * per_blk; q0 < nchunk; q0 += (int64_t)gridDim.x * per_blk) {
+        int64_t q[CPL], qc[CPL];
+        rn_f4 s[CPL], sq[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            q[c] = q0 + (int64_t)(wave * CPL + c) * 64 + lane;
+            qc[c] = q[c] < nchunk ? q[c] : 0;          // lanes past the end read chunk 0 (no branch around a load); their rows are not stored
+            s[c] = sq[c] = rn_f4{0.f, 0.f, 0.f, 0.f};
+        }
+        int f = 0;
+        for (; f + FU <= F; f += FU) {
+            rn_gcf4 p[FU];
+            rn_f4 v[FU][CPL];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) p[u] = (rn_gcf4)fields[f + u];
+#pragma unroll
+            for (int u = 0; u < FU; ++u)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) v[u][c] = p[u][qc[c]];
+#pragma unroll
+            for (int u = 0; u < FU; ++u)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    s[c] += v[u][c];
+                    sq[c] += v[u][c] * v[u][c];
+                }
+        }
+        for (; f < F; ++f) {
+            const rn_gcf4 p = (rn_gcf4)fields[f];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const rn_f4 v = p[qc[c]];
+                s[c] += v;
+                sq[c] += v * v;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const bool ok = q[c] < nchunk;
+            if (SAVE_S && ok) reinterpret_cast<rn_f4*>(S)[q[c]] = s[c];
+            float r = (s[c].x * s[c].x - sq[c].x) + (s[c].y * s[c].y - sq[c].y) + (s[c].z * s[c].z - sq[c].z) + (s[c].w * s[c].w - sq[c].w);
+            for (int o = lanes_per_row >> 1; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+            if (ok && (q[c] % lanes_per_row) == 0) y[q[c] / lanes_per_row] = 0.5f * r;
+        }
+    }
+}
+
 // generic shapes (D not a multiple of 4 or D/4 not a power of two <= 64): one thread per row
 template <bool SAVE_S>
 __global__ void __launch_bounds__(256)
@@ -113,6 +167,70 @@ k_fm_bwd_vec4(const float* const* __restrict__ fields, float* const* __restrict_
     }
 }
 
+// CPL chunks per thread, as k_fm_fwd_wide: 4 KiB contiguous per wave and field for the loads and for the stores; the loads of the next
+// FU fields are issued before the stores of the current ones.
+template <int CPL, int FU>
+__global__ void __launch_bounds__(256)
+k_fm_bwd_wide(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int64_t nchunk, int lanes_per_row,
+              const float* __restrict__ S, const float* __restrict__ gy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per_blk = 256 * CPL;
+    // the host launches this kernel only when nchunk is a multiple of 256 * CPL: every chunk index below is in range
+    for (int64_t q0 = (int64_t)blockIdx.x * per_blk; q0 < nchunk; q0 += (int64_t)gridDim.x * per_blk) {
+        int64_t q[CPL];
+        rn_f4 s[CPL];
+        float g[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            q[c] = q0 + (int64_t)(wave * CPL + c) * 64 + lane;
+            g[c] = gy[q[c] / lanes_per_row];
+            s[c] = reinterpret_cast<const rn_f4*>(S)[q[c]];
+        }
+        rn_f4 v[FU][CPL], nv[FU][CPL];
+        int f = 0;
+        if (FU <= F) {
+            rn_gcf4 p[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) p[u] = (rn_gcf4)fields[u];
+#pragma unroll
+            for (int u = 0; u < FU; ++u)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) v[u][c] = p[u][q[c]];
+        }
+        for (; f + FU <= F; f += FU) {
+            const bool more = f + 2 * FU <= F;            // block-uniform
+            rn_gf4 dp[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) dp[u] = (rn_gf4)dfields[f + u];
+            if (more) {
+                rn_gcf4 p[FU];
+#pragma unroll
+                for (int u = 0; u < FU; ++u) p[u] = (rn_gcf4)fields[f + FU + u];
+#pragma unroll
+                for (int u = 0; u < FU; ++u)
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) nv[u][c] = p[u][q[c]];
+            }
+#pragma unroll
+            for (int u = 0; u < FU; ++u)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) dp[u][q[c]] = g[c] * (s[c] - v[u][c]);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < FU; ++u)
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) v[u][c] = nv[u][c];
+            }
+        }
+        for (; f < F; ++f) {
+            const rn_gcf4 p = (rn_gcf4)fields[f];
+            const rn_gf4 dp = (rn_gf4)dfields[f];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) dp[q[c]] = g[c] * (s[c] - p[q[c]]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_fm_bwd_generic(const float* const* __restrict__ fields, float* const* __restrict__ dfields, int F, int64_t B, int D,
                  const float* __restrict__ S, const float* __restrict__ gy) {
@@ -144,7 +262,12 @@ extern "C" int recnow_fm_fwd(const float* const* fields, int F, int64_t B, int D
     hipStream_t st = (hipStream_t)stream;
     if (fm_vec_ok(D)) {
         const int64_t nchunk = B * D / 4;
-        if (S) hipLaunchKernelGGL(k_fm_fwd_vec4<true>, fm_grid(nchunk), 256, 0, st, fields, F, nchunk, D / 4, y, S);
+        static const int wide = []() { const char* e = getenv("RECNOW_FM_WIDE"); return e ? atoi(e) : 1; }();      // A/B switch: 0 = one chunk per thread
+        if (wide && nchunk >= 256 * 4 * 512) {          // enough chunks for 512 workgroups of 4 per thread
+            const int g = fm_grid((nchunk + 3) / 4);
+            if (S) hipLaunchKernelGGL((k_fm_fwd_wide<true, 4, 4>), g, 256, 0, st, fields, F, nchunk, D / 4, y, S);
+            else hipLaunchKernelGGL((k_fm_fwd_wide<false, 4, 4>), g, 256, 0, st, fields, F, nchunk, D / 4, y, S);
+        } else if (S) hipLaunchKernelGGL(k_fm_fwd_vec4<true>, fm_grid(nchunk), 256, 0, st, fields, F, nchunk, D / 4, y, S);
         else hipLaunchKernelGGL(k_fm_fwd_vec4<false>, fm_grid(nchunk), 256, 0, st, fields, F, nchunk, D / 4, y, S);
     } else {
         if (S) hipLaunchKernelGGL(k_fm_fwd_generic<true>, rn_cdiv(B, 256), 256, 0, st, fields, F, B, D, y, S);
@@ -163,7 +286,10 @@ extern "C" int recnow_fm_bwd(const float* const* fields, float* const* dfields, 
     hipStream_t st = (hipStream_t)stream;
     if (fm_vec_ok(D)) {
         const int64_t nchunk = B * D / 4;
-        hipLaunchKernelGGL(k_fm_bwd_vec4, fm_grid(nchunk), 256, 0, st, fields, dfields, F, nchunk, D / 4, S, gy);
+        static const int wide = []() { const char* e = getenv("RECNOW_FM_WIDE"); return e ? atoi(e) : 1; }();
+        if (wide && nchunk >= 256 * 4 * 512 && nchunk % (256 * 4) == 0)
+            hipLaunchKernelGGL((k_fm_bwd_wide<4, 4>), fm_grid(nchunk / 4), 256, 0, st, fields, dfields, F, nchunk, D / 4, S, gy);
+        else hipLaunchKernelGGL(k_fm_bwd_vec4, fm_grid(nchunk), 256, 0, st, fields, dfields, F, nchunk, D / 4, S, gy);
     } else {
         hipLaunchKernelGGL(k_fm_bwd_generic, fm_grid(B * D), 256, 0, st, fields, dfields, F, B, D, S, gy);
     }
