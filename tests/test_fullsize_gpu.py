@@ -112,6 +112,29 @@ def test_fm_config4_full_size(dev):
         close(a.grad, b.grad, scale=gs)
 
 
+@pytest.mark.parametrize('B,F,D', [(131072 + 37, 6, 16), (65536 + 3, 9, 32)])
+def test_fm_wide_kernels_ragged_sizes(dev, B, F, D):
+    """The four-chunks-per-thread FM kernels (csrc/fm.hip k_fm_fwd_wide / k_fm_bwd_wide: from 524 288 float4 chunks on) on batches
+    that are not a multiple of their 1024-chunk step (the forward masks the tail, the backward takes the one-chunk kernel) and a
+    field count that is not a multiple of the four fields in flight."""
+    from rec_now_amd.layers.fm_layer import FMLayer
+    g = torch.Generator(device='cpu').manual_seed(B)
+    xs = [torch.rand(B, D, generator=g) - 0.5 for _ in range(F)]
+    gy = torch.randn(B, 1, generator=g)
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    y = FMLayer()(xd)
+    y.backward(gy.to(dev))
+    x64 = [x.double().requires_grad_(True) for x in xs]
+    ry = R.fm_layer(x64)
+    ry.backward(gy.double())
+    st = torch.stack(xs).double()
+    scale = float((0.5 * ((st.sum(0) ** 2).sum(1) + (st ** 2).sum((0, 2)))).max())
+    close(y, ry, scale=scale)
+    gs = max(float(v.grad.abs().max()) for v in x64)
+    for a, b in zip(xd, x64):
+        close(a.grad, b.grad, scale=gs)
+
+
 def test_ple_config5_per_rank_size(dev):
     """configs[4] per-rank share: B = 32768, D_in = 128 x 32, 3 tasks; row subset against the oracle is not available for PLE
     without re-deriving its weight layout, so the checks are the size-independent ones: row independence (the outputs and
