@@ -362,6 +362,10 @@ int rn_mix_chain_fwd(const float* T2g, const float* Wc2, const float* x0, float*
     const size_t lds = (2 * CH_TILE + 4 * 2048 + (size_t)D * 2) * sizeof(float);
     const int grid = p.nrb < 512 ? p.nrb : 512;
     RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_MIX_CHAIN, 4.0 * B * D * 130.0, 4.0 * B * (2.0 * LDT + (O ? 3.0 : 2.0) * D), st) : nullptr;
+    if (lds > 64 * 1024) {          // D > 2048: more than the default limit of dynamic LDS per workgroup
+        if (O) RN_HIP(hipFuncSetAttribute((const void*)k_mix_chain_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else RN_HIP(hipFuncSetAttribute((const void*)k_mix_chain_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (O) hipLaunchKernelGGL((k_mix_chain_fwd<true>), grid, CH_THREADS, lds, st, p);
     else hipLaunchKernelGGL((k_mix_chain_fwd<false>), grid, CH_THREADS, lds, st, p);
     rn_prof_end(pr, st);

@@ -373,7 +373,9 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
         if (g > 2048) g = 2048;
         static const bool quad_reduce = []() { const char* e = getenv("RECNOW_REDUCE_QUAD"); return !e || e[0] != '0'; }();      // A/B switch
         int variant = 0, blocks = g;
-        if (d->N % 4 == 0 && quad_reduce && k.splitk >= 16 && (total / 4) % 64 == 0) {      // whole quads per wave: the shuffles need all four lanes in the loop
+        // four lanes per output (each a quarter of the slabs) only where one lane per output would leave the chip idle: with eight slabs in
+        // flight per lane the one-lane form reads faster from 96 workgroups on (c3 layer-end reduction: 19.3 vs 24.1 us)
+        if (d->N % 4 == 0 && quad_reduce && k.splitk >= 16 && (total / 4) % 64 == 0 && rn_cdiv(total / 4, 256) < 96) {      // whole quads per wave: the shuffles need all four lanes in the loop
             variant = 2;
             blocks = rn_cdiv(total, 256) > 4096 ? 4096 : rn_cdiv(total, 256);
         } else if (d->N % 4 == 0) {
