@@ -120,9 +120,9 @@ def one_rank_rccl(dev):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('B,two_streams', [(8192, False), (8192, True), (16384, True)])
+@pytest.mark.parametrize('B,two_streams', [(8192, False), (8192, True), (16384, True), (32768, True)])
 def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B, two_streams):
-    """(8192, 1024) and (16 384, 1024): the 8- and 4-GPU shards of the metric's batch, step route + LayerwiseReducer over a 1-rank
+    """(8192, 1024), (16 384, 1024) and (32 768, 1024): the 8-, 4- and 2-GPU shards of the metric's batch, step route + LayerwiseReducer over a 1-rank
     RCCL group (every collective runs), eager and replayed from graphs, against the fp64 oracle: loss, pair count, scores,
     d loss / d x and all 17 weight gradients."""
     from rec_now_amd import dp
