@@ -67,8 +67,7 @@ PEAK_HBM_GBS = 8000.0                 # same guide, "HBM3E peak BW" (spec; 6.29 
 PROF_EVERY = 5                        # time every 5th hooked launch (24 per step: every launch position gets sampled)
 GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>',
              5: 'k_gemm_shortk', 8: 'k_gemm_split',         # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
-             9: 'k_gemm<128,128,2,2,..,25> (GEMM1 + sub-space forward in its epilogue)',
-             10: 'k_mix_chain_fwd (opt-in RECNOW_CHAIN=1: layer-out product chained into the next GEMM1)'}
+             9: 'k_gemm<128,128,2,2,..,25> (GEMM1 + sub-space forward in its epilogue)'}
 HBM_TAGS = {5: 'k_gemm_shortk', 6: 'k_mix_mid_fwd', 7: 'k_mix_mid_bwd'}
 CHECK_SCALE = 120.0                   # the parity step's inputs: x * 120 (std 6) -> scores of O(0.3), loss != ln 2
 PARITY_TOL = 1e-5                     # north_star: 1e-5 relative, GPU fp32 against the fp64 oracle (row subset + the full batch)
@@ -120,35 +119,54 @@ def _split(named):
             [named['cross.gate_of_layer%d/kernel' % l] for l in range(LAYERS)], named['head.kernel'], named['head.bias'])
 
 
+def _cpu_model(named, dtype):
+    """The oracle's layers over the named weights: (forward closure rows -> scores, {name: leaf tensor})."""
+    R, _ = _oracle()
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype).requires_grad_(True) for k, v in named.items()}
+    U, V, W, b, K, hk, hb = _split(w)
+    return (lambda xc: R.multi_dense_layer(R.dcn_mix_layer(xc, U, V, W, b, K), hk, hb).reshape(-1)), w
+
+
+def cpu_scores(fwd, x, dtype, chunk=8192):
+    """Scores of the rows of x by the oracle's layers, in row chunks (no gradient)."""
+    xt = torch.from_numpy(x)
+    scores = np.empty(x.shape[0], np.float32 if dtype == torch.float32 else np.float64)
+    with torch.no_grad():
+        for lo in range(0, x.shape[0], chunk):
+            scores[lo:lo + chunk] = fwd(xt[lo:lo + chunk].to(dtype)).numpy()
+    return scores
+
+
+def cpu_backward(fwd, x, ds, dtype, chunk=8192):
+    """Backward of the oracle's layers over the rows of x given d loss / d score: returns d loss / d x; the weight gradients
+    accumulate in the leaf tensors of `_cpu_model` (summed over the chunks: the layers are row-separable)."""
+    xt = torch.from_numpy(x)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    ds_t = torch.from_numpy(np.asarray(ds).astype(npdt))
+    dx = np.empty(x.shape, npdt)
+    for lo in range(0, x.shape[0], chunk):
+        xc = xt[lo:lo + chunk].to(dtype).clone().requires_grad_(True)
+        fwd(xc).backward(ds_t[lo:lo + chunk])
+        dx[lo:lo + chunk] = xc.grad.numpy()
+    return dx
+
+
 def cpu_step_full(x, groups, labels, named, chunk=8192, dtype=torch.float32, warm_rows=0):
     """ONE fwd+bwd step of the workload at the full batch on the host: oracle layers in row chunks (torch CPU, `dtype`) + the
     segment-based C pair loss.  dtype float32: the CPU baseline that is timed (after an untimed warm-up over `warm_rows` rows, so the
     figure is not a cold first call); float64: the oracle every output and gradient of the GPU step is held to.
     Returns (loss, dx, {name: grad}, scores, n_pair, seconds)."""
-    R, PO = _oracle()
-    npdt = np.float32 if dtype == torch.float32 else np.float64
-    w = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype).requires_grad_(True) for k, v in named.items()}
-    U, V, W, b, K, hk, hb = _split(w)
-    B = x.shape[0]
-    xt = torch.from_numpy(x)
-    fwd = lambda xc: R.multi_dense_layer(R.dcn_mix_layer(xc, U, V, W, b, K), hk, hb).reshape(-1)       # noqa: E731
+    _, PO = _oracle()
+    fwd, w = _cpu_model(named, dtype)
     if warm_rows:
-        xc = xt[:warm_rows].to(dtype).requires_grad_(True)
+        xc = torch.from_numpy(x[:warm_rows]).to(dtype).requires_grad_(True)
         fwd(xc).sum().backward()
         for v in w.values():
             v.grad = None
     t0 = time.perf_counter()
-    scores = np.empty(B, npdt)
-    with torch.no_grad():
-        for lo in range(0, B, chunk):
-            scores[lo:lo + chunk] = fwd(xt[lo:lo + chunk].to(dtype)).numpy()
+    scores = cpu_scores(fwd, x, dtype, chunk)
     loss, ds, n_pair = PO.pairwise_bpr(groups, labels, scores, grouped=True)
-    ds_t = torch.from_numpy(ds.astype(npdt))
-    dx = np.empty(x.shape, npdt)
-    for lo in range(0, B, chunk):
-        xc = xt[lo:lo + chunk].to(dtype).clone().requires_grad_(True)
-        fwd(xc).backward(ds_t[lo:lo + chunk])
-        dx[lo:lo + chunk] = xc.grad.numpy()
+    dx = cpu_backward(fwd, x, ds, dtype, chunk)
     sec = time.perf_counter() - t0
     return loss, dx, {k: v.grad.numpy() for k, v in w.items()}, scores, n_pair, sec
 
@@ -195,7 +213,7 @@ def rel_err(a, b, scale=None):
     return float(np.abs(a - b).max() / s)
 
 
-def subset_parity(x, groups, labels, named, scores_gpu, dx_gpu, n_pair_gpu, n_groups=4):
+def subset_parity(x, groups, labels, named, scores_gpu, dx_gpu, n_pair_gpu, n_groups=4, p_total=None):
     """~256 rows of whole groups of the full-size GPU step against the fp64 oracle: the layers are row-separable and the pair
     gradient of a row involves its own group only (the global pair count comes from the labels and groups alone)."""
     R, PO = _oracle()
@@ -205,12 +223,52 @@ def subset_parity(x, groups, labels, named, scores_gpu, dx_gpu, n_pair_gpu, n_gr
     U, V, W, b, K, hk, hb = _split(w)
     x64 = torch.from_numpy(x[rows]).double().requires_grad_(True)
     s64 = R.multi_dense_layer(R.dcn_mix_layer(x64, U, V, W, b, K), hk, hb).reshape(-1)
-    _, _, p_total = PO.pairwise_bpr(groups, labels, np.zeros_like(labels), grouped=True)        # pair count: labels and groups only
+    if p_total is None:
+        _, _, p_total = PO.pairwise_bpr(groups, labels, np.zeros_like(labels), grouped=True)    # pair count: labels and groups only
     lsum, ds, p_sub = PO.pairwise_bpr(groups[rows], labels[rows], s64.detach().numpy().astype(np.float32))
     ds_full = ds * (float(np.float32(p_sub)) + 1e-10) / (float(np.float32(p_total)) + 1e-10)      # same terms, global normalisation
     s64.backward(torch.from_numpy(ds_full))
     return {'rows': int(rows.size), 'pairs_total_cpu': int(p_total), 'pairs_total_gpu': int(n_pair_gpu),
             'scores': rel_err(scores_gpu[rows], s64.detach().numpy()), 'dx': rel_err(dx_gpu[rows], x64.grad.numpy())}
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: THIS process has made no GPU call yet (importing torch and counting devices
+    do not initialise the runtime) and makes none -- it starts the N ranks as CHILD processes through torch.distributed.run (never an
+    exec of a process that touched the GPU), relays their output, prints rank 0's JSON line as the LAST line of stdout and exits
+    with the children's return code."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()
+    if visible < n_ranks:
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible on this host (torch.cuda.device_count() = %d, '
+                         'HIP_VISIBLE_DEVICES=%s); one process per GPU, nothing launched'
+                         % (n_ranks, visible, visible, os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + [a for a in argv if a != '--launch']
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    print('[bench] launching %d ranks: %s' % (n_ranks, ' '.join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            line_json = line
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line_json is not None:
+        sys.stdout.write(line_json)
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+        print('[bench] the ranks exited without a JSON line', file=sys.stderr)
+    raise SystemExit(rc)
 
 
 def main():
@@ -240,7 +298,11 @@ def main():
                     help="arithmetic of the long-K products: 'f32' exact fp32 MFMA (the headline), 'bf16x3' the opt-in split-precision kernels "
                          '(fp32 operands as three bf16 pieces, six bf16 MFMA terms, fp32 accumulation; same 1e-5 parity bound, not bit-identical)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
+    ap.add_argument('--launch', action='store_true', help='start the ranks through the self-launcher even when --gpus is 1 (tests: --gpus 1 --force-dist --launch); '
+                    '--gpus N > 1 without WORLD_SIZE in the environment always takes it')
     args = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.launch):
+        self_launch(args.gpus, sys.argv[1:])          # before ANY device call; does not return
 
     # The N > 1 step uses four streams (main, grouping, gradient all-reduce, RCCL's own).  With HIP's default of 4 hardware queues
     # two of them shared a queue: either the grouping ran in front of the forward pass instead of under it, or the all-reduce
@@ -250,8 +312,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -525,7 +587,7 @@ def main():
     # ---- parity step (untimed): same shapes and kernels, inputs scaled so that the scores are of O(1) ----------------------
     parity = None
     cpu = None
-    if world == 1 and (graph is None or pstep is not None) and not args.no_input_grad:      # N > 1: the same kernels run, checked at N = 1
+    if not use_dist and (graph is None or pstep is not None) and not args.no_input_grad:      # under a process group: the cross-rank gate below
         xq = (xd.detach() * CHECK_SCALE).requires_grad_(True)
         loss_q = step(xq)
         torch.cuda.synchronize()
@@ -567,6 +629,78 @@ def main():
             parity['parity_max_rel'] = worst
             parity['ok'] = bool(worst <= PARITY_TOL and abs(parity['loss'] - float(np.log(2.0))) > 1e-3)
 
+    # ---- N > 1 (or --force-dist): the same gate, across the ranks -------------------------------------------------------------
+    # One more step on the scaled inputs; (scores, labels, groups) of every rank are all-gathered ONCE and the reduced loss and the
+    # pair count are held to oracle/pairs_oracle.c on the gathered batch; every rank evaluates the fp64 oracle of the layers on ITS
+    # rows (scores -> gathered -> the global pair gradient -> backward of its rows), the per-rank weight gradients are summed
+    # (all-reduce of the fp64 oracle gradients) and the all-reduced GPU gradients are held to that sum.
+    if use_dist and (graph is None or pstep is not None) and not args.no_input_grad:
+        _, PO = _oracle()
+        rccl_ranks = dist.get_world_size()
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(world, 1)))
+        xq = (xd.detach() * CHECK_SCALE).requires_grad_(True)
+        loss_q = step(xq)
+        torch.cuda.synchronize()
+        p_glob = float(last['n_pair'].item())
+        named = {'cross.' + k: v for k, v in model.cross.named_weights().items()}
+        named['head.kernel'], named['head.bias'] = model.head.kernel, model.head.bias
+        named_np = {k: v.detach().cpu().numpy() for k, v in named.items()}
+        xq_np = x * np.float32(CHECK_SCALE)
+        sc_gpu = last['scores'].detach().cpu().numpy()
+        dx_gpu = (last['dx'] if pstep is not None else xq.grad).cpu().numpy() / (np.float32(p_glob) + np.float32(1e-10))       # every N > 1 route differentiates the loss SUM
+        full_gate = not args.no_cpu_baseline
+        fwd, wleaf = _cpu_model(named_np, torch.float64)
+        sc64 = cpu_scores(fwd, xq_np, torch.float64) if full_gate else sc_gpu.astype(np.float64)
+
+        def gather(a):
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            parts = [torch.empty_like(t) for _ in range(rccl_ranks)]
+            dist.all_gather(parts, t)
+            return torch.cat(parts).cpu().numpy()
+        g_all, y_all, s_all, s64_all = gather(groups), gather(labels), gather(sc_gpu), gather(sc64)
+        # (a) the loss stage + the reduction: oracle pair loss of the GATHERED batch on the GPU's own scores
+        o_loss, _, o_pairs = PO.pairwise_bpr(g_all, y_all, s_all, grouped=True)
+        parity = {'inputs': 'x * %g' % CHECK_SCALE, 'loss': float(loss_q.item()), 'tolerance': PARITY_TOL, 'rccl_ranks': rccl_ranks,
+                  'gathered_rows': int(g_all.size),
+                  'gathered_batch_pairs_oracle': {'loss': rel_err(float(loss_q.item()), o_loss), 'pairs_gpu': int(p_glob), 'pairs_oracle': int(o_pairs),
+                                                  'pairs_equal': int(p_glob) == int(o_pairs)}}
+        worst = parity['gathered_batch_pairs_oracle']['loss']
+        ok = int(p_glob) == int(o_pairs)
+        # ~256 rows of whole groups of THIS rank's shard against the fp64 oracle (scores, d loss / d x), global pair count
+        sub = subset_parity(xq_np, groups, labels, named_np, sc_gpu, dx_gpu, int(p_glob), p_total=int(o_pairs))
+        loc = torch.tensor([sub['scores'], sub['dx']], dtype=torch.float64, device=dev)
+        dist.all_reduce(loc, op=dist.ReduceOp.MAX)
+        parity['subset_fp64'] = dict(sub, scores=float(loc[0].item()), dx=float(loc[1].item()), note='max over the ranks')
+        worst = max(worst, parity['subset_fp64']['scores'], parity['subset_fp64']['dx'])
+        if full_gate:
+            # (b) the whole chain in fp64: global pair gradient from the gathered fp64 scores, backward of the local rows, gradients summed
+            f_loss, ds_all, f_pairs = PO.pairwise_bpr(g_all, y_all, s64_all, grouped=True)
+            lo = rank * rows
+            dx64 = cpu_backward(fwd, xq_np, ds_all[lo:lo + rows], torch.float64)
+            names = sorted(named)
+            flat = torch.cat([torch.from_numpy(wleaf[k].grad.numpy().reshape(-1)) for k in names]).to(dev)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat = flat.cpu().numpy()
+            loc = torch.tensor([rel_err(sc_gpu, sc64, scale=np.abs(s64_all).max()), rel_err(dx_gpu, dx64)], dtype=torch.float64, device=dev)
+            dist.all_reduce(loc, op=dist.ReduceOp.MAX)
+            full = {'loss': rel_err(float(loss_q.item()), f_loss), 'pairs_equal': int(p_glob) == int(f_pairs),
+                    'scores': float(loc[0].item()), 'dx': float(loc[1].item())}
+            off = 0
+            hk_scale = None
+            grads64 = {}
+            for k in names:
+                n = named[k].numel()
+                grads64[k] = flat[off:off + n].reshape(tuple(named[k].shape))
+                off += n
+            hk_scale = float(np.abs(grads64['head.kernel']).max())
+            for k in names:
+                full[k] = rel_err(named[k].grad.cpu().numpy(), grads64[k], scale=hk_scale if k == 'head.bias' else None)
+            parity['oracle_fp64_all_ranks'] = full
+            worst = max([worst] + [v for k, v in full.items() if k != 'pairs_equal'])
+            ok = ok and full['pairs_equal']
+        parity['parity_max_rel'] = worst
+        parity['ok'] = bool(ok and worst <= PARITY_TOL and abs(parity['loss'] - float(np.log(2.0))) > 1e-3)
+
     if rank == 0:
         out = {
             'metric': 'samples/sec fwd+bwd, in-batch pairwise + DCN-v2, B=65536 at 1/2/4/8 GPUs',
@@ -595,6 +729,8 @@ def main():
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
+        if use_dist:
+            out['rccl_ranks'] = parity['rccl_ranks'] if parity and 'rccl_ranks' in parity else dist.get_world_size()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -19,7 +19,6 @@
 // takes the lean interior kernel (no bounds code) whenever B is a multiple of 256.  Zero columns/rows are inert.
 #include "gemm.hpp"
 #include "dcnmix_mid.hpp"
-#include "dcnmix_chain.hpp"
 
 static inline int ldt_of(int S, int N) {
     const int kc = N * S + N;
@@ -458,13 +457,6 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     int rc;
     if (pack_once && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st))) return rc;
     const float* xl = x;
-    // chained products (csrc/dcnmix_chain.hip): the product that leaves layer l and GEMM1 of layer l + 1 in one kernel.  Measured slower
-    // than the two launches (the chip's clock drops when the HBM streams run beside the MFMAs: see the file's header): opt-in,
-    // RECNOW_CHAIN=1 from 512 row blocks on, 2 for any batch (tests)
-    static const int chain_on = []() { const char* e = getenv("RECNOW_CHAIN"); return e ? atoi(e) : 0; }();
-    const bool chain = chain_on && pack_once && rn_mix_chain_fwd_supported(B, D, S, N, m.LDT) && (B / 128 >= 512 || chain_on == 2) &&
-                       rn_gemm_precision() == 0 && rn_mix_mid_supported(S, N, m.LDT);
-    bool t1_ready = false;           // T1 of this layer was produced by the previous layer's chained kernel
     for (int l = 0; l < L; ++l) {
         float* T1 = (float*)(sv + (size_t)(3 * l) * act_block(m));
         float* T2 = (float*)(sv + (size_t)(3 * l + 1) * act_block(m));
@@ -477,9 +469,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             } else if ((rc = pack_weights(m, U_host[l], V_host[l], W_host[l], bias_host[l], gate_host[l], Wc1, Wc2, st))) {
                 return rc;
             }
-            if (t1_ready) {
-                if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
-            } else {
+            {
             RnDeferredReduce red1;
             red1.valid = 0;
             const bool absorb = rn_mix_mid_absorbs_slabs(B, S, N, m.LDT);
@@ -531,16 +521,6 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st, &sl, act_inner))) return rc;
             } else if ((rc = mix_mid_fwd(m, T1, V_host[l], T2, T2g, act_outer, gws, gws_bytes, st))) return rc;
             }      // (not the fused GEMM1)
-            }      // (T1 not already there)
-            t1_ready = false;
-            if (chain && l + 1 < L) {      // out = x * (T2g [W; b]) (+ O_l) and T1 of layer l + 1 in one kernel
-                if ((rc = rn_mix_chain_fwd(T2g, Wc2, x, out, need_dx ? omid + (size_t)l * (xbuf(m) / sizeof(float)) : nullptr,
-                                           Wc1_all + (size_t)(l + 1) * D * m.LDT, gate_host[l + 1],
-                                           (float*)(sv + (size_t)(3 * (l + 1)) * act_block(m)), B, D, m.LDT, act_inner, st)))
-                    return rc;
-                t1_ready = true;
-                xl = out;
-                continue;
             }
             {   // GEMM3: out = x * ([G*H2 | G | 0] [W; b; 0]): K zero-padded NS+N -> KP (a 16-deep k-tile more is cheaper
                 // than a rank-N epilogue update: 215 vs 233 us measured)
@@ -1065,10 +1045,13 @@ extern "C" size_t recnow_dcn_mix_step_workspace_bytes(int64_t B, int D, int S, i
 __global__ void __launch_bounds__(256)
 k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restrict__ n_pair, int reduce_mean, float eps, int64_t B,
               const float* __restrict__ T2g_top, int LDT, float* __restrict__ ds, float* __restrict__ T2g_ds, float* __restrict__ ds_part,
-              const float* __restrict__ loss, float* __restrict__ stats) {
+              float* __restrict__ loss, float* __restrict__ stats, const int32_t* __restrict__ n_seg) {
     __shared__ float sds[STEP_ROWS];
     const float P = (float)(*n_pair);
-    const float sc = reduce_mean ? 1.f / (P + eps) : 1.f;
+    // n_seg[0] < 0: the cooperative grouping launch timed out at a grid barrier and left the identity grouping (scan_sort.hip) -- zero
+    // pairs would read as "loss 0, all-zero gradients" with RECNOW_OK.  Poisoned instead: loss, statistics and d loss / d scores are NaN.
+    const bool bad = n_seg[0] < 0;
+    const float sc = bad ? __int_as_float(0x7fc00000) : (reduce_mean ? 1.f / (P + eps) : 1.f);
     const int64_t r0 = (int64_t)blockIdx.x * STEP_ROWS;
     if (threadIdx.x < STEP_ROWS) {            // one wave
         const int64_t r = r0 + threadIdx.x;
@@ -1078,7 +1061,10 @@ k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restric
         const float t = wave_sum(v);
         if (threadIdx.x == 0) ds_part[blockIdx.x] = t;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) { stats[0] = loss[0]; stats[1] = P; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (bad) loss[0] = sc;
+        if (stats) { stats[0] = bad ? sc : loss[0]; stats[1] = P; }
+    }
     __syncthreads();
     const int q = LDT / 4;
     for (int i = threadIdx.x; i < STEP_ROWS * q; i += 256) {
@@ -1129,7 +1115,7 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
             return rc;
         const float* T2g_top = (const float*)((const char*)w.saved + (size_t)(3 * (L - 1) + 2) * act_block(m));
         hipLaunchKernelGGL(k_step_dscore, rn_cdiv(B, STEP_ROWS), 256, 0, st, w.dsu, (const unsigned long long*)d->n_pair, d->reduce_mean, 1.0e-10f, B,
-                           T2g_top, m.LDT, w.ds, w.T2g_ds, w.ds_part, d->loss, d->stats);
+                           T2g_top, m.LDT, w.ds, w.T2g_ds, w.ds_part, d->loss, d->stats, w.n_seg);
         RN_LAUNCH_CHECK();
     }
     if (phases & RECNOW_STEP_BACKWARD) {

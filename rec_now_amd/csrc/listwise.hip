@@ -333,10 +333,12 @@ extern "C" size_t recnow_listwise_loss_workspace_bytes(int64_t B, int key_dtype)
 // dlogits = dbase / (number of valid lists) (0 when there is none); {loss, (float) number of valid lists}
 __global__ void __launch_bounds__(256)
 k_lw_norm(const float* __restrict__ dbase, const int32_t* __restrict__ n_valid, int64_t B, float* __restrict__ out, const float* __restrict__ loss,
-          float* __restrict__ out2) {
+          float* __restrict__ out2, const int32_t* __restrict__ n_seg) {
     const int nv = n_valid[0];
-    const float sc = nv > 0 ? 1.f / (float)nv : 0.f;
-    if (out2 && blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = loss[0]; out2[1] = (float)nv; }
+    // n_seg[0] < 0: the cooperative grouping launch timed out (scan_sort.hip): NaN loss and gradient, never a silent zero
+    const bool bad = n_seg[0] < 0;
+    const float sc = bad ? __int_as_float(0x7fc00000) : (nv > 0 ? 1.f / (float)nv : 0.f);
+    if (out2 && blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = bad ? sc : loss[0]; out2[1] = (float)nv; }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) out[i] = dbase[i] * sc;
 }
 extern "C" int recnow_listwise_loss(const void* groups, int key_dtype, const float* labels, const float* logits, const float* weights, int64_t B,
@@ -365,7 +367,7 @@ extern "C" int recnow_listwise_loss(const void* groups, int key_dtype, const flo
         return rc;
     int G = rn_cdiv(B, 256);
     if (G > 2048) G = 2048;
-    hipLaunchKernelGGL(k_lw_norm, G, 256, 0, st, w.dbase, w.n_valid, B, dlogits, w.loss, out2);
+    hipLaunchKernelGGL(k_lw_norm, G, 256, 0, st, w.dbase, w.n_valid, B, dlogits, w.loss, out2, w.n_seg);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

@@ -796,10 +796,15 @@ extern "C" size_t recnow_pairwise_loss_workspace_bytes(int64_t B, int key_dtype)
 // dscores = unnormalised pair gradients x 1 / (P + eps) (mean) or as they are (sum); {loss, (float) P} for the caller
 __global__ void __launch_bounds__(256)
 k_pair_norm_grad(const float* __restrict__ d, const unsigned long long* __restrict__ n_pair, int reduce_mean, float eps, int64_t B,
-                 float* __restrict__ out, const float* __restrict__ loss, float* __restrict__ out2) {
+                 float* __restrict__ out, float* __restrict__ loss, float* __restrict__ out2, const int32_t* __restrict__ n_seg) {
     const float P = (float)(*n_pair);
-    const float sc = reduce_mean ? 1.f / (P + eps) : 1.f;
-    if (out2 && blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = loss[0]; out2[1] = P; }
+    // n_seg[0] < 0: the cooperative grouping launch timed out (scan_sort.hip) and left the identity grouping: NaN, never a silent zero
+    const bool bad = n_seg[0] < 0;
+    const float sc = bad ? __int_as_float(0x7fc00000) : (reduce_mean ? 1.f / (P + eps) : 1.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (bad) loss[0] = sc;
+        if (out2) { out2[0] = bad ? sc : loss[0]; out2[1] = P; }
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) out[i] = d[i] * sc;
 }
 extern "C" int recnow_pairwise_loss(const void* groups, int key_dtype, const float* labels, const float* scores, const uint8_t* mask,
@@ -837,7 +842,7 @@ extern "C" int recnow_pairwise_loss(const void* groups, int key_dtype, const flo
         return rc;
     int G = rn_cdiv(B, 256);
     if (G > 2048) G = 2048;
-    hipLaunchKernelGGL(k_pair_norm_grad, G, 256, 0, st, w.dsu, (const unsigned long long*)n_pair, reduce_mean, 1.0e-10f, B, dscores, loss, out2);
+    hipLaunchKernelGGL(k_pair_norm_grad, G, 256, 0, st, w.dsu, (const unsigned long long*)n_pair, reduce_mean, 1.0e-10f, B, dscores, loss, out2, w.n_seg);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

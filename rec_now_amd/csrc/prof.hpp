@@ -18,7 +18,6 @@ struct RnProfRecord {
 #define RN_TAG_MIX_MID_BWD 7        // k_mix_mid_bwd
 #define RN_TAG_GEMM_SPLIT 8         // k_gemm_split (bf16x3 split-precision 128x128 products, opt-in)
 #define RN_TAG_GEMM_MIDF 9          // k_gemm<128,128,..,25>: GEMM1 of DCN-v2 computed transposed with the sub-space forward in its epilogue
-#define RN_TAG_MIX_CHAIN 10         // k_mix_chain_*: the K = N*S+N product leaving a cross layer chained into the K = D product of the next
 #define RN_TAG_MAX 11
 
 bool rn_prof_on();

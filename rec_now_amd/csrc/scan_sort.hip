@@ -415,7 +415,10 @@ struct GroupMidCtl {          // zeroed by the host before the launch
     unsigned pad[14];
 };
 
-__device__ __forceinline__ void gm_barrier(GroupMidCtl* ctl, unsigned target) {
+// Returns false (to every thread of the workgroup) once the error word is set: the caller then leaves through GM_BAIL -- what the other
+// workgroups have published so far may be stale, and offsets derived from it could scatter out of bounds.
+__device__ __forceinline__ bool gm_barrier(GroupMidCtl* ctl, unsigned target) {
+    __shared__ int s_err;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -433,9 +436,24 @@ __device__ __forceinline__ void gm_barrier(GroupMidCtl* ctl, unsigned target) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_err = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    return s_err == 0;
 }
+// A barrier timed out (the workgroups were not co-resident: the host gates this route on the occupancy query, so this is a last line of
+// defence; RECNOW_DEBUG_GROUP_TIMEOUT=1 forces it for the tests): leave a SAFE grouping instead of half-written arrays -- every row its own
+// group (no pairs, in-bounds walks for every consumer) -- and n_seg = -1, which `Segments.num_segments()` / `recnow_group_segments_status`
+// report and which makes the one-call losses return NaN (k_pair_norm_grad, k_step_dscore, k_lw_norm).
+#define GM_BAIL()                                                                                                    \
+    do {                                                                                                             \
+        for (int q_ = 0; q_ < RN_TILE / 256; ++q_) {                                                                 \
+            const int64_t k_ = (int64_t)blockIdx.x * RN_TILE + q_ * 256 + threadIdx.x;                              \
+            if (k_ < B) { order[k_] = (int32_t)k_; seg_id[k_] = (int32_t)k_; seg_first[k_] = (int32_t)k_; super_id[k_] = (int32_t)k_; } \
+        }                                                                                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { seg_first[B] = (int32_t)B; n_seg[0] = -1; n_seg[1] = -1; }       \
+        return;                                                                                                      \
+    } while (0)
 
 __global__ void __launch_bounds__(256)
 k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
@@ -499,7 +517,7 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
             atomicOr(&ctl->mix[half * n_words + w], part[0][col] | part[1][col] | part[2][col] | part[3][col]);
         }
     }
-    gm_barrier(ctl, (++nbar) * G);
+    if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
     const int np = n_words * 4;
     if (tid == 0) {          // the pass plan, as k_sort_plan builds it (every workgroup derives the same one)
         int cur = 0, word_in_buf = -1;
@@ -567,7 +585,7 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         }
         __syncthreads();
         blockhist[(int64_t)tid * G + g] = h[tid];             // digit-major
-        gm_barrier(ctl, (++nbar) * G);
+        if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
         {   // first output position of every digit for this workgroup: counts of the workgroups before it + the digits below
             const unsigned* row = blockhist + (int64_t)tid * G;
             unsigned before = 0, total = 0;
@@ -621,7 +639,7 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
                 kdst[off] = my_key[r];
             }
         }
-        gm_barrier(ctl, (++nbar) * G);
+        if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
     }
     // ---- segments: heads of this tile's 2048 sorted positions, 8 consecutive positions per thread ---------------------------------
     const int32_t* fin = s_final[0] ? idx1 : idx0;
@@ -699,27 +717,13 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         tots += s_cnt[i][1];
     }
     if (tid == 0) { headcnt[2 * g] = toth; headcnt[2 * g + 1] = tots; }
-    gm_barrier(ctl, (++nbar) * G);
+    if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
     int preh = 0, pres = 0, allh = 0, alls = 0;              // heads in the workgroups before this one / in all of them
     for (int b = 0; b < G; ++b) {
         const int a = headcnt[2 * b], c = headcnt[2 * b + 1];
         if (b < g) { preh += a; pres += c; }
         allh += a;
         alls += c;
-    }
-    // a barrier timed out (the workgroups were not co-resident: the host gates this route on the occupancy query, so this is a
-    // last line of defence): every workgroup sees the error word behind the last barrier and leaves a SAFE grouping instead of
-    // half-written arrays -- every row its own group (no pairs, in-bounds walks for every consumer) -- and n_seg = -1, which
-    // `Segments.num_segments()` and `recnow_group_segments_status` report.
-    const bool bad = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    if (bad) {
-        for (int q = 0; q < 8; ++q) {
-            const int64_t k = k0 + q;
-            if (k >= B) break;
-            order[k] = (int32_t)k; seg_id[k] = (int32_t)k; seg_first[k] = (int32_t)k; super_id[k] = (int32_t)k;
-        }
-        if (g == 0 && tid == 0) { seg_first[B] = (int32_t)B; n_seg[0] = -1; n_seg[1] = -1; }
-        return;
     }
     int sid = preh + offh, sup = pres + offs;                 // ids of the LAST head before this thread's first position, + 1
     for (int q = 0; q < 8; ++q) {
@@ -816,6 +820,8 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
         GroupMidCtl* ctl = (GroupMidCtl*)tail;
         int* headcnt = (int*)(tail + rn_align(sizeof(GroupMidCtl)));
         RN_HIP(hipMemsetAsync(ctl, 0, sizeof(GroupMidCtl), st));
+        static const bool dbg_timeout = []() { const char* e = getenv("RECNOW_DEBUG_GROUP_TIMEOUT"); return e && e[0] == '1'; }();
+        if (dbg_timeout) RN_HIP(hipMemsetAsync(&ctl->err, 1, sizeof(int), st));      // tests: every barrier reports the time-out at once
         hipLaunchKernelGGL(k_group_mid, nblk, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
                            headcnt, order, seg_id, seg_first, super_id, n_seg);
         RN_LAUNCH_CHECK();

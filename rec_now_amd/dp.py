@@ -71,28 +71,39 @@ def gathered_pairwise_loss(outputs, labels, groups, loss_fn=None, **kwargs):
     if loss_fn is None:
         from .rec_block.pairwise_loss_from_batch import pairwise_loss as loss_fn
     flat = outputs.reshape(-1)
-    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)):
-        return loss_fn(flat, labels.reshape(-1), groups.reshape(-1), **kwargs)
-    world, rank = dist.get_world_size(), dist.get_rank()
+    # the reference accepts ONE group tensor or a LIST of them (pairs must agree on every one: pairwise_loss_from_batch.py:65-73)
+    as_list = isinstance(groups, (list, tuple))
+    group_list = [torch.as_tensor(g).reshape(-1) for g in (groups if as_list else [groups])]
+    if not group_list:
+        raise ValueError('groups: an empty list')
     n_local = flat.numel()
+    for g in group_list:
+        if g.numel() != n_local:
+            raise ValueError('groups: %d ids for %d outputs' % (g.numel(), n_local))
+    if labels.numel() != n_local:
+        raise ValueError('labels: %d values for %d outputs' % (labels.numel(), n_local))
+    regroup = (lambda gs: list(gs)) if as_list else (lambda gs: gs[0])      # noqa: E731
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)):
+        return loss_fn(flat, labels.reshape(-1), regroup(group_list), **kwargs)
+    world, rank = dist.get_world_size(), dist.get_rank()
     counts = torch.zeros(world, dtype=torch.int64, device=flat.device)
     counts[rank] = n_local
     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     counts = [int(c) for c in counts.tolist()]
     n_max = max(max(counts), 1)
-    # one gather of a (3, n_max) block per rank: scores, labels, group ids (ids as float64 would lose nothing for int64 ids < 2^53;
-    # float32 ids are gathered as they are -- the comparison `g_i - g_j == 0.0` of the reference is on float32)
-    gdt = torch.float64 if groups.dtype in (torch.int64, torch.float64) else torch.float32
-    block = torch.zeros(3, n_max, dtype=gdt, device=flat.device)
-    block[0, :n_local] = flat.detach().to(gdt)
-    block[1, :n_local] = labels.reshape(-1).to(gdt)
-    block[2, :n_local] = groups.reshape(-1).to(gdt)
-    parts = [torch.empty_like(block) for _ in range(world)]
-    dist.all_gather(parts, block)
-    cat = lambda row: torch.cat([parts[r][row, :counts[r]] for r in range(world)])      # noqa: E731
-    s_all = cat(0).to(flat.dtype).requires_grad_(True)
-    y_all = cat(1).to(labels.dtype)
-    g_all = cat(2).to(groups.dtype)
+
+    def gather(v):
+        """all-gather of a ragged (n_local,) vector in ITS OWN dtype (zero padded to the longest shard)."""
+        block = torch.zeros(n_max, dtype=v.dtype, device=flat.device)
+        block[:n_local] = v.reshape(-1).to(flat.device)
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(parts, block)
+        return torch.cat([parts[r][:counts[r]] for r in range(world)])
+    # scores and labels in their own floating-point dtypes; every group-id tensor in its NATIVE dtype: a float block would merge distinct
+    # int32 ids above 2^24 (float32) and hashed int64 ids above 2^53 (float64) after the gather -- silently wrong pairs
+    s_all = gather(flat.detach()).requires_grad_(True)
+    y_all = gather(labels)
+    g_all = regroup([gather(g) for g in group_list])
     with torch.enable_grad():
         loss_all = loss_fn(s_all, y_all, g_all, **kwargs)
         (ds_all,) = torch.autograd.grad(loss_all, s_all, allow_unused=True)
@@ -277,7 +288,9 @@ class LayerwiseReducer(object):
 
     def reduce_in_place(self):
         """After the last `stage_done`: the current stream waits for the communication stream (the gradients are final for whatever
-        comes next).  Returns (global mean loss, P_global) as 0-dim device tensors."""
+        comes next).  Returns (global mean loss, P_global) as 0-dim device tensors.  They are VIEWS of one persistent 2-float buffer that
+        the next step's first `stage_done` overwrites on the communication stream (unlike `reduce()`, which allocates its result):
+        `.clone()` them to keep a value across steps."""
         if self.comm is not None:
             torch.cuda.current_stream().wait_stream(self.comm)
         return self._result[0], self._result[1]

@@ -165,12 +165,24 @@ class DCNMixPairwiseStep(object):
 
     def run(self):
         """One eager step.  Returns (loss, n_pair): 0-dim / 1-element device tensors (global mean loss and pair count under a
-        reducer).  Gradients are in `p.grad` of every parameter, d loss / d x in `self.dx`."""
+        reducer).  Gradients are in `p.grad` of every parameter, d loss / d x in `self.dx`.
+
+        ALIASING: the returned tensors, `self.scores`, `self.dx` and every `p.grad` are views of storage that the NEXT step overwrites
+        (that is what makes the step allocation-free and capturable).  Keep a value across steps with `.clone()` (8 bytes for the loss)."""
         return self._enqueue(lambda key, fn: fn(), whole_backward=self.reducer is not None)
 
     def capture(self):
         """Capture every piece of the step into its own HIP graph (single-stream graphs: a forked capture replays with a host-side
-        join between the branches, +1.5 ms per step measured).  Call once, after a warm-up `run()`."""
+        join between the branches, +1.5 ms per step measured).  Call once, after a warm-up `run()`.
+
+        REQUIRES `DEBUG_CLR_GRAPH_PACKET_CAPTURE=0` in the environment BEFORE `import torch` (the HIP runtime reads it when it loads): with
+        ROCm 7.0's graph AQL-packet capture on, replaying these graphs after the same kernels were launched eagerly in between (a `run()`
+        between two `replay()`s) ends in a GPU memory access fault that takes the process down (tools/graph_dist_probe.py).
+        Raises RuntimeError when the switch is not set, instead of capturing graphs that may fault later."""
+        import os
+        if os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0':
+            raise RuntimeError("DCNMixPairwiseStep.capture(): export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before `import torch` (ROCm 7.0's graph "
+                               'packet capture faults when captured kernels are also launched eagerly between replays; see INTEGRATION.md)')
         torch.cuda.synchronize(self.device)
         self._graphs = {}
         cap = torch.cuda.Stream(device=self.device)
@@ -191,7 +203,7 @@ class DCNMixPairwiseStep(object):
         return self
 
     def replay(self):
-        """One step from the captured graphs (same results as `run()`, bit for bit)."""
+        """One step from the captured graphs (same results as `run()`, bit for bit; the same aliasing: clone what must outlive the next step)."""
         if self._graphs is None:
             raise RuntimeError('capture() first')
         return self._enqueue(lambda key, fn: self._graphs[key].replay())

@@ -31,3 +31,27 @@ def test_bench_line_fields_and_graph_replay(dev):
     graph = _bench('--graph')
     assert graph['config']['hip_graph'] is True
     assert graph['config']['loss'] == eager['config']['loss']                 # same kernels, same order: bit-identical loss
+
+
+def test_self_launch_one_rank_force_dist_is_self_verifying(dev):
+    """`bench.py --gpus N` starts its own ranks (child processes through torch.distributed.run, the parent never touches the GPU).  Driven here
+    with one rank over a real RCCL group: the line carries `rccl_ranks`, and the cross-rank gate -- the reduced loss and pair count against
+    oracle/pairs_oracle.c on the all-gathered batch, every all-reduced weight gradient against the sum of the per-rank fp64 oracles -- holds."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--launch', '--rows', '8192',
+                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['rccl_ranks'] == 1 and line['n_gpus'] == 1
+    par = line['parity']
+    assert par['ok'] and par['parity_max_rel'] <= 1e-5
+    assert par['gathered_batch_pairs_oracle']['pairs_equal'] and par['gathered_rows'] == 8192
+    full = par['oracle_fp64_all_ranks']
+    assert full['pairs_equal'] and len([k for k in full if k.startswith('cross.')]) == 15 and 'head.kernel' in full
+
+
+def test_more_ranks_than_gpus_fails_cleanly(dev):
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode != 0
+    assert 'only %d GPU(s) visible' % (n - 1) in out.stderr

@@ -256,6 +256,64 @@ def test_arbitrarily_sharded_rows_equal_single_process_through_all_gather():
             assert np.abs(out[r][1] - wt.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wt.grad.numpy()).max())
 
 
+def _int_id_cases():
+    """Group ids that a float block would merge: int32 above 2^24 (float32 rounds 2^24 + 1 to 2^24), int64 above 2^53 (float64), and the
+    reference's LIST of group tensors (pairs must agree on every one)."""
+    g, s, y, w = _make_batch(seed=17, B=500, G=23)
+    gi = g.astype(np.int64)
+    return s, y, w, {'int32': torch.from_numpy(((1 << 24) + gi).astype(np.int32)),
+                     'int64': torch.from_numpy((1 << 53) + gi),
+                     'list': [torch.from_numpy((gi // 3).astype(np.float32)), torch.from_numpy(((1 << 24) + gi % 3).astype(np.int32))]}
+
+
+def _take(groups, idx):
+    return [t[idx] for t in groups] if isinstance(groups, list) else groups[idx]
+
+
+def _worker_gather_ids(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rec_now_amd import dp
+    s, y, w, cases = _int_id_cases()
+    mine = torch.from_numpy(np.random.default_rng(9).integers(0, world, len(s)) == rank)
+    res = {}
+    for name, groups in cases.items():
+        wt = torch.from_numpy(w.copy()).requires_grad_(True)
+        sc = torch.from_numpy(s)[mine] * wt[0] + wt[1]
+        loss = dp.gathered_pairwise_loss(sc, torch.from_numpy(y)[mine], _take(groups, mine), loss_fn=R.pairwise_loss)
+        loss.backward()
+        dp.GradientAllReducer([wt]).all_reduce()
+        res[name] = (float(loss), wt.grad.numpy().copy())
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gathered_loss_keeps_integer_ids_exact_and_accepts_group_lists():
+    """ids travel in their native dtype, so int32 ids above 2^24 and int64 ids above 2^53 stay distinct groups after the
+    all-gather; a list of group tensors is gathered tensor by tensor."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_gather_ids, args=(world, port, out), nprocs=world, join=True)
+    s, y, w, cases = _int_id_cases()
+    merged = {}
+    for name, groups in cases.items():
+        wt = torch.from_numpy(w.copy()).requires_grad_(True)
+        sc = torch.from_numpy(s) * wt[0] + wt[1]
+        loss, n_pair = R.pairwise_loss(sc, torch.from_numpy(y), groups, return_num_pair=True)
+        loss.backward()
+        for r in range(world):
+            assert abs(out[r][name][0] - float(loss)) <= 1e-6 * max(1.0, abs(float(loss))), name
+            assert np.abs(out[r][name][1] - wt.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wt.grad.numpy()).max()), name
+        if name != 'list':      # the same ids through a float block of the old width: groups merge, another pair count -- the bug this guards against
+            lossy = groups.to(torch.float32 if name == 'int32' else torch.float64)
+            merged[name] = int(R.pairwise_loss(sc.detach(), torch.from_numpy(y), lossy, return_num_pair=True)[1]) != int(n_pair)
+    assert merged['int32'] and merged['int64']
+
+
 # ---- in-place protocol of step.DCNMixPairwiseStep: gradients and statistics produced inside the buckets ---------------------
 def _worker_inplace(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'

@@ -263,3 +263,14 @@ def test_grouped_c_port_equals_the_quadratic_restatement():
             assert a[2] == b[2]
             assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(a[0]))
             assert B == 0 or np.abs(a[1] - b[1]).max() <= 1e-12
+
+
+def test_c_oracle_under_sanitizers():
+    """SURVEY.md section 5 (sanitizer build): oracle/pairs_oracle.c + oracle/asan_driver.c compiled with -fsanitize=address,undefined and run on
+    the reference's literal goldens, the empty / one-row / NaN-id edge cases and seeded random batches (`make -C oracle asan`)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(['make', '-C', os.path.join(root, 'oracle'), '-s', 'asan'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'asan driver ok' in out.stdout

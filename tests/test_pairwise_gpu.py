@@ -1,6 +1,8 @@
 """GPU parity: rec_now_amd.rec_block.pairwise_loss_from_batch (HIP, through the C ABI) vs the oracle.
 Reads like the reference's tests/rec_block/test_pairwise_loss_from_batch.py, plus randomized / edge cases.
 Integer outputs (pair indices, counts) must be bit-exact; floats within 1e-5 relative."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -532,3 +534,40 @@ def test_one_pass_route_equals_two_pass_route(dev, reduce_mean):
     rc = _lib.load().recnow_pair_bpr_onepass(_lib.ptr(z), _lib.ptr(z), None, _lib.ptr(zi), _lib.ptr(zi), _lib.ptr(zi), 8, 0, 1.0, 1,
                                              _lib.ptr(z), _lib.ptr(z), _lib.ptr(n), _lib.ptr(ws), ws.numel(), _lib.stream())
     assert rc != 0
+
+
+def test_grouping_timeout_poisons_the_one_call_losses(dev):
+    """when the cooperative grouping launch times out at a grid barrier it leaves the identity grouping and n_seg = -1; the
+    one-call consumers (pairwise_loss, listwise loss, the whole-step entry) must not turn that into `loss 0, zero gradients, RECNOW_OK`.
+    RECNOW_DEBUG_GROUP_TIMEOUT=1 makes every barrier of k_group_mid report the time-out (own process: the switch is read once)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+from rec_now_amd.rec_block.listwise_loss_from_batch import listwise_loss_from_batch
+from rec_now_amd.rec_block._segments import build_segments
+dev = torch.device('cuda:0')
+rng = np.random.default_rng(0)
+B = 20000                                     # above the one-workgroup route (8192), inside the cooperative one
+g = torch.from_numpy(rng.integers(0, 300, B).astype(np.float32)).to(dev)
+y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).to(dev)
+s = torch.from_numpy(rng.normal(size=B).astype(np.float32)).to(dev).requires_grad_(True)
+try:
+    build_segments(g).num_segments()
+    raise SystemExit('num_segments() did not raise')
+except RuntimeError as e:
+    assert 'timed out' in str(e)
+loss = pairwise_loss(s, y, g)
+loss.backward()
+assert torch.isnan(loss).item() and torch.isnan(s.grad).all().item(), (loss, s.grad[:4])
+s2 = s.detach().clone().requires_grad_(True)
+lw = listwise_loss_from_batch(g, y, s2)
+lw.backward()
+assert torch.isnan(lw).item() and torch.isnan(s2.grad).all().item(), (lw, s2.grad[:4])
+print('poisoned ok')
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=root,
+                         env=dict(os.environ, RECNOW_DEBUG_GROUP_TIMEOUT='1', PYTHONPATH=root))
+    assert out.returncode == 0 and 'poisoned ok' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
