@@ -608,8 +608,10 @@ extern "C" int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_ho
 struct MixEvents {
     int n = 0;
     hipEvent_t make() {
-        static hipEvent_t pool[16][64];          // per device (an event belongs to the device that was current when it was created)
-        static int have[16];
+        // per device (an event belongs to the device that was current when it was created) AND per host thread: two threads driving one
+        // device would otherwise record and wait on the same pool slots (a wait enqueued by one thread could pick up the other's record)
+        static thread_local hipEvent_t pool[16][64];
+        static thread_local int have[16];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || n >= 64) return nullptr;
         if (n >= have[dev]) {

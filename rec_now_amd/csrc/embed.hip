@@ -383,7 +383,7 @@ k_embed_rows_join(const int64_t* __restrict__ key, const int32_t* __restrict__ o
     }
 }
 __global__ void k_embed_rows_tail(const int32_t* __restrict__ n_seg, int64_t N, int64_t* __restrict__ row_ids) {
-    const int ns = n_seg[0];
+    const int64_t ns = n_seg[0] < 0 ? N : n_seg[0];      // -1: timed-out grouping = the identity grouping (N segments); the host raises on it
     for (int64_t s = ns + (int64_t)blockIdx.x * 256 + threadIdx.x; s < N; s += (int64_t)gridDim.x * 256) row_ids[s] = EMB_SENTINEL;
 }
 extern "C" size_t recnow_embed_rows_bwd_workspace_bytes(int64_t N, int D) {

@@ -21,7 +21,7 @@ k_lw_stats(const float* __restrict__ labels, const float* __restrict__ logits, c
            float* __restrict__ seg_psum, float* __restrict__ seg_pdot, int32_t* __restrict__ first_row,
            int32_t* __restrict__ valid_at_row) {
     const int lane = threadIdx.x & 63;
-    const int G = n_seg[0];
+    const int G = n_seg[0] < 0 ? (int)B : n_seg[0];      // -1: the grouping timed out and left the identity grouping (B one-row lists, none valid)
     for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < G; g += gridDim.x * 4) {
         const int s = seg_first[g], e = seg_first[g + 1];
         float mx = -INFINITY, ysum = 0.f;
@@ -70,7 +70,7 @@ k_lw_stats(const float* __restrict__ labels, const float* __restrict__ logits, c
 __global__ void k_lw_rank(const int32_t* __restrict__ seg_valid, const int32_t* __restrict__ first_row,
                           const int32_t* __restrict__ vscan_excl, const int32_t* __restrict__ n_seg, int64_t B,
                           int32_t* __restrict__ valid_rank, int32_t* __restrict__ n_valid) {
-    const int G = n_seg[0];
+    const int G = n_seg[0] < 0 ? (int)B : n_seg[0];      // -1: the grouping timed out and left the identity grouping (B one-row lists, none valid)
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x)
         valid_rank[g] = seg_valid[g] ? vscan_excl[first_row[g]] : -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) n_valid[0] = vscan_excl[B];

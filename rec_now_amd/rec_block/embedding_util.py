@@ -135,7 +135,7 @@ class _PoolFunction(torch.autograd.Function):
                   _lib.ptr(s.n_seg), _lib.ptr(seg), _lib.ptr(weights), _lib.ptr(cnt), _lib.ptr(dout), N, C, T, D, 1 if mean else 0,
                   _lib.ptr(drows), _lib.ptr(row_ids), _lib.ptr(ws), ws.numel(), _lib.stream())
         if dense_scatter == 'sparse':
-            n_used = int(s.n_seg[0].item())                    # distinct keys (incl. the one "not pooled" key, which sorts last)
+            n_used = s.num_segments()                    # distinct keys (incl. the one "not pooled" key, which sorts last)
             ids = row_ids[:n_used]
             keep = (ids >= 0) & (ids < V)                       # drops the not-pooled key and ids outside the table
             dtable = torch.sparse_coo_tensor(ids[keep].unsqueeze(0), drows[:n_used][keep], (V, D))
@@ -205,6 +205,8 @@ def embedding_using_sparse_batch_segment_ids(embedding_func, slots, target_slots
     _lib.call('recnow_embed_unique', _lib.ptr(key), _lib.ptr(s.order), _lib.ptr(s.seg_id), _lib.ptr(s.seg_first), _lib.ptr(s.n_seg), N,
               _lib.ptr(unique), _lib.ptr(inverse), _lib.ptr(n_unique), _lib.stream())
     U = int(n_unique.item())                       # data-dependent size, as tf.unique's output (the one host sync of the path)
+    if U < 0:
+        s.num_segments()                           # raises: the cooperative grouping kernel timed out (n_seg = -1)
     emb = embedding_func(unique[:U])               # (U, D), ids in ascending order
     if emb.dim() != 2 or emb.shape[0] != U:
         raise ValueError('embedding_func must map n ids to an (n, D) tensor')

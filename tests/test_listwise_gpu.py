@@ -166,6 +166,10 @@ def test_full_size_properties_config5(dev):
     assert abs(loss.item() - ref) <= 1e-5 * abs(ref)
     gsum = np.bincount(gi, weights=sd.grad.double().cpu().numpy(), minlength=G)
     assert np.abs(gsum).max() < 1e-8
+    # the gradient value by value: d loss / d s_i = (softmax_i - y_i / sum_g y) / G_valid inside a valid list, else 0 --
+    # from the per-group fp64 softmax above, no (G, B) tensor needed (listwise_loss_from_batch.py:139-147,166-172)
+    gref = np.where(valid[gi], (np.exp(s64 - mx[gi]) / z[gi] - y64 / np.where(valid, ysum, 1.0)[gi]) / valid.sum(), 0.0)
+    assert np.abs(sd.grad.double().cpu().numpy() - gref).max() <= RTOL * np.abs(gref).max()
     loss2 = M.listwise_loss_from_batch(gd, yd, sd.detach())
     assert loss2.item() == loss.item()
 

@@ -143,6 +143,24 @@ def test_config2_pairwise_literal_case(dev):
     close(sd.grad, rds2, what='dscores (wrong order, occurrence weights)')
 
 
+def _ple_oracle_fwd(layer, w64, dims, n_groups, is_shared):
+    """The fp64 oracle of a PLELayer over the fp64 leaves `w64`, weights mapped by their reference names."""
+    def fwd(xc):
+        layers = []
+        for l in range(len(dims)):
+            entry = {'dnn': [], 'gate': []}
+            for gi in range(n_groups):
+                tn = layer.task_names[gi]
+                scope = 'PLE/ple_layer_%d/task_%s' % (l, tn)
+                entry['dnn'].append([(w64['%s/%s/MultiDenseLayer_%d/kernel' % (scope, scope, i)],
+                                      w64['%s/%s/MultiDenseLayer_%d/bias' % (scope, scope, i)]) for i in range(len(dims[l]))])
+                gk = 'PLE/ple_gate_%d/task_%s/dense/kernel' % (l, tn)
+                entry['gate'].append((w64[gk], w64[gk[:-6] + 'bias']) if gk in w64 else None)
+            layers.append(entry)
+        return R.ple_layer(xc, layers, is_shared, activation='tanh')
+    return fwd
+
+
 def test_ple_config5_per_rank_every_gradient_vs_oracle(dev):
     """configs[4] per-rank share: PLELayer, 3 tasks + 1 shared group, B = 32768, D_in = 128 x 32 = 4096: task outputs, dx and
     every expert / gate weight gradient vs the fp64 oracle (/root/reference/rec_now/layers/ple_layer.py:295-321), weights mapped
@@ -164,19 +182,7 @@ def test_ple_config5_per_rank_every_gradient_vs_oracle(dev):
     n_groups = len(layer.task_names[:layer.num_total_task])
     is_shared = layer.is_shared_tasks
 
-    def fwd(xc):
-        layers = []
-        for l in range(len(dims)):
-            entry = {'dnn': [], 'gate': []}
-            for gi in range(n_groups):
-                tn = layer.task_names[gi]
-                scope = 'PLE/ple_layer_%d/task_%s' % (l, tn)
-                entry['dnn'].append([(w64['%s/%s/MultiDenseLayer_%d/kernel' % (scope, scope, i)],
-                                      w64['%s/%s/MultiDenseLayer_%d/bias' % (scope, scope, i)]) for i in range(len(dims[l]))])
-                gk = 'PLE/ple_gate_%d/task_%s/dense/kernel' % (l, tn)
-                entry['gate'].append((w64[gk], w64[gk[:-6] + 'bias']) if gk in w64 else None)
-            layers.append(entry)
-        return R.ple_layer(xc, layers, is_shared, activation='tanh')
+    fwd = _ple_oracle_fwd(layer, w64, dims, n_groups, is_shared)
 
     routs, rdx, rgrads = run_chunked(fwd, x, gys, w64, chunk=2048)
     assert len(routs) == len(outs) == 3
@@ -191,3 +197,58 @@ def test_ple_config5_per_rank_every_gradient_vs_oracle(dev):
         close(p.grad, rgrads[name], what=name)
         checked += 1
     assert checked >= 4 * 2 * 2 * 2 + 4 + 3          # expert kernels/biases of both layers + their gates
+
+
+def test_config5_end_to_end_per_rank_size_vs_oracle(dev):
+    """configs[4] END TO END at the per-rank size of its 8-GPU row: x (32 768, 4096) -> PLELayer(3 tasks + 1 shared group,
+    [[512, 256], [256, 128]], 2 experts) -> 3 heads MultiDenseLayer(1, 3) -> listwise loss on task 0 (512 lists) (+ a small pointwise term on
+    the other two task logits so that every expert carries a gradient): loss, number of valid lists, d loss / d x, the head and EVERY expert / gate
+    gradient against the fp64 oracle -- layers chunk-wise, the listwise stage in the reference's dense (G, B) form
+    (/root/reference/rec_now/layers/ple_layer.py:295-321, rec_block/listwise_loss_from_batch.py:89-173)."""
+    from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+    from rec_now_amd.layers.ple_layer import PLELayer
+    from rec_now_amd.rec_block.listwise_loss_from_batch import listwise_loss_from_batch
+    B, Din, G = 32768, 4096, 512
+    dims, n_exp = [[512, 256], [256, 128]], 2
+    gen = torch.Generator(device='cpu').manual_seed(55)
+    rng = np.random.default_rng(55)
+    x = torch.randn(B, Din, generator=gen) * 0.05
+    groups = rng.integers(0, G, B).astype(np.float32)
+    labels = (rng.random(B) < 0.25).astype(np.float32)
+    layer, head = PLELayer(3, dims, n_exp, 1, activation='tanh', name='PLE'), MultiDenseLayer(1, 3)
+    xd = x.to(dev).requires_grad_(True)
+    head(torch.stack(list(layer(xd[:256]))))
+    _randomise(layer, 56)
+    with torch.no_grad():
+        head.kernel.mul_(6.0)                    # logits of O(1): the softmax over a list is far from uniform
+        head.bias.fill_(0.1)
+    gd, yd = torch.from_numpy(groups).to(dev), torch.from_numpy(labels).to(dev)
+    logits = head(torch.stack(list(layer(xd)))).reshape(3, B)
+    loss, nv = listwise_loss_from_batch(gd, yd, logits[0], return_num_list=True)
+    total = loss + 0.01 / B * (logits[1].sum() - logits[2].sum())
+    total.backward()
+    named = dict(layer.named_weights())
+    named['head/kernel'], named['head/bias'] = head.kernel, head.bias
+    w64 = weights64(named)
+    ple = _ple_oracle_fwd(layer, w64, dims, len(layer.task_names[:layer.num_total_task]), layer.is_shared_tasks)
+    fwd = lambda xc: R.multi_dense_layer(torch.stack(list(ple(xc))), w64['head/kernel'], w64['head/bias']).reshape(3, -1).t()      # noqa: E731  (rows, 3)
+    (rl,), _, _ = run_chunked(fwd, x, None, w64, chunk=2048, want_dx=False)
+    assert np.abs(rl[:, 0]).std() > 0.2
+    l0 = torch.from_numpy(rl[:, 0].copy()).requires_grad_(True)
+    _, lab, lg = R.to_listwise_sample(torch.from_numpy(groups), torch.from_numpy(labels).double(), l0)
+    rloss = R.listwise_loss_via_softmax_cross_entropy_with_logits(lab, lg)
+    rloss.backward()
+    assert int(nv.item()) == lab.shape[0] > G // 2
+    close(loss, rloss.detach(), what='listwise loss')
+    close(logits.t(), rl, what='task logits')
+    gl = torch.stack([l0.grad, torch.full((B,), 0.01 / B, dtype=torch.float64), torch.full((B,), -0.01 / B, dtype=torch.float64)], dim=1)
+    _, rdx, rgrads = run_chunked(fwd, x, gl, w64, chunk=2048)
+    close(xd.grad, rdx, what='dx')
+    checked = 0
+    for name, p in named.items():
+        if p.grad is None:
+            assert np.abs(rgrads[name]).max() == 0.0, name
+            continue
+        close(p.grad, rgrads[name], what=name)
+        checked += 1
+    assert checked >= 4 * 2 * 2 * 2 + 4 + 3 + 2       # experts of both layers + gates + the heads

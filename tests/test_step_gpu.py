@@ -159,6 +159,35 @@ def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B, two_stream
             close(p.grad, rgrads[name], what=name + ' ' + mode, scale=np.abs(rds).sum() if name == 'head/bias' else None)
 
 
+def test_step_route_at_the_metric_batch_vs_oracle(dev):
+    """B = 65 536 x 1024, N = 1, no reducer: exactly the route `bench.py` times (whole-step entry, eager), outside bench.py -- loss, pair
+    count, scores, d loss / d x and all 17 weight gradients against the fp64 chunked oracle + the C pair oracle (its segment-based form:
+    the quadratic one takes minutes at this size; tests/test_oracle_golden.py holds the two forms together)."""
+    from rec_now_amd.step import DCNMixPairwiseStep
+    B, D, S, N, L = 65536, 1024, 64, 2, 3
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 4242)
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd)
+    named = dict(cross.named_weights())
+    named['head/kernel'], named['head/bias'] = head.kernel, head.bias
+    w64 = weights64(named)
+    fwd = _mix_fwd(w64, L, head=True)
+    (rs,), _, _ = run_chunked(fwd, torch.from_numpy(x), None, w64, chunk=4096, want_dx=False)
+    rloss, rds, rP = PO.pairwise_bpr(groups, labels, rs.astype(np.float32), grouped=True)
+    assert rP > B and abs(rloss - np.log(2.0)) > 1e-3
+    _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), torch.from_numpy(rds), w64, chunk=4096)
+    for f in step.grads:
+        f.fill_(float('nan'))
+    step.dx.fill_(float('nan'))
+    loss, n_pair = step.run()
+    torch.cuda.synchronize()
+    assert int(n_pair.item()) == rP
+    close(step.scores, rs, what='scores')
+    close(loss, np.float64(rloss), what='loss')
+    close(step.dx, rdx, what='dx')
+    for name, p in named.items():
+        close(p.grad, rgrads[name], what=name, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+
+
 def test_gradient_accumulation_onto_bucket_views(dev):
     """dp.LayerwiseReducer + fused.dcn_mix_score(grad_buffers=...): a second backward without clearing the gradients must ADD to
     p.grad (= the bucket view), not overwrite it."""
