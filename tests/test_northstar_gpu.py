@@ -212,7 +212,7 @@ def test_config5_end_to_end_per_rank_size_vs_oracle(dev):
     dims, n_exp = [[512, 256], [256, 128]], 2
     gen = torch.Generator(device='cpu').manual_seed(55)
     rng = np.random.default_rng(55)
-    x = torch.randn(B, Din, generator=gen) * 0.05
+    x = torch.randn(B, Din, generator=gen) * 0.3
     groups = rng.integers(0, G, B).astype(np.float32)
     labels = (rng.random(B) < 0.25).astype(np.float32)
     layer, head = PLELayer(3, dims, n_exp, 1, activation='tanh', name='PLE'), MultiDenseLayer(1, 3)
@@ -233,7 +233,7 @@ def test_config5_end_to_end_per_rank_size_vs_oracle(dev):
     ple = _ple_oracle_fwd(layer, w64, dims, len(layer.task_names[:layer.num_total_task]), layer.is_shared_tasks)
     fwd = lambda xc: R.multi_dense_layer(torch.stack(list(ple(xc))), w64['head/kernel'], w64['head/bias']).reshape(3, -1).t()      # noqa: E731  (rows, 3)
     (rl,), _, _ = run_chunked(fwd, x, None, w64, chunk=2048, want_dx=False)
-    assert np.abs(rl[:, 0]).std() > 0.2
+    assert rl[:, 0].std() > 0.2                 # the softmax over a list is far from uniform
     l0 = torch.from_numpy(rl[:, 0].copy()).requires_grad_(True)
     _, lab, lg = R.to_listwise_sample(torch.from_numpy(groups), torch.from_numpy(labels).double(), l0)
     rloss = R.listwise_loss_via_softmax_cross_entropy_with_logits(lab, lg)
