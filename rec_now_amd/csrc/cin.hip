@@ -10,6 +10,7 @@
 //     dx0t     += (dX_k (x) X_{k-1}) * W_k viewed [(c,h)][f]   (W_k re-laid out once per call)
 // Layouts: x0t [M = B*D][F] (the reference's (B,D,F) transpose, :96-97); X_k [M][H_k].
 #include "gemm.hpp"
+#include "cin_bwd.hpp"
 
 // x0t[(b*D + d)*F + f] = emb[b*(F*D) + f*D + d]
 __global__ void k_cin_in(const float* __restrict__ emb, int64_t B, int D, int F, float* __restrict__ x0t) {
@@ -250,6 +251,15 @@ extern "C" int recnow_cin_bwd(const float* const* weights_host, const float* dou
             d.M = Hk; d.N = F * Hp; d.K = (int)c.M;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
         }
+        // Data gradients.  Fused (csrc/cin_bwd.hip, round 4): T = dX_k W_k is formed ONCE on the matrix cores and both reductions -- over f with x0
+        // for dX_{k-1}, over h with X_{k-1} for dx0 -- run on the accumulator tile: one forward-sized product instead of two.  Other shapes
+        // (rows not a multiple of 128, H_{k-1} not 64 / 128, ...) keep the two products with generated outer-product operands.
+        static const bool fused_on = []() { const char* e = getenv("RECNOW_CIN_FUSED"); return !e || e[0] != '0'; }();      // A/B switch
+        if (fused_on && rn_cin_bwd_fused_supported(c.M, Hk, Hp, F)) {
+            float* dst = (k == 0) ? dx0t : dXp;
+            if (k > 0) seed(dst, Hp, coffs[k - 1]);          // X_{k-1}'s own share of the output gradient, then accumulate
+            if ((rc = rn_cin_bwd_fused(dXk, weights_host[k], x0t, Xp, dst, dx0t, c.M, Hk, Hp, F, st))) return rc;
+        } else {
         {   // gradient w.r.t. X_{k-1}:  (dX_k (x) x0t)[m][(c,f)] * W_k viewed [(c,f)][h]
             float* dst = (k == 0) ? dx0t : dXp;
             if (k > 0) seed(dst, Hp, coffs[k - 1]);          // X_{k-1}'s own share of the output gradient, then accumulate
@@ -271,6 +281,7 @@ extern "C" int recnow_cin_bwd(const float* const* weights_host, const float* dou
             d.M = (int)c.M; d.N = F; d.K = Hk * Hp;
             d.accumulate = 1;
             if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
+        }
         }
         float* t = dXk; dXk = dXp; dXp = t;
     }

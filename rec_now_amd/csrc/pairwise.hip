@@ -412,8 +412,8 @@ k_group_pack_small(const void* __restrict__ groups, int key_dtype, const float* 
     uint16_t* cnt = idx1 + GS_MAXB;                                   // [16][GS_T] u16 = 32 KB
     unsigned* wsum = reinterpret_cast<unsigned*>(cnt + 16 * GS_T);    // 34 words
     uint8_t* solo = reinterpret_cast<uint8_t*>(wsum + 34);            // [B] NaN / inf flags by ORIGINAL row
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned vor = 0, vand = 0xffffffffu;
+    const int tid = threadIdx.x;
+    unsigned vor = 0, vand = 0xffffffffu, ior = 0, iand = 0xffffffffu, bad = 0;
     // canonical keys (recnow_group_keys): -0.0 == +0.0; NaN and +-inf equal nothing, themselves included
     for (int i = tid; i < B; i += GS_T) {
         uint32_t k;
@@ -431,20 +431,14 @@ k_group_pack_small(const void* __restrict__ groups, int key_dtype, const float* 
         solo[i] = so ? 1 : 0;
         vor |= k;
         vand &= k;
+        uint32_t im;
+        bad |= gs_int_key(k, &im) ? 0u : 1u;
+        ior |= im;
+        iand &= im;
         if (cnt_super) cnt_super[i] = 0ull;
     }
     if (tid == 0 && n_pair) *n_pair = 0ull;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        vor |= __shfl_xor(vor, o, 64);
-        vand &= __shfl_xor(vand, o, 64);
-    }
-    if (lane == 0) { wsum[wv] = vor; wsum[16 + wv] = vand; }
-    __syncthreads();
-    vor = 0; vand = 0xffffffffu;
-    for (int i = 0; i < 16; ++i) { vor |= wsum[i]; vand &= wsum[16 + i]; }
-    const unsigned varying = vor ^ vand;
-    __syncthreads();
+    const unsigned varying = gs_varying_bits(key0, B, vor, vand, ior, iand, bad, wsum);      // (small-integer images of the keys when all have one)
     uint32_t* ka = key0; uint32_t* kb = key1;
     uint16_t* ia = idx0; uint16_t* ib = idx1;
     gs_radix_sort_lds(ka, kb, ia, ib, cnt, wsum, B, varying);

@@ -346,25 +346,19 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
     uint16_t* cnt = idx1 + GS_MAXB;                       // [16][GS_T]
     unsigned* wsum = reinterpret_cast<unsigned*>(cnt + 16 * GS_T);   // [16] + 2
     const int tid = threadIdx.x;
-    unsigned vor = 0, vand = 0xffffffffu;
+    unsigned vor = 0, vand = 0xffffffffu, ior = 0, iand = 0xffffffffu, bad = 0;
     for (int i = tid; i < B; i += GS_T) {
         const uint32_t k = words[i];
         key0[i] = k;
         idx0[i] = (uint16_t)i;
         vor |= k;
         vand &= k;
+        uint32_t im;
+        bad |= gs_int_key(k, &im) ? 0u : 1u;
+        ior |= im;
+        iand &= im;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        vor |= __shfl_xor(vor, o, 64);
-        vand &= __shfl_xor(vand, o, 64);
-    }
-    if ((tid & 63) == 0) { wsum[tid >> 6] = vor; wsum[16 + (tid >> 6)] = vand; }      // wsum has room for 32 words (see host)
-    __syncthreads();
-    vor = 0; vand = 0xffffffffu;
-    for (int i = 0; i < 16; ++i) { vor |= wsum[i]; vand &= wsum[16 + i]; }
-    const unsigned varying = vor ^ vand;                  // bits that differ somewhere in the batch
-    __syncthreads();
+    const unsigned varying = gs_varying_bits(key0, B, vor, vand, ior, iand, bad, wsum);      // (keys rewritten to their small-integer images when all have one)
     uint32_t* ka = key0; uint32_t* kb = key1;
     uint16_t* ia = idx0; uint16_t* ib = idx1;
     const int lo = tid * GS_KPT, hi = min(B, lo + GS_KPT);
@@ -412,7 +406,9 @@ struct GroupMidCtl {          // zeroed by the host before the launch
     unsigned bar;
     int err;
     unsigned mix[2 * RN_MAX_WORDS];
-    unsigned pad[14];
+    unsigned imix[2];         // one key word: OR of the keys' small-integer images and OR of their complements (see gs_int_key)
+    unsigned notint;          // != 0: some key has no small-integer image (the keys are sorted as they are)
+    unsigned pad[11];
 };
 
 // Returns false (to every thread of the workgroup) once the error word is set: the caller then leaves through GM_BAIL -- what the other
@@ -447,14 +443,17 @@ __device__ __forceinline__ bool gm_barrier(GroupMidCtl* ctl, unsigned target) {
 // report and which makes the one-call losses return NaN (k_pair_norm_grad, k_step_dscore, k_lw_norm).
 #define GM_BAIL()                                                                                                    \
     do {                                                                                                             \
-        for (int q_ = 0; q_ < RN_TILE / 256; ++q_) {                                                                 \
-            const int64_t k_ = (int64_t)blockIdx.x * RN_TILE + q_ * 256 + threadIdx.x;                              \
+        for (int q_ = 0; q_ < TILE / 256; ++q_) {                                                                 \
+            const int64_t k_ = (int64_t)blockIdx.x * TILE + q_ * 256 + threadIdx.x;                              \
             if (k_ < B) { order[k_] = (int32_t)k_; seg_id[k_] = (int32_t)k_; seg_first[k_] = (int32_t)k_; super_id[k_] = (int32_t)k_; } \
         }                                                                                                            \
         if (blockIdx.x == 0 && threadIdx.x == 0) { seg_first[B] = (int32_t)B; n_seg[0] = -1; n_seg[1] = -1; }       \
         return;                                                                                                      \
     } while (0)
 
+// TILE keys per workgroup (256 threads x TILE / 256): the host picks the smallest of 512 / 1024 / 2048 that keeps the grid at <= 256 workgroups, so
+// that B = 65 536 runs on 128 and B = 262 144 on 256 workgroups instead of 32 and 128 (every phase between two barriers is per-key work).
+template <int TILE>
 __global__ void __launch_bounds__(256)
 k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
             GroupMidCtl* __restrict__ ctl, int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, uint32_t* __restrict__ key0,
@@ -465,38 +464,46 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
     __shared__ unsigned boff[256];
     __shared__ unsigned wtot[4];
     __shared__ unsigned part[4][2 * RN_MAX_WORDS];
+    __shared__ unsigned ipart[4][3];
+    __shared__ int s_useint;
     __shared__ int s_triv[RN_MAX_PASS], s_src[RN_MAX_PASS], s_carried[RN_MAX_PASS], s_wconst[RN_MAX_WORDS], s_final[2];
     __shared__ int s_cnt[4][2];
     const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t base = (int64_t)g * RN_TILE;
+    const int64_t base = (int64_t)g * TILE;
     unsigned nbar = 0;
     // ---- phase 0: identity order, bits that vary over the batch ----------------------------------------------------------
     {
         unsigned o[RN_MAX_WORDS], z[RN_MAX_WORDS];
+        unsigned io = 0u, iz = 0u, bad = 0u;                 // small-integer images of the keys (one key word only)
 #pragma unroll
         for (int w = 0; w < RN_MAX_WORDS; ++w) o[w] = z[w] = 0u;
         // loads from clamped indices, masked afterwards: no load sits under a lane condition (each would end in an `s_waitcnt vmcnt(0)`
         // at its merge, i.e. the eight rounds of a thread would be eight round trips in series)
         for (int w = 0; w < n_words; ++w) {                   // block-uniform trip count
-            uint32_t kk[RN_TILE / 256];
+            uint32_t kk[TILE / 256];
 #pragma unroll
-            for (int r = 0; r < RN_TILE / 256; ++r) {
+            for (int r = 0; r < TILE / 256; ++r) {
                 const int64_t i = base + r * 256 + tid;
                 kk[r] = words[(int64_t)w * B + (i < B ? i : B - 1)];
             }
             unsigned oo = 0u, zz = 0u;
 #pragma unroll
-            for (int r = 0; r < RN_TILE / 256; ++r) {
+            for (int r = 0; r < TILE / 256; ++r) {
                 const bool ok = base + r * 256 + tid < B;
                 oo |= ok ? kk[r] : 0u;
                 zz |= ok ? ~kk[r] : 0u;
+                uint32_t im;
+                const bool isint = gs_int_key(kk[r], &im);
+                io |= ok ? im : 0u;
+                iz |= ok ? ~im : 0u;
+                bad |= (ok && !isint) ? 1u : 0u;
             }
 #pragma unroll
             for (int q = 0; q < RN_MAX_WORDS; ++q)
                 if (q == w) { o[q] = oo; z[q] = zz; }
         }
 #pragma unroll
-        for (int r = 0; r < RN_TILE / 256; ++r) {
+        for (int r = 0; r < TILE / 256; ++r) {
             const int64_t i = base + r * 256 + tid;
             if (i < B) idx0[i] = (int32_t)i;
         }
@@ -511,20 +518,38 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
                 }
                 if (lane == 0) { part[wv][w] = a; part[wv][RN_MAX_WORDS + w] = c; }
             }
+        if (n_words == 1) {                                   // block-uniform
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                io |= __shfl_xor(io, sft, 64);
+                iz |= __shfl_xor(iz, sft, 64);
+                bad |= __shfl_xor(bad, sft, 64);
+            }
+            if (lane == 0) { ipart[wv][0] = io; ipart[wv][1] = iz; ipart[wv][2] = bad; }
+        }
         __syncthreads();
         if (tid < 2 * n_words) {
             const int w = tid % n_words, half = tid / n_words, col = half * RN_MAX_WORDS + w;
             atomicOr(&ctl->mix[half * n_words + w], part[0][col] | part[1][col] | part[2][col] | part[3][col]);
+        }
+        if (n_words == 1 && tid >= 64 && tid < 67) {
+            const int c = tid - 64;
+            const unsigned v = ipart[0][c] | ipart[1][c] | ipart[2][c] | ipart[3][c];
+            atomicOr(c == 2 ? &ctl->notint : &ctl->imix[c], v);
         }
     }
     if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
     const int np = n_words * 4;
     if (tid == 0) {          // the pass plan, as k_sort_plan builds it (every workgroup derives the same one)
         int cur = 0, word_in_buf = -1;
+        const bool useint = n_words == 1 && __hip_atomic_load(&ctl->notint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+        s_useint = useint ? 1 : 0;
         for (int p = 0; p < np; ++p) {
             const int w = n_words - 1 - p / 4, d = p % 4;
-            const unsigned both = __hip_atomic_load(&ctl->mix[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
-                                  __hip_atomic_load(&ctl->mix[n_words + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned both = useint ? (__hip_atomic_load(&ctl->imix[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                                            __hip_atomic_load(&ctl->imix[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                         : (__hip_atomic_load(&ctl->mix[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                                            __hip_atomic_load(&ctl->mix[n_words + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             const int tv = ((both >> (8 * d)) & 255u) == 0u;
             s_triv[p] = tv;
             s_src[p] = cur;
@@ -552,32 +577,36 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         const uint32_t* wk = words + (int64_t)(n_words - 1 - p / 4) * B;
         const int shift = 8 * (p % 4);
         // this tile's keys (kept in registers for the scatter) and its digit histogram
-        int32_t my_idx[RN_TILE / 256];
-        uint32_t my_key[RN_TILE / 256];
+        int32_t my_idx[TILE / 256];
+        uint32_t my_key[TILE / 256];
         h[tid] = 0;
         for (int t = tid; t < 1024; t += 256) (&wcnt[0][0])[t] = 0;
         __syncthreads();
-        const int64_t wbase = base + wv * (RN_TILE / 4);
+        const int64_t wbase = base + wv * (TILE / 4);
         // all eight rounds' loads in flight together (clamped indices; the block-uniform `carried` chooses between two straight-line
         // load sequences instead of sitting inside every round): two dependent round trips per pass, not sixteen
         if (carried) {
 #pragma unroll
-            for (int r = 0; r < RN_TILE / 256; ++r) {
+            for (int r = 0; r < TILE / 256; ++r) {
                 const int64_t e = wbase + r * 64 + lane, ec = e < B ? e : B - 1;
                 my_idx[r] = src[ec];
                 my_key[r] = ksrc[ec];
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < RN_TILE / 256; ++r) {
+            for (int r = 0; r < TILE / 256; ++r) {
                 const int64_t e = wbase + r * 64 + lane;
                 my_idx[r] = src[e < B ? e : B - 1];
             }
 #pragma unroll
-            for (int r = 0; r < RN_TILE / 256; ++r) my_key[r] = wk[my_idx[r]];
+            for (int r = 0; r < TILE / 256; ++r) my_key[r] = wk[my_idx[r]];
+            if (s_useint) {                                   // block-uniform: the keys' small-integer images are what is sorted (and carried)
+#pragma unroll
+                for (int r = 0; r < TILE / 256; ++r) my_key[r] = (uint32_t)__uint_as_float(my_key[r]);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < RN_TILE / 256; ++r) {
+        for (int r = 0; r < TILE / 256; ++r) {
             const bool ok = wbase + r * 64 + lane < B;
             my_idx[r] = ok ? my_idx[r] : 0;
             my_key[r] = ok ? my_key[r] : 0u;
@@ -607,11 +636,11 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
             boff[tid] = woff + inc - total + before;
         }
         __syncthreads();
-        // stable ranks: wave w owns RN_TILE / 4 consecutive keys, 8 rounds of 64 consecutive keys (as k_sort_scatter)
+        // stable ranks: wave w owns TILE / 4 consecutive keys, 8 rounds of 64 consecutive keys (as k_sort_scatter)
         const unsigned long long lt = (1ull << lane) - 1ull;
-        unsigned my_dr[RN_TILE / 256];
+        unsigned my_dr[TILE / 256];
 #pragma unroll
-        for (int r = 0; r < RN_TILE / 256; ++r) {
+        for (int r = 0; r < TILE / 256; ++r) {
             const int64_t e = wbase + r * 64 + lane;
             const bool ok = e < B;
             const unsigned d = (my_key[r] >> shift) & 255u;
@@ -629,7 +658,7 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RN_TILE / 256; ++r) {
+        for (int r = 0; r < TILE / 256; ++r) {
             const int64_t e = wbase + r * 64 + lane;
             if (e < B) {
                 const unsigned d = my_dr[r] & 255u, rank = my_dr[r] >> 8;
@@ -645,46 +674,47 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
     const int32_t* fin = s_final[0] ? idx1 : idx0;
     const uint32_t* kfin = s_final[0] ? key1 : key0;
     const int final_word = s_final[1];
-    const int64_t k0 = base + (int64_t)tid * 8;
+    constexpr int KPT = TILE / 256;                           // consecutive sorted positions per thread
+    const int64_t k0 = base + (int64_t)tid * KPT;
     unsigned hb = 0, sb8 = 0;
     int nh = 0, ns = 0;
     {
         // the nine sorted rows k0 - 1 .. k0 + 7 of this thread, then their solo flags and key words: every load unconditional (clamped
         // positions), a word's nine loads in flight together
-        int32_t f[9];
-        bool so9[9];
+        int32_t f[KPT + 1];
+        bool so9[KPT + 1];
         unsigned dany = 0u, dfirst = 0u;                     // bit q: rows k0 + q - 1 and k0 + q differ in some / in a groups[0] word
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
+        for (int q = 0; q < KPT + 1; ++q) {
             int64_t kq = k0 - 1 + q;
             kq = kq < 0 ? 0 : (kq < B ? kq : B - 1);
             f[q] = fin[kq];
         }
 #pragma unroll
-        for (int q = 0; q < 9; ++q) so9[q] = solo[f[q]] != 0;
+        for (int q = 0; q < KPT + 1; ++q) so9[q] = solo[f[q]] != 0;
         for (int w = 0; w < n_words; ++w) {                  // block-uniform
             if (s_wconst[w]) continue;
-            uint32_t v[9];
+            uint32_t v[KPT + 1];
             if (w == final_word) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) {
+                for (int q = 0; q < KPT + 1; ++q) {
                     int64_t kq = k0 - 1 + q;
                     kq = kq < 0 ? 0 : (kq < B ? kq : B - 1);
                     v[q] = kfin[kq];
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) v[q] = words[(int64_t)w * B + f[q]];
+                for (int q = 0; q < KPT + 1; ++q) v[q] = words[(int64_t)w * B + f[q]];
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < KPT; ++q) {
                 const unsigned df = v[q + 1] != v[q] ? 1u : 0u;
                 dany |= df << q;
                 if (w < n_words_first) dfirst |= df << q;
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < KPT; ++q) {
             const int64_t k = k0 + q;
             if (k < B) {
                 int hd = 1, sh = 1;
@@ -726,7 +756,7 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         alls += c;
     }
     int sid = preh + offh, sup = pres + offs;                 // ids of the LAST head before this thread's first position, + 1
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < KPT; ++q) {
         const int64_t k = k0 + q;
         if (k >= B) break;
         if ((hb >> q) & 1u) { seg_first[sid] = (int32_t)k; ++sid; }
@@ -751,7 +781,7 @@ static int gm_max_coresident() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     if (!have[dev]) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_group_mid, 256, 0) != hipSuccess) per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_group_mid<2048>, 256, 0) != hipSuccess) per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         // one workgroup per CU is what the route counts on (the step's GEMMs hold the other slots)
         cached[dev] = per_cu > 0 ? cus : 0;
@@ -767,7 +797,7 @@ extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) 
     s += rn_align(sizeof(SortPlan));
     s += rn_align((size_t)n_words * 4 * 256 * sizeof(unsigned));    // varying-bit words (2 per key word; sized as before)
     s += 4 * rn_align((size_t)(B + 1) * sizeof(int32_t));           // idx0, idx1, key0, key1
-    s += rn_align((size_t)256 * nblk * sizeof(unsigned));           // blockhist
+    s += rn_align((size_t)256 * (nblk > GM_MAXG ? nblk : GM_MAXG) * sizeof(unsigned));      // blockhist (the cooperative route runs up to GM_MAXG smaller tiles)
     s += 4 * rn_align((size_t)(B + 1) * sizeof(int32_t));           // head, shead, seg_incl, super_incl
     s += rn_scan_ws_bytes(B);
     s += rn_align(sizeof(GroupMidCtl)) + rn_align((size_t)2 * GM_MAXG * sizeof(int));      // cooperative mid-size path
@@ -809,12 +839,19 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     int32_t* idx1 = c.take<int32_t>(B + 1);
     uint32_t* key0 = c.take<uint32_t>(B + 1);
     uint32_t* key1 = c.take<uint32_t>(B + 1);
-    unsigned* blockhist = c.take<unsigned>((size_t)256 * nblk);
+    unsigned* blockhist = c.take<unsigned>((size_t)256 * (nblk > GM_MAXG ? nblk : GM_MAXG));
     int32_t* head = c.take<int32_t>(B + 1);
     int32_t* shead = c.take<int32_t>(B + 1);
     int32_t* seg_incl = c.take<int32_t>(B + 1);
     int32_t* super_incl = c.take<int32_t>(B + 1);
-    if (coop && nblk <= GM_MAXG && nblk <= gm_max_coresident()) {      // one cooperative launch: all nblk workgroups are co-resident (<= one per CU)
+    // one cooperative launch: all its workgroups are co-resident (<= one per CU).  The smallest tile that keeps the grid inside that bound:
+    // more workgroups = less per-key work between two grid barriers (B = 65 536: 128 workgroups of 512 keys; B = 262 144: 256 of 1024)
+    const int maxg = coop ? (gm_max_coresident() < GM_MAXG ? gm_max_coresident() : GM_MAXG) : 0;
+    static const int tile_env = []() { const char* e = getenv("RECNOW_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B switch: 512 / 1024 / 2048
+    int tile = 512;
+    while (tile < RN_TILE && rn_cdiv(B, tile) > maxg) tile *= 2;
+    if (tile_env == 512 || tile_env == 1024 || tile_env == 2048) tile = tile_env > tile ? tile_env : tile;
+    if (coop && rn_cdiv(B, tile) <= maxg) {
         const size_t scan_bytes = rn_scan_ws_bytes(B);
         char* tail = c.base + c.off + scan_bytes;
         GroupMidCtl* ctl = (GroupMidCtl*)tail;
@@ -822,8 +859,16 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
         RN_HIP(hipMemsetAsync(ctl, 0, sizeof(GroupMidCtl), st));
         static const bool dbg_timeout = []() { const char* e = getenv("RECNOW_DEBUG_GROUP_TIMEOUT"); return e && e[0] == '1'; }();
         if (dbg_timeout) RN_HIP(hipMemsetAsync(&ctl->err, 1, sizeof(int), st));      // tests: every barrier reports the time-out at once
-        hipLaunchKernelGGL(k_group_mid, nblk, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
-                           headcnt, order, seg_id, seg_first, super_id, n_seg);
+        const int g = rn_cdiv(B, tile);
+        if (tile == 512)
+            hipLaunchKernelGGL(k_group_mid<512>, g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
+                               headcnt, order, seg_id, seg_first, super_id, n_seg);
+        else if (tile == 1024)
+            hipLaunchKernelGGL(k_group_mid<1024>, g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
+                               headcnt, order, seg_id, seg_first, super_id, n_seg);
+        else
+            hipLaunchKernelGGL(k_group_mid<2048>, g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
+                               headcnt, order, seg_id, seg_first, super_id, n_seg);
         RN_LAUNCH_CHECK();
         return RECNOW_OK;
     }

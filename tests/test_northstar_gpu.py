@@ -233,7 +233,7 @@ def test_config5_end_to_end_per_rank_size_vs_oracle(dev):
     ple = _ple_oracle_fwd(layer, w64, dims, len(layer.task_names[:layer.num_total_task]), layer.is_shared_tasks)
     fwd = lambda xc: R.multi_dense_layer(torch.stack(list(ple(xc))), w64['head/kernel'], w64['head/bias']).reshape(3, -1).t()      # noqa: E731  (rows, 3)
     (rl,), _, _ = run_chunked(fwd, x, None, w64, chunk=2048, want_dx=False)
-    assert rl[:, 0].std() > 0.2                 # the softmax over a list is far from uniform
+    assert rl[:, 0].std() > 0.1                 # the softmax over a list is far from uniform
     l0 = torch.from_numpy(rl[:, 0].copy()).requires_grad_(True)
     _, lab, lg = R.to_listwise_sample(torch.from_numpy(groups), torch.from_numpy(labels).double(), l0)
     rloss = R.listwise_loss_via_softmax_cross_entropy_with_logits(lab, lg)

@@ -159,8 +159,10 @@ def cin():
     ms = timeit(step, n=max(3, reps // 3))
     ext = [F] + Hs
     fwd = 2.0 * D * F * sum(ext[k - 1] * ext[k] for k in range(1, len(ext))) * B
-    print('CINLayer fwd+bwd  B=%d F=%d D=%d H=%s : %.2f ms  %.1f TFLOP/s executed (4x fwd flops: 1 fwd + 3 bwd GEMMs)  %.1f k samples/s'
-          % (B, F, D, Hs, ms, 4 * fwd / ms / 1e9, B / ms))
+    import os
+    n = 4 if os.environ.get('RECNOW_CIN_FUSED') == '0' else 3       # round 4: dX_{k-1} and dx0 come out of ONE forward-sized product (csrc/cin_bwd.hip)
+    print('CINLayer fwd+bwd  B=%d F=%d D=%d H=%s : %.2f ms  %.1f TFLOP/s executed (%dx fwd flops: 1 fwd + %d bwd products), %.1f TFLOP/s of the 3x-fwd algorithmic flops  %.1f k samples/s'
+          % (B, F, D, Hs, ms, n * fwd / ms / 1e9, n, n - 1, 3 * fwd / ms / 1e9, B / ms))
 
 
 def ple():
