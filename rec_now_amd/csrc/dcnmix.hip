@@ -164,6 +164,16 @@ extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int
     return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + mix_pack_bytes(m) + 256;
 }
 
+// Round 4: x_{l+1} = x0 * O_l is NOT materialised between the cross layers of the exact path (two experts).  The product that leaves layer l
+// writes O_l = T2g_l [W; b] only (it no longer reads x0 nor writes x_{l+1}: 306 MB instead of 842 MB per launch at B = 65 536, which turns this
+// HBM-bound launch into an MFMA-bound one), and the two consumers of x_{l+1} -- GEMM1 of layer l + 1 and its weight-gradient product dU -- form
+// x0 * O_l in their operand loads (RECNOW_OPMODE_MUL), where the extra stream rides under MFMA-bound k-loops (+7 us per launch measured on the
+// products that already do this for x0 * g).  Same values bit for bit: one fp32 multiply either way.  RECNOW_XLESS=0 switches it off (A/B).
+static bool mix_xless(const MixDims& m) {
+    static const bool on = []() { const char* e = getenv("RECNOW_XLESS"); return !e || e[0] != '0'; }();
+    return on && m.exact && m.N <= 2 && m.L > 1;
+}
+
 static size_t mix_gemm_ws(const MixDims& m) {
     size_t best = 0;
     recnow_gemm_desc d = rn_gemm_desc_zero();
@@ -457,6 +467,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     int rc;
     if (pack_once && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st))) return rc;
     const float* xl = x;
+    const bool xless = mix_xless(m);
     for (int l = 0; l < L; ++l) {
         float* T1 = (float*)(sv + (size_t)(3 * l) * act_block(m));
         float* T2 = (float*)(sv + (size_t)(3 * l + 1) * act_block(m));
@@ -481,6 +492,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 recnow_gemm_desc d = rn_gemm_desc_zero();
                 d.A = Wc1; d.lda = m.LDT; d.a_trans = 1;             // [U | K]^T: stored [K = D][M = 128 (+ gate columns, unused here)]
                 d.B = xl; d.ldb = D; d.b_trans = 1;                  // x_l^T: stored [N = B][K = D]
+                if (xless && l > 0) { d.B = x; d.B2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.b_mode = RECNOW_OPMODE_MUL; }      // x_l = x0 * O_{l-1}
                 d.C = T1; d.ldc = m.LDT;                             // (not written: the epilogue stores T1 / T2 / T2g itself)
                 d.M = m.NS; d.N = (int)B; d.K = D;
                 d.prof_flops = 2.0 * (double)B * D * m.KC;
@@ -496,6 +508,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             {   // GEMM1: T1[:, :NS] = act_inner(x_l U);  gate logits T1[:, NS:NS+N] = x_l K as the VALU side product
                 recnow_gemm_desc d = rn_gemm_desc_zero();
                 d.A = xl; d.lda = D; d.a_trans = 0;
+                if (xless && l > 0) { d.A = x; d.A2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.a_mode = RECNOW_OPMODE_MUL; }      // x_l = x0 * O_{l-1}
                 d.B = Wc1; d.ldb = m.LDT; d.b_trans = 0;
                 d.C = T1; d.ldc = m.LDT;
                 d.M = (int)B; d.N = m.NS; d.K = D;
@@ -532,6 +545,10 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 d.prof_flops = 2.0 * (double)B * D * m.KC;
                 d.emul = x; d.lde = D; d.e_mode = RECNOW_OPMODE_MUL;
                 if (need_dx) { d.C2 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.ldc2 = D; d.c2_mode = 1; }     // O_l only feeds dx
+                if (xless && l < L - 1) {       // O_l alone: x_{l+1} = x0 * O_l is formed where it is consumed (mix_xless)
+                    d.emul = nullptr; d.e_mode = RECNOW_OPMODE_NONE; d.C2 = nullptr; d.c2_mode = 0;
+                    d.C = omid + (size_t)l * (xbuf(m) / sizeof(float));
+                }
                 if (head && l == L - 1) {       // the layer output only feeds the scoring head: row-dot partials instead of y
                     d.c2_mode = 3; d.ldc2 = D;
                     d.C = omid + (size_t)l * (xbuf(m) / sizeof(float));      // not written (c2_mode 3); a valid aligned address for the checks
@@ -805,6 +822,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = xl; d.lda = D; d.a_trans = 1;
+            if (mix_xless(m) && l > 0) { d.A = x; d.A2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.a_mode = RECNOW_OPMODE_MUL; }      // x_l = x0 * O_{l-1} (not stored)
             d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
             d.C = dWc1; d.ldc = m.NS;
             d.M = D; d.N = m.NS; d.K = (int)B;

@@ -153,6 +153,25 @@ static inline GemmCfg pick_cfg(int N) {
     if (N > 128 && N <= 160) return {128, 160};
     return {128, 128};
 }
+// Small-M dispatch (round 4): the 128-column products with the two-wide side product -- every long-K product of the DCN-v2 step -- run on
+// 64 x 128 tiles when 128-row tiles would leave at most `bm64_max_tiles` output tiles.  Default 128 = the 16 384- and 8192-row shards of the metric's
+// 4- and 8-GPU rows: at 16 384 rows 256 tiles x 2 K-slices (16 k-tiles each, half the slab traffic) instead of 128 x 4, measured 1.17 against 1.22 ms
+// per step; at 8192 rows 128 x 4 fill all 512 workgroup slots where 64 x 4 filled half (the split is capped at 8 k-tiles per slice): 0.78 against
+// 0.79 ms (tools/ab_bm64.sh, profiles/r04_small_m.md).  RECNOW_GEMM_BM64 = 0 switches it off, = N sets the tile bound (A/B).
+static inline int bm64_max_tiles() {
+    static const int v = []() { const char* e = getenv("RECNOW_GEMM_BM64"); return e ? atoi(e) : 128; }();
+    return v;
+}
+static inline bool wants_bm64(const recnow_gemm_desc* d) {
+    if (d->N != 128 || d->sp_r < 1 || d->sp_r > 2 || d->eu_r > 0 || d->as_out || d->c2_mode || d->mid_V || d->batch != 1 || d->K < 512) return false;
+    if (d->M % 64 || rn_gemm_precision() != 0) return false;      // (the opt-in split-precision kernels are 128-row kernels)
+    return (long long)rn_cdiv(d->M, 128) <= bm64_max_tiles();
+}
+static inline GemmCfg pick_cfg(const recnow_gemm_desc* d) {
+    GemmCfg c = pick_cfg(d->N);
+    if (c.BM == 128 && c.BN == 128 && wants_bm64(d)) c.BM = 64;
+    return c;
+}
 
 static inline void pick_split(const recnow_gemm_desc* d, const GemmCfg& c, int* splitk, int* kchunk) {
     const long long tiles = (long long)rn_cdiv(d->M, c.BM) * rn_cdiv(d->N, c.BN) * d->batch;
@@ -192,7 +211,7 @@ static inline bool split_planes_shape(const recnow_gemm_desc* d) {
 
 size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return 0;
-    const GemmCfg c = pick_cfg(d->N);
+    const GemmCfg c = pick_cfg(d);
     int s, kc;
     pick_split(d, c, &s, &kc);
     size_t b = s > 1 ? rn_align((size_t)s * d->batch * d->M * (d->N + (d->sp_r > 0 ? 4 : 0)) * sizeof(float)) : 0;
@@ -229,7 +248,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     if (!d->A || !d->B || !d->C) return RECNOW_EINVAL;
     if ((d->a_mode != RECNOW_OPMODE_NONE && !d->A2) || (d->b_mode != RECNOW_OPMODE_NONE && !d->B2)) return RECNOW_EINVAL;
     if (d->K == 0) return RECNOW_EUNSUPPORTED;
-    const GemmCfg c = pick_cfg(d->N);
+    GemmCfg c = pick_cfg(d);
     GemmK k;
     k.A = d->A; k.A2 = d->a_mode ? d->A2 : nullptr; k.B = d->B; k.B2 = d->b_mode ? d->B2 : nullptr;
     k.bias = d->bias; k.emul = d->emul; k.C = d->C; k.partial = nullptr;
@@ -274,7 +293,8 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     k.E3 = d->E3; k.lde3 = d->lde3; k.rv = d->rv; k.cv = d->cv; k.hv = d->hv; k.hp = d->hp; k.hp_ld = d->hp_ld;
     k.mid_V = d->mid_V; k.mid_T1 = d->mid_T1; k.mid_T2 = d->mid_T2; k.mid_T2g = d->mid_T2g; k.mid_ld = d->mid_ld; k.mid_act_outer = d->mid_act_outer;
     if (d->mid_V) {      // fused sub-space forward: the transposed GEMM1 of DCNMixLayer with two experts of 64 (see recnow_gemm_desc)
-        if (!d->mid_T1 || !d->mid_T2 || !d->mid_T2g || d->M != 128 || d->N % 128 || d->sp_r != 2 || !d->a_trans || !d->b_trans || d->a_mode || d->b_mode ||
+        if (!d->mid_T1 || !d->mid_T2 || !d->mid_T2g || d->M != 128 || d->N % 128 || d->sp_r != 2 || !d->a_trans || !d->b_trans || d->a_mode ||
+            (d->b_mode != RECNOW_OPMODE_NONE && d->b_mode != RECNOW_OPMODE_MUL) ||
             d->batch != 1 || d->bias || d->emul || d->accumulate || d->c_trans || d->mid_ld % 4 || d->mid_ld < 144 ||
             (((uintptr_t)d->mid_T1 | (uintptr_t)d->mid_T2 | (uintptr_t)d->mid_T2g) & 15))
             return RECNOW_EUNSUPPORTED;
@@ -334,8 +354,13 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
         xf |= 4;
     }
     if (xf) {        // side product / rank-R update exist only in the lean 128x128 kernels: the caller guarantees the shape
-        if (edge || c.BM != 128 || c.BN != 128 || d->c2_mode) return RECNOW_EUNSUPPORTED;
+        if (edge || (c.BM != 128 && c.BM != 64) || c.BN != 128 || d->c2_mode) return RECNOW_EUNSUPPORTED;
         rc = RECNOW_EUNSUPPORTED;
+        if (c.BM == 64) {        // small-M dispatch (pick_cfg): 64 x 128 tiles, two-wide side product, fp32 kernels only
+            if (xf != 1 || bk16) return RECNOW_EUNSUPPORTED;
+            rc = rn_gemm_launch_lean64x(k, a_kc, b_kc, d->a_mode, d->b_mode, 9, grid, st);
+            if (rc) return rc;
+        } else {
         // opt-in split precision: the long-K products with a side product (every k_gemm launch of the DCN-v2 step)
         if (split_ok) {
             void* planes = nullptr;
@@ -346,11 +371,12 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
             rc = rn_gemm_launch_split(k, a_kc, b_kc, d->a_mode, planes, grid, st);
         }
         static const bool sp_narrow = []() { const char* e = getenv("RECNOW_SP_NARROW"); return !e || e[0] != '0'; }();      // A/B switch
-        if (d->mid_V) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, 0, 0, 25, grid, st);      // XF 16 | 8 | 1: the fused sub-space forward
+        if (d->mid_V) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, 0, d->b_mode, 25, grid, st);      // XF 16 | 8 | 1: the fused sub-space forward
         else if (rc == RECNOW_EUNSUPPORTED && sp_narrow && xf == 1 && d->sp_r <= 2 && !bk16)
             rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, d->a_mode, d->b_mode, 9, grid, st);
         if (!d->mid_V && rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
+        }
     } else if (use_shortk) {
         // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)
         if (d->c2_mode && ((d->C2 && !host_aligned(d->C2, d->ldc2, 0)) || ((d->c2_mode == 2 || d->c2_mode == 4) && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
@@ -447,12 +473,14 @@ k_colsum_partial(const float* __restrict__ X, const float* __restrict__ X2, int 
     // block (bx, by): columns bx*cw + (tid % cw), rows by*rows .. ; the 256/cw row lanes of a column take rows rl apart
     // (cw = 64 or 128 for matrices narrower than 256 columns: all 256 threads load), four loads in flight each, and are
     // summed in a fixed order through LDS
-    __shared__ float red[256];
+    // fp64 accumulators (the kernel is bound by its loads; a bias gradient is a sum of up to 512 rows per workgroup here and of the slabs
+    // after it, with cancellation: summed in fp32 the full-size PLE + listwise test sat at 1.08e-5 of its 1e-5 bound)
+    __shared__ double red[256];
     const int c = threadIdx.x % cw, rlane = threadIdx.x / cw, rl = 256 / cw;
     const int64_t col = (int64_t)blockIdx.x * cw + c;
     const int64_t r0 = (int64_t)blockIdx.y * rows;
     const int64_t r1 = min(M, r0 + rows);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (col < N) {
         int64_t r = r0 + rlane;
         for (; r + 3 * rl < r1; r += 4 * rl) {
@@ -466,19 +494,19 @@ k_colsum_partial(const float* __restrict__ X, const float* __restrict__ X2, int 
     red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rlane == 0 && col < N) {
-        float t = red[c];
+        double t = red[c];
         for (int u = 1; u < rl; ++u) t += red[u * cw + c];
-        part[(int64_t)blockIdx.y * N + col] = t;
+        part[(int64_t)blockIdx.y * N + col] = (float)t;
     }
 }
 // out[col] = sum over slabs, fixed order: 64 columns x 16 strided slab groups per workgroup, then a 16-term LDS sum (a
 // column-per-thread loop over hundreds of slabs is a chain of dependent-latency loads: 84 us for 512 slabs, measured)
 __global__ void __launch_bounds__(1024)
 k_colsum_final(const float* __restrict__ part, int nslab, int64_t N, float* __restrict__ out, int accumulate) {
-    __shared__ float red[16][64];
+    __shared__ double red[16][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 64 + e;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (col < N) {
         int i = q;
         for (; i + 48 < nslab; i += 64) {
@@ -490,10 +518,10 @@ k_colsum_final(const float* __restrict__ part, int nslab, int64_t N, float* __re
     red[q][e] = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
     if (q == 0 && col < N) {
-        float t = 0.f;
+        double t = 0.0;
 #pragma unroll
         for (int u = 0; u < 16; ++u) t += red[u][e];
-        out[col] = accumulate ? out[col] + t : t;
+        out[col] = accumulate ? (float)((double)out[col] + t) : (float)t;
     }
 }
 
@@ -502,18 +530,18 @@ k_colsum_final(const float* __restrict__ part, int nslab, int64_t N, float* __re
 __global__ void __launch_bounds__(256)
 k_colsum_narrow(const float* __restrict__ X, const float* __restrict__ X2, int mode, int act, int64_t M, int64_t N, int64_t ld,
                 float* __restrict__ part) {
-    __shared__ float red[16];
+    __shared__ double red[16];
     const int64_t col = blockIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * CS_NARROW_ROWS, r1 = min(M, r0 + CS_NARROW_ROWS);
-    float s = 0.f;
+    double s = 0.0;
     for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
         float v = X[r * ld + col];
         if (mode == RECNOW_OPMODE_MUL) v *= X2[r * ld + col];
         else if (mode == RECNOW_OPMODE_ACTGRAD) v *= rn_act_grad_from_out(X2[r * ld + col], act);
         s += v;
     }
-    s = block_sum<float>(s, red);
-    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * N + col] = s;
+    s = block_sum<double>(s, red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * N + col] = (float)s;
 }
 
 size_t rn_colsum_ws_bytes(int64_t M, int64_t N) {

@@ -497,9 +497,9 @@ __device__ __forceinline__ void gemm_midf_epilogue(const GemmK& p, f32x16 (&acc)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, bool EDGE, int A2K, int B2K, int XF = 0>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)      // >= 2 waves/SIMD: VGPR+AGPR <= 256, two workgroups per CU
 k_gemm(const GemmK p) {
-    static_assert(XF == 0 || (!EDGE && BM == 128), "side product / rank-R update: lean 128-row kernels only");
+    static_assert(XF == 0 || (!EDGE && (BM == 128 || (BM == 64 && (XF & ~9) == 0))), "side product / rank-R update: lean 128-row kernels (side product: 64 rows too)");
     static_assert((XF & 4) == 0 || (A_KC && A2K == RECNOW_OPMODE_MUL), "A-stream side output: A [M][K] in MUL mode");
-    static_assert((XF & 16) == 0 || ((XF & 9) == 9 && !A_KC && B_KC && BM == 128 && BN == 128 && WAVES_M == 2 && A2K == 0 && B2K == 0),
+    static_assert((XF & 16) == 0 || ((XF & 9) == 9 && !A_KC && B_KC && BM == 128 && BN == 128 && WAVES_M == 2 && A2K == 0 && (B2K == 0 || B2K == RECNOW_OPMODE_MUL)),
                   "fused sub-space forward: transposed GEMM1, two-wide side product from the B tile");
     constexpr bool MIDF = (XF & 16) != 0;
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
@@ -676,8 +676,11 @@ k_gemm(const GemmK p) {
         // spread over the MFMA loop below (2 per iteration) so the FMAs run in the shadow of in-flight MFMAs.
         // (MIDF: the product is transposed, the rows of the side product are the rows of the B tile)
         constexpr int SP_LD = MIDF ? TB::LD : TA::LD;
-        const float* asx = (MIDF ? Bs + cur * B_SZ : As + cur * A_SZ) + (threadIdx.x & 127) + (threadIdx.x >> 7) * (BK / 2) * SP_LD;
-        const float* bxs = Bxs + cur * BK * 4 + (threadIdx.x >> 7) * (BK / 2) * 4;
+        // thread = (row of the side product, part of the tile's k range): 128 rows x 2 halves, or (64-row tiles) 64 rows x 4 quarters
+        constexpr int SP_ROWS = MIDF ? BN : BM, SP_KPP = BK * SP_ROWS / GEMM_THREADS, SP_KPI = SP_KPP / (BK / 4);      // k's per part / per MFMA-loop iteration
+        static_assert((XF & 1) == 0 || SP_KPI == 1 || SP_KPI == 2, "side product: one or two k per thread and loop iteration");
+        const float* asx = (MIDF ? Bs + cur * B_SZ : As + cur * A_SZ) + (threadIdx.x % SP_ROWS) + (threadIdx.x / SP_ROWS) * SP_KPP * SP_LD;
+        const float* bxs = Bxs + cur * BK * 4 + (threadIdx.x / SP_ROWS) * SP_KPP * 4;
         const float* as = As + cur * A_SZ + a_off;
         const float* bs = Bs + cur * B_SZ + b_off;
         // ONE loop form for full and tail tiles (two forms make the compiler shuffle every accumulator between them):
@@ -715,9 +718,11 @@ k_gemm(const GemmK p) {
             SPV sb0 = SPV(0.f), sb1 = SPV(0.f);
             if constexpr ((XF & 1) != 0) {
                 sa0 = FR(asx);
-                sa1 = FR(asx + SP_LD);
                 sb0 = *reinterpret_cast<const SPV*>(bxs);
-                sb1 = *reinterpret_cast<const SPV*>(bxs + 4);
+                if constexpr (SP_KPI == 2) {
+                    sa1 = FR(asx + SP_LD);
+                    sb1 = *reinterpret_cast<const SPV*>(bxs + 4);
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
@@ -729,11 +734,13 @@ k_gemm(const GemmK p) {
                 SPV nb0 = sb0, nb1 = sb1;
                 if constexpr ((XF & 1) != 0) {
                     if (kk + 4 < BK) {
-                        const int kq = (kk >> 1) + 2;
+                        const int kq = ((kk >> 2) + 1) * SP_KPI;
                         na0 = FR(asx + kq * SP_LD);
-                        na1 = FR(asx + (kq + 1) * SP_LD);
                         nb0 = *reinterpret_cast<const SPV*>(bxs + kq * 4);
-                        nb1 = *reinterpret_cast<const SPV*>(bxs + (kq + 1) * 4);
+                        if constexpr (SP_KPI == 2) {
+                            na1 = FR(asx + (kq + 1) * SP_LD);
+                            nb1 = *reinterpret_cast<const SPV*>(bxs + (kq + 1) * 4);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -750,6 +757,7 @@ k_gemm(const GemmK p) {
 #ifdef RN_SP_PLAIN_FMA
                     // A/B build (tools/build_variant.py -DRN_SP_PLAIN_FMA): the same operations as two plain v_fma_f32 per packed one (the guide
                     // prices one v_pk_fma_f32 at +22 cycles against two v_fma_f32 beside MFMAs); measured in profiles/r04_gemm_pmc.csv
+                    static_assert(SP_KPI == 2, "the plain-FMA A/B variant covers the 128-row kernels only");
                     if constexpr ((XF & 8) != 0) {
                         asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(spn.x) : "v"(sa0), "v"(sb0.x));
                         asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(spn.y) : "v"(sa0), "v"(sb0.y));
@@ -768,8 +776,10 @@ k_gemm(const GemmK p) {
 #else
                     if constexpr ((XF & 8) != 0) {
                         asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(spn) : "v"(sa), "v"(sb0));
-                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(spn) : "v"(sa), "v"(sb1));
+                        if constexpr (SP_KPI == 2)
+                            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(spn) : "v"(sa), "v"(sb1));
                     } else {
+                        static_assert((XF & 8) != 0 || SP_KPI == 2, "four-wide side product: 128-row kernels only");
                         f32x2 lo = {spn.x, spn.y}, hi = {spn.z, spn.w};
                         const f32x2 b0l = {sb0.x, sb0.y}, b0h = {sb0.z, sb0.w}, b1l = {sb1.x, sb1.y}, b1h = {sb1.z, sb1.w};
                         asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(lo) : "v"(sa), "v"(b0l));
@@ -836,7 +846,7 @@ k_gemm(const GemmK p) {
         __syncthreads();
 #endif
     };
-    if constexpr (SLICED && ((BM == 128 && BN == 128 && A2K != RECNOW_OPMODE_OUTER && B2K != RECNOW_OPMODE_OUTER) ||
+    if constexpr (SLICED && (((BM == 128 || BM == 64) && BN == 128 && A2K != RECNOW_OPMODE_OUTER && B2K != RECNOW_OPMODE_OUTER) ||
                              (A2K == RECNOW_OPMODE_NONE && B2K == RECNOW_OPMODE_NONE))) {
         // two copies of the body, the LDS buffer index a compile-time constant in each: every LDS address of the loop is then (a
         // loop-invariant register) + (an immediate offset), no per-k-tile VALU address arithmetic.  (128 x 128 tiles and plain operands only:
@@ -855,8 +865,9 @@ k_gemm(const GemmK p) {
         else spacc = spn;
     }
     if constexpr ((XF & 1) != 0) {
-        // combine the two k-halves through LDS (free now) and write the side columns
-        if (sp_on && threadIdx.x >= 128) *reinterpret_cast<f32x4*>(smem + (threadIdx.x - 128) * 4) = spacc;
+        // combine the k-parts of a row through LDS (free now) and write the side columns
+        constexpr int CB_ROWS = MIDF ? BN : BM, CB_PARTS = GEMM_THREADS / CB_ROWS;
+        if (sp_on && threadIdx.x >= CB_ROWS) *reinterpret_cast<f32x4*>(smem + (threadIdx.x - CB_ROWS) * 4) = spacc;
         __syncthreads();
         if constexpr (MIDF) {
             // the two gate logits of batch row n0 + tid: softmax -> G (LDS, for the epilogue) and the gate columns [128, 144) of the three
@@ -881,8 +892,10 @@ k_gemm(const GemmK p) {
                 }
             }
         } else
-        if (sp_on && threadIdx.x < 128) {
-            const f32x4 o = spacc + *reinterpret_cast<const f32x4*>(smem + threadIdx.x * 4);
+        if (sp_on && threadIdx.x < CB_ROWS) {
+            f32x4 o = spacc;
+#pragma unroll
+            for (int q = 1; q < CB_PARTS; ++q) o = o + *reinterpret_cast<const f32x4*>(smem + ((q - 1) * CB_ROWS + threadIdx.x) * 4);
             const float ov[4] = {o.x, o.y, o.z, o.w};
             const int m = m0 + threadIdx.x;
             for (int r = 0; r < p.sp_r; ++r) {
@@ -899,6 +912,10 @@ k_gemm(const GemmK p) {
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     if constexpr (MIDF) {
         gemm_midf_epilogue(p, acc, smem, n0, wm, wn, lane, wave);
+        RN_TR(3);
+#ifdef RN_GEMM_TRACE
+        if (p.trace && threadIdx.x == 0) p.trace[(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8ll + 6] = clock64();
+#endif
         return;
     } else
     if constexpr (!EDGE) {
@@ -984,6 +1001,7 @@ static inline void rn_gemm_launch_one(const GemmK& k, dim3 grid, hipStream_t st)
     hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, BK, AKC, BKC, EDGE, A2K, B2K, XF>), grid, GEMM_THREADS, lds, st, k);
 }
 int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k, int b2k, int xf, dim3 grid, hipStream_t st);
+int rn_gemm_launch_lean64x(const GemmK& k, bool a_kc, bool b_kc, int a2k, int b2k, int xf, dim3 grid, hipStream_t st);
 // split-precision (bf16x3) 128x128 kernel, k-tiles of 16 (gemm_split.hip)
 int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* planes, dim3 grid, hipStream_t st);
 size_t rn_gemm_split_planes_bytes(int K, int N);

@@ -395,6 +395,7 @@ int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStr
         if (c2_mode == 3) return launch_sk<false, 1, 3, false, 9>(k, st);
         if (c2_mode == 0) return launch_sk<false, 1, 0, false, 9>(k, st);
     }
+    if (k.K == 9 * SK_BK && (ring & 1) && !b_kc && ep == 0 && c2_mode == 0) return launch_sk<false, 0, 0, false, 9>(k, st);      // O_l = T2g [W; b] alone (mix_xless)
     if (k.K == 9 * SK_BK && (ring & 4) && b_kc && ep == 2 && c2_mode == 0)
         return pre ? launch_sk<true, 2, 0, true, 9>(k, st) : launch_sk<true, 2, 0, false, 9>(k, st);
     if (k.K == 9 * SK_BK && b_kc && ep == 0) {

@@ -451,8 +451,7 @@ __device__ __forceinline__ bool gm_barrier(GroupMidCtl* ctl, unsigned target) {
         return;                                                                                                      \
     } while (0)
 
-// TILE keys per workgroup (256 threads x TILE / 256): the host picks the smallest of 512 / 1024 / 2048 that keeps the grid at <= 256 workgroups, so
-// that B = 65 536 runs on 128 and B = 262 144 on 256 workgroups instead of 32 and 128 (every phase between two barriers is per-key work).
+// TILE keys per workgroup (256 threads x TILE / 256): 2048 is what the host launches; 512 / 1024 are A/B instantiations (measured slower, see the host).
 template <int TILE>
 __global__ void __launch_bounds__(256)
 k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
@@ -844,13 +843,14 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     int32_t* shead = c.take<int32_t>(B + 1);
     int32_t* seg_incl = c.take<int32_t>(B + 1);
     int32_t* super_incl = c.take<int32_t>(B + 1);
-    // one cooperative launch: all its workgroups are co-resident (<= one per CU).  The smallest tile that keeps the grid inside that bound:
-    // more workgroups = less per-key work between two grid barriers (B = 65 536: 128 workgroups of 512 keys; B = 262 144: 256 of 1024)
+    // one cooperative launch: all its workgroups are co-resident (<= one per CU).  Keys per workgroup: 2048.  Smaller tiles (more workgroups, less
+    // per-key work between two grid barriers; RECNOW_GROUP_TILE=512 / 1024 selects them where the grid stays inside the bound) measured SLOWER:
+    // B = 65 536 on 128 workgroups of 512 keys 114 us against 89 us on 32 of 2048, B = 262 144 on 256 of 1024 keys 207 against 147 us per fused
+    // loss -- every digit pass makes each thread scan one histogram row over ALL workgroups, and a barrier costs more the more arrive.
     const int maxg = coop ? (gm_max_coresident() < GM_MAXG ? gm_max_coresident() : GM_MAXG) : 0;
     static const int tile_env = []() { const char* e = getenv("RECNOW_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B switch: 512 / 1024 / 2048
-    int tile = 512;
-    while (tile < RN_TILE && rn_cdiv(B, tile) > maxg) tile *= 2;
-    if (tile_env == 512 || tile_env == 1024 || tile_env == 2048) tile = tile_env > tile ? tile_env : tile;
+    int tile = RN_TILE;
+    if ((tile_env == 512 || tile_env == 1024) && rn_cdiv(B, tile_env) <= maxg) tile = tile_env;
     if (coop && rn_cdiv(B, tile) <= maxg) {
         const size_t scan_bytes = rn_scan_ws_bytes(B);
         char* tail = c.base + c.off + scan_bytes;

@@ -194,7 +194,10 @@ class DCNMixPairwiseStep(object):
             with torch.cuda.stream(cap):
                 for key, fn in keys:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=cap):
+                    # thread_local: under a process group the RCCL watchdog thread polls its events while this thread captures; in the default
+                    # 'global' mode that poll is an illegal call DURING A CAPTURE and takes the process down (seen once the eager step before
+                    # capture() got short enough for a collective's bookkeeping to be still pending)
+                    with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
                         fn()
                     self._graphs[key] = g
         finally:

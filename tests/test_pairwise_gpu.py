@@ -445,7 +445,11 @@ def test_small_route_int_ids_determinism_and_routing(dev):
 
 # ---- grouping machinery at mid sizes: the cooperative single-launch path (k_group_mid), several key words ----------------------------
 @pytest.mark.parametrize('B,kind', [(30000, 'f32'), (30000, 'pair_f32'), (70000, 'i64'), (9000, 'f64'), (300000, 'f32_wide'),
-                                    (524288, 'pair_mixed'), (12345, 'all_equal')])
+                                    (524288, 'pair_mixed'), (12345, 'all_equal'),
+                                    # round 4: float ids that are all small non-negative integers are sorted by their integer images (fewer digit
+                                    # passes), on 512- / 1024- / 2048-key tiles; ids that break the rule (>= 2^24, negative, fractional) as before
+                                    (70000, 'int_img'), (262144, 'int_img_big'), (40000, 'int_over'), (40000, 'int_neg'), (40000, 'frac'),
+                                    (20000, 'signed_zero_ints'), (8000, 'int_img'), (8000, 'frac'), (8192, 'int_img_big')])
 def test_build_segments_invariants_mid_sizes(dev, B, kind):
     """Segments of 8192 < B <= 524288 rows (one cooperative launch) and of multi-word keys: the order is a permutation, rows of a
     segment are ascending (stable sort), rows share a segment iff every key word matches (NaN / inf ids are segments of their own),
@@ -466,6 +470,22 @@ def test_build_segments_invariants_mid_sizes(dev, B, kind):
         gs = [rng.normal(size=5000).astype(np.float32)[rng.integers(0, 5000, B)]]
     elif kind == 'pair_mixed':
         gs = [rng.integers(0, 3000, B).astype(np.int32), rng.integers(0, 3, B).astype(np.float32)]
+    elif kind == 'int_img':
+        gs = [rng.integers(0, 4096, B).astype(np.float32)]
+    elif kind == 'int_img_big':
+        gs = [rng.integers(0, 2 ** 24, 3000)[rng.integers(0, 3000, B)].astype(np.float32)]
+        gs[0][:4] = [0.0, 16777215.0, 1.0, 16777215.0]
+    elif kind == 'int_over':
+        gs = [rng.integers(0, 300, B).astype(np.float32)]
+        gs[0][::97] = 16777216.0 + 2.0 * rng.integers(0, 5, len(gs[0][::97]))
+    elif kind == 'int_neg':
+        gs = [rng.integers(-50, 50, B).astype(np.float32)]
+    elif kind == 'frac':
+        gs = [rng.integers(0, 300, B).astype(np.float32) + 0.5]
+    elif kind == 'signed_zero_ints':
+        gs = [rng.integers(0, 10, B).astype(np.float32)]
+        gs[0][gs[0] == 0][::2] = -0.0
+        gs[0][::31] = -0.0
     else:
         gs = [np.full(B, -0.0, np.float32)]
         gs[0][::2] = 0.0                                            # -0.0 and +0.0 are one group

@@ -87,7 +87,42 @@ def run(name, M, N, K, ta, tb, lda, ldb, ldc, a_mode, emul, c_trans, xf=0):
     print('%-40s %9.1f us  %6.1f TFLOP/s' % (name, us, 2.0 * M * N * K / us / 1e6), flush=True)
 
 
+def run_midf(name='MIDF   GEMM1^T + sub-space forward in the epilogue (k_gemm<..,25>)'):
+    """The fused GEMM1 of the c3 step (dcnmix.hip: `d.mid_V`): T1^T = [U | K]^T x^T computed transposed, H1 = tanh, C = H1 V_e off the accumulators,
+    T1 / T2 / T2g written by the epilogue.  Shape index len(SHAPES) (for tools/gemm_trace.py too)."""
+    S, N, LD = 64, 2, 144
+    x = torch.randn(B, D, device=dev) * 0.05
+    Wc1 = torch.randn(D, LD, device=dev) * 0.03          # packed [U_0 | U_1 | K | 0]
+    gate = torch.randn(D, N, device=dev) * 0.03
+    V = torch.randn(N, S, S, device=dev) * 0.1
+    T1, T2, T2g = (torch.empty(B, LD, device=dev) for _ in range(3))
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.a_trans = Wc1.data_ptr(), LD, 1
+    d.B, d.ldb, d.b_trans = x.data_ptr(), D, 1
+    d.C, d.ldc = T1.data_ptr(), LD
+    d.M, d.N, d.K, d.batch = N * S, B, D, 1
+    d.act = 2                                             # RECNOW_ACT_TANH
+    d.sp_bx, d.sp_bx_ks, d.sp_bx_rs, d.sp_cx, d.sp_cx_ms, d.sp_cx_rs, d.sp_r = gate.data_ptr(), N, 1, T1.data_ptr() + 4 * N * S, LD, 1, N
+    d.mid_V, d.mid_T1, d.mid_T2, d.mid_T2g, d.mid_ld, d.mid_act_outer = V.data_ptr(), T1.data_ptr(), T2.data_ptr(), T2g.data_ptr(), LD, 2
+    ws = _lib.workspace(max(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)), 256), dev)
+    st = _lib.stream()
+    for _ in range(2):
+        _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), st)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    print('%-40s %9.1f us  %6.1f TFLOP/s of the product alone' % (name, us, 2.0 * B * (N * S + N) * D / us / 1e6), flush=True)
+
+
 only = int(sys.argv[2]) if len(sys.argv) > 2 else None
-for i, s in enumerate(SHAPES):
-    if only is None or i == only:
-        run(*s)
+if __name__ == '__main__':
+    for i, s in enumerate(SHAPES):
+        if only is None or i == only:
+            run(*s)
+    if only is None or only == len(SHAPES):
+        run_midf()
