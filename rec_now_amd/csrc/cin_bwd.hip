@@ -94,23 +94,20 @@ k_cin_bwd_fused(const CinBwdK p) {
         a_k[i] = (idx & 7) * 4;  a_r[i] = idx >> 3;          // A: [row][k], float4 along k
         b_n[i] = (idx & 31) * 4; b_k[i] = idx >> 5;          // B: [k][n], float4 along n
     }
+    // Staging slots: 0, 1 = the thread's two float4 of the A tile, 2, 3 = of the B tile.  A slot of k-tile t + 1 goes registers -> LDS (`commit`)
+    // and is at once requested again for k-tile t + 2 (`issue`); the four slots are spread over the MFMA steps of k-tile t (below), so that no
+    // staging section stands between the barrier and the MFMAs with both waves of every SIMD in it (the sliced schedule of gemm_kernel.hpp).
     cb_f4 ra[2], rb[2];
-    auto issue = [&](int t) {
-        const int ft = t / KT, kt = t - ft * KT;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ra[i] = *reinterpret_cast<const cb_f4*>(p.dXk + (m0 + a_r[i]) * Hk + kt * CB_BK + a_k[i]);
-            rb[i] = *reinterpret_cast<const cb_f4*>(p.W + (int64_t)(kt * CB_BK + b_k[i]) * ldw + ft * 128 + b_n[i]);
-        }
+    auto issue = [&](int slot, int ft, int kt) {
+        if (slot < 2) ra[slot] = *reinterpret_cast<const cb_f4*>(p.dXk + (m0 + a_r[slot]) * Hk + kt * CB_BK + a_k[slot]);
+        else rb[slot - 2] = *reinterpret_cast<const cb_f4*>(p.W + (int64_t)(kt * CB_BK + b_k[slot - 2]) * ldw + ft * 128 + b_n[slot - 2]);
     };
-    auto commit = [&](int buf) {
-        float* const A = As + buf * CB_A_SZ;
-        float* const B = Bs + buf * CB_B_SZ;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float* a = A + a_k[i] * CB_LDA + a_r[i];
-            a[0] = ra[i].x; a[CB_LDA] = ra[i].y; a[2 * CB_LDA] = ra[i].z; a[3 * CB_LDA] = ra[i].w;
-            *reinterpret_cast<cb_f4*>(B + b_k[i] * CB_LDB + b_n[i]) = rb[i];
+    auto commit = [&](int slot, int buf) {
+        if (slot < 2) {
+            float* a = As + buf * CB_A_SZ + a_k[slot] * CB_LDA + a_r[slot];
+            a[0] = ra[slot].x; a[CB_LDA] = ra[slot].y; a[2 * CB_LDA] = ra[slot].z; a[3 * CB_LDA] = ra[slot].w;
+        } else {
+            *reinterpret_cast<cb_f4*>(Bs + buf * CB_B_SZ + b_k[slot - 2] * CB_LDB + b_n[slot - 2]) = rb[slot - 2];
         }
     };
 
@@ -120,16 +117,27 @@ k_cin_bwd_fused(const CinBwdK p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; dacc[j][r] = 0.f; }
 
-    issue(0);
-    commit(0);
-    issue(NT > 1 ? 1 : 0);
+    // (column tile, k-tile) of the k-tiles t (being computed) and t + 2 (being requested), advanced without divisions; indices past the last
+    // k-tile are clamped to it (loads stay unconditional: the surplus copies land in the buffer nobody reads)
+    auto advance = [&](int& ft, int& kt) {
+        if (ft * KT + kt < NT - 1) {
+            if (++kt == KT) { kt = 0; ++ft; }
+        }
+    };
+    int ft = 0, kt = 0, ft2 = 0, kt2 = 0;
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) issue(slot, 0, 0);
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) commit(slot, 0);
+    advance(ft2, kt2);                                       // k-tile 1
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) issue(slot, ft2, kt2);
+    advance(ft2, kt2);                                       // k-tile 2
     const int a_off = h5 * CB_LDA + 32 * wm + l31;
     const int b_off = h5 * CB_LDB + 64 * wn + l31;
     for (int t = 0; t < NT; ++t) {
         const int cur = t & 1;
         __syncthreads();
-        commit(cur ^ 1);                                     // tile t + 1 (at t = NT - 1: a surplus copy into the buffer nobody reads)
-        issue(min(t + 2, NT - 1));
         const float* as = As + cur * CB_A_SZ + a_off;
         const float* bs = Bs + cur * CB_B_SZ + b_off;
         float a0 = CB_LR(as), b00 = CB_LR(bs), b01 = CB_LR(bs + 32);
@@ -140,12 +148,19 @@ k_cin_bwd_fused(const CinBwdK p) {
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b00, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b01, acc[1], 0, 0, 0);
+            if (s % 4 == 1) {                                // compile-time (unrolled): one staging slot behind MFMA steps 1, 5, 9, 13
+                commit(s / 4, cur ^ 1);
+                issue(s / 4, ft2, kt2);
+            }
             __builtin_amdgcn_sched_barrier(0);
             a0 = a1; b00 = b10; b01 = b11;
         }
-        const int ft = t / KT;
-        if (t - ft * KT == KT - 1) {                         // block-uniform: the T tile of column tile ft is complete
-            const int f = G == 1 ? ft : 2 * ft + wn;
+        advance(ft2, kt2);
+        const bool tile_done = kt == KT - 1;
+        const int ftc = ft;
+        advance(ft, kt);
+        if (tile_done) {                                     // block-uniform: the T tile of column tile ftc is complete
+            const int f = G == 1 ? ftc : 2 * ftc + wn;
             float pr[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

@@ -432,6 +432,33 @@ __device__ __forceinline__ void row_store_full(const float (&r)[NV][4], float* _
 #pragma unroll
     for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(p + (i * TPR + t) * 4) = make_float4(r[i][0], r[i][1], r[i][2], r[i][3]);
 }
+// The streamed tensors of the fast kernels (x, dy in; y, dx out: every byte touched once).  -DRN_STREAM_NT (tools/build_variant.py) makes these accesses
+// non-temporal for the A/B recorded in profiles/r04_configs_summary.md; the product build uses plain accesses.
+template <int TPR, int NV>
+__device__ __forceinline__ void row_load_stream(float (&r)[NV][4], const float* __restrict__ p, int t) {
+#ifdef RN_STREAM_NT
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const rn_f4 q = __builtin_nontemporal_load(reinterpret_cast<const rn_f4*>(p + (i * TPR + t) * 4));
+        r[i][0] = q.x; r[i][1] = q.y; r[i][2] = q.z; r[i][3] = q.w;
+    }
+#else
+    row_load_full<TPR, NV>(r, p, t);
+#endif
+}
+template <int TPR, int NV>
+__device__ __forceinline__ void row_store_stream(const float (&r)[NV][4], float* __restrict__ p, int t) {
+#ifdef RN_STREAM_NT
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        rn_f4 q;
+        q.x = r[i][0]; q.y = r[i][1]; q.z = r[i][2]; q.w = r[i][3];
+        __builtin_nontemporal_store(q, reinterpret_cast<rn_f4*>(p + (i * TPR + t) * 4));
+    }
+#else
+    row_store_full<TPR, NV>(r, p, t);
+#endif
+}
 
 template <int NV, int L, int ACT, bool CS>
 __global__ void __launch_bounds__(256)
@@ -448,7 +475,7 @@ k_dcn_fwd_fast(const float* __restrict__ x, const float* __restrict__ kernels, c
     const int t = threadIdx.x & 63, rsub = threadIdx.x >> 6;
     const int64_t stride = (int64_t)gridDim.x * 4;
     float xn[NV][4];
-    row_load_full<TPR, NV>(xn, x + ((int64_t)blockIdx.x * 4 + rsub) * D, t);
+    row_load_stream<TPR, NV>(xn, x + ((int64_t)blockIdx.x * 4 + rsub) * D, t);
     for (int64_t row0 = (int64_t)blockIdx.x * 4; row0 < B; row0 += stride) {
         const int64_t row = row0 + rsub;
         float x0[NV][4], xl[NV][4];
@@ -456,7 +483,7 @@ k_dcn_fwd_fast(const float* __restrict__ x, const float* __restrict__ kernels, c
         for (int i = 0; i < NV; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) xl[i][e] = x0[i][e] = xn[i][e];
-        row_load_full<TPR, NV>(xn, x + (row0 + stride < B ? row + stride : row) * D, t);
+        row_load_stream<TPR, NV>(xn, x + (row0 + stride < B ? row + stride : row) * D, t);
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             float w[NV][4], bb[NV][4];
@@ -469,7 +496,7 @@ k_dcn_fwd_fast(const float* __restrict__ x, const float* __restrict__ kernels, c
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xl[i][e] = rn_act(x0[i][e] * c + bb[i][e], act);
         }
-        row_store_full<TPR, NV>(xl, y + row * D, t);
+        row_store_stream<TPR, NV>(xl, y + row * D, t);
     }
 }
 
@@ -500,8 +527,8 @@ k_dcn_bwd_fast(const float* __restrict__ x, const float* __restrict__ kernels, c
     float xn[NV][4], gn[NV][4], csn[L];
     {
         const int64_t row = (int64_t)blockIdx.x * RPB + rsub;
-        row_load_full<TPR, NV>(xn, x + row * D, t);
-        row_load_full<TPR, NV>(gn, dy + row * D, t);
+        row_load_stream<TPR, NV>(xn, x + row * D, t);
+        row_load_stream<TPR, NV>(gn, dy + row * D, t);
 #pragma unroll
         for (int l = 0; l < L; ++l) csn[l] = csave[row * L + l];
     }
@@ -517,8 +544,8 @@ k_dcn_bwd_fast(const float* __restrict__ x, const float* __restrict__ kernels, c
         for (int l = 0; l < L; ++l) cs[l] = csn[l];
         {
             const int64_t nrow = row0 + stride < B ? row + stride : row;
-            row_load_full<TPR, NV>(xn, x + nrow * D, t);
-            row_load_full<TPR, NV>(gn, dy + nrow * D, t);
+            row_load_stream<TPR, NV>(xn, x + nrow * D, t);
+            row_load_stream<TPR, NV>(gn, dy + nrow * D, t);
 #pragma unroll
             for (int l = 0; l < L; ++l) csn[l] = csave[nrow * L + l];
         }
@@ -557,7 +584,7 @@ k_dcn_bwd_fast(const float* __restrict__ x, const float* __restrict__ kernels, c
         for (int i = 0; i < NV; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) dx0[i][e] += g[i][e];             // x_0 is x0 itself
-        row_store_full<TPR, NV>(dx0, dx + row * D, t);
+        row_store_stream<TPR, NV>(dx0, dx + row * D, t);
     }
     // per-workgroup combine (rows of the workgroup summed in a fixed order), then one slab per workgroup: as dcn_bwd_saved_body
     float* slab = part + (int64_t)blockIdx.x * 2 * L * D;

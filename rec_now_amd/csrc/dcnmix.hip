@@ -171,7 +171,10 @@ extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int
 // products that already do this for x0 * g).  Same values bit for bit: one fp32 multiply either way.  RECNOW_XLESS=0 switches it off (A/B).
 static bool mix_xless(const MixDims& m) {
     static const bool on = []() { const char* e = getenv("RECNOW_XLESS"); return !e || e[0] != '0'; }();
-    return on && m.exact && m.N <= 2 && m.L > 1;
+    // measured (tools/ab_xless.sh, one box): 8192 rows 0.768 -> 0.758 ms, 16 384 rows 1.176 -> 1.156 ms per step; at 65 536 rows NEUTRAL (3.445 vs 3.450 ms:
+    // the short-K launches lose 13 us on average, the nine long-K launches with a second operand stream gain 5 us each) -- so only below the batch at
+    // which GEMM1 carries the sub-space forward in its epilogue (512 row blocks)
+    return on && m.exact && m.N <= 2 && m.L > 1 && m.B / 128 < 512;
 }
 
 static size_t mix_gemm_ws(const MixDims& m) {

@@ -9,6 +9,14 @@
 #include "common.hpp"
 
 #define FM_UNROLL 8
+// field streams of the wide kernels: -DRN_STREAM_NT (tools/build_variant.py) makes them non-temporal for the A/B of profiles/r04_configs_summary.md
+#ifdef RN_STREAM_NT
+#define FM_LD(p, i) __builtin_nontemporal_load((p) + (i))
+#define FM_ST(p, i, v) __builtin_nontemporal_store((v), (p) + (i))
+#else
+#define FM_LD(p, i) ((p)[i])
+#define FM_ST(p, i, v) ((p)[i] = (v))
+#endif
 
 template <bool SAVE_S>
 __global__ void __launch_bounds__(256)
@@ -74,7 +82,7 @@ k_fm_fwd_wide(const float* const* __restrict__ fields, int F, int64_t nchunk, in
 #pragma unroll
             for (int u = 0; u < FU; ++u)
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) v[u][c] = p[u][qc[c]];
+                for (int c = 0; c < CPL; ++c) v[u][c] = FM_LD(p[u], qc[c]);
 #pragma unroll
             for (int u = 0; u < FU; ++u)
 #pragma unroll
@@ -195,7 +203,7 @@ k_fm_bwd_wide(const float* const* __restrict__ fields, float* const* __restrict_
 #pragma unroll
             for (int u = 0; u < FU; ++u)
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) v[u][c] = p[u][q[c]];
+                for (int c = 0; c < CPL; ++c) v[u][c] = FM_LD(p[u], q[c]);
         }
         for (; f + FU <= F; f += FU) {
             const bool more = f + 2 * FU <= F;            // block-uniform
@@ -209,12 +217,12 @@ k_fm_bwd_wide(const float* const* __restrict__ fields, float* const* __restrict_
 #pragma unroll
                 for (int u = 0; u < FU; ++u)
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) nv[u][c] = p[u][q[c]];
+                    for (int c = 0; c < CPL; ++c) nv[u][c] = FM_LD(p[u], q[c]);
             }
 #pragma unroll
             for (int u = 0; u < FU; ++u)
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) dp[u][q[c]] = g[c] * (s[c] - v[u][c]);
+                for (int c = 0; c < CPL; ++c) FM_ST(dp[u], q[c], g[c] * (s[c] - v[u][c]));
             if (more) {
 #pragma unroll
                 for (int u = 0; u < FU; ++u)

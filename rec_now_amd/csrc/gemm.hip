@@ -154,12 +154,12 @@ static inline GemmCfg pick_cfg(int N) {
     return {128, 128};
 }
 // Small-M dispatch (round 4): the 128-column products with the two-wide side product -- every long-K product of the DCN-v2 step -- run on
-// 64 x 128 tiles when 128-row tiles would leave at most `bm64_max_tiles` output tiles.  Default 128 = the 16 384- and 8192-row shards of the metric's
-// 4- and 8-GPU rows: at 16 384 rows 256 tiles x 2 K-slices (16 k-tiles each, half the slab traffic) instead of 128 x 4, measured 1.17 against 1.22 ms
+// 64 x 128 tiles when 128-row tiles would leave at most `bm64_max_tiles` output tiles.  Default 256 = the 32 768-, 16 384- and 8192-row shards of the metric's
+// 2-, 4- and 8-GPU rows (32 768 rows: 512 tiles in one round without a K split, 1.89 against 1.92 ms per step): at 16 384 rows 256 tiles x 2 K-slices (16 k-tiles each, half the slab traffic) instead of 128 x 4, measured 1.17 against 1.22 ms
 // per step; at 8192 rows 128 x 4 fill all 512 workgroup slots where 64 x 4 filled half (the split is capped at 8 k-tiles per slice): 0.78 against
 // 0.79 ms (tools/ab_bm64.sh, profiles/r04_small_m.md).  RECNOW_GEMM_BM64 = 0 switches it off, = N sets the tile bound (A/B).
 static inline int bm64_max_tiles() {
-    static const int v = []() { const char* e = getenv("RECNOW_GEMM_BM64"); return e ? atoi(e) : 128; }();
+    static const int v = []() { const char* e = getenv("RECNOW_GEMM_BM64"); return e ? atoi(e) : 256; }();
     return v;
 }
 static inline bool wants_bm64(const recnow_gemm_desc* d) {

@@ -19,6 +19,7 @@ int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2
     X(false, true, 0, 0, 25)    // GEMM1 transposed ([U | K]^T x_l^T) with the sub-space forward in its epilogue (XF | 16)
     X(false, true, 0, 1, 25)    //          ... x_l = x0 * O_{l-1} formed in the operand load (dcnmix.hip mix_xless)
     X(true, false, 1, 0, 9)     // GEMM1 (not transposed) of a layer l > 0 likewise
+    X(true, false, 1, 0, 1)     //          ... four-wide form (k-tiles of 16: D <= 256)
     X(true, false, 0, 0, 2)     // GEMM3:   T2g W           + gate-weighted bias as rank-2 update
     X(true, true, 1, 0, 1)      // dT2g:    (x*g) W^T       + bias columns as side product
     X(true, true, 1, 0, 5)      //          ... and dx = g * O written from the A stream (top layer)
