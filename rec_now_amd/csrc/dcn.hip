@@ -432,11 +432,12 @@ __device__ __forceinline__ void row_store_full(const float (&r)[NV][4], float* _
 #pragma unroll
     for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(p + (i * TPR + t) * 4) = make_float4(r[i][0], r[i][1], r[i][2], r[i][3]);
 }
-// The streamed tensors of the fast kernels (x, dy in; y, dx out: every byte touched once).  -DRN_STREAM_NT (tools/build_variant.py) makes these accesses
-// non-temporal for the A/B recorded in profiles/r04_configs_summary.md; the product build uses plain accesses.
+// The streamed tensors of the fast kernels (x, dy in; y, dx out: every byte touched once) move with NON-TEMPORAL loads and stores (round 4, A/B on one
+// box, tools/micro/stream_bench.py: forward 111-113 -> 100.5-100.9 us = 4.8 -> 5.3 TB/s, backward 162-167 -> 146-153 us); -DRN_STREAM_PLAIN
+// (tools/build_variant.py) builds the plain-access variant.
 template <int TPR, int NV>
 __device__ __forceinline__ void row_load_stream(float (&r)[NV][4], const float* __restrict__ p, int t) {
-#ifdef RN_STREAM_NT
+#ifndef RN_STREAM_PLAIN
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const rn_f4 q = __builtin_nontemporal_load(reinterpret_cast<const rn_f4*>(p + (i * TPR + t) * 4));
@@ -448,7 +449,7 @@ __device__ __forceinline__ void row_load_stream(float (&r)[NV][4], const float* 
 }
 template <int TPR, int NV>
 __device__ __forceinline__ void row_store_stream(const float (&r)[NV][4], float* __restrict__ p, int t) {
-#ifdef RN_STREAM_NT
+#ifndef RN_STREAM_PLAIN
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         rn_f4 q;

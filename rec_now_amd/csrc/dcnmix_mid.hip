@@ -457,6 +457,20 @@ k_mix_mid_fwd_fast(const float* __restrict__ T1, const float* __restrict__ V, fl
     else mid_fwd_fast_body<S, N, -1, SL>(T1, V, T2, T2g, B, LDT, act_outer, sl, act_inner);
 }
 
+// A/B (tools/build_variant.py -DRN_MID_NT): the streamed tiles of the fast backward kernel (dT2g, T2, T1 in: read once; dT1 out) as non-temporal accesses.
+// Measured SLOWER (round 4, tools/ab_lib.sh: 48.5 -> 53.4 us per launch -- dT2g was written by the launch just before and is served from the cache): off.
+#ifdef RN_MID_NT
+#define MID_LD4(ptr) mid_nt_load4(ptr)
+#define MID_ST1(ptr, v) __builtin_nontemporal_store((v), (ptr))
+__device__ __forceinline__ float4 mid_nt_load4(const float* p) {
+    typedef float mid_f4 __attribute__((ext_vector_type(4)));
+    const mid_f4 q = __builtin_nontemporal_load(reinterpret_cast<const mid_f4*>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+#else
+#define MID_LD4(ptr) (*reinterpret_cast<const float4*>(ptr))
+#define MID_ST1(ptr, v) (*(ptr) = (v))
+#endif
 template <int S, int N, bool RS, int AI, int AO, int NSL>
 __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1,
                                                   const float* __restrict__ V, float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B,
@@ -494,9 +508,9 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
         for (int i = 0; i < NCH; ++i) {
             const int r = 4 * (tid >> 5) + ((tid >> 3) & 3), k4 = ((tid & 7) + 8 * i) * 4, n = k4 / S;
             const int64_t row = r0 + r;
-            if constexpr (!SL) pd[i] = *reinterpret_cast<const float4*>(dT2g + row * LDT + k4);
-            ph[i] = *reinterpret_cast<const float4*>(T2 + row * LDT + k4);
-            pa[i] = *reinterpret_cast<const float4*>(T1 + row * LDT + k4);
+            if constexpr (!SL) pd[i] = MID_LD4(dT2g + row * LDT + k4);
+            ph[i] = MID_LD4(T2 + row * LDT + k4);
+            pa[i] = MID_LD4(T1 + row * LDT + k4);
             pg[i] = T2[row * LDT + NS + n];
             psc[i] = RS ? rscale[row] : 1.f;
         }
@@ -602,7 +616,7 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                dT1[(r0 + rr) * LDT + col] = acc[r] * rn_act_grad_from_out(Hs[rr * LDA + col], act_inner);
+                MID_ST1(dT1 + (r0 + rr) * LDT + col, acc[r] * rn_act_grad_from_out(Hs[rr * LDA + col], act_inner));
             }
         }
         // dV_n += H1_n^T dC_n over this tile's 32 rows: output blocks (n, mb, cb) stay in registers across tiles

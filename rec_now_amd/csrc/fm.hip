@@ -9,8 +9,9 @@
 #include "common.hpp"
 
 #define FM_UNROLL 8
-// field streams of the wide kernels: -DRN_STREAM_NT (tools/build_variant.py) makes them non-temporal for the A/B of profiles/r04_configs_summary.md
-#ifdef RN_STREAM_NT
+// field streams of the wide kernels are non-temporal (round 4, A/B on one box: forward 89.7 -> 78.9-81.2 us = 6.0 -> 6.6-6.8 TB/s, backward 206.5 -> 194.6-195.1 us);
+// -DRN_STREAM_PLAIN (tools/build_variant.py) builds the plain-access variant
+#ifndef RN_STREAM_PLAIN
 #define FM_LD(p, i) __builtin_nontemporal_load((p) + (i))
 #define FM_ST(p, i, v) __builtin_nontemporal_store((v), (p) + (i))
 #else

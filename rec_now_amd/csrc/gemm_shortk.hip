@@ -28,6 +28,16 @@
 // co-resident workgroups still cover each other's epilogues; spilling the epilogue operands to scratch does not.
 // PRE: the whole tile of `emul` (64 registers per lane) is requested BEFORE the tile's k-loop, so it lands under the MFMAs and the
 // epilogue never waits for a load (EP == 1 products: y = x * (T2g [W; b]) streams x).
+// The epilogue's streamed operands (emul, old C, E2, E3: read once per launch) and its plain outputs move as NON-TEMPORAL accesses (round 4; A/B on one
+// box, tools/ab_lib.sh: step 3.526 -> 3.492 ms, 213 -> 208 us per launch); -DRN_SK_PLAIN (tools/build_variant.py) builds the plain-access variant.  The ring's
+// operand loads stay plain: the weights are re-read by every workgroup from L2.
+#ifndef RN_SK_PLAIN
+#define SK_LDS4(ptr) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr))
+#define SK_STS4(ptr, v) __builtin_nontemporal_store((v), reinterpret_cast<f32x4*>(ptr))
+#else
+#define SK_LDS4(ptr) (*reinterpret_cast<const f32x4*>(ptr))
+#define SK_STS4(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
+#endif
 __host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL, bool PRE, int NK = 0) {
     return (DUAL == 4 || PRE || (NK > 0 && DUAL == 2)) ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3 || NK > 0) ? 3 : 4;      // ring schedule: 32 more operand registers
 }
@@ -176,7 +186,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
         auto pre_load = [&](int s2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                evt[PRE ? s2 : 0][q] = *reinterpret_cast<const f32x4*>(Etp + (int64_t)((s2 >> 1) * 32 + q * 8) * ldp + (s2 & 1) * 32 + (EP == 1 ? e_lane : c_lane));
+                evt[PRE ? s2 : 0][q] = SK_LDS4(Etp + (int64_t)((s2 >> 1) * 32 + q * 8) * ldp + (s2 & 1) * 32 + (EP == 1 ? e_lane : c_lane));
         };
         // fragment reads and MFMAs of one k-tile in LDS buffer `cur`.  npairs = k-pairs of this k-tile that hold data: all 8, except in
         // the last k-tile of a zero-padded depth (DCN-v2: K = N*S + N = 130 stored as 144 -> 1 pair): the MFMA groups of the padding are
@@ -233,12 +243,12 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
             const int i = s2 >> 1, j = s2 & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if ((EP & 1) && !PRE) ev[buf][q] = *reinterpret_cast<const f32x4*>(Et + (int64_t)(i * 32 + q * 8) * p.lde + j * 32 + e_lane);
-                if ((EP & 2) && !PRE) cv[buf][q] = *reinterpret_cast<const f32x4*>(Ct + (int64_t)(i * 32 + q * 8) * p.ldc + j * 32 + c_lane);
-                if (DUAL == 2 || DUAL == 4) fv[buf][q] = *reinterpret_cast<const f32x4*>(Ft + (int64_t)(i * 32 + q * 8) * p.lde2 + j * 32 + f_lane);
-                if (DUAL == 2) dv[buf][q] = *reinterpret_cast<const f32x4*>(Dt + (int64_t)(i * 32 + q * 8) * p.ldc2 + j * 32 + d_lane);
+                if ((EP & 1) && !PRE) ev[buf][q] = SK_LDS4(Et + (int64_t)(i * 32 + q * 8) * p.lde + j * 32 + e_lane);
+                if ((EP & 2) && !PRE) cv[buf][q] = SK_LDS4(Ct + (int64_t)(i * 32 + q * 8) * p.ldc + j * 32 + c_lane);
+                if (DUAL == 2 || DUAL == 4) fv[buf][q] = SK_LDS4(Ft + (int64_t)(i * 32 + q * 8) * p.lde2 + j * 32 + f_lane);
+                if (DUAL == 2) dv[buf][q] = SK_LDS4(Dt + (int64_t)(i * 32 + q * 8) * p.ldc2 + j * 32 + d_lane);
                 if (DUAL == 4) {
-                    dv[buf][q] = *reinterpret_cast<const f32x4*>(Gt + (int64_t)(i * 32 + q * 8) * p.lde3 + j * 32 + g_lane);
+                    dv[buf][q] = SK_LDS4(Gt + (int64_t)(i * 32 + q * 8) * p.lde3 + j * 32 + g_lane);
                     rs[buf][q] = p.rv[m0 + wm * 64 + i * 32 + q * 8 + rr0];
                 }
             }
@@ -309,8 +319,8 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                     f32x4 v = a;
                     if (EP & 1) v = v * (PRE ? evt[PRE ? s2 : 0][2 * h + q] : ev[buf][2 * h + q]);
                     if (EP & 2) v = v + (PRE ? evt[PRE ? s2 : 0][2 * h + q] : cv[buf][2 * h + q]);
-                    if (DUAL != 3) *reinterpret_cast<f32x4*>(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane) = v;
-                    if (DUAL == 1 || (DUAL == 3 && p.C2 != nullptr)) *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) = a;
+                    if (DUAL != 3) SK_STS4(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane, v);
+                    if (DUAL == 1 || (DUAL == 3 && p.C2 != nullptr)) SK_STS4(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane, a);
                     if (DUAL == 2)
                         *reinterpret_cast<f32x4*>(Dt + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc2 + j * 32 + d_lane) =
                             dv[buf][2 * h + q] + a * fv[buf][2 * h + q];
