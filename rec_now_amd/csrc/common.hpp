@@ -118,3 +118,14 @@ typedef const float __attribute__((address_space(1)))* rn_gcf;
 typedef float __attribute__((address_space(1)))* rn_gf;
 typedef const rn_f4 __attribute__((address_space(1)))* rn_gcf4;
 typedef rn_f4 __attribute__((address_space(1)))* rn_gf4;
+// Streamed-once global accesses (every byte of the tensor is touched once by the launch): non-temporal loads / stores.  Round 4 measured them on the
+// HBM-bound layer kernels (DCNLayer, FMLayer: +10..13 % on one box, tools/micro/stream_bench.py); -DRN_STREAM_PLAIN (tools/build_variant.py) builds
+// the plain-access variant for A/B runs.  `p` is a (possibly address-space-qualified) pointer to a native vector or scalar.
+#ifndef RN_STREAM_PLAIN
+#define RN_LD_STREAM(p) __builtin_nontemporal_load(p)
+#define RN_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define RN_LD_STREAM(p) (*(p))
+#define RN_ST_STREAM(p, v) (*(p) = (v))
+#endif
+
