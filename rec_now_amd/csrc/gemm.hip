@@ -165,7 +165,19 @@ static inline int bm64_max_tiles() {
 static inline bool wants_bm64(const recnow_gemm_desc* d) {
     if (d->N != 128 || d->sp_r < 1 || d->sp_r > 2 || d->eu_r > 0 || d->as_out || d->c2_mode || d->mid_V || d->batch != 1 || d->K < 512) return false;
     if (d->M % 64 || rn_gemm_precision() != 0) return false;      // (the opt-in split-precision kernels are 128-row kernels)
-    return (long long)rn_cdiv(d->M, 128) <= bm64_max_tiles();
+    const long long tiles128 = rn_cdiv(d->M, 128);
+    if (tiles128 > bm64_max_tiles()) return false;
+    // few row tiles and a long K (the K = B weight-gradient products, M = D): 64-row tiles where 128-row tiles cannot fill the 512 workgroup slots
+    // under the split's cap of 8 k-tiles per slice (B = 8192: 8 tiles x 32 slices) and up to K = 32 768 (the shards: 1.114 against 1.128 ms per step at
+    // 16 384 rows, 1.805 against 1.812 at 32 768); at the metric's own K = 65 536 the 128-row tiles are the faster ones (145 against 148 us per launch)
+    static const int kb_mode = []() { const char* e = getenv("RECNOW_GEMM_BM64_KB"); return e ? atoi(e) : -1; }();      // A/B: 0 = only to fill the chip, 1 = always
+    if (tiles128 < 64 && kb_mode != 1) {
+        long long s = (512 + tiles128 - 1) / tiles128;
+        const long long maxs = d->K / (8 * 32);
+        if (s > maxs) s = maxs;
+        return tiles128 * (s > 0 ? s : 1) < 512 || (kb_mode != 0 && d->K <= 32768);
+    }
+    return true;
 }
 static inline GemmCfg pick_cfg(const recnow_gemm_desc* d) {
     GemmCfg c = pick_cfg(d->N);
