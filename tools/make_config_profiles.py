@@ -144,7 +144,7 @@ lines.append('| kernel | launches / step | avg us |\n|---|---|---|')
 for r in rows[:8]:
     lines.append('| `%s` | %.0f | %.1f |' % (r['Name'].split('(')[0].replace('void ', '')[:80], int(r['Calls']) / 20, float(r['AverageNs']) / 1e3))
 tot = sum(float(r['TotalDurationNs']) for r in rows) / 20 / 1e3
-lines.append('\nKernel time per step %.0f us = %.0f M rows/s of GPU time; the grouping (`k_group_mid`, one cooperative launch: 4 radix passes over 262 144 keys) is %.0f %% of it.\n'
+lines.append('\nKernel time per step %.0f us = %.0f M rows/s of GPU time; the grouping (`k_group_mid`, one cooperative launch; round 4: the float ids 0..4095 are sorted by their integer images, 2 digit passes instead of 3) is %.0f %% of it.\n'
              % (tot, 262144 / tot, 100 * float(find(rows, 'k_group_mid')['TotalDurationNs']) / 20 / 1e3 / tot))
 open('profiles/%s_configs_summary.md' % tag, 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines))
