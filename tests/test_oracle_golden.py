@@ -274,3 +274,14 @@ def test_c_oracle_under_sanitizers():
     out = subprocess.run(['make', '-C', os.path.join(root, 'oracle'), '-s', 'asan'], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'asan driver ok' in out.stdout
+
+
+def test_gemm_dispatch_logic_under_sanitizers():
+    """SURVEY.md section 5 (sanitizer build), host side: the GEMM's tile-family / small-M / split-K / slab-workspace logic
+    (rec_now_amd/csrc/gemm_dispatch.hpp, host-only) swept over shapes by tools/san/dispatch_san.cpp under -fsanitize=address,undefined."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(['make', '-C', os.path.join(root, 'tools', 'san'), '-s', 'san'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'dispatch sanitizer driver ok' in out.stdout
