@@ -25,8 +25,12 @@ def run_chunked(fwd, x, gy, weights, chunk=4096, want_dx=True):
         hi = min(B, lo + chunk)
         for v in weights.values():
             v.grad = None
-        xc = x[lo:hi].detach().cpu().double().requires_grad_(want_dx)
-        out = fwd(xc)
+        xc = x[lo:hi].detach().cpu().double().requires_grad_(want_dx and gy is not None)
+        if gy is None:                 # forward only (the scores pass in front of a loss): no autograd graph to build
+            with torch.no_grad():
+                out = fwd(xc)
+        else:
+            out = fwd(xc)
         outs = list(out) if isinstance(out, (list, tuple)) else [out]
         if outs_all is None:
             outs_all = [np.empty((B,) + tuple(o.shape[1:]), np.float64) for o in outs]
