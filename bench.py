@@ -232,7 +232,7 @@ def subset_parity(x, groups, labels, named, scores_gpu, dx_gpu, n_pair_gpu, n_gr
             'scores': rel_err(scores_gpu[rows], s64.detach().numpy()), 'dx': rel_err(dx_gpu[rows], x64.grad.numpy())}
 
 
-def self_launch(n_ranks, argv):
+def self_launch(n_ranks, argv, oversubscribe=False):
     """`python bench.py --gpus N` without a launcher: THIS process has made no GPU call yet (importing torch and counting devices
     do not initialise the runtime) and makes none -- it starts the N ranks as CHILD processes through torch.distributed.run (never an
     exec of a process that touched the GPU), relays their output, prints rank 0's JSON line as the LAST line of stdout and exits
@@ -240,7 +240,7 @@ def self_launch(n_ranks, argv):
     import socket
     import subprocess
     visible = torch.cuda.device_count()
-    if visible < n_ranks:
+    if visible < (1 if oversubscribe else n_ranks):
         raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible on this host (torch.cuda.device_count() = %d, '
                          'HIP_VISIBLE_DEVICES=%s); one process per GPU, nothing launched'
                          % (n_ranks, visible, visible, os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')))
@@ -298,11 +298,17 @@ def main():
                     help="arithmetic of the long-K products: 'f32' exact fp32 MFMA (the headline), 'bf16x3' the opt-in split-precision kernels "
                          '(fp32 operands as three bf16 pieces, six bf16 MFMA terms, fp32 accumulation; same 1e-5 parity bound, not bit-identical)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl', help="process-group backend: 'nccl' (= RCCL over xGMI, the product path); 'gloo' is a "
+                    'diagnostic that lets several ranks share one GPU (with --oversubscribe), so that the N > 1 step, reducer and cross-rank gate run with real '
+                    'multi-rank semantics on a one-GPU box (tests/test_bench_gpu.py)')
+    ap.add_argument('--oversubscribe', action='store_true', help='diagnostic (gloo only): rank r uses GPU r %% (visible GPUs) instead of requiring one GPU per rank')
     ap.add_argument('--launch', action='store_true', help='start the ranks through the self-launcher even when --gpus is 1 (tests: --gpus 1 --force-dist --launch); '
                     '--gpus N > 1 without WORLD_SIZE in the environment always takes it')
     args = ap.parse_args()
+    if args.oversubscribe and args.backend != 'gloo':
+        raise SystemExit('--oversubscribe needs --backend gloo (RCCL refuses two ranks on one device)')
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.launch):
-        self_launch(args.gpus, sys.argv[1:])          # before ANY device call; does not return
+        self_launch(args.gpus, sys.argv[1:], oversubscribe=args.oversubscribe)          # before ANY device call; does not return
 
     # The N > 1 step uses four streams (main, grouping, gradient all-reduce, RCCL's own).  With HIP's default of 4 hardware queues
     # two of them shared a queue: either the grouping ran in front of the forward pass instead of under it, or the all-reduce
@@ -316,6 +322,8 @@ def main():
         raise SystemExit('--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    if args.oversubscribe:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.force_dist
@@ -324,7 +332,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
 
     from rec_now_amd import _lib, dp
     from rec_now_amd.rec_block.pairwise_loss_from_batch import group_rows, pairwise_loss_fused
@@ -653,7 +664,9 @@ def main():
         sc64 = cpu_scores(fwd, xq_np, torch.float64) if full_gate else sc_gpu.astype(np.float64)
 
         def gather(a):
-            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            if args.backend == 'nccl':          # (gloo gathers host tensors)
+                t = t.to(dev)
             parts = [torch.empty_like(t) for _ in range(rccl_ranks)]
             dist.all_gather(parts, t)
             return torch.cat(parts).cpu().numpy()
@@ -731,6 +744,7 @@ def main():
             out['cpu_baseline'] = cpu
         if use_dist:
             out['rccl_ranks'] = parity['rccl_ranks'] if parity and 'rccl_ranks' in parity else dist.get_world_size()
+            out['backend'] = args.backend
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

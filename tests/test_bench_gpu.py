@@ -55,3 +55,20 @@ def test_more_ranks_than_gpus_fails_cleanly(dev):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n)], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode != 0
     assert 'only %d GPU(s) visible' % (n - 1) in out.stderr
+
+
+def test_two_ranks_share_one_gpu_over_gloo_and_verify_across_ranks(dev):
+    """The N > 1 step with REAL multi-rank semantics on a one-GPU box: two ranks (two processes on GPU 0, `--backend gloo --oversubscribe`) own the two
+    4096-row halves of one global batch (whole groups per rank, ids distinct across ranks), the step route writes its gradients into the layer-wise
+    reducer's buckets, every bucket is all-reduced across the two processes, and the cross-rank gate holds the reduced loss / pair count to the C pair
+    oracle on the ALL-GATHERED batch and all 17 all-reduced weight gradients to the sum of the two ranks' fp64 oracles."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--oversubscribe', '--rows', '4096',
+                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['backend'] == 'gloo'
+    par = line['parity']
+    assert par['gathered_rows'] == 8192 and par['gathered_batch_pairs_oracle']['pairs_equal']
+    full = par['oracle_fp64_all_ranks']
+    assert full['pairs_equal'] and len([k for k in full if k.startswith('cross.')]) == 15
+    assert par['ok'] and par['parity_max_rel'] <= 1e-5, par
