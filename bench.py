@@ -699,7 +699,6 @@ def main():
             full = {'loss': rel_err(float(loss_q.item()), f_loss), 'pairs_equal': int(p_glob) == int(f_pairs),
                     'scores': float(loc[0].item()), 'dx': float(loc[1].item())}
             off = 0
-            hk_scale = None
             grads64 = {}
             for k in names:
                 n = named[k].numel()
