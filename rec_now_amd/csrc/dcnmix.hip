@@ -19,6 +19,7 @@
 // takes the lean interior kernel (no bounds code) whenever B is a multiple of 256.  Zero columns/rows are inert.
 #include "gemm.hpp"
 #include "dcnmix_mid.hpp"
+#include "dcnmix_tile.hpp"
 
 static inline int ldt_of(int S, int N) {
     const int kc = N * S + N;
@@ -154,6 +155,22 @@ static inline size_t mix_pack_off(const MixDims& m) {       // byte offset of th
     return (size_t)m.L * 3 * act_block(m) + (size_t)(m.L - 1) * xbuf(m) + (m.exact ? (size_t)m.L * xbuf(m) : 0);
 }
 
+// Row-block persistent forward (dcnmix_tile.hip): its fragment-ordered weight packs live behind the packs above.  RECNOW_TILE=0 switches the route
+// off, =1 takes it for every supported batch (tests); default: batches up to MIX_TILE_MAX_B rows (the per-rank shards of the 2/4/8-GPU rows), where
+// the launch-per-product forward is a chain of single-round launches.
+#define MIX_TILE_MAX_B 8192
+static inline bool mix_tile_shape(const MixDims& m) {
+    return m.exact && m.L <= MIX_PACK_MAX_L && m.L <= RN_TILE_MAX_L && rn_mix_tile_supported(m.B, m.D, m.S, m.N, m.L, m.LDT);
+}
+static inline size_t mix_tile_pack_bytes(const MixDims& m) { return mix_tile_shape(m) ? rn_mix_tile_pack_bytes(m.D, m.S, m.N, m.L, m.LDT) : 0; }
+static inline size_t mix_tile_pack_off(const MixDims& m) { return mix_pack_off(m) + mix_pack_bytes(m); }
+static bool mix_tile_on(const MixDims& m) {
+    const char* e = getenv("RECNOW_TILE");            // read per call (tests switch the route inside one process)
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 0 || !mix_tile_shape(m) || rn_gemm_precision() != 0) return false;
+    return mode == 1 || m.B <= MIX_TILE_MAX_B;
+}
+
 // saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D);
 // exact path: then O_0..O_{L-1} (B x D)
 extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int L) {
@@ -161,7 +178,7 @@ extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int
     const MixDims m = mix_dims(B, D, S, N, L);
     // exact path: O_l = T2g_l [W; b] of every layer is kept next to x_{l+1} = x * O_l (second output of GEMM3), so the
     // backward forms dx = sum_l g_l * O_l inside kernels that stream g_l anyway instead of recomputing the products.
-    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + mix_pack_bytes(m) + 256;
+    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + mix_pack_bytes(m) + mix_tile_pack_bytes(m) + 256;
 }
 
 // Round 4: x_{l+1} = x0 * O_l is NOT materialised between the cross layers of the exact path (two experts).  The product that leaves layer l
@@ -471,6 +488,22 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     if (pack_once && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st))) return rc;
     const float* xl = x;
     const bool xless = mix_xless(m);
+    if (mix_tile_on(m) && (y || head)) {       // every layer (+ the scoring head) in one launch of row-block workgroups
+        RnTileFwd t;
+        memset(&t, 0, sizeof(t));
+        t.x = x; t.B = B; t.D = D; t.L = L; t.act_inner = act_inner; t.act_outer = act_outer;
+        t.packs = (float*)(sv + mix_tile_pack_off(m));
+        for (int l = 0; l < L; ++l) {
+            t.U[l] = U_host[l]; t.Kg[l] = gate_host[l]; t.V[l] = V_host[l]; t.W[l] = W_host[l]; t.bias[l] = bias_host[l];
+            t.T1[l] = (float*)(sv + (size_t)(3 * l) * act_block(m));
+            t.T2[l] = (float*)(sv + (size_t)(3 * l + 1) * act_block(m));
+            t.T2g[l] = (float*)(sv + (size_t)(3 * l + 2) * act_block(m));
+            t.O[l] = (need_dx || (xless && l < L - 1)) ? omid + (size_t)l * (xbuf(m) / sizeof(float)) : nullptr;
+            t.xn[l] = l < L - 1 ? (xless ? nullptr : xmid + (size_t)l * (xbuf(m) / sizeof(float))) : (head ? nullptr : y);
+        }
+        if (head) { t.head_w = head->w; t.head_b = head->b; t.scores = head->scores; }
+        return rn_mix_tile_fwd(t, st);
+    }
     for (int l = 0; l < L; ++l) {
         float* T1 = (float*)(sv + (size_t)(3 * l) * act_block(m));
         float* T2 = (float*)(sv + (size_t)(3 * l + 1) * act_block(m));

@@ -1,0 +1,31 @@
+// Row-block persistent forward of the DCN-v2 cross layers for the per-rank shards of the 2/4/8-GPU rows (dcnmix_tile.hip).
+#pragma once
+#include "common.hpp"
+
+#define RN_TILE_MAX_L 8
+// shapes the row-block kernels are instantiated for: two experts of 64, D = 256 / 512 / 1024, whole 32-row blocks
+bool rn_mix_tile_supported(int64_t B, int D, int S, int N, int L, int LDT);
+// bytes of the tile packs of all layers (fragment-ordered copies of U and W, see dcnmix_tile.hip); 0 for unsupported shapes
+size_t rn_mix_tile_pack_bytes(int D, int S, int N, int L, int LDT);
+
+struct RnTileFwd {
+    const float* x;                         // (B, D) first input
+    const float* U[RN_TILE_MAX_L];          // (N, D, S)
+    const float* Kg[RN_TILE_MAX_L];         // (D, N) gate kernels
+    const float* V[RN_TILE_MAX_L];          // (N, S, S)
+    const float* W[RN_TILE_MAX_L];          // (N, S, D)
+    const float* bias[RN_TILE_MAX_L];       // (N, D)
+    float* packs;                           // rn_mix_tile_pack_bytes
+    float* T1[RN_TILE_MAX_L];               // (B, LDT) saved activations, written
+    float* T2[RN_TILE_MAX_L];
+    float* T2g[RN_TILE_MAX_L];
+    float* O[RN_TILE_MAX_L];                // (B, D) O_l = T2g_l [W; b], or NULL (not kept)
+    float* xn[RN_TILE_MAX_L];               // (B, D) x_{l+1} = x * O_l, or NULL (not materialised); xn[L-1] = the layer output y when there is no head
+    const float* head_w;                    // (D) scoring head folded into the last layer, or NULL
+    const float* head_b;                    // (1) or NULL
+    float* scores;                          // (B)
+    int64_t B;
+    int D, L, act_inner, act_outer;
+};
+// packs the weights (one launch) and runs every layer of the forward pass in ONE launch
+int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st);

@@ -18,6 +18,7 @@ struct RnProfRecord {
 #define RN_TAG_MIX_MID_BWD 7        // k_mix_mid_bwd
 #define RN_TAG_GEMM_SPLIT 8         // k_gemm_split (bf16x3 split-precision 128x128 products, opt-in)
 #define RN_TAG_GEMM_MIDF 9          // k_gemm<128,128,..,25>: GEMM1 of DCN-v2 computed transposed with the sub-space forward in its epilogue
+#define RN_TAG_MIX_TILE_FWD 10     // k_mix_tile_fwd: row-block persistent forward of all cross layers (shard sizes)
 #define RN_TAG_MAX 11
 
 bool rn_prof_on();
