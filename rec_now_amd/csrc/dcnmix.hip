@@ -229,6 +229,10 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
     s += rn_mix_mid_bwd_ws_bytes(B, S, N);                   // per-workgroup dV partials of the fused sub-space backward
     s += (size_t)L * (rn_align((size_t)D * m.LDT * sizeof(float)) + rn_align((size_t)m.LDT * D * sizeof(float)));   // per-layer packs
     s += rn_align(rn_colsum_ws_bytes(B, 1));                 // fused scoring head: d bias = sum of dscores
+    if (mix_tile_shape(m)) {                                 // row-block backward: dT1 of every layer, dV partials per layer and workgroup
+        s += (size_t)L * act_block(m);
+        s += rn_align((size_t)L * rn_mix_tile_bwd_grid(B) * N * S * S * sizeof(float));
+    }
     return s + 4096;
 }
 
@@ -684,6 +688,154 @@ struct MixEvents {
         if (two && ev) RN_HIP(hipStreamWaitEvent(on, ev, 0)); \
     } while (0)
 
+// ---- exact-128 backward through the row-block kernel (dcnmix_tile.hip) at shard sizes --------------------------------------------
+// ONE launch walks the data-gradient chain of layers l_hi .. l_lo (dT2g, sub-space backward, g_l, dx); it leaves dT1_l and g_l, and the
+// K = B weight-gradient products of every layer follow (top layer first, so that a layer's event -- and its gradient all-reduce -- is
+// not held back by the layers below).  The chain launch occupies every CU by itself (one workgroup per CU, all registers), so nothing
+// would run beside it: the products start when it ends.
+static int dcnmix_bwd_tile(const MixDims& m, const float* x, const float* const* U_host, const float* const* V_host,
+                           const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
+                           const float* dy, const char* sv, int act_inner, int act_outer, float* dx, float* const* dU_host,
+                           float* const* dV_host, float* const* dW_host, float* const* dbias_host, float* const* dgate_host,
+                           void* ws, size_t ws_bytes, hipStream_t st, hipStream_t st2, const MixHeadGrad* hd, void* const* layer_events,
+                           int l_hi, int l_lo, const float* T2g_ds_ready, const float* ds_part, int ds_nparts) {
+    const int64_t B = m.B;
+    const int D = m.D, S = m.S, N = m.N, L = m.L;
+    const bool top = l_hi == L - 1;
+    const bool two = st2 != nullptr && st2 != st;
+    if (!two) st2 = st;
+    RnCarver c(ws, ws_bytes);
+    c.take<float>((size_t)L * D * m.LDT);
+    float* dWc1 = c.take<float>((size_t)D * m.LDT);
+    c.take<float>(act_block(m) / sizeof(float));
+    float* dC = c.take<float>(act_block(m) / sizeof(float));
+    c.take<float>(act_block(m) / sizeof(float));
+    float* gbuf0 = c.take<float>(xbuf(m) / sizeof(float));
+    float* gbuf1 = c.take<float>(xbuf(m) / sizeof(float));
+    const size_t gemm_ws = mix_gemm_ws(m);
+    void* gws1 = c.take<char>(gemm_ws);
+    void* gws2 = c.take<char>(gemm_ws);
+    void* gws3 = c.take<char>(gemm_ws);
+    c.take<char>(rn_mix_mid_bwd_ws_bytes(B, S, N));
+    const size_t cs_ws_bytes = rn_colsum_ws_bytes(B, 1);
+    void* cs_ws = c.take<char>(cs_ws_bytes);
+    float* dT1_all = c.take<float>((size_t)L * act_block(m) / sizeof(float));
+    const int grid = rn_mix_tile_bwd_grid(B);
+    float* dvpart = c.take<float>((size_t)L * grid * N * S * S);
+    if (!c.ok()) return RECNOW_EWORKSPACE;
+    const float* xmid = (const float*)(sv + (size_t)L * 3 * act_block(m));
+    const float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));
+    const float* Wc1_all = (const float*)(sv + mix_pack_off(m));
+    (void)Wc1_all;
+    MixEvents evs;
+    int rc;
+    const float* T2g_ds = dC;
+    if (hd && top) {
+        const float* T2g_top = (const float*)(sv + (size_t)(3 * (L - 1) + 2) * act_block(m));
+        if (T2g_ds_ready) {
+            T2g_ds = T2g_ds_ready;
+        } else {
+            hipLaunchKernelGGL(k_row_scale, ew_grid(B * (m.LDT / 4)), 256, 0, st, T2g_top, hd->dscores, B, m.LDT, dC);
+            RN_LAUNCH_CHECK();
+            if (hd->db && (rc = rn_colsum(hd->dscores, nullptr, 0, 0, B, 1, 1, hd->db, 0, cs_ws, cs_ws_bytes, st))) return rc;
+        }
+    }
+    auto gbuf_of = [&](int l) { return (l & 1) ? gbuf0 : gbuf1; };          // g_l = d loss / d x_l, l >= 1 (the buffers of the product route)
+    {
+        RnTileBwd t;
+        memset(&t, 0, sizeof(t));
+        t.x = x; t.packs = (const float*)(sv + mix_tile_pack_off(m)); t.B = B; t.D = D; t.L = L; t.l_hi = l_hi; t.l_lo = l_lo;
+        t.act_inner = act_inner; t.act_outer = act_outer; t.dx = dx; t.dvpart = dvpart;
+        for (int l = 0; l < L; ++l) {
+            t.Kg[l] = gate_host[l]; t.bias[l] = bias_host[l];
+            t.T1[l] = (const float*)(sv + (size_t)(3 * l) * act_block(m));
+            t.T2[l] = (const float*)(sv + (size_t)(3 * l + 1) * act_block(m));
+            t.O[l] = omid + (size_t)l * (xbuf(m) / sizeof(float));
+            t.dT1[l] = dT1_all + (size_t)l * (act_block(m) / sizeof(float));
+            t.gout[l] = l > 0 ? gbuf_of(l) : nullptr;
+        }
+        if (top) {
+            if (hd) { t.ds = hd->dscores; t.head_w = hd->w; }
+            else t.gin = dy;
+        } else {
+            t.gin = gbuf_of(l_hi + 1);
+        }
+        if ((rc = rn_mix_tile_bwd(t, st))) return rc;
+    }
+    hipEvent_t e_chain = nullptr;
+    MIX_SIGNAL(e_chain, st);
+    MIX_WAIT(e_chain, st2);
+    int pg = rn_cdiv((int64_t)D * m.NS, 256);
+    if (pg > 2048) pg = 2048;
+    hipEvent_t e_red[RN_TILE_MAX_L + 2];
+    for (int l = 0; l < RN_TILE_MAX_L + 2; ++l) e_red[l] = nullptr;
+    for (int l = l_hi; l >= l_lo; --l) {
+        const float* T2g = (const float*)(sv + (size_t)(3 * l + 2) * act_block(m));
+        const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));
+        const float* g = (l == L - 1) ? dy : gbuf_of(l + 1);
+        const float* dT1 = dT1_all + (size_t)l * (act_block(m) / sizeof(float));
+        RnDeferredReduce red_dw, red_du;
+        red_dw.valid = red_du.valid = 0;
+        // two streams: the dW products on st2, the dU products on st (slabs of layers of equal parity share a buffer: a layer's product
+        // waits for the reduction two layers up), every layer's reduction on st2 behind both
+        void* gwsu = (l & 1) ? gws1 : gws2;
+        if (l + 2 <= l_hi) MIX_WAIT(e_red[l + 2], st);
+        {   // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            const bool top_head = hd && l == L - 1;
+            d.A = g; d.A2 = x; d.a_mode = RECNOW_OPMODE_MUL; d.lda = D; d.a_trans = 1;
+            d.B = T2g; d.ldb = m.LDT; d.b_trans = 0;
+            if (top_head) {      // M^T = (x^T (dscore * T2g))^T: the rank-one head gradient reduced to a row scale of the small operand
+                d.A = x; d.A2 = nullptr; d.a_mode = RECNOW_OPMODE_NONE;
+                d.B = T2g_ds;
+            }
+            d.C = dW_host[l]; d.ldc = D; d.c_trans = 1;
+            d.M = D; d.N = m.NS; d.K = (int)B;
+            d.prof_flops = 2.0 * (double)B * D * m.KC;
+            d.sp_bx = d.B + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
+            if ((rc = rn_gemm_deferred(&d, gws3, gemm_ws, st2, &red_dw))) return rc;
+        }
+        {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
+            recnow_gemm_desc d = rn_gemm_desc_zero();
+            d.A = xl; d.lda = D; d.a_trans = 1;
+            if (mix_xless(m) && l > 0) { d.A = x; d.A2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.a_mode = RECNOW_OPMODE_MUL; }      // x_l = x0 * O_{l-1} (not stored)
+            d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
+            d.C = dWc1; d.ldc = m.NS;
+            d.M = D; d.N = m.NS; d.K = (int)B;
+            d.prof_flops = 2.0 * (double)B * D * m.KC;
+            d.sp_bx = dT1 + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dgate_host[l]; d.sp_cx_ms = N; d.sp_cx_rs = 1; d.sp_r = N;
+            recnow_gemm_desc dq = d;
+            dq.C = dU_host[l]; dq.c_perm_s = S;
+            rc = rn_gemm_deferred(&dq, gwsu, gemm_ws, st, &red_du);
+            if (rc == RECNOW_EUNSUPPORTED) {
+                if ((rc = rn_gemm(&d, gwsu, gemm_ws, st))) return rc;
+                hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st, dWc1, D, S, N, dU_host[l]);
+                RN_LAUNCH_CHECK();
+            } else if (rc) {
+                return rc;
+            }
+        }
+        {
+            hipEvent_t e_du = nullptr;
+            MIX_SIGNAL(e_du, st);
+            MIX_WAIT(e_du, st2);
+        }
+        if ((rc = rn_layer_end_reduce(&red_dw, &red_du, dvpart + (size_t)l * grid * N * S * S, grid, N * S * S, dV_host[l], st2))) return rc;
+        if (hd && l == L - 1) {
+            hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw,
+                               ds_part, ds_nparts, ds_part ? hd->db : nullptr);
+            RN_LAUNCH_CHECK();
+        }
+        MIX_SIGNAL(e_red[l], st2);
+        if (layer_events && layer_events[l]) RN_HIP(hipEventRecord((hipEvent_t)layer_events[l], st2));
+    }
+    hipEvent_t e_done = nullptr;
+    MIX_SIGNAL(e_done, st2);
+    MIX_WAIT(e_done, st);
+    (void)U_host; (void)V_host;
+    return RECNOW_OK;
+}
+
 static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const* U_host, const float* const* V_host,
                             const float* const* W_host, const float* const* bias_host, const float* const* gate_host,
                             const float* dy, const char* sv, int act_inner, int act_outer, float* dx, float* const* dU_host,
@@ -698,6 +850,9 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     const int D = m.D, S = m.S, N = m.N, L = m.L;
     if (l_hi < 0) l_hi = L - 1;
     if (l_lo < 0 || l_lo > l_hi || l_hi > L - 1) return RECNOW_EINVAL;
+    if (mix_tile_on(m) && (l_hi < L - 1 || hd || dy))
+        return dcnmix_bwd_tile(m, x, U_host, V_host, W_host, bias_host, gate_host, dy, sv, act_inner, act_outer, dx, dU_host, dV_host, dW_host,
+                               dbias_host, dgate_host, ws, ws_bytes, st, st2, hd, layer_events, l_hi, l_lo, T2g_ds_ready, ds_part, ds_nparts);
     const bool top = l_hi == L - 1;
     const bool defer_dv = rn_mix_mid_supported(S, N, m.LDT);      // the fused sub-space kernel leaves its dV partials for the layer-end reduction
     const bool two = st2 != nullptr && st2 != st;

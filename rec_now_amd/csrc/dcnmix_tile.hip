@@ -28,35 +28,43 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TL_LDT 144
 #define TL_LDP 132          // row stride of a partial tile (float4 reads of phase B stay aligned)
 #define TL_LDA 129          // H1 tile: odd stride, the per-lane ds_read_b32 of the A fragments (lane = row) is conflict-free
-#define TL_LDG 131          // T2g tile [G*H2 | G]: 130 columns, odd stride
-#define TL_LDS_FLOATS (4 * TL_ROWS * TL_LDP + 4 * TL_ROWS * 2 + TL_ROWS * TL_LDA + TL_ROWS * 2 + TL_ROWS * TL_LDG + 4 * TL_ROWS)
+#define TL_LDG 132          // T2g / dA tile: 130 columns used; float4 rows (the tile leaves for memory as coalesced 16-byte pieces)
+#define TL_LDS_FLOATS (4 * TL_ROWS * TL_LDP + 4 * TL_ROWS * 2 + TL_ROWS * TL_LDA + TL_ROWS * 2 + 2 * TL_ROWS * TL_LDG + 4 * TL_ROWS)
 
 bool rn_mix_tile_supported(int64_t B, int D, int S, int N, int L, int LDT) {
     return N == 2 && S == 64 && LDT == TL_LDT && (D == 256 || D == 512 || D == 1024) && B > 0 && B % TL_ROWS == 0 && L >= 1 && L <= RN_TILE_MAX_L;
 }
-// per layer: P1, P2 (forward) and room for the two packs of a backward kernel in the same layouts
+#define TL_PACK_FLOATS(D) (4 * (D) * TL_NS + 2 * 64 * 64)          // per layer: P1, P2 (forward), P3, P4, V^T (backward)
 size_t rn_mix_tile_pack_bytes(int D, int S, int N, int L, int LDT) {
     if (!rn_mix_tile_supported(TL_ROWS, D, S, N, L, LDT)) return 0;
-    return rn_align((size_t)L * 4 * D * TL_NS * sizeof(float));
+    return rn_align((size_t)L * TL_PACK_FLOATS(D) * sizeof(float));
 }
 
-// P1_l[kg][col][i] = U_l[n = col / 64][d = 4 kg + i][s = col % 64]         (D / 4 x 128 float4)
-// P2_l[g][h][d][i] = W_l[t = 8 g + 4 h + i][d],  W_l as (N S, D)            (16 x 2 x D float4)
+// P1_l[kg][col][i] = U_l[n = col / 64][d = 4 kg + i][s = col % 64]         (D / 4 x 128 float4)      forward GEMM1, B fragments
+// P2_l[g][h][d][i] = W_l[t = 8 g + 4 h + i][d],  W_l as (N S, D)            (16 x 2 x D float4)       forward output product, A fragments
+// P3_l[kg][t][i]   = W_l[t][d = 4 kg + i]                                   (D / 4 x 128 float4)      backward dT2g product, B fragments
+// P4_l[g][h][d][i] = U_l[n][d][s],  n S + s = 8 g + 4 h + i                 (16 x 2 x D float4)       backward g_l product, A fragments
+// VT_l[n][t][s]    = V_l[n][s][t]                                                                      backward dA product, B fragments
 __global__ void __launch_bounds__(256) k_tile_pack(const RnTileFwd p) {
     const int D = p.D, L = p.L;
-    const int64_t per = (int64_t)D * TL_NS, total = (int64_t)L * 2 * per;
+    const int64_t per = (int64_t)D * TL_NS, lay = TL_PACK_FLOATS(D), total = (int64_t)L * lay;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int l = (int)(e / (2 * per));
-        const int64_t j = e - (int64_t)l * 2 * per;
-        float* dst = p.packs + (int64_t)l * 4 * per + j;
-        if (j < per) {
-            const int i = (int)(j & 3), col = (int)((j >> 2) & 127), kg = (int)(j >> 9);
-            *dst = p.U[l][((int64_t)(col >> 6) * D + (4 * kg + i)) * 64 + (col & 63)];
+        const int l = (int)(e / lay);
+        const int64_t j = e - (int64_t)l * lay;
+        const int which = (int)(j / per);
+        const int64_t k = j - (int64_t)which * per;
+        float v;
+        if (which == 0 || which == 2) {
+            const int i = (int)(k & 3), col = (int)((k >> 2) & 127), kg = (int)(k >> 9);
+            v = which == 0 ? p.U[l][((int64_t)(col >> 6) * D + (4 * kg + i)) * 64 + (col & 63)] : p.W[l][(int64_t)col * D + 4 * kg + i];
+        } else if (which == 1 || which == 3) {
+            const int i = (int)(k & 3), d = (int)((k >> 2) % D), t = 4 * (int)((k >> 2) / D) + i;      // t = 8 g + 4 h + i = 4 (2 g + h) + i
+            v = which == 1 ? p.W[l][(int64_t)t * D + d] : p.U[l][((int64_t)(t >> 6) * D + d) * 64 + (t & 63)];
         } else {
-            const int64_t k = j - per;
-            const int i = (int)(k & 3), d = (int)((k >> 2) % D), gh = (int)((k >> 2) / D);
-            *dst = p.W[l][(int64_t)(4 * gh + i) * D + d];        // t = 8 g + 4 h + i = 4 (2 g + h) + i
+            const int sx = (int)(k & 63), t = (int)((k >> 6) & 63), n = (int)(k >> 12);
+            v = p.V[l][(n * 64 + sx) * 64 + t];
         }
+        p.packs[e] = v;
     }
 }
 
@@ -81,7 +89,8 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
     float* Hs = Pg + 4 * TL_ROWS * 2;                 // [32][LDA]    H1 tile
     float* Gs = Hs + TL_ROWS * TL_LDA;                // [32][2]      gates
     float* G2 = Gs + TL_ROWS * 2;                     // [32][LDG]    T2g tile
-    float* Sc = G2 + TL_ROWS * TL_LDG;                // [4][32]      score partials
+    float* T2s = G2 + TL_ROWS * TL_LDG;               // [32][LDG]    T2 tile (H2), on its way to memory
+    float* Sc = T2s + TL_ROWS * TL_LDG;               // [4][32]      score partials
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int act_inner = TANH ? RECNOW_ACT_TANH : p.act_inner, act_outer = TANH ? RECNOW_ACT_TANH : p.act_outer;
     const int64_t ntiles = p.B / TL_ROWS;
@@ -95,7 +104,7 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) xa[b][q] = *reinterpret_cast<const rn_f4*>(p.x + xoff + 32 * b + 8 * q);
         for (int l = 0; l < p.L; ++l) {
-            const rn_f4* __restrict__ P1 = reinterpret_cast<const rn_f4*>(p.packs + (int64_t)l * 4 * D * TL_NS);
+            const rn_f4* __restrict__ P1 = reinterpret_cast<const rn_f4*>(p.packs + (int64_t)l * TL_PACK_FLOATS(D));
             const rn_f4* __restrict__ P2 = P1 + D * 32;
             const rn_f4* __restrict__ Kg4 = reinterpret_cast<const rn_f4*>(p.Kg[l]);
             // ---- GEMM1 over this wave's quarter of K: partial T1 (4 column blocks) + partial gate logits
@@ -196,18 +205,23 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
                 const float* ap = Hs + c * TL_LDA + en * 64 + h;
 #pragma unroll
                 for (int st = 0; st < 32; ++st) a2 = TL_MFMA(ap[2 * st], vb[st], a2);
+#ifdef RN_TILE_TRACE
+                if (l == 1) { if (a2[0] == 12345.f) Sc[0] = 1.f; TL_STAMP(20); }       // (the compare makes the stamp wait for the chain)
+#endif
                 const int col = en * 64 + ecb * 32 + c;
-                float* __restrict__ T2p = p.T2[l] + r0 * TL_LDT + col;
-                float* __restrict__ T2gp = p.T2g[l] + r0 * TL_LDT + col;
+                // the epilogue's LDS reads go out together and the 16 activations are independent chains (one wave per SIMD: a wait per
+                // element cost 0.4 us each); T2 / T2g leave through LDS tiles as coalesced 16-byte pieces behind the barrier
+                float gsel[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gsel[r] = Gs[((r & 3) + 8 * (r >> 2) + 4 * h) * 2 + en];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float h2 = rn_act(a2[r], act_outer);
-                    const float t = Gs[rr * 2 + en] * h2;
-                    T2p[rr * TL_LDT] = h2;
-                    T2gp[rr * TL_LDT] = t;
-                    G2[rr * TL_LDG + col] = t;
+                    T2s[rr * TL_LDG + col] = h2;
+                    G2[rr * TL_LDG + col] = gsel[r] * h2;
                 }
+                if (l == 1) TL_STAMP(21);
                 {   // columns 128 .. 143 of T2 and T2g: [G | 0]; thread = (row, tensor, float4)
                     const int row = tid >> 3, q = tid & 3;
                     rn_f4 g4 = {0.f, 0.f, 0.f, 0.f};
@@ -217,8 +231,20 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
                 }
                 if (tid < 2 * TL_ROWS) G2[(tid >> 1) * TL_LDG + TL_NS + (tid & 1)] = Gs[tid];
             }
+            if (l == 1) TL_STAMP(22);
             __syncthreads();
             TL_STAMP(5 + 6 * l);
+            {   // T2 and T2g rows of the tile: thread = (row, 16-byte piece), eight threads per 128 bytes
+                const int row = tid >> 3;
+                float* __restrict__ T2r = p.T2[l] + (r0 + row) * TL_LDT;
+                float* __restrict__ T2gr = p.T2g[l] + (r0 + row) * TL_LDT;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k4 = ((tid & 7) + 8 * i) * 4;
+                    *reinterpret_cast<rn_f4*>(T2r + k4) = *reinterpret_cast<const rn_f4*>(T2s + row * TL_LDG + k4);
+                    *reinterpret_cast<rn_f4*>(T2gr + k4) = *reinterpret_cast<const rn_f4*>(G2 + row * TL_LDG + k4);
+                }
+            }
             // ---- phase D: O^T = [W; b]^T T2g^T over this wave's d-blocks, two blocks at a time; x_{l+1} = x * O_l into xa
             {
                 float tb[16][4], tg;
@@ -328,7 +354,7 @@ int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st) {
     if (!rn_mix_tile_supported(p.B, p.D, 64, 2, p.L, TL_LDT) || !p.packs || !p.x) return RECNOW_EUNSUPPORTED;
     if (p.head_w && !p.scores) return RECNOW_EINVAL;
     {
-        const int64_t total = (int64_t)p.L * 2 * p.D * TL_NS;
+        const int64_t total = (int64_t)p.L * TL_PACK_FLOATS(p.D);
         int g = rn_cdiv(total, 256 * 4);
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(k_tile_pack, g, 256, 0, st, p);
@@ -345,6 +371,371 @@ int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st) {
         case 256: rc = tile_launch<2>(p, grid, st); break;
         case 512: rc = tile_launch<4>(p, grid, st); break;
         default: rc = tile_launch<8>(p, grid, st); break;
+    }
+    rn_prof_end(pr, st);
+    return rc;
+}
+
+// ---- backward: the data-gradient chain of layers l_hi .. l_lo for a block of 32 rows, one launch -----------------------------------
+// Mirror of the forward.  The gradient g_{l+1} w.r.t. the layer's output sits in the A-fragment layout (ga, as xa above):
+//   * dT2g = (g_{l+1} * x) [W; b]^T: every wave contracts its quarter of D (x streams through the operand ring, and so do O_l and the old dx:
+//     dx (+)= g_{l+1} * O_l leaves from the same loop); partial tiles meet in LDS;
+//   * sub-space backward on the summed tile (k_mix_mid_bwd_fast's arithmetic: dC, <dT2g_n, H2_n>, gate, dA = (dC V^T) act'(H1), dV += H1^T dC);
+//     dT1 = [dA | dlogits | 0] goes to memory (the weight-gradient product dU reads it) and stays in LDS for
+//   * g_l^T = [U | K] dT1^T, transposed like the forward's output product: the accumulators ARE the next layer's ga; g_l is stored for the
+//     weight-gradient product of layer l - 1 (l >= 1) or added to dx (l = 0).
+// dV partial sums: one (N, S, S) block per workgroup and layer (a workgroup with several row blocks adds to its own block), summed by
+// rn_layer_end_reduce in a fixed order.
+#define TLB_LDS_FLOATS (4 * TL_ROWS * TL_LDP + 4 * TL_ROWS * 2 + 2 * TL_ROWS * TL_LDA + TL_ROWS * TL_LDG + 2 * TL_ROWS * 2)
+
+__device__ __forceinline__ rn_f4 tl_ld4(const float* base, unsigned off) {
+    return *reinterpret_cast<const rn_f4*>(reinterpret_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ float tl_ld1(const float* base, unsigned off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); }
+__device__ __forceinline__ void tl_st4(float* base, unsigned off, rn_f4 v) { *reinterpret_cast<rn_f4*>(reinterpret_cast<char*>(base) + off) = v; }
+#define TL_OPAQUE(v) asm volatile("" : "+v"(v))
+
+template <int NB, bool TANH, bool DX>
+__global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
+    constexpr int D = 128 * NB;
+    static_assert(NB % 2 == 0, "d-blocks are walked in pairs");
+    extern __shared__ float lds[];
+    float* Ps = lds;                                  // [4][32][LDP] partial dT2g tiles
+    float* Pg = Ps + 4 * TL_ROWS * TL_LDP;            // [4][32][2]   partial gate columns of dT2g
+    float* Cs = Pg + 4 * TL_ROWS * 2;                 // [32][LDA]    dC tile
+    float* Hs = Cs + TL_ROWS * TL_LDA;                // [32][LDA]    H1 tile
+    float* E2 = Hs + TL_ROWS * TL_LDA;                // [32][LDG]    dA tile (the main columns of dT1)
+    float* Ps2 = E2 + TL_ROWS * TL_LDG;               // [32][2]      <dT2g_n, H2_n>
+    float* Ds = Ps2 + TL_ROWS * 2;                    // [32][2]      dlogits
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int en = w >> 1, ecb = w & 1;
+    const int act_inner = TANH ? RECNOW_ACT_TANH : p.act_inner, act_outer = TANH ? RECNOW_ACT_TANH : p.act_outer;
+    const int64_t ntiles = p.B / TL_ROWS;
+    // per-lane byte offsets (tile-invariant; the tile's first row goes into the uniform base pointers)
+    unsigned vX = (unsigned)((c * D + 4 * h + w * NB * 32) * 4);              // this lane's row of a (B, D) tensor, first column of its quarter
+    unsigned vP = (unsigned)(((w * NB * 8 + h) * 128 + c) * 16);              // P3: float4 (kg, t)
+    unsigned vB = (unsigned)((w * NB * 8 + h) * 16);                          // rows d0 = 4 kg of a (N, D) tensor
+    unsigned vQ = (unsigned)((h * D + w * NB * 32 + c) * 16);                 // P4: float4 (g, h, d)
+    unsigned vK = (unsigned)(((w * NB * 32 + c) * 2 + h) * 4);                // Kg[d][h]
+    const int tr = 4 * (tid >> 5) + ((tid >> 3) & 3);                         // phase c: this thread's row of the tile
+    unsigned vT = (unsigned)((tr * TL_LDT + (tid & 7) * 4) * 4);
+    TL_STAMP(32);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * TL_ROWS;
+        const bool first_tile = tile == (int64_t)blockIdx.x;
+        const float* __restrict__ xt = p.x + r0 * D;
+        rn_f4 ga[NB][4];
+        if (p.gin) {
+            const float* __restrict__ gt = p.gin + r0 * D;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ga[b][q] = tl_ld4(gt, vX + (32 * b + 8 * q) * 4);
+        } else {
+            const float dsr = p.ds[r0 + c];
+            const float* __restrict__ hvp = p.head_w + 4 * h + w * NB * 32;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ga[b][q] = *reinterpret_cast<const rn_f4*>(hvp + 32 * b + 8 * q) * dsr;
+        }
+        for (int l = p.l_hi; l >= p.l_lo; --l) {
+            const float* __restrict__ PL = p.packs + (int64_t)l * TL_PACK_FLOATS(D);
+            const float* __restrict__ P3 = PL + 2 * D * TL_NS;
+            const float* __restrict__ P4 = PL + 3 * D * TL_NS;
+            const float* __restrict__ VT = PL + 4 * D * TL_NS;
+            const float* __restrict__ bl = p.bias[l];
+            const float* __restrict__ Ot = DX ? p.O[l] + r0 * D : nullptr;
+            float* __restrict__ dxt = DX ? p.dx + r0 * D : nullptr;
+            const bool keep_dx = l != p.L - 1;          // the top layer writes dx, the layers below add to it
+            // ---- dT2g partial over this wave's quarter of D; dx (+)= g * O_l on the way
+            f32x16 acc[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+            float g0 = 0.f, g1 = 0.f;
+            {
+                constexpr int NST = NB * 4;
+                rn_f4 wr[3][4], br[3][2], xr[3], orr[3], dr[3];
+                auto ld1 = [&](int s, int slot) {
+                    const int ks = (s >> 2) * 8 + 2 * (s & 3);                  // static part of kg
+                    const unsigned so = (unsigned)((32 * (s >> 2) + 8 * (s & 3)) * 4);
+                    TL_OPAQUE(vP); TL_OPAQUE(vB); TL_OPAQUE(vX);
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) wr[slot][cb] = tl_ld4(P3, vP + (unsigned)(ks * 128 * 16 + cb * 512));
+                    br[slot][0] = tl_ld4(bl, vB + (unsigned)(ks * 16));
+                    br[slot][1] = tl_ld4(bl + D, vB + (unsigned)(ks * 16));
+                    xr[slot] = tl_ld4(xt, vX + so);
+                    if (DX) {       // no load under a run-time condition: the top layer reads the old dx too and drops it
+                        orr[slot] = tl_ld4(Ot, vX + so);
+                        dr[slot] = tl_ld4(dxt, vX + so);
+                    }
+                };
+                ld1(0, 0);
+                ld1(1, 1);
+#pragma unroll
+                for (int s = 0; s < NST; ++s) {
+                    if (s + 2 < NST) ld1(s + 2, (s + 2) % 3);
+                    TL_SB();
+                    const int b = s >> 2, q = s & 3, slot = s % 3;
+                    const rn_f4 gv = ga[b][q];
+                    if (DX) {
+                        const rn_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                        const rn_f4 dv = gv * orr[slot] + (keep_dx ? dr[slot] : zero4);      // a select: the dropped words may be anything
+                        TL_OPAQUE(vX);
+                        tl_st4(dxt, vX + (unsigned)((32 * b + 8 * q) * 4), dv);
+                    }
+                    const rn_f4 a = gv * xr[slot];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) acc[cb] = TL_MFMA(a[i], wr[slot][cb][i], acc[cb]);
+                    g0 += (a.x * br[slot][0].x + a.y * br[slot][0].y) + (a.z * br[slot][0].z + a.w * br[slot][0].w);
+                    g1 += (a.x * br[slot][1].x + a.y * br[slot][1].y) + (a.z * br[slot][1].z + a.w * br[slot][1].w);
+                    TL_SB();
+                }
+            }
+            TL_STAMP(34 + 6 * l);
+            // operands of the sub-space backward for this thread's part of the tile: requested now, used behind the barrier
+            const float* __restrict__ T2t = p.T2[l] + r0 * TL_LDT;
+            const float* __restrict__ T1t = p.T1[l] + r0 * TL_LDT;
+            rn_f4 t2v[4], t1v[4];
+            TL_OPAQUE(vT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                t2v[i] = tl_ld4(T2t, vT + (unsigned)(i * 128));
+                t1v[i] = tl_ld4(T1t, vT + (unsigned)(i * 128));
+            }
+            const float pg0 = T2t[tr * TL_LDT + TL_NS], pg1 = T2t[tr * TL_LDT + TL_NS + 1];
+            const float pgg0 = T2t[(tid & 31) * TL_LDT + TL_NS], pgg1 = T2t[(tid & 31) * TL_LDT + TL_NS + 1];      // gate math rows (threads < 32)
+            float vtb[32];
+            {
+                const float* __restrict__ Vp = VT + en * 4096 + h * 64 + ecb * 32 + c;
+#pragma unroll
+                for (int st = 0; st < 32; ++st) vtb[st] = Vp[st * 128];
+            }
+            {
+                float* Pw = Ps + w * TL_ROWS * TL_LDP + 4 * h * TL_LDP + c;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * TL_LDP + cb * 32] = acc[cb][r];
+                g0 += __shfl_xor(g0, 32, 64);
+                g1 += __shfl_xor(g1, 32, 64);
+                if (h == 0) {
+                    Pg[(w * TL_ROWS + c) * 2] = g0;
+                    Pg[(w * TL_ROWS + c) * 2 + 1] = g1;
+                }
+            }
+            __syncthreads();
+            TL_STAMP(35 + 6 * l);
+            // ---- phase c: dT2g = sum of the partials; dC, H1 tiles, <dT2g_n, H2_n>
+            float dgt0 = 0.f, dgt1 = 0.f;
+            {
+                float ppv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k4 = ((tid & 7) + 8 * i) * 4;
+                    const float* pp = Ps + tr * TL_LDP + k4;
+                    const rn_f4 a0 = *reinterpret_cast<const rn_f4*>(pp), a1 = *reinterpret_cast<const rn_f4*>(pp + TL_ROWS * TL_LDP),
+                                a2 = *reinterpret_cast<const rn_f4*>(pp + 2 * TL_ROWS * TL_LDP), a3 = *reinterpret_cast<const rn_f4*>(pp + 3 * TL_ROWS * TL_LDP);
+                    const rn_f4 d = (a0 + a1) + (a2 + a3);
+                    const rn_f4 h2 = t2v[i], h1 = t1v[i];
+                    const float g = i < 2 ? pg0 : pg1;
+                    float* cd = Cs + tr * TL_LDA + k4;
+                    cd[0] = g * d.x * rn_act_grad_from_out(h2.x, act_outer);
+                    cd[1] = g * d.y * rn_act_grad_from_out(h2.y, act_outer);
+                    cd[2] = g * d.z * rn_act_grad_from_out(h2.z, act_outer);
+                    cd[3] = g * d.w * rn_act_grad_from_out(h2.w, act_outer);
+                    float* hd = Hs + tr * TL_LDA + k4;
+                    hd[0] = h1.x; hd[1] = h1.y; hd[2] = h1.z; hd[3] = h1.w;
+                    ppv[i] = d.x * h2.x + d.y * h2.y + d.z * h2.z + d.w * h2.w;
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    float pp = ppv[2 * n] + ppv[2 * n + 1];
+                    pp += __shfl_xor(pp, 4, 64);
+                    pp += __shfl_xor(pp, 2, 64);
+                    pp += __shfl_xor(pp, 1, 64);
+                    if ((tid & 7) == 0) Ps2[tr * 2 + n] = pp;
+                }
+                if (tid < TL_ROWS) {
+                    dgt0 = (Pg[tid * 2] + Pg[(TL_ROWS + tid) * 2]) + (Pg[(2 * TL_ROWS + tid) * 2] + Pg[(3 * TL_ROWS + tid) * 2]);
+                    dgt1 = (Pg[tid * 2 + 1] + Pg[(TL_ROWS + tid) * 2 + 1]) + (Pg[(2 * TL_ROWS + tid) * 2 + 1] + Pg[(3 * TL_ROWS + tid) * 2 + 1]);
+                }
+            }
+            __syncthreads();
+            TL_STAMP(36 + 6 * l);
+            // ---- phase d: gate backward; dA block -> dT1 + LDS; dV blocks
+            float* __restrict__ dT1t = p.dT1[l] + r0 * TL_LDT;
+            {
+                if (tid < TL_ROWS) {
+                    const float dg0 = Ps2[tid * 2] + dgt0, dg1 = Ps2[tid * 2 + 1] + dgt1;
+                    const float dot = pgg0 * dg0 + pgg1 * dg1;
+                    Ds[tid * 2] = pgg0 * (dg0 - dot);
+                    Ds[tid * 2 + 1] = pgg1 * (dg1 - dot);
+                }
+                f32x16 a2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+                const float* ap = Cs + c * TL_LDA + en * 64 + h;
+#pragma unroll
+                for (int st = 0; st < 32; ++st) a2 = TL_MFMA(ap[2 * st], vtb[st], a2);
+                const int col = en * 64 + ecb * 32 + c;
+                float hsel[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hsel[r] = Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * TL_LDA + col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)       // dA leaves for memory from the LDS tile, behind the barrier, as coalesced 16-byte pieces
+                    E2[((r & 3) + 8 * (r >> 2) + 4 * h) * TL_LDG + col] = a2[r] * rn_act_grad_from_out(hsel[r], act_inner);
+                float* __restrict__ dvp = p.dvpart + ((int64_t)l * gridDim.x + blockIdx.x) * (2 * 64 * 64);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int item = w + 4 * j, n = item >> 2, mb = (item >> 1) & 1, cb = item & 1;
+                    float* __restrict__ dst = dvp + n * 4096 + (mb * 32 + 4 * h) * 64 + cb * 32 + c;
+                    f32x16 av;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) av[r] = first_tile ? 0.f : dst[((r & 3) + 8 * (r >> 2)) * 64];
+                    const float* hp2 = Hs + h * TL_LDA + n * 64 + mb * 32 + c;
+                    const float* cp2 = Cs + h * TL_LDA + n * 64 + cb * 32 + c;
+#pragma unroll
+                    for (int st = 0; st < TL_ROWS / 2; ++st) av = TL_MFMA(hp2[2 * st * TL_LDA], cp2[2 * st * TL_LDA], av);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * 64] = av[r];
+                }
+            }
+            __syncthreads();
+            TL_STAMP(37 + 6 * l);
+            {   // dT1 rows of the tile = [dA | dlogits | 0]: thread = (row, 16-byte piece), eight threads per 128 bytes
+                const int row = tid >> 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k4 = ((tid & 7) + 8 * i) * 4;
+                    *reinterpret_cast<rn_f4*>(dT1t + row * TL_LDT + k4) = *reinterpret_cast<const rn_f4*>(E2 + row * TL_LDG + k4);
+                }
+                if ((tid & 4) == 0) {
+                    const int q = tid & 3;
+                    rn_f4 g4 = {0.f, 0.f, 0.f, 0.f};
+                    if (q == 0) { g4.x = Ds[row * 2]; g4.y = Ds[row * 2 + 1]; }
+                    *reinterpret_cast<rn_f4*>(dT1t + row * TL_LDT + TL_NS + 4 * q) = g4;
+                }
+            }
+            // ---- g_l^T = [U | K] dT1^T over this wave's d-blocks, two blocks at a time; the accumulators are the next layer's ga
+            if (l > 0 || DX) {
+                float tb[16][4], tg;
+                {
+                    const float* gp = E2 + c * TL_LDG + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) tb[g][i] = gp[8 * g + i];
+                    tg = Ds[c * 2 + h];
+                }
+                float* __restrict__ gt = l > 0 ? p.gout[l] + r0 * D : dxt;            // l = 0: g_0 is added to dx
+                const bool add_dx = l == 0;
+                const float* __restrict__ Kl = p.Kg[l];
+                constexpr int NST = (NB / 2) * 16;
+                rn_f4 wr[8];                                            // ring of four step slots: 3 steps ahead, two loads per step
+                auto ld2 = [&](int s, int slot) {
+                    const int pb = s >> 4, g = s & 15;
+                    TL_OPAQUE(vQ);
+                    wr[slot] = tl_ld4(P4, vQ + (unsigned)((2 * g * D + (2 * pb) * 32) * 16));
+                    wr[slot + 1] = tl_ld4(P4, vQ + (unsigned)((2 * g * D + (2 * pb + 1) * 32) * 16));
+                };
+#pragma unroll
+                for (int s = 0; s < 3; ++s) ld2(s, 2 * s);
+#pragma unroll
+                for (int pb = 0; pb < NB / 2; ++pb) {
+                    rn_f4 dxo[2][4];
+                    float kz[2];
+                    TL_OPAQUE(vK); TL_OPAQUE(vX);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        kz[u] = tl_ld1(Kl, vK + (unsigned)((2 * pb + u) * 32 * 2 * 4));
+                        if (DX) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) dxo[u][q] = tl_ld4(dxt, vX + (unsigned)((32 * (2 * pb + u) + 8 * q) * 4));
+                        }
+                    }
+                    f32x16 o[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int s = pb * 16 + g;
+                        if (s + 3 < NST) ld2(s + 3, (2 * (s + 3)) % 8);
+                        TL_SB();
+                        const int slot = (2 * s) % 8;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            o[0] = TL_MFMA(wr[slot][i], tb[g][i], o[0]);
+                            o[1] = TL_MFMA(wr[slot + 1][i], tb[g][i], o[1]);
+                        }
+                        TL_SB();
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        o[u] = TL_MFMA(kz[u], tg, o[u]);                // the gate kernel's columns (k-pair 128, 129: dlogits)
+                        const int b = 2 * pb + u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const rn_f4 gv = {o[u][4 * q], o[u][4 * q + 1], o[u][4 * q + 2], o[u][4 * q + 3]};
+                            ga[b][q] = gv;
+                            TL_OPAQUE(vX);
+                            const rn_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                            tl_st4(gt, vX + (unsigned)((32 * b + 8 * q) * 4), DX ? gv + (add_dx ? dxo[u][q] : zero4) : gv);
+                        }
+                    }
+                }
+            }
+            TL_STAMP(38 + 6 * l);
+        }
+    }
+}
+
+int rn_mix_tile_bwd_grid(int64_t B) {
+    const int64_t tiles = B / TL_ROWS;
+    return (int)(tiles < 256 ? tiles : 256);
+}
+
+template <int NB>
+static int tile_bwd_launch(const RnTileBwd& p, int grid, hipStream_t st) {
+    const size_t lds = (size_t)TLB_LDS_FLOATS * sizeof(float);
+    const bool tanh2 = p.act_inner == RECNOW_ACT_TANH && p.act_outer == RECNOW_ACT_TANH;
+    const bool dx = p.dx != nullptr;
+    static bool allowed[4] = {false, false, false, false};
+    const int v = (tanh2 ? 2 : 0) + (dx ? 1 : 0);
+    const void* fn = v == 3 ? (const void*)k_mix_tile_bwd<NB, true, true> : v == 2 ? (const void*)k_mix_tile_bwd<NB, true, false>
+                   : v == 1 ? (const void*)k_mix_tile_bwd<NB, false, true> : (const void*)k_mix_tile_bwd<NB, false, false>;
+    if (!allowed[v]) {
+        RN_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed[v] = true;
+    }
+    if (v == 3) hipLaunchKernelGGL((k_mix_tile_bwd<NB, true, true>), grid, 256, lds, st, p);
+    else if (v == 2) hipLaunchKernelGGL((k_mix_tile_bwd<NB, true, false>), grid, 256, lds, st, p);
+    else if (v == 1) hipLaunchKernelGGL((k_mix_tile_bwd<NB, false, true>), grid, 256, lds, st, p);
+    else hipLaunchKernelGGL((k_mix_tile_bwd<NB, false, false>), grid, 256, lds, st, p);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+int rn_mix_tile_bwd(const RnTileBwd& p, hipStream_t st) {
+    if (!rn_mix_tile_supported(p.B, p.D, 64, 2, p.L, TL_LDT) || !p.packs || !p.x || !p.dvpart) return RECNOW_EUNSUPPORTED;
+    if (p.l_hi < p.l_lo || p.l_lo < 0 || p.l_hi >= p.L) return RECNOW_EINVAL;
+    if (!p.gin && (!p.ds || !p.head_w)) return RECNOW_EINVAL;
+    const int grid = rn_mix_tile_bwd_grid(p.B);
+    const int nl = p.l_hi - p.l_lo + 1;
+    RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_MIX_TILE_BWD, (double)nl * (4.0 * p.B * p.D * 130 + 8.0 * p.B * 2 * 64 * 64),
+                                                    (double)nl * (12.0 * p.B * TL_LDT + 16.0 * p.B * p.D), st)
+                                    : nullptr;
+    int rc;
+    switch (p.D) {
+        case 256: rc = tile_bwd_launch<2>(p, grid, st); break;
+        case 512: rc = tile_bwd_launch<4>(p, grid, st); break;
+        default: rc = tile_bwd_launch<8>(p, grid, st); break;
     }
     rn_prof_end(pr, st);
     return rc;

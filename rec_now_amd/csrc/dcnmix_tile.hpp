@@ -29,3 +29,27 @@ struct RnTileFwd {
 };
 // packs the weights (one launch) and runs every layer of the forward pass in ONE launch
 int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st);
+
+// Data-gradient chain of the backward pass, layers l_hi .. l_lo (descending) in ONE launch: per layer dT2g -> sub-space backward -> g_l,
+// with dx accumulated on the way.  The K = B weight-gradient products stay separate launches: they read what this kernel leaves
+// (dT1_l, g_l) and the saved activations.
+struct RnTileBwd {
+    const float* x;                         // (B, D)
+    const float* packs;                     // the forward's packs (P3, P4, V^T)
+    const float* Kg[RN_TILE_MAX_L];         // (D, N)
+    const float* bias[RN_TILE_MAX_L];       // (N, D)
+    const float* T1[RN_TILE_MAX_L];         // saved activations
+    const float* T2[RN_TILE_MAX_L];
+    const float* O[RN_TILE_MAX_L];          // (B, D), read when dx != NULL
+    float* dT1[RN_TILE_MAX_L];              // (B, LDT) out: [dA | dlogits | 0]
+    float* gout[RN_TILE_MAX_L];             // (B, D) out: g_l = d loss / d x_l for l >= 1 (NULL for l = 0)
+    const float* gin;                       // (B, D) gradient w.r.t. the output of layer l_hi, or NULL: the folded head's ds (x) head_w
+    const float* ds;                        // (B) d loss / d scores (folded head)
+    const float* head_w;                    // (D)
+    float* dx;                              // (B, D) or NULL
+    float* dvpart;                          // [layer][workgroup][N S S] partial sums of dV
+    int64_t B;
+    int D, L, l_hi, l_lo, act_inner, act_outer;
+};
+int rn_mix_tile_bwd_grid(int64_t B);        // workgroups of the launch = dV partials per layer
+int rn_mix_tile_bwd(const RnTileBwd& p, hipStream_t st);

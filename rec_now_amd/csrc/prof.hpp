@@ -19,7 +19,8 @@ struct RnProfRecord {
 #define RN_TAG_GEMM_SPLIT 8         // k_gemm_split (bf16x3 split-precision 128x128 products, opt-in)
 #define RN_TAG_GEMM_MIDF 9          // k_gemm<128,128,..,25>: GEMM1 of DCN-v2 computed transposed with the sub-space forward in its epilogue
 #define RN_TAG_MIX_TILE_FWD 10     // k_mix_tile_fwd: row-block persistent forward of all cross layers (shard sizes)
-#define RN_TAG_MAX 11
+#define RN_TAG_MIX_TILE_BWD 11     // k_mix_tile_bwd: the data-gradient chain of the cross layers, row-block persistent
+#define RN_TAG_MAX 12
 
 bool rn_prof_on();
 // returns a slot (or nullptr when profiling is off / the pool is full) and records e0 on st
