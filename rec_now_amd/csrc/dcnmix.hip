@@ -158,7 +158,7 @@ static inline size_t mix_pack_off(const MixDims& m) {       // byte offset of th
 // Row-block persistent forward (dcnmix_tile.hip): its fragment-ordered weight packs live behind the packs above.  RECNOW_TILE=0 switches the route
 // off, =1 takes it for every supported batch (tests); default: batches up to MIX_TILE_MAX_B rows (the per-rank shards of the 2/4/8-GPU rows), where
 // the launch-per-product forward is a chain of single-round launches.
-#define MIX_TILE_MAX_B 8192
+#define MIX_TILE_MAX_B 16384
 static inline bool mix_tile_shape(const MixDims& m) {
     return m.exact && m.L <= MIX_PACK_MAX_L && m.L <= RN_TILE_MAX_L && rn_mix_tile_supported(m.B, m.D, m.S, m.N, m.L, m.LDT);
 }
@@ -850,7 +850,12 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     const int D = m.D, S = m.S, N = m.N, L = m.L;
     if (l_hi < 0) l_hi = L - 1;
     if (l_lo < 0 || l_lo > l_hi || l_hi > L - 1) return RECNOW_EINVAL;
-    if (mix_tile_on(m) && (l_hi < L - 1 || hd || dy))
+    // The row-block backward chain is OPT-IN (RECNOW_TILE_BWD=1): measured (two boxes, 8192 rows per GPU) 0.744-0.748 ms per step against 0.728-0.734
+    // with the product-route backward behind the row-block forward -- its launch fills every CU by itself, so the K = B weight-gradient products
+    // that the product route runs BESIDE its chain come after it, and its dT2g loop is bound by the address unit (x, O_l and dx move as 32-byte
+    // pieces of 32 rows per instruction).  Parity-tested like the default (tests/test_tile_gpu.py).
+    const char* tb_env = getenv("RECNOW_TILE_BWD");
+    if (mix_tile_on(m) && tb_env && tb_env[0] == '1' && (l_hi < L - 1 || hd || dy))
         return dcnmix_bwd_tile(m, x, U_host, V_host, W_host, bias_host, gate_host, dy, sv, act_inner, act_outer, dx, dU_host, dV_host, dW_host,
                                dbias_host, dgate_host, ws, ws_bytes, st, st2, hd, layer_events, l_hi, l_lo, T2g_ds_ready, ds_part, ds_nparts);
     const bool top = l_hi == L - 1;

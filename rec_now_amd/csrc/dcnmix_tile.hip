@@ -76,6 +76,14 @@ extern "C" int recnow_debug_tile_trace(long long* out) { return (int)hipMemcpyFr
 #else
 #define TL_STAMP(i) do { } while (0)
 #endif
+// uniform base pointer (SGPRs) + per-lane 32-bit byte offset kept opaque, so that the compiler neither folds the step's constant into a
+// new 64-bit address per load nor parks one address per step in registers
+__device__ __forceinline__ rn_f4 tl_ld4(const float* base, unsigned off) {
+    return *reinterpret_cast<const rn_f4*>(reinterpret_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ float tl_ld1(const float* base, unsigned off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); }
+__device__ __forceinline__ void tl_st4(float* base, unsigned off, rn_f4 v) { *reinterpret_cast<rn_f4*>(reinterpret_cast<char*>(base) + off) = v; }
+#define TL_OPAQUE(v) asm volatile("" : "+v"(v))
 #define TL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define TL_SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -106,7 +114,6 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
         for (int l = 0; l < p.L; ++l) {
             const rn_f4* __restrict__ P1 = reinterpret_cast<const rn_f4*>(p.packs + (int64_t)l * TL_PACK_FLOATS(D));
             const rn_f4* __restrict__ P2 = P1 + D * 32;
-            const rn_f4* __restrict__ Kg4 = reinterpret_cast<const rn_f4*>(p.Kg[l]);
             // ---- GEMM1 over this wave's quarter of K: partial T1 (4 column blocks) + partial gate logits
             f32x16 acc[4];
 #pragma unroll
@@ -115,23 +122,26 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
             float g0 = 0.f, g1 = 0.f;
             {
-                constexpr int NST = NB * 4;
-                rn_f4 wr[3][4], gr[3][2];
-                const int kg0 = w * NB * 8 + h;
+                constexpr int NST = NB * 4, PF = 3, NSL = PF + 1;       // operands PF steps (PF x 16 MFMAs) ahead in a ring of NSL register sets
+                rn_f4 wr[NSL][4], gr[NSL][2];
+                unsigned vP = (unsigned)(((w * NB * 8 + h) * 128 + c) * 16), vG = (unsigned)((w * NB * 8 + h) * 32);
+                const float* __restrict__ P1f = reinterpret_cast<const float*>(P1);
+                const float* __restrict__ Kgf = p.Kg[l];
                 auto ld1 = [&](int s, int slot) {
-                    const int kg = kg0 + (s >> 2) * 8 + 2 * (s & 3);
+                    const int ks = (s >> 2) * 8 + 2 * (s & 3);                  // static part of kg
+                    TL_OPAQUE(vP); TL_OPAQUE(vG);
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) wr[slot][cb] = P1[kg * 128 + cb * 32 + c];
-                    gr[slot][0] = Kg4[kg * 2];
-                    gr[slot][1] = Kg4[kg * 2 + 1];
+                    for (int cb = 0; cb < 4; ++cb) wr[slot][cb] = tl_ld4(P1f, vP + (unsigned)(ks * 128 * 16 + cb * 512));
+                    gr[slot][0] = tl_ld4(Kgf, vG + (unsigned)(ks * 32));
+                    gr[slot][1] = tl_ld4(Kgf, vG + (unsigned)(ks * 32 + 16));
                 };
-                ld1(0, 0);
-                ld1(1, 1);
+#pragma unroll
+                for (int s = 0; s < PF; ++s) ld1(s, s);
 #pragma unroll
                 for (int s = 0; s < NST; ++s) {
-                    if (s + 2 < NST) ld1(s + 2, (s + 2) % 3);
+                    if (s + PF < NST) ld1(s + PF, (s + PF) % NSL);
                     TL_SB();
-                    const int b = s >> 2, q = s & 3, slot = s % 3;
+                    const int b = s >> 2, q = s & 3, slot = s % NSL;
                     const rn_f4 a = xa[b][q];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -388,12 +398,6 @@ int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st) {
 // rn_layer_end_reduce in a fixed order.
 #define TLB_LDS_FLOATS (4 * TL_ROWS * TL_LDP + 4 * TL_ROWS * 2 + 2 * TL_ROWS * TL_LDA + TL_ROWS * TL_LDG + 2 * TL_ROWS * 2)
 
-__device__ __forceinline__ rn_f4 tl_ld4(const float* base, unsigned off) {
-    return *reinterpret_cast<const rn_f4*>(reinterpret_cast<const char*>(base) + off);
-}
-__device__ __forceinline__ float tl_ld1(const float* base, unsigned off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); }
-__device__ __forceinline__ void tl_st4(float* base, unsigned off, rn_f4 v) { *reinterpret_cast<rn_f4*>(reinterpret_cast<char*>(base) + off) = v; }
-#define TL_OPAQUE(v) asm volatile("" : "+v"(v))
 
 template <int NB, bool TANH, bool DX>
 __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
@@ -456,8 +460,8 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
             float g0 = 0.f, g1 = 0.f;
             {
-                constexpr int NST = NB * 4;
-                rn_f4 wr[3][4], br[3][2], xr[3], orr[3], dr[3];
+                constexpr int NST = NB * 4, PF = 3, NSL = PF + 1;       // operands PF steps ahead in a ring of NSL register sets
+                rn_f4 wr[NSL][4], br[NSL][2], xr[NSL], orr[NSL], dr[NSL];
                 auto ld1 = [&](int s, int slot) {
                     const int ks = (s >> 2) * 8 + 2 * (s & 3);                  // static part of kg
                     const unsigned so = (unsigned)((32 * (s >> 2) + 8 * (s & 3)) * 4);
@@ -472,13 +476,13 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
                         dr[slot] = tl_ld4(dxt, vX + so);
                     }
                 };
-                ld1(0, 0);
-                ld1(1, 1);
+#pragma unroll
+                for (int s = 0; s < PF; ++s) ld1(s, s);
 #pragma unroll
                 for (int s = 0; s < NST; ++s) {
-                    if (s + 2 < NST) ld1(s + 2, (s + 2) % 3);
+                    if (s + PF < NST) ld1(s + PF, (s + PF) % NSL);
                     TL_SB();
-                    const int b = s >> 2, q = s & 3, slot = s % 3;
+                    const int b = s >> 2, q = s & 3, slot = s % NSL;
                     const rn_f4 gv = ga[b][q];
                     if (DX) {
                         const rn_f4 zero4 = {0.f, 0.f, 0.f, 0.f};

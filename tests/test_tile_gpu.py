@@ -17,11 +17,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _route(mode):
+def _route(mode, bwd='1'):
+    """mode '1': row-block forward (and, bwd '1', the opt-in row-block backward chain); '0': the launch-per-product route; None: defaults."""
     if mode is None:
         os.environ.pop('RECNOW_TILE', None)
+        os.environ.pop('RECNOW_TILE_BWD', None)
     else:
         os.environ['RECNOW_TILE'] = mode
+        os.environ['RECNOW_TILE_BWD'] = bwd
 
 
 def _run_fused(dev, cross, head, xd, gs):
@@ -45,6 +48,8 @@ def test_tile_forward_vs_oracle_and_product_route(dev, B, D, L, ai, ao):
     try:
         _route('1')
         tile = _run_fused(dev, cross, head, xd, gs)
+        _route('1', bwd='0')             # the default pairing at shard sizes: row-block forward, product-route backward
+        mixed = _run_fused(dev, cross, head, xd, gs)
         _route('0')
         prod = _run_fused(dev, cross, head, xd, gs)
     finally:
@@ -57,8 +62,13 @@ def test_tile_forward_vs_oracle_and_product_route(dev, B, D, L, ai, ao):
     close(tile['hk'], hk64.grad, what='head kernel')
     close(tile['hb'], hb64.grad, what='head bias', scale=np.abs(gs).sum())
     assert not torch.equal(tile['s'], prod['s'])          # two routes (another summation order), not one route twice
+    assert torch.equal(tile['s'], mixed['s']) and not torch.equal(tile['dx'], mixed['dx'])          # same forward, another backward
     for k in tile:
         close(tile[k], prod[k], rtol=4e-6, what=k + ' tile vs product route', scale=(np.abs(gs).sum() if k == 'hb' else None))
+        close(mixed[k], prod[k], rtol=4e-6, what=k + ' tile forward + product backward vs product route', scale=(np.abs(gs).sum() if k == 'hb' else None))
+    close(mixed['dx'], x64.grad, what='dx (tile forward, product backward)')
+    for k in w:
+        close(mixed[k], w64[k].grad, what=k + ' (tile forward, product backward)')
 
 
 def test_tile_forward_of_the_layer_without_head_and_without_input_gradient(dev):
