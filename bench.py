@@ -67,7 +67,9 @@ PEAK_HBM_GBS = 8000.0                 # same guide, "HBM3E peak BW" (spec; 6.29 
 PROF_EVERY = 5                        # time every 5th hooked launch (24 per step: every launch position gets sampled)
 GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>',
              5: 'k_gemm_shortk', 8: 'k_gemm_split',         # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
-             9: 'k_gemm<128,128,2,2,..,25> (GEMM1 + sub-space forward in its epilogue)'}
+             9: 'k_gemm<128,128,2,2,..,25> (GEMM1 + sub-space forward in its epilogue)',
+             10: 'k_mix_tile_fwd (row-block persistent forward of all cross layers, shard sizes)',
+             11: 'k_mix_tile_bwd (row-block persistent backward chain, opt-in)'}
 HBM_TAGS = {5: 'k_gemm_shortk', 6: 'k_mix_mid_fwd', 7: 'k_mix_mid_bwd'}
 CHECK_SCALE = 120.0                   # the parity step's inputs: x * 120 (std 6) -> scores of O(0.3), loss != ln 2
 PARITY_TOL = 1e-5                     # north_star: 1e-5 relative, GPU fp32 against the fp64 oracle (row subset + the full batch)
@@ -536,7 +538,7 @@ def main():
         prof_note = 'every %dth hooked launch of 10 EAGER steps run before the graphs were captured (the timed steps replay HIP graphs)' % PROF_EVERY
         cnt, ms, fl, by = hook_pre
     if prof and not hook_done:               # collected and switched off HERE: the samples are launches of the timed steps only
-        cnt = (ctypes.c_int * 16)()          # the library fills RN_TAG_MAX (= 11) entries
+        cnt = (ctypes.c_int * 16)()          # the library fills RN_TAG_MAX (= 12) entries
         ms = (ctypes.c_double * 16)()
         fl = (ctypes.c_double * 16)()
         by = (ctypes.c_double * 16)()

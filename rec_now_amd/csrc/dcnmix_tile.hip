@@ -460,43 +460,90 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
             float g0 = 0.f, g1 = 0.f;
             {
-                constexpr int NST = NB * 4, PF = 3, NSL = PF + 1;       // operands PF steps ahead in a ring of NSL register sets
-                rn_f4 wr[NSL][4], br[NSL][2], xr[NSL], orr[NSL], dr[NSL];
+                // The (B, D) streams of this loop -- x, O_l, the old dx in, the new dx out -- move BLOCK-wise as whole 128-byte row pieces (a wave
+                // instruction = 8 rows x 128 B = 8 lines; in the fragment layout it was 32 rows x 32 B = 32 line requests per instruction and
+                // the loop was bound by the address unit: 46 us per layer against 16 for the same loop without the streams) and change layout
+                // in a wave-private LDS tile: written as rows, read back as this lane's fragment pieces.  The tiles live in the wave's own
+                // partial-tile region, free until the loop's end; LDS operations of one wave complete in order, so no barrier is involved.
+                constexpr int NST = NB * 4, PF = 3, NSL = PF + 1;       // weights PF steps ahead in a ring of NSL register sets
+                constexpr int SLD = 36, STILE = TL_ROWS * SLD;         // staging tile: 32 rows x 32 columns, row stride 36 (conflict-free both ways)
+                static_assert(3 * STILE <= TL_ROWS * TL_LDP, "three staging tiles fit the wave's partial-tile region");
+                float* Sx = Ps + w * TL_ROWS * TL_LDP;
+                float* So = Sx + STILE;
+                float* Sd = So + STILE;
+                const int lC = (lane >> 3) * SLD + (lane & 7) * 4;      // row layout: lane = (row % 8, 16-byte piece), instruction j = rows 8 j ..
+                const int lA = c * SLD + 4 * h;                         // fragment layout: this lane's row, pieces 8 q + 4 h
+                unsigned vC = (unsigned)(((lane >> 3) * D + w * NB * 32 + (lane & 7) * 4) * 4);
+                rn_f4 wr[NSL][4], br[NSL][2];
+                rn_f4 px[4], po[4], pd[4];                              // block b + 1 on its way in (row layout)
                 auto ld1 = [&](int s, int slot) {
                     const int ks = (s >> 2) * 8 + 2 * (s & 3);                  // static part of kg
-                    const unsigned so = (unsigned)((32 * (s >> 2) + 8 * (s & 3)) * 4);
-                    TL_OPAQUE(vP); TL_OPAQUE(vB); TL_OPAQUE(vX);
+                    TL_OPAQUE(vP); TL_OPAQUE(vB);
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb) wr[slot][cb] = tl_ld4(P3, vP + (unsigned)(ks * 128 * 16 + cb * 512));
                     br[slot][0] = tl_ld4(bl, vB + (unsigned)(ks * 16));
                     br[slot][1] = tl_ld4(bl + D, vB + (unsigned)(ks * 16));
-                    xr[slot] = tl_ld4(xt, vX + so);
-                    if (DX) {       // no load under a run-time condition: the top layer reads the old dx too and drops it
-                        orr[slot] = tl_ld4(Ot, vX + so);
-                        dr[slot] = tl_ld4(dxt, vX + so);
+                };
+                auto ldblk = [&](int b) {
+                    TL_OPAQUE(vC);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned so = (unsigned)((8 * j * D + 32 * b) * 4);
+                        px[j] = tl_ld4(xt, vC + so);
+                        if (DX) {       // no load under a run-time condition: the top layer reads the old dx too and drops it
+                            po[j] = tl_ld4(Ot, vC + so);
+                            pd[j] = tl_ld4(dxt, vC + so);
+                        }
+                    }
+                };
+                ldblk(0);
+#pragma unroll
+                for (int s = 0; s < PF; ++s) ld1(s, s);
+                rn_f4 fx[2], fo[2], fd[2];                              // fragment pieces of step s (slot s & 1) and s + 1
+                auto rdfrag = [&](int q, int slot) {
+                    fx[slot] = *reinterpret_cast<const rn_f4*>(Sx + lA + 8 * q);
+                    if (DX) {
+                        fo[slot] = *reinterpret_cast<const rn_f4*>(So + lA + 8 * q);
+                        fd[slot] = *reinterpret_cast<const rn_f4*>(Sd + lA + 8 * q);
                     }
                 };
 #pragma unroll
-                for (int s = 0; s < PF; ++s) ld1(s, s);
-#pragma unroll
                 for (int s = 0; s < NST; ++s) {
-                    if (s + PF < NST) ld1(s + PF, (s + PF) % NSL);
-                    TL_SB();
                     const int b = s >> 2, q = s & 3, slot = s % NSL;
+                    if (q == 0) {           // block b: rows into the tiles, block b + 1 requested, the first two steps' pieces read back
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            *reinterpret_cast<rn_f4*>(Sx + lC + 8 * j * SLD) = px[j];
+                            if (DX) {
+                                *reinterpret_cast<rn_f4*>(So + lC + 8 * j * SLD) = po[j];
+                                *reinterpret_cast<rn_f4*>(Sd + lC + 8 * j * SLD) = pd[j];
+                            }
+                        }
+                        if (b + 1 < NB) ldblk(b + 1);
+                        rdfrag(0, s & 1);
+                    }
+                    if (s + PF < NST) ld1(s + PF, (s + PF) % NSL);
+                    if (q < 3) rdfrag(q + 1, (s + 1) & 1);
+                    TL_SB();
                     const rn_f4 gv = ga[b][q];
                     if (DX) {
                         const rn_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                        const rn_f4 dv = gv * orr[slot] + (keep_dx ? dr[slot] : zero4);      // a select: the dropped words may be anything
-                        TL_OPAQUE(vX);
-                        tl_st4(dxt, vX + (unsigned)((32 * b + 8 * q) * 4), dv);
+                        const rn_f4 dv = gv * fo[s & 1] + (keep_dx ? fd[s & 1] : zero4);      // a select: the dropped words may be anything
+                        *reinterpret_cast<rn_f4*>(Sd + lA + 8 * q) = dv;
                     }
-                    const rn_f4 a = gv * xr[slot];
+                    const rn_f4 a = gv * fx[s & 1];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int cb = 0; cb < 4; ++cb) acc[cb] = TL_MFMA(a[i], wr[slot][cb][i], acc[cb]);
                     g0 += (a.x * br[slot][0].x + a.y * br[slot][0].y) + (a.z * br[slot][0].z + a.w * br[slot][0].w);
                     g1 += (a.x * br[slot][1].x + a.y * br[slot][1].y) + (a.z * br[slot][1].z + a.w * br[slot][1].w);
+                    if (DX && q == 3) {     // the block's new dx: back to rows, out as whole 128-byte pieces
+                        TL_OPAQUE(vC);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            tl_st4(dxt, vC + (unsigned)((8 * j * D + 32 * b) * 4), *reinterpret_cast<const rn_f4*>(Sd + lC + 8 * j * SLD));
+                    }
                     TL_SB();
                 }
             }

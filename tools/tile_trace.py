@@ -19,8 +19,11 @@ from rec_now_amd.fused import dcn_mix_score  # noqa: E402
 from test_fused_gpu import _build  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+NODX = len(sys.argv) > 2 and sys.argv[2] == 'nodx'          # x as data: the backward chain without the O_l / dx streams
 dev = torch.device('cuda:0')
 x, xd, cross, head, w, hk, hb = _build(dev, B, 1024, 64, 2, 3, 1)
+if NODX:
+    xd = xd.detach()
 gs = torch.from_numpy(np.random.default_rng(1).normal(size=B).astype(np.float32)).to(dev)
 lib = _lib.load()
 lib.recnow_debug_tile_trace.restype = ctypes.c_int
