@@ -850,12 +850,11 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     const int D = m.D, S = m.S, N = m.N, L = m.L;
     if (l_hi < 0) l_hi = L - 1;
     if (l_lo < 0 || l_lo > l_hi || l_hi > L - 1) return RECNOW_EINVAL;
-    // The row-block backward chain is OPT-IN (RECNOW_TILE_BWD=1): measured (two boxes, 8192 rows per GPU) 0.744-0.748 ms per step against 0.728-0.734
-    // with the product-route backward behind the row-block forward -- its launch fills every CU by itself, so the K = B weight-gradient products
-    // that the product route runs BESIDE its chain come after it, and its dT2g loop is bound by the address unit (x, O_l and dx move as 32-byte
-    // pieces of 32 rows per instruction).  Parity-tested like the default (tests/test_tile_gpu.py).
+    // The row-block backward chain (RECNOW_TILE_BWD=0 keeps the product-route backward behind the row-block forward: A/B switch, read per call).
+    // Measured on one box, ms per step at 8192 / 16 384 rows per GPU: product route 0.760-0.765 / 1.138-1.143, row-block forward alone 0.723-0.726 /
+    // 1.135-1.154, forward and backward 0.699-0.708 / 1.128-1.129.
     const char* tb_env = getenv("RECNOW_TILE_BWD");
-    if (mix_tile_on(m) && tb_env && tb_env[0] == '1' && (l_hi < L - 1 || hd || dy))
+    if (mix_tile_on(m) && !(tb_env && tb_env[0] == '0') && (l_hi < L - 1 || hd || dy))
         return dcnmix_bwd_tile(m, x, U_host, V_host, W_host, bias_host, gate_host, dy, sv, act_inner, act_outer, dx, dU_host, dV_host, dW_host,
                                dbias_host, dgate_host, ws, ws_bytes, st, st2, hd, layer_events, l_hi, l_lo, T2g_ds_ready, ds_part, ds_nparts);
     const bool top = l_hi == L - 1;

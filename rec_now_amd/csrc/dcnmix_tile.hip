@@ -29,7 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TL_LDP 132          // row stride of a partial tile (float4 reads of phase B stay aligned)
 #define TL_LDA 129          // H1 tile: odd stride, the per-lane ds_read_b32 of the A fragments (lane = row) is conflict-free
 #define TL_LDG 132          // T2g / dA tile: 130 columns used; float4 rows (the tile leaves for memory as coalesced 16-byte pieces)
-#define TL_LDS_FLOATS (4 * TL_ROWS * TL_LDP + 4 * TL_ROWS * 2 + TL_ROWS * TL_LDA + TL_ROWS * 2 + 2 * TL_ROWS * TL_LDG + 4 * TL_ROWS)
+#define TL_LDS_FLOATS(D) (4 * TL_ROWS * TL_LDP + 4 * TL_ROWS * 2 + TL_ROWS * TL_LDA + TL_ROWS * 2 + 2 * TL_ROWS * TL_LDG + 4 * TL_ROWS + (D))
 
 bool rn_mix_tile_supported(int64_t B, int D, int S, int N, int L, int LDT) {
     return N == 2 && S == 64 && LDT == TL_LDT && (D == 256 || D == 512 || D == 1024) && B > 0 && B % TL_ROWS == 0 && L >= 1 && L <= RN_TILE_MAX_L;
@@ -99,9 +99,12 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
     float* G2 = Gs + TL_ROWS * 2;                     // [32][LDG]    T2g tile
     float* T2s = G2 + TL_ROWS * TL_LDG;               // [32][LDG]    T2 tile (H2), on its way to memory
     float* Sc = T2s + TL_ROWS * TL_LDG;               // [4][32]      score partials
+    float* Hv = Sc + 4 * TL_ROWS;                     // [D]          the scoring head's vector (zeros without a head)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
     const int act_inner = TANH ? RECNOW_ACT_TANH : p.act_inner, act_outer = TANH ? RECNOW_ACT_TANH : p.act_outer;
     const int64_t ntiles = p.B / TL_ROWS;
+    for (int i = tid; i < D; i += 256) Hv[i] = p.head_w ? p.head_w[i] : 0.f;
+    __syncthreads();
     TL_STAMP(0);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * TL_ROWS;
@@ -236,7 +239,9 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
                     const int row = tid >> 3, q = tid & 3;
                     rn_f4 g4 = {0.f, 0.f, 0.f, 0.f};
                     if (q == 0) { g4.x = Gs[row * 2]; g4.y = Gs[row * 2 + 1]; }
-                    float* dst = ((tid & 4) ? p.T2g[l] : p.T2[l]) + (r0 + row) * TL_LDT + TL_NS + 4 * q;
+                    float* const t2u = p.T2[l];            // uniform pointers first: a per-lane choice between two kernel-argument array
+                    float* const t2gu = p.T2g[l];          // elements became a VECTOR load of the pointer with a full vmcnt(0) behind it
+                    float* dst = ((tid & 4) ? t2gu : t2u) + (r0 + row) * TL_LDT + TL_NS + 4 * q;
                     *reinterpret_cast<rn_f4*>(dst) = g4;
                 }
                 if (tid < 2 * TL_ROWS) G2[(tid >> 1) * TL_LDG + TL_NS + (tid & 1)] = Gs[tid];
@@ -269,7 +274,9 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
                 const bool last = l == p.L - 1;
                 float* __restrict__ Og = p.O[l];
                 float* __restrict__ Xg = p.xn[l];
-                const float* __restrict__ hv = last ? p.head_w : nullptr;
+                const bool use_head = last && p.head_w != nullptr;
+                // the head vector is read from LDS: a global load under the `last layer` condition had a wait for EVERYTHING in flight behind it
+                const float* hvp = Hv + 4 * h + w * NB * 32;
                 const float* __restrict__ bl = p.bias[l] + h * D + w * NB * 32 + c;
                 float sp = 0.f;
                 constexpr int NST = (NB / 2) * 16;                      // steps: (pair of blocks, g); 8 MFMAs each
@@ -322,15 +329,12 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
                             const rn_f4 xv = x0[u][q] * ov;
                             xa[b][q] = xv;
                             if (Xg) *reinterpret_cast<rn_f4*>(Xg + xoff + 32 * b + 8 * q) = xv;
-                            if (hv) {
-                                const rn_f4 h4 = *reinterpret_cast<const rn_f4*>(hv + 4 * h + w * NB * 32 + 32 * b + 8 * q);
-                                const rn_f4 t = xv * h4;
-                                sp += (t.x + t.y) + (t.z + t.w);
-                            }
+                            const rn_f4 t = xv * *reinterpret_cast<const rn_f4*>(hvp + 32 * b + 8 * q);
+                            sp += (t.x + t.y) + (t.z + t.w);
                         }
                     }
                 }
-                if (hv) {                           // scoring head: join the two k-halves of a row, then the four waves in a fixed order
+                if (use_head) {                     // scoring head: join the two k-halves of a row, then the four waves in a fixed order
                     sp += __shfl_xor(sp, 32, 64);
                     if (h == 0) Sc[w * TL_ROWS + c] = sp;
                     __syncthreads();
@@ -345,7 +349,7 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
 
 template <int NB>
 static int tile_launch(const RnTileFwd& p, int grid, hipStream_t st) {
-    const size_t lds = (size_t)TL_LDS_FLOATS * sizeof(float);
+    const size_t lds = (size_t)TL_LDS_FLOATS(128 * NB) * sizeof(float);
     const bool tanh2 = p.act_inner == RECNOW_ACT_TANH && p.act_outer == RECNOW_ACT_TANH;
     static bool allowed[2] = {false, false};
     if (!allowed[tanh2 ? 1 : 0]) {
@@ -399,6 +403,15 @@ int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st) {
 #define TLB_LDS_FLOATS (4 * TL_ROWS * TL_LDP + 4 * TL_ROWS * 2 + 2 * TL_ROWS * TL_LDA + TL_ROWS * TL_LDG + 2 * TL_ROWS * 2)
 
 
+// The layer gradient ga (128 registers per lane) is kept in ACCUMULATION registers and copied out four at a time where a step needs it: left to
+// the allocator it stayed in the 256 architectural registers, and the rows of the next block -- in flight from memory -- were what got parked
+// in AGPRs, behind a full s_waitcnt vmcnt(0) right after their loads (one memory round trip per block of the dT2g loop).
+__device__ __forceinline__ float tl_a2v(float a) { float v; asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+__device__ __forceinline__ float tl_v2a(float v) { float a; asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+struct TlAcc4 { float x, y, z, w; };
+__device__ __forceinline__ TlAcc4 tl_park(rn_f4 v) { return TlAcc4{tl_v2a(v.x), tl_v2a(v.y), tl_v2a(v.z), tl_v2a(v.w)}; }
+__device__ __forceinline__ rn_f4 tl_fetch(const TlAcc4& a) { return rn_f4{tl_a2v(a.x), tl_a2v(a.y), tl_a2v(a.z), tl_a2v(a.w)}; }
+
 template <int NB, bool TANH, bool DX>
 __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
     constexpr int D = 128 * NB;
@@ -428,20 +441,40 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
         const int64_t r0 = tile * TL_ROWS;
         const bool first_tile = tile == (int64_t)blockIdx.x;
         const float* __restrict__ xt = p.x + r0 * D;
-        rn_f4 ga[NB][4];
+        TlAcc4 ga[NB][4];
         if (p.gin) {
             const float* __restrict__ gt = p.gin + r0 * D;
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; b += 2) {          // eight loads in flight, then parked (one at a time each load was a round trip)
+                rn_f4 t[2][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ga[b][q] = tl_ld4(gt, vX + (32 * b + 8 * q) * 4);
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t[u][q] = tl_ld4(gt, vX + (32 * (b + u) + 8 * q) * 4);
+                TL_SB();
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ga[b + u][q] = tl_park(t[u][q]);
+                TL_SB();
+            }
         } else {
             const float dsr = p.ds[r0 + c];
             const float* __restrict__ hvp = p.head_w + 4 * h + w * NB * 32;
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; b += 2) {
+                rn_f4 t[2][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ga[b][q] = *reinterpret_cast<const rn_f4*>(hvp + 32 * b + 8 * q) * dsr;
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t[u][q] = *reinterpret_cast<const rn_f4*>(hvp + 32 * (b + u) + 8 * q);
+                TL_SB();
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ga[b + u][q] = tl_park(t[u][q] * dsr);
+                TL_SB();
+            }
         }
         for (int l = p.l_hi; l >= p.l_lo; --l) {
             const float* __restrict__ PL = p.packs + (int64_t)l * TL_PACK_FLOATS(D);
@@ -465,7 +498,7 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
                 // the loop was bound by the address unit: 46 us per layer against 16 for the same loop without the streams) and change layout
                 // in a wave-private LDS tile: written as rows, read back as this lane's fragment pieces.  The tiles live in the wave's own
                 // partial-tile region, free until the loop's end; LDS operations of one wave complete in order, so no barrier is involved.
-                constexpr int NST = NB * 4, PF = 3, NSL = PF + 1;       // weights PF steps ahead in a ring of NSL register sets
+                constexpr int NST = NB * 4, PF = 2, NSL = PF + 1;       // weights PF steps ahead in a ring of NSL register sets (a third step ahead spills)
                 constexpr int SLD = 36, STILE = TL_ROWS * SLD;         // staging tile: 32 rows x 32 columns, row stride 36 (conflict-free both ways)
                 static_assert(3 * STILE <= TL_ROWS * TL_LDP, "three staging tiles fit the wave's partial-tile region");
                 float* Sx = Ps + w * TL_ROWS * TL_LDP;
@@ -525,7 +558,7 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
                     if (s + PF < NST) ld1(s + PF, (s + PF) % NSL);
                     if (q < 3) rdfrag(q + 1, (s + 1) & 1);
                     TL_SB();
-                    const rn_f4 gv = ga[b][q];
+                    const rn_f4 gv = tl_fetch(ga[b][q]);
                     if (DX) {
                         const rn_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
                         const rn_f4 dv = gv * fo[s & 1] + (keep_dx ? fd[s & 1] : zero4);      // a select: the dropped words may be anything
@@ -647,7 +680,10 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
                     float* __restrict__ dst = dvp + n * 4096 + (mb * 32 + 4 * h) * 64 + cb * 32 + c;
                     f32x16 av;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) av[r] = first_tile ? 0.f : dst[((r & 3) + 8 * (r >> 2)) * 64];
+                    for (int r = 0; r < 16; ++r) {       // the load is unconditional (workspace memory), the first block of a workgroup drops it
+                        const float old = dst[((r & 3) + 8 * (r >> 2)) * 64];
+                        av[r] = first_tile ? 0.f : old;
+                    }
                     const float* hp2 = Hs + h * TL_LDA + n * 64 + mb * 32 + c;
                     const float* cp2 = Cs + h * TL_LDA + n * 64 + cb * 32 + c;
 #pragma unroll
@@ -734,7 +770,7 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const rn_f4 gv = {o[u][4 * q], o[u][4 * q + 1], o[u][4 * q + 2], o[u][4 * q + 3]};
-                            ga[b][q] = gv;
+                            ga[b][q] = tl_park(gv);
                             TL_OPAQUE(vX);
                             const rn_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
                             tl_st4(gt, vX + (unsigned)((32 * b + 8 * q) * 4), DX ? gv + (add_dx ? dxo[u][q] : zero4) : gv);

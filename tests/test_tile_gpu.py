@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _route(mode, bwd='1'):
-    """mode '1': row-block forward (and, bwd '1', the opt-in row-block backward chain); '0': the launch-per-product route; None: defaults."""
+    """mode '1': row-block forward and (bwd '1') the row-block backward chain, bwd '0': the product-route backward behind it; mode '0': the
+    launch-per-product route; None: the defaults."""
     if mode is None:
         os.environ.pop('RECNOW_TILE', None)
         os.environ.pop('RECNOW_TILE_BWD', None)
@@ -48,7 +49,7 @@ def test_tile_forward_vs_oracle_and_product_route(dev, B, D, L, ai, ao):
     try:
         _route('1')
         tile = _run_fused(dev, cross, head, xd, gs)
-        _route('1', bwd='0')             # the default pairing at shard sizes: row-block forward, product-route backward
+        _route('1', bwd='0')             # the A/B pairing: row-block forward, product-route backward
         mixed = _run_fused(dev, cross, head, xd, gs)
         _route('0')
         prod = _run_fused(dev, cross, head, xd, gs)
