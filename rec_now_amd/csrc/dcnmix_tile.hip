@@ -109,6 +109,22 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * TL_ROWS;
         const int64_t xoff = (r0 + c) * D + 4 * h + w * NB * 32;        // this lane's row, first column of its quarter (+ 32 b + 8 q)
+        // Operand rings of the two product loops.  Their first steps are requested one phase EARLY -- GEMM1's at the end of the layer before
+        // (for the last layer: layer 0 again, what the workgroup's next block starts with), the output product's before the sub-space stage --
+        // so that no loop starts with a load latency (every one of them cost ~3 us).  No load sits under a condition.
+        constexpr int NST1 = NB * 4, PF1 = 3, NSL1 = PF1 + 1;       // GEMM1: operands PF1 steps (PF1 x 16 MFMAs) ahead in a ring of NSL1 register sets
+        rn_f4 wr1[NSL1][4], gr1[NSL1][2];
+        unsigned vP = (unsigned)(((w * NB * 8 + h) * 128 + c) * 16), vG = (unsigned)((w * NB * 8 + h) * 32);
+        auto ld1 = [&](const float* P1f, const float* Kgf, int s, int slot) {
+            const int ks = (s >> 2) * 8 + 2 * (s & 3);                  // static part of kg
+            TL_OPAQUE(vP); TL_OPAQUE(vG);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) wr1[slot][cb] = tl_ld4(P1f, vP + (unsigned)(ks * 128 * 16 + cb * 512));
+            gr1[slot][0] = tl_ld4(Kgf, vG + (unsigned)(ks * 32));
+            gr1[slot][1] = tl_ld4(Kgf, vG + (unsigned)(ks * 32 + 16));
+        };
+#pragma unroll
+        for (int s = 0; s < PF1; ++s) ld1(p.packs, p.Kg[0], s, s);
         rn_f4 xa[NB][4];
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -117,6 +133,7 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
         for (int l = 0; l < p.L; ++l) {
             const rn_f4* __restrict__ P1 = reinterpret_cast<const rn_f4*>(p.packs + (int64_t)l * TL_PACK_FLOATS(D));
             const rn_f4* __restrict__ P2 = P1 + D * 32;
+            const int ln = l + 1 < p.L ? l + 1 : 0;                     // the layer whose GEMM1 comes next in this workgroup
             // ---- GEMM1 over this wave's quarter of K: partial T1 (4 column blocks) + partial gate logits
             f32x16 acc[4];
 #pragma unroll
@@ -125,37 +142,36 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
             float g0 = 0.f, g1 = 0.f;
             {
-                constexpr int NST = NB * 4, PF = 3, NSL = PF + 1;       // operands PF steps (PF x 16 MFMAs) ahead in a ring of NSL register sets
-                rn_f4 wr[NSL][4], gr[NSL][2];
-                unsigned vP = (unsigned)(((w * NB * 8 + h) * 128 + c) * 16), vG = (unsigned)((w * NB * 8 + h) * 32);
                 const float* __restrict__ P1f = reinterpret_cast<const float*>(P1);
                 const float* __restrict__ Kgf = p.Kg[l];
-                auto ld1 = [&](int s, int slot) {
-                    const int ks = (s >> 2) * 8 + 2 * (s & 3);                  // static part of kg
-                    TL_OPAQUE(vP); TL_OPAQUE(vG);
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) wr[slot][cb] = tl_ld4(P1f, vP + (unsigned)(ks * 128 * 16 + cb * 512));
-                    gr[slot][0] = tl_ld4(Kgf, vG + (unsigned)(ks * 32));
-                    gr[slot][1] = tl_ld4(Kgf, vG + (unsigned)(ks * 32 + 16));
-                };
-#pragma unroll
-                for (int s = 0; s < PF; ++s) ld1(s, s);
-#pragma unroll
-                for (int s = 0; s < NST; ++s) {
-                    if (s + PF < NST) ld1(s + PF, (s + PF) % NSL);
+                for (int s = 0; s < NST1; ++s) {
+                    if (s + PF1 < NST1) ld1(P1f, Kgf, s + PF1, (s + PF1) % NSL1);
                     TL_SB();
-                    const int b = s >> 2, q = s & 3, slot = s % NSL;
+                    const int b = s >> 2, q = s & 3, slot = s % NSL1;
                     const rn_f4 a = xa[b][q];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int cb = 0; cb < 4; ++cb) acc[cb] = TL_MFMA(a[i], wr[slot][cb][i], acc[cb]);
-                    g0 += a.x * gr[slot][0].x + a.y * gr[slot][0].z + a.z * gr[slot][1].x + a.w * gr[slot][1].z;
-                    g1 += a.x * gr[slot][0].y + a.y * gr[slot][0].w + a.z * gr[slot][1].y + a.w * gr[slot][1].w;
+                        for (int cb = 0; cb < 4; ++cb) acc[cb] = TL_MFMA(a[i], wr1[slot][cb][i], acc[cb]);
+                    g0 += a.x * gr1[slot][0].x + a.y * gr1[slot][0].z + a.z * gr1[slot][1].x + a.w * gr1[slot][1].z;
+                    g1 += a.x * gr1[slot][0].y + a.y * gr1[slot][0].w + a.z * gr1[slot][1].y + a.w * gr1[slot][1].w;
                     TL_SB();
                 }
             }
             TL_STAMP(2 + 6 * l);
+            // the output product's ring: its first three steps are requested here, two barriers ahead of the loop
+            constexpr int NST2 = (NB / 2) * 16;                     // steps: (pair of blocks, g); 8 MFMAs each
+            rn_f4 wr2[8];                                           // ring of four step slots: 3 steps ahead, two loads per step
+            const int d0w = w * NB * 32 + c;
+            auto ld2 = [&](int s, int slot) {
+                const int pb = s >> 4, g = s & 15;
+                const int64_t row = (int64_t)(2 * g + h) * D;
+                wr2[slot] = P2[row + d0w + (2 * pb) * 32];
+                wr2[slot + 1] = P2[row + d0w + (2 * pb + 1) * 32];
+            };
+#pragma unroll
+            for (int s = 0; s < 3; ++s) ld2(s, 2 * s);
             // B fragments of the sub-space stage (this wave's output block (n, cb)): requested now, needed two barriers on
             const int en = w >> 1, ecb = w & 1;
             float vb[32];
@@ -279,17 +295,6 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
                 const float* hvp = Hv + 4 * h + w * NB * 32;
                 const float* __restrict__ bl = p.bias[l] + h * D + w * NB * 32 + c;
                 float sp = 0.f;
-                constexpr int NST = (NB / 2) * 16;                      // steps: (pair of blocks, g); 8 MFMAs each
-                rn_f4 wr[8];                                            // ring of four step slots: 3 steps ahead, two loads per step
-                const int d0w = w * NB * 32 + c;
-                auto ld2 = [&](int s, int slot) {
-                    const int pb = s >> 4, g = s & 15;
-                    const int64_t row = (int64_t)(2 * g + h) * D;
-                    wr[slot] = P2[row + d0w + (2 * pb) * 32];
-                    wr[slot + 1] = P2[row + d0w + (2 * pb + 1) * 32];
-                };
-#pragma unroll
-                for (int s = 0; s < 3; ++s) ld2(s, 2 * s);
 #pragma unroll
                 for (int pb = 0; pb < NB / 2; ++pb) {
                     rn_f4 x0[2][4];
@@ -308,13 +313,15 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_fwd(const RnTileFwd p) {
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int s = pb * 16 + g;
-                        if (s + 3 < NST) ld2(s + 3, (2 * (s + 3)) % 8);
+                        if (s + 3 < NST2) ld2(s + 3, (2 * (s + 3)) % 8);
+                        if (pb == NB / 2 - 1 && g >= 16 - PF1)          // the last steps: GEMM1 of the next layer (or of the next block) starts its ring
+                            ld1(p.packs + (int64_t)ln * TL_PACK_FLOATS(D), p.Kg[ln], g - (16 - PF1), g - (16 - PF1));
                         TL_SB();
                         const int slot = (2 * s) % 8;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            o[0] = TL_MFMA(wr[slot][i], tb[g][i], o[0]);
-                            o[1] = TL_MFMA(wr[slot + 1][i], tb[g][i], o[1]);
+                            o[0] = TL_MFMA(wr2[slot][i], tb[g][i], o[0]);
+                            o[1] = TL_MFMA(wr2[slot + 1][i], tb[g][i], o[1]);
                         }
                         TL_SB();
                     }
