@@ -769,6 +769,10 @@ static int dcnmix_bwd_tile(const MixDims& m, const float* x, const float* const*
     if (pg > 2048) pg = 2048;
     hipEvent_t e_red[RN_TILE_MAX_L + 2];
     for (int l = 0; l < RN_TILE_MAX_L + 2; ++l) e_red[l] = nullptr;
+    struct SlotGuard {      // the dW / dU products of a layer run as a concurrent pair: each aims at half the workgroup slots (gemm_dispatch.hpp)
+        explicit SlotGuard(bool on) { if (on) rn_gemm_split_slots(256); }
+        ~SlotGuard() { rn_gemm_split_slots(0); }
+    } slot_guard(two);
     for (int l = l_hi; l >= l_lo; --l) {
         const float* T2g = (const float*)(sv + (size_t)(3 * l + 2) * act_block(m));
         const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));

@@ -169,6 +169,10 @@ static inline bool split_planes_shape(const recnow_gemm_desc* d) {
     return d->sp_r > 0 && d->N == 128 && d->K <= 4096 && d->K % 16 == 0 && d->batch == 1 && !d->a_trans;
 }
 
+// workgroup slots the K split of the NEXT launches of this host thread aims at (0 = the default); see pick_split
+static thread_local int g_split_slots = 0;
+void rn_gemm_split_slots(int slots) { g_split_slots = slots; }
+
 size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return 0;
     const GemmCfg c = pick_cfg(d);
@@ -227,7 +231,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     if (d->sp_r < 0 || d->sp_r > 4 || d->eu_r < 0 || d->eu_r > 4 || (d->sp_r > 0 && d->eu_r > 0)) return RECNOW_EINVAL;
     if (d->sp_r > 0 && (!d->sp_bx || !d->sp_cx || d->batch != 1)) return RECNOW_EINVAL;
     if (d->eu_r > 0 && (!d->eu_p || !d->eu_q || d->batch != 1)) return RECNOW_EINVAL;
-    pick_split(d, c, &k.splitk, &k.kchunk);
+    pick_split(d, c, &k.splitk, &k.kchunk, g_split_slots > 0 ? g_split_slots : 512);
     k.perm_s = 0;
     if (d->c_perm_s > 0) {
         if (k.splitk <= 1) return RECNOW_EUNSUPPORTED;       // the permuted store lives in the split-K reduce

@@ -17,6 +17,8 @@ struct RnDeferredReduce {
     int valid;
 };
 int rn_gemm_deferred(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st, RnDeferredReduce* out);
+// K-split target of the following launches of this host thread: workgroup slots to fill (0 = default 512); products launched as concurrent pairs ask for 256
+void rn_gemm_split_slots(int slots);
 // the slabs of a deferred (valid) product: slab s, row m, column c at partial[s * stride + m * ld + c]; side columns behind the N main ones
 void rn_deferred_slabs(const RnDeferredReduce* r, const float** partial, int* nsplit, int* ld, int64_t* stride);
 int rn_layer_end_reduce(const RnDeferredReduce* a, const RnDeferredReduce* b, const float* dv_part, int dv_nparts, int dv_total, float* dV,
