@@ -563,7 +563,6 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
                         rdfrag(0, s & 1);
                     }
                     if (s + PF < NST) ld1(s + PF, (s + PF) % NSL);
-                    if (q < 3) rdfrag(q + 1, (s + 1) & 1);
                     TL_SB();
                     const rn_f4 gv = tl_fetch(ga[b][q]);
                     if (DX) {
@@ -578,6 +577,10 @@ __global__ void __launch_bounds__(256, 1) k_mix_tile_bwd(const RnTileBwd p) {
                         for (int cb = 0; cb < 4; ++cb) acc[cb] = TL_MFMA(a[i], wr[slot][cb][i], acc[cb]);
                     g0 += (a.x * br[slot][0].x + a.y * br[slot][0].y) + (a.z * br[slot][0].z + a.w * br[slot][0].w);
                     g1 += (a.x * br[slot][1].x + a.y * br[slot][1].y) + (a.z * br[slot][1].z + a.w * br[slot][1].w);
+                    // the next step's pieces are read BEHIND this step's MFMAs: LDS counts complete in order, so a read issued in front of them
+                    // stood between this step's own pieces and its products (a wait of one LDS latency per step, one wave per SIMD)
+                    TL_SB();
+                    if (q < 3) rdfrag(q + 1, (s + 1) & 1);
                     if (DX && q == 3) {     // the block's new dx: back to rows, out as whole 128-byte pieces
                         TL_OPAQUE(vC);
 #pragma unroll
