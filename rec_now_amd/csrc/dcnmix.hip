@@ -171,6 +171,12 @@ static bool mix_tile_on(const MixDims& m) {
     return mode == 1 || m.B <= MIX_TILE_MAX_B;
 }
 
+// RECNOW_TILE_BWD=0: the product-route backward behind the row-block forward (A/B switch, read per call)
+static bool mix_tile_bwd_on() {
+    const char* e = getenv("RECNOW_TILE_BWD");
+    return !(e && e[0] == '0');
+}
+
 // saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D);
 // exact path: then O_0..O_{L-1} (B x D)
 extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int L) {
@@ -489,10 +495,15 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     float* xmid = (float*)(sv + (size_t)L * 3 * act_block(m));
     float* omid = xmid + (size_t)(L - 1) * (xbuf(m) / sizeof(float));        // exact path only
     int rc;
-    if (pack_once && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st))) return rc;
+    const bool tile_fwd = mix_tile_on(m) && (y || head);
+    // the [U | K] / [W; b] / head packs feed the launch-per-product kernels only: with the row-block kernels in both directions nobody reads them
+    // (a product-route backward behind a row-block forward -- RECNOW_TILE_BWD=0 -- packs them itself: dcnmix_bwd_exact)
+    if (pack_once && !(tile_fwd && mix_tile_bwd_on()) &&
+        (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st)))
+        return rc;
     const float* xl = x;
     const bool xless = mix_xless(m);
-    if (mix_tile_on(m) && (y || head)) {       // every layer (+ the scoring head) in one launch of row-block workgroups
+    if (tile_fwd) {       // every layer (+ the scoring head) in one launch of row-block workgroups
         RnTileFwd t;
         memset(&t, 0, sizeof(t));
         t.x = x; t.B = B; t.D = D; t.L = L; t.act_inner = act_inner; t.act_outer = act_outer;
@@ -856,9 +867,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     if (l_lo < 0 || l_lo > l_hi || l_hi > L - 1) return RECNOW_EINVAL;
     // The row-block backward chain (RECNOW_TILE_BWD=0 keeps the product-route backward behind the row-block forward: A/B switch, read per call).
     // Measured on one box, ms per step at 8192 / 16 384 rows per GPU: product route 0.760-0.765 / 1.138-1.143, row-block forward alone 0.723-0.726 /
-    // 1.135-1.154, forward and backward 0.699-0.708 / 1.128-1.129.
-    const char* tb_env = getenv("RECNOW_TILE_BWD");
-    if (mix_tile_on(m) && !(tb_env && tb_env[0] == '0') && (l_hi < L - 1 || hd || dy))
+    // 1.135-1.154, forward and backward 0.699-0.708 / 1.128-1.129 (0.67-0.68 / 1.10 with the paired weight-gradient products at 256 slots).
+    if (mix_tile_on(m) && mix_tile_bwd_on() && (l_hi < L - 1 || hd || dy))
         return dcnmix_bwd_tile(m, x, U_host, V_host, W_host, bias_host, gate_host, dy, sv, act_inner, act_outer, dx, dU_host, dV_host, dW_host,
                                dbias_host, dgate_host, ws, ws_bytes, st, st2, hd, layer_events, l_hi, l_lo, T2g_ds_ready, ds_part, ds_nparts);
     const bool top = l_hi == L - 1;
@@ -893,6 +903,10 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     if (L <= MIX_PACK_MAX_L) {         // [U | K | 0] of every layer: packed ONCE per step by the forward, kept behind the activations in `saved`
         Wc1_all = (float*)(sv + mix_pack_off(m));
         Wh = Wc1_all + (size_t)2 * L * D * m.LDT;
+        if (top && mix_tile_on(m)) {   // ... unless the forward ran the row-block kernels and left them out (RECNOW_TILE_BWD=0 A/B pairing): packed here
+            float* Wc2_all = Wc1_all + (size_t)L * D * m.LDT;
+            if ((rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, hd ? hd->w : nullptr, const_cast<float*>(Wh), st))) return rc;
+        }
     } else if (top) {
         int pgw = rn_cdiv((int64_t)D * m.LDT, 256);
         if (pgw > 2048) pgw = 2048;
