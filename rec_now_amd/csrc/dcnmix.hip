@@ -164,10 +164,12 @@ static inline bool mix_tile_shape(const MixDims& m) {
 }
 static inline size_t mix_tile_pack_bytes(const MixDims& m) { return mix_tile_shape(m) ? rn_mix_tile_pack_bytes(m.D, m.S, m.N, m.L, m.LDT) : 0; }
 static inline size_t mix_tile_pack_off(const MixDims& m) { return mix_pack_off(m) + mix_pack_bytes(m); }
-static bool mix_tile_on(const MixDims& m) {
+// `maybe`: everything but the precision mode -- what a backward pass uses to decide whether the forward that filled `saved` MAY have run the
+// row-block kernels (and left the product-route weight packs out), whatever the precision switch says by now
+static bool mix_tile_on(const MixDims& m, bool maybe = false) {
     const char* e = getenv("RECNOW_TILE");            // read per call (tests switch the route inside one process)
     const int mode = e ? atoi(e) : -1;
-    if (mode == 0 || !mix_tile_shape(m) || rn_gemm_precision() != 0) return false;
+    if (mode == 0 || !mix_tile_shape(m) || (!maybe && rn_gemm_precision() != 0)) return false;
     return mode == 1 || m.B <= MIX_TILE_MAX_B;
 }
 
@@ -903,7 +905,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     if (L <= MIX_PACK_MAX_L) {         // [U | K | 0] of every layer: packed ONCE per step by the forward, kept behind the activations in `saved`
         Wc1_all = (float*)(sv + mix_pack_off(m));
         Wh = Wc1_all + (size_t)2 * L * D * m.LDT;
-        if (top && mix_tile_on(m)) {   // ... unless the forward ran the row-block kernels and left them out (RECNOW_TILE_BWD=0 A/B pairing): packed here
+        if (top && mix_tile_on(m, true)) {   // ... unless the forward ran the row-block kernels and left them out (RECNOW_TILE_BWD=0 A/B pairing, or the precision switched in between): packed here
             float* Wc2_all = Wc1_all + (size_t)L * D * m.LDT;
             if ((rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, hd ? hd->w : nullptr, const_cast<float*>(Wh), st))) return rc;
         }

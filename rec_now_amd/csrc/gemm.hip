@@ -176,9 +176,7 @@ void rn_gemm_split_slots(int slots) { g_split_slots = slots; }
 size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return 0;
     const GemmCfg c = pick_cfg(d);
-    int s, kc;
-    pick_split(d, c, &s, &kc);
-    size_t b = rnd_slab_bytes(d, s, 256);
+    size_t b = rnd_slab_bytes_any(d, c, 256);
     if (split_planes_shape(d)) b += rn_gemm_split_planes_bytes(d->K, d->N);      // whatever the precision mode is when the product runs
     return b;
 }

@@ -79,3 +79,13 @@ static inline size_t rnd_slab_bytes(const recnow_gemm_desc* d, int splitk, size_
     const size_t b = (size_t)splitk * d->batch * d->M * (d->N + (d->sp_r > 0 ? 4 : 0)) * sizeof(float);
     return (b + align - 1) / align * align;
 }
+// what a workspace query reserves: the larger of the two slot targets a launch may run with (fewer slots usually means fewer slices, but a product
+// that is not split for occupancy any more may still be split for accuracy: tools/san found M 1000, N 4096, K 32 768 with 4 slices against 2)
+static inline size_t rnd_slab_bytes_any(const recnow_gemm_desc* d, const GemmCfg& c, size_t align) {
+    int s = 1, kc = 0;
+    pick_split(d, c, &s, &kc, 512);
+    size_t b = rnd_slab_bytes(d, s, align);
+    pick_split(d, c, &s, &kc, 256);
+    const size_t b2 = rnd_slab_bytes(d, s, align);
+    return b2 > b ? b2 : b;
+}

@@ -11,7 +11,7 @@
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { printf("FAILED %s:%d: %s  (M %d N %d K %d batch %d sp_r %d)\n", __FILE__, __LINE__, #c, d.M, d.N, d.K, d.batch, d.sp_r); ++fails; } } while (0)
 
-static void one(int M, int N, int K, int batch, int sp_r, int c2_mode, const RnDispatchEnv& env, int* out_bm = nullptr, int* out_s = nullptr) {
+static void one(int M, int N, int K, int batch, int sp_r, int c2_mode, const RnDispatchEnv& env, int* out_bm = nullptr, int* out_s = nullptr, int slots = 512) {
     recnow_gemm_desc d;
     memset(&d, 0, sizeof(d));
     d.M = M; d.N = N; d.K = K; d.batch = batch; d.sp_r = sp_r; d.c2_mode = c2_mode;
@@ -20,8 +20,9 @@ static void one(int M, int N, int K, int batch, int sp_r, int c2_mode, const RnD
     CHECK(c.BN == 32 || c.BN == 64 || c.BN == 128 || c.BN == 160);
     if (c.BM == 64) CHECK(M % 64 == 0 && N == 128 && sp_r >= 1 && sp_r <= 2 && env.precision == 0 && batch == 1);
     int s = 0, kc = 0;
-    pick_split(&d, c, &s, &kc);
+    pick_split(&d, c, &s, &kc, slots);
     CHECK(s >= 1 && kc >= 32 && kc % 32 == 0);
+    CHECK(rnd_slab_bytes(&d, s, 256) <= rnd_slab_bytes_any(&d, c, 256));      // what the workspace query reserves holds either slot target
     CHECK((long long)(s - 1) * kc < K);                    // the last slice starts inside K
     CHECK((long long)s * kc >= K);                         // the slices cover K
     if (c2_mode) CHECK(s == 1);                            // fused second outputs need the whole K in one workgroup
@@ -47,6 +48,7 @@ int main(void) {
                             for (int c2 : {0, 1}) {
                                 if (sp_r && batch != 1) continue;
                                 one(M, N, K, batch, sp_r, c2, env);
+                                one(M, N, K, batch, sp_r, c2, env, nullptr, nullptr, 256);      // products launched as concurrent pairs (dcnmix_bwd_tile)
                             }
     // the hot-path products, as DESIGN.md 5g / 5h state them (default switches)
     const RnDispatchEnv def = {256, -1, 0};
@@ -57,6 +59,7 @@ int main(void) {
     one(1024, 128, 65536, 1, 2, 0, def, &bm, &s); d.M = 1024; d.K = 65536; CHECK(bm == 128 && s == 64);                                        // dU / dW: 8 tiles x 64 slabs
     one(8192, 128, 1024, 1, 2, 0, def, &bm, &s); d.M = 8192; d.K = 1024; CHECK(bm == 64 && s == 4);                                            // the 8-GPU shard: 128 tiles x 4
     one(1024, 128, 8192, 1, 2, 0, def, &bm, &s); d.M = 1024; d.K = 8192; CHECK(bm == 64 && s == 32);
+    one(1024, 128, 8192, 1, 2, 0, def, &bm, &s, 256); CHECK(bm == 64 && s == 16);                                                              // ... as one of a concurrent pair: 16 tiles x 16 slices
     one(16384, 128, 1024, 1, 2, 0, def, &bm, &s); d.M = 16384; d.K = 1024; CHECK(bm == 64 && s == 2);
     one(32768, 128, 1024, 1, 2, 0, def, &bm, &s); d.M = 32768; CHECK(bm == 64 && s == 1);
     one(32768, 4096, 512, 1, 0, 0, def, &bm, &s); d.M = 32768; d.N = 4096; d.K = 512; d.sp_r = 0; CHECK(bm == 128 && s == 1);                  // PLE expert layer
