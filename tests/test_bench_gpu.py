@@ -12,9 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _clean_env():
+    """The environment of a bench.py child WITHOUT the launcher variables another test of this pytest process may have exported (the
+    one-rank RCCL fixture of test_step_gpu.py sets WORLD_SIZE / RANK / MASTER_*): with them bench.py would believe a launcher started it."""
+    return {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE', 'GROUP_RANK')}
+
+
 def _bench(*flags):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline'] + list(flags),
-                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=_clean_env())
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
 
@@ -38,7 +44,7 @@ def test_self_launch_one_rank_force_dist_is_self_verifying(dev):
     with one rank over a real RCCL group: the line carries `rccl_ranks`, and the cross-rank gate -- the reduced loss and pair count against
     oracle/pairs_oracle.c on the all-gathered batch, every all-reduced weight gradient against the sum of the per-rank fp64 oracles -- holds."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--launch', '--rows', '8192',
-                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=600, cwd=ROOT, env=_clean_env())
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line['rccl_ranks'] == 1 and line['n_gpus'] == 1
@@ -52,7 +58,7 @@ def test_self_launch_one_rank_force_dist_is_self_verifying(dev):
 def test_more_ranks_than_gpus_fails_cleanly(dev):
     import torch
     n = torch.cuda.device_count() + 1
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n)], capture_output=True, text=True, timeout=120, cwd=ROOT, env=_clean_env())
     assert out.returncode != 0
     assert 'only %d GPU(s) visible' % (n - 1) in out.stderr
 
@@ -63,7 +69,7 @@ def test_two_ranks_share_one_gpu_over_gloo_and_verify_across_ranks(dev):
     reducer's buckets, every bucket is all-reduced across the two processes, and the cross-rank gate holds the reduced loss / pair count to the C pair
     oracle on the ALL-GATHERED batch and all 17 all-reduced weight gradients to the sum of the two ranks' fp64 oracles."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--oversubscribe', '--rows', '4096',
-                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=_clean_env())
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['backend'] == 'gloo'
