@@ -46,25 +46,36 @@ size_t rn_mix_tile_pack_bytes(int D, int S, int N, int L, int LDT) {
 // P4_l[g][h][d][i] = U_l[n][d][s],  n S + s = 8 g + 4 h + i                 (16 x 2 x D float4)       backward g_l product, A fragments
 // VT_l[n][t][s]    = V_l[n][s][t]                                                                      backward dA product, B fragments
 __global__ void __launch_bounds__(256) k_tile_pack(const RnTileFwd p) {
+    // one thread per 16-byte output piece: the four i of a piece are four rows (P1, P2) or four consecutive elements (P3, P4) of the source
     const int D = p.D, L = p.L;
-    const int64_t per = (int64_t)D * TL_NS, lay = TL_PACK_FLOATS(D), total = (int64_t)L * lay;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int l = (int)(e / lay);
-        const int64_t j = e - (int64_t)l * lay;
-        const int which = (int)(j / per);
-        const int64_t k = j - (int64_t)which * per;
-        float v;
-        if (which == 0 || which == 2) {
-            const int i = (int)(k & 3), col = (int)((k >> 2) & 127), kg = (int)(k >> 9);
-            v = which == 0 ? p.U[l][((int64_t)(col >> 6) * D + (4 * kg + i)) * 64 + (col & 63)] : p.W[l][(int64_t)col * D + 4 * kg + i];
-        } else if (which == 1 || which == 3) {
-            const int i = (int)(k & 3), d = (int)((k >> 2) % D), t = 4 * (int)((k >> 2) / D) + i;      // t = 8 g + 4 h + i = 4 (2 g + h) + i
-            v = which == 1 ? p.W[l][(int64_t)t * D + d] : p.U[l][((int64_t)(t >> 6) * D + d) * 64 + (t & 63)];
-        } else {
-            const int sx = (int)(k & 63), t = (int)((k >> 6) & 63), n = (int)(k >> 12);
-            v = p.V[l][(n * 64 + sx) * 64 + t];
+    const int64_t per4 = (int64_t)D * TL_NS / 4, lay4 = TL_PACK_FLOATS(D) / 4, total4 = (int64_t)L * lay4;
+    rn_f4* __restrict__ out = reinterpret_cast<rn_f4*>(p.packs);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+        const int l = (int)(e / lay4);
+        const int64_t j = e - (int64_t)l * lay4;
+        const int which = (int)(j / per4);
+        const int64_t k = j - (int64_t)which * per4;
+        rn_f4 v;
+        if (which == 0) {               // P1[kg][col]: U[n][4 kg + i][s]
+            const int col = (int)(k & 127), kg = (int)(k >> 7);
+            const float* src = p.U[l] + ((int64_t)(col >> 6) * D + 4 * kg) * 64 + (col & 63);
+            v = rn_f4{src[0], src[64], src[128], src[192]};
+        } else if (which == 2) {        // P3[kg][t]: W[t][4 kg .. 4 kg + 3]
+            const int t = (int)(k & 127), kg = (int)(k >> 7);
+            v = *reinterpret_cast<const rn_f4*>(p.W[l] + (int64_t)t * D + 4 * kg);
+        } else if (which == 1) {        // P2[g][h][d]: W[4 (2 g + h) + i][d]
+            const int d = (int)(k % D), t0 = 4 * (int)(k / D);
+            const float* src = p.W[l] + (int64_t)t0 * D + d;
+            v = rn_f4{src[0], src[D], src[2 * D], src[3 * D]};
+        } else if (which == 3) {        // P4[g][h][d]: U[n][d][s .. s + 3],  n S + s = 4 (2 g + h)
+            const int d = (int)(k % D), t0 = 4 * (int)(k / D);
+            v = *reinterpret_cast<const rn_f4*>(p.U[l] + ((int64_t)(t0 >> 6) * D + d) * 64 + (t0 & 63));
+        } else {                        // VT[n][t][s .. s + 3] = V[n][s + i][t]
+            const int s4 = (int)(k & 15) * 4, t = (int)((k >> 4) & 63), n = (int)(k >> 10);
+            const float* src = p.V[l] + (n * 64 + s4) * 64 + t;
+            v = rn_f4{src[0], src[64], src[128], src[192]};
         }
-        p.packs[e] = v;
+        out[e] = v;
     }
 }
 
