@@ -173,10 +173,12 @@ static bool mix_tile_on(const MixDims& m, bool maybe = false) {
     return mode == 1 || m.B <= MIX_TILE_MAX_B;
 }
 
-// RECNOW_TILE_BWD=0: the product-route backward behind the row-block forward (A/B switch, read per call)
-static bool mix_tile_bwd_on() {
+// The row-block backward chain walks all its layers in one launch and leaves g_l of EVERY layer for the weight-gradient products behind it: the two
+// ping-pong gradient buffers of the workspace hold g_1 and g_2, i.e. at most three layers (deeper stacks take the product-route backward, which
+// consumes g_l layer by layer).  RECNOW_TILE_BWD=0: the product-route backward behind the row-block forward (A/B switch, read per call).
+static bool mix_tile_bwd_on(const MixDims& m) {
     const char* e = getenv("RECNOW_TILE_BWD");
-    return !(e && e[0] == '0');
+    return m.L <= 3 && !(e && e[0] == '0');
 }
 
 // saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D);
@@ -500,7 +502,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     const bool tile_fwd = mix_tile_on(m) && (y || head);
     // the [U | K] / [W; b] / head packs feed the launch-per-product kernels only: with the row-block kernels in both directions nobody reads them
     // (a product-route backward behind a row-block forward -- RECNOW_TILE_BWD=0 -- packs them itself: dcnmix_bwd_exact)
-    if (pack_once && !(tile_fwd && mix_tile_bwd_on()) &&
+    if (pack_once && !(tile_fwd && mix_tile_bwd_on(m)) &&
         (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st)))
         return rc;
     const float* xl = x;
@@ -870,7 +872,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     // The row-block backward chain (RECNOW_TILE_BWD=0 keeps the product-route backward behind the row-block forward: A/B switch, read per call).
     // Measured on one box, ms per step at 8192 / 16 384 rows per GPU: product route 0.760-0.765 / 1.138-1.143, row-block forward alone 0.723-0.726 /
     // 1.135-1.154, forward and backward 0.699-0.708 / 1.128-1.129 (0.67-0.68 / 1.10 with the paired weight-gradient products at 256 slots).
-    if (mix_tile_on(m) && mix_tile_bwd_on() && (l_hi < L - 1 || hd || dy))
+    if (mix_tile_on(m) && mix_tile_bwd_on(m) && (l_hi < L - 1 || hd || dy))
         return dcnmix_bwd_tile(m, x, U_host, V_host, W_host, bias_host, gate_host, dy, sv, act_inner, act_outer, dx, dU_host, dV_host, dW_host,
                                dbias_host, dgate_host, ws, ws_bytes, st, st2, hd, layer_events, l_hi, l_lo, T2g_ds_ready, ds_part, ds_nparts);
     const bool top = l_hi == L - 1;

@@ -42,7 +42,8 @@ def _run_fused(dev, cross, head, xd, gs):
 
 # 8448 rows = 264 row blocks on 256 workgroups: eight workgroups walk a second block
 @pytest.mark.parametrize('B,D,L,ai,ao', [(512, 256, 2, 'tanh', 'tanh'), (1024, 512, 3, 'tanh', 'tanh'), (2048, 1024, 3, 'tanh', 'tanh'),
-                                          (8448, 1024, 3, 'tanh', 'tanh'), (768, 1024, 1, 'relu', 'sigmoid'), (1280, 512, 2, None, 'tanh')])
+                                          (8448, 1024, 3, 'tanh', 'tanh'), (768, 1024, 1, 'relu', 'sigmoid'), (1280, 512, 2, None, 'tanh'),
+                                          (512, 256, 4, 'tanh', 'tanh')])      # four layers: row-block forward, product-route backward (two g buffers)
 def test_tile_forward_vs_oracle_and_product_route(dev, B, D, L, ai, ao):
     x, xd, cross, head, w, hk, hb = _build(dev, B, D, 64, 2, L, B + D + L, ai, ao)
     gs = np.random.default_rng(1).normal(size=B).astype(np.float32)
@@ -63,7 +64,8 @@ def test_tile_forward_vs_oracle_and_product_route(dev, B, D, L, ai, ao):
     close(tile['hk'], hk64.grad, what='head kernel')
     close(tile['hb'], hb64.grad, what='head bias', scale=np.abs(gs).sum())
     assert not torch.equal(tile['s'], prod['s'])          # two routes (another summation order), not one route twice
-    assert torch.equal(tile['s'], mixed['s']) and not torch.equal(tile['dx'], mixed['dx'])          # same forward, another backward
+    assert torch.equal(tile['s'], mixed['s'])          # same forward ...
+    assert torch.equal(tile['dx'], mixed['dx']) == (L > 3)          # ... another backward (up to three layers: deeper stacks take the product route anyway)
     for k in tile:
         close(tile[k], prod[k], rtol=4e-6, what=k + ' tile vs product route', scale=(np.abs(gs).sum() if k == 'hb' else None))
         close(mixed[k], prod[k], rtol=4e-6, what=k + ' tile forward + product backward vs product route', scale=(np.abs(gs).sum() if k == 'hb' else None))
