@@ -1,5 +1,6 @@
-// Row-block persistent forward of DCNMixLayer (+ the folded scoring head) for SMALL batches: the per-rank shards of the metric's
-// 2/4/8-GPU rows (8192 .. 32 768 rows).  /root/reference/rec_now/layers/dcn_mix_layer.py:123-150, every layer, in ONE launch.
+// Row-block persistent forward and backward of DCNMixLayer (+ the folded scoring head) for SMALL batches: the per-rank shards of the metric's
+// 4- and 8-GPU rows (batches up to 16 384 rows; dcnmix.hip `mix_tile_on`).  /root/reference/rec_now/layers/dcn_mix_layer.py:123-150 and its
+// backward, every layer, in ONE launch per direction.  Design notes, measurements and what the stamps / the ISA showed: DESIGN.md 5i.
 //
 // Why: at 8192 rows the launch-per-product forward is 9 launches (GEMM1, sub-space stage, output product per layer) that are each ONE
 // round of workgroups -- prologue + a few k-tiles + epilogue, 27 / 15 / 28 us for 2.2 GFLOP (16 us at the rate the chip sustains) -- and
@@ -17,7 +18,10 @@
 //     multiplied by x (loaded in the same layout).  O_l (and x_{l+1} when asked for) leave as 16-byte pieces per lane.
 //   * the scoring head of the last layer is a row dot in that layout (no y tensor).
 // MFMA work per block and layer: 512 + 32 + 520 instructions per wave = 33 us at 2.1 GHz; the weights stream from L2 (every workgroup
-// reads the same 1 MB per layer).  Exact fp32 like the GEMM kernels; other summation order (K in four quarters).
+// reads the same 1 MB per layer): operands three steps (48 MFMAs) ahead in register rings, addressed as uniform base + opaque per-lane offset.
+// Exact fp32 like the GEMM kernels; other summation order (K in four quarters).  One wave per SIMD and 512 registers per lane: nothing runs
+// beside these launches.  Rules this file follows because their absence was measured: no load under a run-time condition,
+// no per-lane choice between kernel-argument array elements, tiles leave for memory through LDS as coalesced 16-byte pieces.
 #include "dcnmix_tile.hpp"
 #include "prof.hpp"
 
@@ -410,8 +414,8 @@ int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st) {
 
 // ---- backward: the data-gradient chain of layers l_hi .. l_lo for a block of 32 rows, one launch -----------------------------------
 // Mirror of the forward.  The gradient g_{l+1} w.r.t. the layer's output sits in the A-fragment layout (ga, as xa above):
-//   * dT2g = (g_{l+1} * x) [W; b]^T: every wave contracts its quarter of D (x streams through the operand ring, and so do O_l and the old dx:
-//     dx (+)= g_{l+1} * O_l leaves from the same loop); partial tiles meet in LDS;
+//   * dT2g = (g_{l+1} * x) [W; b]^T: every wave contracts its quarter of D; x, O_l and the old dx come in block-wise as whole row pieces through
+//     wave-private LDS tiles, and dx (+)= g_{l+1} * O_l leaves the same way from the same loop; partial tiles meet in LDS;
 //   * sub-space backward on the summed tile (k_mix_mid_bwd_fast's arithmetic: dC, <dT2g_n, H2_n>, gate, dA = (dC V^T) act'(H1), dV += H1^T dC);
 //     dT1 = [dA | dlogits | 0] goes to memory (the weight-gradient product dU reads it) and stays in LDS for
 //   * g_l^T = [U | K] dT1^T, transposed like the forward's output product: the accumulators ARE the next layer's ga; g_l is stored for the
