@@ -18,6 +18,7 @@ bucket's all-reduce is launched as soon as its piece has been enqueued (the coll
 ordinary stream work between the graph launches).
 """
 import ctypes
+import os
 
 import torch
 
@@ -108,6 +109,10 @@ class DCNMixPairwiseStep(object):
         self._layer_events = None
         if reducer is not None:
             self._layer_events = (ctypes.c_void_p * L)(*[reducer.events[L - 1 - l].handle for l in range(L)])
+        # the library's own rule for the row-block kernels (csrc/dcnmix.hip `mix_tile_on`): two experts of 64, D = 256 / 512 / 1024, <= 16 384 rows
+        tile_env = os.environ.get('RECNOW_TILE')
+        self._tile_route = (N == 2 and S == 64 and D in (256, 512, 1024) and tile_env != '0' and (B <= 16384 or tile_env == '1')
+                            and lib.recnow_get_gemm_precision() == 0)
         self._bind_grads()                     # p.grad = the step's gradient storage, written in place by every step
 
     @staticmethod
@@ -133,17 +138,29 @@ class DCNMixPairwiseStep(object):
         replay: launches its graph).  Returns after everything is enqueued."""
         self._bind_grads()
         main = torch.cuda.current_stream()
-        # grouping (sort by group id, segments) does not depend on the scores: on a side stream, under the forward pass
-        _lib.call('recnow_event_record', self._fork.handle, _lib._P(main.cuda_stream))
-        self._fork.wait(self.side)
-        torch.cuda.set_stream(self.side)           # (the `with torch.cuda.stream(..)` form costs ~40 us of host time)
-        try:
+        # Where the grouping of the batch runs (A/B switch RECNOW_STEP_GROUP = side | inline | after).  Under the launch-per-product forward it
+        # hides on a side stream.  The row-block forward (csrc/dcnmix_tile.hip, batches <= 16 384 rows) holds every CU by itself: the
+        # grouping's one workgroup only gets a CU when that launch drains, and the fork / join events are pure cost -- measured 0.676-0.687
+        # (side) vs 0.667-0.672 ms (inline) per step at 8192 rows, 1.105 vs 1.087-1.091 ms at 16 384.
+        mode = os.environ.get('RECNOW_STEP_GROUP') or ('inline' if self._tile_route else 'side')
+        if mode == 'side':
+            # grouping (sort by group id, segments) does not depend on the scores: on a side stream, under the forward pass
+            _lib.call('recnow_event_record', self._fork.handle, _lib._P(main.cuda_stream))
+            self._fork.wait(self.side)
+            torch.cuda.set_stream(self.side)           # (the `with torch.cuda.stream(..)` form costs ~40 us of host time)
+            try:
+                launch('group', lambda: self._call(_GROUP))
+            finally:
+                torch.cuda.set_stream(main)
+            _lib.call('recnow_event_record', self._grouped.handle, _lib._P(self.side.cuda_stream))
+            launch('forward', lambda: self._call(_FORWARD))
+            self._grouped.wait(main)
+        elif mode == 'inline':
             launch('group', lambda: self._call(_GROUP))
-        finally:
-            torch.cuda.set_stream(main)
-        _lib.call('recnow_event_record', self._grouped.handle, _lib._P(self.side.cuda_stream))
-        launch('forward', lambda: self._call(_FORWARD))
-        self._grouped.wait(main)
+            launch('forward', lambda: self._call(_FORWARD))
+        else:
+            launch('forward', lambda: self._call(_FORWARD))
+            launch('group', lambda: self._call(_GROUP))
         if whole_backward:
             # eager under a reducer: ONE call walks all layers (the weight-gradient products of a layer run on the second stream beside
             # the chain of the layers below) and records the stages' events itself where each stage's last gradient is issued
