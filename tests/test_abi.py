@@ -59,3 +59,31 @@ def test_every_module_of_the_package_imports():
     assert len(names) > 15
     for n in names:
         importlib.import_module(n)
+
+
+def test_size_queries_cover_the_row_block_route():
+    """Host-only size queries (no device call): for the shapes the row-block persistent kernels take (csrc/dcnmix_tile.hip: two experts of 64,
+    D = 256 / 512 / 1024, whole 32-row blocks) `saved` holds their fragment-ordered weight packs -- P1 .. P4 of D x 128 floats and V^T per layer --
+    and the workspace one dT1 block per layer plus one dV partial per layer and workgroup; other shapes do not pay for them."""
+    from rec_now_amd import _lib
+    lib = _lib.load()
+    B, D, S, N, L = 8192, 1024, 64, 2, 3
+    ldt = 144
+    act = B * ldt * 4
+    packs = L * (4 * D * 128 + 2 * 64 * 64) * 4
+    # three experts of 64: no row-block kernels, no extra buffers; the same sizes otherwise (N S + N = 195 -> another leading dimension, so compare
+    # each shape with its own lower bound instead)
+    sv = lib.recnow_dcn_mix_saved_bytes(B, D, S, N, L)
+    ws = lib.recnow_dcn_mix_workspace_bytes(B, D, S, N, L)
+    base_saved = L * 3 * act + (L - 1) * B * D * 4 + L * B * D * 4 + (2 * L + 1) * D * ldt * 4
+    assert sv >= base_saved + packs
+    assert sv < base_saved + packs + (1 << 20)                      # alignment slack only
+    assert ws >= L * act + L * 256 * N * S * S * 4 + 3 * act + 2 * B * D * 4
+    # a width without an instantiation (D = 1152: exact-128 path, leading dimension 144) and a batch off the exact path (B % 256 != 0: leading
+    # dimension 160, no O_l, no packs at all): what the formulation itself keeps plus alignment slack -- the packs (7 MB / 6 MB) are not in there
+    d2 = 1152
+    base2 = L * 3 * act + (2 * L - 1) * B * d2 * 4 + (2 * L + 1) * d2 * ldt * 4
+    assert base2 <= lib.recnow_dcn_mix_saved_bytes(B, d2, S, N, L) < base2 + (1 << 20)
+    b3 = 8200
+    base3 = L * 3 * b3 * 160 * 4 + (L - 1) * b3 * D * 4
+    assert base3 <= lib.recnow_dcn_mix_saved_bytes(b3, D, S, N, L) < base3 + (1 << 20)
