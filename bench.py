@@ -69,8 +69,12 @@ GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,
              5: 'k_gemm_shortk', 8: 'k_gemm_split',         # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
              9: 'k_gemm<128,128,2,2,..,25> (GEMM1 + sub-space forward in its epilogue)',
              10: 'k_mix_tile_fwd (row-block persistent forward of all cross layers, shard sizes)',
-             11: 'k_mix_tile_bwd (row-block persistent backward chain, opt-in)'}
+             11: 'k_mix_tile_bwd (row-block persistent backward chain of all cross layers, shard sizes)',
+             12: 'k_gemm<64,128,1,4> (small-M dispatch of the long-K products, shard sizes)'}
 HBM_TAGS = {5: 'k_gemm_shortk', 6: 'k_mix_mid_fwd', 7: 'k_mix_mid_bwd'}
+# tags that only the every-launch mode records (csrc/prof.hpp): with them the hooked intervals cover the whole step
+PHASE_TAGS = {6: 'k_mix_mid_fwd', 7: 'k_mix_mid_bwd', 13: 'grouping of the batch (keys, radix sort, segments)',
+              14: 'loss stage (pair walks, finalize, d loss / d scores)', 15: 'weight packs + layer-end reductions + head post-processing'}
 CHECK_SCALE = 120.0                   # the parity step's inputs: x * 120 (std 6) -> scores of O(0.3), loss != ln 2
 PARITY_TOL = 1e-5                     # north_star: 1e-5 relative, GPU fp32 against the fp64 oracle (row subset + the full batch)
 
@@ -234,6 +238,58 @@ def subset_parity(x, groups, labels, named, scores_gpu, dx_gpu, n_pair_gpu, n_gr
             'scores': rel_err(scores_gpu[rows], s64.detach().numpy()), 'dx': rel_err(dx_gpu[rows], x64.grad.numpy())}
 
 
+def step_account(lib, run_step, sync, steps=10):
+    """Where a step's time goes when launches of two streams overlap: `steps` extra UNTIMED steps with EVERY hooked launch and phase
+    recorded (recnow_prof_sample_every(1) + recnow_prof_intervals), then a sweep over the intervals in which every instant is divided
+    equally among the launches running at it -- a kernel family's EXCLUSIVE (shared) time per step.  Under one stream this is its plain
+    kernel time; under the second stream of the backward pass two co-running products get half of their common time each instead of
+    both being charged all of it.  Returns {'per_step_ms': {name: ms}, 'covered_ms_per_step': .., 'launches_per_step': {name: n}}."""
+    cap = 96 * steps
+    if lib.recnow_prof_enable(cap) != 0 or lib.recnow_prof_sample_every(1) != 0:
+        return None
+    sync()
+    for _ in range(steps):
+        run_step()
+    sync()
+    tags, t0, t1 = (ctypes.c_int * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+    n = lib.recnow_prof_intervals(tags, t0, t1, cap)
+    lib.recnow_prof_enable(0)
+    if n <= 0:
+        return None
+    names = dict(GEMM_TAGS)
+    names.update(PHASE_TAGS)
+    ev = []
+    for i in range(n):
+        if t1[i] > t0[i]:
+            ev.append((t0[i], 1, i))
+            ev.append((t1[i], 0, i))
+    ev.sort(key=lambda e: (e[0], e[1]))          # ends before starts at equal times
+    share = [0.0] * n
+    active = set()
+    last = None
+    covered = 0.0
+    for t, start, i in ev:
+        if active and last is not None and t > last:
+            dt = t - last
+            covered += dt
+            for j in active:
+                share[j] += dt / len(active)
+        last = t
+        if start:
+            active.add(i)
+        else:
+            active.discard(i)
+    per, cnt = {}, {}
+    for i in range(n):
+        k = names.get(tags[i], 'tag %d' % tags[i])
+        per[k] = per.get(k, 0.0) + share[i] / steps
+        cnt[k] = cnt.get(k, 0) + 1
+    return {'per_step_ms': dict(sorted(per.items(), key=lambda kv: -kv[1])), 'covered_ms_per_step': covered / steps,
+            'launches_per_step': {k: v / steps for k, v in cnt.items()}, 'by_tag': {t: sum(share[i] for i in range(n) if tags[i] == t) / steps for t in set(tags[:n])},
+            'what': 'exclusive time per kernel family: %d untimed steps with every hooked launch and phase recorded; an instant shared by k '
+                    'running launches counts 1/k for each' % steps}
+
+
 def self_launch(n_ranks, argv, oversubscribe=False):
     """`python bench.py --gpus N` without a launcher: THIS process has made no GPU call yet (importing torch and counting devices
     do not initialise the runtime) and makes none -- it starts the N ranks as CHILD processes through torch.distributed.run (never an
@@ -292,6 +348,11 @@ def main():
                          "'weak': 65536 rows per GPU")
     ap.add_argument('--rows', type=int, default=None, help='rows per GPU (diagnostics: the per-rank shard of the 2/4/8-GPU rows on one GPU, '
                     'e.g. --rows 8192 --force-dist; default 65536 / N under strong scaling, 65536 under weak scaling)')
+    ap.add_argument('--shard', choices=['blocks', 'hash'], default='blocks',
+                    help="how the global batch reaches the ranks.  'blocks' (default): every rank draws its own rows-per-GPU rows of whole groups with ids "
+                         "distinct across ranks (equal, 256-aligned shards).  'hash': ONE global batch (the same on every rank) split by "
+                         "rec_now_amd.dp.shard_rows_by_group -- every group on one rank, i.e. RAGGED per-rank batches (B %% 256 != 0), which the step runs on "
+                         "padded storage (recnow_dcn_mix_step_desc.B_pad); the cross-rank gate is the same")
     ap.add_argument('--group-inline', action='store_true', help='diagnostic: the grouping of the batch on the main stream instead of a side stream under the forward pass')
     ap.add_argument('--hostprof', default=None, help='diagnostic: cProfile the host side of 20 extra (untimed) steps into this file')
     ap.add_argument('--unfused', action='store_true', help='diagnostic: the drop-in composition head(cross(x)) and pairwise_loss(outputs, labels, groups) '
@@ -353,7 +414,23 @@ def main():
         rows = GLOBAL_BATCH // world if args.scaling == 'strong' else B_PER_GPU
     else:
         rows = args.rows
-    x, groups, labels = synth_batch(rows, 3, rank)
+    if args.shard == 'hash':
+        # ONE global batch, identical on every rank; rank r keeps the rows whose group hashes to r (whole groups, ragged shard sizes)
+        xg, gg, yg = synth_batch(rows * world, 3, 0)
+        mine = np.nonzero(dp.shard_rows_by_group(gg.astype(np.int64), world).numpy() == rank)[0]
+        x, groups, labels = np.ascontiguousarray(xg[mine]), np.ascontiguousarray(gg[mine]), np.ascontiguousarray(yg[mine])
+        rows = int(mine.size)
+        del xg, gg, yg
+    else:
+        x, groups, labels = synth_batch(rows, 3, rank)
+    # rows of every rank (ragged under --shard hash): the whole-job throughput counts all of them, the cross-rank gate slices by them
+    rank_rows = [rows]
+    if use_dist:
+        cnt_t = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=dev if args.backend == 'nccl' else 'cpu')
+        cnt_t[dist.get_rank()] = rows
+        dist.all_reduce(cnt_t, op=dist.ReduceOp.SUM)
+        rank_rows = [int(v) for v in cnt_t.tolist()]
+    total_rows = sum(rank_rows)
     xd, gd, yd = (torch.from_numpy(v).to(dev) for v in (x, groups, labels))
     model(xd[:256])                           # lazy build on the device
     # The step includes the gradient w.r.t. x (in a model x is the concatenated embedding output and needs it); a data-only
@@ -562,6 +639,32 @@ def main():
         sync()
         with open(args.hostprof, 'w') as fh:
             pstats.Stats(pr, stream=fh).sort_stats('cumulative').print_stats(45)
+    # diagnostics of the step route (untimed, after the timed region): the exclusive-time account and, under a process group, what the
+    # collectives add to a step (the same step with RECNOW_DP_SKIP_COLLECTIVE semantics switched on for ten steps on every rank)
+    account, comm = None, None
+    if pstep is not None and graph is None and not args.no_prof:
+        account = step_account(lib, run_step, sync)
+        mark('step account done')
+    if use_dist and pstep is not None and graph is None:
+        def timed_ms(n=10):
+            sync()
+            c0 = time.perf_counter()
+            for _ in range(n):
+                run_step()
+            sync()
+            tt = torch.tensor([(time.perf_counter() - c0) * 1e3 / n], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        with_ms = timed_ms()
+        dp._SKIP_COLLECTIVE = True
+        try:
+            without_ms = timed_ms()
+        finally:
+            dp._SKIP_COLLECTIVE = False
+        comm = {'with_collectives_ms': with_ms, 'without_collectives_ms': without_ms, 'comm_exposed_ms': with_ms - without_ms,
+                'what': 'ms per step over 10 untimed steps (max over the ranks), with and without the gradient all-reduces (event hops and the '
+                        'scale launches stay): the difference is what the collectives cost a step after the overlap with the backward pass'}
+        mark('comm probe done')
     if prof:
         traffic_tab, stale = {}, None
         try:
@@ -573,6 +676,12 @@ def main():
         except (OSError, ValueError, KeyError):
             stale = None                      # no PMC table at all
         tag = max(GEMM_TAGS, key=lambda t: ms[t])
+        if account is not None:
+            # the kernel family with the largest EXCLUSIVE time (launches of the second stream are timed while they overlap: their summed
+            # event times count the shared time twice)
+            excl = {t: account['by_tag'].get(t, 0.0) for t in GEMM_TAGS if cnt[t] > 0}
+            if excl:
+                tag = max(excl, key=lambda t: excl[t])
         if cnt[tag] > 0:
             achieved = fl[tag] / (ms[tag] * 1e-3) / 1e12
             # k_gemm_split executes every algorithmic fp32 multiply-add as six bf16 MFMA terms: its ceiling is the dense bf16 peak / 6
@@ -592,8 +701,19 @@ def main():
                                                             'avg_launch_us': ms[t] * 1e3 / cnt[t],
                                                             'algorithmic_bytes_per_launch': by[t] / cnt[t]}
                                               for t in HBM_TAGS if cnt[t] > 0 and ms[t] > 0}}
+            if account is not None:
+                roofline['exclusive_ms_per_step'] = account['per_step_ms']
+                roofline['exclusive_covered_ms_per_step'] = account['covered_ms_per_step']
+                roofline['exclusive_note'] = account['what']
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rank_ms = [elapsed * 1e3 / args.steps]
     if use_dist:
+        per_rank = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        per_rank[dist.get_rank()] = elapsed * 1e3 / args.steps
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        rank_ms = [float(v) for v in per_rank.tolist()]
+        if args.backend != 'nccl':
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -666,12 +786,14 @@ def main():
         sc64 = cpu_scores(fwd, xq_np, torch.float64) if full_gate else sc_gpu.astype(np.float64)
 
         def gather(a):
-            t = torch.from_numpy(np.ascontiguousarray(a))
+            a = np.ascontiguousarray(a)
+            t = torch.zeros(max(rank_rows), dtype=torch.from_numpy(a[:0]).dtype)      # shards may be ragged (--shard hash): padded to the longest
+            t[:a.shape[0]] = torch.from_numpy(a)
             if args.backend == 'nccl':          # (gloo gathers host tensors)
                 t = t.to(dev)
             parts = [torch.empty_like(t) for _ in range(rccl_ranks)]
             dist.all_gather(parts, t)
-            return torch.cat(parts).cpu().numpy()
+            return torch.cat([parts[r][:rank_rows[r]] for r in range(rccl_ranks)]).cpu().numpy()
         g_all, y_all, s_all, s64_all = gather(groups), gather(labels), gather(sc_gpu), gather(sc64)
         # (a) the loss stage + the reduction: oracle pair loss of the GATHERED batch on the GPU's own scores
         o_loss, _, o_pairs = PO.pairwise_bpr(g_all, y_all, s_all, grouped=True)
@@ -690,7 +812,7 @@ def main():
         if full_gate:
             # (b) the whole chain in fp64: global pair gradient from the gathered fp64 scores, backward of the local rows, gradients summed
             f_loss, ds_all, f_pairs = PO.pairwise_bpr(g_all, y_all, s64_all, grouped=True)
-            lo = rank * rows
+            lo = sum(rank_rows[:rank])
             dx64 = cpu_backward(fwd, xq_np, ds_all[lo:lo + rows], torch.float64)
             names = sorted(named)
             flat = torch.cat([torch.from_numpy(wleaf[k].grad.numpy().reshape(-1)) for k in names]).to(dev)
@@ -718,7 +840,7 @@ def main():
     if rank == 0:
         out = {
             'metric': 'samples/sec fwd+bwd, in-batch pairwise + DCN-v2, B=65536 at 1/2/4/8 GPUs',
-            'value': rows * world * args.steps / elapsed,
+            'value': total_rows * args.steps / elapsed,
             'unit': 'samples/s',
             'n_gpus': world,
             'steps': args.steps,
@@ -726,14 +848,21 @@ def main():
             'ms_per_step': elapsed * 1e3 / args.steps,
             'higher_is_better': True,
             'scaling': args.scaling if args.rows is None else 'weak',
+            'shard': args.shard,
             'vs_baseline': None,
             'dtype': 'f32' if args.gemm_precision == 'f32' else 'f32 operands as 3 x bf16, bf16 MFMA, f32 accumulate (opt-in, --gemm-precision bf16x3)',
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
-                                   'in-batch pairwise (logistic), global B=%d = %d rows on each of %d GPU(s), 64 fields x 16-dim, ~64 rows/group' % (rows * world, rows, world),
-                       'rows_per_gpu': rows,
-                       'global_batch': rows * world, 'input_grad': not args.no_input_grad, 'hip_graph': bool(use_graph), 'parallelism': 'dp%d' % world,
-                       'route': ('whole-step entry recnow_dcn_mix_step (one C call per phase, grouping on a side stream)' + (', replayed from HIP graphs' if use_graph else '') + (', weight-gradient products on a second stream' if two_streams else '')) if use_step else
+                                   'in-batch pairwise (logistic), global B=%d = %s rows on %d GPU(s), 64 fields x 16-dim, ~64 rows/group'
+                                   % (total_rows, ('%d' % rows) if len(set(rank_rows)) == 1 else '/'.join(str(r) for r in rank_rows), world),
+                       'rows_per_gpu': rows, 'rows_per_rank': rank_rows,
+                       'global_batch': total_rows, 'input_grad': not args.no_input_grad, 'hip_graph': bool(use_graph), 'parallelism': 'dp%d' % world,
+                       'route': ('whole-step entry recnow_dcn_mix_step (one C call per phase; cross layers: %s; grouping of the batch: %s)'
+                                 % ('row-block persistent kernels k_mix_tile_fwd / k_mix_tile_bwd' if pstep.tile_route() else 'one launch per product (k_gemm / k_gemm_shortk)',
+                                    {'side': 'on a side stream under the forward pass', 'inline': 'on the main stream in front of the forward pass',
+                                     'after': 'on the main stream behind the forward pass'}.get(getattr(pstep, 'group_mode', 'side'), '?'))
+                                 + (', replayed from HIP graphs' if use_graph else '') + (', weight-gradient products on a second stream' if two_streams else '')
+                                 + (', ragged batch on padded storage (%d -> %d rows)' % (pstep.B, pstep.B_pad) if pstep.B_pad != pstep.B else '')) if use_step else
                                 'fused node dcn_mix_score through autograd + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
                        'loss': float(loss.item()), 'host_enqueue_ms_per_step': host_ms,
                        'grads_copied_into_buckets': getattr(layerwise, 'last_foreign', None) if layerwise is not None else None},
@@ -746,6 +875,10 @@ def main():
         if use_dist:
             out['rccl_ranks'] = parity['rccl_ranks'] if parity and 'rccl_ranks' in parity else dist.get_world_size()
             out['backend'] = args.backend
+            out['ms_per_step_per_rank'] = {'min': min(rank_ms), 'max': max(rank_ms), 'ranks': rank_ms}
+            if comm is not None:
+                out['comm_exposed_ms'] = comm['comm_exposed_ms']
+                out['comm'] = comm
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -407,6 +407,11 @@ int recnow_dcn_mix_bwd(const float* x, const float* const* U_host, const float* 
  * of layer l has been issued (layers are walked L-1 .. 0; the head's gradients are complete at event L-1), so a data-parallel
  * caller can all-reduce a layer's gradients while the lower layers' backward still runs. */
 int recnow_dcn_mix_score_supported(int64_t B, int D, int S, int N, int L);
+/* 1 when a step / score / layer call of this shape runs the row-block persistent kernels (csrc/dcnmix_tile.hip: two experts of 64,
+ * D in {256, 512, 1024}, batches up to 16 384 rows; RECNOW_TILE=0 / =1 and the precision mode are read at every call): the ONE
+ * statement of that rule -- callers that place other work around the cross layers (rec_now_amd/step.py: where the grouping of the
+ * batch runs) ask here instead of restating it. */
+int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L);
 int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_host, const float* const* V_host, const float* const* W_host,
                              const float* const* bias_host, const float* const* gate_host, const float* head_w, const float* head_b,
                              int64_t B, int D, int S, int N, int L, int act_inner, int act_outer, float* scores, void* saved,
@@ -479,6 +484,14 @@ typedef struct recnow_dcn_mix_step_desc {
     void* const* layer_events_host;     /* optional HOST array of L hipEvent_t (entries may be NULL), as recnow_dcn_mix_score_bwd: event l is
                                            recorded once every weight gradient of layer l has been issued.  Must be NULL while the call
                                            is being captured into a graph (an event recorded inside a capture belongs to the graph). */
+    int64_t B_pad;                      /* 0 or == B: every buffer has B rows.  > B (ABI 4): RAGGED batch on the fast route -- the per-rank
+                                           batches of whole groups that data parallelism produces (rec_now_amd/dp.py shard_rows_by_group)
+                                           are not multiples of 256.  x, dx and scores then have B_pad rows of storage, B_pad a multiple of
+                                           256 that recnow_dcn_mix_score_supported accepts; rows [B, B_pad) of x must be ZERO (written once
+                                           by the caller); the layers run over B_pad rows, the grouping and the loss over the first B
+                                           (labels, groups, mask: B elements), d loss / d scores of the padding rows is zero, so they add
+                                           exactly 0.0f to every gradient; scores[B..B_pad) = head_b and dx rows >= B = 0 are written.
+                                           Workspace: recnow_dcn_mix_step_workspace_bytes(B_pad, ...). */
 } recnow_dcn_mix_step_desc;
 size_t recnow_dcn_mix_step_workspace_bytes(int64_t B, int D, int S, int N, int L, int group_dtype);
 int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* desc_host, int phases, int layer_hi, int layer_lo, void* stream);
@@ -608,8 +621,9 @@ int recnow_embed_scatter_rows(const float* drows, const int64_t* row_ids, int64_
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the GEMM kernels on the launch stream.
  * recnow_prof_enable(capacity > 0) arms `capacity` launch slots, (0) disables.  recnow_prof_collect synchronises and
- * returns per-kernel-family totals in HOST arrays of 9 entries indexed by tag: 1 = k_gemm<128,128>, 2 = k_gemm<128,160>,
- * 3 = k_gemm<256,64>, 4 = k_gemm<256,32>, 5 = k_gemm_shortk, 6 = k_mix_mid_fwd, 7 = k_mix_mid_bwd, 8 = k_gemm_split: launches, total
+ * returns per-kernel-family totals in HOST arrays of 16 entries indexed by tag: 1 = k_gemm<128,128>, 2 = k_gemm<128,160>,
+ * 3 = k_gemm<256,64>, 4 = k_gemm<256,32>, 5 = k_gemm_shortk, 6 = k_mix_mid_fwd, 7 = k_mix_mid_bwd, 8 = k_gemm_split, 9 = the fused GEMM1,
+ * 10 / 11 = k_mix_tile_fwd / _bwd, 12 = k_gemm<64,128> (csrc/prof.hpp): launches, total
  * milliseconds, total algorithmic flops (2*M*N*K*batch) and (bytes_host, may be NULL) total algorithmic HBM bytes: every
  * operand read once, every output written once, read-modify-write outputs twice.
  * ---------------------------------------------------------------------------------------------------------- */
@@ -618,6 +632,12 @@ int recnow_prof_enable(int capacity);
  * serialisation each; with n coprime to the launches per step every launch position is sampled equally often. */
 int recnow_prof_sample_every(int n);
 int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host, double* bytes_host);
+/* The recorded launches one by one instead of per-tag totals: tag_host / t0_ms_host / t1_ms_host (HOST arrays of `capacity` entries) get
+ * the tag and the interval of every record, in milliseconds after the first record's start; returns the number written or a negative
+ * code; synchronises and rewinds like recnow_prof_collect.  After recnow_prof_sample_every(1) the records are EVERY hooked launch plus
+ * the phase tags 13 (grouping), 14 (loss stage), 15 (packs, layer-end reductions): the timeline from which a caller tells overlapping
+ * launches of two streams apart. */
+int recnow_prof_intervals(int* tag_host, double* t0_ms_host, double* t1_ms_host, int capacity);
 
 /* HIP events owned through the C ABI (timing disabled): the layer_events_host of recnow_dcn_mix_score_bwd.  A host framework
  * whose event type is created lazily (torch.cuda.Event) cannot hand a handle over before the first record. */

@@ -67,6 +67,7 @@ SIGNATURES = {
     'recnow_dcn_mix_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                                  _Z, _P, _P]),
     'recnow_dcn_mix_score_supported': (_I, [_L, _I, _I, _I, _I]),
+    'recnow_dcn_mix_tile_route': (_I, [_L, _I, _I, _I, _I]),
     'recnow_dcn_mix_score_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _Z, _P, _I]),
     'recnow_dcn_mix_score_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                                        _P, _P, _Z, _P, _P, _P]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     'recnow_prof_enable': (_I, [_I]),
     'recnow_prof_sample_every': (_I, [_I]),
     'recnow_prof_collect': (_I, [_P, _P, _P, _P]),
+    'recnow_prof_intervals': (_I, [_P, _P, _P, _I]),
     'recnow_event_create': (_I, [_P]),
     'recnow_event_destroy': (_I, [_P]),
     'recnow_event_record': (_I, [_P, _P]),
@@ -126,7 +128,7 @@ class GemmDesc(ctypes.Structure):
         ('mid_V', _P), ('mid_T1', _P), ('mid_T2', _P), ('mid_T2g', _P), ('mid_ld', _L), ('mid_act_outer', _I), ('mid_pad', _I),
     ]
 
-ABI_VERSION = 3      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)
+ABI_VERSION = 4      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)
 
 class StepDesc(ctypes.Structure):
     """recnow_dcn_mix_step_desc of include/recnow.h."""
@@ -137,7 +139,7 @@ class StepDesc(ctypes.Structure):
         ('U_host', _P), ('V_host', _P), ('W_host', _P), ('bias_host', _P), ('gate_host', _P), ('head_w', _P), ('head_b', _P),
         ('scores', _P), ('loss', _P), ('n_pair', _P), ('stats', _P), ('dx', _P),
         ('dU_host', _P), ('dV_host', _P), ('dW_host', _P), ('dbias_host', _P), ('dgate_host', _P), ('dhead_w', _P), ('dhead_b', _P),
-        ('ws', _P), ('ws_bytes', _Z), ('stream2', _P), ('layer_events_host', _P),
+        ('ws', _P), ('ws_bytes', _Z), ('stream2', _P), ('layer_events_host', _P), ('B_pad', _L),
     ]
 
 

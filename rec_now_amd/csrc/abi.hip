@@ -2,5 +2,6 @@
 // Bumped whenever an exported signature or recnow_gemm_desc changes incompatibly; rec_now_amd/_lib.py refuses a library whose
 // version differs from the one its SIGNATURES table was written for.  2: recnow_prof_collect (4 arrays), recnow_embed_pool_fwd
 // (V), recnow_gemm_desc (second outputs, side products); 3 (round 3): recnow_dcn_mix_step + its descriptor, recnow_pairwise_loss,
-// recnow_listwise_loss, the packed weights kept in recnow_dcn_mix_saved_bytes.
-extern "C" int recnow_abi_version(void) { return 3; }
+// recnow_listwise_loss, the packed weights kept in recnow_dcn_mix_saved_bytes; 4 (round 5): recnow_dcn_mix_step_desc.B_pad (ragged per-rank
+// batches on the fast route), recnow_dcn_mix_tile_route.
+extern "C" int recnow_abi_version(void) { return 4; }

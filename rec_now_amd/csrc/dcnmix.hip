@@ -17,9 +17,11 @@
 // Leading dimension of the small activations: LDT = N*S+N rounded up to the GEMM's column-tile width (32/64/128/160/
 // multiples of 128) and K of the (N*S+N)-deep products rounded up to 16/32, all zero padded, so every GEMM of the layer
 // takes the lean interior kernel (no bounds code) whenever B is a multiple of 256.  Zero columns/rows are inert.
+#include <mutex>
 #include "gemm.hpp"
 #include "dcnmix_mid.hpp"
 #include "dcnmix_tile.hpp"
+#include "prof.hpp"
 
 static inline int ldt_of(int S, int N) {
     const int kc = N * S + N;
@@ -180,6 +182,30 @@ static bool mix_tile_on(const MixDims& m, bool maybe = false) {
 static bool mix_tile_bwd_on(const MixDims& m) {
     const char* e = getenv("RECNOW_TILE_BWD");
     return m.L <= 3 && !(e && e[0] == '0');
+}
+
+// Which weight packs the forward that filled a `saved` buffer left in it, and which route the top piece of the backward took.
+// The route rule (RECNOW_TILE, the precision mode) is read per call, so it can change between a forward and its backward: a product-route forward
+// (precision 1, RECNOW_TILE=0) followed by a row-block backward would read tile packs nobody wrote, and the other way round.  The forward records
+// what it packed under the address of `saved` (host side: a stamp inside the device buffer could not be read back without a synchronisation); the
+// backward packs what is missing for the route it takes, and the lower pieces of a backward cut into layer ranges follow the top piece.  A buffer
+// this process has no record of (filled through another copy of the library, or 256 forwards ago) is "unknown": the backward then packs for itself.
+enum { MIX_HAS_PRODUCT_PACKS = 1, MIX_HAS_TILE_PACKS = 2, MIX_BWD_TILE = 4 };
+struct MixStamp { const void* sv; int bits; };
+static std::mutex g_mix_stamp_mu;
+static MixStamp g_mix_stamps[256];
+static unsigned g_mix_stamp_next = 0;
+static void mix_stamp_put(const void* sv, int bits) {
+    std::lock_guard<std::mutex> lk(g_mix_stamp_mu);
+    for (int i = 0; i < 256; ++i)
+        if (g_mix_stamps[i].sv == sv) { g_mix_stamps[i].bits = bits; return; }
+    g_mix_stamps[g_mix_stamp_next++ % 256] = MixStamp{sv, bits};
+}
+static int mix_stamp_get(const void* sv) {
+    std::lock_guard<std::mutex> lk(g_mix_stamp_mu);
+    for (int i = 0; i < 256; ++i)
+        if (g_mix_stamps[i].sv == sv) return g_mix_stamps[i].bits;
+    return -1;
 }
 
 // saved layout, per layer l: T1, T2, T2g (B x LDT each); then the L-1 intermediate layer outputs x_1..x_{L-1} (B x D);
@@ -503,9 +529,14 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     const bool tile_fwd = mix_tile_on(m) && (y || head);
     // the [U | K] / [W; b] / head packs feed the launch-per-product kernels only: with the row-block kernels in both directions nobody reads them
     // (a product-route backward behind a row-block forward -- RECNOW_TILE_BWD=0 -- packs them itself: dcnmix_bwd_exact)
-    if (pack_once && !(tile_fwd && mix_tile_bwd_on(m)) &&
-        (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st)))
-        return rc;
+    const bool pack_product = pack_once && !(tile_fwd && mix_tile_bwd_on(m));
+    {
+        RnProfRecord* pr_pack = (pack_product && rn_prof_on()) ? rn_prof_begin(RN_TAG_LAYER_END, 0.0, 0.0, st) : nullptr;
+        if (pack_product && (rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, head ? head->w : nullptr, Wh_saved, st)))
+            return rc;
+        rn_prof_end(pr_pack, st);
+    }
+    mix_stamp_put(saved, (pack_product ? MIX_HAS_PRODUCT_PACKS : 0) | (tile_fwd ? MIX_HAS_TILE_PACKS : 0));
     const float* xl = x;
     const bool xless = mix_xless(m);
     if (tile_fwd) {       // every layer (+ the scoring head) in one launch of row-block workgroups
@@ -655,6 +686,11 @@ extern "C" int recnow_dcn_mix_fwd(const float* x, const float* const* U_host, co
 extern "C" int recnow_dcn_mix_score_supported(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
     return mix_head_ok(mix_dims(B, D, S, N, L)) ? 1 : 0;
+}
+
+extern "C" int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L) {
+    if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
+    return mix_tile_on(mix_dims(B, D, S, N, L)) ? 1 : 0;
 }
 
 extern "C" int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_host, const float* const* V_host,
@@ -840,12 +876,14 @@ static int dcnmix_bwd_tile(const MixDims& m, const float* x, const float* const*
             MIX_SIGNAL(e_du, st);
             MIX_WAIT(e_du, st2);
         }
+        RnProfRecord* pr_end = rn_prof_on() ? rn_prof_begin(RN_TAG_LAYER_END, 0.0, 0.0, st2) : nullptr;
         if ((rc = rn_layer_end_reduce(&red_dw, &red_du, dvpart + (size_t)l * grid * N * S * S, grid, N * S * S, dV_host[l], st2))) return rc;
         if (hd && l == L - 1) {
             hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw,
                                ds_part, ds_nparts, ds_part ? hd->db : nullptr);
             RN_LAUNCH_CHECK();
         }
+        rn_prof_end(pr_end, st2);
         MIX_SIGNAL(e_red[l], st2);
         if (layer_events && layer_events[l]) RN_HIP(hipEventRecord((hipEvent_t)layer_events[l], st2));
     }
@@ -873,10 +911,19 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     // The row-block backward chain (RECNOW_TILE_BWD=0 keeps the product-route backward behind the row-block forward: A/B switch, read per call).
     // Measured on one box, ms per step at 8192 / 16 384 rows per GPU: product route 0.760-0.765 / 1.138-1.143, row-block forward alone 0.723-0.726 /
     // 1.135-1.154, forward and backward 0.699-0.708 / 1.128-1.129 (0.67-0.68 / 1.10 with the paired weight-gradient products at 256 slots).
-    if (mix_tile_on(m) && mix_tile_bwd_on(m) && (l_hi < L - 1 || hd || dy))
+    const bool top = l_hi == L - 1;
+    const int have = mix_stamp_get(sv);          // what the forward left in `saved` (-1: a forward this copy of the library did not see)
+    bool want_tile = mix_tile_on(m) && mix_tile_bwd_on(m) && (l_hi < L - 1 || hd || dy);
+    if (!top && have >= 0) want_tile = (have & MIX_BWD_TILE) != 0 && mix_tile_shape(m);      // a lower piece follows the top piece of its pass
+    if (want_tile) {
+        if (top && !(have >= 0 && (have & MIX_HAS_TILE_PACKS))) {      // product-route forward (or unknown): the fragment-ordered packs are made here
+            int rc0;
+            if ((rc0 = rn_mix_tile_pack(U_host, gate_host, V_host, W_host, bias_host, D, L, (float*)(sv + mix_tile_pack_off(m)), st))) return rc0;
+        }
+        if (top) mix_stamp_put(sv, (have < 0 ? 0 : have) | MIX_HAS_TILE_PACKS | MIX_BWD_TILE);
         return dcnmix_bwd_tile(m, x, U_host, V_host, W_host, bias_host, gate_host, dy, sv, act_inner, act_outer, dx, dU_host, dV_host, dW_host,
                                dbias_host, dgate_host, ws, ws_bytes, st, st2, hd, layer_events, l_hi, l_lo, T2g_ds_ready, ds_part, ds_nparts);
-    const bool top = l_hi == L - 1;
+    }
     const bool defer_dv = rn_mix_mid_supported(S, N, m.LDT);      // the fused sub-space kernel leaves its dV partials for the layer-end reduction
     const bool two = st2 != nullptr && st2 != st;
     if (!two) st2 = st;
@@ -908,10 +955,13 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
     if (L <= MIX_PACK_MAX_L) {         // [U | K | 0] of every layer: packed ONCE per step by the forward, kept behind the activations in `saved`
         Wc1_all = (float*)(sv + mix_pack_off(m));
         Wh = Wc1_all + (size_t)2 * L * D * m.LDT;
-        if (top && mix_tile_on(m, true)) {   // ... unless the forward ran the row-block kernels and left them out (RECNOW_TILE_BWD=0 A/B pairing, or the precision switched in between): packed here
+        // ... unless the forward ran the row-block kernels in both directions and left them out (RECNOW_TILE_BWD=0 A/B pairing, or the precision /
+        // RECNOW_TILE switched in between): packed here.  Unknown forward: packed whenever the shape may have taken the row-block route.
+        if (top && (have >= 0 ? !(have & MIX_HAS_PRODUCT_PACKS) : mix_tile_on(m, true))) {
             float* Wc2_all = Wc1_all + (size_t)L * D * m.LDT;
             if ((rc = pack_all(m, U_host, W_host, bias_host, gate_host, Wc1_all, Wc2_all, hd ? hd->w : nullptr, const_cast<float*>(Wh), st))) return rc;
         }
+        if (top && have >= 0) mix_stamp_put(sv, (have | MIX_HAS_PRODUCT_PACKS) & ~MIX_BWD_TILE);
     } else if (top) {
         int pgw = rn_cdiv((int64_t)D * m.LDT, 256);
         if (pgw > 2048) pgw = 2048;
@@ -1059,6 +1109,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             }
         }
         // the layer's end: slab reductions of dW (+ dbias) and dU (+ dgate) and the dV partial sum in ONE launch
+        RnProfRecord* pr_end = rn_prof_on() ? rn_prof_begin(RN_TAG_LAYER_END, 0.0, 0.0, st2) : nullptr;
         if ((rc = rn_layer_end_reduce(&red_dw, &red_du, defer_dv ? (const float*)mid_ws : nullptr, rn_mix_mid_bwd_nparts(B), N * S * S, dV_host[l], st2)))
             return rc;
         if (hd && l == L - 1) {      // dW = w_head * M^T, dbias likewise, d w_head = sum_k [W; b] * M^T (on the reduced M^T)
@@ -1066,6 +1117,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
                                ds_part, ds_nparts, ds_part ? hd->db : nullptr);
             RN_LAUNCH_CHECK();
         }
+        rn_prof_end(pr_end, st2);
         MIX_SIGNAL(e_side_prev, st2);
         // every weight gradient of layer l has been issued (dW, dbias above; dV in the sub-space kernel; dU, dgate just now): a
         // caller-owned event lets the all-reduce of this layer start while the lower layers' backward still runs
@@ -1281,9 +1333,11 @@ extern "C" size_t recnow_dcn_mix_step_workspace_bytes(int64_t B, int D, int S, i
 // the top layer's dscore * T2g (the row-scaled small operand of the fused head's weight gradient) for the same rows; the
 // workgroup's partial sum of ds (d head bias, joined by k_head_post); {loss, (float) P} for the caller's statistics.
 __global__ void __launch_bounds__(256)
-k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restrict__ n_pair, int reduce_mean, float eps, int64_t B,
+k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restrict__ n_pair, int reduce_mean, float eps, int64_t B, int64_t BP,
               const float* __restrict__ T2g_top, int LDT, float* __restrict__ ds, float* __restrict__ T2g_ds, float* __restrict__ ds_part,
               float* __restrict__ loss, float* __restrict__ stats, const int32_t* __restrict__ n_seg) {
+    // B rows of the batch, BP >= B rows of storage (recnow_dcn_mix_step_desc.B_pad): the padding rows get d loss / d score = 0 and a zero
+    // row of dscore * T2g, so that the backward products, which run over all BP rows, add exactly nothing for them
     __shared__ float sds[STEP_ROWS];
     const float P = (float)(*n_pair);
     // n_seg[0] < 0: the cooperative grouping launch timed out at a grid barrier and left the identity grouping (scan_sort.hip) -- zero
@@ -1294,7 +1348,7 @@ k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restric
     if (threadIdx.x < STEP_ROWS) {            // one wave
         const int64_t r = r0 + threadIdx.x;
         const float v = r < B ? dsu[r] * sc : 0.f;
-        if (r < B) ds[r] = v;
+        if (r < BP) ds[r] = v;
         sds[threadIdx.x] = v;
         const float t = wave_sum(v);
         if (threadIdx.x == 0) ds_part[blockIdx.x] = t;
@@ -1308,7 +1362,7 @@ k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restric
     for (int i = threadIdx.x; i < STEP_ROWS * q; i += 256) {
         const int rl = i / q, c4 = i % q;
         const int64_t r = r0 + rl;
-        if (r < B) {
+        if (r < BP) {
             float4 v = reinterpret_cast<const float4*>(T2g_top + r * LDT)[c4];
             const float s = sds[rl];
             v.x *= s; v.y *= s; v.z *= s; v.w *= s;
@@ -1320,27 +1374,33 @@ k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restric
 extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases, int layer_hi, int layer_lo, void* stream) {
     if (!d || d->B < 0 || d->D < 1 || d->S < 1 || d->N < 1 || d->L < 1 || d->B > 0x7fffffffll) return RECNOW_EINVAL;
     if (phases & ~(RECNOW_STEP_GROUP | RECNOW_STEP_FORWARD | RECNOW_STEP_LOSS | RECNOW_STEP_BACKWARD)) return RECNOW_EINVAL;
-    if (d->B == 0 || !recnow_dcn_mix_score_supported(d->B, d->D, d->S, d->N, d->L)) return RECNOW_EUNSUPPORTED;
-    if (recnow_key_words(d->group_dtype) < 1) return RECNOW_EINVAL;
-    if (!d->ws || d->ws_bytes < recnow_dcn_mix_step_workspace_bytes(d->B, d->D, d->S, d->N, d->L, d->group_dtype)) return RECNOW_EWORKSPACE;
+    // B rows of the batch; BP rows of storage behind x, dx and scores (B_pad: a ragged per-rank batch on the fast route, rows >= B of x zero).
+    // The layers run over BP rows, the grouping and the pair loss over the first B; k_step_dscore gives the padding rows a zero gradient.
     const int64_t B = d->B;
+    const int64_t BP = d->B_pad > 0 ? d->B_pad : B;
+    if (BP < B || BP > 0x7fffffffll || (BP != B && BP % 256)) return RECNOW_EINVAL;
+    if (B == 0 || !recnow_dcn_mix_score_supported(BP, d->D, d->S, d->N, d->L)) return RECNOW_EUNSUPPORTED;
+    if (recnow_key_words(d->group_dtype) < 1) return RECNOW_EINVAL;
+    if (!d->ws || d->ws_bytes < recnow_dcn_mix_step_workspace_bytes(BP, d->D, d->S, d->N, d->L, d->group_dtype)) return RECNOW_EWORKSPACE;
     const int D = d->D, S = d->S, N = d->N, L = d->L;
-    const StepWs w = step_carve(d->ws, d->ws_bytes, B, D, S, N, L, d->group_dtype);
+    const StepWs w = step_carve(d->ws, d->ws_bytes, BP, D, S, N, L, d->group_dtype);
     if (!w.ok) return RECNOW_EWORKSPACE;
-    const MixDims m = mix_dims(B, D, S, N, L);
+    const MixDims m = mix_dims(BP, D, S, N, L);
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (phases & RECNOW_STEP_GROUP) {
         if (!d->groups) return RECNOW_EINVAL;
+        RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_STEP_GROUP, 0.0, 16.0 * B, st) : nullptr;
         RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
         if ((rc = recnow_group_keys(d->groups, d->group_dtype, B, w.words, w.solo, stream))) return rc;
         if ((rc = recnow_group_segments(w.words, w.solo, B, w.n_words, w.n_words, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp,
                                         w.grp_bytes, stream)))
             return rc;
+        rn_prof_end(pr, st);
     }
     if (phases & RECNOW_STEP_FORWARD) {
         if (!d->scores) return RECNOW_EINVAL;
-        if ((rc = recnow_dcn_mix_score_fwd(d->x, d->U_host, d->V_host, d->W_host, d->bias_host, d->gate_host, d->head_w, d->head_b, B, D, S, N, L,
+        if ((rc = recnow_dcn_mix_score_fwd(d->x, d->U_host, d->V_host, d->W_host, d->bias_host, d->gate_host, d->head_w, d->head_b, BP, D, S, N, L,
                                            d->act_inner, d->act_outer, d->scores, w.saved, w.saved_bytes, w.mix, w.mix_bytes, stream,
                                            d->dx ? 1 : 0)))
             return rc;
@@ -1348,13 +1408,15 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
     if (phases & RECNOW_STEP_LOSS) {
         if (!d->scores || !d->labels || !d->loss || !d->n_pair) return RECNOW_EINVAL;
         const int flags = RECNOW_PAIR_LABEL_GT | (d->only_use_wrong_order_pair ? RECNOW_PAIR_WRONG_ORDER : 0);
+        RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_STEP_LOSS, 0.0, 16.0 * B + 8.0 * BP * m.LDT, st) : nullptr;
         if ((rc = recnow_pair_bpr_onepass(d->scores, d->labels, d->mask, w.order, w.seg_id, w.seg_first, B, flags, d->factor, d->reduce_mean,
                                           d->loss, w.dsu, d->n_pair, w.pair, w.pair_bytes, stream)))
             return rc;
         const float* T2g_top = (const float*)((const char*)w.saved + (size_t)(3 * (L - 1) + 2) * act_block(m));
-        hipLaunchKernelGGL(k_step_dscore, rn_cdiv(B, STEP_ROWS), 256, 0, st, w.dsu, (const unsigned long long*)d->n_pair, d->reduce_mean, 1.0e-10f, B,
+        hipLaunchKernelGGL(k_step_dscore, rn_cdiv(BP, STEP_ROWS), 256, 0, st, w.dsu, (const unsigned long long*)d->n_pair, d->reduce_mean, 1.0e-10f, B, BP,
                            T2g_top, m.LDT, w.ds, w.T2g_ds, w.ds_part, d->loss, d->stats, w.n_seg);
         RN_LAUNCH_CHECK();
+        rn_prof_end(pr, st);
     }
     if (phases & RECNOW_STEP_BACKWARD) {
         if (!d->x || !d->U_host || !d->V_host || !d->W_host || !d->bias_host || !d->gate_host || !d->head_w || !d->dU_host || !d->dV_host ||
@@ -1364,7 +1426,7 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
         hd.w = d->head_w; hd.dscores = w.ds; hd.dw = d->dhead_w; hd.db = d->dhead_b;
         if ((rc = dcnmix_bwd_exact(m, d->x, d->U_host, d->V_host, d->W_host, d->bias_host, d->gate_host, nullptr, (const char*)w.saved,
                                    d->act_inner, d->act_outer, d->dx, d->dU_host, d->dV_host, d->dW_host, d->dbias_host, d->dgate_host, w.mix,
-                                   w.mix_bytes, st, (hipStream_t)d->stream2, &hd, d->layer_events_host, layer_hi, layer_lo, w.T2g_ds, w.ds_part, rn_cdiv(B, STEP_ROWS))))
+                                   w.mix_bytes, st, (hipStream_t)d->stream2, &hd, d->layer_events_host, layer_hi, layer_lo, w.T2g_ds, w.ds_part, rn_cdiv(BP, STEP_ROWS))))
             return rc;
     }
     return RECNOW_OK;

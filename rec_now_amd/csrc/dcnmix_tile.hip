@@ -22,6 +22,8 @@
 // Exact fp32 like the GEMM kernels; other summation order (K in four quarters).  One wave per SIMD and 512 registers per lane: nothing runs
 // beside these launches.  Rules this file follows because their absence was measured: no load under a run-time condition,
 // no per-lane choice between kernel-argument array elements, tiles leave for memory through LDS as coalesced 16-byte pieces.
+#include <string.h>
+#include <atomic>
 #include "dcnmix_tile.hpp"
 #include "prof.hpp"
 
@@ -373,12 +375,17 @@ template <int NB>
 static int tile_launch(const RnTileFwd& p, int grid, hipStream_t st) {
     const size_t lds = (size_t)TL_LDS_FLOATS(128 * NB) * sizeof(float);
     const bool tanh2 = p.act_inner == RECNOW_ACT_TANH && p.act_outer == RECNOW_ACT_TANH;
-    static bool allowed[2] = {false, false};
-    if (!allowed[tanh2 ? 1 : 0]) {
+    // more than 64 KB of dynamic LDS: raised once per DEVICE and kernel (the attribute belongs to the function on the current device: a process
+    // that drives a second GPU must raise it there too); std::atomic<bool>: concurrent host threads may race to raise it, never to skip it
+    static std::atomic<bool> raised[2][64];
+    int dev = 0;
+    RN_HIP(hipGetDevice(&dev));
+    const int which = tanh2 ? 1 : 0;
+    if (dev < 0 || dev >= 64 || !raised[which][dev].load(std::memory_order_acquire)) {
         hipError_t e = tanh2 ? hipFuncSetAttribute((const void*)k_mix_tile_fwd<NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                              : hipFuncSetAttribute((const void*)k_mix_tile_fwd<NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        allowed[tanh2 ? 1 : 0] = true;
+        if (dev >= 0 && dev < 64) raised[which][dev].store(true, std::memory_order_release);
     }
     if (tanh2) hipLaunchKernelGGL((k_mix_tile_fwd<NB, true>), grid, 256, lds, st, p);
     else hipLaunchKernelGGL((k_mix_tile_fwd<NB, false>), grid, 256, lds, st, p);
@@ -386,15 +393,32 @@ static int tile_launch(const RnTileFwd& p, int grid, hipStream_t st) {
     return RECNOW_OK;
 }
 
+static int tile_pack_launch(const RnTileFwd& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.L * TL_PACK_FLOATS(p.D);
+    int g = rn_cdiv(total, 256 * 4);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_tile_pack, g, 256, 0, st, p);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+// the packs alone: a row-block backward behind a forward that did not run the row-block kernels (dcnmix.hip, route stamps)
+int rn_mix_tile_pack(const float* const* U, const float* const* Kg, const float* const* V, const float* const* W, const float* const* bias, int D, int L,
+                     float* packs, hipStream_t st) {
+    if (L < 1 || L > RN_TILE_MAX_L || !packs || !(D == 256 || D == 512 || D == 1024)) return RECNOW_EUNSUPPORTED;
+    RnTileFwd p;
+    memset(&p, 0, sizeof(p));
+    p.D = D; p.L = L; p.packs = packs;
+    for (int l = 0; l < L; ++l) { p.U[l] = U[l]; p.Kg[l] = Kg[l]; p.V[l] = V[l]; p.W[l] = W[l]; p.bias[l] = bias[l]; }
+    return tile_pack_launch(p, st);
+}
+
 int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st) {
     if (!rn_mix_tile_supported(p.B, p.D, 64, 2, p.L, TL_LDT) || !p.packs || !p.x) return RECNOW_EUNSUPPORTED;
     if (p.head_w && !p.scores) return RECNOW_EINVAL;
     {
-        const int64_t total = (int64_t)p.L * TL_PACK_FLOATS(p.D);
-        int g = rn_cdiv(total, 256 * 4);
-        if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(k_tile_pack, g, 256, 0, st, p);
-        RN_LAUNCH_CHECK();
+        int rcp;
+        if ((rcp = tile_pack_launch(p, st))) return rcp;
     }
     const int64_t tiles = p.B / TL_ROWS;
     const int grid = (int)(tiles < 256 ? tiles : 256);
@@ -818,13 +842,15 @@ static int tile_bwd_launch(const RnTileBwd& p, int grid, hipStream_t st) {
     const size_t lds = (size_t)TLB_LDS_FLOATS * sizeof(float);
     const bool tanh2 = p.act_inner == RECNOW_ACT_TANH && p.act_outer == RECNOW_ACT_TANH;
     const bool dx = p.dx != nullptr;
-    static bool allowed[4] = {false, false, false, false};
+    static std::atomic<bool> raised[4][64];      // per device, as in tile_launch
     const int v = (tanh2 ? 2 : 0) + (dx ? 1 : 0);
     const void* fn = v == 3 ? (const void*)k_mix_tile_bwd<NB, true, true> : v == 2 ? (const void*)k_mix_tile_bwd<NB, true, false>
                    : v == 1 ? (const void*)k_mix_tile_bwd<NB, false, true> : (const void*)k_mix_tile_bwd<NB, false, false>;
-    if (!allowed[v]) {
+    int dev = 0;
+    RN_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !raised[v][dev].load(std::memory_order_acquire)) {
         RN_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        allowed[v] = true;
+        if (dev >= 0 && dev < 64) raised[v][dev].store(true, std::memory_order_release);
     }
     if (v == 3) hipLaunchKernelGGL((k_mix_tile_bwd<NB, true, true>), grid, 256, lds, st, p);
     else if (v == 2) hipLaunchKernelGGL((k_mix_tile_bwd<NB, true, false>), grid, 256, lds, st, p);

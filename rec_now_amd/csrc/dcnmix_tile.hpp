@@ -29,6 +29,9 @@ struct RnTileFwd {
 };
 // packs the weights (one launch) and runs every layer of the forward pass in ONE launch
 int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st);
+// the pack launch alone (HOST arrays of L device pointers, as recnow_dcn_mix_fwd takes them)
+int rn_mix_tile_pack(const float* const* U, const float* const* Kg, const float* const* V, const float* const* W, const float* const* bias, int D, int L,
+                     float* packs, hipStream_t st);
 
 // Data-gradient chain of the backward pass, layers l_hi .. l_lo (descending) in ONE launch: per layer dT2g -> sub-space backward -> g_l,
 // with dx accumulated on the way.  The K = B weight-gradient products stay separate launches: they read what this kernel leaves

@@ -278,7 +278,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     const bool a_kc = d->a_trans == 0, b_kc = d->b_trans != 0;
     int rc;
     int tag = (c.BM == 256 && c.BN == 32) ? RN_TAG_GEMM_256x32 : (c.BM == 256) ? RN_TAG_GEMM_256x64
-            : (c.BN == 160) ? RN_TAG_GEMM_128x160 : RN_TAG_GEMM_128x128;
+            : (c.BN == 160) ? RN_TAG_GEMM_128x160 : (c.BM == 64) ? RN_TAG_GEMM_64x128 : RN_TAG_GEMM_128x128;
     // short-K products (K <= 256, e.g. the K = N*S+N = 130 contractions of DCN-v2) are prologue/epilogue dominated:
     // BK = 16 halves the LDS footprint so 4 workgroups per CU overlap each other's load/store phases.
     const bool short_k = d->K <= 256 || (d->c2_mode && d->K <= 512);

@@ -11,6 +11,7 @@ bool rn_prof_on() { return g_on; }
 
 RnProfRecord* rn_prof_begin(int tag, double flops, double bytes, hipStream_t st) {
     if (!g_on || g_used >= g_pool.size()) return nullptr;
+    if (tag >= RN_TAG_FIRST_PHASE && g_every != 1) return nullptr;      // phase tags: every-launch mode only (prof.hpp)
     if ((g_seq++ % (unsigned)g_every) != 0) return nullptr;
     RnProfRecord* r = &g_pool[g_used++];
     r->tag = tag;
@@ -73,6 +74,27 @@ extern "C" int recnow_prof_collect(int* count_host, double* ms_host, double* flo
     }
     g_used = 0;
     return RECNOW_OK;
+}
+
+
+// Synchronises and returns the recorded launches one by one: tag and [t0, t1] in milliseconds after the FIRST record's start (events of
+// different streams of one device share a clock).  With recnow_prof_sample_every(1) this is the timeline of every hooked launch and phase:
+// what overlaps under a second stream can then be told apart (bench.py: exclusive time per kernel family).  Rewinds the pool like
+// recnow_prof_collect (use one or the other per measurement).  Returns the number of records written (<= capacity) or a negative code.
+extern "C" int recnow_prof_intervals(int* tag_host, double* t0_ms_host, double* t1_ms_host, int capacity) {
+    if (!tag_host || !t0_ms_host || !t1_ms_host || capacity < 0) return RECNOW_EINVAL;
+    int n = 0;
+    for (size_t i = 0; i < g_used && n < capacity; ++i) {
+        RnProfRecord& r = g_pool[i];
+        if (hipEventSynchronize(r.e1) != hipSuccess) return RECNOW_EINVAL;
+        float a = 0.f, b = 0.f;
+        if (i > 0 && hipEventElapsedTime(&a, g_pool[0].e0, r.e0) != hipSuccess) return RECNOW_EINVAL;
+        if (hipEventElapsedTime(&b, g_pool[0].e0, r.e1) != hipSuccess) return RECNOW_EINVAL;
+        tag_host[n] = r.tag; t0_ms_host[n] = a; t1_ms_host[n] = b;
+        ++n;
+    }
+    g_used = 0;
+    return n;
 }
 
 

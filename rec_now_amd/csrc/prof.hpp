@@ -20,7 +20,15 @@ struct RnProfRecord {
 #define RN_TAG_GEMM_MIDF 9          // k_gemm<128,128,..,25>: GEMM1 of DCN-v2 computed transposed with the sub-space forward in its epilogue
 #define RN_TAG_MIX_TILE_FWD 10     // k_mix_tile_fwd: row-block persistent forward of all cross layers (shard sizes)
 #define RN_TAG_MIX_TILE_BWD 11     // k_mix_tile_bwd: the data-gradient chain of the cross layers, row-block persistent
-#define RN_TAG_MAX 12
+#define RN_TAG_GEMM_64x128 12       // k_gemm<64,128,..>: the small-M dispatch of the long-K products (shards below 256 row tiles of 128)
+// Phase tags: recorded only in the every-launch mode (recnow_prof_sample_every(1)), where the intervals of ALL hooked launches give the
+// step's account (recnow_prof_intervals: bench.py's exclusive time per kernel family under two streams).  In the sampled mode they would
+// shift which launch positions the every-n-th rule picks.
+#define RN_TAG_STEP_GROUP 13        // grouping of the batch (keys, radix sort, segments): RECNOW_STEP_GROUP
+#define RN_TAG_STEP_LOSS 14         // the loss stage: pair walks, finalize, d loss / d scores (RECNOW_STEP_LOSS)
+#define RN_TAG_LAYER_END 15         // weight packs, layer-end slab reductions, head post-processing
+#define RN_TAG_MAX 16
+#define RN_TAG_FIRST_PHASE 13
 
 bool rn_prof_on();
 // returns a slot (or nullptr when profiling is off / the pool is full) and records e0 on st

@@ -17,7 +17,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .layers._ops import DCN_MIX_TWO_STREAMS, _host_ptr_array
+from .layers._ops import DCN_MIX_TWO_STREAMS, _host_ptr_array, pad_rows, ragged_pad_rows
 
 
 class GpuEvent(object):
@@ -52,6 +52,10 @@ class DCNMixScoreFunction(torch.autograd.Function):
         ps = [_lib.f32c(p, 'weight') for p in params]
         U, V, W, bias, gate = (ps[i * L:(i + 1) * L] for i in range(5))
         N, D, S = U[0].shape
+        rows = x.shape[0]
+        padded = ragged_pad_rows(rows, D, S, N, L)      # a ragged per-rank batch: zero-padded copy on the exact-128 route (layers/_ops.py)
+        if padded:
+            x = pad_rows(x, padded)
         B = x.shape[0]
         lib = _lib.load()
         saved = _lib.workspace(lib.recnow_dcn_mix_saved_bytes(B, D, S, N, L), x.device)
@@ -64,7 +68,8 @@ class DCNMixScoreFunction(torch.autograd.Function):
         ctx.save_for_backward(x, saved, hw, *ps)
         ctx.meta = (B, D, S, N, L, act_inner, act_outer, need_dx, head_w.shape, None if head_b is None else head_b.shape, events,
                     grad_buffers)
-        return scores
+        ctx.rows = rows
+        return scores[:rows] if padded else scores
 
     @staticmethod
     def backward(ctx, dscores):
@@ -72,6 +77,8 @@ class DCNMixScoreFunction(torch.autograd.Function):
         B, D, S, N, L, act_inner, act_outer, need_dx, hw_shape, hb_shape, events, gbuf = ctx.meta
         U, V, W, bias, gate = (ps[i * L:(i + 1) * L] for i in range(5))
         ds = _lib.f32c(dscores, 'grad').reshape(-1)
+        if ctx.rows != B:
+            ds = pad_rows(ds, B)
         dx = torch.empty_like(x) if need_dx else None
         # gradient storage: fresh tensors, or the caller's buffers (dp.LayerwiseReducer hands out views of one flat bucket per
         # layer, so the all-reduce runs in place: no packing before and no copy after the collective)
@@ -94,11 +101,14 @@ class DCNMixScoreFunction(torch.autograd.Function):
                   act_inner, act_outer, _lib.ptr(dx) if need_dx else None, _host_ptr_array(dU), _host_ptr_array(dV),
                   _host_ptr_array(dW), _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(dhw), _lib.ptr(dhb), _lib.ptr(ws),
                   ws.numel(), _lib.stream(), _lib.side_stream(x.device) if DCN_MIX_TWO_STREAMS else None, ev)
+        if need_dx and ctx.rows != B:
+            dx = dx[:ctx.rows]
         return (dx, dhw.view(hw_shape), None if dhb is None else dhb.view(hb_shape), None, None, None, None, None) + tuple(grads)
 
 
-def fused_route_available(cross, head, x):
-    """True when `dcn_mix_score` runs as one fused node for this input (else it calls the two layers)."""
+def fused_route_available(cross, head, x, rows=None):
+    """True when `dcn_mix_score` runs as one fused node for this input (else it calls the two layers).  rows: the row count to ask for
+    instead of x.shape[0] (step.py: the padded storage of a ragged batch)."""
     if not (cross.built and head.built):
         return False
     if cross._cb_inner is not None or cross._cb_outer is not None:
@@ -108,7 +118,9 @@ def fused_route_available(cross, head, x):
     if x.dim() != 2 or not x.is_cuda:
         return False
     N, D, S = cross.origin_to_sub_kernels[0].shape
-    return bool(_lib.load().recnow_dcn_mix_score_supported(x.shape[0], D, S, N, cross.num_layer))
+    if rows is None:
+        rows = ragged_pad_rows(x.shape[0], D, S, N, cross.num_layer) or x.shape[0]      # a ragged batch takes the route on padded rows
+    return bool(_lib.load().recnow_dcn_mix_score_supported(rows, D, S, N, cross.num_layer))
 
 
 def score_params(cross, head):

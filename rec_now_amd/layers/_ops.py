@@ -1,5 +1,6 @@
 """torch.autograd.Function wrappers over the C ABI for the layer kernels (host plumbing only: shapes, buffers, streams)."""
 import ctypes
+import os
 
 import torch
 
@@ -170,7 +171,6 @@ class DCNStepFunction(torch.autograd.Function):
         return dx0, dxl, dw, db, None
 
 
-import os
 # Opt-in: run the weight-gradient products of the DCN-v2 backward on a second HIP stream (recnow_dcn_mix_bwd's stream2).
 # Measured on MI355X at the north-star shape: 5.43 vs 5.54 ms/step (-2 %), every GEMM already fills all 256 CUs, so the
 # default stays single-stream (per-launch timings then remain meaningful for the roofline hook).
@@ -178,6 +178,27 @@ DCN_MIX_TWO_STREAMS = os.environ.get('RECNOW_TWO_STREAMS', '0') in ('1', '2')
 
 
 # ---- DCN-v2 mix ---------------------------------------------------------------------------------------------------
+def ragged_pad_rows(B, D, S, N, L):
+    """Rows of padded storage for a RAGGED batch on the exact-128 routes, or 0 (run as it is).
+
+    The per-rank batches of data parallelism are whole groups (dp.shard_rows_by_group), i.e. not multiples of 256, and the fast
+    routes of the cross layers (exact-128 formulation, fused sub-space kernels, row-block kernels) want whole 256-row blocks.  A
+    batch of at least RECNOW_PAD_MIN_ROWS rows (default 2048; smaller ones stay on the general kernels, where the padding would be
+    a large share of the work) whose shape the fast routes take once padded runs on a zero-padded copy: zero rows of x with a zero
+    upstream gradient add exactly 0.0f to every weight gradient, and their outputs are sliced away.  RECNOW_PAD_RAGGED=0: off."""
+    if B % 256 == 0 or os.environ.get('RECNOW_PAD_RAGGED') == '0' or B < int(os.environ.get('RECNOW_PAD_MIN_ROWS', '2048')):
+        return 0
+    Bp = -(-B // 256) * 256
+    return Bp if _lib.load().recnow_dcn_mix_score_supported(Bp, D, S, N, L) else 0
+
+
+def pad_rows(t, rows):
+    """t (B, ...) -> (rows, ...) with zero rows behind the B rows of t."""
+    out = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    out[:t.shape[0]].copy_(t)
+    return out
+
+
 class DCNMixFunction(torch.autograd.Function):
     """All L layers of DCNMixLayer.  params = U_0..U_{L-1}, V_0.., W_0.., bias_0.., gate_0.. (5*L tensors)."""
 
@@ -187,6 +208,10 @@ class DCNMixFunction(torch.autograd.Function):
         ps = [_lib.f32c(p, 'weight') for p in params]
         U, V, W, bias, gate = (ps[i * L:(i + 1) * L] for i in range(5))
         N, D, S = U[0].shape
+        rows = x.shape[0]
+        padded = ragged_pad_rows(rows, D, S, N, L)
+        if padded:
+            x = pad_rows(x, padded)
         B = x.shape[0]
         lib = _lib.load()
         saved = _lib.workspace(lib.recnow_dcn_mix_saved_bytes(B, D, S, N, L), x.device)
@@ -200,7 +225,8 @@ class DCNMixFunction(torch.autograd.Function):
                   _lib.ptr(saved), saved.numel(), _lib.ptr(ws), ws.numel(), _lib.stream(), int(need_dx))
         ctx.save_for_backward(x, saved, *ps)
         ctx.meta = (B, D, S, N, L, act_inner, act_outer, need_dx)
-        return y
+        ctx.rows = rows
+        return y[:rows] if padded else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -208,6 +234,8 @@ class DCNMixFunction(torch.autograd.Function):
         B, D, S, N, L, act_inner, act_outer, need_dx = ctx.meta
         U, V, W, bias, gate = (ps[i * L:(i + 1) * L] for i in range(5))
         dy = _lib.f32c(dy, 'grad')
+        if ctx.rows != B:
+            dy = pad_rows(dy, B)
         dx = torch.empty_like(x) if need_dx else None
         grads = [torch.empty_like(p) for p in ps]
         dU, dV, dW, dbias, dgate = (grads[i * L:(i + 1) * L] for i in range(5))
@@ -218,6 +246,8 @@ class DCNMixFunction(torch.autograd.Function):
                   act_inner, act_outer, _lib.ptr(dx) if need_dx else None, _host_ptr_array(dU), _host_ptr_array(dV), _host_ptr_array(dW),
                   _host_ptr_array(dbias), _host_ptr_array(dgate), _lib.ptr(ws), ws.numel(), _lib.stream(),
                   _lib.side_stream(x.device) if DCN_MIX_TWO_STREAMS else None)
+        if need_dx and ctx.rows != B:
+            dx = dx[:ctx.rows]
         return (dx, None, None, None) + tuple(grads)
 
 

@@ -35,6 +35,11 @@ class DCNMixPairwiseStep(object):
 
     x (B, D) float32, labels (B,), groups (B,) float32 / int32 / float64 / int64 ids, optional mask (B,) bool: device tensors
     whose STORAGE is reused by every step (copy new batches into them) -- a captured graph replays addresses.
+    RAGGED batches (B not a multiple of 256: what `dp.shard_rows_by_group` hands a rank, whole groups per rank): the step owns padded
+    storage of B_pad = ceil(B / 256) * 256 rows behind `self.x`, `self.scores`, `self.dx` (each a view of the first B rows; `x` is
+    COPIED into it once -- refill `step.x`, not the tensor passed in); the padding rows of x are zero and stay zero, the layers run
+    over B_pad rows on the same kernels as any other batch, the grouping and the loss over the B rows of the batch, and the padding
+    rows receive d loss / d score = 0, i.e. they add exactly nothing to any gradient (recnow_dcn_mix_step_desc.B_pad).
     reduce_mean: the reference's mean over the pairs (`loss` = sum / (P + 1e-10)); False: the loss sum and its gradient (the
     data-parallel form: the reducer divides by the global pair count).  need_dx: also d loss / d x (`self.dx`).
     reducer: optional dp.LayerwiseReducer built over `stages_for(cross, head)`.
@@ -42,9 +47,11 @@ class DCNMixPairwiseStep(object):
 
     def __init__(self, cross, head, x, labels, groups, mask=None, reduce_mean=True, need_dx=True, factor=1.0,
                  only_use_wrong_order_pair=False, reducer=None, two_streams=False):
-        if not fused_route_available(cross, head, x):
+        B = int(x.shape[0]) if x.dim() == 2 else 0
+        B_pad = -(-B // 256) * 256
+        if B < 1 or not fused_route_available(cross, head, x, rows=B_pad):
             raise ValueError('DCNMixPairwiseStep needs the fused north-star shape (recnow_dcn_mix_score_supported): N*S and D multiples '
-                             'of 128, B a multiple of 256, built-in activations, a linear MultiDenseLayer(1, 1) head')
+                             'of 128, built-in activations, a linear MultiDenseLayer(1, 1) head (any B >= 1: ragged batches run on padded storage)')
         self.cross, self.head, self.reducer = cross, head, reducer
         if reducer is not None:
             reduce_mean = False        # the data-parallel form: loss SUM and its gradient, divided by the GLOBAL pair count by the reducer
@@ -52,20 +59,27 @@ class DCNMixPairwiseStep(object):
         self.device = dev
         N, D, S = cross.origin_to_sub_kernels[0].shape
         L = cross.num_layer
-        B = x.shape[0]
-        self.B, self.D, self.L = B, D, L
-        self.x = _lib.f32c(x, 'inputs')
+        self.B, self.B_pad, self.D, self.L = B, B_pad, D, L
+        if B_pad == B:
+            self.x = _lib.f32c(x, 'inputs')
+            self._x_store = self.x
+        else:                              # ragged: padded storage owned by the step, the padding rows zero once and for all
+            self._x_store = torch.zeros((B_pad, D), dtype=torch.float32, device=dev)
+            self.x = self._x_store[:B]
+            self.x.copy_(_lib.f32c(x, 'inputs'))
         self.labels = _lib.f32c(labels, 'labels').reshape(-1)
         self.groups, gdt = _as_key_tensor(groups)
         self.mask = None if mask is None else (mask.reshape(-1) != 0).to(torch.uint8).contiguous()
         if self.labels.numel() != B or self.groups.numel() != B or (self.mask is not None and self.mask.numel() != B):
             raise ValueError('labels / groups / mask must have %d elements' % B)
         lib = _lib.load()
-        self.scores = torch.empty(B, dtype=torch.float32, device=dev)
+        self._scores_store = torch.empty(B_pad, dtype=torch.float32, device=dev)
+        self.scores = self._scores_store[:B]
         self.loss = torch.empty((), dtype=torch.float32, device=dev)
         self.n_pair = torch.empty(1, dtype=torch.int64, device=dev)
-        self.dx = torch.empty_like(self.x) if need_dx else None
-        self.ws = _lib.workspace(lib.recnow_dcn_mix_step_workspace_bytes(B, D, S, N, L, gdt), dev)
+        self._dx_store = torch.empty((B_pad, D), dtype=torch.float32, device=dev) if need_dx else None
+        self.dx = self._dx_store[:B] if need_dx else None
+        self.ws = _lib.workspace(lib.recnow_dcn_mix_step_workspace_bytes(B_pad, D, S, N, L, gdt), dev)
         # parameters in the order of fused.score_params: head kernel, head bias, U_0.., V_0.., W_0.., bias_0.., gate_0..
         self.params = score_params(cross, head)
         self.grads = []
@@ -82,16 +96,17 @@ class DCNMixPairwiseStep(object):
         self._keep = [_host_ptr_array(w5(i)) for i in range(5)] + [_host_ptr_array(g5(i)) for i in range(5)]      # host pointer arrays: alive as long as the descriptor
         d = _lib.StepDesc()
         d.B, d.D, d.S, d.N, d.L = B, D, S, N, L
+        d.B_pad = B_pad if B_pad != B else 0
         d.act_inner, d.act_outer, d.group_dtype = cross._act_inner, cross._act_outer, gdt
         d.only_use_wrong_order_pair, d.reduce_mean, d.factor = int(bool(only_use_wrong_order_pair)), int(bool(reduce_mean)), float(factor)
         P = lambda t: None if t is None else t.data_ptr()           # noqa: E731
-        d.x, d.labels, d.groups, d.mask = P(self.x), P(self.labels), P(self.groups), P(self.mask)
+        d.x, d.labels, d.groups, d.mask = P(self._x_store), P(self.labels), P(self.groups), P(self.mask)
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)            # noqa: E731
         d.U_host, d.V_host, d.W_host, d.bias_host, d.gate_host = (cast(a) for a in self._keep[:5])
         d.dU_host, d.dV_host, d.dW_host, d.dbias_host, d.dgate_host = (cast(a) for a in self._keep[5:])
         d.head_w, d.head_b = P(ps[0]), P(ps[1])
         d.dhead_w, d.dhead_b = P(self.grads[0]), P(self.grads[1])
-        d.scores, d.loss, d.n_pair, d.stats, d.dx = P(self.scores), P(self.loss), P(self.n_pair), P(self.stats), P(self.dx)
+        d.scores, d.loss, d.n_pair, d.stats, d.dx = P(self._scores_store), P(self.loss), P(self.n_pair), P(self.stats), P(self._dx_store)
         d.ws, d.ws_bytes = P(self.ws), self.ws.numel()
         # optional second stream of the backward pass (weight-gradient products beside the data-gradient chain): pays at small
         # shards, where a single product leaves most of the chip idle (8192 rows: -12 % per step, eager); neutral at 65 536 rows
@@ -109,11 +124,13 @@ class DCNMixPairwiseStep(object):
         self._layer_events = None
         if reducer is not None:
             self._layer_events = (ctypes.c_void_p * L)(*[reducer.events[L - 1 - l].handle for l in range(L)])
-        # the library's own rule for the row-block kernels (csrc/dcnmix.hip `mix_tile_on`): two experts of 64, D = 256 / 512 / 1024, <= 16 384 rows
-        tile_env = os.environ.get('RECNOW_TILE')
-        self._tile_route = (N == 2 and S == 64 and D in (256, 512, 1024) and tile_env != '0' and (B <= 16384 or tile_env == '1')
-                            and lib.recnow_get_gemm_precision() == 0)
+        self._shape = (B_pad, D, S, N, L)
         self._bind_grads()                     # p.grad = the step's gradient storage, written in place by every step
+
+    def tile_route(self):
+        """Whether THIS call's cross layers run the row-block persistent kernels: the library's own rule (csrc/dcnmix.hip `mix_tile_on` through
+        recnow_dcn_mix_tile_route: shape, batch, RECNOW_TILE and the precision mode, read per call) -- asked, not restated."""
+        return bool(_lib.load().recnow_dcn_mix_tile_route(*self._shape))
 
     @staticmethod
     def stages_for(cross, head):
@@ -142,7 +159,8 @@ class DCNMixPairwiseStep(object):
         # hides on a side stream.  The row-block forward (csrc/dcnmix_tile.hip, batches <= 16 384 rows) holds every CU by itself: the
         # grouping's one workgroup only gets a CU when that launch drains, and the fork / join events are pure cost -- measured 0.676-0.687
         # (side) vs 0.667-0.672 ms (inline) per step at 8192 rows, 1.105 vs 1.087-1.091 ms at 16 384.
-        mode = os.environ.get('RECNOW_STEP_GROUP') or ('inline' if self._tile_route else 'side')
+        mode = os.environ.get('RECNOW_STEP_GROUP') or ('inline' if self.tile_route() else 'side')
+        self.group_mode = mode
         if mode == 'side':
             # grouping (sort by group id, segments) does not depend on the scores: on a side stream, under the forward pass
             _lib.call('recnow_event_record', self._fork.handle, _lib._P(main.cuda_stream))

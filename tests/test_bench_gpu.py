@@ -53,6 +53,33 @@ def test_self_launch_one_rank_force_dist_is_self_verifying(dev):
     assert par['gathered_batch_pairs_oracle']['pairs_equal'] and par['gathered_rows'] == 8192
     full = par['oracle_fp64_all_ranks']
     assert full['pairs_equal'] and len([k for k in full if k.startswith('cross.')]) == 15 and 'head.kernel' in full
+    # the N > 1 line describes itself: the dominant kernel by EXCLUSIVE time is a row-block kernel at this shard size, the route says where the
+    # grouping ran, and the price of the collectives is measured
+    roof = line['roofline']
+    assert roof['kernel'].startswith('k_mix_tile_'), roof['kernel']
+    assert 'row-block persistent kernels' in line['config']['route'] and 'on the main stream in front of the forward pass' in line['config']['route']
+    excl = roof['exclusive_ms_per_step']
+    assert any(k.startswith('grouping') for k in excl) and any(k.startswith('loss stage') for k in excl)
+    assert 0.5 * line['ms_per_step'] < roof['exclusive_covered_ms_per_step'] < 1.5 * line['ms_per_step']
+    assert abs(sum(excl.values()) - roof['exclusive_covered_ms_per_step']) < 1e-6 * max(1.0, roof['exclusive_covered_ms_per_step'])
+    assert 'comm_exposed_ms' in line and line['comm']['with_collectives_ms'] > 0 and line['comm']['without_collectives_ms'] > 0
+    assert line['ms_per_step_per_rank']['min'] <= line['ms_per_step_per_rank']['max'] and len(line['ms_per_step_per_rank']['ranks']) == 1
+
+
+def test_ragged_shard_runs_within_a_few_percent_of_the_aligned_one(dev):
+    """`--rows 8177 --force-dist`: a ragged per-rank batch (whole groups per rank are never multiples of 256) on the fast route -- padded
+    storage, same kernels -- self-verifying like every N > 1 line, and as fast as the 8192-row shard (the driver's box-to-box spread is
+    +-3 %; 10 % here: two short runs on a shared box)."""
+    def run(rows):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--rows', str(rows), '--steps', '30', '--warmup', '5',
+                              '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, cwd=ROOT, env=_clean_env())
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    ragged, aligned = run(8177), run(8192)
+    assert ragged['parity']['ok'] and ragged['parity']['gathered_rows'] == 8177 and ragged['config']['rows_per_rank'] == [8177]
+    assert 'ragged batch on padded storage (8177 -> 8192 rows)' in ragged['config']['route']
+    assert ragged['roofline']['kernel'].startswith('k_mix_tile_')
+    assert ragged['ms_per_step'] <= 1.10 * aligned['ms_per_step'], (ragged['ms_per_step'], aligned['ms_per_step'])
 
 
 def test_more_ranks_than_gpus_fails_cleanly(dev):
@@ -65,14 +92,19 @@ def test_more_ranks_than_gpus_fails_cleanly(dev):
 
 def test_two_ranks_share_one_gpu_over_gloo_and_verify_across_ranks(dev):
     """The N > 1 step with REAL multi-rank semantics on a one-GPU box: two ranks (two processes on GPU 0, `--backend gloo --oversubscribe`) own the two
-    4096-row halves of one global batch (whole groups per rank, ids distinct across ranks), the step route writes its gradients into the layer-wise
+    shards of ONE global batch of 8192 rows split by `dp.shard_rows_by_group` (`--shard hash`: whole groups per rank, ragged shard sizes), the step route writes its gradients into the layer-wise
     reducer's buckets, every bucket is all-reduced across the two processes, and the cross-rank gate holds the reduced loss / pair count to the C pair
     oracle on the ALL-GATHERED batch and all 17 all-reduced weight gradients to the sum of the two ranks' fp64 oracles."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--oversubscribe', '--rows', '4096',
-                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=_clean_env())
+                          '--shard', 'hash', '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=_clean_env())
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['backend'] == 'gloo'
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['backend'] == 'gloo' and line['shard'] == 'hash'
+    # --shard hash: ONE global batch of 8192 rows split by dp.shard_rows_by_group -- whole groups per rank, RAGGED shards on padded storage
+    rr = line['config']['rows_per_rank']
+    assert sum(rr) == 8192 and len(rr) == 2 and all(r % 256 for r in rr), rr
+    assert 'ragged batch on padded storage' in line['config']['route']
+    assert 'comm_exposed_ms' in line and len(line['ms_per_step_per_rank']['ranks']) == 2
     par = line['parity']
     assert par['gathered_rows'] == 8192 and par['gathered_batch_pairs_oracle']['pairs_equal']
     full = par['oracle_fp64_all_ranks']

@@ -48,3 +48,30 @@ def test_fm_single_tensor_is_wrapped_B11(dev):
     from rec_now_amd.layers.fm_layer import FMLayer
     out = FMLayer()(torch.rand(5, 8, device=dev))
     assert float(out.abs().max()) < 1e-6
+
+
+def test_config1_fm_into_pointwise_bce_fwd_bwd_vs_oracle(dev):
+    """BASELINE.json configs[0] as ONE composition: FMLayer over 32 fields of (1024, 8) -> logit (B, 1) -> pointwise BCE
+    (`sigmoid_cross_entropy_with_logits`, mean = `focal_crossentropy_loss(alpha=None, gamma=None)`, rec_block/focal_loss.py:48) -> the
+    gradient of every field tensor.  SURVEY 8d c1: x ~ U(-0.05, 0.05), labels ~ Bernoulli(0.25), seed 1.
+    /root/reference/rec_now/layers/fm_layer.py:24-42."""
+    from rec_now_amd.layers.fm_layer import FMLayer
+    from rec_now_amd.rec_block.focal_loss import focal_crossentropy_loss
+    B, F, D = 1024, 32, 8
+    rng = np.random.default_rng(1)
+    xs = [rng.uniform(-0.05, 0.05, (B, D)).astype(np.float32) for _ in range(F)]
+    labels = (rng.random((B, 1)) < 0.25).astype(np.float32)
+    for gain in (1.0, 40.0):        # c1's own scale (logits ~ 1e-2: the loss sits near ln 2), and logits of O(1) where sigmoid' is not flat
+        xd = [torch.from_numpy(x * np.float32(gain)).to(dev).requires_grad_(True) for x in xs]
+        loss = focal_crossentropy_loss(torch.from_numpy(labels).to(dev), FMLayer()(xd), alpha=None, gamma=None, return_mean=True)
+        loss.backward()
+        x64 = [torch.from_numpy(x * np.float32(gain)).double().requires_grad_(True) for x in xs]
+        ref = R.focal_crossentropy_loss(torch.from_numpy(labels).double(), R.fm_layer(x64), alpha=None, gamma=None, return_mean=True)
+        ref.backward()
+        assert abs(float(loss) - float(ref)) <= RTOL * abs(float(ref)), (gain, float(loss), float(ref))
+        if gain > 1.0:
+            assert abs(float(ref) - np.log(2.0)) > 1e-2
+        gs = max(np.abs(b.grad.numpy()).max() for b in x64)
+        for a, b in zip(xd, x64):
+            assert a.grad.shape == (B, D)
+            assert np.abs(a.grad.cpu().numpy() - b.grad.numpy()).max() <= RTOL * gs, gain

@@ -188,6 +188,93 @@ def test_step_route_at_the_metric_batch_vs_oracle(dev):
         close(p.grad, rgrads[name], what=name, scale=np.abs(rds).sum() if name == 'head/bias' else None)
 
 
+def _oracle_step(x, groups, labels, cross, head, L, grouped=True):
+    """fp64 chunked oracle of the layers + the C pair oracle: (scores, loss, d loss / d score, pairs, dx, {name: grad}, named weights)."""
+    named = dict(cross.named_weights())
+    named['head/kernel'], named['head/bias'] = head.kernel, head.bias
+    w64 = weights64(named)
+    fwd = _mix_fwd(w64, L, head=True)
+    (rs,), _, _ = run_chunked(fwd, torch.from_numpy(x), None, w64, chunk=4096, want_dx=False)
+    rloss, rds, rP = PO.pairwise_bpr(groups, labels, rs.astype(np.float32), grouped=grouped)
+    _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), torch.from_numpy(rds), w64, chunk=4096)
+    return rs, rloss, rds, rP, rdx, rgrads, named
+
+
+@pytest.mark.parametrize('B,reduced', [(8177, True), (16411, True), (65500, False)])
+def test_ragged_batches_on_the_fast_route_vs_oracle(dev, one_rank_rccl, B, reduced):
+    """The batches data parallelism really produces: whole groups per rank (dp.shard_rows_by_group), i.e. B % 256 != 0.  The step owns
+    padded storage (recnow_dcn_mix_step_desc.B_pad: zero rows of x, zero d loss / d score) and runs the SAME kernels as a full batch --
+    8177 and 16 411 rows on the row-block persistent kernels through the reducer over a 1-rank RCCL group, 65 500 rows on the
+    launch-per-product route -- against the fp64 oracle of the B rows: loss, pair count, scores, d loss / d x, all 17 weight gradients.
+    /root/reference/rec_now/rec_block/pairwise_loss_from_batch.py:254-279, layers/dcn_mix_layer.py:114-151."""
+    from rec_now_amd import _lib, dp
+    from rec_now_amd.fused import GpuEvent
+    from rec_now_amd.step import DCNMixPairwiseStep
+    D, S, N, L = 1024, 64, 2, 3
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 900 + B)
+    reducer = None
+    if reduced:
+        stages = DCNMixPairwiseStep.stages_for(cross, head)
+        reducer = dp.LayerwiseReducer(stages, [GpuEvent() for _ in stages], dev)
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd, reducer=reducer, two_streams=reduced)
+    assert step.B == B and step.B_pad == -(-B // 256) * 256 and step.x.shape[0] == B and step.x.data_ptr() != xd.data_ptr()
+    assert step.tile_route() == bool(_lib.load().recnow_dcn_mix_tile_route(step.B_pad, D, S, N, L)) == (B <= 16384)
+    rs, rloss, rds, rP, rdx, rgrads, named = _oracle_step(x, groups, labels, cross, head, L)
+    assert rP > B and abs(rloss - np.log(2.0)) > 1e-3
+    for f in (reducer._flat if reduced else step.grads):
+        f.fill_(float('nan'))
+    step._dx_store.fill_(float('nan'))
+    step._scores_store.fill_(float('nan'))
+    for rep in range(2):                  # twice: the second step runs on the storage the first one left (padding rows still zero)
+        loss, p_glob = step.run()
+    torch.cuda.synchronize()
+    assert int(p_glob.item()) == rP and int(step.n_pair.item()) == rP
+    close(step.scores, rs, what='scores')
+    close(loss, np.float64(rloss), what='loss')
+    div = (np.float32(rP) + np.float32(1e-10)) if reduced else np.float32(1.0)      # under a reducer dx is the loss SUM's gradient
+    close(step.dx / div, rdx, what='dx')
+    for name, p in named.items():
+        close(p.grad, rgrads[name], what=name, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+    # the padding: x rows stay zero, their dx is exactly zero, their scores are the head bias
+    assert not step._x_store[B:].any() and not step._dx_store[B:].any()
+    assert torch.equal(step._scores_store[B:], torch.full_like(step._scores_store[B:], float(head.bias.reshape(-1)[0])))
+
+
+def test_ragged_batch_layer_routes_vs_oracle(dev):
+    """B = 8177 through the drop-in routes: `head(cross(x))` + `pairwise_loss` as INTEGRATION.md writes it, and the fused node
+    `dcn_mix_score`.  Both run the exact-128 formulation on a zero-padded copy (layers/_ops.py `ragged_pad_rows`); the same batch
+    with the padding switched off (general kernels, leading dimension 160) is the third route.  All against the fp64 oracle."""
+    from rec_now_amd.fused import dcn_mix_score, score_params
+    from rec_now_amd.layers._ops import ragged_pad_rows
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+    B, D, S, N, L = 8177, 1024, 64, 2, 3
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 31)
+    assert ragged_pad_rows(B, D, S, N, L) == 8192 and ragged_pad_rows(8192, D, S, N, L) == 0 and ragged_pad_rows(300, D, S, N, L) == 0
+    rs, rloss, rds, rP, rdx, rgrads, named = _oracle_step(x, groups, labels, cross, head, L)
+    params = score_params(cross, head)
+    for route in ('drop-in', 'fused', 'drop-in unpadded'):
+        if route == 'drop-in unpadded':
+            os.environ['RECNOW_PAD_RAGGED'] = '0'
+        try:
+            for p in params:
+                p.grad = None
+            xr = xd.detach().clone().requires_grad_(True)
+            scores = dcn_mix_score(cross, head, xr) if route == 'fused' else head(cross(xr)).reshape(-1)
+            assert scores.shape == (B,)
+            loss, n_pair = pairwise_loss(scores, yd, gd, return_num_pair=True)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop('RECNOW_PAD_RAGGED', None)
+        assert int(n_pair.item()) == rP, route
+        close(scores, rs, what='scores ' + route)
+        close(loss, np.float64(rloss), what='loss ' + route)
+        assert xr.grad.shape == (B, D)
+        close(xr.grad, rdx, what='dx ' + route)
+        for name, p in named.items():
+            close(p.grad, rgrads[name], what=name + ' ' + route, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+
+
 def test_gradient_accumulation_onto_bucket_views(dev):
     """dp.LayerwiseReducer + fused.dcn_mix_score(grad_buffers=...): a second backward without clearing the gradients must ADD to
     p.grad (= the bucket view), not overwrite it."""
