@@ -56,7 +56,10 @@ def test_self_launch_one_rank_force_dist_is_self_verifying(dev):
     # the N > 1 line describes itself: the dominant kernel by EXCLUSIVE time is a row-block kernel at this shard size, the route says where the
     # grouping ran, and the price of the collectives is measured
     roof = line['roofline']
-    assert roof['kernel'].startswith('k_mix_tile_'), roof['kernel']
+    # (8192 rows: the six K = B weight-gradient products on 64-row tiles, or one of the two row-block launches -- never the 128 x 128 family, which
+    # does not run at this size; round 4's line named it)
+    assert roof['kernel'].startswith('k_mix_tile_') or roof['kernel'].startswith('k_gemm<64,128'), roof['kernel']
+    assert any(k.startswith('k_mix_tile_fwd') for k in roof['exclusive_ms_per_step']) and any(k.startswith('k_mix_tile_bwd') for k in roof['exclusive_ms_per_step'])
     assert 'row-block persistent kernels' in line['config']['route'] and 'on the main stream in front of the forward pass' in line['config']['route']
     excl = roof['exclusive_ms_per_step']
     assert any(k.startswith('grouping') for k in excl) and any(k.startswith('loss stage') for k in excl)
@@ -78,7 +81,7 @@ def test_ragged_shard_runs_within_a_few_percent_of_the_aligned_one(dev):
     ragged, aligned = run(8177), run(8192)
     assert ragged['parity']['ok'] and ragged['parity']['gathered_rows'] == 8177 and ragged['config']['rows_per_rank'] == [8177]
     assert 'ragged batch on padded storage (8177 -> 8192 rows)' in ragged['config']['route']
-    assert ragged['roofline']['kernel'].startswith('k_mix_tile_')
+    assert ragged['roofline']['kernel'].startswith('k_mix_tile_') or ragged['roofline']['kernel'].startswith('k_gemm<64,128')
     assert ragged['ms_per_step'] <= 1.10 * aligned['ms_per_step'], (ragged['ms_per_step'], aligned['ms_per_step'])
 
 
