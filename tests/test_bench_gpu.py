@@ -74,7 +74,7 @@ def test_ragged_shard_runs_within_a_few_percent_of_the_aligned_one(dev):
     storage, same kernels -- self-verifying like every N > 1 line, and as fast as the 8192-row shard (the driver's box-to-box spread is
     +-3 %; 10 % here: two short runs on a shared box)."""
     def run(rows):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--rows', str(rows), '--steps', '30', '--warmup', '5',
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--rows', str(rows), '--steps', '20', '--warmup', '3',
                               '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, cwd=ROOT, env=_clean_env())
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads(out.stdout.strip().splitlines()[-1])
