@@ -297,6 +297,13 @@ typedef struct recnow_gemm_desc {
      * fragments (k pairs (s, s + 4): no LDS round trip), H2 = mid_act_outer(C) -> mid_T2, G = softmax(logits), mid_T2g = [G * H2 | G | 0],
      * logits -> mid_T1[:, 128 + e].  mid_V (2, 64, 64); mid_T1 / mid_T2 / mid_T2g (N x mid_ld).  C is not written. */
     const float* mid_V; float* mid_T1; float* mid_T2; float* mid_T2g; int64_t mid_ld; int mid_act_outer; int mid_pad;
+    /* c2_mode 5 / 6 (ABI 4; short-K kernel, K = 144, b_trans 1, no emul / accumulate; C2 unused): the LAST product of a backward pass writes the
+     * whole input gradient in one go,
+     *   C[m][n] = acc + E2 * E3 [+ E4 * E5] + rv[m] * cv[n] * E6          (elementwise products; c2_mode 6 leaves the bracket out)
+     * all five tensors with the leading dimension lde2 (= lde3), every one read once, C written once and never read.  DCN-v2 (round 5): d loss / d x
+     * = g_0 + g_1 * O_0 + g_2 * O_1 + dscore (x) w_head * O_2 is accumulated ONCE, by the product that forms g_0, instead of as a read-modify-write in
+     * the product of every layer: 8 instead of 10 passes over a (B, D) tensor per step. */
+    const float* E4; const float* E5; const float* E6;
     /* a_trans = 0: A stored [M][K] (lda = row stride);  1: stored [K][M]
      * b_trans = 0: B stored [K][N] (ldb = row stride);  1: stored [N][K] */
 } recnow_gemm_desc;

@@ -126,6 +126,7 @@ class GemmDesc(ctypes.Structure):
         ('C2', _P), ('ldc2', _L), ('E2', _P), ('lde2', _L), ('c2_mode', _I), ('c2_pad', _I), ('as_in', _P), ('as_out', _P),
         ('E3', _P), ('lde3', _L), ('rv', _P), ('cv', _P), ('hv', _P), ('hp', _P), ('hp_ld', _I), ('hp_pad', _I), ('k_valid', _I), ('k_pad', _I), ('c_perm_s', _I), ('c_perm_pad', _I),
         ('mid_V', _P), ('mid_T1', _P), ('mid_T2', _P), ('mid_T2g', _P), ('mid_ld', _L), ('mid_act_outer', _I), ('mid_pad', _I),
+        ('E4', _P), ('E5', _P), ('E6', _P),
     ]
 
 ABI_VERSION = 4      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)

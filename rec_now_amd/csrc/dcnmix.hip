@@ -985,6 +985,10 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             RN_LAUNCH_CHECK();
         }
     }
+    // the input gradient in one go (c2_mode 5 / 6 of the short-K kernel: two experts of 64, K = 144): fused head, 2 or 3 layers.  RECNOW_DX_ONCE=0: the
+    // read-modify-write chain of rounds 1-4 (A/B switch, read per call).  A pass cut into layer pieces decides the same way in every piece.
+    const char* dx_once_env = getenv("RECNOW_DX_ONCE");
+    const bool dx_once = hd && dx && (L == 2 || L == 3) && m.KP == 144 && !(dx_once_env && dx_once_env[0] == '0');
     hipEvent_t e_g = nullptr;        // "g of this layer (and the packs) are ready" -> side stream may start the layer
     MIX_SIGNAL(e_g, st);
     hipEvent_t e_side_prev = nullptr;   // side stream finished the previous (higher) layer: dT1/dC/g buffers reusable
@@ -1076,10 +1080,24 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             d.M = (int)B; d.N = D; d.K = m.KP; d.k_valid = m.KC;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.accumulate = (l == 0) ? 1 : 0;
+            if (dx_once) {
+                // Round 5: d loss / d x = g_0 + g_1 * O_0 [+ g_2 * O_1] + dscore (x) w_head * O_{L-1} is written ONCE, by layer 0's product (c2_mode 5 / 6):
+                // the products of the layers above leave g_l alone (1 pass over B x D each instead of 4), layer 0's reads g_1, O_0, g_2, O_1, O_{L-1}
+                // and writes dx (6 instead of 2): 8 passes per step where the read-modify-write chain took 10.  g_1 / g_2 sit in the two ping-pong
+                // buffers until then (hence L <= 3).
+                if (l == 0) {
+                    d.accumulate = 0;
+                    d.c2_mode = (L == 3) ? 5 : 6;
+                    d.E2 = gbuf0; d.E3 = omid; d.lde2 = d.lde3 = D;                                       // g_1 (layer 1 writes gbuf0), O_0
+                    if (L == 3) { d.E4 = gbuf1; d.E5 = omid + (size_t)1 * (xbuf(m) / sizeof(float)); }    // g_2, O_1
+                    d.E6 = omid + (size_t)(L - 1) * (xbuf(m) / sizeof(float)); d.rv = hd->dscores; d.cv = hd->w;
+                }
+            } else {
             if (l > 0 && dx) { d.C2 = dx; d.ldc2 = D; d.E2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.lde2 = D; d.c2_mode = 2; }
             if (hd && l == L - 1 && l > 0 && dx) {       // first write of dx: g_{l-1} * O_{l-1} + dscore (x) w_head * O_{L-1}
                 d.c2_mode = 4;
                 d.E3 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.lde3 = D; d.rv = hd->dscores; d.cv = hd->w;
+            }
             }
             if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
         }

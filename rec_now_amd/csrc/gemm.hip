@@ -249,7 +249,16 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     k.C2 = d->C2; k.E2 = d->E2; k.ldc2 = d->ldc2; k.lde2 = d->lde2;
     k.as_in = d->as_in; k.as_out = d->as_out;
     if ((d->as_in != nullptr) != (d->as_out != nullptr)) return RECNOW_EINVAL;
-    if (d->c2_mode < 0 || d->c2_mode > 4 || (d->c2_mode && d->c2_mode != 3 && !d->C2) || ((d->c2_mode == 2 || d->c2_mode == 4) && !d->E2)) return RECNOW_EINVAL;
+    if (d->c2_mode < 0 || d->c2_mode > 6 || (d->c2_mode && d->c2_mode != 3 && d->c2_mode < 5 && !d->C2) || ((d->c2_mode == 2 || d->c2_mode >= 4) && !d->E2))
+        return RECNOW_EINVAL;
+    if (d->c2_mode >= 5) {      // the input gradient in one go: C = acc + E2 * E3 [+ E4 * E5] + rv (x) cv * E6
+        if (!d->E3 || !d->E6 || !d->rv || !d->cv || ((uintptr_t)d->cv & 15) || d->lde2 != d->lde3 || d->emul || d->accumulate || (d->c2_mode == 5 && (!d->E4 || !d->E5)))
+            return RECNOW_EINVAL;
+        if (!host_aligned(d->E2, d->lde2, 0) || !host_aligned(d->E3, d->lde2, 0) || !host_aligned(d->E6, d->lde2, 0) ||
+            (d->c2_mode == 5 && (!host_aligned(d->E4, d->lde2, 0) || !host_aligned(d->E5, d->lde2, 0))))
+            return RECNOW_EUNSUPPORTED;
+    }
+    k.E4 = d->E4; k.E5 = d->E5; k.E6 = d->E6;
     if (d->c2_mode == 3 && (!d->hv || !d->hp || !d->emul || d->hp_ld < d->N / 64 || ((uintptr_t)d->hv & 15))) return RECNOW_EINVAL;
     if (d->c2_mode == 4 && (!d->E3 || !d->rv || !d->cv || ((uintptr_t)d->cv & 15) || !host_aligned(d->E3, d->lde3, 0))) return RECNOW_EINVAL;
     k.E3 = d->E3; k.lde3 = d->lde3; k.rv = d->rv; k.cv = d->cv; k.hv = d->hv; k.hp = d->hp; k.hp_ld = d->hp_ld;
@@ -305,7 +314,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
         const double mk = (double)d->M * d->K, kn = (double)d->K * d->N, mn = (double)d->M * d->N;
         const double elems = mk * (1 + (d->a_mode && d->a_mode != RECNOW_OPMODE_OUTER ? 1 : 0)) + kn * (1 + (d->b_mode && d->b_mode != RECNOW_OPMODE_OUTER ? 1 : 0)) +
                              mn * (1 + (d->emul ? 1 : 0) + (d->accumulate ? 1 : 0)) +
-                             (d->c2_mode == 1 ? mn : d->c2_mode == 2 ? 3 * mn : d->c2_mode == 3 ? 0.0 : d->c2_mode == 4 ? 3 * mn : 0.0) +
+                             (d->c2_mode == 1 ? mn : d->c2_mode == 2 ? 3 * mn : d->c2_mode == 3 ? 0.0 : d->c2_mode == 4 ? 3 * mn : d->c2_mode == 5 ? 5 * mn : d->c2_mode == 6 ? 3 * mn : 0.0) +
                              (d->as_out ? 2 * mk : 0.0);
         pr = rn_prof_begin(tag, d->prof_flops > 0.0 ? d->prof_flops : 2.0 * d->M * d->N * (double)d->K * d->batch, 4.0 * elems * d->batch, st);
     }
@@ -341,7 +350,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
         }
     } else if (use_shortk) {
         // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)
-        if (d->c2_mode && ((d->C2 && !host_aligned(d->C2, d->ldc2, 0)) || ((d->c2_mode == 2 || d->c2_mode == 4) && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
+        if (d->c2_mode && d->c2_mode < 5 && ((d->C2 && !host_aligned(d->C2, d->ldc2, 0)) || ((d->c2_mode == 2 || d->c2_mode == 4) && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
         rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, st);
         if (rc) return rc;
     } else if (d->c2_mode) {

@@ -42,6 +42,7 @@ struct GemmK {
     int64_t ldc2, lde2;        //   4: C2 = acc * E2 + rv[m] * cv[n] * E3, C2 is not read)
     const float* E3;           // c2_mode 4: third epilogue tensor (leading dimension lde3)
     int64_t lde3;
+    const float *E4, *E5, *E6; // c2_mode 5 / 6: C = acc + E2 * E3 [+ E4 * E5] + rv (x) cv * E6 (all with the leading dimension lde2)
     const float *rv, *cv;      // c2_mode 4: row / column vectors of the rank-one factor
     const float* hv;           // c2_mode 3: column vector of the fused row-dot (the scoring head's kernel)
     float* hp;                 // c2_mode 3: partials hp[m][hp_ld], entry 2 * column tile + wave column

@@ -24,6 +24,9 @@
 // 3 (scoring head folded into the last cross layer): C2 = acc, C = acc * emul is NOT stored, its row-dot with hv leaves as
 //   partials hp[m][2 * column tile + wave column] (fixed order, summed by the consumer);
 // 4 (first dx write of the backward): C = acc, C2 = acc * E2 + rv[m] * cv[n] * E3[m][n] (C2 is written, never read).
+// 5 / 6 (round 5: the input gradient accumulated ONCE, by the last product of the backward pass): C = acc + E2 * E3 [+ E4 * E5] + rv[m] * cv[n] * E6
+//   (6: without the bracket); three / five (B, D) tensors read once, C written once.  Their epilogue moves in HALF sub-tiles (16 rows): two
+//   register sets of 2 x 5 float4 instead of 4 x 5 per set, the loads of half s + 1 requested before half s is combined and stored.
 // Workgroups per CU (= waves per SIMD): the epilogue's operand registers set it.  These products are HBM-bound, three or two
 // co-resident workgroups still cover each other's epilogues; spilling the epilogue operands to scratch does not.
 // PRE: the whole tile of `emul` (64 registers per lane) is requested BEFORE the tile's k-loop, so it lands under the MFMAs and the
@@ -39,7 +42,7 @@
 #define SK_STS4(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
 #endif
 __host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL, bool PRE, int NK = 0) {
-    return (DUAL == 4 || PRE || (NK > 0 && DUAL == 2)) ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3 || NK > 0) ? 3 : 4;      // ring schedule: 32 more operand registers
+    return (DUAL >= 4 || PRE || (NK > 0 && DUAL == 2)) ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3 || NK > 0) ? 3 : 4;      // ring schedule: 32 more operand registers
 }
 
 // NK > 0 (the depth in k-tiles as a template parameter, NK % 3 == 0): the RING schedule.  Per-workgroup timestamps (tools/gemm_trace.py)
@@ -75,6 +78,8 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     const int nk = p.K / SK_BK;
     const int ntiles = row_tiles * col_tiles;
     constexpr bool EARLY = NK >= 3 && ((EP && !PRE) || DUAL == 2 || DUAL == 4);       // ring schedule with epilogue loads
+    constexpr bool ONCE = DUAL == 5 || DUAL == 6;                                     // C = acc + E2 * E3 [+ E4 * E5] + rv (x) cv * E6
+    static_assert(!ONCE || (EP == 0 && NK >= 3), "the one-go input gradient: ring schedule, no emul / accumulate");
 
     // slot (= workgroup index + round * grid) -> tile.  XCD-aware: slots of one XCD enumerate (row tile, column tile) with
     // the column tile fastest; row tiles are dealt round-robin to the 8 XCDs.
@@ -253,6 +258,29 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 }
             }
         };
+        // ONCE: operands of half sub-tile `step` = 2 * s2 + h (rows i * 32 + 16 h + 8 q + rr0, q = 0, 1) into register set `buf`
+        f32x4 o5[ONCE ? 2 : 1][5][2];
+        float r5[ONCE ? 2 : 1][2];
+        const float* F1t = ONCE ? p.E2 + (int64_t)m0 * p.lde2 + n0 : nullptr;
+        const float* G1t = ONCE ? p.E3 + (int64_t)m0 * p.lde2 + n0 : nullptr;
+        const float* F2t = DUAL == 5 ? p.E4 + (int64_t)m0 * p.lde2 + n0 : nullptr;
+        const float* G2t = DUAL == 5 ? p.E5 + (int64_t)m0 * p.lde2 + n0 : nullptr;
+        const float* H6t = ONCE ? p.E6 + (int64_t)m0 * p.lde2 + n0 : nullptr;
+        auto issue5 = [&](int step, int buf) {
+            const int s2 = step >> 1, h = step & 1, i = s2 >> 1, j = s2 & 1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int64_t off = (int64_t)(i * 32 + 16 * h + q * 8) * p.lde2 + j * 32 + f_lane;
+                o5[ONCE ? buf : 0][0][q] = SK_LDS4(F1t + off);
+                o5[ONCE ? buf : 0][1][q] = SK_LDS4(G1t + off);
+                if (DUAL == 5) {
+                    o5[ONCE ? buf : 0][2][q] = SK_LDS4(F2t + off);
+                    o5[ONCE ? buf : 0][3][q] = SK_LDS4(G2t + off);
+                }
+                o5[ONCE ? buf : 0][4][q] = SK_LDS4(H6t + off);
+                r5[ONCE ? buf : 0][q] = p.rv[m0 + wm * 64 + i * 32 + 16 * h + q * 8 + rr0];
+            }
+        };
         if (NK) {
 #pragma unroll
             for (int t = 0; t < (NK ? NK : 1); ++t) {
@@ -264,6 +292,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 // epilogue operands of sub-tile 0: requested three k-tiles early (behind this k-tile's ring loads: the ring wait two k-tiles on
                 // is the first one that stands behind them), so the epilogue starts on landed data
                 if (EARLY && t == NK - 3) issue(0, 0);
+                if (ONCE && t == NK - 3) issue5(0, 0);
                 if (t == NK - 1) ktile(cur, p.tail_pairs);
                 else ktile(cur, SK_BK / 2);
                 ring_store((t + 1) % 3, smem + (cur ^ 1) * BUF);
@@ -297,7 +326,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
         // buffer `fr` was consumed by the last k-tile and is free: staging space of the epilogue (16 rows x 36 per wave)
         const int fr = (f + nk - 1) & 1;
         float* stg = smem + fr * BUF + wave * (16 * 36);
-        if (DUAL == 3 || DUAL == 4) {
+        if (DUAL == 3 || DUAL == 4 || ONCE) {
             const float* colv = (DUAL == 3 ? p.hv : p.cv) + n0 + wn * 64 + cc;
             hv4[0] = *reinterpret_cast<const f32x4*>(colv);
             hv4[1] = *reinterpret_cast<const f32x4*>(colv + 32);
@@ -310,6 +339,7 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
             if (DUAL == 3 && j == 0) hs[0] = hs[1] = hs[2] = hs[3] = 0.f;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {          // accumulator registers 8h..8h+7 hold rows 16h..16h+15 of the sub-tile
+                if (ONCE && 2 * s2 + h + 1 < 8) issue5(2 * s2 + h + 1, (h ^ 1));      // (2 s2 + h) & 1 = h: the sets alternate with h
 #pragma unroll
                 for (int r = 0; r < 8; ++r) stg[((r & 3) + 8 * (r >> 2) + row_l) * 36 + col_l] = acc[i][j][8 * h + r];
                 RN_LDS_WAVE_SYNC();
@@ -317,6 +347,13 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rr0) * 36 + cc);
                     f32x4 v = a;
+                    if (ONCE) {
+                        // the order of the former three launches: (g_2 * O_1 + (w_head * ds) * O_2) + g_1 * O_0, then + g_0
+                        f32x4 t = (hv4[j] * r5[ONCE ? h : 0][q]) * o5[ONCE ? h : 0][4][q];
+                        if (DUAL == 5) t = o5[ONCE ? h : 0][2][q] * o5[ONCE ? h : 0][3][q] + t;
+                        t = o5[ONCE ? h : 0][0][q] * o5[ONCE ? h : 0][1][q] + t;
+                        v = t + a;
+                    }
                     if (EP & 1) v = v * (PRE ? evt[PRE ? s2 : 0][2 * h + q] : ev[buf][2 * h + q]);
                     if (EP & 2) v = v + (PRE ? evt[PRE ? s2 : 0][2 * h + q] : cv[buf][2 * h + q]);
                     if (DUAL != 3) SK_STS4(Ct + (int64_t)(i * 32 + 16 * h + q * 8) * p.ldc + j * 32 + c_lane, v);
@@ -394,7 +431,7 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
 int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st) {
     static const bool pre = []() { const char* e = getenv("RECNOW_SK_PRE"); return !e || e[0] != '0'; }();     // A/B switch of the whole-tile emul prefetch
     // nine k-tiles (DCN-v2: K = N*S + N = 130 stored as 144): the ring schedule; RECNOW_SK_RING=0 is the A/B switch
-    static const int ring = []() { const char* e = getenv("RECNOW_SK_RING"); return e ? atoi(e) : 15; }();
+    static const int ring = []() { const char* e = getenv("RECNOW_SK_RING"); return e ? atoi(e) : 31; }();
     if (k.K == 9 * SK_BK && (ring & 1) && pre && !b_kc && ep == 1) {
         if (c2_mode == 1) return launch_sk<false, 1, 1, true, 9>(k, st);
         if (c2_mode == 3) return launch_sk<false, 1, 3, true, 9>(k, st);
@@ -411,7 +448,11 @@ int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStr
     if (k.K == 9 * SK_BK && b_kc && ep == 0) {
         if (c2_mode == 2 && (ring & 2)) return launch_sk<true, 0, 2, false, 9>(k, st);
         if (c2_mode == 4 && (ring & 8)) return launch_sk<true, 0, 4, false, 9>(k, st);
+        if (c2_mode == 5) return launch_sk<true, 0, 5, false, 9>(k, st);
+        if (c2_mode == 6) return launch_sk<true, 0, 6, false, 9>(k, st);
+        if (c2_mode == 0 && (ring & 16)) return launch_sk<true, 0, 0, false, 9>(k, st);      // g_l alone (the input gradient is accumulated once, c2_mode 5 / 6)
     }
+    if (c2_mode >= 5) return RECNOW_EUNSUPPORTED;
     if (pre && !b_kc && ep == 1) {
         if (c2_mode == 1) return launch_sk<false, 1, 1, true>(k, st);
         if (c2_mode == 3) return launch_sk<false, 1, 3, true>(k, st);

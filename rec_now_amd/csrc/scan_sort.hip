@@ -438,9 +438,11 @@ __device__ __forceinline__ bool gm_barrier(GroupMidCtl* ctl, unsigned target) {
     return s_err == 0;
 }
 // A barrier timed out (the workgroups were not co-resident: the host gates this route on the occupancy query, so this is a last line of
-// defence; RECNOW_DEBUG_GROUP_TIMEOUT=1 forces it for the tests): leave a SAFE grouping instead of half-written arrays -- every row its own
-// group (no pairs, in-bounds walks for every consumer) -- and n_seg = -1, which `Segments.num_segments()` / `recnow_group_segments_status`
-// report and which makes the one-call losses return NaN (k_pair_norm_grad, k_step_dscore, k_lw_norm).
+// defence; RECNOW_DEBUG_GROUP_TIMEOUT=1 forces it for the tests): this workgroup leaves the identity grouping in ITS ranges -- every row its own
+// group -- so that whatever the other workgroups have written or still write, every index in the arrays stays in [0, B] (in-bounds walks for
+// every consumer; NOT necessarily a consistent grouping when only some workgroups bail), and n_seg = -1, which `Segments.num_segments()` /
+// `recnow_group_segments_status` report and which makes the one-call losses return NaN (k_pair_norm_grad, k_step_dscore, k_lw_norm).  Workgroup 0
+// publishes the segment count last and re-reads the error word before it does (end of the kernel).
 #define GM_BAIL()                                                                                                    \
     do {                                                                                                             \
         for (int q_ = 0; q_ < TILE / 256; ++q_) {                                                                 \
@@ -764,9 +766,15 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
         super_id[k] = sup - 1;
     }
     if (g == 0 && tid == 0) {
+        // a workgroup can time out at the LAST barrier and set ctl->err just as the last arrival completes the count; its peers
+        // may have read err before that and passed.  The bailing workgroup then rewrites ITS ranges with the identity grouping while the others
+        // write real segments -- every value stays in [0, B] (walks stay in bounds), but the arrays are not a grouping.  So the error word is
+        // read once more here, after this workgroup's own writes, and the count is published as -1 (every consumer poisons its result on
+        // n_seg < 0) whenever any workgroup has reported a time-out by now.
+        const int late = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seg_first[allh] = (int32_t)B;
-        n_seg[0] = allh;
-        n_seg[1] = alls;
+        n_seg[0] = late ? -1 : allh;
+        n_seg[1] = late ? -1 : alls;
     }
 }
 

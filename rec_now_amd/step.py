@@ -159,7 +159,10 @@ class DCNMixPairwiseStep(object):
         # hides on a side stream.  The row-block forward (csrc/dcnmix_tile.hip, batches <= 16 384 rows) holds every CU by itself: the
         # grouping's one workgroup only gets a CU when that launch drains, and the fork / join events are pure cost -- measured 0.676-0.687
         # (side) vs 0.667-0.672 ms (inline) per step at 8192 rows, 1.105 vs 1.087-1.091 ms at 16 384.
-        mode = os.environ.get('RECNOW_STEP_GROUP') or ('inline' if self.tile_route() else 'side')
+        # Round 5, 65 536 rows (tools/ab_env.sh, one box, two alternating repetitions): side 3.362 / 3.391, inline 3.350 / 3.351, after 3.362 / 3.370 ms per step.
+        # Since the integer-image sort (round 4) the grouping launch takes 42-50 us by itself; under the forward GEMMs it was stretched to 160-280 us
+        # of shared CUs and bought nothing back: inline everywhere (RECNOW_STEP_GROUP=side keeps the side-stream placement for A/B).
+        mode = os.environ.get('RECNOW_STEP_GROUP') or 'inline'
         self.group_mode = mode
         if mode == 'side':
             # grouping (sort by group id, segments) does not depend on the scores: on a side stream, under the forward pass
