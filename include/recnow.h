@@ -609,8 +609,12 @@ int recnow_focal_loss_bwd(const float* labels, const float* logits, int64_t B, f
  *                          drows / row_ids hold N slots.  The entry range is cut into fixed chunks (a hot id may own millions of
  *                          entries); pieces are joined in ascending chunk order (ws: recnow_embed_rows_bwd_workspace_bytes).
  *   recnow_embed_scatter_rows: dtable[row_ids[s]][:] = drows[s][:] into a zero-initialised dense (V,D) gradient. */
+/* id_limit / key32 (ABI 4): id_limit = V > 0 says the ids index a table of V rows (V < 2^31 - 1): entries that are not pooled AND ids outside
+ * [0, V) then carry the key V instead of INT64_MIN -- it sorts last and is dropped like every id outside the table -- and key32 (optional,
+ * N int32) receives the same keys as 32-bit values: the sort of the backward pass runs on ONE key word (three 8-bit digit passes for
+ * V = 2^20 instead of four on two words).  id_limit = 0, key32 = NULL: the INT64_MIN form (ids of unknown range: the unique path). */
 int recnow_slot_targets(const void* slots, int slot_dtype, const void* targets, int T, const int64_t* ids, int64_t N,
-                        int32_t* seg, int64_t* key, void* stream);
+                        int32_t* seg, int64_t* key, int64_t id_limit, int32_t* key32, void* stream);
 int recnow_embed_pool_fwd(const float* table, int D, int64_t V, const int64_t* rows, const int32_t* seg, const float* weights,
                           int64_t B, int C, int T, int mean, float* out, float* cnt, void* stream);
 int recnow_embed_pool_bwd_weights(const float* table, int D, int64_t V, const int64_t* rows, const int32_t* seg, const float* cnt,
@@ -622,8 +626,9 @@ int recnow_embed_rows_bwd(const int64_t* key, const int32_t* order, const int32_
                           const int32_t* n_seg, const int32_t* seg, const float* weights, const float* cnt, const float* dout,
                           int64_t N, int C, int T, int D, int mean, float* drows, int64_t* row_ids, void* ws, size_t ws_bytes,
                           void* stream);
+/* n_seg (ABI 4, optional DEVICE pointer: the segment count of recnow_group_segments): only the first n_seg[0] slots are read. */
 int recnow_embed_scatter_rows(const float* drows, const int64_t* row_ids, int64_t n_slots, int D, int64_t V, float* dtable,
-                              void* stream);
+                              const int32_t* n_seg, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): per-launch HIP-event timing of the GEMM kernels on the launch stream.

@@ -92,13 +92,13 @@ SIGNATURES = {
     'recnow_focal_loss_workspace_bytes': (_Z, [_L]),
     'recnow_focal_loss_fwd': (_I, [_P, _P, _L, _F, _F, _P, _P, _P, _Z, _P]),
     'recnow_focal_loss_bwd': (_I, [_P, _P, _L, _F, _F, _I, _P, _P, _F, _P, _P]),
-    'recnow_slot_targets': (_I, [_P, _I, _P, _I, _P, _L, _P, _P, _P]),
+    'recnow_slot_targets': (_I, [_P, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P]),
     'recnow_embed_pool_fwd': (_I, [_P, _I, _L, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'recnow_embed_pool_bwd_weights': (_I, [_P, _I, _L, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     'recnow_embed_unique': (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P]),
     'recnow_embed_rows_bwd_workspace_bytes': (_Z, [_L, _I]),
     'recnow_embed_rows_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
-    'recnow_embed_scatter_rows': (_I, [_P, _P, _L, _I, _L, _P, _P]),
+    'recnow_embed_scatter_rows': (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),
     'recnow_prof_enable': (_I, [_I]),
     'recnow_prof_sample_every': (_I, [_I]),
     'recnow_prof_collect': (_I, [_P, _P, _P, _P]),

@@ -25,7 +25,7 @@
 template <typename ST>
 __global__ void __launch_bounds__(256)
 k_slot_targets(const ST* __restrict__ slots, const ST* __restrict__ targets, int T, const int64_t* __restrict__ ids, int64_t N,
-               int32_t* __restrict__ seg, int64_t* __restrict__ key) {
+               int32_t* __restrict__ seg, int64_t* __restrict__ key, int64_t not_pooled_key, int64_t id_limit, int32_t* __restrict__ key32) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tg_raw[];
     ST* tg = reinterpret_cast<ST*>(tg_raw);
     // target lists longer than SLOT_PIECE go through LDS piece by piece (front to back; an earlier piece's match stands)
@@ -49,23 +49,35 @@ k_slot_targets(const ST* __restrict__ slots, const ST* __restrict__ targets, int
                 t = before >= 0 ? before : t;
             }
             seg[i] = t;
-            if (key && p0 + SLOT_PIECE >= T) key[i] = t >= 0 ? ids[i] : EMB_SENTINEL;
+            if (key && p0 + SLOT_PIECE >= T) {
+                // id_limit > 0 (round 5, a table of V = id_limit rows): entries that are not pooled AND ids outside the table share the key
+                // not_pooled_key = V -- one past the last row, so it sorts last and is dropped by the scatter like every id outside the table --
+                // which keeps every key below 2^31: the sort runs on the 32-bit copy (three 8-bit digit passes for V = 2^20, where INT64_MIN in
+                // a 64-bit key cost a fourth pass on a second key word, and the second word four empty pass iterations)
+                const int64_t id = ids[i];
+                const bool in = t >= 0 && (id_limit <= 0 || (id >= 0 && id < id_limit));
+                const int64_t k = in ? id : not_pooled_key;
+                key[i] = k;
+                if (key32) key32[i] = (int32_t)k;
+            }
         }
     }
 }
 
 extern "C" int recnow_slot_targets(const void* slots, int slot_dtype, const void* targets, int T, const int64_t* ids, int64_t N,
-                                   int32_t* seg, int64_t* key, void* stream) {
+                                   int32_t* seg, int64_t* key, int64_t id_limit, int32_t* key32, void* stream) {
     if (N < 0 || T < 0 || (slot_dtype != RECNOW_KEY_I32 && slot_dtype != RECNOW_KEY_I64)) return RECNOW_EINVAL;
     if (N == 0) return RECNOW_OK;
     if (!slots || (T > 0 && !targets) || !seg || (key && !ids)) return RECNOW_EINVAL;
+    if (id_limit < 0 || (key32 && (!key || id_limit <= 0 || id_limit >= 0x7fffffffll))) return RECNOW_EINVAL;
+    const int64_t not_pooled_key = id_limit > 0 ? id_limit : EMB_SENTINEL;
     int64_t g = (N + 255) / 256;
     if (g > 4096) g = 4096;
     hipStream_t st = (hipStream_t)stream;
     if (slot_dtype == RECNOW_KEY_I32)
-        hipLaunchKernelGGL(k_slot_targets<int32_t>, (int)g, 256, (size_t)((min(T, SLOT_PIECE) + 3) & ~3) * sizeof(int32_t) + 16, st, (const int32_t*)slots, (const int32_t*)targets, T, ids, N, seg, key);
+        hipLaunchKernelGGL(k_slot_targets<int32_t>, (int)g, 256, (size_t)((min(T, SLOT_PIECE) + 3) & ~3) * sizeof(int32_t) + 16, st, (const int32_t*)slots, (const int32_t*)targets, T, ids, N, seg, key, not_pooled_key, id_limit, key32);
     else
-        hipLaunchKernelGGL(k_slot_targets<int64_t>, (int)g, 256, (size_t)((min(T, SLOT_PIECE) + 3) & ~3) * sizeof(int64_t) + 16, st, (const int64_t*)slots, (const int64_t*)targets, T, ids, N, seg, key);
+        hipLaunchKernelGGL(k_slot_targets<int64_t>, (int)g, 256, (size_t)((min(T, SLOT_PIECE) + 3) & ~3) * sizeof(int64_t) + 16, st, (const int64_t*)slots, (const int64_t*)targets, T, ids, N, seg, key, not_pooled_key, id_limit, key32);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }
@@ -505,10 +517,13 @@ extern "C" int recnow_embed_rows_bwd(const int64_t* key, const int32_t* order, c
 // dtable[row_ids[s]][:] = drows[s][:] for every used slot s (row ids are unique: one writer per table row)
 __global__ void __launch_bounds__(256)
 k_embed_scatter(const float* __restrict__ drows, const int64_t* __restrict__ row_ids, int64_t n_slots, int D, int64_t V, int LPE,
-                float* __restrict__ dtable) {
+                float* __restrict__ dtable, const int32_t* __restrict__ n_seg) {
     // a group of LPE lanes (pow2 >= D, 16..64) per slot: at D = 16 a wave moves four rows per step
     const int gl = threadIdx.x % LPE;
     const int64_t per = 256 / LPE;
+    // only the first n_seg slots hold a segment (the rest carry the sentinel): with the count on the device the sweep stops there instead
+    // of reading all N row ids (6.5 M for 0.3 M distinct ids: 79 -> ~10 us)
+    if (n_seg && n_seg[0] >= 0 && n_seg[0] < n_slots) n_slots = n_seg[0];
     for (int64_t s = (int64_t)blockIdx.x * per + threadIdx.x / LPE; s < n_slots; s += (int64_t)gridDim.x * per) {
         const int64_t id = row_ids[s];
         if (id < 0 || id >= V) continue;
@@ -516,14 +531,14 @@ k_embed_scatter(const float* __restrict__ drows, const int64_t* __restrict__ row
     }
 }
 extern "C" int recnow_embed_scatter_rows(const float* drows, const int64_t* row_ids, int64_t n_slots, int D, int64_t V, float* dtable,
-                                         void* stream) {
+                                         const int32_t* n_seg, void* stream) {
     if (n_slots < 0 || D < 1 || V < 0) return RECNOW_EINVAL;
     if (n_slots == 0 || V == 0) return RECNOW_OK;
     if (!drows || !row_ids || !dtable) return RECNOW_EINVAL;
     const int LPE = D <= 16 ? 16 : D <= 32 ? 32 : 64;
     int64_t g = (n_slots + 256 / LPE - 1) / (256 / LPE);
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_embed_scatter, (int)g, 256, 0, (hipStream_t)stream, drows, row_ids, n_slots, D, V, LPE, dtable);
+    hipLaunchKernelGGL(k_embed_scatter, (int)g, 256, 0, (hipStream_t)stream, drows, row_ids, n_slots, D, V, LPE, dtable, n_seg);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

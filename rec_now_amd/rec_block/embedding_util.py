@@ -23,8 +23,10 @@ def _slot_tensor(slots):
     raise TypeError('slots must be an integer tensor (string slots of the reference are hashed upstream); got %s' % slots.dtype)
 
 
-def _slot_targets(slots, target_slots, ids, want_key):
-    """(B,C) slots -> seg (B,C) int32 target index or -1, and optionally the int64 sort key (id, or KEY_NOT_POOLED)."""
+def _slot_targets(slots, target_slots, ids, want_key, id_limit=0):
+    """(B,C) slots -> seg (B,C) int32 target index or -1, and optionally the int64 sort key (id, or KEY_NOT_POOLED).
+    id_limit = V (a table of V < 2^31 - 1 rows): entries that are not pooled and ids outside the table carry the key V instead, and a
+    third value -- the same keys as int32 -- is returned for the sort (one key word: three digit passes for V = 2^20 instead of four)."""
     if not isinstance(target_slots, list):
         target_slots = list(target_slots)
     if len(set(target_slots)) != len(target_slots):
@@ -36,8 +38,12 @@ def _slot_targets(slots, target_slots, ids, want_key):
     targets = _lib.const_array(target_slots, tdt, dev)
     seg = torch.empty(slots.shape, dtype=torch.int32, device=dev)
     key = torch.empty(slots.shape, dtype=torch.int64, device=dev) if want_key else None
+    narrow = bool(want_key and 0 < id_limit < (1 << 31) - 1)
+    key32 = torch.empty(slots.shape, dtype=torch.int32, device=dev) if narrow else None
     _lib.call('recnow_slot_targets', _lib.ptr(slots), sdt, _lib.ptr(targets), len(target_slots), _lib.ptr(ids) if want_key else None,
-              slots.numel(), _lib.ptr(seg), _lib.ptr(key), _lib.stream())
+              slots.numel(), _lib.ptr(seg), _lib.ptr(key), int(id_limit) if narrow else 0, _lib.ptr(key32), _lib.stream())
+    if id_limit:
+        return seg, key, key32
     return seg, key
 
 
@@ -81,13 +87,14 @@ class EmbeddingTable(torch.nn.Module):
 class _Sorted(object):
     """Entries sorted by id (lazy: only the backward of a trainable table, or the unique path, needs it)."""
 
-    def __init__(self, key):
+    def __init__(self, key, key32=None):
         self.key = key
+        self.key32 = key32          # the same keys as int32 (table path, V < 2^31 - 1): what the sort runs on
         self._seg = None
 
     def segments(self):
         if self._seg is None:
-            self._seg = build_segments(self.key.reshape(-1))
+            self._seg = build_segments((self.key if self.key32 is None else self.key32).reshape(-1))
         return self._seg
 
 
@@ -141,7 +148,7 @@ class _PoolFunction(torch.autograd.Function):
             dtable = torch.sparse_coo_tensor(ids[keep].unsqueeze(0), drows[:n_used][keep], (V, D))
         elif dense_scatter:
             dtable = torch.zeros((V, D), dtype=torch.float32, device=dev)
-            _lib.call('recnow_embed_scatter_rows', _lib.ptr(drows), _lib.ptr(row_ids), N, D, V, _lib.ptr(dtable), _lib.stream())
+            _lib.call('recnow_embed_scatter_rows', _lib.ptr(drows), _lib.ptr(row_ids), N, D, V, _lib.ptr(dtable), _lib.ptr(s.n_seg), _lib.stream())
         else:
             dtable = drows[:V]                      # unique path: segment s IS unique id s
         return dtable, None, None, dweights, None, None, None, None
@@ -181,10 +188,13 @@ def embedding_using_sparse_batch_segment_ids(embedding_func, slots, target_slots
         if weights.shape != ids.shape:
             raise ValueError('weights must have the shape of ids')
     T = len(target_slots)
-    seg, key = _slot_targets(slots, target_slots, ids, True)
+    if isinstance(embedding_func, EmbeddingTable):
+        seg, key, key32 = _slot_targets(slots, target_slots, ids, True, id_limit=int(embedding_func.weight.shape[0]))
+    else:
+        (seg, key), key32 = _slot_targets(slots, target_slots, ids, True), None
     if seg.shape != ids.shape:
         raise ValueError('slots and ids must have the same (B, C) shape')
-    srt = _Sorted(key)
+    srt = _Sorted(key, key32)
     mean = method == 'mean'
     if isinstance(embedding_func, EmbeddingTable):
         return _PoolFunction.apply(embedding_func.weight, ids, seg, weights, T, mean, srt, 'sparse' if embedding_func.sparse_grad else True)
