@@ -269,6 +269,9 @@ extern "C" size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N,
     if (mix_tile_shape(m)) {                                 // row-block backward: dT1 of every layer, dV partials per layer and workgroup
         s += (size_t)L * act_block(m);
         s += rn_align((size_t)L * rn_mix_tile_bwd_grid(B) * N * S * S * sizeof(float));
+        // ... and one split-K slab buffer per weight-gradient product (2 L of them; three are carved above): behind the chain launch all six
+        // products are independent, and sharing slab buffers made each wait for an earlier layer's reduction (round 5, kernel trace at 8192 rows)
+        if (2 * L > 3) s += (size_t)(2 * L - 3) * rn_align(mix_gemm_ws(m));
     }
     return s + 4096;
 }
@@ -688,6 +691,12 @@ extern "C" int recnow_dcn_mix_score_supported(int64_t B, int D, int S, int N, in
     return mix_head_ok(mix_dims(B, D, S, N, L)) ? 1 : 0;
 }
 
+int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order, const int32_t* seg_id,
+                        const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean, float* loss, float* dscores_unnorm,
+                        int64_t* n_pair, void* ws, size_t ws_bytes, void* stream, const double** part_out, int* nparts_out);      // pairwise.hip
+int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
+                       int32_t* n_seg, hipStream_t st);       // scan_sort.hip
+
 extern "C" int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
     return mix_tile_on(mix_dims(B, D, S, N, L)) ? 1 : 0;
@@ -819,23 +828,55 @@ static int dcnmix_bwd_tile(const MixDims& m, const float* x, const float* const*
     MIX_WAIT(e_chain, st2);
     int pg = rn_cdiv((int64_t)D * m.NS, 256);
     if (pg > 2048) pg = 2048;
-    hipEvent_t e_red[RN_TILE_MAX_L + 2];
-    for (int l = 0; l < RN_TILE_MAX_L + 2; ++l) e_red[l] = nullptr;
     struct SlotGuard {      // the dW / dU products of a layer run as a concurrent pair: each aims at half the workgroup slots (gemm_dispatch.hpp)
         explicit SlotGuard(bool on) { if (on) rn_gemm_split_slots(256); }
         ~SlotGuard() { rn_gemm_split_slots(0); }
     } slot_guard(two);
+    // Round 5.  The six K = B products behind the chain are independent of each other; what serialised them was the sharing of split-K slab
+    // buffers (dW of every layer in one buffer: dW_l waited for the reduction of layer l + 1 on the second stream) and the reductions queued
+    // between them.  Kernel trace of the 8192-row step: pairs at 378-427 us, then dU_1 ALONE, dW_1 + dU_0 at 477, dW_0 alone at 551, the last
+    // reduction at 587-595 -- 217 us for 12.9 GFLOP.  Now every product owns its slabs, ALL products are issued first (dW_l on the second stream,
+    // dU_l on the first: three concurrent pairs back to back), and the reductions follow: the top layer's (+ the head's post-processing) on the
+    // first stream, the others on the second, each behind the events of its two products.
+    void* slab_w[RN_TILE_MAX_L];
+    void* slab_u[RN_TILE_MAX_L];
+    {
+        void* pool[2 * RN_TILE_MAX_L];
+        int np = 0;
+        pool[np++] = gws1; pool[np++] = gws2; pool[np++] = gws3;
+        for (int i = 3; i < 2 * L; ++i) pool[np++] = c.take<char>(gemm_ws);
+        if (!c.ok()) return RECNOW_EWORKSPACE;
+        for (int l = 0; l < L; ++l) { slab_w[l] = pool[2 * l]; slab_u[l] = pool[2 * l + 1]; }
+    }
+    RnDeferredReduce red_dw[RN_TILE_MAX_L], red_du[RN_TILE_MAX_L];
+    hipEvent_t e_dw[RN_TILE_MAX_L], e_du[RN_TILE_MAX_L];
+    for (int l = 0; l < RN_TILE_MAX_L; ++l) { red_dw[l].valid = red_du[l].valid = 0; e_dw[l] = e_du[l] = nullptr; }
+    // The reduction of layer l (slab sums of dW_l / dU_l, the dV partials, the head's post-processing, the layer's event) is enqueued ONE PAIR LATE --
+    // behind the products of layer l - 1 on its stream -- and alternates between the streams: layer l_hi's on the first (behind dU of the layer
+    // below, waiting for its dW), the next on the second, ...  So a pair never waits for a reduction, every layer's event (= its gradient
+    // all-reduce under a process group) still fires while the products of the layers below run, and only the last layer's reduction is a tail.
+    auto reduce_layer = [&](int l) -> int {
+        const bool on_first = ((l_hi - l) & 1) == 0;
+        hipStream_t sr = on_first ? st : st2;
+        if (on_first) MIX_WAIT(e_dw[l], st);
+        else MIX_WAIT(e_du[l], st2);
+        RnProfRecord* pr_end = rn_prof_on() ? rn_prof_begin(RN_TAG_LAYER_END, 0.0, 0.0, sr) : nullptr;
+        int rr;
+        if ((rr = rn_layer_end_reduce(&red_dw[l], &red_du[l], dvpart + (size_t)l * grid * N * S * S, grid, N * S * S, dV_host[l], sr))) return rr;
+        if (hd && l == L - 1) {
+            hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, sr, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw,
+                               ds_part, ds_nparts, ds_part ? hd->db : nullptr);
+            RN_LAUNCH_CHECK();
+        }
+        rn_prof_end(pr_end, sr);
+        if (layer_events && layer_events[l]) RN_HIP(hipEventRecord((hipEvent_t)layer_events[l], sr));
+        return RECNOW_OK;
+    };
     for (int l = l_hi; l >= l_lo; --l) {
         const float* T2g = (const float*)(sv + (size_t)(3 * l + 2) * act_block(m));
         const float* xl = (l == 0) ? x : xmid + (size_t)(l - 1) * (xbuf(m) / sizeof(float));
         const float* g = (l == L - 1) ? dy : gbuf_of(l + 1);
         const float* dT1 = dT1_all + (size_t)l * (act_block(m) / sizeof(float));
-        RnDeferredReduce red_dw, red_du;
-        red_dw.valid = red_du.valid = 0;
-        // two streams: the dW products on st2, the dU products on st (slabs of layers of equal parity share a buffer: a layer's product
-        // waits for the reduction two layers up), every layer's reduction on st2 behind both
-        void* gwsu = (l & 1) ? gws1 : gws2;
-        if (l + 2 <= l_hi) MIX_WAIT(e_red[l + 2], st);
         {   // dW^T = (x*g)^T T2g[:, :NS] stored transposed straight into dW (NS x D);  dbias[n][d] as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
             const bool top_head = hd && l == L - 1;
@@ -849,7 +890,8 @@ static int dcnmix_bwd_tile(const MixDims& m, const float* x, const float* const*
             d.M = D; d.N = m.NS; d.K = (int)B;
             d.prof_flops = 2.0 * (double)B * D * m.KC;
             d.sp_bx = d.B + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dbias_host[l]; d.sp_cx_ms = 1; d.sp_cx_rs = D; d.sp_r = N;
-            if ((rc = rn_gemm_deferred(&d, gws3, gemm_ws, st2, &red_dw))) return rc;
+            if ((rc = rn_gemm_deferred(&d, slab_w[l], gemm_ws, st2, &red_dw[l]))) return rc;
+            MIX_SIGNAL(e_dw[l], st2);
         }
         {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
@@ -862,31 +904,19 @@ static int dcnmix_bwd_tile(const MixDims& m, const float* x, const float* const*
             d.sp_bx = dT1 + m.NS; d.sp_bx_ks = m.LDT; d.sp_bx_rs = 1; d.sp_cx = dgate_host[l]; d.sp_cx_ms = N; d.sp_cx_rs = 1; d.sp_r = N;
             recnow_gemm_desc dq = d;
             dq.C = dU_host[l]; dq.c_perm_s = S;
-            rc = rn_gemm_deferred(&dq, gwsu, gemm_ws, st, &red_du);
-            if (rc == RECNOW_EUNSUPPORTED) {
-                if ((rc = rn_gemm(&d, gwsu, gemm_ws, st))) return rc;
+            rc = rn_gemm_deferred(&dq, slab_u[l], gemm_ws, st, &red_du[l]);
+            if (rc == RECNOW_EUNSUPPORTED) {       // no split: the product stores (D, N S) and is unpacked (dWc1 is reused in stream order)
+                if ((rc = rn_gemm(&d, slab_u[l], gemm_ws, st))) return rc;
                 hipLaunchKernelGGL(k_unpack_u, pg, 256, 0, st, dWc1, D, S, N, dU_host[l]);
                 RN_LAUNCH_CHECK();
             } else if (rc) {
                 return rc;
             }
+            MIX_SIGNAL(e_du[l], st);
         }
-        {
-            hipEvent_t e_du = nullptr;
-            MIX_SIGNAL(e_du, st);
-            MIX_WAIT(e_du, st2);
-        }
-        RnProfRecord* pr_end = rn_prof_on() ? rn_prof_begin(RN_TAG_LAYER_END, 0.0, 0.0, st2) : nullptr;
-        if ((rc = rn_layer_end_reduce(&red_dw, &red_du, dvpart + (size_t)l * grid * N * S * S, grid, N * S * S, dV_host[l], st2))) return rc;
-        if (hd && l == L - 1) {
-            hipLaunchKernelGGL(k_head_post, rn_cdiv(D, 32), 256, 0, st2, dW_host[l], dbias_host[l], W_host[l], bias_host[l], hd->w, m.NS, N, D, hd->dw,
-                               ds_part, ds_nparts, ds_part ? hd->db : nullptr);
-            RN_LAUNCH_CHECK();
-        }
-        rn_prof_end(pr_end, st2);
-        MIX_SIGNAL(e_red[l], st2);
-        if (layer_events && layer_events[l]) RN_HIP(hipEventRecord((hipEvent_t)layer_events[l], st2));
+        if (l < l_hi && (rc = reduce_layer(l + 1))) return rc;
     }
+    if ((rc = reduce_layer(l_lo))) return rc;
     hipEvent_t e_done = nullptr;
     MIX_SIGNAL(e_done, st2);
     MIX_WAIT(e_done, st);
@@ -1350,10 +1380,12 @@ extern "C" size_t recnow_dcn_mix_step_workspace_bytes(int64_t B, int D, int S, i
 // Loss stage, last kernel: ds = d(loss)/d(scores) from the unnormalised pair gradients (x 1 / (P + eps) when the loss is the mean);
 // the top layer's dscore * T2g (the row-scaled small operand of the fused head's weight gradient) for the same rows; the
 // workgroup's partial sum of ds (d head bias, joined by k_head_post); {loss, (float) P} for the caller's statistics.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restrict__ n_pair, int reduce_mean, float eps, int64_t B, int64_t BP,
               const float* __restrict__ T2g_top, int LDT, float* __restrict__ ds, float* __restrict__ T2g_ds, float* __restrict__ ds_part,
-              float* __restrict__ loss, float* __restrict__ stats, const int32_t* __restrict__ n_seg) {
+              float* __restrict__ loss, float* __restrict__ stats, const int32_t* __restrict__ n_seg, const double* __restrict__ loss_part, int n_loss_part) {
+    // Round 5: the first workgroup also sums the pair kernel's loss partials -- 1024 threads, the code of k_loss_finalize (pairwise.hip): the same
+    // terms in the same order, so the loss is bit-identical to the autograd route's -- instead of a launch of its own in front of this one.
     // B rows of the batch, BP >= B rows of storage (recnow_dcn_mix_step_desc.B_pad): the padding rows get d loss / d score = 0 and a zero
     // row of dscore * T2g, so that the backward products, which run over all BP rows, add exactly nothing for them
     __shared__ float sds[STEP_ROWS];
@@ -1363,6 +1395,18 @@ k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restric
     const bool bad = n_seg[0] < 0;
     const float sc = bad ? __int_as_float(0x7fc00000) : (reduce_mean ? 1.f / (P + eps) : 1.f);
     const int64_t r0 = (int64_t)blockIdx.x * STEP_ROWS;
+    if (blockIdx.x == 0) {                    // block-uniform
+        __shared__ double red[16];
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n_loss_part; i += blockDim.x) s += loss_part[i];     // fixed order per thread, fixed tree
+        s = block_sum<double>(s, red);
+        if (threadIdx.x == 0) {
+            float v = (float)s;
+            if (reduce_mean) v = v / (P + eps);
+            loss[0] = v;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < STEP_ROWS) {            // one wave
         const int64_t r = r0 + threadIdx.x;
         const float v = r < B ? dsu[r] * sc : 0.f;
@@ -1377,7 +1421,7 @@ k_step_dscore(const float* __restrict__ dsu, const unsigned long long* __restric
     }
     __syncthreads();
     const int q = LDT / 4;
-    for (int i = threadIdx.x; i < STEP_ROWS * q; i += 256) {
+    for (int i = threadIdx.x; i < STEP_ROWS * q; i += 1024) {
         const int rl = i / q, c4 = i % q;
         const int64_t r = r0 + rl;
         if (r < BP) {
@@ -1409,11 +1453,15 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
     if (phases & RECNOW_STEP_GROUP) {
         if (!d->groups) return RECNOW_EINVAL;
         RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_STEP_GROUP, 0.0, 16.0 * B, st) : nullptr;
-        RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
-        if ((rc = recnow_group_keys(d->groups, d->group_dtype, B, w.words, w.solo, stream))) return rc;
-        if ((rc = recnow_group_segments(w.words, w.solo, B, w.n_words, w.n_words, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp,
-                                        w.grp_bytes, stream)))
-            return rc;
+        // small shards (<= 8192 rows, float32 / int32 ids): keys, solo flags, sort and segments in ONE launch straight from the id tensor
+        rc = rn_group_small_raw(d->groups, d->group_dtype, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, st);
+        if (rc == RECNOW_EUNSUPPORTED) {
+            RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
+            if ((rc = recnow_group_keys(d->groups, d->group_dtype, B, w.words, w.solo, stream))) return rc;
+            rc = recnow_group_segments(w.words, w.solo, B, w.n_words, w.n_words, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp,
+                                       w.grp_bytes, stream);
+        }
+        if (rc) return rc;
         rn_prof_end(pr, st);
     }
     if (phases & RECNOW_STEP_FORWARD) {
@@ -1427,12 +1475,14 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
         if (!d->scores || !d->labels || !d->loss || !d->n_pair) return RECNOW_EINVAL;
         const int flags = RECNOW_PAIR_LABEL_GT | (d->only_use_wrong_order_pair ? RECNOW_PAIR_WRONG_ORDER : 0);
         RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_STEP_LOSS, 0.0, 16.0 * B + 8.0 * BP * m.LDT, st) : nullptr;
-        if ((rc = recnow_pair_bpr_onepass(d->scores, d->labels, d->mask, w.order, w.seg_id, w.seg_first, B, flags, d->factor, d->reduce_mean,
-                                          d->loss, w.dsu, d->n_pair, w.pair, w.pair_bytes, stream)))
+        const double* loss_part = nullptr;
+        int n_loss_part = 0;
+        if ((rc = rn_pair_bpr_onepass(d->scores, d->labels, d->mask, w.order, w.seg_id, w.seg_first, B, flags, d->factor, d->reduce_mean,
+                                      d->loss, w.dsu, d->n_pair, w.pair, w.pair_bytes, stream, &loss_part, &n_loss_part)))
             return rc;
         const float* T2g_top = (const float*)((const char*)w.saved + (size_t)(3 * (L - 1) + 2) * act_block(m));
-        hipLaunchKernelGGL(k_step_dscore, rn_cdiv(BP, STEP_ROWS), 256, 0, st, w.dsu, (const unsigned long long*)d->n_pair, d->reduce_mean, 1.0e-10f, B, BP,
-                           T2g_top, m.LDT, w.ds, w.T2g_ds, w.ds_part, d->loss, d->stats, w.n_seg);
+        hipLaunchKernelGGL(k_step_dscore, rn_cdiv(BP, STEP_ROWS), 1024, 0, st, w.dsu, (const unsigned long long*)d->n_pair, d->reduce_mean, 1.0e-10f, B, BP,
+                           T2g_top, m.LDT, w.ds, w.T2g_ds, w.ds_part, d->loss, d->stats, w.n_seg, loss_part, n_loss_part);
         RN_LAUNCH_CHECK();
         rn_prof_end(pr, st);
     }

@@ -624,9 +624,13 @@ extern "C" int recnow_pair_bpr_fwdbwd(const float* scores, const float* labels, 
     return RECNOW_OK;
 }
 
-extern "C" int recnow_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
-                                      const int32_t* seg_id, const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean,
-                                      float* loss, float* dscores_unnorm, int64_t* n_pair, void* ws, size_t ws_bytes, void* stream) {
+// part_out != NULL (library-internal: the loss stage of recnow_dcn_mix_step): the per-workgroup loss partials are NOT summed here -- the caller's next
+// kernel (k_step_dscore, 1024 threads: the same sum in the same order as k_loss_finalize) does it, one launch less per step; *part_out / *nparts_out
+// receive the partials.  B must be > 0 then.
+int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
+                        const int32_t* seg_id, const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean,
+                        float* loss, float* dscores_unnorm, int64_t* n_pair, void* ws, size_t ws_bytes, void* stream,
+                        const double** part_out, int* nparts_out) {
     if (B < 0 || !loss || !n_pair) return RECNOW_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) {
@@ -645,9 +649,20 @@ extern "C" int recnow_pair_bpr_onepass(const float* scores, const float* labels,
     RN_DISPATCH_LONG(2, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga);
     RN_DISPATCH_FLAGS(k_pair_one, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
                       (unsigned long long*)n_pair, dscores_unnorm);
-    hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, pw.part, G, (const unsigned long long*)n_pair, (int64_t)0, reduce_mean, loss);
+    if (part_out) {
+        *part_out = pw.part;
+        *nparts_out = G;
+    } else {
+        hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, pw.part, G, (const unsigned long long*)n_pair, (int64_t)0, reduce_mean, loss);
+    }
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
+}
+extern "C" int recnow_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
+                                      const int32_t* seg_id, const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean,
+                                      float* loss, float* dscores_unnorm, int64_t* n_pair, void* ws, size_t ws_bytes, void* stream) {
+    return rn_pair_bpr_onepass(scores, labels, mask, order, seg_id, seg_first, B, flags, factor, reduce_mean, loss, dscores_unnorm, n_pair, ws, ws_bytes,
+                               stream, nullptr, nullptr);
 }
 
 extern "C" int recnow_pair_scale_grad(const float* dscores_unnorm, const float* g, const int64_t* n_pair, float eps, int64_t B, float* out,

@@ -5,6 +5,7 @@
 //
 // HBM-bound integer work on <= a few MB: everything here is about few launches, coalesced 4-B streams and
 // LDS-resident counters, not MFMA.
+#include <atomic>
 #include "common.hpp"
 #include "scan.hpp"
 #include "group_small.hpp"
@@ -354,6 +355,11 @@ __global__ void k_seg_empty(int32_t* seg_first, int32_t* n_seg) {
 //   4-bit digits: a thread's 16 digit counters (each <= 8) pack into one 64-bit register; passes whose digit is constant
 //   over the batch are skipped (OR/AND of all keys); counters [16][1024] u16 are scanned block-wide in digit-major order.
 // ------------------------------------------------------------------------------------------------
+// RAW = 0: canonical key words + solo flags from recnow_group_keys (the C ABI's two-call form).  RAW = 1 / 2 (round 5, the step's GROUP phase at
+// shard sizes): `words` IS the caller's float32 / int32 id tensor -- the canonical key (-0.0 -> +0.0) and the solo flag (NaN, +-inf) of
+// k_keys_f32 are formed here and the flags live in an LDS bit set, so that the phase is ONE launch instead of a fill, a key kernel and this one
+// (kernel trace at 8192 rows: 5.2 + 5.0 + 31.8 us in front of the forward launch).
+template <int RAW>
 __global__ void __launch_bounds__(GS_T)
 k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int B, int32_t* __restrict__ order,
               int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
@@ -364,10 +370,21 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
     uint16_t* idx1 = idx0 + GS_MAXB;
     uint16_t* cnt = idx1 + GS_MAXB;                       // [16][GS_T]
     unsigned* wsum = reinterpret_cast<unsigned*>(cnt + 16 * GS_T);   // [16] + 2
+    __shared__ unsigned s_solo[GS_MAXB / 32];             // RAW: bit i = row i pairs with nobody
     const int tid = threadIdx.x;
+    if (RAW == 1) {
+        for (int i = tid; i < GS_MAXB / 32; i += GS_T) s_solo[i] = 0u;
+        __syncthreads();
+    }
+    auto is_solo = [&](int row) -> bool { return RAW == 0 ? solo[row] != 0 : RAW == 1 ? ((s_solo[row >> 5] >> (row & 31)) & 1u) != 0u : false; };
     unsigned vor = 0, vand = 0xffffffffu, ior = 0, iand = 0xffffffffu, bad = 0;
     for (int i = tid; i < B; i += GS_T) {
-        const uint32_t k = words[i];
+        uint32_t k = words[i];
+        if (RAW == 1) {
+            const float v = __uint_as_float(k);
+            if (v == 0.0f) k = 0u;                        // -0.0 == +0.0
+            if (!(fabsf(v) < INFINITY)) atomicOr(&s_solo[i >> 5], 1u << (i & 31));
+        }
         key0[i] = k;
         idx0[i] = (uint16_t)i;
         vor |= k;
@@ -386,7 +403,7 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
     unsigned heads = 0, nh = 0;
     for (int i = lo; i < hi; ++i) {
         bool h = true;
-        if (i > 0) h = (ka[i] != ka[i - 1]) || solo[ia[i]] || solo[ia[i - 1]];
+        if (i > 0) h = (ka[i] != ka[i - 1]) || is_solo(ia[i]) || is_solo(ia[i - 1]);
         heads |= (h ? 1u : 0u) << (i - lo);
         nh += h ? 1u : 0u;
     }
@@ -797,6 +814,27 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
     }
 }
 
+// The grouping of a small batch (B <= 8192) straight from ONE float32 / int32 id tensor in one launch (library-internal: the GROUP phase of
+// recnow_dcn_mix_step).  Returns RECNOW_EUNSUPPORTED for other shapes: the caller then takes recnow_group_keys + recnow_group_segments.
+int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
+                       int32_t* n_seg, hipStream_t st) {
+    if (B < 1 || B > GS_MAXB || (dtype != RECNOW_KEY_F32 && dtype != RECNOW_KEY_I32)) return RECNOW_EUNSUPPORTED;
+    static std::atomic<bool> raised[64];
+    int dev = 0;
+    RN_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
+        RN_HIP(hipFuncSetAttribute((const void*)k_group_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+        RN_HIP(hipFuncSetAttribute((const void*)k_group_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+        if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
+    }
+    if (dtype == RECNOW_KEY_F32)
+        hipLaunchKernelGGL(k_group_small<1>, 1, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (const uint8_t*)nullptr, (int)B, order, seg_id, seg_first, super_id, n_seg);
+    else
+        hipLaunchKernelGGL(k_group_small<2>, 1, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (const uint8_t*)nullptr, (int)B, order, seg_id, seg_first, super_id, n_seg);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
 // Largest grid of k_group_mid whose workgroups are all resident at once on the CURRENT device: occupancy x compute units, queried
 // once per device (a CU mask, a smaller partition (CPX) or a register-hungrier build all show up here).  The hand-rolled grid
 // barrier is only correct below it; anything larger takes the multi-launch chain.
@@ -849,10 +887,12 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
         int dev = 0;
         RN_HIP(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !lds_raised[dev]) {
-            RN_HIP(hipFuncSetAttribute((const void*)k_group_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+            RN_HIP(hipFuncSetAttribute((const void*)k_group_small<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+            RN_HIP(hipFuncSetAttribute((const void*)k_group_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+            RN_HIP(hipFuncSetAttribute((const void*)k_group_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
             if (dev >= 0 && dev < 64) lds_raised[dev] = true;
         }
-        hipLaunchKernelGGL(k_group_small, 1, GS_T, gs_lds_bytes(), st, words, solo, (int)B, order, seg_id, seg_first, super_id, n_seg);
+        hipLaunchKernelGGL(k_group_small<0>, 1, GS_T, gs_lds_bytes(), st, words, solo, (int)B, order, seg_id, seg_first, super_id, n_seg);
         RN_LAUNCH_CHECK();
         return RECNOW_OK;
     }
