@@ -609,9 +609,13 @@ def main():
     if graph is None:
         run_step = step
     prof = not args.no_prof and graph is None
+    # the two timing events around a sampled launch serialise the stream for ~2 us each: nothing at 65 536 rows (24 hooked launches of ~150 us per
+    # step), but 0.03 ms of a 0.64 ms step at 8192 rows when every 5th launch is sampled (measured: 0.640 timed vs 0.611 ms unhooked).  The
+    # shards sample every 23rd hooked launch instead (about one per step; 23 is prime, so every launch position still comes up).
+    prof_every = PROF_EVERY if rows >= 65536 else 23
     if prof:
         _lib.check(lib.recnow_prof_enable(64 * (args.steps + 1)), 'recnow_prof_enable')
-        _lib.check(lib.recnow_prof_sample_every(PROF_EVERY), 'recnow_prof_sample_every')
+        _lib.check(lib.recnow_prof_sample_every(prof_every), 'recnow_prof_sample_every')
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -620,7 +624,7 @@ def main():
     elapsed = time.perf_counter() - t0
     mark('timed region done')
     roofline = None
-    prof_note = 'every %dth hooked launch of the timed region' % PROF_EVERY
+    prof_note = 'every %dth hooked launch of the timed region' % (PROF_EVERY if rows >= 65536 else 23)
     hook_done = False
     if not prof and hook_pre is not None:
         prof, hook_done = True, True

@@ -440,7 +440,12 @@ __device__ __forceinline__ float cs_term(const float* __restrict__ X, const floa
 }
 __global__ void __launch_bounds__(256)
 k_colsum_partial(const float* __restrict__ X, const float* __restrict__ X2, int mode, int act, int64_t M, int64_t N, int64_t ld,
-                 float* __restrict__ part, int rows, int cw) {
+                 float* __restrict__ part, int rows, int cw, int64_t x_bs, int64_t part_bs) {
+    // blockIdx.z: one of a batch of equally shaped matrices (rn_colsum_batched: the bias gradients of all experts of a layer in ONE launch -- a
+    // single (32 768 x 512) matrix is 128 workgroups, half the chip; round 5)
+    X += (int64_t)blockIdx.z * x_bs;
+    if (X2) X2 += (int64_t)blockIdx.z * x_bs;
+    part += (int64_t)blockIdx.z * part_bs;
     // block (bx, by): columns bx*cw + (tid % cw), rows by*rows .. ; the 256/cw row lanes of a column take rows rl apart
     // (cw = 64 or 128 for matrices narrower than 256 columns: all 256 threads load), four loads in flight each, and are
     // summed in a fixed order through LDS
@@ -473,8 +478,10 @@ k_colsum_partial(const float* __restrict__ X, const float* __restrict__ X2, int 
 // out[col] = sum over slabs, fixed order: 64 columns x 16 strided slab groups per workgroup, then a 16-term LDS sum (a
 // column-per-thread loop over hundreds of slabs is a chain of dependent-latency loads: 84 us for 512 slabs, measured)
 __global__ void __launch_bounds__(1024)
-k_colsum_final(const float* __restrict__ part, int nslab, int64_t N, float* __restrict__ out, int accumulate) {
+k_colsum_final(const float* __restrict__ part, int nslab, int64_t N, float* __restrict__ out, int accumulate, int64_t part_bs, int64_t out_bs) {
     __shared__ double red[16][64];
+    part += (int64_t)blockIdx.y * part_bs;
+    out += (int64_t)blockIdx.y * out_bs;
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t col = (int64_t)blockIdx.x * 64 + e;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
@@ -546,9 +553,29 @@ int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int
     } else {
         const int cw = N <= 64 ? 64 : N <= 128 ? 128 : 256;
         dim3 g1(rn_cdiv(N, cw), nslab);
-        hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws, rows, cw);
+        hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws, rows, cw, (int64_t)0, (int64_t)0);
     }
-    hipLaunchKernelGGL(k_colsum_final, rn_cdiv(N, 64), 1024, 0, st, (const float*)ws, nslab, N, out, accumulate);
+    hipLaunchKernelGGL(k_colsum_final, rn_cdiv(N, 64), 1024, 0, st, (const float*)ws, nslab, N, out, accumulate, (int64_t)0, (int64_t)0);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+// `batch` matrices of one shape, x_bs floats apart (X2 likewise), out[b * out_bs + col]: two launches for all of them.  N >= 64 columns (narrower
+// ones: one rn_colsum per matrix).  ws: batch * rn_colsum_ws_bytes(M, N).  The sums of a matrix are those of rn_colsum, term for term.
+int rn_colsum_batched(const float* X, const float* X2, int mode, int act, int64_t M, int64_t N, int64_t ld, int batch, int64_t x_bs, float* out,
+                      int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (M < 1 || N < 64 || batch < 1 || batch > 65535) return RECNOW_EUNSUPPORTED;
+    if (!X || (mode && !X2) || !ws || !out) return RECNOW_EINVAL;
+    const size_t one = rn_colsum_ws_bytes(M, N);
+    if (ws_bytes < one * (size_t)batch) return RECNOW_EWORKSPACE;
+    const int rows = cs_rows(M, N);
+    const int nslab = rn_cdiv(M, rows);
+    const int cw = N <= 64 ? 64 : N <= 128 ? 128 : 256;
+    const int64_t part_bs = (int64_t)(one / sizeof(float));
+    dim3 g1(rn_cdiv(N, cw), nslab, batch);
+    hipLaunchKernelGGL(k_colsum_partial, g1, 256, 0, st, X, X2, mode, act, M, N, ld, (float*)ws, rows, cw, x_bs, part_bs);
+    dim3 g2(rn_cdiv(N, 64), batch);
+    hipLaunchKernelGGL(k_colsum_final, g2, 1024, 0, st, (const float*)ws, nslab, N, out, 0, part_bs, out_bs);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
 }

@@ -38,3 +38,5 @@ static inline recnow_gemm_desc rn_gemm_desc_zero() {
 int rn_colsum(const float* X, const float* X2, int mode, int act, int64_t M, int64_t N, int64_t ld, float* out,
               int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rn_colsum_ws_bytes(int64_t M, int64_t N);
+int rn_colsum_batched(const float* X, const float* X2, int mode, int act, int64_t M, int64_t N, int64_t ld, int batch, int64_t x_bs, float* out,
+                      int64_t out_bs, void* ws, size_t ws_bytes, hipStream_t st);

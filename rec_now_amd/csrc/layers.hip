@@ -265,7 +265,7 @@ extern "C" size_t recnow_multi_dense_workspace_bytes(int64_t B, int D, int U, in
     if (t > s) s = t;
     size_t sk = (N == 1 && U == 1) ? head_ws_bytes(B, D) : 0;
     if (xty_ok(B, D, U, N) && xty_ws_bytes(B, D, U) > sk) sk = xty_ws_bytes(B, D, U);
-    return (s > sk ? s : sk) + rn_colsum_ws_bytes(B, U) + 256;
+    return (s > sk ? s : sk) + rn_colsum_ws_bytes(B, U) * (size_t)(N > 0 ? N : 1) + 256;      // (the column sums of all N experts' bias gradients run as one launch)
 }
 
 extern "C" int recnow_multi_dense_fwd(const float* x, int x_batched, const float* kernel, const float* bias, int64_t B, int D,
@@ -356,10 +356,14 @@ extern "C" int recnow_multi_dense_bwd(const float* x, int x_batched, const float
         if ((rc = rn_gemm(&d, ws, ws_bytes, st))) return rc;
     }
     if (dbias) {
-        for (int n = 0; n < N; ++n)
-            if ((rc = rn_colsum(dy + (int64_t)n * B * U, y + (int64_t)n * B * U, zmode, act, B, U, U, dbias + (int64_t)n * U, 0, ws,
-                                ws_bytes, st)))
-                return rc;
+        // the bias gradients of all N experts in one pair of launches (N > 1, U >= 64); else one column sum per expert
+        rc = N > 1 ? rn_colsum_batched(dy, y, zmode, act, B, U, U, N, (int64_t)B * U, dbias, U, ws, ws_bytes, st) : RECNOW_EUNSUPPORTED;
+        if (rc == RECNOW_EUNSUPPORTED) {
+            rc = RECNOW_OK;
+            for (int n = 0; n < N && !rc; ++n)
+                rc = rn_colsum(dy + (int64_t)n * B * U, y + (int64_t)n * B * U, zmode, act, B, U, U, dbias + (int64_t)n * U, 0, ws, ws_bytes, st);
+        }
+        if (rc) return rc;
     }
     if (dx && narrow_ok(B, D, U, N)) {
         if ((rc = narrow_dense(dy, y, zmode, act, kernel, 1, nullptr, RECNOW_ACT_LINEAR, B, U, D, dx, st))) return rc;

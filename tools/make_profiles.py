@@ -86,6 +86,11 @@ with open('profiles/%s_bench_pmc_hbm.csv' % tag, 'w') as fo:
             fam[key][0] += n
             fam[key][1] += n * b
 traffic = {k: v / n for k, (n, v) in fam.items()}
+# HBM bytes of one STEP: every dispatch of the counter run, (2 FETCH + WRITE) * 1024, over the steps it ran (one k_pack_all / k_tile_pack launch per step)
+step_bytes = sum(n * (2 * fv + pmc['WRITE_SIZE'].get(k, (0, 0.0))[1]) * 1024 for k, (n, fv) in pmc['FETCH_SIZE'].items() if not k.startswith('void at::') and 'rocclr' not in k)
+# (the lazy build of the layers on 256 rows takes the row-block route, i.e. k_tile_pack: the k_pack_all launches are the full-size steps)
+n_steps_pmc = max(sum(n for k, (n, fv) in pmc['FETCH_SIZE'].items() if k.startswith('k_pack_all')), 1)
+traffic_step_gb = step_bytes / n_steps_pmc / 1e9
 sys.path.insert(0, ROOT)
 from bench import kernel_source_hash      # noqa: E402  (bench.py refuses the table when the kernel sources have changed since)
 json.dump({'kernel_source_sha256': kernel_source_hash(),
@@ -93,7 +98,6 @@ json.dump({'kernel_source_sha256': kernel_source_hash(),
                      'WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section (FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950); '
                      'launch-weighted mean over the instantiations of each tile family',
            'hbm_bytes_per_launch': traffic}, open('profiles/traffic.json', 'w'), indent=1)
-steps = 19      # 3 warm-up + 10 timed + 5 untimed host-enqueue diagnostic + 1 parity step
 hook = bench_line('gpurun_out/%s_stats.log' % tag)
 clean = json.load(open('gpurun_out/%s_bench.json' % tag)) if os.path.exists('gpurun_out/%s_bench.json' % tag) else None
 with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
@@ -102,9 +106,13 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
              'and the initialisers -- are dropped, so every average is over launches of the benchmarked shape): `%s_bench_kernel_stats.csv`; HBM counters '
              '(separate --pmc passes): `%s_bench_pmc_hbm.csv`; bench line of the same build WITHOUT the profiler: `%s_bench.json`; GEMM '
              'microbenchmark (`tools/gemm_bench.py`): `%s_gemm_bench.txt`.\n\n' % (n_dropped, tag, tag, tag, tag))
-    fo.write('Sum of kernel durations: %.1f ms over %d steps (3 warm-up + 10 timed + 5 untimed host-enqueue diagnostic + 1 parity step) = %.3f ms/step; the '
-             'grouping kernels run on a side stream under the forward pass, so this sum exceeds the wall time per step; `__amd_rocclr_copyBuffer` is the '
-             'parity step copying results to the host, outside the timed region.\n\n' % (tot / 1e6, steps, tot / 1e6 / steps))
+    n_steps_trace = max(sum(r['Calls'] for r in rows if r['Name'].startswith('k_pack_all')), 1)
+    fo.write('Sum of kernel durations: %.1f ms over %d steps (warm-up + timed + the untimed diagnostics: host-enqueue loop, exclusive-time account, parity step) = %.3f ms/step; '
+             'the grouping of the batch runs on the main stream in front of the forward pass since round 5; `__amd_rocclr_copyBuffer` is the '
+             'parity step copying results to the host, outside the timed region.\n\n' % (tot / 1e6, n_steps_trace, tot / 1e6 / n_steps_trace))
+    fo.write('**HBM traffic of one step (PMC, `%s_bench_pmc_hbm.csv`): %.2f GB** = the sum over every dispatch of the counter run of (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes, '
+             'divided by its %d steps (algorithmic: 1.34 GB; round 4: 11.3 GB -- the input gradient is now written once by layer 0\'s product instead of as a '
+             'read-modify-write in the product of every layer).\n\n' % (tag, traffic_step_gb, n_steps_pmc))
     gem = [r for r in rows if 'k_gemm<128, 128' in r['Name'] and ', 25>' not in r['Name']]      # (the ', 25>' instantiation: GEMM1 + sub-space forward, listed on its own)
     if gem:
         gavg = sum(r['TotalDurationNs'] for r in gem) / sum(r['Calls'] for r in gem) / 1e3
@@ -130,7 +138,8 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
     fo.write('\n## The per-rank shards of the metric\'s 2 / 4 / 8-GPU rows on one GPU (`bench.py --rows R --force-dist`: every collective of the N > 1 path over a 1-rank RCCL group)\n\n')
     fo.write('| rows per GPU (N) | ms/step unprofiled | ideal = 1-GPU step / N | strong-scaling efficiency of the shard | host enqueue ms | kernel stats |\n|---|---|---|---|---|---|\n')
     base = None
-    for rws, n in ((65536, 1), (32768, 2), (16384, 4), (8192, 8)):
+    accounts = []
+    for rws, n in ((65536, 1), (32768, 2), (16384, 4), (8192, 8), (8177, 8)):
         pth = 'gpurun_out/%s_bench_rows%d.json' % (tag, rws)
         if not os.path.exists(pth):
             continue
@@ -138,6 +147,7 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
         shutil.copy(pth, 'profiles/%s_bench_rows%d.json' % (tag, rws))
         if base is None:
             base = d['ms_per_step']
+        acct = (d.get('roofline') or {}).get('exclusive_ms_per_step')
         ks = ''
         try:
             ft = newest('gpurun_out/%s_stats_rows%d/*/*_kernel_trace.csv' % (tag, rws))
@@ -146,6 +156,23 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
         except (IndexError, StopIteration):
             pass
         fo.write('| %d (%d) | %.3f | %.3f | %.2f | %.3f | %s |\n' % (rws, n, d['ms_per_step'], base / n, base / n / d['ms_per_step'], d['config']['host_enqueue_ms_per_step'], ks))
+        if acct:
+            accounts.append((rws, d.get('comm_exposed_ms'), acct))
+    if accounts:
+        fo.write('\nExclusive time per kernel family and step (ms; `roofline.exclusive_ms_per_step` of the lines above: ten untimed steps with every hooked launch '
+                 'and phase recorded, an instant shared by k running launches counts 1/k for each) and what the collectives add to a step (`comm_exposed_ms`):\n\n')
+        for rws, ce, acct in accounts:
+            fo.write('* %d rows (comm exposed %s ms): %s\n' % (rws, ('%.3f' % ce) if ce is not None else '-', '; '.join('%s %.3f' % (k.split(' (')[0], v) for k, v in acct.items())))
+    ph = 'gpurun_out/%s_bench_hash2.json' % tag
+    if os.path.exists(ph):
+        try:
+            d = json.loads(open(ph).read().strip().splitlines()[-1])
+            shutil.copy(ph, 'profiles/%s_bench_hash2.json' % tag)
+            fo.write('\n`--gpus 2 --backend gloo --oversubscribe --shard hash --rows 32768` (ONE global batch of 65 536 rows split by `dp.shard_rows_by_group` over two '
+                     'processes on this GPU): rows per rank %s, %.3f ms/step, cross-rank gate %s (worst %.2g).\n'
+                     % (d['config']['rows_per_rank'], d['ms_per_step'], 'ok' if d['parity']['ok'] else 'FAILED', d['parity']['parity_max_rel']))
+        except (ValueError, KeyError, IndexError):
+            pass
     pg = 'gpurun_out/%s_bench_rows8192_graph.json' % tag
     if os.path.exists(pg):
         d = json.loads(open(pg).read().strip().splitlines()[-1])

@@ -11,9 +11,11 @@ python3 $R/bench.py --steps 20 --warmup 5 --unfused --no-cpu-baseline > $O/${TAG
 python3 $R/bench.py --steps 20 --warmup 5 --route autograd --no-cpu-baseline > $O/${TAG}_bench_autograd.json 2>> $O/${TAG}_bench.err
 python3 $R/bench.py --steps 20 --warmup 5 --gemm-precision bf16x3 --no-cpu-baseline > $O/${TAG}_bench_bf16x3.json 2>> $O/${TAG}_bench.err
 # the per-rank shards of the metric's 1/2/4/8-GPU rows on one GPU, every collective of the N > 1 path over a 1-rank RCCL group
-for rows in 65536 32768 16384 8192; do
+for rows in 65536 32768 16384 8192 8177; do       # (8177: a ragged per-rank batch on padded storage, recnow_dcn_mix_step_desc.B_pad)
   python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --rows $rows --force-dist > $O/${TAG}_bench_rows${rows}.json 2>> $O/${TAG}_bench.err || exit 1
 done
+# ONE global batch of 65 536 rows split by dp.shard_rows_by_group over two ranks (two processes on this one GPU over gloo): ragged shards, cross-rank gate
+python3 $R/bench.py --gpus 2 --backend gloo --oversubscribe --shard hash --rows 32768 --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_hash2.json 2>> $O/${TAG}_bench.err
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --rows 8192 --force-dist --graph > $O/${TAG}_bench_rows8192_graph.json 2>> $O/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 for d in stats pmc_fetch pmc_write stats_rows32768 stats_rows16384 stats_rows8192; do rm -rf $O/${TAG}_$d; done
