@@ -239,22 +239,37 @@ class LayerwiseReducer(object):
     to the live `p.grad` (= the bucket view), and `reduce` all-reduces the accumulated sum -- note that `reduce` scales the whole
     bucket by 1 / (P_global + eps) each time it runs, so accumulate with ONE `reduce` at the end of the accumulation window."""
 
-    def __init__(self, stages, events, device):
+    def __init__(self, stages, events, device, one_collective=None):
         self.stages = [[p for p in stage if p.requires_grad] for stage in stages]
         self.events = list(events)
         if len(self.events) != len(self.stages):
             raise ValueError('one event per stage')
         dev = torch.device(device)
         self.comm = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None      # CPU (gloo tests): in order
+        # one_collective (default: RECNOW_DP_ONE_BUCKET=1 in the environment, else off): ONE all-reduce over all stages' gradients behind the last
+        # stage instead of one per stage under the backward pass.  Per-stage collectives hide all but the last bucket's -- when something can run
+        # beside the backward launches.  The row-block backward chain of the shard sizes is ONE launch that holds every CU, followed by ~140 us of
+        # weight-gradient products: the stages' events then fire within ~40 us of each other at the end of the pass (DESIGN.md section 7), so
+        # three 1 MB ring all-reduces (latency-bound: ~3 x (2 (N-1) hops x ~2 us + 2 x 1.06 MB (N-1)/N / 153 GB/s) each) queue up behind the
+        # step, where one 3.2 MB all-reduce pays the hop latency once.  Which wins is a property of the node: the switch makes it an A/B.
+        self.one_collective = (_os.environ.get('RECNOW_DP_ONE_BUCKET') == '1') if one_collective is None else bool(one_collective)
         self._flat, self._view = [], {}
+        # the stages' buckets are slices of ONE allocation (each starting on a 16-byte boundary): per-stage collectives see their own
+        # slice, the one-collective form the whole of it
+        sizes = [sum(p.numel() for p in stage) + (2 if i == 0 else 0) for i, stage in enumerate(self.stages)]
+        starts, total = [], 0
+        for n in sizes:
+            starts.append(total)
+            total += -(-n // 4) * 4
+        self._all = torch.zeros(max(total, 4), dtype=torch.float32, device=dev)
         for i, stage in enumerate(self.stages):
-            n = sum(p.numel() for p in stage) + (2 if i == 0 else 0)
-            flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            flat = self._all[starts[i]:starts[i] + sizes[i]]
             off = 0
             for p in stage:
                 self._view[id(p)] = flat[off:off + p.numel()]
                 off += p.numel()
             self._flat.append(flat)
+        self._rest = self._all[-(-sizes[0] // 4) * 4:] if len(sizes) > 1 else self._all[:0]      # everything behind the first stage (+ its statistics)
 
     def buffer_of(self, param):
         """The slice of its stage's flat bucket that holds `param`'s gradient (1-D view), or None for a foreign parameter."""
@@ -275,7 +290,19 @@ class LayerwiseReducer(object):
         flat = self._flat[i]
         n_grad = flat.numel() - (2 if i == 0 else 0)
         stats = self._flat[0][-2:]
+        last = i == len(self._flat) - 1
         if self.comm is None:                       # CPU tensors (gloo tests): in order on the host
+            if self.one_collective:
+                if not last:
+                    return
+                if is_dist() and not _SKIP_COLLECTIVE:
+                    dist.all_reduce(self._all, op=dist.ReduceOp.SUM)
+                inv = 1.0 / (stats[1] + eps)
+                self._result = torch.stack([stats[0] * inv, stats[1]])
+                n0 = self._flat[0].numel() - 2
+                self._flat[0][:n0].mul_(inv)
+                self._rest.mul_(inv)
+                return
             if is_dist() and not _SKIP_COLLECTIVE:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat[:n_grad].mul_(1.0 / (stats[1] + eps))
@@ -287,9 +314,27 @@ class LayerwiseReducer(object):
         ev = self.events[i]
         if not recorded:
             _lib.call('recnow_event_record', ev.handle, _lib._P(main.cuda_stream))
-        ev.wait(self.comm)
         if getattr(self, '_result', None) is None or not self._result.is_cuda:
             self._result = torch.empty(2, dtype=torch.float32, device=flat.device)
+        if self.one_collective:
+            if not last:
+                return
+            for e in self.events:                   # the stages' events are recorded on different streams: wait for every one of them
+                e.wait(self.comm)
+            if is_dist() and not _SKIP_COLLECTIVE:
+                torch.cuda.set_stream(self.comm)
+                try:
+                    dist.all_reduce(self._all, op=dist.ReduceOp.SUM)
+                finally:
+                    torch.cuda.set_stream(main)
+            n0 = self._flat[0].numel() - 2
+            _lib.call('recnow_scale_by_inv_count', _lib.ptr(self._flat[0]), n0, _lib.ptr(stats[1:]), float(eps), _lib.ptr(stats), _lib.ptr(self._result),
+                      _lib._P(self.comm.cuda_stream))
+            if self._rest.numel():
+                _lib.call('recnow_scale_by_inv_count', _lib.ptr(self._rest), self._rest.numel(), _lib.ptr(stats[1:]), float(eps), None, None,
+                          _lib._P(self.comm.cuda_stream))
+            return
+        ev.wait(self.comm)
         if is_dist() and not _SKIP_COLLECTIVE:
             torch.cuda.set_stream(self.comm)        # (the context manager costs ~40 us of host time per use)
             try:

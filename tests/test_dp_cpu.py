@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -315,7 +316,7 @@ def test_gathered_loss_keeps_integer_ids_exact_and_accepts_group_lists():
 
 
 # ---- in-place protocol of step.DCNMixPairwiseStep: gradients and statistics produced inside the buckets ---------------------
-def _worker_inplace(rank, world, port, out):
+def _worker_inplace(rank, world, port, out, one_collective=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -328,7 +329,7 @@ def _worker_inplace(rank, world, port, out):
     f = lambda p, n, wgt: R.bpr_loss_func(p, n, wgt, 1.0, reduce_mean=False)      # noqa: E731
     local_sum, n_pair = R.pairwise_loss(sc, torch.from_numpy(y[mine]), torch.from_numpy(g[mine].astype(np.float32)), f, return_num_pair=True)
     ga, gb = torch.autograd.grad(local_sum, [wa, wb])
-    red = dp.LayerwiseReducer([[wb], [wa]], [None, None], 'cpu')
+    red = dp.LayerwiseReducer([[wb], [wa]], [None, None], 'cpu', one_collective=one_collective)
     # what the step's kernels do on the GPU: gradients written into the bucket slices, {loss sum, pair count} into the slot
     red.buffer_of(wb).copy_(gb.reshape(-1))
     red.buffer_of(wa).copy_(ga.reshape(-1))
@@ -342,12 +343,14 @@ def _worker_inplace(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_in_place_reducer_protocol_equals_single_process():
+@pytest.mark.parametrize('one_collective', [False, True])
+def test_in_place_reducer_protocol_equals_single_process(one_collective):
+    """one_collective: ONE all-reduce over all stages behind the last one (RECNOW_DP_ONE_BUCKET=1) instead of one per stage."""
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker_inplace, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker_inplace, args=(world, port, out, one_collective), nprocs=world, join=True)
     g, s, y, w = _make_batch(seed=13, B=600, G=29)
     wa = torch.from_numpy(w[:2].copy()).requires_grad_(True)
     wb = torch.from_numpy(w[2:3].copy()).requires_grad_(True)
