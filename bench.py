@@ -64,6 +64,7 @@ ROWS_PER_GROUP = 64
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 16 * 157.3     # same guide: the fp32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
 PEAK_HBM_GBS = 8000.0                 # same guide, "HBM3E peak BW" (spec; 6.29 TB/s is the measured copy ceiling)
+REWARM_STEPS, REWARM_SECONDS = 3, 0.06   # untimed steps between the host-side preparations of the timed region (gc, hook events) and its start: at least 3, and 60 ms of them
 PROF_EVERY = 5                        # time every 5th hooked launch (24 per step: every launch position gets sampled)
 GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>',
              5: 'k_gemm_shortk', 8: 'k_gemm_split',         # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
@@ -620,12 +621,45 @@ def main():
     if prof:
         _lib.check(lib.recnow_prof_enable(64 * (args.steps + 1)), 'recnow_prof_enable')
         _lib.check(lib.recnow_prof_sample_every(prof_every), 'recnow_prof_sample_every')
+    # The cyclic garbage collector stays out of the timed region: a full (generation-2) collection of this process's heap takes 35-65 ms -- seen in
+    # round 5 as ONE step of 36-66 ms at a fixed wall time after start-up (whichever step that was), followed by five slower steps while the GPU's
+    # clocks recovered from the idle gap; the autograd routes, which allocate graph objects every step, hit it inside 20 timed steps (5.2 ms
+    # average against 3.4), the step entry allocates nothing and never did.  Collected once here, disabled until the timed steps are done.
+    import gc
+    gc.collect()
+    gc.disable()
+    # ... and the GPU has idled for tens of milliseconds under that collection and the creation of the hook's events: its clocks take ~5 steps to
+    # come back (per-step times after such a gap: 4.3 4.2 3.9 3.7 3.65 ... 3.45 ms; with eight more untimed steps still 3.58 3.51 3.44 3.36 3.35 3.31
+    # ... 3.24).  60 ms of further UNTIMED steps close the gap; their hook samples are discarded, so the roofline samples are launches of the timed
+    # steps only.  (`config.untimed_steps` says how many steps ran before the timed ones in all.)
+    rewarm = 0
+    c0 = time.perf_counter()
+    while rewarm < REWARM_STEPS or (time.perf_counter() - c0 < REWARM_SECONDS and rewarm < 500):      # (the ramp is a matter of time, not of steps)
+        run_step()
+        torch.cuda.synchronize()
+        rewarm += 1
+    for _ in range(2):
+        run_step()
+    rewarm += 2
+    if prof:
+        _c, _m, _f, _b = (ctypes.c_int * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
+        _lib.check(lib.recnow_prof_collect(_c, _m, _f, _b), 'recnow_prof_collect')      # (synchronises; rewinds the sample pool)
+        _lib.check(lib.recnow_prof_sample_every(prof_every), 'recnow_prof_sample_every')
     sync()
+    if os.environ.get('RECNOW_BENCH_STEPTIMES') == '1':      # diagnostic: every step's own wall time, device-synchronised (changes what is measured)
+        per = []
+        for _ in range(args.steps):
+            c0 = time.perf_counter()
+            run_step()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - c0) * 1e3)
+        print('[bench] per-step ms: %s' % ' '.join('%.2f' % v for v in per), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run_step()
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     mark('timed region done')
     roofline = None
     prof_note = 'every %dth hooked launch of the timed region' % (PROF_EVERY if rows >= 65536 else 23)
@@ -891,7 +925,7 @@ def main():
                                  + (', replayed from HIP graphs' if use_graph else '') + (', weight-gradient products on a second stream' if two_streams else '')
                                  + (', ragged batch on padded storage (%d -> %d rows)' % (pstep.B, pstep.B_pad) if pstep.B_pad != pstep.B else '')) if use_step else
                                 'fused node dcn_mix_score through autograd + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
-                       'loss': float(loss.item()), 'host_enqueue_ms_per_step': host_ms,
+                       'loss': float(loss.item()), 'host_enqueue_ms_per_step': host_ms, 'untimed_steps': args.warmup + rewarm,
                        'grads_copied_into_buckets': getattr(layerwise, 'last_foreign', None) if layerwise is not None else None},
             'roofline': roofline,
             'parity': parity,

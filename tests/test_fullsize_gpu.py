@@ -72,11 +72,11 @@ def test_cin_config4_per_rank_size(dev):
     """configs[3] layer alone: F = 64, D = 16, H = [128, 128, 128]: the output, d / d x on ALL rows and ALL THREE
     weight gradients against the fp64 oracle evaluated chunk-wise over the whole batch (oracle/dense_ref.cin_layer_gemm_form,
     reference /root/reference/rec_now/layers/cin_layer.py:101-110; weight gradients summed over the chunks in fp64).
-    B = 4096 here; the per-rank size B = 16 384 of the same layer -- all rows, all weight gradients -- runs inside the c4 MODEL test
+    B = 2048 here; the per-rank size B = 16 384 of the same layer -- all rows, all weight gradients -- runs inside the c4 MODEL test
     (tests/test_models_gpu.py::test_config4_model_per_rank_size_vs_oracle): one fp64 oracle of that size per suite run."""
     from _chunked_oracle import run_chunked
     from rec_now_amd.layers.cin_layer import CINLayer
-    B, F, D, Hs = 4096, 64, 16, [128, 128, 128]
+    B, F, D, Hs = 2048, 64, 16, [128, 128, 128]
     g = torch.Generator(device='cpu').manual_seed(12)
     x = torch.randn(B, F * D, generator=g) * 0.3
     gy = torch.randn(B, D, generator=g)
