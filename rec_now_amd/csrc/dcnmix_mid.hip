@@ -584,6 +584,10 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
     // re-read last tile again, which nobody uses).
     prefetch((int64_t)blockIdx.x * MID_ROWS);
     __syncthreads();                       // VTs complete
+    if (sl.stagger > 0 && (int)blockIdx.x >= (int)gridDim.x / 2) {      // experiment: de-phase the two workgroups of a CU (every wave leaves the bounded loop)
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (long long)sl.stagger && wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(8);
+    }
     stage();
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * MID_ROWS;
@@ -709,7 +713,7 @@ int rn_mix_mid_fwd(const float* T1, const float* V, float* T2, float* T2g, int64
     if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
     if (slabs && (!rn_mix_mid_absorbs_slabs(B, S, N, LDT) || (slabs->n != 2 && slabs->n != 4))) return RECNOW_EUNSUPPORTED;
     RnSlabs sl;
-    sl.p = nullptr; sl.n = 0; sl.ld = 0; sl.stride = 0;
+    sl.p = nullptr; sl.n = 0; sl.ld = 0; sl.stride = 0; sl.stagger = 0;
     if (slabs) sl = *slabs;
     const size_t lds = mid_fwd_lds(S, N);
     int rc;
@@ -753,8 +757,10 @@ int rn_mix_mid_bwd(const float* dT2g, const float* T2, const float* T1, const fl
     if (!rn_mix_mid_supported(S, N, LDT)) return RECNOW_EUNSUPPORTED;
     if (slabs && (!rn_mix_mid_absorbs_slabs(B, S, N, LDT) || (slabs->n != 2 && slabs->n != 4))) return RECNOW_EUNSUPPORTED;
     RnSlabs sl;
-    sl.p = nullptr; sl.n = 0; sl.ld = 0; sl.stride = 0;
+    sl.p = nullptr; sl.n = 0; sl.ld = 0; sl.stride = 0; sl.stagger = 0;
     if (slabs) sl = *slabs;
+    static const int stagger = []() { const char* e = getenv("RECNOW_MID_STAGGER"); return e ? atoi(e) : 0; }();      // experiment, 10 ns ticks
+    sl.stagger = stagger;
     if (ws_bytes < rn_mix_mid_bwd_ws_bytes(B, S, N)) return RECNOW_EWORKSPACE;
     const size_t lds = mid_bwd_lds(S, N);
     const int grid = mid_grid(B);

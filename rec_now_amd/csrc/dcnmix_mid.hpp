@@ -11,6 +11,7 @@ struct RnSlabs {
     const float* p;
     int n, ld;
     int64_t stride;
+    int stagger;        // backward fast kernel, experiment (RECNOW_MID_STAGGER, 10 ns ticks): the second resident round of workgroups starts this late
 };
 bool rn_mix_mid_absorbs_slabs(int64_t B, int S, int N, int LDT);
 size_t rn_mix_mid_bwd_ws_bytes(int64_t B, int S, int N);
