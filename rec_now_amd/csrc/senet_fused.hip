@@ -62,19 +62,32 @@ k_senet_fused_fwd(const float* const* __restrict__ fields, SfDims dm, int64_t B,
     const int64_t FD = (int64_t)F * D;
     int P = 1;                                             // threads per hidden unit in the first product (power of two <= 8)
     while (P < 8 && 2 * P * SF_R * M <= 256) P *= 2;
+    // Round 5: the rows of step s + 1 are REQUESTED while step s runs its excitation (a second register set, unconditional loads from clamped
+    // rows -- a load under a lane condition ends in a full wait at its merge, DESIGN.md 5e -- masked when used): a step was
+    // load -> wait -> squeeze -> two small products -> scale -> store, strictly in series per workgroup (3.5 TB/s with eight workgroups per CU).
+    sf_f4 vn[SF_R];
+    auto request = [&](int64_t r0) {
+#pragma unroll
+        for (int j = 0; j < SF_R; ++j) {
+            const int64_t r = r0 + j < B ? r0 + j : B - 1;
+            vn[j] = *reinterpret_cast<const RN_GLOBAL sf_f4*>(xf + r * D);
+        }
+    };
+    request((int64_t)blockIdx.x * SF_R);
     for (int64_t b0 = (int64_t)blockIdx.x * SF_R; b0 < B; b0 += (int64_t)gridDim.x * SF_R) {
         sf_f4 v[SF_R];
 #pragma unroll
-        for (int j = 0; j < SF_R; ++j) {
-            v[j] = sf_f4{0.f, 0.f, 0.f, 0.f};
-            if (col && b0 + j < B) v[j] = *reinterpret_cast<const RN_GLOBAL sf_f4*>(xf + (b0 + j) * D);
-        }
+        for (int j = 0; j < SF_R; ++j) v[j] = (col && b0 + j < B) ? vn[j] : sf_f4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                                   // previous step is done with sq / hs / ws (and the weights are loaded)
 #pragma unroll
         for (int j = 0; j < SF_R; ++j) {
             float s = (v[j].x + v[j].y) + (v[j].z + v[j].w);
             for (int o = Q / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (col && d == 0) sq[j * F + f] = s / (float)D;
+        }
+        {
+            const int64_t nb0 = b0 + (int64_t)gridDim.x * SF_R;
+            request(nb0 < B ? nb0 : b0);                   // (the last step re-reads its own rows: the loads stay unconditional)
         }
         __syncthreads();
         {                                                  // h = act1(sq W1 + b1): P threads share one output's k range
@@ -171,15 +184,25 @@ k_senet_fused_bwd(const float* const* __restrict__ fields, float* const* __restr
             pb[i] = o_z2 + (o - 2 * FM - M);
         }
     }
+    // the fields and the upstream gradient of step s + 1 are requested while step s computes (as the forward kernel, round 5)
+    sf_f4 vn[SF_R], gn[SF_R];
+    const int tq = col ? t : QT - 1;                       // a thread beyond the row (F * D / 4 < 256) reads the last float4 and masks it
+    auto request = [&](int64_t r0) {
+#pragma unroll
+        for (int j = 0; j < SF_R; ++j) {
+            const int64_t r = r0 + j < B ? r0 + j : B - 1;
+            vn[j] = *reinterpret_cast<const RN_GLOBAL sf_f4*>(xf + r * D);
+            gn[j] = *reinterpret_cast<const sf_f4*>(dout + r * FD + tq * 4);
+        }
+    };
+    request((int64_t)blockIdx.x * SF_R);
     for (int64_t b0 = (int64_t)blockIdx.x * SF_R; b0 < B; b0 += (int64_t)gridDim.x * SF_R) {
         sf_f4 v[SF_R], g[SF_R];
 #pragma unroll
         for (int j = 0; j < SF_R; ++j) {
-            v[j] = g[j] = sf_f4{0.f, 0.f, 0.f, 0.f};
-            if (col && b0 + j < B) {
-                v[j] = *reinterpret_cast<const RN_GLOBAL sf_f4*>(xf + (b0 + j) * D);
-                g[j] = *reinterpret_cast<const sf_f4*>(dout + (b0 + j) * FD + t * 4);
-            }
+            const bool live = col && b0 + j < B;
+            v[j] = live ? vn[j] : sf_f4{0.f, 0.f, 0.f, 0.f};
+            g[j] = live ? gn[j] : sf_f4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();                                   // previous step is done with the row vectors
         for (int i = t; i < SF_R * F; i += 256) {
@@ -197,6 +220,10 @@ k_senet_fused_bwd(const float* const* __restrict__ fields, float* const* __restr
             float s = (v[j].x * g[j].x + v[j].y * g[j].y) + (v[j].z * g[j].z + v[j].w * g[j].w);
             for (int o = Q / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (col && d == 0) z2[j * SF_RS + f] = s;
+        }
+        {
+            const int64_t nb0 = b0 + (int64_t)gridDim.x * SF_R;
+            request(nb0 < B ? nb0 : b0);
         }
         __syncthreads();
         if (t < SF_R * F) {                                // dz2 = dW * act2'(w)   (rows past B: zero)
