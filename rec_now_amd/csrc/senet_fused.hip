@@ -12,7 +12,9 @@
 #include "common.hpp"
 #include "gemm.hpp"
 
-#define SF_R 4                 // batch rows per workgroup step
+#ifndef SF_R
+#define SF_R 4                 // batch rows per workgroup step (-DSF_R=8: A/B through tools/build_variant.py)
+#endif
 typedef float sf_f4 __attribute__((ext_vector_type(4)));
 
 struct SfDims {
@@ -90,8 +92,9 @@ k_senet_fused_fwd(const float* const* __restrict__ fields, SfDims dm, int64_t B,
             request(nb0 < B ? nb0 : b0);                   // (the last step re-reads its own rows: the loads stay unconditional)
         }
         __syncthreads();
-        {                                                  // h = act1(sq W1 + b1): P threads share one output's k range
-            const int o = t / P, part = t - o * P;
+        // h = act1(sq W1 + b1): P threads share one output's k range; 256 / P outputs per round (the P lanes of an output run the same rounds)
+        for (int o = t / P; o < (SF_R * M + 256 / P - 1) / (256 / P) * (256 / P); o += 256 / P) {
+            const int part = t % P;
             const bool act = o < SF_R * M;
             const int j = act ? o / M : 0, m = act ? o - j * M : 0;
             float a = 0.f;
@@ -105,15 +108,15 @@ k_senet_fused_fwd(const float* const* __restrict__ fields, SfDims dm, int64_t B,
             }
         }
         __syncthreads();
-        if (t < SF_R * F) {                                // w = act2(h W2 + b2)
-            const int j = t / F, k = t - j * F;
+        for (int i = t; i < SF_R * F; i += 256) {          // w = act2(h W2 + b2)
+            const int j = i / F, k = i - j * F;
             float a = b2s[k];
             for (int m = 0; m < M; ++m) a += hs[j * M + m] * w2s[m * F + k];
             a = rn_act(a, dm.act2);
-            ws[t] = a;
+            ws[i] = a;
             if (b0 + j < B) {
                 w_save[(b0 + j) * F + k] = a;
-                sq_save[(b0 + j) * F + k] = sq[t];
+                sq_save[(b0 + j) * F + k] = sq[i];
             }
         }
         __syncthreads();
@@ -226,13 +229,14 @@ k_senet_fused_bwd(const float* const* __restrict__ fields, float* const* __restr
             request(nb0 < B ? nb0 : b0);
         }
         __syncthreads();
-        if (t < SF_R * F) {                                // dz2 = dW * act2'(w)   (rows past B: zero)
-            const int j = t / F, k = t - j * F;
+        for (int i = t; i < SF_R * F; i += 256) {          // dz2 = dW * act2'(w)   (rows past B: zero)
+            const int j = i / F, k = i - j * F;
             z2[j * SF_RS + k] *= rn_act_grad_from_out(ws[j * SF_RS + k], dm.act2);
         }
         __syncthreads();
-        {                                                  // dz1 = (dz2 W2^T) * act1'(h): P threads share one output's k range
-            const int o = t / P, part = t - o * P;
+        // dz1 = (dz2 W2^T) * act1'(h): P threads share one output's k range; 256 / P outputs per round
+        for (int o = t / P; o < (SF_R * M + 256 / P - 1) / (256 / P) * (256 / P); o += 256 / P) {
+            const int part = t % P;
             const bool act = o < SF_R * M;
             const int j = act ? o / M : 0, m = act ? o - j * M : 0;
             float a = 0.f;
@@ -242,8 +246,8 @@ k_senet_fused_bwd(const float* const* __restrict__ fields, float* const* __restr
             if (act && part == 0) z1[j * SF_RS + m] = a * rn_act_grad_from_out(hs[j * SF_RS + m], dm.act1);
         }
         __syncthreads();
-        if (t < SF_R * F) {                                // dsq = dz1 W1^T
-            const int j = t / F, k = t - j * F;
+        for (int i = t; i < SF_R * F; i += 256) {          // dsq = dz1 W1^T
+            const int j = i / F, k = i - j * F;
             float a = 0.f;
             for (int m = 0; m < M; ++m) a += z1[j * SF_RS + m] * w1s[k * L1 + m];
             dq[j * SF_RS + k] = a;
