@@ -632,15 +632,12 @@ def main():
     # come back (per-step times after such a gap: 4.3 4.2 3.9 3.7 3.65 ... 3.45 ms; with eight more untimed steps still 3.58 3.51 3.44 3.36 3.35 3.31
     # ... 3.24).  60 ms of further UNTIMED steps close the gap; their hook samples are discarded, so the roofline samples are launches of the timed
     # steps only.  (`config.untimed_steps` says how many steps ran before the timed ones in all.)
-    rewarm = 0
-    c0 = time.perf_counter()
-    while rewarm < REWARM_STEPS or (time.perf_counter() - c0 < REWARM_SECONDS and rewarm < 500):      # (the ramp is a matter of time, not of steps)
+    # The ramp is a matter of time, not of steps -- but the COUNT must be the same on every rank (a step holds collectives: ranks that ran different
+    # numbers of steps would wait for each other forever), so it is derived from the shard size, not from a clock: ~60 ms of steps at the
+    # step time this shape is known to take (3.3 ms per 65 536 rows + 0.25 ms of fixed cost), at least three.
+    rewarm = max(REWARM_STEPS, min(120, int(REWARM_SECONDS * 1e3 / (3.3 * rows / 65536.0 + 0.25)) + 1))
+    for _ in range(rewarm):
         run_step()
-        torch.cuda.synchronize()
-        rewarm += 1
-    for _ in range(2):
-        run_step()
-    rewarm += 2
     if prof:
         _c, _m, _f, _b = (ctypes.c_int * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
         _lib.check(lib.recnow_prof_collect(_c, _m, _f, _b), 'recnow_prof_collect')      # (synchronises; rewinds the sample pool)

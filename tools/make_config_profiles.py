@@ -14,7 +14,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 PEAK_HBM, PEAK_MFMA = 8000.0, 157.3
-NAMES = {'fm': 'fm_c4', 'dcn': 'dcn', 'cin': 'cin_c4', 'ple': 'ple_c5', 'pair': 'pairwise_c2c3', 'list': 'listwise_c5'}
+NAMES = {'fm': 'fm_c4', 'dcn': 'dcn', 'cin': 'cin_c4', 'ple': 'ple_c5', 'pair': 'pairwise_c2c3', 'list': 'listwise_c5',
+         'embed': 'embed', 'senet': 'senet', 'ipnn': 'inner_pnn', 'attn': 'attention'}
 
 
 def stats(key):
@@ -41,7 +42,7 @@ def pmc(key):
 
 def find(rows, prefix):
     for r in rows:
-        if r['Name'].replace('void ', '').startswith(prefix):
+        if r['Name'].replace('void ', '').startswith(prefix):  # noqa: E501
             return r
     return None
 
@@ -146,5 +147,43 @@ for r in rows[:8]:
 tot = sum(float(r['TotalDurationNs']) for r in rows) / 20 / 1e3
 lines.append('\nKernel time per step %.0f us = %.0f M rows/s of GPU time; the grouping (`k_group_mid`, one cooperative launch; round 4: the float ids 0..4095 are sorted by their integer images, 2 digit passes instead of 3) is %.0f %% of it.\n'
              % (tot, 262144 / tot, 100 * float(find(rows, 'k_group_mid')['TotalDurationNs']) / 20 / 1e3 / tot))
+# ---- HBM-bound layers beside the hot path (round 5) --------------------------------------------------------------------
+B, F, D, L = 131072, 64, 16, 50
+P = F * (F - 1) // 2
+try:
+    lines.append('## SURVEY 8f rows (round 5): achieved HBM GB/s of the kernels\' own bytes (inputs read once, outputs written once), B = 131 072, F = 64, D = 16\n')
+    lines.append('| kernel | avg us | bytes / launch | achieved GB/s | of 8 TB/s |\n|---|---|---|---|---|')
+    for key, items in (('senet', (('k_senet_fused_fwd', 8.0 * B * F * D, 'x read, x2 written'), ('k_senet_fused_bwd', 12.0 * B * F * D, 'x, dout read, dx written'))),
+                       ('ipnn', (('k_ipnn_fwd_gram', 4.0 * B * F * D + 4.0 * B * P, 'x read, P = 2016 pair products written'),
+                                 ('k_ipnn_bwd_gram', 8.0 * B * F * D + 4.0 * B * P, 'dP, x read, dx written'))),
+                       ('attn', (('k_attn_dot_v4<4, false>', 4.0 * B * L * D, 'user embeddings read (L = 50)'),
+                                 ('k_attn_dot_v4<4, true>', 8.0 * B * L * D, 'user embeddings read, their gradient written')))):
+        rows = stats(key)
+        tus, tb = 0.0, 0.0
+        for pre, byts, what in items:
+            r = find(rows, pre)
+            if r is None:
+                continue
+            us = float(r['AverageNs']) / 1e3
+            tus += us
+            tb += byts
+            lines.append('| `%s` (%s) | %.1f | %.0f MB | %.0f | %.2f |' % (r['Name'].split('(')[0].replace('void ', '')[:60], what, us, byts / 1e6, byts / us / 1e3, byts / us / 1e3 / PEAK_HBM))
+        if tus:
+            lines.append('| %s forward + backward | %.1f | %.0f MB | %.0f | %.2f |' % (NAMES[key], tus, tb / 1e6, tb / tus / 1e3, tb / tus / 1e3 / PEAK_HBM))
+    rows = stats('embed')
+    lines.append('\n## Pooled embedding lookup (SURVEY 8f.2): B = 65 536 x C = 100 ids, T = 64, D = 16, V = 2^20, Zipf ids -- kernels of one forward + backward\n')
+    lines.append('| kernel | launches / step | avg us | us / step |\n|---|---|---|---|')
+    nstep = max(int(find(rows, 'k_embed_rows_chunks')['Calls']), 1)
+    tot = 0.0
+    for r in rows[:18]:
+        if r['Name'].startswith('void at::') or 'rocclr' in r['Name']:
+            continue
+        per = float(r['TotalDurationNs']) / nstep / 1e3
+        tot += per
+        lines.append('| `%s` | %.1f | %.1f | %.1f |' % (r['Name'].split('(')[0].replace('void ', '')[:70], int(r['Calls']) / nstep, float(r['AverageNs']) / 1e3, per))
+    lines.append('\n(`k_embed_pool_fwd_v4` and `k_slot_targets` are also launched by the forward-only timing loop of the harness: their per-step figures count both.)  '
+                 'Listed kernels: %.0f us per step.\n' % tot)
+except (IndexError, TypeError, KeyError) as e:      # a refresh without those traces
+    lines.append('(no SURVEY 8f traces in this refresh: %s)\n' % e)
 open('profiles/%s_configs_summary.md' % tag, 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines))

@@ -6,11 +6,11 @@ TAG=${1:-r03}
 R=$PWD; O=$R/gpurun_out
 export RECNOW_LB_NOGRAPH=1
 cd /tmp && export TMPDIR=/tmp
-for key in fm dcn cin ple pair list; do
+for key in fm dcn cin ple pair list embed senet ipnn attn; do
   rm -rf $O/${TAG}_cfg_$key
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_cfg_$key -- python3 $R/tools/layer_bench.py 10 $key > $O/${TAG}_cfg_$key.log 2>&1 || exit 1
   find $O/${TAG}_cfg_$key -type f ! -name '*kernel_stats.csv' -delete
-  grep -v "^W2\|^$" $O/${TAG}_cfg_$key.log | grep -i "fwd+bwd\|pairwise_loss\|listwise" | head -6
+  grep -v "^W2\|^$" $O/${TAG}_cfg_$key.log | grep -i "fwd+bwd\|pairwise_loss\|listwise\|fwd " | head -6
 done
 for key in fm dcn; do
   for cnt in FETCH_SIZE WRITE_SIZE; do
