@@ -635,7 +635,7 @@ def main():
     # The ramp is a matter of time, not of steps -- but the COUNT must be the same on every rank (a step holds collectives: ranks that ran different
     # numbers of steps would wait for each other forever), so it is derived from the shard size, not from a clock: ~60 ms of steps at the
     # step time this shape is known to take (3.3 ms per 65 536 rows + 0.25 ms of fixed cost), at least three.
-    rewarm = max(REWARM_STEPS, min(120, int(REWARM_SECONDS * 1e3 / (3.3 * rows / 65536.0 + 0.25)) + 1))
+    rewarm = max(REWARM_STEPS, min(120, int(REWARM_SECONDS * 1e3 / (3.3 * max(rank_rows) / 65536.0 + 0.25)) + 1))      # (rank_rows: identical on every rank)
     for _ in range(rewarm):
         run_step()
     if prof:
