@@ -131,11 +131,8 @@ k_senet_fused_fwd(const float* const* __restrict__ fields, SfDims dm, int64_t B,
 // The per-row vectors of a step live in LDS with a FIXED row stride SF_RS (F, M <= 64): the rows of one vector are then
 // immediate offsets of one address, so a weight-gradient output costs two address registers, not two per row.
 #define SF_RS 64
-#ifndef SF_BWD_MINWG
-#define SF_BWD_MINWG 1         // workgroups per CU the backward kernel is compiled for (register cap 512 / (4 waves-per-SIMD share)); A/B through tools/build_variant.py
-#endif
 template <int NACC>
-__global__ void __launch_bounds__(256, SF_BWD_MINWG)
+__global__ void __launch_bounds__(256)
 k_senet_fused_bwd(const float* const* __restrict__ fields, float* const* __restrict__ dfields, SfDims dm, int64_t B,
                   const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ dout,
                   const float* __restrict__ sq_save, const float* __restrict__ h_save, const float* __restrict__ w_save,
