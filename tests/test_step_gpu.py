@@ -240,6 +240,34 @@ def test_ragged_batches_on_the_fast_route_vs_oracle(dev, one_rank_rccl, B, reduc
     assert torch.equal(step._scores_store[B:], torch.full_like(step._scores_store[B:], float(head.bias.reshape(-1)[0])))
 
 
+@pytest.mark.parametrize('B,D,L', [(100, 256, 2), (300, 512, 3), (1, 256, 1)])
+def test_small_ragged_batches_through_the_step_vs_oracle(dev, B, D, L):
+    """Batches below one 256-row block (down to a single row) through the step entry: padded to 256 / 512 rows, the grouping of the B rows in one
+    launch from the raw ids, every gradient against the fp64 oracle; mask and integer ids ride along at B = 300."""
+    from rec_now_amd.step import DCNMixPairwiseStep
+    S, N = 64, 2
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, max(B, 256), D, S, N, L, 77 + B)
+    x, groups, labels = x[:B], (groups[:B] % 7), labels[:B]
+    xd, yd = xd[:B].contiguous(), yd[:B].contiguous()
+    gd = torch.from_numpy(groups.astype(np.int32) if B == 300 else groups).to(dev)
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd)
+    assert step.B == B and step.B_pad == -(-B // 256) * 256
+    rs, rloss, rds, rP, rdx, rgrads, named = _oracle_step(x, groups, labels, cross, head, L, grouped=False)
+    for _ in range(2):
+        loss, n_pair = step.run()
+    torch.cuda.synchronize()
+    assert int(n_pair.item()) == rP
+    close(step.scores, rs, what='scores')
+    close(loss, np.float64(rloss), what='loss')
+    if rP > 0:
+        close(step.dx, rdx, what='dx')
+        for name, p in named.items():
+            close(p.grad, rgrads[name], what=name, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+    else:
+        assert not step.dx.any() and all(not p.grad.any() for p in named.values())
+    assert not step._x_store[B:].any() and not step._dx_store[B:].any()
+
+
 def test_ragged_batch_layer_routes_vs_oracle(dev):
     """B = 8177 through the drop-in routes: `head(cross(x))` + `pairwise_loss` as INTEGRATION.md writes it, and the fused node
     `dcn_mix_score`.  Both run the exact-128 formulation on a zero-padded copy (layers/_ops.py `ragged_pad_rows`); the same batch
