@@ -471,6 +471,26 @@ __device__ __forceinline__ float4 mid_nt_load4(const float* p) {
 #define MID_LD4(ptr) (*reinterpret_cast<const float4*>(ptr))
 #define MID_ST1(ptr, v) (*(ptr) = (v))
 #endif
+// -DRN_MID_TRACE (tools/build_variant.py midtrace -DRN_MID_TRACE; tools/mid_trace.py): 100 MHz wall-clock stamps of the phases of every tile of
+// workgroups 0 and gridDim.x / 2 of the LAST launch, read back through recnow_debug_mid_trace.  Not in product builds (the macros are empty).
+// Round 5, one box, microseconds per 32-row tile of workgroup 0 (a tile every 6.2-7.8 us): gate math 0.1-0.6 | request of the next tile (24 loads per
+// thread) 0.7-1.4 | dA chain (32 dependent MFMAs + 64 LDS operand reads) 1.4-2.2 | 16 dT1 stores per lane 0.5-1.6 | dV chains (2 x 16 MFMAs) 1.3-1.5 |
+// barrier 0.1 | gate columns 0.2-0.5 | staging the next tile into LDS (32 ds_write_b32 per thread, waits for its loads) 0.6-1.5: the phases of a
+// workgroup run in series and each is bound by the ISSUE of many small instructions, not by a roofline.  Interleaving the dA and dV chains (three
+// independent accumulators in one fully unrolled loop) measured SLOWER (46 -> 52.6 us per launch: the merged loop's LDS reads and register pressure cost
+// more than the dependency bubbles it removes) and is not kept.
+#ifdef RN_MID_TRACE
+__device__ long long g_mid_trace[2 * 16 * 10];
+#define MT_STAMP(k, i) do { if (threadIdx.x == 0 && (k) < 16 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) \
+        g_mid_trace[((blockIdx.x ? 1 : 0) * 16 + (k)) * 10 + (i)] = wall_clock64(); } while (0)
+#define MT_STAMP_ACC(k, i, v) do { asm volatile("" :: "v"(v)); MT_STAMP(k, i); } while (0)      // (the stamp waits for the accumulator it names)
+extern "C" int recnow_debug_mid_trace(long long* out_host) {
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_mid_trace), sizeof(long long) * 2 * 16 * 10);
+}
+#else
+#define MT_STAMP(k, i) do { } while (0)
+#define MT_STAMP_ACC(k, i, v) do { } while (0)
+#endif
 template <int S, int N, bool RS, int AI, int AO, int NSL>
 __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g, const float* __restrict__ T2, const float* __restrict__ T1,
                                                   const float* __restrict__ V, float* __restrict__ dT1, float* __restrict__ dVpart, int64_t B,
@@ -589,9 +609,12 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
         while (wall_clock64() - t0 < (long long)sl.stagger && wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(8);
     }
     stage();
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    MT_STAMP(0, 0);
+    int mt_k = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++mt_k) {
         const int64_t r0 = tile * MID_ROWS;
         __syncthreads();
+        MT_STAMP(mt_k, 1);
         if (tid < MID_ROWS) {
             float dg[N];
             float dot = 0.f;
@@ -603,10 +626,12 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
 #pragma unroll
             for (int n = 0; n < N; ++n) Ds[tid * N + n] = pgg[n] * (dg[n] - dot);
         }
+        MT_STAMP(mt_k, 2);
         {
             const int64_t nt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
             prefetch(nt * MID_ROWS);
         }
+        MT_STAMP(mt_k, 3);
         {   // dA_n = (dC_n V_n^T) * act_inner'(H1_n): one 32x32 output block (n, cb) per wave
             const int n = w / (S / 32), cb = w - n * (S / 32);
             f32x16 acc;
@@ -616,6 +641,7 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
             const float* bp = VTs + (n * S + (lane >> 5)) * LV + cb * 32 + (lane & 31);
 #pragma unroll 8
             for (int st = 0; st < S / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], bp[2 * st * LV], acc, 0, 0, 0);
+            MT_STAMP_ACC(mt_k, 4, acc[0]);
             const int col = n * S + cb * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -623,6 +649,7 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
                 MID_ST1(dT1 + (r0 + rr) * LDT + col, acc[r] * rn_act_grad_from_out(Hs[rr * LDA + col], act_inner));
             }
         }
+        MT_STAMP(mt_k, 5);
         // dV_n += H1_n^T dC_n over this tile's 32 rows: output blocks (n, mb, cb) stay in registers across tiles
 #pragma unroll
         for (int j = 0; j < VI; ++j) {
@@ -636,7 +663,9 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
                     accV[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st * LDA], bp[2 * st * LDA], accV[j], 0, 0, 0);
             }
         }
+        MT_STAMP_ACC(mt_k, 6, accV[0][0]);
         __syncthreads();
+        MT_STAMP(mt_k, 7);
         {   // columns NS .. NS + 15 of dT1: [dlogits | 0]; thread = (row, float4), two threads write each float4 (same values)
             const int row = tid >> 3, q = tid & 3;
             float g4[4];
@@ -644,7 +673,9 @@ __device__ __forceinline__ void mid_bwd_fast_body(const float* __restrict__ dT2g
             for (int e = 0; e < 4; ++e) g4[e] = 4 * q + e < N ? Ds[row * N + ((4 * q + e) < N ? 4 * q + e : 0)] : 0.f;
             *reinterpret_cast<float4*>(dT1 + (r0 + row) * LDT + NS + 4 * q) = make_float4(g4[0], g4[1], g4[2], g4[3]);
         }
+        MT_STAMP(mt_k, 8);
         stage();
+        MT_STAMP(mt_k, 9);
     }
     float* P = dVpart + (int64_t)blockIdx.x * N * S * S;
 #pragma unroll
