@@ -616,8 +616,10 @@ def main():
     prof = not args.no_prof and graph is None
     # the two timing events around a sampled launch serialise the stream for ~2 us each: nothing at 65 536 rows (24 hooked launches of ~150 us per
     # step), but 0.03 ms of a 0.64 ms step at 8192 rows when every 5th launch is sampled (measured: 0.640 timed vs 0.611 ms unhooked).  The
-    # shards sample every 23rd hooked launch instead (about one per step; 23 is prime, so every launch position still comes up).
-    prof_every = PROF_EVERY if rows >= 65536 else 23
+    # shards sample every 7th hooked launch instead (about one per step at the 8 hooked launches of a row-block step, four at the 27 of the
+    # product route; 7 is coprime to both, so every launch position comes up within a few steps: with every 23rd the backward chain's
+    # position went unsampled in a 20-step run and the line named the forward launch).
+    prof_every = PROF_EVERY if rows >= 65536 else 7
     if prof:
         _lib.check(lib.recnow_prof_enable(64 * (args.steps + 1)), 'recnow_prof_enable')
         _lib.check(lib.recnow_prof_sample_every(prof_every), 'recnow_prof_sample_every')
@@ -659,7 +661,7 @@ def main():
     gc.enable()
     mark('timed region done')
     roofline = None
-    prof_note = 'every %dth hooked launch of the timed region' % (PROF_EVERY if rows >= 65536 else 23)
+    prof_note = 'every %dth hooked launch of the timed region' % (PROF_EVERY if rows >= 65536 else 7)
     hook_done = False
     if not prof and hook_pre is not None:
         prof, hook_done = True, True
