@@ -696,6 +696,8 @@ int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t*
                         int64_t* n_pair, void* ws, size_t ws_bytes, void* stream, const double** part_out, int* nparts_out);      // pairwise.hip
 int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
                        int32_t* n_seg, hipStream_t st);       // scan_sort.hip
+int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st);       // scan_sort.hip
 
 extern "C" int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
@@ -1455,6 +1457,9 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
         RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_STEP_GROUP, 0.0, 16.0 * B, st) : nullptr;
         // small shards (<= 8192 rows, float32 / int32 ids): keys, solo flags, sort and segments in ONE launch straight from the id tensor
         rc = rn_group_small_raw(d->groups, d->group_dtype, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, st);
+        // larger batches: the cooperative launch forms keys and solo flags from the id tensor as well
+        if (rc == RECNOW_EUNSUPPORTED)
+            rc = rn_group_mid_raw(d->groups, d->group_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st);
         if (rc == RECNOW_EUNSUPPORTED) {
             RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
             if ((rc = recnow_group_keys(d->groups, d->group_dtype, B, w.words, w.solo, stream))) return rc;

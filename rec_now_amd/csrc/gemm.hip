@@ -343,8 +343,11 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
         }
         static const bool sp_narrow = []() { const char* e = getenv("RECNOW_SP_NARROW"); return !e || e[0] != '0'; }();      // A/B switch
         if (d->mid_V) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, 0, d->b_mode, 25, grid, st);      // XF 16 | 8 | 1: the fused sub-space forward
-        else if (rc == RECNOW_EUNSUPPORTED && sp_narrow && xf == 1 && d->sp_r <= 2 && !bk16)
-            rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, d->a_mode, d->b_mode, 9, grid, st);
+        else if (rc == RECNOW_EUNSUPPORTED && sp_narrow && xf == 1 && d->sp_r <= 2 && !bk16) {
+            static const bool glds = []() { const char* e = getenv("RECNOW_GEMM_GLDS"); return e && e[0] == '1'; }();      // A/B switch: LDS-DMA operand staging (XF | 32)
+            if (glds && !a_kc && !b_kc && d->a_mode == 0 && d->b_mode == 0) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, 0, 0, 41, grid, st);
+            if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, d->a_mode, d->b_mode, 9, grid, st);
+        }
         if (!d->mid_V && rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, bk16 ? 16 : 32, d->a_mode, d->b_mode, xf, grid, st);
         if (rc) return rc;
         }

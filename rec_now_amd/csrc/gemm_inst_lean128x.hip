@@ -16,6 +16,7 @@ int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2
     X(true, true, 0, 0, 9)
     X(false, false, 0, 0, 9)
     X(false, false, 1, 0, 9)
+    X(false, false, 0, 0, 41)   // XF | 32: both operands staged by LDS-DMA (RECNOW_GEMM_GLDS=1: the A/B of DESIGN 5k)
     X(false, true, 0, 0, 25)    // GEMM1 transposed ([U | K]^T x_l^T) with the sub-space forward in its epilogue (XF | 16)
     X(false, true, 0, 1, 25)    //          ... x_l = x0 * O_{l-1} formed in the operand load (dcnmix.hip mix_xless)
     X(true, false, 1, 0, 9)     // GEMM1 (not transposed) of a layer l > 0 likewise

@@ -6,6 +6,9 @@
 #include <type_traits>
 
 #define GEMM_THREADS 256
+#ifndef RN_GLDS_SPREAD
+#define RN_GLDS_SPREAD 8      // XF & 32: the LDS-DMAs of a k-tile go out behind its first RN_GLDS_SPREAD MFMA groups (of BK / 2)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // native 4-wide vector for the staging registers: HIP's float4 is a STRUCT, and whole-struct copies (global -> regs -> LDS)
@@ -294,6 +297,18 @@ struct Tile {
             v[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p + base) + bo);
             if (K2 != RECNOW_OPMODE_NONE) y[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p2 + base) + bo);
         }
+    }
+    // XF & 32 (round 5, the A/B VERDICT round 4 asked for): LDS-DMA staging of a plain [k][row] operand.  The float4 slots of such a tile are lane-linear
+    // in LDS (slot idx -> float offset 4 * idx: coords() and LD = ROWS), so one global_load_lds_dwordx4 per slot writes the wave's 64 pieces as the
+    // contiguous 1 KiB they occupy anyway: the LDS image, the fragment reads and the k order are those of the register-staged kernel (bit-identical results).
+    // The destination is wave-uniform (M0), the source per lane: SGPR tile base + the same opaque 32-bit byte offset as issue().
+    __device__ __forceinline__ void dma(int i, const float* __restrict__ p, int64_t ld, int r0, int k0, float* __restrict__ S) {
+        static_assert(!KC && !RAGGED, "LDS-DMA staging: [k][row] operands, whole slots");
+        const int64_t base = tile_base(ld, r0, k0);
+        asm volatile("" : "+v"(boff[i]));
+        const char* g = reinterpret_cast<const char*>(p + base) + boff[i];
+        float* dst = S + (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 64 + i * GEMM_THREADS) * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
     template <int K2>
     __device__ __forceinline__ void commit(int i, float* __restrict__ S, int act) {
@@ -586,8 +601,29 @@ k_gemm(const GemmK p) {
     // run in lockstep -- no wave of the CU had an MFMA to issue (counters: pipe idle 30 % of the kernel).
     constexpr bool SLICED = !EDGE && A2K >= 0 && B2K >= 0 && (XF & 4) == 0;
     constexpr int NSL = TA::NV + TB::NV;
+    // XF & 32: both operands go global -> LDS by LDS-DMA (Tile::dma), one k-tile ahead into the buffer the barrier that opened the iteration freed;
+    // hipcc counts the DMAs and drains them (vmcnt(0)) in front of the barrier that closes the iteration.  No staging registers, no ds_write.
+    constexpr bool GLDS = (XF & 32) != 0;
+    static_assert(!GLDS || (SLICED && !A_KC && !B_KC && A2K == RECNOW_OPMODE_NONE && B2K == RECNOW_OPMODE_NONE && !MIDF), "LDS-DMA staging: plain [k][row] operands");
     auto a_issue = [&](int i, int k0) { ta.template issue<A2K>(i, Ab, A2b, p.lda, m0, k0, p.a_ld2, p.a_hq); };
     auto b_issue = [&](int i, int k0) { tb.template issue<B2K>(i, Bb, B2b, p.ldb, n0, k0, p.b_ld2, p.b_hq); };
+    if constexpr (GLDS) {
+        if (ntile > 0) {
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) ta.dma(i, Ab, p.lda, m0, k_begin, As);
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) tb.dma(i, Bb, p.ldb, n0, k_begin, Bs);
+            if ((XF & 1) && threadIdx.x < BK) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    bxr[r] = r < p.sp_r ? p.bx[(int64_t)(k_begin + threadIdx.x) * p.bx_ks + r * p.bx_rs] : 0.f;
+                *reinterpret_cast<f32x4*>(Bxs + threadIdx.x * 4) = mk4(bxr[0], bxr[1], bxr[2], bxr[3]);
+                const int k1 = k_begin + min(1, ntile - 1) * BK;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bxr[r] = r < p.sp_r ? p.bx[(int64_t)(k1 + threadIdx.x) * p.bx_ks + r * p.bx_rs] : 0.f;
+            }
+        }
+    } else
     if constexpr (SLICED) {
         if (ntile > 0) {
 #pragma unroll
@@ -704,7 +740,17 @@ k_gemm(const GemmK p) {
             const int k2 = k_begin + min(t + 2, ntile - 1) * BK;
             float* const As_n = As + (cur ^ 1) * A_SZ;
             float* const Bs_n = Bs + (cur ^ 1) * B_SZ;
+            const int k1n = k_begin + min(t + 1, ntile - 1) * BK;      // GLDS: the NEXT k-tile (clamped: the surplus DMAs of the last iteration land in the buffer nobody reads)
             auto stage = [&](int g) {
+                if constexpr (GLDS) {
+#pragma unroll
+                    for (int sl = 0; sl < NSL; ++sl) {
+                        if (sl * RN_GLDS_SPREAD / NSL != g) continue;
+                        if (sl < TA::NV) ta.dma(sl, Ab, p.lda, m0, k1n, As_n);
+                        else tb.dma(sl - TA::NV, Bb, p.ldb, n0, k1n, Bs_n);
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) {
                     if (sl * NG / NSL != g) continue;

@@ -490,9 +490,17 @@ __device__ __forceinline__ bool gm_barrier(GroupMidCtl* ctl, unsigned target) {
     } while (0)
 
 // TILE keys per workgroup (256 threads x TILE / 256): 2048 is what the host launches; 512 / 1024 are A/B instantiations (measured slower, see the host).
-template <int TILE>
+// RAW = 0: canonical key words + solo flags from recnow_group_keys.  RAW = 1 / 2 (round 5, one float32 / int32 id tensor, n_words = 1: the GROUP phase
+// of recnow_dcn_mix_step above 8192 rows): `words` IS the id tensor -- every read of it forms the canonical key (-0.0 -> +0.0) on the way, and phase 0
+// writes the solo flags (NaN, +-inf) itself, one grid barrier before anybody gathers them: the fill of `solo` and the key kernel in front of this launch go.
+template <int RAW>
+__device__ __forceinline__ uint32_t gm_canon(uint32_t k) {
+    if (RAW == 1) return __uint_as_float(k) == 0.0f ? 0u : k;
+    return k;
+}
+template <int TILE, int RAW = 0>
 __global__ void __launch_bounds__(256)
-k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
+k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
             GroupMidCtl* __restrict__ ctl, int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, uint32_t* __restrict__ key0,
             uint32_t* __restrict__ key1, unsigned* __restrict__ blockhist, int* __restrict__ headcnt, int32_t* __restrict__ order,
             int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
@@ -521,7 +529,20 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
 #pragma unroll
             for (int r = 0; r < TILE / 256; ++r) {
                 const int64_t i = base + r * 256 + tid;
-                kk[r] = words[(int64_t)w * B + (i < B ? i : B - 1)];
+                kk[r] = gm_canon<RAW>(words[(int64_t)w * B + (i < B ? i : B - 1)]);
+            }
+            if (RAW == 1) {                                   // the solo flags of this workgroup's keys (read by others only behind a grid barrier)
+#pragma unroll
+                for (int r = 0; r < TILE / 256; ++r) {
+                    const int64_t i = base + r * 256 + tid;
+                    if (i < B) solo[i] = (fabsf(__uint_as_float(kk[r])) < INFINITY) ? 0 : 1;
+                }
+            } else if (RAW == 2) {
+#pragma unroll
+                for (int r = 0; r < TILE / 256; ++r) {
+                    const int64_t i = base + r * 256 + tid;
+                    if (i < B) solo[i] = 0;
+                }
             }
             unsigned oo = 0u, zz = 0u;
 #pragma unroll
@@ -636,7 +657,7 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
                 my_idx[r] = src[e < B ? e : B - 1];
             }
 #pragma unroll
-            for (int r = 0; r < TILE / 256; ++r) my_key[r] = wk[my_idx[r]];
+            for (int r = 0; r < TILE / 256; ++r) my_key[r] = gm_canon<RAW>(wk[my_idx[r]]);
             if (s_useint) {                                   // block-uniform: the keys' small-integer images are what is sorted (and carried)
 #pragma unroll
                 for (int r = 0; r < TILE / 256; ++r) my_key[r] = (uint32_t)__uint_as_float(my_key[r]);
@@ -741,7 +762,7 @@ k_group_mid(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < KPT + 1; ++q) v[q] = words[(int64_t)w * B + f[q]];
+                for (int q = 0; q < KPT + 1; ++q) v[q] = gm_canon<RAW>(words[(int64_t)w * B + f[q]]);
             }
 #pragma unroll
             for (int q = 0; q < KPT; ++q) {
@@ -868,6 +889,66 @@ extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) 
     return s;
 }
 
+// The cooperative route (one launch, all workgroups co-resident: <= one per CU) over the workspace of recnow_group_segments; RECNOW_EUNSUPPORTED when the
+// batch does not fit it (the caller then takes the multi-launch chain).  raw = 0: canonical key words + solo flags; raw = 1 / 2: `words` is a float32 / int32
+// id tensor (n_words = 1), the kernel forms keys and solo flags itself (`solo` is written, not read, by the caller's side).
+static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t B, int n_words, int n_words_first, int32_t* order, int32_t* seg_id,
+                         int32_t* seg_first, int32_t* super_id, int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st) {
+    static const bool coop = []() { const char* e = getenv("RECNOW_GROUP_COOP"); return !e || e[0] != '0'; }();      // A/B switch
+    if (!coop) return RECNOW_EUNSUPPORTED;
+    const int nblk = rn_cdiv(B, RN_TILE);
+    RnCarver c(ws, ws_bytes);
+    c.take<SortPlan>(1);
+    c.take<unsigned>((size_t)n_words * 4 * 256);
+    int32_t* idx0 = c.take<int32_t>(B + 1);
+    int32_t* idx1 = c.take<int32_t>(B + 1);
+    uint32_t* key0 = c.take<uint32_t>(B + 1);
+    uint32_t* key1 = c.take<uint32_t>(B + 1);
+    unsigned* blockhist = c.take<unsigned>((size_t)256 * (nblk > GM_MAXG ? nblk : GM_MAXG));
+    c.take<int32_t>(B + 1);
+    c.take<int32_t>(B + 1);
+    c.take<int32_t>(B + 1);
+    c.take<int32_t>(B + 1);
+    // Keys per workgroup: 2048.  Smaller tiles (more workgroups, less
+    // per-key work between two grid barriers; RECNOW_GROUP_TILE=512 / 1024 selects them where the grid stays inside the bound) measured SLOWER:
+    // B = 65 536 on 128 workgroups of 512 keys 114 us against 89 us on 32 of 2048, B = 262 144 on 256 of 1024 keys 207 against 147 us per fused
+    // loss -- every digit pass makes each thread scan one histogram row over ALL workgroups, and a barrier costs more the more arrive.
+    const int maxg = gm_max_coresident() < GM_MAXG ? gm_max_coresident() : GM_MAXG;
+    static const int tile_env = []() { const char* e = getenv("RECNOW_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B switch: 512 / 1024 / 2048
+    int tile = RN_TILE;
+    if (raw == 0 && (tile_env == 512 || tile_env == 1024) && rn_cdiv(B, tile_env) <= maxg) tile = tile_env;
+    if (rn_cdiv(B, tile) > maxg) return RECNOW_EUNSUPPORTED;
+    const size_t scan_bytes = rn_scan_ws_bytes(B);
+    char* tail = c.base + c.off + scan_bytes;
+    GroupMidCtl* ctl = (GroupMidCtl*)tail;
+    int* headcnt = (int*)(tail + rn_align(sizeof(GroupMidCtl)));
+    RN_HIP(hipMemsetAsync(ctl, 0, sizeof(GroupMidCtl), st));
+    static const bool dbg_timeout = []() { const char* e = getenv("RECNOW_DEBUG_GROUP_TIMEOUT"); return e && e[0] == '1'; }();
+    if (dbg_timeout) RN_HIP(hipMemsetAsync(&ctl->err, 1, sizeof(int), st));      // tests: every barrier reports the time-out at once
+    const int g = rn_cdiv(B, tile);
+#define GM_LAUNCH(T, R)                                                                                                                          \
+    hipLaunchKernelGGL((k_group_mid<T, R>), g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist, headcnt, \
+                       order, seg_id, seg_first, super_id, n_seg)
+    if (raw == 1) GM_LAUNCH(2048, 1);
+    else if (raw == 2) GM_LAUNCH(2048, 2);
+    else if (tile == 512) GM_LAUNCH(512, 0);
+    else if (tile == 1024) GM_LAUNCH(1024, 0);
+    else GM_LAUNCH(2048, 0);
+#undef GM_LAUNCH
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
+// The step's GROUP phase above GS_MAXB rows (one float32 / int32 id tensor): the cooperative launch straight from the ids -- no fill of `solo`, no key kernel.
+// RECNOW_EUNSUPPORTED: other id types, or a batch beyond the co-resident grid (the caller takes recnow_group_keys + recnow_group_segments).
+int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st) {
+    static const bool on = []() { const char* e = getenv("RECNOW_GROUP_RAW"); return !e || e[0] != '0'; }();      // A/B switch
+    if (!on || B <= GS_MAXB || (dtype != RECNOW_KEY_F32 && dtype != RECNOW_KEY_I32) || !solo || !ws) return RECNOW_EUNSUPPORTED;
+    if (ws_bytes < recnow_group_segments_workspace_bytes(B, 1)) return RECNOW_EWORKSPACE;
+    return rn_group_coop(dtype == RECNOW_KEY_F32 ? 1 : 2, (const uint32_t*)group, solo, B, 1, 1, order, seg_id, seg_first, super_id, n_seg, ws, ws_bytes, st);
+}
+
 extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo, int64_t B, int n_words, int n_words_first,
                                      int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id, int32_t* n_seg,
                                      void* ws, size_t ws_bytes, void* stream) {
@@ -897,9 +978,10 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
         return RECNOW_OK;
     }
     const int nblk = rn_cdiv(B, RN_TILE);
+    int rc0 = rn_group_coop(0, words, const_cast<uint8_t*>(solo), B, n_words, n_words_first, order, seg_id, seg_first, super_id, n_seg, ws, ws_bytes, st);
+    if (rc0 != RECNOW_EUNSUPPORTED) return rc0;
     RnCarver c(ws, ws_bytes);
     SortPlan* plan = c.take<SortPlan>(1);
-    static const bool coop = []() { const char* e = getenv("RECNOW_GROUP_COOP"); return !e || e[0] != '0'; }();      // A/B switch
     unsigned* ghist = c.take<unsigned>((size_t)n_words * 4 * 256);
     int32_t* idx0 = c.take<int32_t>(B + 1);
     int32_t* idx1 = c.take<int32_t>(B + 1);
@@ -910,35 +992,6 @@ extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo,
     int32_t* shead = c.take<int32_t>(B + 1);
     int32_t* seg_incl = c.take<int32_t>(B + 1);
     int32_t* super_incl = c.take<int32_t>(B + 1);
-    // one cooperative launch: all its workgroups are co-resident (<= one per CU).  Keys per workgroup: 2048.  Smaller tiles (more workgroups, less
-    // per-key work between two grid barriers; RECNOW_GROUP_TILE=512 / 1024 selects them where the grid stays inside the bound) measured SLOWER:
-    // B = 65 536 on 128 workgroups of 512 keys 114 us against 89 us on 32 of 2048, B = 262 144 on 256 of 1024 keys 207 against 147 us per fused
-    // loss -- every digit pass makes each thread scan one histogram row over ALL workgroups, and a barrier costs more the more arrive.
-    const int maxg = coop ? (gm_max_coresident() < GM_MAXG ? gm_max_coresident() : GM_MAXG) : 0;
-    static const int tile_env = []() { const char* e = getenv("RECNOW_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B switch: 512 / 1024 / 2048
-    int tile = RN_TILE;
-    if ((tile_env == 512 || tile_env == 1024) && rn_cdiv(B, tile_env) <= maxg) tile = tile_env;
-    if (coop && rn_cdiv(B, tile) <= maxg) {
-        const size_t scan_bytes = rn_scan_ws_bytes(B);
-        char* tail = c.base + c.off + scan_bytes;
-        GroupMidCtl* ctl = (GroupMidCtl*)tail;
-        int* headcnt = (int*)(tail + rn_align(sizeof(GroupMidCtl)));
-        RN_HIP(hipMemsetAsync(ctl, 0, sizeof(GroupMidCtl), st));
-        static const bool dbg_timeout = []() { const char* e = getenv("RECNOW_DEBUG_GROUP_TIMEOUT"); return e && e[0] == '1'; }();
-        if (dbg_timeout) RN_HIP(hipMemsetAsync(&ctl->err, 1, sizeof(int), st));      // tests: every barrier reports the time-out at once
-        const int g = rn_cdiv(B, tile);
-        if (tile == 512)
-            hipLaunchKernelGGL(k_group_mid<512>, g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
-                               headcnt, order, seg_id, seg_first, super_id, n_seg);
-        else if (tile == 1024)
-            hipLaunchKernelGGL(k_group_mid<1024>, g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
-                               headcnt, order, seg_id, seg_first, super_id, n_seg);
-        else
-            hipLaunchKernelGGL(k_group_mid<2048>, g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist,
-                               headcnt, order, seg_id, seg_first, super_id, n_seg);
-        RN_LAUNCH_CHECK();
-        return RECNOW_OK;
-    }
     void* scan_ws = (void*)(c.base + c.off);
     size_t scan_ws_bytes = ws_bytes - c.off;
 
