@@ -169,6 +169,9 @@ static inline size_t mix_tile_pack_bytes(const MixDims& m) { return mix_tile_sha
 static inline size_t mix_tile_pack_off(const MixDims& m) { return mix_pack_off(m) + mix_pack_bytes(m); }
 // `maybe`: everything but the precision mode -- what a backward pass uses to decide whether the forward that filled `saved` MAY have run the
 // row-block kernels (and left the product-route weight packs out), whatever the precision switch says by now
+// Set by the GROUP phase of recnow_dcn_mix_step when its front kernel has written the tile packs of THIS call's weights into `saved`; taken (and cleared)
+// by the row-block forward of the same call, which then skips its own pack launch.  Per host thread: a step is enqueued by one thread.
+static thread_local const void* tl_step_tile_packed = nullptr;      // the `saved` buffer whose tile packs are current, or NULL
 static bool mix_tile_on(const MixDims& m, bool maybe = false) {
     const char* e = getenv("RECNOW_TILE");            // read per call (tests switch the route inside one process)
     const int mode = e ? atoi(e) : -1;
@@ -556,6 +559,8 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             t.xn[l] = l < L - 1 ? (xless ? nullptr : xmid + (size_t)l * (xbuf(m) / sizeof(float))) : (head ? nullptr : y);
         }
         if (head) { t.head_w = head->w; t.head_b = head->b; t.scores = head->scores; }
+        t.packed = (tl_step_tile_packed != nullptr && tl_step_tile_packed == (const void*)saved) ? 1 : 0;
+        tl_step_tile_packed = nullptr;
         return rn_mix_tile_fwd(t, st);
     }
     for (int l = 0; l < L; ++l) {
@@ -694,10 +699,11 @@ extern "C" int recnow_dcn_mix_score_supported(int64_t B, int D, int S, int N, in
 int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order, const int32_t* seg_id,
                         const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean, float* loss, float* dscores_unnorm,
                         int64_t* n_pair, void* ws, size_t ws_bytes, void* stream, const double** part_out, int* nparts_out);      // pairwise.hip
+// scan_sort.hip; pack != NULL: the launch also writes the weight packs of the row-block kernels on further workgroups (k_front_small / k_front_mid)
 int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                       int32_t* n_seg, hipStream_t st);       // scan_sort.hip
+                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack);
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st);       // scan_sort.hip
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack);
 
 extern "C" int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
@@ -1452,14 +1458,28 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
     const MixDims m = mix_dims(BP, D, S, N, L);
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    if ((phases & RECNOW_STEP_FORWARD) && !d->scores) return RECNOW_EINVAL;
     if (phases & RECNOW_STEP_GROUP) {
         if (!d->groups) return RECNOW_EINVAL;
         RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_STEP_GROUP, 0.0, 16.0 * B, st) : nullptr;
         // small shards (<= 8192 rows, float32 / int32 ids): keys, solo flags, sort and segments in ONE launch straight from the id tensor
-        rc = rn_group_small_raw(d->groups, d->group_dtype, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, st);
+        // ... and, when the forward pass of this call runs the row-block kernels, the packs of their weights on the launch's other workgroups
+        // (RECNOW_STEP_FRONT=0: the pack stays a launch of its own in front of the forward kernel)
+        static const bool front = []() { const char* e = getenv("RECNOW_STEP_FRONT"); return !e || e[0] != '0'; }();
+        RnTileFwd pk;
+        const RnTileFwd* pack = nullptr;
+        if (front && (phases & RECNOW_STEP_FORWARD) && mix_tile_on(m) && d->U_host && d->V_host && d->W_host && d->bias_host && d->gate_host) {
+            memset(&pk, 0, sizeof(pk));
+            pk.D = D; pk.L = L; pk.packs = (float*)((char*)w.saved + mix_tile_pack_off(m));
+            for (int l = 0; l < L; ++l) { pk.U[l] = d->U_host[l]; pk.Kg[l] = d->gate_host[l]; pk.V[l] = d->V_host[l]; pk.W[l] = d->W_host[l]; pk.bias[l] = d->bias_host[l]; }
+            pack = &pk;
+        }
+        tl_step_tile_packed = nullptr;
+        rc = rn_group_small_raw(d->groups, d->group_dtype, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, st, pack);
         // larger batches: the cooperative launch forms keys and solo flags from the id tensor as well
         if (rc == RECNOW_EUNSUPPORTED)
-            rc = rn_group_mid_raw(d->groups, d->group_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st);
+            rc = rn_group_mid_raw(d->groups, d->group_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, pack);
+        if (rc == RECNOW_OK && pack) tl_step_tile_packed = w.saved;
         if (rc == RECNOW_EUNSUPPORTED) {
             RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
             if ((rc = recnow_group_keys(d->groups, d->group_dtype, B, w.words, w.solo, stream))) return rc;
@@ -1471,10 +1491,10 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
     }
     if (phases & RECNOW_STEP_FORWARD) {
         if (!d->scores) return RECNOW_EINVAL;
-        if ((rc = recnow_dcn_mix_score_fwd(d->x, d->U_host, d->V_host, d->W_host, d->bias_host, d->gate_host, d->head_w, d->head_b, BP, D, S, N, L,
-                                           d->act_inner, d->act_outer, d->scores, w.saved, w.saved_bytes, w.mix, w.mix_bytes, stream,
-                                           d->dx ? 1 : 0)))
-            return rc;
+        rc = recnow_dcn_mix_score_fwd(d->x, d->U_host, d->V_host, d->W_host, d->bias_host, d->gate_host, d->head_w, d->head_b, BP, D, S, N, L,
+                                      d->act_inner, d->act_outer, d->scores, w.saved, w.saved_bytes, w.mix, w.mix_bytes, stream, d->dx ? 1 : 0);
+        tl_step_tile_packed = nullptr;     // (taken by the row-block forward; cleared here whatever route or error the call took)
+        if (rc) return rc;
     }
     if (phases & RECNOW_STEP_LOSS) {
         if (!d->scores || !d->labels || !d->loss || !d->n_pair) return RECNOW_EINVAL;

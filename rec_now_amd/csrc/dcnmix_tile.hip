@@ -30,7 +30,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define TL_ROWS 32
-#define TL_NS 128
 #define TL_LDT 144
 #define TL_LDP 132          // row stride of a partial tile (float4 reads of phase B stay aligned)
 #define TL_LDA 129          // H1 tile: odd stride, the per-lane ds_read_b32 of the A fragments (lane = row) is conflict-free
@@ -40,49 +39,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 bool rn_mix_tile_supported(int64_t B, int D, int S, int N, int L, int LDT) {
     return N == 2 && S == 64 && LDT == TL_LDT && (D == 256 || D == 512 || D == 1024) && B > 0 && B % TL_ROWS == 0 && L >= 1 && L <= RN_TILE_MAX_L;
 }
-#define TL_PACK_FLOATS(D) (4 * (D) * TL_NS + 2 * 64 * 64)          // per layer: P1, P2 (forward), P3, P4, V^T (backward)
 size_t rn_mix_tile_pack_bytes(int D, int S, int N, int L, int LDT) {
     if (!rn_mix_tile_supported(TL_ROWS, D, S, N, L, LDT)) return 0;
     return rn_align((size_t)L * TL_PACK_FLOATS(D) * sizeof(float));
 }
 
-// P1_l[kg][col][i] = U_l[n = col / 64][d = 4 kg + i][s = col % 64]         (D / 4 x 128 float4)      forward GEMM1, B fragments
-// P2_l[g][h][d][i] = W_l[t = 8 g + 4 h + i][d],  W_l as (N S, D)            (16 x 2 x D float4)       forward output product, A fragments
-// P3_l[kg][t][i]   = W_l[t][d = 4 kg + i]                                   (D / 4 x 128 float4)      backward dT2g product, B fragments
-// P4_l[g][h][d][i] = U_l[n][d][s],  n S + s = 8 g + 4 h + i                 (16 x 2 x D float4)       backward g_l product, A fragments
-// VT_l[n][t][s]    = V_l[n][s][t]                                                                      backward dA product, B fragments
+// (layouts of the packs: tl_pack_range, dcnmix_tile.hpp)
 __global__ void __launch_bounds__(256) k_tile_pack(const RnTileFwd p) {
-    // one thread per 16-byte output piece: the four i of a piece are four rows (P1, P2) or four consecutive elements (P3, P4) of the source
-    const int D = p.D, L = p.L;
-    const int64_t per4 = (int64_t)D * TL_NS / 4, lay4 = TL_PACK_FLOATS(D) / 4, total4 = (int64_t)L * lay4;
-    rn_f4* __restrict__ out = reinterpret_cast<rn_f4*>(p.packs);
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
-        const int l = (int)(e / lay4);
-        const int64_t j = e - (int64_t)l * lay4;
-        const int which = (int)(j / per4);
-        const int64_t k = j - (int64_t)which * per4;
-        rn_f4 v;
-        if (which == 0) {               // P1[kg][col]: U[n][4 kg + i][s]
-            const int col = (int)(k & 127), kg = (int)(k >> 7);
-            const float* src = p.U[l] + ((int64_t)(col >> 6) * D + 4 * kg) * 64 + (col & 63);
-            v = rn_f4{src[0], src[64], src[128], src[192]};
-        } else if (which == 2) {        // P3[kg][t]: W[t][4 kg .. 4 kg + 3]
-            const int t = (int)(k & 127), kg = (int)(k >> 7);
-            v = *reinterpret_cast<const rn_f4*>(p.W[l] + (int64_t)t * D + 4 * kg);
-        } else if (which == 1) {        // P2[g][h][d]: W[4 (2 g + h) + i][d]
-            const int d = (int)(k % D), t0 = 4 * (int)(k / D);
-            const float* src = p.W[l] + (int64_t)t0 * D + d;
-            v = rn_f4{src[0], src[D], src[2 * D], src[3 * D]};
-        } else if (which == 3) {        // P4[g][h][d]: U[n][d][s .. s + 3],  n S + s = 4 (2 g + h)
-            const int d = (int)(k % D), t0 = 4 * (int)(k / D);
-            v = *reinterpret_cast<const rn_f4*>(p.U[l] + ((int64_t)(t0 >> 6) * D + d) * 64 + (t0 & 63));
-        } else {                        // VT[n][t][s .. s + 3] = V[n][s + i][t]
-            const int s4 = (int)(k & 15) * 4, t = (int)((k >> 4) & 63), n = (int)(k >> 10);
-            const float* src = p.V[l] + (n * 64 + s4) * 64 + t;
-            v = rn_f4{src[0], src[64], src[128], src[192]};
-        }
-        out[e] = v;
-    }
+    tl_pack_range(p, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
 // diagnostic build (tools/build_variant.py tiletrace -DRN_TILE_TRACE, tools/tile_trace.py): wall-clock stamps (100 MHz) of workgroup 0, wave 0
@@ -416,7 +380,7 @@ int rn_mix_tile_pack(const float* const* U, const float* const* Kg, const float*
 int rn_mix_tile_fwd(const RnTileFwd& p, hipStream_t st) {
     if (!rn_mix_tile_supported(p.B, p.D, 64, 2, p.L, TL_LDT) || !p.packs || !p.x) return RECNOW_EUNSUPPORTED;
     if (p.head_w && !p.scores) return RECNOW_EINVAL;
-    {
+    if (!p.packed) {
         int rcp;
         if ((rcp = tile_pack_launch(p, st))) return rcp;
     }

@@ -66,38 +66,67 @@ __device__ __forceinline__ unsigned gs_varying_bits(uint32_t* key0, int B, unsig
     return a ^ b;
 }
 
-// Stable LSD radix sort (4-bit digits, constant digits skipped) of B <= GS_MAXB keys held in LDS, by one 1024-thread workgroup.
-// ka/ia hold keys / original positions on entry and the sorted order on return (the pointers are swapped in place); kb/ib are
-// the ping-pong buffers, cnt [16][GS_T] u16, wsum >= 34 words.  Thread t owns positions [8t, 8t + 8) of the current order.
+// Stable LSD radix sort of B <= GS_MAXB keys held in LDS, by one 1024-thread workgroup (round 5: 8-bit digits ranked by wave-level multi-split; the
+// 4-bit passes with per-thread counters took 5.2 us each -- phase stamps of tools/gs_trace.py -- i.e. 10.4 us for ids 0..127, 15.2 us for ids 0..1023).
+// ka/ia hold keys / original positions on entry and the sorted order on return (the pointers are swapped in place); kb/ib are the ping-pong buffers,
+// cnt >= 256 * 18 u16 (the callers give [16][GS_T]), wsum >= 34 words.
+// Per pass (digits whose bits are constant over the batch are skipped, and only the VARYING bits of a digit are matched): wave w owns positions
+// [512 w, 512 w + 512) in 8 rounds of 64 consecutive keys; in a round the lanes with equal digits find each other by one ballot per varying bit, the
+// lowest of them advances the wave's counter of that digit (cnt[digit][wave], LDS operations of a wave complete in order) and every lane keeps
+// (count before the round) + (equal digits in lower lanes) = its rank among the wave's keys of that digit.  An exclusive scan over cnt in
+// (digit, wave) order turns the counters into output offsets; destination = offset + rank: stable.
 __device__ __forceinline__ void gs_radix_sort_lds(uint32_t*& ka, uint32_t*& kb, uint16_t*& ia, uint16_t*& ib, uint16_t* cnt,
                                                   unsigned* wsum, int B, unsigned varying) {
-    const int tid = threadIdx.x;
-    const int lo = tid * GS_KPT, hi = min(B, lo + GS_KPT);
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 4 * pass;
-        if (((varying >> shift) & 15u) == 0) continue;    // block-uniform: this digit is the same for every key
-        unsigned long long c64 = 0;
-        for (int i = lo; i < hi; ++i) c64 += 1ull << (4 * ((ka[i] >> shift) & 15u));
-#pragma unroll
-        for (int d = 0; d < 16; ++d) cnt[d * GS_T + tid] = (uint16_t)((c64 >> (4 * d)) & 15u);
+    constexpr int WS = 18;                                // u16 per digit row (16 used): 9 words -- the rows of 32 consecutive digits start in 32 different banks
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* cnt32 = reinterpret_cast<uint32_t*>(cnt);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 8 * pass;
+        const unsigned vb = (varying >> shift) & 255u;
+        if (vb == 0) continue;                            // block-uniform: this digit is the same for every key
+        for (int i = tid; i < 256 * WS / 2; i += GS_T) cnt32[i] = 0u;
         __syncthreads();
-        // exclusive scan of the flattened [digit][thread] counters: thread t owns entries [16t, 16t + 16)
-        unsigned loc[16], sum = 0;
+        uint32_t kreg[GS_KPT];
+        unsigned ireg[GS_KPT], lr[GS_KPT];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { loc[j] = cnt[tid * 16 + j]; sum += loc[j]; }
+        for (int r = 0; r < GS_KPT; ++r) {
+            const int pos = w * (64 * GS_KPT) + r * 64 + lane;
+            const bool ok = pos < B;
+            const int pc = ok ? pos : 0;
+            const uint32_t k = ka[pc];
+            kreg[r] = k;
+            ireg[r] = ia[pc];
+            const unsigned d = (k >> shift) & 255u;
+            unsigned long long peers = __ballot(ok);
+            for (unsigned bits = vb; bits; bits &= bits - 1u) {      // block-uniform trip count
+                const bool bit = (d >> (__ffs(bits) - 1)) & 1u;
+                const unsigned long long m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const unsigned below = (unsigned)__popcll(peers & lt);
+            const unsigned prior = cnt[d * WS + w];
+            if (ok && below == 0u) cnt[d * WS + w] = (uint16_t)(prior + (unsigned)__popcll(peers));
+            lr[r] = prior + below;
+        }
+        __syncthreads();
+        // exclusive scan of the counters in (digit, wave) order: thread t owns digit t / 4, waves 4 (t % 4) .. + 3
+        const int sd = (tid >> 2) * WS + (tid & 3) * 4;
+        unsigned loc[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { loc[j] = cnt[sd + j]; sum += loc[j]; }
         unsigned run = gs_block_exclusive_scan(sum, wsum, nullptr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cnt[sd + j] = (uint16_t)run; run += loc[j]; }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { cnt[tid * 16 + j] = (uint16_t)run; run += loc[j]; }
-        __syncthreads();
-        unsigned long long r64 = 0;                       // running per-digit rank inside this thread's chunk
-        for (int i = lo; i < hi; ++i) {
-            const uint32_t k = ka[i];
-            const unsigned d = (k >> shift) & 15u;
-            const unsigned dst = cnt[d * GS_T + tid] + (unsigned)((r64 >> (4 * d)) & 15u);
-            r64 += 1ull << (4 * d);
-            kb[dst] = k;
-            ib[dst] = ia[i];
+        for (int r = 0; r < GS_KPT; ++r) {
+            const int pos = w * (64 * GS_KPT) + r * 64 + lane;
+            if (pos < B) {
+                const unsigned dst = cnt[((kreg[r] >> shift) & 255u) * WS + w] + lr[r];
+                kb[dst] = kreg[r];
+                ib[dst] = (uint16_t)ireg[r];
+            }
         }
         __syncthreads();
         uint32_t* tk = ka; ka = kb; kb = tk;

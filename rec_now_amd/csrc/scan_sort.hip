@@ -9,6 +9,8 @@
 #include "common.hpp"
 #include "scan.hpp"
 #include "group_small.hpp"
+#include "dcnmix_tile.hpp"
+#define RN_FRONT_PACK_WGS 255      // pack workgroups of the step's front kernels (k_front_small / k_front_mid)
 
 // ------------------------------------------------------------------------------------------------
 // keys
@@ -359,10 +361,26 @@ __global__ void k_seg_empty(int32_t* seg_first, int32_t* n_seg) {
 // shard sizes): `words` IS the caller's float32 / int32 id tensor -- the canonical key (-0.0 -> +0.0) and the solo flag (NaN, +-inf) of
 // k_keys_f32 are formed here and the flags live in an LDS bit set, so that the phase is ONE launch instead of a fill, a key kernel and this one
 // (kernel trace at 8192 rows: 5.2 + 5.0 + 31.8 us in front of the forward launch).
+// diagnostic build (tools/build_variant.py gstrace -DRN_GS_TRACE, tools/gs_trace.py): wall-clock stamps (100 MHz) of thread 0
+#ifdef RN_GS_TRACE
+__device__ long long g_gs_trace[16];
+#define GS_STAMP(i) do { if (threadIdx.x == 0) g_gs_trace[(i)] = wall_clock64(); } while (0)
+__device__ long long g_gm_trace[64];
+__device__ int g_gm_n;
+#define GM_STAMP() do { if (g == GM_TRACE_WG && threadIdx.x == 0) { g_gm_trace[gm_n < 63 ? gm_n : 63] = wall_clock64(); ++gm_n; g_gm_n = gm_n; } } while (0)
+#ifndef GM_TRACE_WG
+#define GM_TRACE_WG 0
+#endif
+extern "C" int recnow_debug_gm_trace(long long* out) { int n = 0; hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_gm_n), sizeof(int)); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gm_trace), sizeof(long long) * 64); return n; }
+extern "C" int recnow_debug_gs_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gs_trace), sizeof(long long) * 16); }
+#else
+#define GS_STAMP(i) do { } while (0)
+#define GM_STAMP() do { } while (0)
+#endif
 template <int RAW>
-__global__ void __launch_bounds__(GS_T)
-k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int B, int32_t* __restrict__ order,
-              int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
+__device__ __forceinline__ void
+group_small_body(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int B, int32_t* __restrict__ order,
+                 int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gs_lds[];
     uint32_t* key0 = reinterpret_cast<uint32_t*>(gs_lds);
     uint32_t* key1 = key0 + GS_MAXB;
@@ -372,6 +390,7 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
     unsigned* wsum = reinterpret_cast<unsigned*>(cnt + 16 * GS_T);   // [16] + 2
     __shared__ unsigned s_solo[GS_MAXB / 32];             // RAW: bit i = row i pairs with nobody
     const int tid = threadIdx.x;
+    GS_STAMP(0);
     if (RAW == 1) {
         for (int i = tid; i < GS_MAXB / 32; i += GS_T) s_solo[i] = 0u;
         __syncthreads();
@@ -394,11 +413,14 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
         ior |= im;
         iand &= im;
     }
+    GS_STAMP(1);
     const unsigned varying = gs_varying_bits(key0, B, vor, vand, ior, iand, bad, wsum);      // (keys rewritten to their small-integer images when all have one)
+    GS_STAMP(2);
     uint32_t* ka = key0; uint32_t* kb = key1;
     uint16_t* ia = idx0; uint16_t* ib = idx1;
     const int lo = tid * GS_KPT, hi = min(B, lo + GS_KPT);
     gs_radix_sort_lds(ka, kb, ia, ib, cnt, wsum, B, varying);
+    GS_STAMP(3);
     // segment heads over the sorted order; solo rows (NaN / inf ids) are segments of their own
     unsigned heads = 0, nh = 0;
     for (int i = lo; i < hi; ++i) {
@@ -409,6 +431,7 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
     }
     unsigned total = 0;
     unsigned g = gs_block_exclusive_scan(nh, wsum, &total);
+    GS_STAMP(4);
     for (int i = lo; i < hi; ++i) {
         const bool h = (heads >> (i - lo)) & 1u;
         if (h) { seg_first[g] = i; ++g; }
@@ -421,6 +444,28 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
         n_seg[0] = (int32_t)total;
         n_seg[1] = (int32_t)total;
     }
+    GS_STAMP(5);
+#ifdef RN_GS_TRACE
+    if (threadIdx.x == 0) g_gs_trace[6] = (long long)varying;
+#endif
+}
+template <int RAW>
+__global__ void __launch_bounds__(GS_T)
+k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ solo, int B, int32_t* __restrict__ order,
+              int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
+    group_small_body<RAW>(words, solo, B, order, seg_id, seg_first, super_id, n_seg);
+}
+// Front kernel of recnow_dcn_mix_step at shard sizes (round 5): workgroup 0 groups the batch, the others write the weight packs of the row-block
+// kernels (dcnmix_tile.hpp) -- two launches that depend on nothing but the step's inputs, one of which keeps ONE compute unit busy for ~20 us.
+template <int RAW>
+__global__ void __launch_bounds__(GS_T)
+k_front_small(const uint32_t* __restrict__ words, int B, int32_t* __restrict__ order, int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first,
+              int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg, const RnTileFwd pack) {
+    if (blockIdx.x == 0) {
+        group_small_body<RAW>(words, nullptr, B, order, seg_id, seg_first, super_id, n_seg);
+        return;
+    }
+    tl_pack_range(pack, (int64_t)(blockIdx.x - 1) * GS_T + threadIdx.x, (int64_t)(gridDim.x - 1) * GS_T);
 }
 
 
@@ -438,6 +483,9 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
 // `gm_max_coresident()` says all workgroups fit on the device at once.
 // ------------------------------------------------------------------------------------------------
 #define GM_MAXG 256
+// batches from this size on run 4096 keys per workgroup: half the workgroups at every grid barrier and in every histogram row (phase stamps, tools/gs_trace.py, one box:
+// 262 144 rows 79.0 -> 74.6 us, 65 536 rows 44.5 -> 52.8 us -- the phases of a workgroup take longer than what the cheaper barriers save there)
+#define GM_TILE4096_FROM 262144ll
 struct GroupMidCtl {          // zeroed by the host before the launch
     unsigned bar;
     int err;
@@ -482,10 +530,10 @@ __device__ __forceinline__ bool gm_barrier(GroupMidCtl* ctl, unsigned target) {
 #define GM_BAIL()                                                                                                    \
     do {                                                                                                             \
         for (int q_ = 0; q_ < TILE / 256; ++q_) {                                                                 \
-            const int64_t k_ = (int64_t)blockIdx.x * TILE + q_ * 256 + threadIdx.x;                              \
+            const int64_t k_ = (int64_t)g * TILE + q_ * 256 + threadIdx.x;                                      \
             if (k_ < B) { order[k_] = (int32_t)k_; seg_id[k_] = (int32_t)k_; seg_first[k_] = (int32_t)k_; super_id[k_] = (int32_t)k_; } \
         }                                                                                                            \
-        if (blockIdx.x == 0 && threadIdx.x == 0) { seg_first[B] = (int32_t)B; n_seg[0] = -1; n_seg[1] = -1; }       \
+        if (g == 0 && threadIdx.x == 0) { seg_first[B] = (int32_t)B; n_seg[0] = -1; n_seg[1] = -1; }              \
         return;                                                                                                      \
     } while (0)
 
@@ -498,12 +546,13 @@ __device__ __forceinline__ uint32_t gm_canon(uint32_t k) {
     if (RAW == 1) return __uint_as_float(k) == 0.0f ? 0u : k;
     return k;
 }
-template <int TILE, int RAW = 0>
-__global__ void __launch_bounds__(256)
-k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
-            GroupMidCtl* __restrict__ ctl, int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, uint32_t* __restrict__ key0,
-            uint32_t* __restrict__ key1, unsigned* __restrict__ blockhist, int* __restrict__ headcnt, int32_t* __restrict__ order,
-            int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
+template <int TILE, int RAW>
+__device__ __forceinline__ void
+group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
+               GroupMidCtl* __restrict__ ctl, int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, uint32_t* __restrict__ key0,
+               uint32_t* __restrict__ key1, unsigned* __restrict__ blockhist, int* __restrict__ headcnt, int32_t* __restrict__ order,
+               int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg,
+               const int G, const int g) {
     __shared__ unsigned h[256];
     __shared__ unsigned wcnt[4][256];
     __shared__ unsigned boff[256];
@@ -513,9 +562,15 @@ k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
     __shared__ int s_useint;
     __shared__ int s_triv[RN_MAX_PASS], s_src[RN_MAX_PASS], s_carried[RN_MAX_PASS], s_wconst[RN_MAX_WORDS], s_final[2];
     __shared__ int s_cnt[4][2];
-    const int G = gridDim.x, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int s_red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;      // G workgroups take part, this one is g
+    const int Gp = (G + 3) & ~3;
     const int64_t base = (int64_t)g * TILE;
     unsigned nbar = 0;
+#ifdef RN_GS_TRACE
+    int gm_n = 0;
+#endif
+    GM_STAMP();
     // ---- phase 0: identity order, bits that vary over the batch ----------------------------------------------------------
     {
         unsigned o[RN_MAX_WORDS], z[RN_MAX_WORDS];
@@ -596,7 +651,9 @@ k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
             atomicOr(c == 2 ? &ctl->notint : &ctl->imix[c], v);
         }
     }
+    GM_STAMP();
     if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
+    GM_STAMP();
     const int np = n_words * 4;
     if (tid == 0) {          // the pass plan, as k_sort_plan builds it (every workgroup derives the same one)
         int cur = 0, word_in_buf = -1;
@@ -671,15 +728,30 @@ k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
             if (ok) atomicAdd(&h[(my_key[r] >> shift) & 255u], 1u);
         }
         __syncthreads();
-        blockhist[(int64_t)tid * G + g] = h[tid];             // digit-major
+        blockhist[(int64_t)tid * Gp + g] = h[tid];            // digit-major, rows of Gp = G rounded up to 4 entries (16-byte row reads below)
+        GM_STAMP();
         if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
+        GM_STAMP();
         {   // first output position of every digit for this workgroup: counts of the workgroups before it + the digits below
-            const unsigned* row = blockhist + (int64_t)tid * G;
+            // (round 5: the row is read as 16-byte pieces, sixteen in flight -- one entry per iteration was a chain of G dependent waits: 9.6 us of a
+            // pass at G = 128, phase stamps of tools/gs_trace.py; the pad entries of a row are never written and are masked here)
+            const uint4* row4 = reinterpret_cast<const uint4*>(blockhist + (int64_t)tid * Gp);
+            const int n4 = Gp >> 2;
             unsigned before = 0, total = 0;
-            for (int b = 0; b < G; ++b) {
-                const unsigned v = row[b];
-                before += b < g ? v : 0u;
-                total += v;
+            for (int c0 = 0; c0 < n4; c0 += 16) {
+                uint4 v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = row4[c0 + j < n4 ? c0 + j : n4 - 1];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int b = (c0 + j) * 4;
+                    const unsigned e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        total += (c0 + j < n4 && b + q < G) ? e[q] : 0u;
+                        before += (c0 + j < n4 && b + q < g) ? e[q] : 0u;
+                    }
+                }
             }
             unsigned inc = total;
 #pragma unroll
@@ -694,6 +766,7 @@ k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
             boff[tid] = woff + inc - total + before;
         }
         __syncthreads();
+        GM_STAMP();
         // stable ranks: wave w owns TILE / 4 consecutive keys, 8 rounds of 64 consecutive keys (as k_sort_scatter)
         const unsigned long long lt = (1ull << lane) - 1ull;
         unsigned my_dr[TILE / 256];
@@ -726,7 +799,9 @@ k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
                 kdst[off] = my_key[r];
             }
         }
+        GM_STAMP();
         if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
+        GM_STAMP();
     }
     // ---- segments: heads of this tile's 2048 sorted positions, 8 consecutive positions per thread ---------------------------------
     const int32_t* fin = s_final[0] ? idx1 : idx0;
@@ -805,13 +880,22 @@ k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
         tots += s_cnt[i][1];
     }
     if (tid == 0) { headcnt[2 * g] = toth; headcnt[2 * g + 1] = tots; }
+    GM_STAMP();
     if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
+    GM_STAMP();
     int preh = 0, pres = 0, allh = 0, alls = 0;              // heads in the workgroups before this one / in all of them
-    for (int b = 0; b < G; ++b) {
-        const int a = headcnt[2 * b], c = headcnt[2 * b + 1];
-        if (b < g) { preh += a; pres += c; }
-        allh += a;
-        alls += c;
+    {   // thread b reads workgroup b's pair (G <= 256 = the block), block reduction (round 5: every thread walked all G pairs: 9 us at G = 128)
+        const int bc = tid < G ? tid : G - 1;
+        const int a0 = headcnt[2 * bc], c0 = headcnt[2 * bc + 1];
+        int r4[4] = {tid < g ? a0 : 0, tid < g ? c0 : 0, tid < G ? a0 : 0, tid < G ? c0 : 0};
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r4[q] += __shfl_xor(r4[q], o, 64);
+        }
+        if (lane == 0) { s_red[wv][0] = r4[0]; s_red[wv][1] = r4[1]; s_red[wv][2] = r4[2]; s_red[wv][3] = r4[3]; }
+        __syncthreads();
+        for (int i = 0; i < 4; ++i) { preh += s_red[i][0]; pres += s_red[i][1]; allh += s_red[i][2]; alls += s_red[i][3]; }
     }
     int sid = preh + offh, sup = pres + offs;                 // ids of the LAST head before this thread's first position, + 1
     for (int q = 0; q < KPT; ++q) {
@@ -833,12 +917,37 @@ k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
         n_seg[0] = late ? -1 : allh;
         n_seg[1] = late ? -1 : alls;
     }
+    GM_STAMP();
+}
+template <int TILE, int RAW = 0>
+__global__ void __launch_bounds__(256)
+k_group_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
+            GroupMidCtl* __restrict__ ctl, int32_t* __restrict__ idx0, int32_t* __restrict__ idx1, uint32_t* __restrict__ key0,
+            uint32_t* __restrict__ key1, unsigned* __restrict__ blockhist, int* __restrict__ headcnt, int32_t* __restrict__ order,
+            int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first, int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg) {
+    group_mid_body<TILE, RAW>(words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id, seg_first, super_id,
+                              n_seg, (int)gridDim.x, (int)blockIdx.x);
+}
+// Front kernel of recnow_dcn_mix_step above GS_MAXB rows: the first G workgroups (dispatched first: co-resident as before) group the batch, the others
+// write the weight packs of the row-block kernels (see k_front_small).
+template <int RAW>
+__global__ void __launch_bounds__(256)
+k_front_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int64_t B, GroupMidCtl* __restrict__ ctl, int32_t* __restrict__ idx0,
+            int32_t* __restrict__ idx1, uint32_t* __restrict__ key0, uint32_t* __restrict__ key1, unsigned* __restrict__ blockhist,
+            int* __restrict__ headcnt, int32_t* __restrict__ order, int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first,
+            int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg, const int G, const RnTileFwd pack) {
+    if ((int)blockIdx.x < G) {
+        group_mid_body<RN_TILE, RAW>(words, solo, B, 1, 1, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id, seg_first, super_id, n_seg, G,
+                                     (int)blockIdx.x);
+        return;
+    }
+    tl_pack_range(pack, (int64_t)((int)blockIdx.x - G) * 256 + threadIdx.x, (int64_t)((int)gridDim.x - G) * 256);
 }
 
 // The grouping of a small batch (B <= 8192) straight from ONE float32 / int32 id tensor in one launch (library-internal: the GROUP phase of
 // recnow_dcn_mix_step).  Returns RECNOW_EUNSUPPORTED for other shapes: the caller then takes recnow_group_keys + recnow_group_segments.
 int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                       int32_t* n_seg, hipStream_t st) {
+                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack) {
     if (B < 1 || B > GS_MAXB || (dtype != RECNOW_KEY_F32 && dtype != RECNOW_KEY_I32)) return RECNOW_EUNSUPPORTED;
     static std::atomic<bool> raised[64];
     int dev = 0;
@@ -846,7 +955,18 @@ int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, 
     if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
         RN_HIP(hipFuncSetAttribute((const void*)k_group_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
         RN_HIP(hipFuncSetAttribute((const void*)k_group_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+        RN_HIP(hipFuncSetAttribute((const void*)k_front_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
+        RN_HIP(hipFuncSetAttribute((const void*)k_front_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds_bytes()));
         if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
+    }
+    if (pack) {      // + the weight packs: one pack workgroup per remaining compute unit (every workgroup of this kernel holds 112 KB of LDS)
+        const int grid = 1 + RN_FRONT_PACK_WGS;
+        if (dtype == RECNOW_KEY_F32)
+            hipLaunchKernelGGL(k_front_small<1>, grid, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (int)B, order, seg_id, seg_first, super_id, n_seg, *pack);
+        else
+            hipLaunchKernelGGL(k_front_small<2>, grid, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (int)B, order, seg_id, seg_first, super_id, n_seg, *pack);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
     }
     if (dtype == RECNOW_KEY_F32)
         hipLaunchKernelGGL(k_group_small<1>, 1, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (const uint8_t*)nullptr, (int)B, order, seg_id, seg_first, super_id, n_seg);
@@ -893,7 +1013,7 @@ extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) 
 // batch does not fit it (the caller then takes the multi-launch chain).  raw = 0: canonical key words + solo flags; raw = 1 / 2: `words` is a float32 / int32
 // id tensor (n_words = 1), the kernel forms keys and solo flags itself (`solo` is written, not read, by the caller's side).
 static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t B, int n_words, int n_words_first, int32_t* order, int32_t* seg_id,
-                         int32_t* seg_first, int32_t* super_id, int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st) {
+                         int32_t* seg_first, int32_t* super_id, int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack = nullptr) {
     static const bool coop = []() { const char* e = getenv("RECNOW_GROUP_COOP"); return !e || e[0] != '0'; }();      // A/B switch
     if (!coop) return RECNOW_EUNSUPPORTED;
     const int nblk = rn_cdiv(B, RN_TILE);
@@ -917,6 +1037,7 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
     static const int tile_env = []() { const char* e = getenv("RECNOW_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B switch: 512 / 1024 / 2048
     int tile = RN_TILE;
     if (raw == 0 && (tile_env == 512 || tile_env == 1024) && rn_cdiv(B, tile_env) <= maxg) tile = tile_env;
+    if (raw == 0 && (tile_env == 4096 || (tile_env == 0 && B >= GM_TILE4096_FROM))) tile = 4096;
     if (rn_cdiv(B, tile) > maxg) return RECNOW_EUNSUPPORTED;
     const size_t scan_bytes = rn_scan_ws_bytes(B);
     char* tail = c.base + c.off + scan_bytes;
@@ -929,10 +1050,18 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
 #define GM_LAUNCH(T, R)                                                                                                                          \
     hipLaunchKernelGGL((k_group_mid<T, R>), g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist, headcnt, \
                        order, seg_id, seg_first, super_id, n_seg)
-    if (raw == 1) GM_LAUNCH(2048, 1);
+    if (raw && pack) {      // + the weight packs on workgroups behind the grouping's
+        if (raw == 1)
+            hipLaunchKernelGGL(k_front_mid<1>, g + RN_FRONT_PACK_WGS, 256, 0, st, words, solo, B, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id,
+                               seg_first, super_id, n_seg, g, *pack);
+        else
+            hipLaunchKernelGGL(k_front_mid<2>, g + RN_FRONT_PACK_WGS, 256, 0, st, words, solo, B, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id,
+                               seg_first, super_id, n_seg, g, *pack);
+    } else if (raw == 1) GM_LAUNCH(2048, 1);
     else if (raw == 2) GM_LAUNCH(2048, 2);
     else if (tile == 512) GM_LAUNCH(512, 0);
     else if (tile == 1024) GM_LAUNCH(1024, 0);
+    else if (tile == 4096) GM_LAUNCH(4096, 0);
     else GM_LAUNCH(2048, 0);
 #undef GM_LAUNCH
     RN_LAUNCH_CHECK();
@@ -942,11 +1071,11 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
 // The step's GROUP phase above GS_MAXB rows (one float32 / int32 id tensor): the cooperative launch straight from the ids -- no fill of `solo`, no key kernel.
 // RECNOW_EUNSUPPORTED: other id types, or a batch beyond the co-resident grid (the caller takes recnow_group_keys + recnow_group_segments).
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st) {
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack) {
     static const bool on = []() { const char* e = getenv("RECNOW_GROUP_RAW"); return !e || e[0] != '0'; }();      // A/B switch
     if (!on || B <= GS_MAXB || (dtype != RECNOW_KEY_F32 && dtype != RECNOW_KEY_I32) || !solo || !ws) return RECNOW_EUNSUPPORTED;
     if (ws_bytes < recnow_group_segments_workspace_bytes(B, 1)) return RECNOW_EWORKSPACE;
-    return rn_group_coop(dtype == RECNOW_KEY_F32 ? 1 : 2, (const uint32_t*)group, solo, B, 1, 1, order, seg_id, seg_first, super_id, n_seg, ws, ws_bytes, st);
+    return rn_group_coop(dtype == RECNOW_KEY_F32 ? 1 : 2, (const uint32_t*)group, solo, B, 1, 1, order, seg_id, seg_first, super_id, n_seg, ws, ws_bytes, st, pack);
 }
 
 extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo, int64_t B, int n_words, int n_words_first,

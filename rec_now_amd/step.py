@@ -177,8 +177,9 @@ class DCNMixPairwiseStep(object):
             launch('forward', lambda: self._call(_FORWARD))
             self._grouped.wait(main)
         elif mode == 'inline':
-            launch('group', lambda: self._call(_GROUP))
-            launch('forward', lambda: self._call(_FORWARD))
+            # ONE call for both phases: at shard sizes the library then packs the row-block kernels' weights on spare workgroups of the grouping
+            # launch (k_front_small / k_front_mid, csrc/scan_sort.hip) instead of in a launch of its own in front of the forward kernel
+            launch('front', lambda: self._call(_GROUP | _FORWARD))
         else:
             launch('forward', lambda: self._call(_FORWARD))
             launch('group', lambda: self._call(_GROUP))
@@ -224,7 +225,7 @@ class DCNMixPairwiseStep(object):
         torch.cuda.synchronize(self.device)
         self._graphs = {}
         cap = torch.cuda.Stream(device=self.device)
-        keys = [('group', lambda: self._call(_GROUP)), ('forward', lambda: self._call(_FORWARD))]
+        keys = [('group', lambda: self._call(_GROUP)), ('forward', lambda: self._call(_FORWARD)), ('front', lambda: self._call(_GROUP | _FORWARD))]
         for i, (hi, lo) in enumerate(self.pieces):
             keys.append(('bwd%d' % i, lambda hi=hi, lo=lo, i=i: self._call((_LOSS if i == 0 else 0) | _BACKWARD, hi, lo)))
         stream2, self.desc.stream2 = self.desc.stream2, None      # captured pieces are single-stream (a forked capture replays slowly)
