@@ -317,6 +317,11 @@ int recnow_gemm(const recnow_gemm_desc* desc_host, void* ws, size_t ws_bytes, vo
  * Also read once from the environment (RECNOW_GEMM_PRECISION=bf16x3).  Shapes without a split kernel run mode 0 regardless. */
 int recnow_set_gemm_precision(int mode);
 int recnow_get_gemm_precision(void);
+/* Process-wide operand staging of the long-K products whose two operands are plain [k][row] tensors (the K = B weight-gradient products dU_l of
+ * DCNMixLayer): 0 (default) global -> registers -> LDS, 1 LDS-DMA (global_load_lds_dwordx4, no staging registers).  Same LDS image, same k order:
+ * the results are bit-identical; kept as an A/B switch (profiles/r05_glds_ab.md: neutral).  Also read once from RECNOW_GEMM_GLDS=1.  Returns RECNOW_OK. */
+int recnow_set_gemm_staging(int mode);
+int recnow_get_gemm_staging(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * MultiDenseLayer: rec_now/layers/multi_dense_layer.py:80-94.   y[n] = act(x[n] @ kernel[n] + bias[n])

@@ -50,6 +50,8 @@ SIGNATURES = {
     'recnow_gemm': (_I, [_P, _P, _Z, _P]),
     'recnow_set_gemm_precision': (_I, [_I]),
     'recnow_get_gemm_precision': (_I, []),
+    'recnow_set_gemm_staging': (_I, [_I]),
+    'recnow_get_gemm_staging': (_I, []),
     'recnow_multi_dense_workspace_bytes': (_Z, [_L, _I, _I, _I]),
     'recnow_multi_dense_fwd': (_I, [_P, _I, _P, _P, _L, _I, _I, _I, _I, _P, _P, _Z, _P]),
     'recnow_multi_dense_bwd': (_I, [_P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),

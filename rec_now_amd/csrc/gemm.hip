@@ -12,6 +12,7 @@
 // lanes 0-31 (k) and 32 consecutive floats for lanes 32-63 (k+1): conflict-free ds_read_b32 with no padding tricks.
 // An operand that is k-contiguous in memory ([m][k]) is loaded as float4 along k (coalesced 128-B rows) and transposed
 // on the LDS write; its row stride is ROWS+1 floats so those 4-B writes are conflict-free too.
+#include <atomic>
 #include "gemm_kernel.hpp"
 #include "prof.hpp"
 
@@ -153,6 +154,7 @@ static inline RnDispatchEnv dispatch_env() {
 }
 static inline GemmCfg pick_cfg(const recnow_gemm_desc* d) { return pick_cfg(d, dispatch_env()); }
 
+static std::atomic<int> g_gemm_staging{[]() { const char* e = getenv("RECNOW_GEMM_GLDS"); return (e && e[0] == '1') ? 1 : 0; }()};      // recnow_set_gemm_staging
 static int g_gemm_precision = []() {
     const char* e = getenv("RECNOW_GEMM_PRECISION");
     return (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? 1 : 0;
@@ -344,7 +346,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
         static const bool sp_narrow = []() { const char* e = getenv("RECNOW_SP_NARROW"); return !e || e[0] != '0'; }();      // A/B switch
         if (d->mid_V) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, 0, d->b_mode, 25, grid, st);      // XF 16 | 8 | 1: the fused sub-space forward
         else if (rc == RECNOW_EUNSUPPORTED && sp_narrow && xf == 1 && d->sp_r <= 2 && !bk16) {
-            static const bool glds = []() { const char* e = getenv("RECNOW_GEMM_GLDS"); return e && e[0] == '1'; }();      // A/B switch: LDS-DMA operand staging (XF | 32)
+            const bool glds = g_gemm_staging.load(std::memory_order_relaxed) == 1;      // A/B switch: LDS-DMA operand staging (XF | 32)
             if (glds && !a_kc && !b_kc && d->a_mode == 0 && d->b_mode == 0) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, 0, 0, 41, grid, st);
             if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, d->a_mode, d->b_mode, 9, grid, st);
         }
@@ -584,6 +586,12 @@ int rn_colsum_batched(const float* X, const float* X2, int mode, int act, int64_
 }
 
 extern "C" int recnow_set_gemm_precision(int mode) { return rn_gemm_set_precision(mode); }
+extern "C" int recnow_set_gemm_staging(int mode) {
+    if (mode != 0 && mode != 1) return RECNOW_EINVAL;
+    g_gemm_staging.store(mode, std::memory_order_relaxed);
+    return RECNOW_OK;
+}
+extern "C" int recnow_get_gemm_staging(void) { return g_gemm_staging.load(std::memory_order_relaxed); }
 extern "C" int recnow_get_gemm_precision(void) { return rn_gemm_precision(); }
 extern "C" size_t recnow_gemm_workspace_bytes(const recnow_gemm_desc* desc_host) {
     return desc_host ? rn_gemm_ws_bytes(desc_host) : 0;

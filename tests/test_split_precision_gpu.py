@@ -138,3 +138,22 @@ def test_split_mode_dcn_mix_model_vs_oracle(dev, split_mode, route):
     for k, p in cross.named_weights().items():
         close(p.grad, w64[k].grad, what=k)
     close(head.kernel.grad, hk64.grad, what='head kernel')
+
+
+@pytest.mark.parametrize('M,K', [(256, 512), (1024, 8192), (1024, 65536)])
+def test_lds_dma_staging_is_bit_identical_to_register_staging(dev, M, K):
+    """`recnow_set_gemm_staging(1)` (RECNOW_GEMM_GLDS=1) moves both operands of the plain [k][row] products -- dU_l = x_l^T dA with dgate as the side
+    product, here at small sizes, split over K, and at the step's own depth -- global -> LDS by LDS-DMA (`k_gemm<.., 41>`, csrc/gemm_kernel.hpp
+    Tile::dma) instead of through registers: same LDS image, same k order, so the same bits (profiles/r05_glds_ab.md is the timing A/B)."""
+    from rec_now_amd import _lib
+    lib = _lib.load()
+    assert lib.recnow_get_gemm_staging() == 0
+    C0, Cx0, R, Rx = _product(dev, M, 128, K, 1, 0, 0, 77 + K, scale=0.05)
+    _lib.call('recnow_set_gemm_staging', 1)
+    try:
+        assert lib.recnow_get_gemm_staging() == 1
+        C1, Cx1, _, _ = _product(dev, M, 128, K, 1, 0, 0, 77 + K, scale=0.05)
+    finally:
+        _lib.call('recnow_set_gemm_staging', 0)
+    assert np.array_equal(C0, C1) and np.array_equal(Cx0, Cx1)
+    assert np.abs(C1 - R).max() <= 1e-5 * np.abs(R).max() and np.abs(Cx1 - Rx).max() <= 1e-5 * np.abs(Rx).max()

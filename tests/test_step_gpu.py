@@ -104,6 +104,48 @@ def test_step_with_mask_and_wrong_order_pairs(dev):
             assert torch.equal(p.grad, g)
 
 
+@pytest.mark.parametrize('B,kind', [(4096, 'f32'), (9216, 'f32'), (9216, 'i32'), (16384, 'f32')])
+def test_step_grouping_from_raw_ids_equals_the_two_call_form(dev, B, kind):
+    """The step's GROUP phase forms canonical keys and solo flags INSIDE its grouping launch (k_front_small up to 8192 rows, k_front_mid<RAW> above:
+    csrc/scan_sort.hip), with the row-block weight packs on the launch's other workgroups; `pairwise_loss` goes through recnow_group_keys +
+    recnow_group_segments.  Ids with -0.0 / +0.0 (one group), NaN and +-inf (rows that pair with nobody: g_i - g_j is NaN in the reference,
+    rec_block/pairwise_loss_from_batch.py:33-35) and negative values must give the same loss, pair count and gradients bit for bit."""
+    from rec_now_amd.fused import score_params
+    from rec_now_amd.step import DCNMixPairwiseStep
+    D, S, N, L = 256, 64, 2, 2
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 21)
+    rng = np.random.default_rng(22)
+    if kind == 'f32':
+        g = groups.copy()
+        g[rng.integers(0, B, B // 16)] = -0.0
+        g[rng.integers(0, B, B // 16)] = 0.0
+        g[rng.integers(0, B, 40)] = np.nan
+        g[rng.integers(0, B, 40)] = np.inf
+        g[rng.integers(0, B, 40)] = -np.inf
+        g[rng.integers(0, B, B // 8)] *= -1.0
+        g[rng.integers(0, B, B // 8)] += 0.5
+        gd = torch.from_numpy(g).to(dev)
+    else:
+        g = groups.astype(np.int32) - 7
+        g[rng.integers(0, B, 50)] = np.iinfo(np.int32).min
+        g[rng.integers(0, B, 50)] = np.iinfo(np.int32).max
+        gd = torch.from_numpy(g).to(dev)
+    params = score_params(cross, head)
+    loss_a, n_a, scores_a, dx_a, grads_a = _autograd_route(cross, head, xd, yd, gd, params)
+    assert n_a > 0
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd)
+    for _ in range(2):                      # twice: the second step reuses every buffer (solo flags included)
+        for p in params:
+            p.grad = None
+        loss, n_pair = step.run()
+        torch.cuda.synchronize()
+        assert int(n_pair.item()) == n_a and torch.equal(loss, loss_a)
+        assert torch.equal(step.scores, scores_a) and torch.equal(step.dx, dx_a)
+        for p, gr in zip(params, grads_a):
+            if p is not head.bias:
+                assert torch.equal(p.grad, gr)
+
+
 @pytest.fixture(scope='module')
 def one_rank_rccl(dev):
     import torch.distributed as dist

@@ -32,7 +32,10 @@ def trace_stats(trace_csv, out_csv=None):
     ev.sort()
     # the first step starts with its grouping launch (side stream) next to k_pack_all (main stream): everything that started more than
     # 200 us before the first k_keys_* dispatch belongs to the lazy build
-    t_keys = next((e[0] for e in ev if e[2].startswith('k_keys_')), ev[0][0])
+    # (round 5: the step's grouping launch forms the keys itself -- k_front_small / k_front_mid / k_group_mid<.., RAW> -- so any of the grouping kernels marks the spot;
+    #  the lazy build on 256 rows runs no grouping)
+    marks = ('k_keys_', 'void k_front_', 'void k_group_mid', 'void k_group_small')
+    t_keys = next((e[0] for e in ev if e[2].startswith(marks)), ev[0][0])
     first = next((i for i, e in enumerate(ev) if e[0] >= t_keys - 200000), 0)
     agg = collections.OrderedDict()
     for s0, e0, n in ev[first:]:
