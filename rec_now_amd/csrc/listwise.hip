@@ -341,6 +341,9 @@ k_lw_norm(const float* __restrict__ dbase, const int32_t* __restrict__ n_valid, 
     if (out2 && blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = bad ? sc : loss[0]; out2[1] = (float)nv; }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) out[i] = dbase[i] * sc;
 }
+struct RnTileFwd;
+int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack);       // scan_sort.hip
 extern "C" int recnow_listwise_loss(const void* groups, int key_dtype, const float* labels, const float* logits, const float* weights, int64_t B,
                                     float pos_neg_th, float pad_logit, float* out2, float* dlogits, void* ws, size_t ws_bytes, void* stream) {
     if (B < 0 || !out2) return RECNOW_EINVAL;
@@ -354,11 +357,17 @@ extern "C" int recnow_listwise_loss(const void* groups, int key_dtype, const flo
     if (ws_bytes < recnow_listwise_loss_workspace_bytes(B, key_dtype)) return RECNOW_EWORKSPACE;
     const LwLossWs w = lw_loss_carve(ws, B, key_dtype);
     int rc;
+    // one float32 / int32 id tensor above the one-workgroup size: keys and solo flags are formed inside the cooperative grouping launch (scan_sort.hip)
+    rc = rn_group_mid_raw(groups, key_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, nullptr);
+    if (rc != RECNOW_EUNSUPPORTED) {
+        if (rc) return rc;
+    } else {
     RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
     if ((rc = recnow_group_keys(groups, key_dtype, B, w.words, w.solo, stream))) return rc;
     if ((rc = recnow_group_segments(w.words, w.solo, B, w.n_words, w.n_words, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes,
                                     stream)))
         return rc;
+    }
     if ((rc = recnow_listwise_segments(labels, logits, w.order, w.seg_first, w.n_seg, B, pos_neg_th, pad_logit, w.seg_valid, w.seg_lse, w.seg_ysum,
                                        w.seg_psum, w.seg_pdot, w.valid_rank, w.n_valid, w.lw, w.lw_bytes, stream)))
         return rc;

@@ -1037,7 +1037,7 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
     static const int tile_env = []() { const char* e = getenv("RECNOW_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B switch: 512 / 1024 / 2048
     int tile = RN_TILE;
     if (raw == 0 && (tile_env == 512 || tile_env == 1024) && rn_cdiv(B, tile_env) <= maxg) tile = tile_env;
-    if (raw == 0 && (tile_env == 4096 || (tile_env == 0 && B >= GM_TILE4096_FROM))) tile = 4096;
+    if (tile_env == 4096 || (tile_env == 0 && B >= GM_TILE4096_FROM)) tile = 4096;
     if (rn_cdiv(B, tile) > maxg) return RECNOW_EUNSUPPORTED;
     const size_t scan_bytes = rn_scan_ws_bytes(B);
     char* tail = c.base + c.off + scan_bytes;
@@ -1050,14 +1050,16 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
 #define GM_LAUNCH(T, R)                                                                                                                          \
     hipLaunchKernelGGL((k_group_mid<T, R>), g, 256, 0, st, words, solo, B, n_words, n_words_first, ctl, idx0, idx1, key0, key1, blockhist, headcnt, \
                        order, seg_id, seg_first, super_id, n_seg)
-    if (raw && pack) {      // + the weight packs on workgroups behind the grouping's
+    if (raw && pack && tile == RN_TILE) {      // + the weight packs on workgroups behind the grouping's
         if (raw == 1)
             hipLaunchKernelGGL(k_front_mid<1>, g + RN_FRONT_PACK_WGS, 256, 0, st, words, solo, B, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id,
                                seg_first, super_id, n_seg, g, *pack);
         else
             hipLaunchKernelGGL(k_front_mid<2>, g + RN_FRONT_PACK_WGS, 256, 0, st, words, solo, B, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id,
                                seg_first, super_id, n_seg, g, *pack);
-    } else if (raw == 1) GM_LAUNCH(2048, 1);
+    } else if (raw == 1 && tile == 4096) GM_LAUNCH(4096, 1);
+    else if (raw == 2 && tile == 4096) GM_LAUNCH(4096, 2);
+    else if (raw == 1) GM_LAUNCH(2048, 1);
     else if (raw == 2) GM_LAUNCH(2048, 2);
     else if (tile == 512) GM_LAUNCH(512, 0);
     else if (tile == 1024) GM_LAUNCH(1024, 0);
@@ -1068,7 +1070,8 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
     return RECNOW_OK;
 }
 
-// The step's GROUP phase above GS_MAXB rows (one float32 / int32 id tensor): the cooperative launch straight from the ids -- no fill of `solo`, no key kernel.
+// Grouping above GS_MAXB rows straight from ONE float32 / int32 id tensor (the step's GROUP phase, the one-call pairwise and listwise losses): the cooperative
+// launch forms keys and solo flags itself -- no fill of `solo`, no key kernel.
 // RECNOW_EUNSUPPORTED: other id types, or a batch beyond the co-resident grid (the caller takes recnow_group_keys + recnow_group_segments).
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
                      int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack) {
