@@ -492,7 +492,8 @@ struct GroupMidCtl {          // zeroed by the host before the launch
     unsigned mix[2 * RN_MAX_WORDS];
     unsigned imix[2];         // one key word: OR of the keys' small-integer images and OR of their complements (see gs_int_key)
     unsigned notint;          // != 0: some key has no small-integer image (the keys are sorted as they are)
-    unsigned pad[11];
+    unsigned anysolo;         // != 0: some row carries a solo flag (NaN / +-inf id): the heads phase gathers the flags only then
+    unsigned pad[10];
 };
 
 // Returns false (to every thread of the workgroup) once the error word is set: the caller then leaves through GM_BAIL -- what the other
@@ -559,7 +560,7 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
     __shared__ unsigned wtot[4];
     __shared__ unsigned part[4][2 * RN_MAX_WORDS];
     __shared__ unsigned ipart[4][3];
-    __shared__ int s_useint;
+    __shared__ int s_useint, s_anysolo;
     __shared__ int s_triv[RN_MAX_PASS], s_src[RN_MAX_PASS], s_carried[RN_MAX_PASS], s_wconst[RN_MAX_WORDS], s_final[2];
     __shared__ int s_cnt[4][2];
     __shared__ int s_red[4][4];
@@ -575,6 +576,7 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
     {
         unsigned o[RN_MAX_WORDS], z[RN_MAX_WORDS];
         unsigned io = 0u, iz = 0u, bad = 0u;                 // small-integer images of the keys (one key word only)
+        unsigned anys = 0u;                                   // this thread saw a solo row
 #pragma unroll
         for (int w = 0; w < RN_MAX_WORDS; ++w) o[w] = z[w] = 0u;
         // loads from clamped indices, masked afterwards: no load sits under a lane condition (each would end in an `s_waitcnt vmcnt(0)`
@@ -590,7 +592,9 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
 #pragma unroll
                 for (int r = 0; r < TILE / 256; ++r) {
                     const int64_t i = base + r * 256 + tid;
-                    if (i < B) solo[i] = (fabsf(__uint_as_float(kk[r])) < INFINITY) ? 0 : 1;
+                    const bool fl = !(fabsf(__uint_as_float(kk[r])) < INFINITY);
+                    if (i < B) solo[i] = fl ? 1 : 0;
+                    anys |= (i < B && fl) ? 1u : 0u;
                 }
             } else if (RAW == 2) {
 #pragma unroll
@@ -615,6 +619,14 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
             for (int q = 0; q < RN_MAX_WORDS; ++q)
                 if (q == w) { o[q] = oo; z[q] = zz; }
         }
+        if (RAW == 0) {
+#pragma unroll
+            for (int r = 0; r < TILE / 256; ++r) {
+                const int64_t i = base + r * 256 + tid;
+                anys |= (solo[i < B ? i : B - 1] != 0) ? 1u : 0u;
+            }
+        }
+        if (__ballot(anys != 0u) != 0ull && lane == 0) atomicOr(&ctl->anysolo, 1u);
 #pragma unroll
         for (int r = 0; r < TILE / 256; ++r) {
             const int64_t i = base + r * 256 + tid;
@@ -659,6 +671,7 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
         int cur = 0, word_in_buf = -1;
         const bool useint = n_words == 1 && __hip_atomic_load(&ctl->notint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
         s_useint = useint ? 1 : 0;
+        s_anysolo = __hip_atomic_load(&ctl->anysolo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1 : 0;
         for (int p = 0; p < np; ++p) {
             const int w = n_words - 1 - p / 4, d = p % 4;
             const unsigned both = useint ? (__hip_atomic_load(&ctl->imix[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
@@ -803,83 +816,104 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
         if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
         GM_STAMP();
     }
-    // ---- segments: heads of this tile's 2048 sorted positions, 8 consecutive positions per thread ---------------------------------
+    // ---- segments: heads of this tile's sorted positions ------------------------------------------------------------------------------------
+    // Round 5: thread (round r, tid) owns position base + r * 256 + tid, so every array access of this phase is coalesced (with TILE / 256 CONSECUTIVE
+    // positions per thread a wave instruction read 64 pieces 32-64 bytes apart: 9.4 us of 74 at 262 144 rows, phase stamps of tools/gs_trace.py).  A
+    // position's predecessor is the lane below; across waves and rounds the edge values go through LDS, the block's own predecessor is a uniform load.
+    // The solo flags are gathered only when the batch has any (ctl->anysolo, set in phase 0).
     const int32_t* fin = s_final[0] ? idx1 : idx0;
     const uint32_t* kfin = s_final[0] ? key1 : key0;
     const int final_word = s_final[1];
-    constexpr int KPT = TILE / 256;                           // consecutive sorted positions per thread
-    const int64_t k0 = base + (int64_t)tid * KPT;
-    unsigned hb = 0, sb8 = 0;
-    int nh = 0, ns = 0;
-    {
-        // the nine sorted rows k0 - 1 .. k0 + 7 of this thread, then their solo flags and key words: every load unconditional (clamped
-        // positions), a word's nine loads in flight together
-        int32_t f[KPT + 1];
-        bool so9[KPT + 1];
-        unsigned dany = 0u, dfirst = 0u;                     // bit q: rows k0 + q - 1 and k0 + q differ in some / in a groups[0] word
+    constexpr int R = TILE / 256;
+    __shared__ uint32_t s_edge[R][4];                         // the value of lane 63 of (round, wave)
+    __shared__ int s_hc[R][4], s_sc[R][4];                    // heads of (round, wave); then their exclusive prefix in (round, wave) order
+    const unsigned long long ltm = (1ull << lane) - 1ull;
+    const int64_t kprev = base > 0 ? base - 1 : 0;            // the block's predecessor (position 0 has none: it is a head by definition)
+    int32_t f[R];
 #pragma unroll
-        for (int q = 0; q < KPT + 1; ++q) {
-            int64_t kq = k0 - 1 + q;
-            kq = kq < 0 ? 0 : (kq < B ? kq : B - 1);
-            f[q] = fin[kq];
+    for (int r = 0; r < R; ++r) {
+        const int64_t k = base + r * 256 + tid;
+        f[r] = fin[k < B ? k : B - 1];
+    }
+    const int32_t fprev = fin[kprev];
+    // pv[r] = the value of position k - 1 for this thread's position of round r (vb: the value in front of the block)
+    auto prev_of = [&](const uint32_t (&v)[R], uint32_t vb, uint32_t (&pv)[R]) {
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) s_edge[r][wv] = v[r];
         }
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < KPT + 1; ++q) so9[q] = solo[f[q]] != 0;
-        for (int w = 0; w < n_words; ++w) {                  // block-uniform
-            if (s_wconst[w]) continue;
-            uint32_t v[KPT + 1];
-            if (w == final_word) {
-#pragma unroll
-                for (int q = 0; q < KPT + 1; ++q) {
-                    int64_t kq = k0 - 1 + q;
-                    kq = kq < 0 ? 0 : (kq < B ? kq : B - 1);
-                    v[q] = kfin[kq];
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < KPT + 1; ++q) v[q] = gm_canon<RAW>(words[(int64_t)w * B + f[q]]);
-            }
-#pragma unroll
-            for (int q = 0; q < KPT; ++q) {
-                const unsigned df = v[q + 1] != v[q] ? 1u : 0u;
-                dany |= df << q;
-                if (w < n_words_first) dfirst |= df << q;
-            }
+        for (int r = 0; r < R; ++r) {
+            uint32_t pr = __shfl_up(v[r], 1, 64);
+            if (lane == 0) pr = wv > 0 ? s_edge[r][wv - 1] : (r > 0 ? s_edge[r > 0 ? r - 1 : 0][3] : vb);
+            pv[r] = pr;
         }
+        __syncthreads();
+    };
+    unsigned dany = 0u, dfirst = 0u, sob = 0u;                // bit r: position k and k - 1 differ in some / in a groups[0] word; one of them is solo
+    if (s_anysolo) {                                          // block-uniform (and the same in every workgroup)
+        uint32_t sv[R], sp[R];
 #pragma unroll
-        for (int q = 0; q < KPT; ++q) {
-            const int64_t k = k0 + q;
-            if (k < B) {
-                int hd = 1, sh = 1;
-                if (k > 0) {
-                    const bool so = so9[q + 1] | so9[q];
-                    hd = (so || ((dany >> q) & 1u)) ? 1 : 0;
-                    sh = (so || ((dfirst >> q) & 1u)) ? 1 : 0;
-                }
-                hb |= (unsigned)hd << q;
-                sb8 |= (unsigned)sh << q;
-                nh += hd;
-                ns += sh;
-                order[k] = f[q + 1];
+        for (int r = 0; r < R; ++r) sv[r] = solo[f[r]];
+        const uint32_t vb = solo[fprev];
+        prev_of(sv, vb, sp);
+#pragma unroll
+        for (int r = 0; r < R; ++r) sob |= ((sv[r] | sp[r]) != 0u ? 1u : 0u) << r;
+    }
+    for (int w = 0; w < n_words; ++w) {                       // block-uniform
+        if (s_wconst[w]) continue;
+        uint32_t v[R], pv[R], vb;
+        if (w == final_word) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t k = base + r * 256 + tid;
+                v[r] = kfin[k < B ? k : B - 1];
             }
+            vb = kfin[kprev];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = gm_canon<RAW>(words[(int64_t)w * B + f[r]]);
+            vb = gm_canon<RAW>(words[(int64_t)w * B + fprev]);
+        }
+        prev_of(v, vb, pv);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned df = v[r] != pv[r] ? 1u : 0u;
+            dany |= df << r;
+            if (w < n_words_first) dfirst |= df << r;
         }
     }
-    // exclusive prefix of (nh, ns) inside the workgroup
-    int inh = nh, ins = ns;
+    unsigned hb = 0, sbm = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t1 = __shfl_up(inh, o, 64), t2 = __shfl_up(ins, o, 64);
-        if (lane >= o) { inh += t1; ins += t2; }
+    for (int r = 0; r < R; ++r) {
+        const int64_t k = base + r * 256 + tid;
+        const bool valid = k < B;
+        const bool so = (sob >> r) & 1u;
+        const bool hd = valid && (k == 0 || so || ((dany >> r) & 1u));
+        const bool sh = valid && (k == 0 || so || ((dfirst >> r) & 1u));
+        hb |= (hd ? 1u : 0u) << r;
+        sbm |= (sh ? 1u : 0u) << r;
+        const unsigned long long mh = __ballot(hd), ms = __ballot(sh);
+        if (lane == 0) { s_hc[r][wv] = (int)__popcll(mh); s_sc[r][wv] = (int)__popcll(ms); }
+        if (valid) order[k] = f[r];
     }
-    if (lane == 63) { s_cnt[wv][0] = inh; s_cnt[wv][1] = ins; }
     __syncthreads();
-    int offh = inh - nh, offs = ins - ns, toth = 0, tots = 0;
-    for (int i = 0; i < 4; ++i) {
-        if (i < wv) { offh += s_cnt[i][0]; offs += s_cnt[i][1]; }
-        toth += s_cnt[i][0];
-        tots += s_cnt[i][1];
+    if (wv == 0) {                                            // exclusive prefix of the 4 R <= 64 counts in (round, wave) order
+        int* hc = &s_hc[0][0];
+        int* sc = &s_sc[0][0];
+        const int a = lane < 4 * R ? hc[lane] : 0, c = lane < 4 * R ? sc[lane] : 0;
+        int ia = a, ic = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t1 = __shfl_up(ia, o, 64), t2 = __shfl_up(ic, o, 64);
+            if (lane >= o) { ia += t1; ic += t2; }
+        }
+        if (lane < 4 * R) { hc[lane] = ia - a; sc[lane] = ic - c; }
+        if (lane == 63) { s_cnt[0][0] = ia; s_cnt[0][1] = ic; }
     }
-    if (tid == 0) { headcnt[2 * g] = toth; headcnt[2 * g + 1] = tots; }
+    __syncthreads();
+    if (tid == 0) { headcnt[2 * g] = s_cnt[0][0]; headcnt[2 * g + 1] = s_cnt[0][1]; }
     GM_STAMP();
     if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
     GM_STAMP();
@@ -897,14 +931,18 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
         __syncthreads();
         for (int i = 0; i < 4; ++i) { preh += s_red[i][0]; pres += s_red[i][1]; allh += s_red[i][2]; alls += s_red[i][3]; }
     }
-    int sid = preh + offh, sup = pres + offs;                 // ids of the LAST head before this thread's first position, + 1
-    for (int q = 0; q < KPT; ++q) {
-        const int64_t k = k0 + q;
-        if (k >= B) break;
-        if ((hb >> q) & 1u) { seg_first[sid] = (int32_t)k; ++sid; }
-        if ((sb8 >> q) & 1u) ++sup;
-        seg_id[k] = sid - 1;
-        super_id[k] = sup - 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t k = base + r * 256 + tid;
+        const bool hd = (hb >> r) & 1u, sh = (sbm >> r) & 1u;
+        const unsigned long long mh = __ballot(hd), ms = __ballot(sh);
+        const int eh = preh + s_hc[r][wv] + (int)__popcll(mh & ltm);      // heads in front of position k
+        const int es = pres + s_sc[r][wv] + (int)__popcll(ms & ltm);
+        if (k < B) {
+            if (hd) seg_first[eh] = (int32_t)k;
+            seg_id[k] = hd ? eh : eh - 1;
+            super_id[k] = sh ? es : es - 1;
+        }
     }
     if (g == 0 && tid == 0) {
         // a workgroup can time out at the LAST barrier and set ctl->err just as the last arrival completes the count; its peers
