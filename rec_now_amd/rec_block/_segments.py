@@ -65,13 +65,17 @@ def build_segments(groups):
     n_words = sum(nws)
     if n_words > 8:
         raise ValueError('at most 8 key words (e.g. 8 float32/int32 or 4 int64 group tensors) are supported')
-    words = torch.empty((n_words, max(B, 1)), dtype=torch.int32, device=dev)
     solo = torch.zeros(max(B, 1), dtype=torch.uint8, device=dev)
     st = _lib.stream()
-    off = 0
-    for (t, dt), nw in zip(keyed, nws):
-        _lib.call('recnow_group_keys', _lib.ptr(t), dt, B, _lib.ptr(words[off:]), _lib.ptr(solo), st)
-        off += nw
+    if len(keyed) == 1 and keyed[0][1] == _KEY_I32 and B > 0:
+        # ONE int32 id tensor (the pooled lookup's 6.5 M sort keys): its bits ARE the key words -- recnow_group_keys would copy them (18 us there)
+        words = keyed[0][0].reshape(1, -1)
+    else:
+        words = torch.empty((n_words, max(B, 1)), dtype=torch.int32, device=dev)
+        off = 0
+        for (t, dt), nw in zip(keyed, nws):
+            _lib.call('recnow_group_keys', _lib.ptr(t), dt, B, _lib.ptr(words[off:]), _lib.ptr(solo), st)
+            off += nw
     seg = Segments()
     seg.B, seg.device = B, dev
     seg.order = torch.empty(max(B, 1), dtype=torch.int32, device=dev)
