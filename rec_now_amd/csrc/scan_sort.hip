@@ -547,6 +547,19 @@ __device__ __forceinline__ uint32_t gm_canon(uint32_t k) {
     if (RAW == 1) return __uint_as_float(k) == 0.0f ? 0u : k;
     return k;
 }
+// The scattered (index, key) pairs of a digit pass are read by OTHER workgroups -- on other XCDs, i.e. through other L2s -- right behind the next grid barrier.
+// Tried (round 5, -DRN_GM_WT_SCATTER): written through (sc1), so that the barrier's release fence finds nothing dirty (MI355X_MICROARCH.md, publish-large).  For
+// RANDOM 4-byte stores that loses: every store becomes a partial write to memory -- scatter phase 5.7 -> 11.9 us, the barrier behind it 7.2 -> 10.8 us, the
+// launch 62 -> 72-74 us at 262 144 rows (phase stamps, one box, twice).  Plain stores (merged in L2, written back by the fence) are the default.
+template <typename T>
+__device__ __forceinline__ void gm_store_wt(T* p, T v) {
+    static_assert(sizeof(T) == 4, "one dword");
+#ifdef RN_GM_WT_SCATTER
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");      // (covered by gm_barrier's own `s_waitcnt vmcnt(0)`)
+#else
+    *p = v;
+#endif
+}
 template <int TILE, int RAW>
 __device__ __forceinline__ void
 group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int64_t B, int n_words, int n_words_first,
@@ -819,8 +832,8 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
                 const unsigned d = my_dr[r] & 255u, rank = my_dr[r] >> 8;
                 unsigned off = boff[d] + rank;
                 for (int pw = 0; pw < wv; ++pw) off += wcnt[pw][d];
-                dst[off] = my_idx[r];
-                kdst[off] = my_key[r];
+                gm_store_wt(dst + off, my_idx[r]);
+                gm_store_wt(kdst + off, my_key[r]);
             }
         }
         GM_STAMP();
