@@ -131,7 +131,7 @@ class GemmDesc(ctypes.Structure):
         ('E4', _P), ('E5', _P), ('E6', _P),
     ]
 
-ABI_VERSION = 4      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)
+ABI_VERSION = 5      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)
 
 class StepDesc(ctypes.Structure):
     """recnow_dcn_mix_step_desc of include/recnow.h."""
