@@ -494,10 +494,47 @@ struct GroupMidCtl {          // zeroed by the host before the launch
     unsigned notint;          // != 0: some key has no small-integer image (the keys are sorted as they are)
     unsigned anysolo;         // != 0: some row carries a solo flag (NaN / +-inf id): the heads phase gathers the flags only then
     unsigned pad[10];
+    unsigned grp[8 * 16];     // hierarchical barrier: arrivals of the workgroups with index % 8 == q (one 64-byte line each)
+    unsigned gen[8 * 16];     // ... and the epoch those workgroups poll
 };
 
 // Returns false (to every thread of the workgroup) once the error word is set: the caller then leaves through GM_BAIL -- what the other
 // workgroups have published so far may be stale, and offsets derived from it could scatter out of bounds.
+// Round 5 (-DRN_GM_HIER_BARRIER, A/B): the same hand-off with the arrivals spread over eight counters -- workgroup g arrives on counter g % 8 (round-robin
+// dispatch: its XCD's, which is a matter of speed only), the last arrival of a counter arrives on the top counter, the last of those publishes the epoch on
+// eight words, one per group, which the group's workgroups poll: 16 instead of 128 workgroups hammer one line.  e = number of this barrier (1-based), G
+// workgroups take part, this one is g.  Measured (phase stamps, one box, two alternating repetitions): 262 144 rows (64 workgroups) 63.2 -> 62.2 us, 65 536 rows (32)
+// 41.8 -> 45.3 us, 16 384 rows (8) 22.5 -> 24.8 us -- the second hop costs more than the contention it removes at these grid sizes; the flat counter stays.
+__device__ __forceinline__ bool gm_barrier_hier(GroupMidCtl* ctl, unsigned e, int G, int g) {
+    __shared__ int s_err2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int q = g & 7, ngrp = G < 8 ? G : 8, in_grp = (G - q + 7) >> 3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned a = __hip_atomic_fetch_add(&ctl->grp[q * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a + 1u == e * (unsigned)in_grp) {
+            const unsigned t = __hip_atomic_fetch_add(&ctl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1u == e * (unsigned)ngrp)
+                for (int i = 0; i < ngrp; ++i) __hip_atomic_store(&ctl->gen[i * 16], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&ctl->gen[q * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) {
+            if (__hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (wall_clock64() - t0 > 200000000LL) {          // 2 s of the 100 MHz clock
+                __hip_atomic_store(&ctl->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_err2 = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_err2 == 0;
+}
 __device__ __forceinline__ bool gm_barrier(GroupMidCtl* ctl, unsigned target) {
     __shared__ int s_err;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -528,6 +565,11 @@ __device__ __forceinline__ bool gm_barrier(GroupMidCtl* ctl, unsigned target) {
 // every consumer; NOT necessarily a consistent grouping when only some workgroups bail), and n_seg = -1, which `Segments.num_segments()` /
 // `recnow_group_segments_status` report and which makes the one-call losses return NaN (k_pair_norm_grad, k_step_dscore, k_lw_norm).  Workgroup 0
 // publishes the segment count last and re-reads the error word before it does (end of the kernel).
+#ifdef RN_GM_HIER_BARRIER
+#define GM_BAR() gm_barrier_hier(ctl, ++nbar, G, g)
+#else
+#define GM_BAR() gm_barrier(ctl, (++nbar) * G)
+#endif
 #define GM_BAIL()                                                                                                    \
     do {                                                                                                             \
         for (int q_ = 0; q_ < TILE / 256; ++q_) {                                                                 \
@@ -684,7 +726,7 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
         if (n_words == 1) blockhist[(int64_t)tid * Gp + g] = h[tid];      // (behind the barrier above: the histogram is complete)
     }
     GM_STAMP();
-    if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
+    if (!GM_BAR()) GM_BAIL();
     GM_STAMP();
     const int np = n_words * 4;
     if (tid == 0) {          // the pass plan, as k_sort_plan builds it (every workgroup derives the same one)
@@ -766,7 +808,7 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
             __syncthreads();
             blockhist[(int64_t)tid * Gp + g] = h[tid];        // digit-major, rows of Gp = G rounded up to 4 entries (16-byte row reads below)
             GM_STAMP();
-            if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
+            if (!GM_BAR()) GM_BAIL();
             GM_STAMP();
         }
         {   // first output position of every digit for this workgroup: counts of the workgroups before it + the digits below
@@ -837,7 +879,7 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
             }
         }
         GM_STAMP();
-        if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
+        if (!GM_BAR()) GM_BAIL();
         GM_STAMP();
     }
     // ---- segments: heads of this tile's sorted positions ------------------------------------------------------------------------------------
@@ -939,7 +981,7 @@ group_mid_body(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, i
     __syncthreads();
     if (tid == 0) { headcnt[2 * g] = s_cnt[0][0]; headcnt[2 * g + 1] = s_cnt[0][1]; }
     GM_STAMP();
-    if (!gm_barrier(ctl, (++nbar) * G)) GM_BAIL();
+    if (!GM_BAR()) GM_BAIL();
     GM_STAMP();
     int preh = 0, pres = 0, allh = 0, alls = 0;              // heads in the workgroups before this one / in all of them
     {   // thread b reads workgroup b's pair (G <= 256 = the block), block reduction (round 5: every thread walked all G pairs: 9 us at G = 128)
