@@ -398,6 +398,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # stdout carries ONE line, the JSON of rank 0: from here on file descriptor 1 points at stderr, so whatever a library prints through C stdio or
+    # Python's sys.stdout during the run (RCCL writes a five-line version banner to stdout when its first communicator comes up) lands there; the JSON
+    # line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit('--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -943,13 +949,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL prints a version banner through C stdio, which is flushed at exit, i.e. after a Python print: flush the C
-        # streams first so that the JSON line is the LAST line on stdout
+        # (C stdio is flushed first: anything still buffered belongs to stderr's side of the redirection above)
         try:
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
 
 
 if __name__ == '__main__':
