@@ -395,6 +395,7 @@ def main():
     # stream sat behind the whole backward pass (kernel trace, +0.09 ms per step).  The HIP runtime reads this when it
     # initialises, i.e. at the first device call below.
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes on this driver); also set by self_launch, here for a rank started by an outside launcher
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
