@@ -55,11 +55,12 @@ __device__ __forceinline__ bool pair_ok(const Member& a, const Member& b) {   //
 // per member from L1/L2).  Block-uniform decision; oversize ranges (one huge group) fall back to global loads.
 #define PW_STAGE 2048
 __device__ __forceinline__ bool stage_members(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id,
-                                              const int32_t* __restrict__ seg_first, int64_t B, Member* lds, int* base) {
+                                              const int32_t* __restrict__ seg_first, int64_t B, Member* lds, int* base, int rows_per_block = 0) {
     *base = 0;
-    const int64_t k0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t rpb = rows_per_block > 0 ? rows_per_block : (int64_t)blockDim.x;
+    const int64_t k0 = (int64_t)blockIdx.x * rpb;
     if (k0 >= B) return false;
-    const int64_t k1 = min(B, k0 + (int64_t)blockDim.x) - 1;
+    const int64_t k1 = min(B, k0 + rpb) - 1;
     const int lo = seg_first[seg_id[k0]], hi = seg_first[seg_id[k1] + 1];
     if (hi - lo > PW_STAGE) return false;
     for (int i = threadIdx.x; i < hi - lo; i += blockDim.x) lds[i] = mem[lo + i];
@@ -284,38 +285,59 @@ k_pair_bpr(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, c
 // terms come out of the SAME walk, so counting and loss are one launch each for the long and the short rows instead of two.  The
 // gradient is left unnormalised (d sum / d score); the 1 / (P + 1e-10) of the mean is applied where the incoming gradient is
 // multiplied in (k_pair_scale_grad), because P is complete only when this kernel is.
-template <int FLAGS>
-__global__ void __launch_bounds__(256)
-k_pair_one(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
-           const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la, const float* __restrict__ long_ga,
-           double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair, float* __restrict__ dscores) {
+// Round 5 (second session): LPR lanes share the walk of ONE row (members s + sub, s + sub + LPR, ...): a walk is a chain of ~40 dependent-issue
+// instructions per member (two transcendentals), and with one lane per row a 64-member group made the launch 64 such steps long whatever the grid --
+// 12.6 us at 8192 rows, where the grid is 32 workgroups.  The lanes' gradient terms meet by two fixed-order butterfly steps (the same bits on every
+// lane and run), their loss terms and counts go into the block sum as they are.  A block owns 256 / LPR consecutive sorted rows.
+template <int FLAGS, int LPR>
+__device__ __forceinline__ void pair_one_body(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
+                                              int64_t B, float factor, const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la,
+                                              const float* __restrict__ long_ga, double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair,
+                                              float* __restrict__ dscores) {
     __shared__ double red[16];
     __shared__ long long redc[16];
     __shared__ Member staged[PW_STAGE];
     int sbase;
-    const bool in_lds = stage_members(mem, seg_id, seg_first, B, staged, &sbase);
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_lds = stage_members(mem, seg_id, seg_first, B, staged, &sbase, 256 / LPR);
+    const int sub = (int)threadIdx.x % LPR;
+    const int64_t kr = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int64_t k = kr < B ? kr : B - 1;         // (surplus lanes of the last block walk the last row again and contribute nothing)
     double lsum = 0.0;
     long long c = 0;
-    if (k < B) {
+    {
         const Member me = mem[k];
         const int g = seg_id[k];
         const int s = seg_first[g], e = seg_first[g + 1];
         const bool is_long = e - s > PW_LONG;       // walked by k_pair_long
         int cc = 0;
         float la = 0.f, ga = 0.f;
-        PW_WALK(in_lds, staged, sbase, mem, (is_long ? e : s), e, j, o, {
-            cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
-            bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
-        });
+        if (in_lds) {
+#pragma unroll 4
+            for (int j = (is_long ? e : s) + sub; j < e; j += LPR) {
+                const Member o = staged[j - sbase];
+                cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
+                bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
+            }
+        } else {
+#pragma unroll 4
+            for (int j = (is_long ? e : s) + sub; j < e; j += LPR) {
+                const Member o = mem[j];
+                cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
+                bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) ga += __shfl_xor(ga, o, 64);
         if (is_long) {
-            cc = long_cnt[k];
-            la = long_la[k];
+            cc = sub == 0 ? long_cnt[k] : 0;
+            la = sub == 0 ? long_la[k] : 0.f;
             ga = long_ga[k];
         }
-        dscores[me.row] = factor * ga;
-        lsum = (double)la;
-        c = cc;
+        if (kr < B) {
+            if (sub == 0) dscores[me.row] = factor * ga;
+            lsum = (double)la;
+            c = cc;
+        }
     }
     lsum = block_sum<double>(lsum, red);
     c = block_sum<long long>(c, redc);
@@ -323,6 +345,20 @@ k_pair_one(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, c
         block_loss[blockIdx.x] = lsum;
         if (c) atomicAdd(n_pair, (unsigned long long)c);      // integer atomics: order-independent
     }
+}
+template <int FLAGS>
+__global__ void __launch_bounds__(256)
+k_pair_one(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
+           const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la, const float* __restrict__ long_ga,
+           double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair, float* __restrict__ dscores) {
+    pair_one_body<FLAGS, 1>(mem, seg_id, seg_first, B, factor, long_cnt, long_la, long_ga, block_loss, n_pair, dscores);
+}
+template <int FLAGS>
+__global__ void __launch_bounds__(256)
+k_pair_one4(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
+            const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la, const float* __restrict__ long_ga,
+            double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair, float* __restrict__ dscores) {
+    pair_one_body<FLAGS, 4>(mem, seg_id, seg_first, B, factor, long_cnt, long_la, long_ga, block_loss, n_pair, dscores);
 }
 
 // out[i] = d[i] * g[0] / (P + eps)   (P = *n_pair; n_pair == NULL: no division)
@@ -482,12 +518,13 @@ __global__ void k_seg_empty2(int32_t* seg_first, int32_t* n_seg, unsigned long l
 
 // ---- host side ---------------------------------------------------------------------------------------
 #define RN_PW_T 256
+#define RN_PW_LPR 4        // lanes per row of k_pair_one4
 #define RN_VEC_BLOCKS 1024
 
 extern "C" size_t recnow_pairwise_workspace_bytes(int64_t B) {
     if (B < 0) return 0;
     size_t s = rn_align((size_t)(B + 1) * sizeof(Member));
-    size_t nb = (size_t)rn_cdiv(B > 0 ? B : 1, RN_PW_T);
+    size_t nb = (size_t)rn_cdiv(B > 0 ? B : 1, RN_PW_T / RN_PW_LPR);      // block partials of k_pair_one4 (RN_PW_T / RN_PW_LPR rows per block)
     if (nb < RN_VEC_BLOCKS) nb = RN_VEC_BLOCKS;
     s += rn_align(nb * sizeof(double));
     s += 3 * rn_align((size_t)(B > 0 ? B : 1) * sizeof(float));          // k_pair_long: counts, loss and gradient terms per sorted row
@@ -522,7 +559,7 @@ static inline PairWs pair_ws(void* ws, size_t ws_bytes, int64_t B) {
     RnCarver c(ws, ws_bytes);
     PairWs p;
     p.mem = c.take<Member>(B + 1);
-    const int G = rn_cdiv(B, RN_PW_T);
+    const int G = rn_cdiv(B, RN_PW_T / RN_PW_LPR);
     p.part = c.take<double>(G > RN_VEC_BLOCKS ? G : RN_VEC_BLOCKS);
     p.long_cnt = c.take<int32_t>(B);
     p.long_la = c.take<float>(B);
@@ -647,13 +684,26 @@ int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t*
     int rc = (flags & RECNOW_PAIR_MEMBERS_PACKED) ? RECNOW_OK : pack_members(scores, labels, mask, order, B, pw.mem, st, nullptr, n_pair);
     if (rc) return rc;
     RN_DISPATCH_LONG(2, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga);
-    RN_DISPATCH_FLAGS(k_pair_one, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
-                      (unsigned long long*)n_pair, dscores_unnorm);
+    // Four lanes per row while the one-lane grid would leave most of the chip idle (B <= 32 768: at most 128 workgroups).  Measured (tools/layer_bench.py, GPU
+    // time of the loss fwd+bwd, one box): B = 8192 / 128 groups 66 -> 62 us, Zipf-skewed 130 -> 117 us, the 8192-row step 0.609 -> 0.602 ms; B = 65 536 / 1024 groups
+    // 81 -> 86 us (four times the block sums and staging for a grid that already fills the chip): one lane per row stays there.  RECNOW_PAIR_LPR=1 / =4 force a form.
+    static const int lpr_env = []() { const char* e = getenv("RECNOW_PAIR_LPR"); return e ? atoi(e) : 0; }();
+    const bool quad = lpr_env == 4 || (lpr_env != 1 && B <= 32768);
+    int nparts = G;
+    if (quad) {
+        const int G = rn_cdiv(B, RN_PW_T / RN_PW_LPR);          // (shadows the one-lane grid inside the dispatch macro)
+        nparts = G;
+        RN_DISPATCH_FLAGS(k_pair_one4, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
+                          (unsigned long long*)n_pair, dscores_unnorm);
+    } else {
+        RN_DISPATCH_FLAGS(k_pair_one, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
+                          (unsigned long long*)n_pair, dscores_unnorm);
+    }
     if (part_out) {
         *part_out = pw.part;
-        *nparts_out = G;
+        *nparts_out = nparts;
     } else {
-        hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, pw.part, G, (const unsigned long long*)n_pair, (int64_t)0, reduce_mean, loss);
+        hipLaunchKernelGGL(k_loss_finalize, 1, 1024, 0, st, pw.part, nparts, (const unsigned long long*)n_pair, (int64_t)0, reduce_mean, loss);
     }
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
