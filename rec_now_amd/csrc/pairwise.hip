@@ -289,14 +289,12 @@ k_pair_bpr(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, c
 // instructions per member (two transcendentals), and with one lane per row a 64-member group made the launch 64 such steps long whatever the grid --
 // 12.6 us at 8192 rows, where the grid is 32 workgroups.  The lanes' gradient terms meet by two fixed-order butterfly steps (the same bits on every
 // lane and run), their loss terms and counts go into the block sum as they are.  A block owns 256 / LPR consecutive sorted rows.
-template <int FLAGS, int LPR>
+// SKIP_LONG: rows of long segments contribute nothing here and their dscores entry is not written (the long-row workgroups of k_pair_all do both).
+template <int FLAGS, int LPR, bool SKIP_LONG = false>
 __device__ __forceinline__ void pair_one_body(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
                                               int64_t B, float factor, const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la,
                                               const float* __restrict__ long_ga, double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair,
-                                              float* __restrict__ dscores) {
-    __shared__ double red[16];
-    __shared__ long long redc[16];
-    __shared__ Member staged[PW_STAGE];
+                                              float* __restrict__ dscores, Member* staged, double* red, long long* redc) {
     int sbase;
     const bool in_lds = stage_members(mem, seg_id, seg_first, B, staged, &sbase, 256 / LPR);
     const int sub = (int)threadIdx.x % LPR;
@@ -328,12 +326,12 @@ __device__ __forceinline__ void pair_one_body(const Member* __restrict__ mem, co
         }
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) ga += __shfl_xor(ga, o, 64);
-        if (is_long) {
+        if (is_long && !SKIP_LONG) {
             cc = sub == 0 ? long_cnt[k] : 0;
             la = sub == 0 ? long_la[k] : 0.f;
             ga = long_ga[k];
         }
-        if (kr < B) {
+        if (kr < B && !(SKIP_LONG && is_long)) {
             if (sub == 0) dscores[me.row] = factor * ga;
             lsum = (double)la;
             c = cc;
@@ -351,14 +349,83 @@ __global__ void __launch_bounds__(256)
 k_pair_one(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
            const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la, const float* __restrict__ long_ga,
            double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair, float* __restrict__ dscores) {
-    pair_one_body<FLAGS, 1>(mem, seg_id, seg_first, B, factor, long_cnt, long_la, long_ga, block_loss, n_pair, dscores);
+    __shared__ double red[16];
+    __shared__ long long redc[16];
+    __shared__ Member staged[PW_STAGE];
+    pair_one_body<FLAGS, 1>(mem, seg_id, seg_first, B, factor, long_cnt, long_la, long_ga, block_loss, n_pair, dscores, staged, red, redc);
 }
 template <int FLAGS>
 __global__ void __launch_bounds__(256)
 k_pair_one4(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
             const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la, const float* __restrict__ long_ga,
             double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair, float* __restrict__ dscores) {
-    pair_one_body<FLAGS, 4>(mem, seg_id, seg_first, B, factor, long_cnt, long_la, long_ga, block_loss, n_pair, dscores);
+    __shared__ double red[16];
+    __shared__ long long redc[16];
+    __shared__ Member staged[PW_STAGE];
+    pair_one_body<FLAGS, 4>(mem, seg_id, seg_first, B, factor, long_cnt, long_la, long_ga, block_loss, n_pair, dscores, staged, red, redc);
+}
+// Round 5 (second session): the loss walk as ONE launch.  Workgroups [0, g_one) are k_pair_one / k_pair_one4 with the rows of long segments left out;
+// workgroup g_one + b is k_pair_long's workgroup b (64 consecutive sorted rows, a wave per row of a long segment) -- but instead of parking (count, loss
+// term, gradient term) per sorted row for a second kernel it writes the row's dscores entry, adds the counts to n_pair and leaves its loss terms as
+// block_loss[g_one + b] (0 for the usual workgroup without a long segment).  No workgroup reads what another one writes: the batch without long groups no
+// longer pays an empty launch (~6 us in front of every thread-per-row launch), the skewed batch no longer a round trip through three B-sized arrays.
+template <int FLAGS, int LPR>
+__global__ void __launch_bounds__(256)
+k_pair_all(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
+           double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair, float* __restrict__ dscores, int g_one) {
+    __shared__ double red[16];
+    __shared__ long long redc[16];
+    __shared__ Member staged[PW_STAGE];
+    if ((int)blockIdx.x < g_one) {
+        pair_one_body<FLAGS, LPR, true>(mem, seg_id, seg_first, B, factor, nullptr, nullptr, nullptr, block_loss, n_pair, dscores, staged, red, redc);
+        return;
+    }
+    const int64_t k0 = (int64_t)((int)blockIdx.x - g_one) * 64;
+    double lsum = 0.0;
+    long long csum = 0;
+    if (k0 < B) {                                                       // block-uniform
+        const int64_t kl = min(B, k0 + 64) - 1;
+        const int g0 = seg_id[k0], g1 = seg_id[kl];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        bool staged_used = false;
+        for (int phase = 0; phase < 2; ++phase) {                       // (as k_pair_long: only the first and the last row's segment can be long)
+            if (phase == 1 && g1 == g0) break;
+            const int g = phase == 0 ? g0 : g1;
+            const int s = seg_first[g], e = seg_first[g + 1];
+            if (e - s <= PW_LONG) continue;
+            const bool in_lds = e - s <= PW_STAGE;
+            if (in_lds) {
+                if (staged_used) __syncthreads();
+                for (int i = threadIdx.x; i < e - s; i += 256) staged[i] = mem[s + i];
+                __syncthreads();
+                staged_used = true;
+            }
+            const int64_t ka = k0 > s ? k0 : (int64_t)s, kb = kl < (int64_t)e - 1 ? kl : (int64_t)e - 1;
+            for (int64_t k = ka + w; k <= kb; k += 4) {
+                const Member me = mem[k];
+                int cc = 0;
+                float la = 0.f, ga = 0.f;
+                PW_WALK_STRIDED(in_lds, staged, s, mem, s + lane, e, j, o, {
+                    cc += (j != (int)k && pair_ok<FLAGS>(me, o)) ? 1 : 0;
+                    bpr_term<FLAGS>(me, o, j != (int)k, factor, la, ga);
+                });
+                cc = wave_sum(cc);
+                la = wave_sum(la);
+                ga = wave_sum(ga);
+                if (lane == 0) {
+                    dscores[me.row] = factor * ga;
+                    lsum += (double)la;                                 // (lane 0 of wave w: this wave's rows in ascending order)
+                    csum += cc;
+                }
+            }
+        }
+    }
+    lsum = block_sum<double>(lsum, red);
+    csum = block_sum<long long>(csum, redc);
+    if (threadIdx.x == 0) {
+        block_loss[blockIdx.x] = lsum;
+        if (csum) atomicAdd(n_pair, (unsigned long long)csum);
+    }
 }
 
 // out[i] = d[i] * g[0] / (P + eps)   (P = *n_pair; n_pair == NULL: no division)
@@ -524,7 +591,7 @@ __global__ void k_seg_empty2(int32_t* seg_first, int32_t* n_seg, unsigned long l
 extern "C" size_t recnow_pairwise_workspace_bytes(int64_t B) {
     if (B < 0) return 0;
     size_t s = rn_align((size_t)(B + 1) * sizeof(Member));
-    size_t nb = (size_t)rn_cdiv(B > 0 ? B : 1, RN_PW_T / RN_PW_LPR);      // block partials of k_pair_one4 (RN_PW_T / RN_PW_LPR rows per block)
+    size_t nb = 2 * (size_t)rn_cdiv(B > 0 ? B : 1, RN_PW_T / RN_PW_LPR);  // block partials of k_pair_all: RN_PW_T / RN_PW_LPR rows per thread-per-row block + 64 per long-row block
     if (nb < RN_VEC_BLOCKS) nb = RN_VEC_BLOCKS;
     s += rn_align(nb * sizeof(double));
     s += 3 * rn_align((size_t)(B > 0 ? B : 1) * sizeof(float));          // k_pair_long: counts, loss and gradient terms per sorted row
@@ -559,7 +626,7 @@ static inline PairWs pair_ws(void* ws, size_t ws_bytes, int64_t B) {
     RnCarver c(ws, ws_bytes);
     PairWs p;
     p.mem = c.take<Member>(B + 1);
-    const int G = rn_cdiv(B, RN_PW_T / RN_PW_LPR);
+    const int G = 2 * rn_cdiv(B, RN_PW_T / RN_PW_LPR);
     p.part = c.take<double>(G > RN_VEC_BLOCKS ? G : RN_VEC_BLOCKS);
     p.long_cnt = c.take<int32_t>(B);
     p.long_la = c.take<float>(B);
@@ -683,21 +750,41 @@ int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t*
     // RECNOW_PAIR_MEMBERS_PACKED: recnow_group_pack_small has packed the members into `ws` and cleared *n_pair
     int rc = (flags & RECNOW_PAIR_MEMBERS_PACKED) ? RECNOW_OK : pack_members(scores, labels, mask, order, B, pw.mem, st, nullptr, n_pair);
     if (rc) return rc;
-    RN_DISPATCH_LONG(2, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga);
     // Four lanes per row while the one-lane grid would leave most of the chip idle (B <= 32 768: at most 128 workgroups).  Measured (tools/layer_bench.py, GPU
     // time of the loss fwd+bwd, one box): B = 8192 / 128 groups 66 -> 62 us, Zipf-skewed 130 -> 117 us, the 8192-row step 0.609 -> 0.602 ms; B = 65 536 / 1024 groups
     // 81 -> 86 us (four times the block sums and staging for a grid that already fills the chip): one lane per row stays there.  RECNOW_PAIR_LPR=1 / =4 force a form.
     static const int lpr_env = []() { const char* e = getenv("RECNOW_PAIR_LPR"); return e ? atoi(e) : 0; }();
+    static const bool one_launch = []() { const char* e = getenv("RECNOW_PAIR_ALL"); return !e || e[0] != '0'; }();      // A/B switch: 0 = k_pair_long + k_pair_one(4)
     const bool quad = lpr_env == 4 || (lpr_env != 1 && B <= 32768);
     int nparts = G;
-    if (quad) {
-        const int G = rn_cdiv(B, RN_PW_T / RN_PW_LPR);          // (shadows the one-lane grid inside the dispatch macro)
-        nparts = G;
-        RN_DISPATCH_FLAGS(k_pair_one4, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
-                          (unsigned long long*)n_pair, dscores_unnorm);
+    if (one_launch) {
+        const int g_one = rn_cdiv(B, quad ? RN_PW_T / RN_PW_LPR : RN_PW_T), g_all = g_one + rn_cdiv(B, 64);
+        nparts = g_all;
+#define RN_PAIR_ALL(F)                                                                                                                              \
+    do {                                                                                                                                            \
+        if (quad) hipLaunchKernelGGL((k_pair_all<F, RN_PW_LPR>), g_all, RN_PW_T, 0, st, pw.mem, seg_id, seg_first, B, factor, pw.part,                \
+                                     (unsigned long long*)n_pair, dscores_unnorm, g_one);                                                            \
+        else hipLaunchKernelGGL((k_pair_all<F, 1>), g_all, RN_PW_T, 0, st, pw.mem, seg_id, seg_first, B, factor, pw.part, (unsigned long long*)n_pair, \
+                                dscores_unnorm, g_one);                                                                                              \
+    } while (0)
+        switch (flags & 3) {
+            case 0: RN_PAIR_ALL(0); break;
+            case 1: RN_PAIR_ALL(1); break;
+            case 2: RN_PAIR_ALL(2); break;
+            default: RN_PAIR_ALL(3); break;
+        }
+#undef RN_PAIR_ALL
     } else {
-        RN_DISPATCH_FLAGS(k_pair_one, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
-                          (unsigned long long*)n_pair, dscores_unnorm);
+        RN_DISPATCH_LONG(2, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga);
+        if (quad) {
+            const int G = rn_cdiv(B, RN_PW_T / RN_PW_LPR);          // (shadows the one-lane grid inside the dispatch macro)
+            nparts = G;
+            RN_DISPATCH_FLAGS(k_pair_one4, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
+                              (unsigned long long*)n_pair, dscores_unnorm);
+        } else {
+            RN_DISPATCH_FLAGS(k_pair_one, pw.mem, seg_id, seg_first, B, factor, pw.long_cnt, pw.long_la, pw.long_ga, pw.part,
+                              (unsigned long long*)n_pair, dscores_unnorm);
+        }
     }
     if (part_out) {
         *part_out = pw.part;
