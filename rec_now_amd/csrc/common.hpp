@@ -19,6 +19,9 @@ static inline size_t rn_align(size_t x, size_t a = 256) { return (x + a - 1) / a
 static inline int rn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Workspace carving: every carve is 256-B aligned so vector accesses stay aligned.
+// internal flag bits of rn_pair_bpr_onepass (pairwise.hip; set by the step's loss stage, dcnmix.hip; never part of the C ABI's flags):
+#define RN_PAIR_UNPACKED (1 << 30)         // no pack launch: the walk's workgroups fill their LDS stages from (scores, labels, mask) through `order`
+#define RN_PAIR_NPAIR_ZEROED (1 << 29)     // *n_pair has been cleared by an earlier launch of the caller (the step's front kernel)
 struct RnCarver {
     char* base;
     size_t off;

@@ -700,10 +700,11 @@ int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t*
                         const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean, float* loss, float* dscores_unnorm,
                         int64_t* n_pair, void* ws, size_t ws_bytes, void* stream, const double** part_out, int* nparts_out);      // pairwise.hip
 // scan_sort.hip; pack != NULL: the launch also writes the weight packs of the row-block kernels on further workgroups (k_front_small / k_front_mid)
+// zero1 / zeroed: a front kernel also clears one 64-bit word (the step's pair counter) and reports it
 int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack);
+                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed);
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack);
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed);
 
 extern "C" int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
@@ -1459,6 +1460,7 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((phases & RECNOW_STEP_FORWARD) && !d->scores) return RECNOW_EINVAL;
+    int npair_zeroed = 0;                    // the GROUP phase of this call cleared *n_pair for its LOSS phase
     if (phases & RECNOW_STEP_GROUP) {
         if (!d->groups) return RECNOW_EINVAL;
         RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_STEP_GROUP, 0.0, 16.0 * B, st) : nullptr;
@@ -1475,10 +1477,13 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
             pack = &pk;
         }
         tl_step_tile_packed = nullptr;
-        rc = rn_group_small_raw(d->groups, d->group_dtype, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, st, pack);
+        // (the loss stage of THIS call adds into *n_pair: a front kernel clears it on the way)
+        unsigned long long* zero1 = ((phases & RECNOW_STEP_LOSS) && d->n_pair) ? (unsigned long long*)d->n_pair : nullptr;
+        rc = rn_group_small_raw(d->groups, d->group_dtype, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, st, pack, zero1, &npair_zeroed);
         // larger batches: the cooperative launch forms keys and solo flags from the id tensor as well
         if (rc == RECNOW_EUNSUPPORTED)
-            rc = rn_group_mid_raw(d->groups, d->group_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, pack);
+            rc = rn_group_mid_raw(d->groups, d->group_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, pack, zero1,
+                                  &npair_zeroed);
         if (rc == RECNOW_OK && pack) tl_step_tile_packed = w.saved;
         if (rc == RECNOW_EUNSUPPORTED) {
             RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
@@ -1498,7 +1503,10 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
     }
     if (phases & RECNOW_STEP_LOSS) {
         if (!d->scores || !d->labels || !d->loss || !d->n_pair) return RECNOW_EINVAL;
-        const int flags = RECNOW_PAIR_LABEL_GT | (d->only_use_wrong_order_pair ? RECNOW_PAIR_WRONG_ORDER : 0);
+        // no pack launch: the pair walk fills its LDS stages from the inputs (RN_PAIR_UNPACKED); RECNOW_STEP_PACK=1 keeps the packed form (A/B)
+        static const bool packed = []() { const char* e = getenv("RECNOW_STEP_PACK"); return e && e[0] == '1'; }();
+        const int flags = RECNOW_PAIR_LABEL_GT | (d->only_use_wrong_order_pair ? RECNOW_PAIR_WRONG_ORDER : 0) |
+                          (packed ? 0 : (RN_PAIR_UNPACKED | (npair_zeroed ? RN_PAIR_NPAIR_ZEROED : 0)));
         RnProfRecord* pr = rn_prof_on() ? rn_prof_begin(RN_TAG_STEP_LOSS, 0.0, 16.0 * B + 8.0 * BP * m.LDT, st) : nullptr;
         const double* loss_part = nullptr;
         int n_loss_part = 0;

@@ -27,6 +27,22 @@ __device__ __forceinline__ Member load_member(const float* __restrict__ scores, 
     return m;
 }
 
+// Where a walk's member records come from: the packed array (k_pack_members), or -- UNP, the step's loss stage since round 5 -- straight from the loss's
+// inputs through the sorted order (three dependent gathers instead of one 16-byte load: used to FILL the LDS stage of a workgroup, which is what the walks
+// read; a walk that cannot be staged -- a group of more than 2048 rows -- pays the gathers per member).  Saves the pack launch in front of the walk.
+template <bool UNP>
+struct MemberSrc {
+    const Member* __restrict__ mem;
+    const float* __restrict__ scores;
+    const float* __restrict__ labels;
+    const uint8_t* __restrict__ mask;
+    const int32_t* __restrict__ order;
+    __device__ __forceinline__ Member operator[](int64_t k) const {
+        if constexpr (UNP) return load_member(scores, labels, mask, order, k);
+        else return mem[k];
+    }
+};
+
 // zero_b / zero_1 (optional): the B per-row counters and the one total that the counting kernel adds into -- cleared here
 // instead of by two memset launches (a loss call is a chain of few-microsecond launches; each one removed is ~4 us)
 __global__ void k_pack_members(const float* __restrict__ scores, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
@@ -54,7 +70,8 @@ __device__ __forceinline__ bool pair_ok(const Member& a, const Member& b) {   //
 // in LDS once, coalesced, and every per-row walk reads LDS (a walk is a chain of dependent 16-byte loads otherwise: ~0.4 us
 // per member from L1/L2).  Block-uniform decision; oversize ranges (one huge group) fall back to global loads.
 #define PW_STAGE 2048
-__device__ __forceinline__ bool stage_members(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id,
+template <typename SRC>
+__device__ __forceinline__ bool stage_members(const SRC mem, const int32_t* __restrict__ seg_id,
                                               const int32_t* __restrict__ seg_first, int64_t B, Member* lds, int* base, int rows_per_block = 0) {
     *base = 0;
     const int64_t rpb = rows_per_block > 0 ? rows_per_block : (int64_t)blockDim.x;
@@ -290,8 +307,8 @@ k_pair_bpr(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, c
 // 12.6 us at 8192 rows, where the grid is 32 workgroups.  The lanes' gradient terms meet by two fixed-order butterfly steps (the same bits on every
 // lane and run), their loss terms and counts go into the block sum as they are.  A block owns 256 / LPR consecutive sorted rows.
 // SKIP_LONG: rows of long segments contribute nothing here and their dscores entry is not written (the long-row workgroups of k_pair_all do both).
-template <int FLAGS, int LPR, bool SKIP_LONG = false>
-__device__ __forceinline__ void pair_one_body(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
+template <int FLAGS, int LPR, bool SKIP_LONG = false, typename SRC = const Member*>
+__device__ __forceinline__ void pair_one_body(const SRC mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first,
                                               int64_t B, float factor, const int32_t* __restrict__ long_cnt, const float* __restrict__ long_la,
                                               const float* __restrict__ long_ga, double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair,
                                               float* __restrict__ dscores, Member* staged, double* red, long long* redc) {
@@ -303,7 +320,7 @@ __device__ __forceinline__ void pair_one_body(const Member* __restrict__ mem, co
     double lsum = 0.0;
     long long c = 0;
     {
-        const Member me = mem[k];
+        const Member me = in_lds ? staged[k - sbase] : mem[k];          // (the staged range covers every row of the block)
         const int g = seg_id[k];
         const int s = seg_first[g], e = seg_first[g + 1];
         const bool is_long = e - s > PW_LONG;       // walked by k_pair_long
@@ -369,15 +386,16 @@ k_pair_one4(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, 
 // term, gradient term) per sorted row for a second kernel it writes the row's dscores entry, adds the counts to n_pair and leaves its loss terms as
 // block_loss[g_one + b] (0 for the usual workgroup without a long segment).  No workgroup reads what another one writes: the batch without long groups no
 // longer pays an empty launch (~6 us in front of every thread-per-row launch), the skewed batch no longer a round trip through three B-sized arrays.
-template <int FLAGS, int LPR>
+template <int FLAGS, int LPR, bool UNP>
 __global__ void __launch_bounds__(256)
-k_pair_all(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
+k_pair_all(const MemberSrc<UNP> mem, const int32_t* __restrict__ seg_id, const int32_t* __restrict__ seg_first, int64_t B, float factor,
            double* __restrict__ block_loss, unsigned long long* __restrict__ n_pair, float* __restrict__ dscores, int g_one) {
     __shared__ double red[16];
     __shared__ long long redc[16];
     __shared__ Member staged[PW_STAGE];
     if ((int)blockIdx.x < g_one) {
-        pair_one_body<FLAGS, LPR, true>(mem, seg_id, seg_first, B, factor, nullptr, nullptr, nullptr, block_loss, n_pair, dscores, staged, red, redc);
+        pair_one_body<FLAGS, LPR, true, MemberSrc<UNP>>(mem, seg_id, seg_first, B, factor, nullptr, nullptr, nullptr, block_loss, n_pair, dscores, staged, red,
+                                                         redc);
         return;
     }
     const int64_t k0 = (int64_t)((int)blockIdx.x - g_one) * 64;
@@ -402,7 +420,7 @@ k_pair_all(const Member* __restrict__ mem, const int32_t* __restrict__ seg_id, c
             }
             const int64_t ka = k0 > s ? k0 : (int64_t)s, kb = kl < (int64_t)e - 1 ? kl : (int64_t)e - 1;
             for (int64_t k = ka + w; k <= kb; k += 4) {
-                const Member me = mem[k];
+                const Member me = in_lds ? staged[k - s] : mem[k];
                 int cc = 0;
                 float la = 0.f, ga = 0.f;
                 PW_WALK_STRIDED(in_lds, staged, s, mem, s + lane, e, j, o, {
@@ -747,14 +765,22 @@ int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t*
     if (ws_bytes < recnow_pairwise_workspace_bytes(B)) return RECNOW_EWORKSPACE;
     const PairWs pw = pair_ws(ws, ws_bytes, B);
     const int G = rn_cdiv(B, RN_PW_T);
+    static const bool one_launch = []() { const char* e = getenv("RECNOW_PAIR_ALL"); return !e || e[0] != '0'; }();      // A/B switch: 0 = k_pair_long + k_pair_one(4)
+    // RN_PAIR_UNPACKED (internal: the step's loss stage): no pack launch -- the walk's workgroups fill their LDS stages from the inputs through `order`;
+    // RN_PAIR_NPAIR_ZEROED: an earlier launch of the caller has cleared *n_pair (the step's grouping launch), else a fill does it here.
+    const bool unpacked = one_launch && (flags & RN_PAIR_UNPACKED) != 0 && !(flags & RECNOW_PAIR_MEMBERS_PACKED);
     // RECNOW_PAIR_MEMBERS_PACKED: recnow_group_pack_small has packed the members into `ws` and cleared *n_pair
-    int rc = (flags & RECNOW_PAIR_MEMBERS_PACKED) ? RECNOW_OK : pack_members(scores, labels, mask, order, B, pw.mem, st, nullptr, n_pair);
+    int rc = RECNOW_OK;
+    if (unpacked) {
+        if (!(flags & RN_PAIR_NPAIR_ZEROED)) RN_HIP(hipMemsetAsync(n_pair, 0, sizeof(int64_t), st));
+    } else if (!(flags & RECNOW_PAIR_MEMBERS_PACKED)) {
+        rc = pack_members(scores, labels, mask, order, B, pw.mem, st, nullptr, n_pair);
+    }
     if (rc) return rc;
     // Four lanes per row while the one-lane grid would leave most of the chip idle (B <= 32 768: at most 128 workgroups).  Measured (tools/layer_bench.py, GPU
     // time of the loss fwd+bwd, one box): B = 8192 / 128 groups 66 -> 62 us, Zipf-skewed 130 -> 117 us, the 8192-row step 0.609 -> 0.602 ms; B = 65 536 / 1024 groups
     // 81 -> 86 us (four times the block sums and staging for a grid that already fills the chip): one lane per row stays there.  RECNOW_PAIR_LPR=1 / =4 force a form.
     static const int lpr_env = []() { const char* e = getenv("RECNOW_PAIR_LPR"); return e ? atoi(e) : 0; }();
-    static const bool one_launch = []() { const char* e = getenv("RECNOW_PAIR_ALL"); return !e || e[0] != '0'; }();      // A/B switch: 0 = k_pair_long + k_pair_one(4)
     const bool quad = lpr_env == 4 || (lpr_env != 1 && B <= 32768);
     int nparts = G;
     if (one_launch) {
@@ -762,10 +788,19 @@ int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t*
         nparts = g_all;
 #define RN_PAIR_ALL(F)                                                                                                                              \
     do {                                                                                                                                            \
-        if (quad) hipLaunchKernelGGL((k_pair_all<F, RN_PW_LPR>), g_all, RN_PW_T, 0, st, pw.mem, seg_id, seg_first, B, factor, pw.part,                \
-                                     (unsigned long long*)n_pair, dscores_unnorm, g_one);                                                            \
-        else hipLaunchKernelGGL((k_pair_all<F, 1>), g_all, RN_PW_T, 0, st, pw.mem, seg_id, seg_first, B, factor, pw.part, (unsigned long long*)n_pair, \
-                                dscores_unnorm, g_one);                                                                                              \
+        if (unpacked) {                                                                                                                             \
+            const MemberSrc<true> src{pw.mem, scores, labels, mask, order};                                                                         \
+            if (quad) hipLaunchKernelGGL((k_pair_all<F, RN_PW_LPR, true>), g_all, RN_PW_T, 0, st, src, seg_id, seg_first, B, factor, pw.part,         \
+                                         (unsigned long long*)n_pair, dscores_unnorm, g_one);                                                        \
+            else hipLaunchKernelGGL((k_pair_all<F, 1, true>), g_all, RN_PW_T, 0, st, src, seg_id, seg_first, B, factor, pw.part,                      \
+                                    (unsigned long long*)n_pair, dscores_unnorm, g_one);                                                             \
+        } else {                                                                                                                                    \
+            const MemberSrc<false> src{pw.mem, nullptr, nullptr, nullptr, nullptr};                                                                 \
+            if (quad) hipLaunchKernelGGL((k_pair_all<F, RN_PW_LPR, false>), g_all, RN_PW_T, 0, st, src, seg_id, seg_first, B, factor, pw.part,        \
+                                         (unsigned long long*)n_pair, dscores_unnorm, g_one);                                                        \
+            else hipLaunchKernelGGL((k_pair_all<F, 1, false>), g_all, RN_PW_T, 0, st, src, seg_id, seg_first, B, factor, pw.part,                     \
+                                    (unsigned long long*)n_pair, dscores_unnorm, g_one);                                                             \
+        }                                                                                                                                           \
     } while (0)
         switch (flags & 3) {
             case 0: RN_PAIR_ALL(0); break;
@@ -798,8 +833,8 @@ int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t*
 extern "C" int recnow_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t* mask, const int32_t* order,
                                       const int32_t* seg_id, const int32_t* seg_first, int64_t B, int flags, float factor, int reduce_mean,
                                       float* loss, float* dscores_unnorm, int64_t* n_pair, void* ws, size_t ws_bytes, void* stream) {
-    return rn_pair_bpr_onepass(scores, labels, mask, order, seg_id, seg_first, B, flags, factor, reduce_mean, loss, dscores_unnorm, n_pair, ws, ws_bytes,
-                               stream, nullptr, nullptr);
+    return rn_pair_bpr_onepass(scores, labels, mask, order, seg_id, seg_first, B, flags & ~(RN_PAIR_UNPACKED | RN_PAIR_NPAIR_ZEROED), factor, reduce_mean, loss,
+                               dscores_unnorm, n_pair, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
 extern "C" int recnow_pair_scale_grad(const float* dscores_unnorm, const float* g, const int64_t* n_pair, float eps, int64_t B, float* out,
@@ -955,7 +990,7 @@ k_pair_norm_grad(const float* __restrict__ d, const unsigned long long* __restri
 }
 struct RnTileFwd;
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack);       // scan_sort.hip
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed);       // scan_sort.hip
 extern "C" int recnow_pairwise_loss(const void* groups, int key_dtype, const float* labels, const float* scores, const uint8_t* mask,
                                     int64_t B, int flags, float factor, int reduce_mean, float* loss, int64_t* n_pair, float* out2,
                                     float* dscores, void* ws, size_t ws_bytes, void* stream) {
@@ -979,7 +1014,7 @@ extern "C" int recnow_pairwise_loss(const void* groups, int key_dtype, const flo
                                           n_pair, w.pair, w.pair_bytes, stream)))
             return rc;
         f |= RECNOW_PAIR_MEMBERS_PACKED;
-    } else if ((rc = rn_group_mid_raw(groups, key_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, nullptr)) !=
+    } else if ((rc = rn_group_mid_raw(groups, key_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, nullptr, nullptr, nullptr)) !=
                RECNOW_EUNSUPPORTED) {
         // (one float32 / int32 id tensor: keys and solo flags formed inside the cooperative grouping launch, scan_sort.hip)
         if (rc) return rc;

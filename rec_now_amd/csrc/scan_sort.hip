@@ -460,8 +460,9 @@ k_group_small(const uint32_t* __restrict__ words, const uint8_t* __restrict__ so
 template <int RAW>
 __global__ void __launch_bounds__(GS_T)
 k_front_small(const uint32_t* __restrict__ words, int B, int32_t* __restrict__ order, int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first,
-              int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg, const RnTileFwd pack) {
+              int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg, const RnTileFwd pack, unsigned long long* __restrict__ zero1) {
     if (blockIdx.x == 0) {
+        if (zero1 && threadIdx.x == 0) *zero1 = 0ull;      // the step's pair counter (its loss stage adds into it: dcnmix.hip)
         group_small_body<RAW>(words, nullptr, B, order, seg_id, seg_first, super_id, n_seg);
         return;
     }
@@ -1039,7 +1040,8 @@ __global__ void __launch_bounds__(256)
 k_front_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int64_t B, GroupMidCtl* __restrict__ ctl, int32_t* __restrict__ idx0,
             int32_t* __restrict__ idx1, uint32_t* __restrict__ key0, uint32_t* __restrict__ key1, unsigned* __restrict__ blockhist,
             int* __restrict__ headcnt, int32_t* __restrict__ order, int32_t* __restrict__ seg_id, int32_t* __restrict__ seg_first,
-            int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg, const int G, const RnTileFwd pack) {
+            int32_t* __restrict__ super_id, int32_t* __restrict__ n_seg, const int G, const RnTileFwd pack, unsigned long long* __restrict__ zero1) {
+    if (zero1 && blockIdx.x == 0 && threadIdx.x == 0) *zero1 = 0ull;
     if ((int)blockIdx.x < G) {
         group_mid_body<RN_TILE, RAW>(words, solo, B, 1, 1, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id, seg_first, super_id, n_seg, G,
                                      (int)blockIdx.x);
@@ -1051,7 +1053,7 @@ k_front_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
 // The grouping of a small batch (B <= 8192) straight from ONE float32 / int32 id tensor in one launch (library-internal: the GROUP phase of
 // recnow_dcn_mix_step).  Returns RECNOW_EUNSUPPORTED for other shapes: the caller then takes recnow_group_keys + recnow_group_segments.
 int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack) {
+                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed) {
     if (B < 1 || B > GS_MAXB || (dtype != RECNOW_KEY_F32 && dtype != RECNOW_KEY_I32)) return RECNOW_EUNSUPPORTED;
     static std::atomic<bool> raised[64];
     int dev = 0;
@@ -1066,10 +1068,11 @@ int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, 
     if (pack) {      // + the weight packs: one pack workgroup per remaining compute unit (every workgroup of this kernel holds 112 KB of LDS)
         const int grid = 1 + RN_FRONT_PACK_WGS;
         if (dtype == RECNOW_KEY_F32)
-            hipLaunchKernelGGL(k_front_small<1>, grid, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (int)B, order, seg_id, seg_first, super_id, n_seg, *pack);
+            hipLaunchKernelGGL(k_front_small<1>, grid, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (int)B, order, seg_id, seg_first, super_id, n_seg, *pack, zero1);
         else
-            hipLaunchKernelGGL(k_front_small<2>, grid, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (int)B, order, seg_id, seg_first, super_id, n_seg, *pack);
+            hipLaunchKernelGGL(k_front_small<2>, grid, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (int)B, order, seg_id, seg_first, super_id, n_seg, *pack, zero1);
         RN_LAUNCH_CHECK();
+        if (zeroed) *zeroed = zero1 ? 1 : 0;
         return RECNOW_OK;
     }
     if (dtype == RECNOW_KEY_F32)
@@ -1115,9 +1118,11 @@ extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) 
 
 // The cooperative route (one launch, all workgroups co-resident: <= one per CU) over the workspace of recnow_group_segments; RECNOW_EUNSUPPORTED when the
 // batch does not fit it (the caller then takes the multi-launch chain).  raw = 0: canonical key words + solo flags; raw = 1 / 2: `words` is a float32 / int32
-// id tensor (n_words = 1), the kernel forms keys and solo flags itself (`solo` is written, not read, by the caller's side).
+// id tensor (n_words = 1), the kernel forms keys and solo flags itself (`solo` is written, not read, by the caller's side).  zero1 / zeroed: the front
+// kernels (pack != NULL) also clear one 64-bit word for the caller and say so; the other forms leave *zeroed alone.
 static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t B, int n_words, int n_words_first, int32_t* order, int32_t* seg_id,
-                         int32_t* seg_first, int32_t* super_id, int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack = nullptr) {
+                         int32_t* seg_first, int32_t* super_id, int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack = nullptr,
+                         unsigned long long* zero1 = nullptr, int* zeroed = nullptr) {
     static const bool coop = []() { const char* e = getenv("RECNOW_GROUP_COOP"); return !e || e[0] != '0'; }();      // A/B switch
     if (!coop) return RECNOW_EUNSUPPORTED;
     const int nblk = rn_cdiv(B, RN_TILE);
@@ -1157,10 +1162,11 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
     if (raw && pack && tile == RN_TILE) {      // + the weight packs on workgroups behind the grouping's
         if (raw == 1)
             hipLaunchKernelGGL(k_front_mid<1>, g + RN_FRONT_PACK_WGS, 256, 0, st, words, solo, B, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id,
-                               seg_first, super_id, n_seg, g, *pack);
+                               seg_first, super_id, n_seg, g, *pack, zero1);
         else
             hipLaunchKernelGGL(k_front_mid<2>, g + RN_FRONT_PACK_WGS, 256, 0, st, words, solo, B, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id,
-                               seg_first, super_id, n_seg, g, *pack);
+                               seg_first, super_id, n_seg, g, *pack, zero1);
+        if (zeroed) *zeroed = zero1 ? 1 : 0;
     } else if (raw == 1 && tile == 4096) GM_LAUNCH(4096, 1);
     else if (raw == 2 && tile == 4096) GM_LAUNCH(4096, 2);
     else if (raw == 1) GM_LAUNCH(2048, 1);
@@ -1178,11 +1184,12 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
 // launch forms keys and solo flags itself -- no fill of `solo`, no key kernel.
 // RECNOW_EUNSUPPORTED: other id types, or a batch beyond the co-resident grid (the caller takes recnow_group_keys + recnow_group_segments).
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack) {
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed) {
     static const bool on = []() { const char* e = getenv("RECNOW_GROUP_RAW"); return !e || e[0] != '0'; }();      // A/B switch
     if (!on || B <= GS_MAXB || (dtype != RECNOW_KEY_F32 && dtype != RECNOW_KEY_I32) || !solo || !ws) return RECNOW_EUNSUPPORTED;
     if (ws_bytes < recnow_group_segments_workspace_bytes(B, 1)) return RECNOW_EWORKSPACE;
-    return rn_group_coop(dtype == RECNOW_KEY_F32 ? 1 : 2, (const uint32_t*)group, solo, B, 1, 1, order, seg_id, seg_first, super_id, n_seg, ws, ws_bytes, st, pack);
+    return rn_group_coop(dtype == RECNOW_KEY_F32 ? 1 : 2, (const uint32_t*)group, solo, B, 1, 1, order, seg_id, seg_first, super_id, n_seg, ws, ws_bytes, st, pack,
+                         zero1, zeroed);
 }
 
 extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo, int64_t B, int n_words, int n_words_first,

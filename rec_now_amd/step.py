@@ -179,23 +179,26 @@ class DCNMixPairwiseStep(object):
         elif mode == 'inline':
             # ONE call for both phases: at shard sizes the library then packs the row-block kernels' weights on spare workgroups of the grouping
             # launch (k_front_small / k_front_mid, csrc/scan_sort.hip) instead of in a launch of its own in front of the forward kernel
-            launch('front', lambda: self._call(_GROUP | _FORWARD))
+            # ... and, with the loss stage in the same call, clears the pair counter there, so that the pair walk (which fills its LDS stages
+            # straight from scores / labels / mask through the sorted order) is the loss stage's first launch: no pack kernel, no fill
+            launch('front', lambda: self._call(_GROUP | _FORWARD | _LOSS))
         else:
             launch('forward', lambda: self._call(_FORWARD))
             launch('group', lambda: self._call(_GROUP))
+        loss0 = 0 if mode == 'inline' else _LOSS      # (inline: the loss stage ran in the front call)
         if whole_backward:
             # eager under a reducer: ONE call walks all layers (the weight-gradient products of a layer run on the second stream beside
             # the chain of the layers below) and records the stages' events itself where each stage's last gradient is issued
             self.desc.layer_events_host = ctypes.cast(self._layer_events, ctypes.c_void_p)
             try:
-                self._call(_LOSS | _BACKWARD, self.L - 1, 0)
+                self._call(loss0 | _BACKWARD, self.L - 1, 0)
             finally:
                 self.desc.layer_events_host = None
             for i in range(len(self.pieces)):
                 self.reducer.stage_done(i, recorded=True)
             return self.reducer.reduce_in_place()
         for i, (hi, lo) in enumerate(self.pieces):
-            launch('bwd%d' % i, lambda hi=hi, lo=lo, i=i: self._call((_LOSS if i == 0 else 0) | _BACKWARD, hi, lo))
+            launch(('bwd%d' if loss0 else 'bwdx%d') % i, lambda hi=hi, lo=lo, i=i: self._call((loss0 if i == 0 else 0) | _BACKWARD, hi, lo))
             if self.reducer is not None:
                 self.reducer.stage_done(i)
         if self.reducer is not None:
@@ -225,9 +228,10 @@ class DCNMixPairwiseStep(object):
         torch.cuda.synchronize(self.device)
         self._graphs = {}
         cap = torch.cuda.Stream(device=self.device)
-        keys = [('group', lambda: self._call(_GROUP)), ('forward', lambda: self._call(_FORWARD)), ('front', lambda: self._call(_GROUP | _FORWARD))]
+        keys = [('group', lambda: self._call(_GROUP)), ('forward', lambda: self._call(_FORWARD)), ('front', lambda: self._call(_GROUP | _FORWARD | _LOSS))]
         for i, (hi, lo) in enumerate(self.pieces):
             keys.append(('bwd%d' % i, lambda hi=hi, lo=lo, i=i: self._call((_LOSS if i == 0 else 0) | _BACKWARD, hi, lo)))
+            keys.append(('bwdx%d' % i, lambda hi=hi, lo=lo: self._call(_BACKWARD, hi, lo)))      # behind a front piece that holds the loss stage
         stream2, self.desc.stream2 = self.desc.stream2, None      # captured pieces are single-stream (a forked capture replays slowly)
         try:
             with torch.cuda.stream(cap):

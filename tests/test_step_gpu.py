@@ -26,6 +26,7 @@ pytestmark = pytest.mark.gpu
 def _model(dev, B, D, S, N, L, seed, head_gain=40.0):
     from rec_now_amd.layers.dcn_mix_layer import DCNMixLayer
     from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+    torch.manual_seed(seed)                   # the layers' Glorot kernels come from torch's global generator: the same model in every run
     rng = np.random.default_rng(seed)
     x = rng.normal(0.0, 0.7, (B, D)).astype(np.float32)
     groups = rng.integers(0, max(B // 64, 2), B).astype(np.float32)
@@ -299,7 +300,9 @@ def test_small_ragged_batches_through_the_step_vs_oracle(dev, B, D, L):
         loss, n_pair = step.run()
     torch.cuda.synchronize()
     assert int(n_pair.item()) == rP
-    close(step.scores, rs, what='scores')
+    # (a handful of scores: the bound is relative to the tensor's largest magnitude, and ONE score that happens to cancel to ~0.1 while its D
+    #  terms are O(1) made this comparison fail once in a few runs with unseeded weights: scores are O(1) by construction, so that is the scale)
+    close(step.scores, rs, what='scores', scale=max(float(np.abs(rs).max()), 1.0) if B < 32 else None)
     close(loss, np.float64(rloss), what='loss')
     if rP > 0:
         close(step.dx, rdx, what='dx')
