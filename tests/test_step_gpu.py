@@ -147,6 +147,44 @@ def test_step_grouping_from_raw_ids_equals_the_two_call_form(dev, B, kind):
                 assert torch.equal(p.grad, gr)
 
 
+@pytest.mark.parametrize('B', [4096, 12288])
+def test_step_loss_walk_with_long_groups_equals_the_packed_form(dev, B):
+    """The step's loss stage walks the pairs WITHOUT a pack launch (csrc/pairwise.hip k_pair_all<.., UNP>: a workgroup fills its LDS stage from scores /
+    labels / mask through the sorted order), `pairwise_loss` on the packed member array.  A batch with one group beyond the 2048-member stage (its rows'
+    walks gather per member), one long group that fits the stage (a wave per row) and many small ones, a mask on top: the same loss, pair count and
+    gradients bit for bit (the arithmetic and its order are those of the packed form; /root/reference/rec_now/rec_block/pairwise_loss_from_batch.py:228-279)."""
+    from rec_now_amd.fused import dcn_mix_score, score_params
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss
+    from rec_now_amd.step import DCNMixPairwiseStep
+    D, S, N, L = 256, 64, 2, 2
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 31)
+    rng = np.random.default_rng(32)
+    g = groups.copy()
+    perm = rng.permutation(B)
+    g[perm[:2500]] = 1.0e6          # > PW_STAGE members: never staged
+    g[perm[2500:3200]] = 2.0e6      # > PW_LONG, fits the stage
+    gd = torch.from_numpy(g).to(dev)
+    mask = torch.from_numpy(rng.random(B) < 0.9).to(dev)
+    params = score_params(cross, head)
+    for p in params:
+        p.grad = None
+    xr = xd.detach().clone().requires_grad_(True)
+    loss_a, n_a = pairwise_loss(dcn_mix_score(cross, head, xr), yd, gd, mask=mask, return_num_pair=True)
+    loss_a.backward()
+    ref = [p.grad.detach().clone() for p in params]
+    assert int(n_a.item()) > 2500 * 100
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd, mask=mask)
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        loss, n_pair = step.run()
+        torch.cuda.synchronize()
+        assert int(n_pair.item()) == int(n_a.item()) and torch.equal(loss, loss_a.detach()) and torch.equal(step.dx, xr.grad)
+        for p, gr in zip(params, ref):
+            if p is not head.bias:
+                assert torch.equal(p.grad, gr)
+
+
 @pytest.fixture(scope='module')
 def one_rank_rccl(dev):
     import torch.distributed as dist
