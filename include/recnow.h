@@ -453,7 +453,10 @@ int recnow_dcn_mix_score_bwd(const float* x, const float* const* U_host, const f
  *                         gradient of the loss SUM: a data-parallel caller divides by the global pair count after its all-reduce);
  *   RECNOW_STEP_BACKWARD  recnow_dcn_mix_score_bwd for the cross layers layer_hi .. layer_lo (descending; the head's gradients
  *                         belong to layer L-1).  A caller that all-reduces per layer issues one call (one graph) per layer.
- * All of a step's phases must use the same descriptor contents and workspace.  Shapes: recnow_dcn_mix_score_supported. */
+ * All of a step's phases must use the same descriptor contents and workspace.  Shapes: recnow_dcn_mix_score_supported.
+ * Any split of the phases over calls gives the same results; GROUP | FORWARD | LOSS in ONE call is the cheapest form at shard sizes (round 5): the
+ * grouping launch then also writes the row-block kernels' weight packs on its spare workgroups and clears the pair counter, and the pair walk
+ * fills its LDS stages straight from scores / labels / mask (no pack launch, no fill). */
 #define RECNOW_STEP_GROUP 1
 #define RECNOW_STEP_FORWARD 2
 #define RECNOW_STEP_LOSS 4
