@@ -167,9 +167,17 @@ int rn_gemm_set_precision(int mode) {
 }
 
 // products whose B operand the split-precision kernel splits once per launch into global planes (weights: small, L2-resident)
+// (round 6: also the (K, 128) activation operand of the K = B weight-gradient products, [k][n] rows of ldb floats -- each of the eight row-tile
+// workgroups that read a k-tile of it split it again before)
 static inline bool split_planes_shape(const recnow_gemm_desc* d) {
-    return d->sp_r > 0 && d->N == 128 && d->K <= 4096 && d->K % 16 == 0 && d->batch == 1 && !d->a_trans;
+    return d->sp_r > 0 && d->N == 128 && d->K % 16 == 0 && d->batch == 1 && ((!d->a_trans && d->K <= 4096) || (d->a_trans && !d->b_trans));
 }
+
+// short-K products whose packed weights the split-precision short-K kernel splits into planes (K = 144: the ring schedule)
+static inline bool shortk_planes_shape(const recnow_gemm_desc* d) {
+    return d->K == 144 && d->N % 128 == 0 && d->M % 128 == 0 && d->batch == 1 && !d->a_trans && d->sp_r == 0 && d->eu_r == 0;
+}
+static inline void tag_used_split_shortk() {}
 
 // workgroup slots the K split of the NEXT launches of this host thread aims at (0 = the default); see pick_split
 static thread_local int g_split_slots = 0;
@@ -180,6 +188,7 @@ size_t rn_gemm_ws_bytes(const recnow_gemm_desc* d) {
     const GemmCfg c = pick_cfg(d);
     size_t b = rnd_slab_bytes_any(d, c, 256);
     if (split_planes_shape(d)) b += rn_gemm_split_planes_bytes(d->K, d->N);      // whatever the precision mode is when the product runs
+    if (shortk_planes_shape(d) && b < rn_gemm_shortk_planes_bytes(d->K, d->N)) b = rn_gemm_shortk_planes_bytes(d->K, d->N);
     return b;
 }
 
@@ -356,7 +365,13 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     } else if (use_shortk) {
         // C = (A B) [* emul] [+ C] with a short K: persistent kernel, no per-tile prologue, pipelined epilogue (gemm_shortk.hip)
         if (d->c2_mode && d->c2_mode < 5 && ((d->C2 && !host_aligned(d->C2, d->ldc2, 0)) || ((d->c2_mode == 2 || d->c2_mode == 4) && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
-        rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, st);
+        rc = RECNOW_EUNSUPPORTED;
+        static const bool sk_split = []() { const char* e = getenv("RECNOW_SPLIT_SHORTK"); return !e || e[0] != '0'; }();      // A/B switch
+        if (g_gemm_precision == 1 && sk_split && shortk_planes_shape(d) && ws && ws_bytes >= rn_gemm_shortk_planes_bytes(d->K, d->N)) {
+            rc = rn_gemm_launch_shortk_split(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, ws, st);
+            if (rc == RECNOW_OK) tag_used_split_shortk();
+        }
+        if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, st);
         if (rc) return rc;
     } else if (d->c2_mode) {
         return RECNOW_EUNSUPPORTED;          // the second output exists only in the short-K kernel

@@ -13,7 +13,7 @@
 //     row tile go to consecutive workgroups of the SAME XCD, so the A row-panel is fetched into one L2 instead of eight.
 //   * nine-k-tile products (K = 144, DCN-v2) run the RING schedule (NK = 9 below): operands two k-tiles ahead in three rotating
 //     register sets, the k-loop unrolled, every wait an exact count.
-#include "gemm_kernel.hpp"
+#include "gemm_split.hpp"
 
 #define SK_BM 128
 #define SK_BN 128
@@ -41,7 +41,12 @@
 #define SK_LDS4(ptr) (*reinterpret_cast<const f32x4*>(ptr))
 #define SK_STS4(ptr, v) (*reinterpret_cast<f32x4*>(ptr) = (v))
 #endif
-__host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL, bool PRE, int NK = 0) {
+// SPL (round 6): the split-precision form of the ring schedule -- A (fp32, [row][k]) is split into three bf16 pieces on its way into LDS, B comes as
+// piece planes (rn_split_planes of the packed weights, once per launch), a k-tile is six groups of four v_mfma_f32_32x32x16_bf16 (the arithmetic of
+// gemm_split.hip: per-product error <= 2^-25, fp32 accumulation); 216 8-pass MFMAs per wave and tile instead of 260 16-pass ones.  The accumulator
+// layout is the fp32 kernel's, so every epilogue below is shared.  LDS: two stages of 2 x 3 planes (50 688 B): two workgroups per CU.
+__host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL, bool PRE, int NK = 0, bool SPL = false) {
+    if (SPL) return 2;
     return (DUAL >= 4 || PRE || (NK > 0 && DUAL == 2)) ? 2 : (EP == 3 || DUAL == 2 || DUAL == 3 || NK > 0) ? 3 : 4;      // ring schedule: 32 more operand registers
 }
 
@@ -53,15 +58,16 @@ __host__ __device__ constexpr int sk_wg_per_cu(int EP, int DUAL, bool PRE, int N
 // one), every load and LDS write is unconditional (a workgroup without a next tile re-reads its own), and the k-loop is unrolled, so
 // every `s_waitcnt vmcnt` is an exact count.  PRE: the tile of `emul` is requested in four groups at k-tiles 0, 2, 4, 6,
 // each behind that k-tile's ring loads, so no ring wait stands behind a load younger than two k-tiles.
-template <bool B_KC, int EP, int DUAL, bool PRE = false, int NK = 0>
-__global__ void __launch_bounds__(GEMM_THREADS, sk_wg_per_cu(EP, DUAL, PRE, NK))
-k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
+template <bool B_KC, int EP, int DUAL, bool PRE = false, int NK = 0, bool SPL = false>
+__global__ void __launch_bounds__(GEMM_THREADS, sk_wg_per_cu(EP, DUAL, PRE, NK, SPL))
+k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware, const char* __restrict__ b_planes, int64_t b_plane_bytes) {
+    static_assert(!SPL || NK >= 3, "split precision: the ring schedule only");
     static_assert(!PRE || ((EP == 1 || EP == 2) && DUAL != 2 && DUAL != 4), "whole-tile prefetch: emul (EP 1) or the old C (EP 2)");
     static_assert(NK % 3 == 0, "ring schedule: three register sets, the same set holds k-tile 0 of every tile");
     static_assert(!PRE || NK == 0 || NK >= 7, "ring schedule: the four groups of the emul tile go out at k-tiles 0, 2, 4, 6");
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
-    constexpr int A_SZ = SK_BK * TA::LD, B_SZ = SK_BK * TB::LD, BUF = A_SZ + B_SZ;
+    constexpr int A_SZ = SK_BK * TA::LD, B_SZ = SK_BK * TB::LD, BUF = SPL ? SPL_STAGE / 4 : A_SZ + B_SZ;      // floats per LDS stage
     static_assert(4 * 16 * 36 <= BUF, "half sub-tile staging of 4 waves fits one operand buffer");
     extern __shared__ __attribute__((aligned(16))) float smem[];       // [A0 | B0 | A1 | B1]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -124,8 +130,27 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     int m0, n0;
     tile_of(slot, m0, n0);
     // ring schedule: operand registers of the three sets (set s = k-tile % 3)
-    f32x4 ra[NK ? 3 : 1][TA::NV], rb[NK ? 3 : 1][TB::NV];
+    f32x4 ra[NK ? 3 : 1][TA::NV], rb[(NK && !SPL) ? 3 : 1][TB::NV];
+    u32x4 rp[SPL ? 3 : 1][3];           // split precision: the three piece units of B
+    // split precision: this thread's unit (8 consecutive k of one row) of each operand: A (row = tid >> 1, octet = tid & 1: adjacent lanes cover
+    // 64 contiguous bytes of a row), B planes (column = tid & 127, octet = tid >> 7: a wave copies 1 KiB)
+    unsigned sa_bo = (unsigned)(((threadIdx.x >> 1) * p.lda + 8 * (threadIdx.x & 1)) * 4);
+    unsigned sb_bo = (unsigned)((((threadIdx.x >> 7) * p.N) + (threadIdx.x & 127)) * 16);
+    const int sa_soff = ((threadIdx.x & 1) * SPL_PLANE_H + (threadIdx.x >> 1)) * 16;
+    const int sb_soff = SPL_OPER + ((threadIdx.x >> 7) * SPL_PLANE_H + (threadIdx.x & 127)) * 16;
+    const int sfa_off = ((lane >> 5) * SPL_PLANE_H + wm * 64 + (lane & 31)) * 16;
+    const int sfb_off = SPL_OPER + ((lane >> 5) * SPL_PLANE_H + wn * 64 + (lane & 31)) * 16;
     auto ring_load = [&](int set, int mm, int nn, int k0) {
+        if constexpr (SPL) {
+            const char* __restrict__ pa = reinterpret_cast<const char*>(p.A + (int64_t)mm * p.lda + k0);
+            const char* __restrict__ pb = b_planes + ((int64_t)(k0 >> 3) * p.N + nn) * 16;
+            asm volatile("" : "+v"(sa_bo));
+            ra[set][0] = *reinterpret_cast<const f32x4*>(pa + sa_bo);
+            ra[set][1] = *reinterpret_cast<const f32x4*>(pa + sa_bo + 16);
+            asm volatile("" : "+v"(sb_bo));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rp[SPL ? set : 0][q] = *reinterpret_cast<const u32x4*>(pb + q * b_plane_bytes + sb_bo);
+        } else {
         const char* __restrict__ pa = reinterpret_cast<const char*>(p.A + TA::tile_base(p.lda, mm, k0));
         const char* __restrict__ pb = reinterpret_cast<const char*>(p.B + TB::tile_base(p.ldb, nn, k0));
 #pragma unroll
@@ -136,14 +161,26 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
 #pragma unroll
         for (int i = 0; i < TB::NV; ++i) {
             asm volatile("" : "+v"(tb.boff[i]));
-            rb[set][i] = *reinterpret_cast<const f32x4*>(pb + tb.boff[i]);
+            rb[SPL ? 0 : set][i] = *reinterpret_cast<const f32x4*>(pb + tb.boff[i]);
+        }
         }
     };
     auto ring_store = [&](int set, float* S) {
+        if constexpr (SPL) {
+            char* Sc = reinterpret_cast<char*>(S);
+            const float x[8] = {ra[set][0].x, ra[set][0].y, ra[set][0].z, ra[set][0].w, ra[set][1].x, ra[set][1].y, ra[set][1].z, ra[set][1].w};
+            u32x4 w[3];
+            spl_split8(x, w);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(Sc + sa_soff + q * SPL_PLANE) = w[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(Sc + sb_soff + q * SPL_PLANE) = rp[SPL ? set : 0][q];
+        } else {
 #pragma unroll
         for (int i = 0; i < TA::NV; ++i) { ta.v[i] = ra[set][i]; ta.store_slot(i, S); }
 #pragma unroll
-        for (int i = 0; i < TB::NV; ++i) { tb.v[i] = rb[set][i]; tb.store_slot(i, S + A_SZ); }
+        for (int i = 0; i < TB::NV; ++i) { tb.v[i] = rb[SPL ? 0 : set][i]; tb.store_slot(i, S + A_SZ); }
+        }
     };
     if (NK) {
         ring_load(0, m0, n0, 0);
@@ -197,6 +234,25 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
         // the last k-tile of a zero-padded depth (DCN-v2: K = N*S + N = 130 stored as 144 -> 1 pair): the MFMA groups of the padding are
         // skipped behind a scalar branch each (10 % of a tile's MFMAs).  The fragment reads and the schedule of the groups stay as they are.
         auto ktile = [&](int cur, int npairs) {
+            if constexpr (SPL) {       // (the zero padding of the depth holds zeros in both operands: every k-tile runs whole)
+                const char* S = reinterpret_cast<const char*>(smem + cur * BUF);
+                bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        af[q][i] = *reinterpret_cast<const bf16x8*>(S + q * SPL_PLANE + sfa_off + i * 512);
+                        bf[q][i] = *reinterpret_cast<const bf16x8*>(S + q * SPL_PLANE + sfb_off + i * 512);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#define SKS_TERM(SA, SB)                                                                                              \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SA][i], bf[SB][j], acc[i][j], 0, 0, 0);
+                SKS_TERM(0, 0) SKS_TERM(0, 1) SKS_TERM(1, 0) SKS_TERM(1, 1) SKS_TERM(0, 2) SKS_TERM(2, 0)
+#undef SKS_TERM
+                return;
+            }
             const float* as = smem + cur * BUF + a_off;
             const float* bs = smem + cur * BUF + A_SZ + b_off;
             float a0[2], b0[2], a1[2], b1[2];
@@ -395,13 +451,13 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware) {
     if (cu_key >= 0) atomicSub(&p.cu_slots[cu_key], 1);          // thread 0 only (cu_key stays -1 elsewhere)
 }
 
-template <bool B_KC, int EP, int DUAL, bool PRE = false, int NK = 0>
-static int launch_sk(const GemmK& k, hipStream_t st) {
+template <bool B_KC, int EP, int DUAL, bool PRE = false, int NK = 0, bool SPL = false>
+static int launch_sk(const GemmK& k, hipStream_t st, const char* planes = nullptr) {
     using TA = Tile<SK_BM, SK_BK, true>;
     using TB = Tile<SK_BN, SK_BK, B_KC>;
-    constexpr size_t lds = 2 * SK_BK * (size_t)(TA::LD + TB::LD) * sizeof(float);
+    constexpr size_t lds = SPL ? (size_t)2 * SPL_STAGE : 2 * SK_BK * (size_t)(TA::LD + TB::LD) * sizeof(float);
     const int rt = k.M / SK_BM, ct = k.N / SK_BN;
-    const int resident = 256 * sk_wg_per_cu(EP, DUAL, PRE, NK);
+    const int resident = 256 * sk_wg_per_cu(EP, DUAL, PRE, NK, SPL);
     int grid = rt * ct < resident ? rt * ct : resident;
     const int xcd = (rt % 8 == 0 && grid % 8 == 0) ? 1 : 0;
     GemmK kk = k;
@@ -420,9 +476,37 @@ static int launch_sk(const GemmK& k, hipStream_t st) {
         kk.cu_slots = cu_slots;
         kk.stagger_ticks = stagger_us * 100;
     }
-    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL, PRE, NK>), grid, GEMM_THREADS, lds, st, kk, rt, ct, xcd);
+    const int64_t pb = (int64_t)(k.K / 8) * k.N * 16;
+    hipLaunchKernelGGL((k_gemm_shortk<B_KC, EP, DUAL, PRE, NK, SPL>), grid, GEMM_THREADS, lds, st, kk, rt, ct, xcd, planes, pb);
     RN_LAUNCH_CHECK();
     return RECNOW_OK;
+}
+
+size_t rn_gemm_shortk_planes_bytes(int K, int N) { return rn_align((size_t)(K / 8) * N * 16 * 3); }
+
+// Split-precision forms of the six products of the DCN-v2 step (K = 144, ring schedule).  `planes`: rn_gemm_shortk_planes_bytes(K, N) bytes of
+// workspace; the packed weights are split into them first.  RECNOW_EUNSUPPORTED: the caller runs the fp32 kernel.
+int rn_gemm_launch_shortk_split(const GemmK& k, bool b_kc, int ep, int c2_mode, void* planes, hipStream_t st) {
+    if (k.K != 9 * SK_BK || !planes || (int64_t)128 * k.lda >= (1ll << 29)) return RECNOW_EUNSUPPORTED;
+    const bool fwd = !b_kc && ep == 1 && (c2_mode == 0 || c2_mode == 1 || c2_mode == 3);
+    const bool fwd0 = !b_kc && ep == 0 && c2_mode == 0;
+    const bool bwd = b_kc && ((ep == 2 && c2_mode == 0) || (ep == 0 && (c2_mode == 0 || c2_mode == 2 || c2_mode == 4 || c2_mode == 5 || c2_mode == 6)));
+    if (!fwd && !fwd0 && !bwd) return RECNOW_EUNSUPPORTED;
+    int rc = rn_split_planes(k.B, k.ldb, b_kc ? 1 : 0, k.K, k.N, planes, st);
+    if (rc) return rc;
+    const char* pl = (const char*)planes;
+    if (fwd) {      // (no whole-tile prefetch of emul: its 64 registers are the fragments' here)
+        if (c2_mode == 1) return launch_sk<false, 1, 1, false, 9, true>(k, st, pl);
+        if (c2_mode == 3) return launch_sk<false, 1, 3, false, 9, true>(k, st, pl);
+        return launch_sk<false, 1, 0, false, 9, true>(k, st, pl);
+    }
+    if (fwd0) return launch_sk<false, 0, 0, false, 9, true>(k, st, pl);
+    if (ep == 2) return launch_sk<true, 2, 0, false, 9, true>(k, st, pl);
+    if (c2_mode == 2) return launch_sk<true, 0, 2, false, 9, true>(k, st, pl);
+    if (c2_mode == 4) return launch_sk<true, 0, 4, false, 9, true>(k, st, pl);
+    if (c2_mode == 5) return launch_sk<true, 0, 5, false, 9, true>(k, st, pl);
+    if (c2_mode == 6) return launch_sk<true, 0, 6, false, 9, true>(k, st, pl);
+    return launch_sk<true, 0, 0, false, 9, true>(k, st, pl);
 }
 
 // ep: bit 0 = multiply by emul, bit 1 = accumulate into C.  c2_mode: second output (recnow_gemm_desc).  The caller

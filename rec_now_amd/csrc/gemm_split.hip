@@ -15,46 +15,10 @@
 // global planes of the same units by k_split_planes (every one of the 512 workgroups would otherwise split the same tile), the
 // loader then copies units.  Side product (sp_r <= 4 extra columns): fp32 FMAs on the A staging registers at LDS-write time,
 // reduced across the threads that share a row at the end (there is no fp32 image in LDS to read it from).
-#include "gemm_kernel.hpp"
+#include "gemm_split.hpp"
 #include "prof.hpp"
+#include <atomic>
 #include <type_traits>
-
-typedef __bf16 bf16x8 __attribute__((__vector_size__(16)));
-typedef __bf16 bf16x2 __attribute__((__vector_size__(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-#define SPL_BK 16
-#define SPL_PLANE_H 132                                  // 16-byte units per k-half: 128 rows + 4 (the second half starts 64 B
-                                                         //   into the 128-B bank row of the stores: 8-lane store groups of 4 rows x 2 halves tile it)
-#define SPL_PLANE (2 * SPL_PLANE_H * 16)                 // bytes per piece plane
-#define SPL_OPER (3 * SPL_PLANE)                         // bytes per operand and stage
-#define SPL_STAGE (2 * SPL_OPER)
-#define SPL_BX_OFF (2 * SPL_STAGE)                       // side-product weights: ring of 4 k-tiles x 16 k x 4 floats
-#define SPL_BX_RING 4
-#define SPL_LDS (SPL_BX_OFF + SPL_BX_RING * SPL_BK * 4 * 4)
-
-// (u, v) -> three packed bf16 pairs (low half = piece of u, high half = piece of v)
-__device__ __forceinline__ void spl_split2(float u, float v, unsigned& p1, unsigned& p2, unsigned& p3) {
-    bf16x2 h = {(__bf16)u, (__bf16)v};
-    p1 = __builtin_bit_cast(unsigned, h);
-    f32x2 r = {u - __builtin_bit_cast(float, p1 << 16), v - __builtin_bit_cast(float, p1 & 0xffff0000u)};
-    bf16x2 g = {(__bf16)r.x, (__bf16)r.y};
-    p2 = __builtin_bit_cast(unsigned, g);
-    r.x -= __builtin_bit_cast(float, p2 << 16);
-    r.y -= __builtin_bit_cast(float, p2 & 0xffff0000u);
-    bf16x2 f = {(__bf16)r.x, (__bf16)r.y};
-    p3 = __builtin_bit_cast(unsigned, f);
-}
-// eight consecutive k of one row -> one 16-byte unit per piece
-__device__ __forceinline__ void spl_split8(const float (&x)[8], u32x4 (&w)[3]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        unsigned p1, p2, p3;
-        spl_split2(x[2 * e], x[2 * e + 1], p1, p2, p3);
-        w[0][e] = p1; w[1][e] = p2; w[2][e] = p3;
-    }
-}
 
 // B (K x N; [K][N] rows of ldb floats, or [N][K] when b_kc) -> planes[s][K/8][N] units of 8 bf16 (16 B): unit (o, n) of piece s
 // holds piece s of B[8 o .. 8 o + 7][n].  One thread per unit.
@@ -75,6 +39,13 @@ __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ 
     const int64_t ps = total * 16;
 #pragma unroll
     for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(planes + s * ps + u * 16) = w[s];
+}
+
+int rn_split_planes(const float* B, int64_t ldb, int b_kc, int K, int N, void* planes, hipStream_t st) {
+    const int64_t units = (int64_t)(K / 8) * N;
+    hipLaunchKernelGGL(k_split_planes, (unsigned)((units + 255) / 256), 256, 0, st, B, ldb, b_kc ? 1 : 0, K, N, (char*)planes);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
 }
 
 // One fp32 operand's staging registers for ONE k-tile.  Every thread owns exactly one unit = 8 consecutive k (k-half h) of one
@@ -321,7 +292,273 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
     gemm_lean_epilogue<2, 2, 0>(p, acc, smem, m0, n0, wm, wn, lane, wave, z, bidx);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the lean form of the product (k_gemm_s3).  Same arithmetic, tile, LDS image and pipeline depth as k_gemm_split; what the counters
+// and the ISA of k_gemm_split blamed is gone from the k-loop (tools/micro/split3/split3_bench.hip is the stand-alone bench the numbers come from):
+//   * B is ALWAYS piece planes (k_split_planes: weights, and -- new -- the (B, 128) activation operand of the K = B products, split once per launch
+//     instead of by each of the eight row-tile workgroups that read it): the loader copies three 16-byte units per thread and k-tile;
+//   * the side weights (<= 2 extra columns) of the whole k-chunk are staged in LDS once, in front of the loop -- k_gemm_split loaded and stored
+//     them inside the loop under `tid < 16` (a branch around a load: a full vmcnt(0) at its merge) -- and the side product is 16 scalar
+//     FMAs per thread and k-tile on two columns (four packed ones on a padded quad before);
+//   * operand loads take the `global_load v, voff, s[base]` form (block-uniform tile base + an opaque 32-bit per-lane byte offset);
+//   * the last k-tile runs without the (surplus) staging of a tile nobody reads: no weights of zero in the side product.
+// Instructions per MFMA in the k-loop: 4.7 (A alone) / 5.1 (A * A2) against 6.9; one MI355X, GEMM1 shape (65 536 x 1024 x 128 + 2 side columns):
+// 124-127 us -> 98-103 us; [k][row] operand with pre-split B (the dU shape) 95 us.  In-kernel clock under this loop 1.70 GHz (stamped build), MFMAs
+// alone on the same fragments 65 us at 1.78 GHz: the loop holds the matrix pipe 68 % busy at the clock the power budget leaves for bf16 MFMAs.
+// A thread stages one unit (8 consecutive k of one row): [row][k] operands (row = tid >> 1, octet = tid & 1): adjacent lanes cover 64 contiguous
+// bytes of a row (two streams of 32 B per lane at a row stride measured 20 % slower once a second operand doubles the bytes); [k][row] operands
+// (row = tid & 127, octet = tid >> 7): eight dword loads, one per k row (a wave reads 256 contiguous bytes of each).
+#define S3_BX_MAXK 2048                                   // side weights staged per k-chunk: 2 floats per k
+#define S3_LDS(kchunk) (SPL_BX_OFF + (kchunk) * 8)
+template <bool A_KC, int A2K>
+__global__ void __launch_bounds__(GEMM_THREADS, 2)
+k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char spl_smem[];
+    int bx = blockIdx.x, z = blockIdx.z;
+    if (p.xcd_remap == 1) {       // as k_gemm: the row tiles of one k-slab become consecutive workgroups of one XCD
+        const int gx = gridDim.x, lin = bx + gx * z, xcd = lin & 7, i = lin >> 3;
+        z = xcd * ((int)gridDim.z >> 3) + i / gx;
+        bx = i % gx;
+    }
+    const int ks = z;                                      // batch == 1 (the side product belongs to one product)
+    const int k_begin = ks * p.kchunk, k_end = min(p.K, k_begin + p.kchunk);
+    const int m0 = bx * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int nt = (k_end - k_begin) / SPL_BK;             // even, >= 2 (the launcher's check)
+    const int a_row = A_KC ? tid >> 1 : tid & 127;
+    const int a_h = A_KC ? tid & 1 : __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int b_row = tid & 127, b_h = tid >> 7;
+    const unsigned ldau = (unsigned)p.lda;
+    const unsigned a_goff = A_KC ? (unsigned)a_row * ldau + 8u * a_h : 8u * a_h * ldau + (unsigned)a_row;
+    const int a_soff = (a_h * SPL_PLANE_H + a_row) * 16;
+    const int b_soff = SPL_OPER + (b_h * SPL_PLANE_H + b_row) * 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float sp0 = 0.f, sp1 = 0.f;
+    float va[2][8], ya[A2K != RECNOW_OPMODE_NONE ? 2 : 1][8];
+    u32x4 bpl[3], wq[3];
+
+    auto a_base = [&](int t) { return A_KC ? (int64_t)m0 * p.lda + k_begin + t * SPL_BK : (int64_t)(k_begin + t * SPL_BK) * p.lda + m0; };
+    auto clampt = [&](int t) { return min(t, nt - 1); };
+    unsigned a_bo[A_KC ? 1 : 8];
+    a_bo[0] = a_goff * 4u;
+    if (!A_KC) {
+#pragma unroll
+        for (int e = 1; e < 8; ++e) a_bo[A_KC ? 0 : e] = (a_goff + (unsigned)e * ldau) * 4u;
+    }
+    auto a_issue = [&](float (&v)[8], float (&y)[8], int t) {
+        const char* pa = reinterpret_cast<const char*>(p.A + a_base(t));
+        const char* pa2 = reinterpret_cast<const char*>(p.A2 + a_base(t));
+        if (A_KC) {
+            asm volatile("" : "+v"(a_bo[0]));
+            const f32x4 a = *reinterpret_cast<const f32x4*>(pa + a_bo[0]), b = *reinterpret_cast<const f32x4*>(pa + a_bo[0] + 16);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            if (A2K != RECNOW_OPMODE_NONE) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(pa2 + a_bo[0]), d = *reinterpret_cast<const f32x4*>(pa2 + a_bo[0] + 16);
+                y[0] = c.x; y[1] = c.y; y[2] = c.z; y[3] = c.w; y[4] = d.x; y[5] = d.y; y[6] = d.z; y[7] = d.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                asm volatile("" : "+v"(a_bo[A_KC ? 0 : e]));
+                v[e] = *reinterpret_cast<const float*>(pa + a_bo[A_KC ? 0 : e]);
+                if (A2K != RECNOW_OPMODE_NONE) y[e] = *reinterpret_cast<const float*>(pa2 + a_bo[A_KC ? 0 : e]);
+            }
+        }
+    };
+    unsigned b_bo = (unsigned)((b_h * 128 + b_row) * 16);
+    auto b_issue = [&](int t) {
+        const char* src = b_planes + (int64_t)((k_begin + t * SPL_BK) >> 3) * 128 * 16;
+        asm volatile("" : "+v"(b_bo));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) bpl[s] = *reinterpret_cast<const u32x4*>(src + s * b_plane_bytes + b_bo);
+    };
+    auto b_store = [&](char* S) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(S + b_soff + s * SPL_PLANE) = bpl[s];
+    };
+    auto a_combine = [&](float (&v)[8], const float (&y)[8]) {
+        if (A2K == RECNOW_OPMODE_MUL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= y[e];
+        } else if (A2K != RECNOW_OPMODE_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= rn_act_grad_from_out(y[e], p.a_act);
+        }
+    };
+    const float* bxl = reinterpret_cast<const float*>(spl_smem + SPL_BX_OFF);
+    auto a_side = [&](const float (&v)[8], int t) {       // this thread's unit times the two side columns of k-tile t (broadcast reads)
+        const float* b = bxl + (t * SPL_BK + 8 * a_h) * 2;
+        f32x4 q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = *reinterpret_cast<const f32x4*>(b + 4 * e);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sp0 = fmaf(v[2 * e], q[e].x, sp0);
+            sp1 = fmaf(v[2 * e], q[e].y, sp1);
+            sp0 = fmaf(v[2 * e + 1], q[e].z, sp0);
+            sp1 = fmaf(v[2 * e + 1], q[e].w, sp1);
+        }
+    };
+    auto split_pairs = [&](const float (&v)[8], int e0) {
+#pragma unroll
+        for (int e = e0; e < e0 + 2; ++e) {
+            unsigned p1, p2, p3;
+            spl_split2(v[2 * e], v[2 * e + 1], p1, p2, p3);
+            wq[0][e] = p1; wq[1][e] = p2; wq[2][e] = p3;
+        }
+    };
+    auto a_store = [&](char* S) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(S + a_soff + s * SPL_PLANE) = wq[s];
+    };
+
+    // the chunk's side weights -> LDS: bxl[k][0 .. 1] (a missing second column: zeros)
+    for (int i = tid; i < k_end - k_begin; i += GEMM_THREADS) {
+        const float* src = p.bx + (int64_t)(k_begin + i) * p.bx_ks;
+        f32x2 w;
+        w.x = src[0];
+        w.y = p.sp_r > 1 ? src[p.bx_rs] : 0.f;
+        *reinterpret_cast<f32x2*>(spl_smem + SPL_BX_OFF + i * 8) = w;
+    }
+    // prologue: k-tile 0 -> stage 0; A of k-tiles 1 (set 1) and 2 (set 0), B of k-tile 1 requested
+    a_issue(va[0], ya[0], 0);
+    b_issue(0);
+    a_issue(va[1], ya[A2K != RECNOW_OPMODE_NONE ? 1 : 0], clampt(1));
+    __syncthreads();
+    a_combine(va[0], ya[0]);
+    a_side(va[0], 0);
+    split_pairs(va[0], 0);
+    split_pairs(va[0], 2);
+    a_store(spl_smem);
+    b_store(spl_smem);
+    a_issue(va[0], ya[0], clampt(2));
+    b_issue(clampt(1));
+    __syncthreads();
+
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_off[i] = ((lane >> 5) * SPL_PLANE_H + wm * 64 + i * 32 + (lane & 31)) * 16;
+        b_off[i] = SPL_OPER + ((lane >> 5) * SPL_PLANE_H + wn * 64 + i * 32 + (lane & 31)) * 16;
+    }
+#define S3_TERM(SA, SB)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SA][i], bf[SB][j], acc[i][j], 0, 0, 0);
+    // one k-tile: t = its index; SLOT holds A of k-tile t + 1; STG: stage k-tile t + 1 (false: the last k-tile, compute only)
+    auto ktile = [&](int t, auto slot_c, auto stage_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int YS = A2K != RECNOW_OPMODE_NONE ? SLOT : 0;
+        constexpr bool STG = decltype(stage_c)::value;
+        const char* S = spl_smem + (t & 1) * SPL_STAGE;
+        char* Sn = spl_smem + ((t & 1) ^ 1) * SPL_STAGE;
+        bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[s][i] = *reinterpret_cast<const bf16x8*>(S + s * SPL_PLANE + a_off[i]);
+                bf[s][i] = *reinterpret_cast<const bf16x8*>(S + s * SPL_PLANE + b_off[i]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        S3_TERM(0, 0)
+        if (STG) {
+            a_combine(va[SLOT], ya[YS]);
+            split_pairs(va[SLOT], 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        S3_TERM(0, 1)
+        if (STG) {
+            a_side(va[SLOT], t + 1);
+            split_pairs(va[SLOT], 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        S3_TERM(1, 0)
+        if (STG) a_store(Sn);
+        __builtin_amdgcn_sched_barrier(0);
+        S3_TERM(1, 1)
+        if (STG) {
+            a_issue(va[SLOT], ya[YS], clampt(t + 3));
+            b_store(Sn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        S3_TERM(0, 2)
+        if (STG) b_issue(clampt(t + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        S3_TERM(2, 0)
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using BT = std::integral_constant<bool, true>;
+    using BF = std::integral_constant<bool, false>;
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+        ktile(t, I1(), BT());
+        ktile(t + 1, I0(), BT());
+    }
+    ktile(t, I1(), BT());
+    ktile(t + 1, I0(), BF());
+#undef S3_TERM
+
+    // side product: the two threads of a row (its two k-octets): adjacent lanes (KC) or 128 threads apart (through LDS)
+    float* smem = reinterpret_cast<float*>(spl_smem);
+    auto side_out = [&](int m, float s0, float s1) {
+        if (p.splitk > 1) {
+            float* dst = p.partial + ((int64_t)z * p.M + m) * p.npart + p.N;
+            dst[0] = s0;
+            if (p.sp_r > 1) dst[1] = s1;
+        } else {
+            p.cx[(int64_t)m * p.cx_ms] = s0;
+            if (p.sp_r > 1) p.cx[(int64_t)m * p.cx_ms + p.cx_rs] = s1;
+        }
+    };
+    if (A_KC) {
+        sp0 += __shfl_xor(sp0, 1);
+        sp1 += __shfl_xor(sp1, 1);
+        if ((tid & 1) == 0) side_out(m0 + a_row, sp0, sp1);
+    } else {
+        if (tid >= 128) *reinterpret_cast<f32x2*>(smem + (tid - 128) * 2) = f32x2{sp0, sp1};
+        __syncthreads();
+        if (tid < 128) {
+            const f32x2 o = *reinterpret_cast<const f32x2*>(smem + tid * 2);
+            side_out(m0 + tid, sp0 + o.x, sp1 + o.y);
+        }
+        __syncthreads();
+    }
+    gemm_lean_epilogue<2, 2, 0>(p, acc, smem, m0, 0, wm, wn, lane, wave, z, 0);
+}
+
 size_t rn_gemm_split_planes_bytes(int K, int N) { return rn_align((size_t)(K / 8) * N * 16 * 3); }
+
+// Launcher: the (layout, operand kind) combinations of the DCN-v2 step, N = 128 (one column tile: the side product belongs to
+// it).  `planes` != NULL: B is split once into planes there (rn_gemm_split_planes_bytes(K, N) bytes) before the product.
+// RECNOW_EUNSUPPORTED -> the caller runs the fp32 kernel.
+// Lean form (round 6): N = 128, at most two side columns, whole k-chunks of an even number of k-tiles, the chunk's side weights in LDS.
+static bool s3_shape(const GemmK& k, int a2k) {
+    return k.batch == 1 && k.N == 128 && k.sp_r >= 1 && k.sp_r <= 2 && k.kchunk % (2 * SPL_BK) == 0 && k.K % k.kchunk == 0 && k.kchunk <= S3_BX_MAXK &&
+           (a2k == RECNOW_OPMODE_NONE || a2k == RECNOW_OPMODE_MUL) && !k.as_out;
+}
+static std::atomic<int> g_s3_lds_ready[4];      // dynamic-LDS attribute raised per instantiation (the default limit is 64 KB; a chunk of 2048 k needs 66 KB)
+template <bool A_KC, int A2K>
+static int s3_launch(const GemmK& k, const char* planes, int64_t pb, dim3 grid, hipStream_t st, int slot) {
+    const size_t lds = S3_LDS(k.kchunk);
+    if (lds > 64 * 1024 && !g_s3_lds_ready[slot].load(std::memory_order_acquire)) {
+        RN_HIP(hipFuncSetAttribute((const void*)k_gemm_s3<A_KC, A2K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS(S3_BX_MAXK)));
+        g_s3_lds_ready[slot].store(1, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_gemm_s3<A_KC, A2K>), grid, GEMM_THREADS, lds, st, k, planes, pb);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
 
 // Launcher: the (layout, operand kind) combinations of the DCN-v2 step, N = 128 (one column tile: the side product belongs to
 // it).  `planes` != NULL: B is split once into planes there (rn_gemm_split_planes_bytes(K, N) bytes) before the product.
@@ -331,7 +568,15 @@ int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* pl
     // element offsets inside a tile are 32-bit
     if ((int64_t)128 * k.lda >= (1ll << 31) || (int64_t)128 * k.ldb >= (1ll << 31)) return RECNOW_EUNSUPPORTED;
     const int64_t pb = (int64_t)(k.K / 8) * k.N * 16;
-    if (planes && k.batch == 1 && a_kc) {
+    static const bool s3_on = []() { const char* e = getenv("RECNOW_SPLIT_LEAN"); return !e || e[0] != '0'; }();      // A/B switch: 0 = k_gemm_split of rounds 2-5
+    if (planes && s3_on && s3_shape(k, a2k) && (a_kc || !b_kc)) {
+        const int64_t units = (int64_t)(k.K / 8) * k.N;
+        hipLaunchKernelGGL(k_split_planes, (unsigned)((units + 255) / 256), 256, 0, st, k.B, k.ldb, b_kc ? 1 : 0, k.K, k.N, (char*)planes);
+        RN_LAUNCH_CHECK();
+        if (a_kc) return a2k == 0 ? s3_launch<true, 0>(k, (const char*)planes, pb, grid, st, 0) : s3_launch<true, RECNOW_OPMODE_MUL>(k, (const char*)planes, pb, grid, st, 1);
+        return a2k == 0 ? s3_launch<false, 0>(k, (const char*)planes, pb, grid, st, 2) : s3_launch<false, RECNOW_OPMODE_MUL>(k, (const char*)planes, pb, grid, st, 3);
+    }
+    if (planes && k.batch == 1 && a_kc && k.K <= 4096) {
         const int64_t units = (int64_t)(k.K / 8) * k.N;
         hipLaunchKernelGGL(k_split_planes, (unsigned)((units + 255) / 256), 256, 0, st, k.B, k.ldb, b_kc ? 1 : 0, k.K, k.N, (char*)planes);
         RN_LAUNCH_CHECK();
