@@ -82,6 +82,7 @@ CHECK_SCALE = 120.0                   # the parity step's inputs: x * 120 (std 6
 # 1024 / 65 536 terms cancel: the reference's own fp32 arithmetic has the same property), so the bounds are PARITY_TOL / floor; what is measured sits
 # 5-10x inside them (first run: 1.8e-3 at the 1e-3 floor) and is reported per tensor.
 ELEM_GATES = ((1e-3, 1e-2), (1e-2, 1e-3))
+SPLIT_FROM_ROWS = 32768               # --gemm-precision auto: split-precision products from this many rows per GPU (measured: 1.68 vs 1.82 ms at 32 768 rows, 1.10 vs 1.01 at 16 384)
 PARITY_TOL = 1e-5                     # north_star: 1e-5 relative, GPU fp32 against the fp64 oracle (row subset + the full batch)
 
 
@@ -374,9 +375,12 @@ def main():
     ap.add_argument('--hostprof', default=None, help='diagnostic: cProfile the host side of 20 extra (untimed) steps into this file')
     ap.add_argument('--unfused', action='store_true', help='diagnostic: the drop-in composition head(cross(x)) and pairwise_loss(outputs, labels, groups) '
                     'instead of the model-level fused node (rec_now_amd/fused.py) with grouping on a side stream')
-    ap.add_argument('--gemm-precision', choices=['f32', 'bf16x3'], default='f32',
-                    help="arithmetic of the long-K products: 'f32' exact fp32 MFMA (the headline), 'bf16x3' the opt-in split-precision kernels "
-                         '(fp32 operands as three bf16 pieces, six bf16 MFMA terms, fp32 accumulation; same 1e-5 parity bound, not bit-identical)')
+    ap.add_argument('--gemm-precision', choices=['auto', 'f32', 'bf16x3'], default='auto',
+                    help="arithmetic of the 18 products of the step: 'f32' exact fp32 MFMA; 'bf16x3' the split-precision kernels (fp32 operands as three "
+                         "bf16 pieces, six bf16 MFMA terms, fp32 accumulation: per-product error <= 2^-25, same 1e-5 parity gate, not bit-identical); "
+                         "'auto' (default): whichever is faster at this shard size under that gate -- bf16x3 from 32 768 rows per GPU (product route), "
+                         "f32 below (row-block kernels).  The other mode's step time is measured in the same run and reported beside the headline "
+                         "(`exact_f32` / `split_precision` at the end of the JSON line)")
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl', help="process-group backend: 'nccl' (= RCCL over xGMI, the product path); 'gloo' is a "
                     'diagnostic that lets several ranks share one GPU (with --oversubscribe), so that the N > 1 step, reducer and cross-rank gate run with real '
@@ -428,7 +432,6 @@ def main():
     from rec_now_amd.rec_block.pairwise_loss_from_batch import group_rows, pairwise_loss_fused
     lib = _lib.load()
     dp.FORCE_COLLECTIVES = bool(args.force_dist)
-    _lib.call('recnow_set_gemm_precision', 1 if args.gemm_precision == 'bf16x3' else 0)
 
     torch.manual_seed(3)                      # identical replicated weights on every rank
     model = Model()
@@ -447,6 +450,10 @@ def main():
         del xg, gg, yg
     else:
         x, groups, labels = synth_batch(rows, 3, rank)
+    # the arithmetic of the products (see --gemm-precision): chosen from the NOMINAL shard size, so that every rank takes the same mode
+    nominal_rows = rows if args.shard != 'hash' else (args.rows if args.rows is not None else GLOBAL_BATCH // world)
+    precision = args.gemm_precision if args.gemm_precision != 'auto' else ('bf16x3' if nominal_rows >= SPLIT_FROM_ROWS else 'f32')
+    _lib.call('recnow_set_gemm_precision', 1 if precision == 'bf16x3' else 0)
     # rows of every rank (ragged under --shard hash): the whole-job throughput counts all of them, the cross-rank gate slices by them
     rank_rows = [rows]
     if use_dist:
@@ -765,6 +772,33 @@ def main():
                 roofline['exclusive_ms_per_step'] = account['per_step_ms']
                 roofline['exclusive_covered_ms_per_step'] = account['covered_ms_per_step']
                 roofline['exclusive_note'] = account['what']
+    # ---- the OTHER arithmetic, same run, same buffers (untimed by the headline): `exact_f32` beside a split-precision headline and vice versa
+    other = None
+    if pstep is not None and graph is None and not args.no_input_grad:
+        other_mode = 'f32' if precision == 'bf16x3' else 'bf16x3'
+        _lib.call('recnow_set_gemm_precision', 1 if other_mode == 'bf16x3' else 0)
+        for _ in range(max(rewarm, 5)):
+            run_step()
+        sync()
+        c0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        sync()
+        tt = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=dev)
+        if use_dist:
+            if args.backend != 'nccl':
+                tt = tt.cpu()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        o_el = float(tt.item())
+        other = {'gemm_precision': other_mode, 'ms_per_step': o_el * 1e3 / args.steps, 'value': total_rows * args.steps / o_el, 'unit': 'samples/s',
+                 'steps': args.steps, 'route': 'row-block persistent kernels' if pstep.tile_route() else 'one launch per product',
+                 'note': 'the same step on the same buffers with the other arithmetic of the products, timed after the headline (its own warm-up, '
+                         'barrier + synchronize on both sides, max over the ranks); parity of this mode: tests/test_step_gpu.py, tests/test_northstar_gpu.py'}
+        _lib.call('recnow_set_gemm_precision', 1 if precision == 'bf16x3' else 0)
+        for _ in range(2):
+            run_step()
+        sync()
+        mark('other precision mode done')
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rank_ms = [elapsed * 1e3 / args.steps]
     if use_dist:
@@ -917,7 +951,7 @@ def main():
             'scaling': args.scaling if args.rows is None else 'weak',
             'shard': args.shard,
             'vs_baseline': None,
-            'dtype': 'f32' if args.gemm_precision == 'f32' else 'f32 operands as 3 x bf16, bf16 MFMA, f32 accumulate (opt-in, --gemm-precision bf16x3)',
+            'dtype': 'f32' if precision == 'f32' else 'f32 via 3 x bf16 six-term split (bf16 MFMA, f32 accumulate; per-product error <= 2^-25)',
             'data': 'synthetic',
             'config': {'workload': 'configs[2]: dcn_mix_layer (3 cross layers, low-rank 64, 2 experts) + MultiDense(1,1) head + '
                                    'in-batch pairwise (logistic), global B=%d = %s rows on %d GPU(s), 64 fields x 16-dim, ~64 rows/group'
@@ -931,6 +965,8 @@ def main():
                                  + (', replayed from HIP graphs' if use_graph else '') + (', weight-gradient products on a second stream' if two_streams else '')
                                  + (', ragged batch on padded storage (%d -> %d rows)' % (pstep.B, pstep.B_pad) if pstep.B_pad != pstep.B else '')) if use_step else
                                 'fused node dcn_mix_score through autograd + grouping on a side stream' if fused else ('drop-in layers' if args.unfused else 'drop-in layers (fused route not available)'),
+                       'gemm_precision': precision, 'gemm_precision_rule': args.gemm_precision if args.gemm_precision != 'auto' else
+                       'auto: bf16x3 from %d rows per GPU, f32 below (the faster one at each shard size, both under the 1e-5 gate)' % SPLIT_FROM_ROWS,
                        'loss': float(loss.item()), 'host_enqueue_ms_per_step': host_ms, 'untimed_steps': args.warmup + rewarm,
                        'grads_copied_into_buckets': getattr(layerwise, 'last_foreign', None) if layerwise is not None else None},
             'roofline': roofline,
@@ -939,6 +975,8 @@ def main():
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
+        if other is not None:           # (last key of the line: it survives in a tail of the output)
+            out['exact_f32' if other['gemm_precision'] == 'f32' else 'split_precision'] = other
         if use_dist:
             out['rccl_ranks'] = parity['rccl_ranks'] if parity and 'rccl_ranks' in parity else dist.get_world_size()
             out['backend'] = args.backend
@@ -946,6 +984,9 @@ def main():
             if comm is not None:
                 out['comm_exposed_ms'] = comm['comm_exposed_ms']
                 out['comm'] = comm
+        if other is not None:           # keep it the LAST key of the line
+            k = 'exact_f32' if other['gemm_precision'] == 'f32' else 'split_precision'
+            out[k] = out.pop(k)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -702,9 +702,9 @@ int rn_pair_bpr_onepass(const float* scores, const float* labels, const uint8_t*
 // scan_sort.hip; pack != NULL: the launch also writes the weight packs of the row-block kernels on further workgroups (k_front_small / k_front_mid)
 // zero1 / zeroed: a front kernel also clears one 64-bit word (the step's pair counter) and reports it
 int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed);
+                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed, int* packed);
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed);
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed, int* packed);
 
 extern "C" int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
@@ -1479,12 +1479,13 @@ extern "C" int recnow_dcn_mix_step(const recnow_dcn_mix_step_desc* d, int phases
         tl_step_tile_packed = nullptr;
         // (the loss stage of THIS call adds into *n_pair: a front kernel clears it on the way)
         unsigned long long* zero1 = ((phases & RECNOW_STEP_LOSS) && d->n_pair) ? (unsigned long long*)d->n_pair : nullptr;
-        rc = rn_group_small_raw(d->groups, d->group_dtype, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, st, pack, zero1, &npair_zeroed);
+        int packs_written = 0;          // the grouping launch also wrote the row-block kernels' weight packs (only the front kernels do)
+        rc = rn_group_small_raw(d->groups, d->group_dtype, B, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, st, pack, zero1, &npair_zeroed, &packs_written);
         // larger batches: the cooperative launch forms keys and solo flags from the id tensor as well
         if (rc == RECNOW_EUNSUPPORTED)
             rc = rn_group_mid_raw(d->groups, d->group_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, pack, zero1,
-                                  &npair_zeroed);
-        if (rc == RECNOW_OK && pack) tl_step_tile_packed = w.saved;
+                                  &npair_zeroed, &packs_written);
+        if (rc == RECNOW_OK && pack && packs_written) tl_step_tile_packed = w.saved;
         if (rc == RECNOW_EUNSUPPORTED) {
             RN_HIP(hipMemsetAsync(w.solo, 0, (size_t)B, st));
             if ((rc = recnow_group_keys(d->groups, d->group_dtype, B, w.words, w.solo, stream))) return rc;

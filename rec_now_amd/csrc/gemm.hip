@@ -170,7 +170,8 @@ int rn_gemm_set_precision(int mode) {
 // (round 6: also the (K, 128) activation operand of the K = B weight-gradient products, [k][n] rows of ldb floats -- each of the eight row-tile
 // workgroups that read a k-tile of it split it again before)
 static inline bool split_planes_shape(const recnow_gemm_desc* d) {
-    return d->sp_r > 0 && d->N == 128 && d->K % 16 == 0 && d->batch == 1 && ((!d->a_trans && d->K <= 4096) || (d->a_trans && !d->b_trans));
+    static const bool kb = []() { const char* e = getenv("RECNOW_SPLIT_LEAN"); return e && e[0] == '2'; }();      // A/B switch, see rn_gemm_launch_split
+    return d->sp_r > 0 && d->N == 128 && d->K % 16 == 0 && d->batch == 1 && ((!d->a_trans && d->K <= 4096) || (kb && d->a_trans && !d->b_trans));
 }
 
 // short-K products whose packed weights the split-precision short-K kernel splits into planes (K = 144: the ring schedule)

@@ -233,9 +233,12 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware, const 
         // fragment reads and MFMAs of one k-tile in LDS buffer `cur`.  npairs = k-pairs of this k-tile that hold data: all 8, except in
         // the last k-tile of a zero-padded depth (DCN-v2: K = N*S + N = 130 stored as 144 -> 1 pair): the MFMA groups of the padding are
         // skipped behind a scalar branch each (10 % of a tile's MFMAs).  The fragment reads and the schedule of the groups stay as they are.
-        auto ktile = [&](int cur, int npairs) {
+        // split precision: the staging of the next k-tile (register set `nset` -> the free stage Sn: split of A, six 16-byte writes) is cut into
+        // pieces behind the MFMA groups of this one (nset < 0: nothing to stage)
+        auto ktile = [&](int cur, int npairs, int nset = -1, float* Sn = nullptr) {
             if constexpr (SPL) {       // (the zero padding of the depth holds zeros in both operands: every k-tile runs whole)
                 const char* S = reinterpret_cast<const char*>(smem + cur * BUF);
+                char* Sc = reinterpret_cast<char*>(Sn);
                 bf16x8 af[3][2], bf[3][2];
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
@@ -244,12 +247,41 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware, const 
                         af[q][i] = *reinterpret_cast<const bf16x8*>(S + q * SPL_PLANE + sfa_off + i * 512);
                         bf[q][i] = *reinterpret_cast<const bf16x8*>(S + q * SPL_PLANE + sfb_off + i * 512);
                     }
+                u32x4 w[3];
+                const int ns = nset < 0 ? 0 : nset;
+                auto pairs = [&](int e0) {
+                    const float x[4] = {e0 ? ra[ns][1].x : ra[ns][0].x, e0 ? ra[ns][1].y : ra[ns][0].y, e0 ? ra[ns][1].z : ra[ns][0].z, e0 ? ra[ns][1].w : ra[ns][0].w};
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        unsigned p1, p2, p3;
+                        spl_split2(x[2 * e], x[2 * e + 1], p1, p2, p3);
+                        w[0][e0 + e] = p1; w[1][e0 + e] = p2; w[2][e0 + e] = p3;
+                    }
+                };
                 __builtin_amdgcn_sched_barrier(0);
 #define SKS_TERM(SA, SB)                                                                                              \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
                     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SA][i], bf[SB][j], acc[i][j], 0, 0, 0);
-                SKS_TERM(0, 0) SKS_TERM(0, 1) SKS_TERM(1, 0) SKS_TERM(1, 1) SKS_TERM(0, 2) SKS_TERM(2, 0)
+                SKS_TERM(0, 0)
+                if (nset >= 0) pairs(0);
+                __builtin_amdgcn_sched_barrier(0);
+                SKS_TERM(0, 1)
+                if (nset >= 0) pairs(2);
+                __builtin_amdgcn_sched_barrier(0);
+                SKS_TERM(1, 0)
+                if (nset >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(Sc + sa_soff + q * SPL_PLANE) = w[q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                SKS_TERM(1, 1)
+                if (nset >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(Sc + sb_soff + q * SPL_PLANE) = rp[SPL ? ns : 0][q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                SKS_TERM(0, 2) SKS_TERM(2, 0)
 #undef SKS_TERM
                 return;
             }
@@ -349,9 +381,13 @@ k_gemm_shortk(const GemmK p, int row_tiles, int col_tiles, int xcd_aware, const 
                 // is the first one that stands behind them), so the epilogue starts on landed data
                 if (EARLY && t == NK - 3) issue(0, 0);
                 if (ONCE && t == NK - 3) issue5(0, 0);
-                if (t == NK - 1) ktile(cur, p.tail_pairs);
-                else ktile(cur, SK_BK / 2);
-                ring_store((t + 1) % 3, smem + (cur ^ 1) * BUF);
+                if constexpr (SPL) {
+                    ktile(cur, SK_BK / 2, (t + 1) % 3, smem + (cur ^ 1) * BUF);
+                } else {
+                    if (t == NK - 1) ktile(cur, p.tail_pairs);
+                    else ktile(cur, SK_BK / 2);
+                    ring_store((t + 1) % 3, smem + (cur ^ 1) * BUF);
+                }
                 __syncthreads();
             }
         } else {

@@ -569,7 +569,11 @@ int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* pl
     if ((int64_t)128 * k.lda >= (1ll << 31) || (int64_t)128 * k.ldb >= (1ll << 31)) return RECNOW_EUNSUPPORTED;
     const int64_t pb = (int64_t)(k.K / 8) * k.N * 16;
     static const bool s3_on = []() { const char* e = getenv("RECNOW_SPLIT_LEAN"); return !e || e[0] != '0'; }();      // A/B switch: 0 = k_gemm_split of rounds 2-5
-    if (planes && s3_on && s3_shape(k, a2k) && (a_kc || !b_kc)) {
+    // [k][row] operands (the K = B weight-gradient products) with a pre-split activation operand: built and measured in the step -- 103 / 130 us
+    // (A / A * A2) + 18 us for the split of the (B, 128) operand against 111 / 126 us for k_gemm_split, which splits B in every workgroup: the
+    // pre-pass costs what the leaner loop gains, so these products stay on k_gemm_split (RECNOW_SPLIT_LEAN=2 routes them here: A/B switch)
+    static const bool s3_kb = []() { const char* e = getenv("RECNOW_SPLIT_LEAN"); return e && e[0] == '2'; }();
+    if (planes && s3_on && s3_shape(k, a2k) && (a_kc || (!b_kc && s3_kb))) {
         const int64_t units = (int64_t)(k.K / 8) * k.N;
         hipLaunchKernelGGL(k_split_planes, (unsigned)((units + 255) / 256), 256, 0, st, k.B, k.ldb, b_kc ? 1 : 0, k.K, k.N, (char*)planes);
         RN_LAUNCH_CHECK();

@@ -343,7 +343,7 @@ k_lw_norm(const float* __restrict__ dbase, const int32_t* __restrict__ n_valid, 
 }
 struct RnTileFwd;
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed);       // scan_sort.hip
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed, int* packed);       // scan_sort.hip
 extern "C" int recnow_listwise_loss(const void* groups, int key_dtype, const float* labels, const float* logits, const float* weights, int64_t B,
                                     float pos_neg_th, float pad_logit, float* out2, float* dlogits, void* ws, size_t ws_bytes, void* stream) {
     if (B < 0 || !out2) return RECNOW_EINVAL;
@@ -358,7 +358,7 @@ extern "C" int recnow_listwise_loss(const void* groups, int key_dtype, const flo
     const LwLossWs w = lw_loss_carve(ws, B, key_dtype);
     int rc;
     // one float32 / int32 id tensor above the one-workgroup size: keys and solo flags are formed inside the cooperative grouping launch (scan_sort.hip)
-    rc = rn_group_mid_raw(groups, key_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, nullptr, nullptr, nullptr);
+    rc = rn_group_mid_raw(groups, key_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, nullptr, nullptr, nullptr, nullptr);
     if (rc != RECNOW_EUNSUPPORTED) {
         if (rc) return rc;
     } else {

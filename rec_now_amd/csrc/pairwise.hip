@@ -990,7 +990,7 @@ k_pair_norm_grad(const float* __restrict__ d, const unsigned long long* __restri
 }
 struct RnTileFwd;
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed);       // scan_sort.hip
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed, int* packed);       // scan_sort.hip
 extern "C" int recnow_pairwise_loss(const void* groups, int key_dtype, const float* labels, const float* scores, const uint8_t* mask,
                                     int64_t B, int flags, float factor, int reduce_mean, float* loss, int64_t* n_pair, float* out2,
                                     float* dscores, void* ws, size_t ws_bytes, void* stream) {
@@ -1014,7 +1014,7 @@ extern "C" int recnow_pairwise_loss(const void* groups, int key_dtype, const flo
                                           n_pair, w.pair, w.pair_bytes, stream)))
             return rc;
         f |= RECNOW_PAIR_MEMBERS_PACKED;
-    } else if ((rc = rn_group_mid_raw(groups, key_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, nullptr, nullptr, nullptr)) !=
+    } else if ((rc = rn_group_mid_raw(groups, key_dtype, B, w.solo, w.order, w.seg_id, w.seg_first, w.super_id, w.n_seg, w.grp, w.grp_bytes, st, nullptr, nullptr, nullptr, nullptr)) !=
                RECNOW_EUNSUPPORTED) {
         // (one float32 / int32 id tensor: keys and solo flags formed inside the cooperative grouping launch, scan_sort.hip)
         if (rc) return rc;

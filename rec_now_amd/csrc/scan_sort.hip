@@ -1053,7 +1053,8 @@ k_front_mid(const uint32_t* __restrict__ words, uint8_t* __restrict__ solo, int6
 // The grouping of a small batch (B <= 8192) straight from ONE float32 / int32 id tensor in one launch (library-internal: the GROUP phase of
 // recnow_dcn_mix_step).  Returns RECNOW_EUNSUPPORTED for other shapes: the caller then takes recnow_group_keys + recnow_group_segments.
 int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed) {
+                       int32_t* n_seg, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed, int* packed) {
+    if (packed) *packed = 0;            // set only where the launch really wrote the weight packs (a grouping launch without them must not mark them current)
     if (B < 1 || B > GS_MAXB || (dtype != RECNOW_KEY_F32 && dtype != RECNOW_KEY_I32)) return RECNOW_EUNSUPPORTED;
     static std::atomic<bool> raised[64];
     int dev = 0;
@@ -1073,6 +1074,7 @@ int rn_group_small_raw(const void* group, int dtype, int64_t B, int32_t* order, 
             hipLaunchKernelGGL(k_front_small<2>, grid, GS_T, gs_lds_bytes(), st, (const uint32_t*)group, (int)B, order, seg_id, seg_first, super_id, n_seg, *pack, zero1);
         RN_LAUNCH_CHECK();
         if (zeroed) *zeroed = zero1 ? 1 : 0;
+        if (packed) *packed = 1;
         return RECNOW_OK;
     }
     if (dtype == RECNOW_KEY_F32)
@@ -1094,6 +1096,12 @@ static int gm_max_coresident() {
     if (!have[dev]) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_group_mid<2048>, 256, 0) != hipSuccess) per_cu = 0;
+        // ... and of the front kernels, which carry the same barrier among their first G workgroups (their pack workgroups never wait: they end
+        // without looking at the barrier, so residency of the G grouping workgroups is all the barrier needs)
+        int f1 = 0, f2 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&f1, (const void*)k_front_mid<1>, 256, 0) != hipSuccess) f1 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&f2, (const void*)k_front_mid<2>, 256, 0) != hipSuccess) f2 = 0;
+        if (f1 < 1 || f2 < 1) per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         // one workgroup per CU is what the route counts on (the step's GEMMs hold the other slots)
         cached[dev] = per_cu > 0 ? cus : 0;
@@ -1122,7 +1130,8 @@ extern "C" size_t recnow_group_segments_workspace_bytes(int64_t B, int n_words) 
 // kernels (pack != NULL) also clear one 64-bit word for the caller and say so; the other forms leave *zeroed alone.
 static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t B, int n_words, int n_words_first, int32_t* order, int32_t* seg_id,
                          int32_t* seg_first, int32_t* super_id, int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack = nullptr,
-                         unsigned long long* zero1 = nullptr, int* zeroed = nullptr) {
+                         unsigned long long* zero1 = nullptr, int* zeroed = nullptr, int* packed = nullptr) {
+    if (packed) *packed = 0;
     static const bool coop = []() { const char* e = getenv("RECNOW_GROUP_COOP"); return !e || e[0] != '0'; }();      // A/B switch
     if (!coop) return RECNOW_EUNSUPPORTED;
     const int nblk = rn_cdiv(B, RN_TILE);
@@ -1167,6 +1176,7 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
             hipLaunchKernelGGL(k_front_mid<2>, g + RN_FRONT_PACK_WGS, 256, 0, st, words, solo, B, ctl, idx0, idx1, key0, key1, blockhist, headcnt, order, seg_id,
                                seg_first, super_id, n_seg, g, *pack, zero1);
         if (zeroed) *zeroed = zero1 ? 1 : 0;
+        if (packed) *packed = 1;
     } else if (raw == 1 && tile == 4096) GM_LAUNCH(4096, 1);
     else if (raw == 2 && tile == 4096) GM_LAUNCH(4096, 2);
     else if (raw == 1) GM_LAUNCH(2048, 1);
@@ -1184,12 +1194,13 @@ static int rn_group_coop(int raw, const uint32_t* words, uint8_t* solo, int64_t 
 // launch forms keys and solo flags itself -- no fill of `solo`, no key kernel.
 // RECNOW_EUNSUPPORTED: other id types, or a batch beyond the co-resident grid (the caller takes recnow_group_keys + recnow_group_segments).
 int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int32_t* order, int32_t* seg_id, int32_t* seg_first, int32_t* super_id,
-                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed) {
+                     int32_t* n_seg, void* ws, size_t ws_bytes, hipStream_t st, const RnTileFwd* pack, unsigned long long* zero1, int* zeroed, int* packed) {
+    if (packed) *packed = 0;
     static const bool on = []() { const char* e = getenv("RECNOW_GROUP_RAW"); return !e || e[0] != '0'; }();      // A/B switch
     if (!on || B <= GS_MAXB || (dtype != RECNOW_KEY_F32 && dtype != RECNOW_KEY_I32) || !solo || !ws) return RECNOW_EUNSUPPORTED;
     if (ws_bytes < recnow_group_segments_workspace_bytes(B, 1)) return RECNOW_EWORKSPACE;
     return rn_group_coop(dtype == RECNOW_KEY_F32 ? 1 : 2, (const uint32_t*)group, solo, B, 1, 1, order, seg_id, seg_first, super_id, n_seg, ws, ws_bytes, st, pack,
-                         zero1, zeroed);
+                         zero1, zeroed, packed);
 }
 
 extern "C" int recnow_group_segments(const uint32_t* words, const uint8_t* solo, int64_t B, int n_words, int n_words_first,

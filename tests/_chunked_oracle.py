@@ -9,6 +9,26 @@ import numpy as np
 import torch
 
 
+GEMM_PRECISIONS = ('f32', 'bf16x3')      # the two arithmetics of the DCN-v2 products: every north-star parity test holds BOTH to the same 1e-5 bound
+
+
+class gemm_precision:
+    """`with gemm_precision('bf16x3'):` -- the split-precision products (recnow_set_gemm_precision(1): fp32 operands as three bf16 pieces, six bf16
+    MFMA terms, fp32 accumulation) for the block, the exact-fp32 kernels restored behind it."""
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from rec_now_amd import _lib
+        _lib.call('recnow_set_gemm_precision', 1 if self.mode == 'bf16x3' else 0)
+        return self.mode
+
+    def __exit__(self, *exc):
+        from rec_now_amd import _lib
+        _lib.call('recnow_set_gemm_precision', 0)
+        return False
+
+
 def weights64(named):
     """{name: tensor} -> {name: fp64 CPU leaf with requires_grad}."""
     return {k: v.detach().cpu().double().requires_grad_(True) for k, v in named.items()}

@@ -30,9 +30,17 @@ def test_bench_line_fields_and_graph_replay(dev):
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
                 'data', 'config', 'roofline'):
         assert key in eager, key
-    assert eager['n_gpus'] == 1 and eager['steps'] == 2 and eager['vs_baseline'] is None and eager['dtype'] == 'f32'
+    assert eager['n_gpus'] == 1 and eager['steps'] == 2 and eager['vs_baseline'] is None
+    # round 6: the default arithmetic at 65 536 rows is the six-term 3 x bf16 split (same 1e-5 gate); the exact-fp32 step is timed in the same run and
+    # is the LAST key of the line
+    assert eager['config']['gemm_precision'] == 'bf16x3' and eager['dtype'].startswith('f32 via 3 x bf16 six-term split')
+    assert list(eager)[-1] == 'exact_f32' and eager['exact_f32']['gemm_precision'] == 'f32' and eager['exact_f32']['ms_per_step'] > 0
     r = eager['roofline']
-    assert r['bound'] == 'mfma' and 0.3 < r['frac'] < 1.0 and r['unit'] == 'TFLOP/s'
+    assert r['bound'] == 'mfma' and 0.2 < r['frac'] < 1.0 and r['unit'] == 'TFLOP/s'
+    assert abs(r['peak'] - 16 * 157.3 / 6) < 1e-6 and r['kernel'] == 'k_gemm_split'      # the split products' ceiling: dense bf16 peak / 6 terms
+    exact = _bench('--gemm-precision', 'f32')
+    assert exact['dtype'] == 'f32' and list(exact)[-1] == 'split_precision' and exact['roofline']['peak'] == 157.3
+    assert exact['parity']['ok'] and exact['parity_max_rel'] <= 1e-5
     assert eager['parity']['ok'] and eager['parity_max_rel'] <= 1e-5          # in-run parity vs the fp64 subset oracle (north_star tolerance)
     graph = _bench('--graph')
     assert graph['config']['hip_graph'] is True

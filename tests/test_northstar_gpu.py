@@ -14,7 +14,7 @@ import torch
 
 import dense_ref as R
 import pairs_oracle as PO
-from _chunked_oracle import close, run_chunked, weights64
+from _chunked_oracle import GEMM_PRECISIONS, close, gemm_precision, run_chunked, weights64
 
 pytestmark = pytest.mark.gpu
 
@@ -52,15 +52,21 @@ def test_dcn_mix_config3_every_gradient_vs_oracle(dev):
     xd = x.to(dev).requires_grad_(True)
     layer(xd[:256])
     _randomise(layer, 22)
-    y = layer(xd)
-    y.backward(gy.to(dev))
     w64 = weights64(layer.named_weights())
     (ry,), rdx, rgrads = run_chunked(_mix_fwd(w64, L), x, gy, w64, chunk=4096)
-    close(y, ry, what='y')
-    close(xd.grad, rdx, what='dx')
     assert len(rgrads) == 5 * L
-    for name, p in layer.named_weights().items():
-        close(p.grad, rgrads[name], what=name)
+    for prec in GEMM_PRECISIONS:            # exact fp32 MFMA and the six-term 3 x bf16 split: ONE oracle, the same bound
+        xd.grad = None
+        for p in layer.named_weights().values():
+            p.grad = None
+        with gemm_precision(prec):
+            y = layer(xd)
+            y.backward(gy.to(dev))
+            torch.cuda.synchronize()
+        close(y, ry, what='y ' + prec)
+        close(xd.grad, rdx, what='dx ' + prec)
+        for name, p in layer.named_weights().items():
+            close(p.grad, rgrads[name], what=name + ' ' + prec)
 
 
 # (the shard sizes: tests/test_step_gpu.py, through the reducer.  The fused node at the FULL batch is what tests/test_step_gpu.py
@@ -87,31 +93,36 @@ def test_config3_model_drop_in_signature(dev, B, route):
     with torch.no_grad():
         head.kernel.mul_(40.0)          # scores of O(1): pair terms away from the softplus(0) = ln 2 plateau
         head.bias.fill_(0.3)
-    if route == 'fused':
-        assert fused_route_available(cross, head, xd)
-        scores = dcn_mix_score(cross, head, xd)
-    else:
-        scores = head(cross(xd)).reshape(-1)
-    loss, n_pair = pairwise_loss(scores, torch.from_numpy(labels).to(dev), torch.from_numpy(groups).to(dev), return_num_pair=True)
-    loss.backward()
     named = dict(cross.named_weights())
     named['head/kernel'], named['head/bias'] = head.kernel, head.bias
     w64 = weights64(named)
     fwd = _mix_fwd(w64, L, head=True)
     (rs,), _, _ = run_chunked(fwd, torch.from_numpy(x), None, w64, chunk=4096, want_dx=False)
-    close(scores, rs, what='scores')
     assert np.abs(rs).max() > 0.5 and np.abs(rs).std() > 0.05            # not the degenerate all-scores-equal case
     rloss, rds, rP = PO.pairwise_bpr(groups, labels, rs.astype(np.float32))
-    assert int(n_pair.item()) == rP and rP > B
-    assert abs(rloss - np.log(2.0)) > 1e-3
-    close(loss, np.float64(rloss), what='loss')
-    rds_t = torch.from_numpy(rds)
-    _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), rds_t, w64, chunk=4096)
-    close(xd.grad, rdx, what='dx')
-    for name, p in named.items():
-        # d loss / d head bias = sum_i dscore_i, which is 0 in exact arithmetic (every pair adds +t to one row and -t to another):
-        # its error is measured against the magnitude of the terms that cancel
-        close(p.grad, rgrads[name], what=name, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+    assert rP > B and abs(rloss - np.log(2.0)) > 1e-3
+    _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), torch.from_numpy(rds), w64, chunk=4096)
+    for prec in GEMM_PRECISIONS:            # both arithmetics of the products against the ONE oracle evaluation above
+        xd.grad = None
+        for p in named.values():
+            p.grad = None
+        with gemm_precision(prec):
+            if route == 'fused':
+                assert fused_route_available(cross, head, xd)
+                scores = dcn_mix_score(cross, head, xd)
+            else:
+                scores = head(cross(xd)).reshape(-1)
+            loss, n_pair = pairwise_loss(scores, torch.from_numpy(labels).to(dev), torch.from_numpy(groups).to(dev), return_num_pair=True)
+            loss.backward()
+            torch.cuda.synchronize()
+        close(scores, rs, what='scores ' + prec)
+        assert int(n_pair.item()) == rP
+        close(loss, np.float64(rloss), what='loss ' + prec)
+        close(xd.grad, rdx, what='dx ' + prec)
+        for name, p in named.items():
+            # d loss / d head bias = sum_i dscore_i, which is 0 in exact arithmetic (every pair adds +t to one row and -t to another):
+            # its error is measured against the magnitude of the terms that cancel
+            close(p.grad, rgrads[name], what=name + ' ' + prec, scale=np.abs(rds).sum() if name == 'head/bias' else None)
 
 
 def test_config2_pairwise_literal_case(dev):

@@ -17,7 +17,7 @@ import pytest
 import torch
 
 import pairs_oracle as PO
-from _chunked_oracle import close, run_chunked, weights64
+from _chunked_oracle import GEMM_PRECISIONS, close, gemm_precision, run_chunked, weights64
 from test_northstar_gpu import _mix_fwd, _randomise
 
 pytestmark = pytest.mark.gpu
@@ -224,13 +224,15 @@ def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B, two_stream
     rloss, rds, rP = PO.pairwise_bpr(groups, labels, rs.astype(np.float32))
     assert rP > B and abs(rloss - np.log(2.0)) > 1e-3
     _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), torch.from_numpy(rds), w64, chunk=4096)
-    for mode in ('eager', 'graph'):
+    # 'eager split': the same step with the split-precision products (at these sizes the product route: the row-block kernels are exact-fp32 only)
+    for mode in ('eager', 'eager split', 'graph'):
         if mode == 'graph':
             step.capture()
         for f in reducer._flat:
             f.fill_(float('nan'))
-        loss, p_glob = step.run() if mode == 'eager' else step.replay()
-        torch.cuda.synchronize()
+        with gemm_precision('bf16x3' if mode == 'eager split' else 'f32'):
+            loss, p_glob = step.replay() if mode == 'graph' else step.run()
+            torch.cuda.synchronize()
         assert int(p_glob.item()) == rP and int(step.n_pair.item()) == rP, mode
         close(step.scores, rs, what='scores ' + mode)
         close(loss, np.float64(rloss), what='loss ' + mode)
@@ -256,17 +258,19 @@ def test_step_route_at_the_metric_batch_vs_oracle(dev):
     rloss, rds, rP = PO.pairwise_bpr(groups, labels, rs.astype(np.float32), grouped=True)
     assert rP > B and abs(rloss - np.log(2.0)) > 1e-3
     _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), torch.from_numpy(rds), w64, chunk=4096)
-    for f in step.grads:
-        f.fill_(float('nan'))
-    step.dx.fill_(float('nan'))
-    loss, n_pair = step.run()
-    torch.cuda.synchronize()
-    assert int(n_pair.item()) == rP
-    close(step.scores, rs, what='scores')
-    close(loss, np.float64(rloss), what='loss')
-    close(step.dx, rdx, what='dx')
-    for name, p in named.items():
-        close(p.grad, rgrads[name], what=name, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+    for prec in GEMM_PRECISIONS:            # the exact-fp32 products and the six-term split (bench.py's default at this size): one oracle, one bound
+        for f in step.grads:
+            f.fill_(float('nan'))
+        step.dx.fill_(float('nan'))
+        with gemm_precision(prec):
+            loss, n_pair = step.run()
+            torch.cuda.synchronize()
+        assert int(n_pair.item()) == rP
+        close(step.scores, rs, what='scores ' + prec)
+        close(loss, np.float64(rloss), what='loss ' + prec)
+        close(step.dx, rdx, what='dx ' + prec)
+        for name, p in named.items():
+            close(p.grad, rgrads[name], what=name + ' ' + prec, scale=np.abs(rds).sum() if name == 'head/bias' else None)
 
 
 def _oracle_step(x, groups, labels, cross, head, L, grouped=True):
@@ -306,16 +310,18 @@ def test_ragged_batches_on_the_fast_route_vs_oracle(dev, one_rank_rccl, B, reduc
         f.fill_(float('nan'))
     step._dx_store.fill_(float('nan'))
     step._scores_store.fill_(float('nan'))
-    for rep in range(2):                  # twice: the second step runs on the storage the first one left (padding rows still zero)
-        loss, p_glob = step.run()
-    torch.cuda.synchronize()
-    assert int(p_glob.item()) == rP and int(step.n_pair.item()) == rP
-    close(step.scores, rs, what='scores')
-    close(loss, np.float64(rloss), what='loss')
-    div = (np.float32(rP) + np.float32(1e-10)) if reduced else np.float32(1.0)      # under a reducer dx is the loss SUM's gradient
-    close(step.dx / div, rdx, what='dx')
-    for name, p in named.items():
-        close(p.grad, rgrads[name], what=name, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+    for prec in GEMM_PRECISIONS:
+        with gemm_precision(prec):
+            for rep in range(2):                  # twice: the second step runs on the storage the first one left (padding rows still zero)
+                loss, p_glob = step.run()
+            torch.cuda.synchronize()
+        assert int(p_glob.item()) == rP and int(step.n_pair.item()) == rP
+        close(step.scores, rs, what='scores ' + prec)
+        close(loss, np.float64(rloss), what='loss ' + prec)
+        div = (np.float32(rP) + np.float32(1e-10)) if reduced else np.float32(1.0)      # under a reducer dx is the loss SUM's gradient
+        close(step.dx / div, rdx, what='dx ' + prec)
+        for name, p in named.items():
+            close(p.grad, rgrads[name], what=name + ' ' + prec, scale=np.abs(rds).sum() if name == 'head/bias' else None)
     # the padding: x rows stay zero, their dx is exactly zero, their scores are the head bias
     assert not step._x_store[B:].any() and not step._dx_store[B:].any()
     assert torch.equal(step._scores_store[B:], torch.full_like(step._scores_store[B:], float(head.bias.reshape(-1)[0])))
@@ -408,3 +414,41 @@ def test_gradient_accumulation_onto_bucket_views(dev):
     torch.cuda.synchronize()
     for p, g1 in zip(params, once):
         close(p.grad, 2.0 * g1, rtol=1e-6, what='accumulated gradient')
+
+
+_TILE4096_CHILD = r'''
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/tests'); sys.path.insert(0, %(root)r + '/oracle')
+from test_step_gpu import _model
+from rec_now_amd.step import DCNMixPairwiseStep
+dev = torch.device('cuda:0')
+x, groups, labels, xd, yd, gd, cross, head = _model(dev, 16384, 256, 64, 2, 2, 77)
+step = DCNMixPairwiseStep(cross, head, xd, yd, gd)
+assert step.tile_route()
+for _ in range(2):
+    loss, n_pair = step.run()
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for t in [loss, step.scores, step.dx] + list(step.grads):
+    h.update(t.detach().cpu().numpy().tobytes())
+print('DIGEST', h.hexdigest(), int(n_pair.item()))
+'''
+
+
+def test_grouping_tile_without_a_front_kernel_does_not_mark_the_weight_packs_current(dev):
+    """ADVICE round 5 (medium): with RECNOW_GROUP_TILE=4096 the cooperative grouping of a 16 384-row shard runs WITHOUT the front kernel's pack workgroups;
+    the GROUP phase must then not mark the row-block kernels' weight packs as written (the forward would skip its pack launch and run on stale or
+    uninitialised packs).  Two child processes (the switches are read once per process): that setting against RECNOW_STEP_FRONT=0 (the pack as a launch
+    of its own) -- loss, scores, d loss / d x and every gradient bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for extra in ({'RECNOW_GROUP_TILE': '4096'}, {'RECNOW_STEP_FRONT': '0'}):
+        env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+        env.update(extra)
+        out = subprocess.run([sys.executable, '-c', _TILE4096_CHILD % {'root': root}], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith('DIGEST')][-1])
+    assert digests[0] == digests[1], digests
