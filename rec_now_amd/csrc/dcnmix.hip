@@ -167,6 +167,19 @@ static inline bool mix_tile_shape(const MixDims& m) {
 }
 static inline size_t mix_tile_pack_bytes(const MixDims& m) { return mix_tile_shape(m) ? rn_mix_tile_pack_bytes(m.D, m.S, m.N, m.L, m.LDT) : 0; }
 static inline size_t mix_tile_pack_off(const MixDims& m) { return mix_pack_off(m) + mix_pack_bytes(m); }
+// Round 6: the split-precision piece planes of the packed weights, behind the tile packs: per layer P1 ([U | K] as the B operand of GEMM1),
+// P2 ([W; b] of the product that leaves the layer), P3 (W^T -- or the fused head's W * w_head -- of the dT2g product), P4 ([U | K]^T of the
+// product that forms g_{l-1}); written ONCE per step by the forward (rn_split_planes_multi behind k_pack_all) instead of by a split launch in
+// front of each of the 12 products that read them.
+static inline bool mix_planes_shape(const MixDims& m) { return m.exact && m.L <= MIX_PACK_MAX_L && 4 * m.L <= RN_SPLIT_MAX_JOBS && m.NS == 128 && m.KP == 144; }
+static inline size_t mix_plane_long(const MixDims& m) { return rn_gemm_split_planes_bytes(m.D, 128); }
+static inline size_t mix_plane_short(const MixDims& m) { return rn_gemm_split_planes_bytes(m.KP, m.D); }
+static inline size_t mix_planes_bytes(const MixDims& m) { return mix_planes_shape(m) ? (size_t)m.L * 2 * (mix_plane_long(m) + mix_plane_short(m)) : 0; }
+static inline size_t mix_planes_off(const MixDims& m) { return mix_tile_pack_off(m) + mix_tile_pack_bytes(m); }
+static inline char* mix_plane(const MixDims& m, const void* saved, int l, int which) {      // which: 0 = P1, 1 = P2, 2 = P3, 3 = P4
+    char* base = (char*)saved + mix_planes_off(m) + (size_t)l * 2 * (mix_plane_long(m) + mix_plane_short(m));
+    return base + (which == 0 ? 0 : which == 1 ? mix_plane_long(m) : which == 2 ? mix_plane_long(m) + mix_plane_short(m) : 2 * mix_plane_long(m) + mix_plane_short(m));
+}
 // `maybe`: everything but the precision mode -- what a backward pass uses to decide whether the forward that filled `saved` MAY have run the
 // row-block kernels (and left the product-route weight packs out), whatever the precision switch says by now
 // Set by the GROUP phase of recnow_dcn_mix_step when its front kernel has written the tile packs of THIS call's weights into `saved`; taken (and cleared)
@@ -193,7 +206,7 @@ static bool mix_tile_bwd_on(const MixDims& m) {
 // what it packed under the address of `saved` (host side: a stamp inside the device buffer could not be read back without a synchronisation); the
 // backward packs what is missing for the route it takes, and the lower pieces of a backward cut into layer ranges follow the top piece.  A buffer
 // this process has no record of (filled through another copy of the library, or 256 forwards ago) is "unknown": the backward then packs for itself.
-enum { MIX_HAS_PRODUCT_PACKS = 1, MIX_HAS_TILE_PACKS = 2, MIX_BWD_TILE = 4 };
+enum { MIX_HAS_PRODUCT_PACKS = 1, MIX_HAS_TILE_PACKS = 2, MIX_BWD_TILE = 4, MIX_HAS_SPLIT_PLANES = 8, MIX_PLANES_HEAD = 16 };      // (.._HEAD: the top layer's P3 holds W * w_head)
 struct MixStamp { const void* sv; int bits; };
 static std::mutex g_mix_stamp_mu;
 static MixStamp g_mix_stamps[256];
@@ -218,7 +231,7 @@ extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int
     const MixDims m = mix_dims(B, D, S, N, L);
     // exact path: O_l = T2g_l [W; b] of every layer is kept next to x_{l+1} = x * O_l (second output of GEMM3), so the
     // backward forms dx = sum_l g_l * O_l inside kernels that stream g_l anyway instead of recomputing the products.
-    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + mix_pack_bytes(m) + mix_tile_pack_bytes(m) + 256;
+    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + mix_pack_bytes(m) + mix_tile_pack_bytes(m) + mix_planes_bytes(m) + 256;
 }
 
 // Round 4: x_{l+1} = x0 * O_l is NOT materialised between the cross layers of the exact path (two experts).  The product that leaves layer l
@@ -542,7 +555,26 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
             return rc;
         rn_prof_end(pr_pack, st);
     }
-    mix_stamp_put(saved, (pack_product ? MIX_HAS_PRODUCT_PACKS : 0) | (tile_fwd ? MIX_HAS_TILE_PACKS : 0));
+    // split precision: the piece planes of every layer's packed weights, one launch (RECNOW_SPLIT_PLANES_ONCE=0: each product splits its own, A/B switch)
+    static const bool planes_once = []() { const char* e = getenv("RECNOW_SPLIT_PLANES_ONCE"); return !e || e[0] != '0'; }();
+    const bool planes_on = planes_once && pack_product && rn_gemm_precision() == 1 && mix_planes_shape(m);
+    if (planes_on) {
+        RnSplitJobs jobs;
+        jobs.n = 0;
+        for (int l = 0; l < L; ++l) {
+            const float* wc1 = Wc1_all + (size_t)l * D * m.LDT;
+            const float* wc2 = Wc2_all + (size_t)l * m.LDT * D;
+            jobs.job[jobs.n++] = RnSplitJob{wc1, m.LDT, 0, D, 128, mix_plane(m, saved, l, 0)};
+            jobs.job[jobs.n++] = RnSplitJob{wc2, D, 0, m.KP, D, mix_plane(m, saved, l, 1)};
+            jobs.job[jobs.n++] = RnSplitJob{(head && l == L - 1) ? Wh_saved : W_host[l], D, 1, D, 128, mix_plane(m, saved, l, 2)};
+            jobs.job[jobs.n++] = RnSplitJob{wc1, m.LDT, 1, m.KP, D, mix_plane(m, saved, l, 3)};
+        }
+        RnProfRecord* pr_pl = rn_prof_on() ? rn_prof_begin(RN_TAG_LAYER_END, 0.0, 0.0, st) : nullptr;
+        rc = rn_split_planes_multi(jobs, st);
+        rn_prof_end(pr_pl, st);
+        if (rc) return rc;
+    }
+    mix_stamp_put(saved, (pack_product ? MIX_HAS_PRODUCT_PACKS : 0) | (tile_fwd ? MIX_HAS_TILE_PACKS : 0) | (planes_on ? MIX_HAS_SPLIT_PLANES | (head ? MIX_PLANES_HEAD : 0) : 0));
     const float* xl = x;
     const bool xless = mix_xless(m);
     if (tile_fwd) {       // every layer (+ the scoring head) in one launch of row-block workgroups
@@ -612,6 +644,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 d.sp_bx = gate_host[l]; d.sp_bx_ks = N; d.sp_bx_rs = 1; d.sp_cx = T1 + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
                 // a shard small enough for this product to be split over K: the sub-space kernel sums the slabs (and applies act_inner)
                 // on its way in -- no reduction launch
+                if (planes_on && !d.A2) rn_gemm_planes_hint(mix_plane(m, saved, l, 0));
                 if (absorb) rc = rn_gemm_deferred(&d, gws, gws_bytes, st, &red1);
                 else rc = rn_gemm(&d, gws, gws_bytes, st);
                 if (rc) return rc;
@@ -649,6 +682,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                     d.C = omid + (size_t)l * (xbuf(m) / sizeof(float));      // not written (c2_mode 3); a valid aligned address for the checks
                     d.hv = head->w; d.hp = hp; d.hp_ld = 2 * (D / 128);
                 }
+                if (planes_on) rn_gemm_planes_hint(mix_plane(m, saved, l, 1));
                 if ((rc = rn_gemm(&d, gws, gws_bytes, st))) return rc;
                 if (head && l == L - 1) {
                     hipLaunchKernelGGL(k_head_scores, ew_grid(B), 256, 0, st, hp, 2 * (D / 128), head->b, B, head->scores);
@@ -1009,6 +1043,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
             RN_LAUNCH_CHECK();
         }
     }
+    // split precision: the forward of this pass left the piece planes of the packed weights in `saved` (and nothing repacked them since)
+    const bool planes_bwd = rn_gemm_precision() == 1 && have >= 0 && (have & MIX_HAS_SPLIT_PLANES) && (have & MIX_HAS_PRODUCT_PACKS) && mix_planes_shape(m);
     const float* T2g_ds = dC;          // fused head: dscore * T2g of the top layer (dC is scratch of the unfused sub-space route only)
     if (hd && top) {
         const float* T2g_top = (const float*)(sv + (size_t)(3 * (L - 1) + 2) * act_block(m));
@@ -1085,6 +1121,8 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
                 d.as_out = dx;
             }
             // split over K at small shards: the sub-space kernel sums the slabs on its way in (no reduction launch)
+            // (split precision: the planes of W^T / W * w_head that the forward left; the head's variant only behind a forward that had the head)
+            if (planes_bwd && (l < L - 1 || ((hd != nullptr) == ((have & MIX_PLANES_HEAD) != 0)))) rn_gemm_planes_hint(mix_plane(m, sv, l, 2));
             if (absorb_bwd) rc = rn_gemm_deferred(&d, gws, gemm_ws, st, &red_t2g);
             else rc = rn_gemm(&d, gws, gemm_ws, st);
             if (rc) return rc;
@@ -1138,6 +1176,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
                 d.E3 = omid + (size_t)l * (xbuf(m) / sizeof(float)); d.lde3 = D; d.rv = hd->dscores; d.cv = hd->w;
             }
             }
+            if (planes_bwd) rn_gemm_planes_hint(mix_plane(m, sv, l, 3));
             if ((rc = rn_gemm(&d, gws, gemm_ws, st))) return rc;
         }
         if (l > 0) MIX_SIGNAL(e_g, st);

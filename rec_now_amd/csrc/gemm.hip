@@ -146,6 +146,7 @@ k_layer_end_reduce(const GemmK pa, int va, int na, const GemmK pb, int vb, int n
 // ---- host dispatch -------------------------------------------------------------------------------------
 // (tile family, small-M rule and K split: gemm_dispatch.hpp, host-only so that it also builds under the CPU sanitizers)
 #include "gemm_dispatch.hpp"
+#include "gemm_split.hpp"
 int rn_gemm_precision();
 static inline RnDispatchEnv dispatch_env() {
     static const int bm64 = []() { const char* e = getenv("RECNOW_GEMM_BM64"); return e ? atoi(e) : 256; }();        // A/B: 0 = off, N = tile bound
@@ -215,7 +216,12 @@ static bool gemm_interior(const recnow_gemm_desc* d, const GemmCfg& c, int bk, i
 }
 
 static_assert(sizeof(GemmK) <= sizeof(((RnDeferredReduce*)nullptr)->k), "RnDeferredReduce::k holds a GemmK");
+static thread_local const void* tl_planes_hint = nullptr;
+void rn_gemm_planes_hint(const void* planes) { tl_planes_hint = planes; }
+
 static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st, RnDeferredReduce* defer) {
+    const void* planes_ready = tl_planes_hint;      // (for THIS call only)
+    tl_planes_hint = nullptr;
     if (defer) defer->valid = 0;
     if (!d || d->M < 0 || d->N < 0 || d->K < 0 || d->batch < 0) return RECNOW_EINVAL;
     if (d->M == 0 || d->N == 0 || d->batch == 0) return RECNOW_OK;
@@ -351,7 +357,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
                 const size_t used = k.splitk > 1 ? rn_align((size_t)k.splitk * d->batch * d->M * k.npart * sizeof(float)) : 0;
                 if (ws && ws_bytes >= used + rn_gemm_split_planes_bytes(d->K, d->N)) planes = (char*)ws + used;
             }
-            rc = rn_gemm_launch_split(k, a_kc, b_kc, d->a_mode, planes, grid, st);
+            rc = rn_gemm_launch_split(k, a_kc, b_kc, d->a_mode, planes, grid, st, planes_ready);
         }
         static const bool sp_narrow = []() { const char* e = getenv("RECNOW_SP_NARROW"); return !e || e[0] != '0'; }();      // A/B switch
         if (d->mid_V) rc = rn_gemm_launch_lean128x(k, a_kc, b_kc, 32, 0, d->b_mode, 25, grid, st);      // XF 16 | 8 | 1: the fused sub-space forward
@@ -368,8 +374,8 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
         if (d->c2_mode && d->c2_mode < 5 && ((d->C2 && !host_aligned(d->C2, d->ldc2, 0)) || ((d->c2_mode == 2 || d->c2_mode == 4) && !host_aligned(d->E2, d->lde2, 0)))) return RECNOW_EUNSUPPORTED;
         rc = RECNOW_EUNSUPPORTED;
         static const bool sk_split = []() { const char* e = getenv("RECNOW_SPLIT_SHORTK"); return !e || e[0] != '0'; }();      // A/B switch
-        if (g_gemm_precision == 1 && sk_split && shortk_planes_shape(d) && ws && ws_bytes >= rn_gemm_shortk_planes_bytes(d->K, d->N)) {
-            rc = rn_gemm_launch_shortk_split(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, ws, st);
+        if (g_gemm_precision == 1 && sk_split && shortk_planes_shape(d) && (planes_ready || (ws && ws_bytes >= rn_gemm_shortk_planes_bytes(d->K, d->N)))) {
+            rc = rn_gemm_launch_shortk_split(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, ws, st, planes_ready);
             if (rc == RECNOW_OK) tag_used_split_shortk();
         }
         if (rc == RECNOW_EUNSUPPORTED) rc = rn_gemm_launch_shortk(k, b_kc, (d->emul ? 1 : 0) | (d->accumulate ? 2 : 0), d->c2_mode, st);

@@ -27,6 +27,17 @@ int rn_layer_end_reduce(const RnDeferredReduce* a, const RnDeferredReduce* b, co
 int rn_gemm_precision();
 int rn_gemm_set_precision(int mode);
 
+// Split-precision piece planes (gemm_split.hip).  rn_split_planes_multi: the B operands of several products in ONE launch (the packed weights
+// of every cross layer, once per step); planes of one job: rn_gemm_split_planes_bytes(K, N) bytes, layout [piece][K / 8][N] units of 8 bf16.
+#define RN_SPLIT_MAX_JOBS 16
+struct RnSplitJob { const float* B; int64_t ldb; int b_kc, K, N; char* planes; };
+struct RnSplitJobs { RnSplitJob job[RN_SPLIT_MAX_JOBS]; int n; };
+int rn_split_planes_multi(const RnSplitJobs& jobs, hipStream_t st);
+size_t rn_gemm_split_planes_bytes(int K, int N);
+// The next rn_gemm / rn_gemm_deferred call of THIS host thread finds the piece planes of its B operand at `planes` (the layout and size its own
+// split would write) and skips that split; consumed (or dropped) by that one call.
+void rn_gemm_planes_hint(const void* planes);
+
 static inline recnow_gemm_desc rn_gemm_desc_zero() {
     recnow_gemm_desc d;
     memset(&d, 0, sizeof(d));

@@ -1050,9 +1050,9 @@ static inline void rn_gemm_launch_one(const GemmK& k, dim3 grid, hipStream_t st)
 int rn_gemm_launch_lean128x(const GemmK& k, bool a_kc, bool b_kc, int bk, int a2k, int b2k, int xf, dim3 grid, hipStream_t st);
 int rn_gemm_launch_lean64x(const GemmK& k, bool a_kc, bool b_kc, int a2k, int b2k, int xf, dim3 grid, hipStream_t st);
 // split-precision (bf16x3) 128x128 kernel, k-tiles of 16 (gemm_split.hip)
-int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* planes, dim3 grid, hipStream_t st);
+int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* planes, dim3 grid, hipStream_t st, const void* ready = nullptr);
 size_t rn_gemm_split_planes_bytes(int K, int N);
-int rn_gemm_launch_shortk_split(const GemmK& k, bool b_kc, int ep, int c2_mode, void* planes, hipStream_t st);
+int rn_gemm_launch_shortk_split(const GemmK& k, bool b_kc, int ep, int c2_mode, void* planes, hipStream_t st, const void* ready = nullptr);
 size_t rn_gemm_shortk_planes_bytes(int K, int N);
 // persistent short-K kernel (gemm_shortk.hip): ep = (emul ? 1 : 0) | (accumulate ? 2 : 0)
 int rn_gemm_launch_shortk(const GemmK& k, bool b_kc, int ep, int c2_mode, hipStream_t st);

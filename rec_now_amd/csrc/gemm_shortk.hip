@@ -522,15 +522,17 @@ size_t rn_gemm_shortk_planes_bytes(int K, int N) { return rn_align((size_t)(K / 
 
 // Split-precision forms of the six products of the DCN-v2 step (K = 144, ring schedule).  `planes`: rn_gemm_shortk_planes_bytes(K, N) bytes of
 // workspace; the packed weights are split into them first.  RECNOW_EUNSUPPORTED: the caller runs the fp32 kernel.
-int rn_gemm_launch_shortk_split(const GemmK& k, bool b_kc, int ep, int c2_mode, void* planes, hipStream_t st) {
-    if (k.K != 9 * SK_BK || !planes || (int64_t)128 * k.lda >= (1ll << 29)) return RECNOW_EUNSUPPORTED;
+int rn_gemm_launch_shortk_split(const GemmK& k, bool b_kc, int ep, int c2_mode, void* planes, hipStream_t st, const void* ready) {
+    if (k.K != 9 * SK_BK || (!planes && !ready) || (int64_t)128 * k.lda >= (1ll << 29)) return RECNOW_EUNSUPPORTED;
     const bool fwd = !b_kc && ep == 1 && (c2_mode == 0 || c2_mode == 1 || c2_mode == 3);
     const bool fwd0 = !b_kc && ep == 0 && c2_mode == 0;
     const bool bwd = b_kc && ((ep == 2 && c2_mode == 0) || (ep == 0 && (c2_mode == 0 || c2_mode == 2 || c2_mode == 4 || c2_mode == 5 || c2_mode == 6)));
     if (!fwd && !fwd0 && !bwd) return RECNOW_EUNSUPPORTED;
-    int rc = rn_split_planes(k.B, k.ldb, b_kc ? 1 : 0, k.K, k.N, planes, st);
-    if (rc) return rc;
-    const char* pl = (const char*)planes;
+    if (!ready) {       // (ready: the caller split the packed weights already, once per step)
+        int rc = rn_split_planes(k.B, k.ldb, b_kc ? 1 : 0, k.K, k.N, planes, st);
+        if (rc) return rc;
+    }
+    const char* pl = ready ? (const char*)ready : (const char*)planes;
     if (fwd) {      // (no whole-tile prefetch of emul: its 64 registers are the fragments' here)
         if (c2_mode == 1) return launch_sk<false, 1, 1, false, 9, true>(k, st, pl);
         if (c2_mode == 3) return launch_sk<false, 1, 3, false, 9, true>(k, st, pl);

@@ -41,6 +41,40 @@ __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ 
     for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(planes + s * ps + u * 16) = w[s];
 }
 
+// Several operands in ONE launch (the packed weights of every cross layer, once per step: dcnmix.hip): blockIdx.y = job
+__global__ void __launch_bounds__(256) k_split_planes_multi(const RnSplitJobs jobs) {
+    const RnSplitJob j = jobs.job[blockIdx.y];
+    const int64_t total = (int64_t)(j.K / 8) * j.N;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+        const int n = (int)(u % j.N), o = (int)(u / j.N);
+        float x[8];
+        if (j.b_kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(j.B + (int64_t)n * j.ldb + 8 * o), b = *reinterpret_cast<const f32x4*>(j.B + (int64_t)n * j.ldb + 8 * o + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = j.B[(int64_t)(8 * o + e) * j.ldb + n];
+        }
+        u32x4 w[3];
+        spl_split8(x, w);
+        const int64_t ps = total * 16;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<u32x4*>(j.planes + s * ps + u * 16) = w[s];
+    }
+}
+int rn_split_planes_multi(const RnSplitJobs& jobs, hipStream_t st) {
+    if (jobs.n < 1 || jobs.n > RN_SPLIT_MAX_JOBS) return RECNOW_EINVAL;
+    int64_t most = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        const int64_t u = (int64_t)(jobs.job[i].K / 8) * jobs.job[i].N;
+        if (jobs.job[i].K % 8 || (jobs.job[i].b_kc && (jobs.job[i].ldb % 4 || ((uintptr_t)jobs.job[i].B & 15)))) return RECNOW_EUNSUPPORTED;
+        if (u > most) most = u;
+    }
+    hipLaunchKernelGGL(k_split_planes_multi, dim3((unsigned)((most + 255) / 256), (unsigned)jobs.n), 256, 0, st, jobs);
+    RN_LAUNCH_CHECK();
+    return RECNOW_OK;
+}
+
 int rn_split_planes(const float* B, int64_t ldb, int b_kc, int K, int N, void* planes, hipStream_t st) {
     const int64_t units = (int64_t)(K / 8) * N;
     hipLaunchKernelGGL(k_split_planes, (unsigned)((units + 255) / 256), 256, 0, st, B, ldb, b_kc ? 1 : 0, K, N, (char*)planes);
@@ -563,7 +597,7 @@ static int s3_launch(const GemmK& k, const char* planes, int64_t pb, dim3 grid, 
 // Launcher: the (layout, operand kind) combinations of the DCN-v2 step, N = 128 (one column tile: the side product belongs to
 // it).  `planes` != NULL: B is split once into planes there (rn_gemm_split_planes_bytes(K, N) bytes) before the product.
 // RECNOW_EUNSUPPORTED -> the caller runs the fp32 kernel.
-int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* planes, dim3 grid, hipStream_t st) {
+int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* planes, dim3 grid, hipStream_t st, const void* ready) {
     if (grid.y != 1 || k.K % SPL_BK || k.kchunk % SPL_BK || k.sp_r <= 0) return RECNOW_EUNSUPPORTED;
     // element offsets inside a tile are 32-bit
     if ((int64_t)128 * k.lda >= (1ll << 31) || (int64_t)128 * k.ldb >= (1ll << 31)) return RECNOW_EUNSUPPORTED;
@@ -573,6 +607,9 @@ int rn_gemm_launch_split(const GemmK& k, bool a_kc, bool b_kc, int a2k, void* pl
     // (A / A * A2) + 18 us for the split of the (B, 128) operand against 111 / 126 us for k_gemm_split, which splits B in every workgroup: the
     // pre-pass costs what the leaner loop gains, so these products stay on k_gemm_split (RECNOW_SPLIT_LEAN=2 routes them here: A/B switch)
     static const bool s3_kb = []() { const char* e = getenv("RECNOW_SPLIT_LEAN"); return e && e[0] == '2'; }();
+    // ready != NULL: the caller holds the planes of this product's B already (the packed weights of a step are split once, dcnmix.hip)
+    if (ready && s3_on && s3_shape(k, a2k) && a_kc)
+        return a2k == 0 ? s3_launch<true, 0>(k, (const char*)ready, pb, grid, st, 0) : s3_launch<true, RECNOW_OPMODE_MUL>(k, (const char*)ready, pb, grid, st, 1);
     if (planes && s3_on && s3_shape(k, a2k) && (a_kc || (!b_kc && s3_kb))) {
         const int64_t units = (int64_t)(k.K / 8) * k.N;
         hipLaunchKernelGGL(k_split_planes, (unsigned)((units + 255) / 256), 256, 0, st, k.B, k.ldb, b_kc ? 1 : 0, k.K, k.N, (char*)planes);

@@ -1,6 +1,7 @@
 // Shared pieces of the split-precision (3 x bf16, six MFMA terms) products: gemm_split.hip (long-K) and gemm_shortk.hip (K <= 512).
 #pragma once
 #include "gemm_kernel.hpp"
+#include "gemm.hpp"
 
 typedef __bf16 bf16x8 __attribute__((__vector_size__(16)));
 typedef __bf16 bf16x2 __attribute__((__vector_size__(4)));
