@@ -86,6 +86,19 @@ SPLIT_FROM_ROWS = 32768               # --gemm-precision auto: split-precision p
 PARITY_TOL = 1e-5                     # north_star: 1e-5 relative, GPU fp32 against the fp64 oracle (row subset + the full batch)
 
 
+def cpu_share():
+    """CPUs this process may really use (the cgroup quota: a GPU box shows 256 logical CPUs and grants 16).  The host legs of this script -- the CPU baseline
+    and the fp64 oracle of the gate -- run on twice that many threads (measured best on such a box: 56 s with 32 threads against 102 s with torch's
+    default of 128, which mostly waits for its quota)."""
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            return max(1, -(-int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return os.cpu_count() or 1
+
+
 def kernel_source_hash():
     """sha256 over the HIP sources of the library: profiles/traffic.json is only valid for the build it was measured on."""
     h = hashlib.sha256()
@@ -428,6 +441,8 @@ def main():
         else:
             dist.init_process_group('gloo')
 
+    # host legs (CPU baseline, fp64 gate): threads from the cgroup's CPU share, not from the 256 logical CPUs a GPU box shows
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 2 * cpu_share()) // max(world, 1)))
     from rec_now_amd import _lib, dp
     from rec_now_amd.rec_block.pairwise_loss_from_batch import group_rows, pairwise_loss_fused
     lib = _lib.load()
@@ -871,7 +886,7 @@ def main():
     if use_dist and (graph is None or pstep is not None) and not args.no_input_grad:
         _, PO = _oracle()
         rccl_ranks = dist.get_world_size()
-        torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(world, 1)))
+        torch.set_num_threads(max(1, min(os.cpu_count() or 1, 2 * cpu_share()) // max(world, 1)))
         xq = (xd.detach() * CHECK_SCALE).requires_grad_(True)
         loss_q = step(xq)
         torch.cuda.synchronize()
