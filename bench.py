@@ -360,9 +360,398 @@ def self_launch(n_ranks, argv, oversubscribe=False):
     raise SystemExit(rc)
 
 
+
+# ---- configs[3] / configs[4]: data-parallel MODEL steps (VERDICT round 5, row e''): bench.py --config c4 | c5 -------------------------------------------
+C5_AUX = (0.5 / 64, 0.5 / 64, -0.5 / 64)        # per-row weights of the pointwise terms of the c5 loss sum (one list = 64 rows: O(1e-2) of the listwise terms)
+MODEL_CONFIGS = {
+    'c4': {'rows': 16384, 'ranks': 8,
+           'workload': 'configs[3]: cin_layer (L=3, H=128) || fm_layer -> Dense(17 -> 1) head -> in-batch pairwise (logistic), 64 fields x 16-dim, '
+                       '~8 rows/group; global B = 131072 on 8 GPUs = 16384 rows per GPU'},
+    'c5': {'rows': 32768, 'ranks': 8,
+           'workload': 'configs[4]: ple_layer (3 tasks + 1 shared group, experts [[512, 256], [256, 128]] x 2) -> 3 heads MultiDense(1, 3) -> '
+                       'listwise_loss_from_batch on every task logit, 128 fields x 32-dim = 4096 inputs, 64 rows/list; global B = 262144 on 8 GPUs = 32768 rows per GPU'},
+}
+
+
+def _c4_oracle(named, dtype, F, Dm, n_layers):
+    R, _ = _oracle()
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype).requires_grad_(True) for k, v in named.items()}
+
+    def fwd(xc):
+        fields = [xc[:, f * Dm:(f + 1) * Dm] for f in range(F)]
+        feat = torch.cat([R.cin_layer_gemm_form(xc, [w['cin.%d' % k] for k in range(1, n_layers + 1)], F, Dm, True, True), R.fm_layer(fields)], dim=1)
+        return R.multi_dense_layer(feat, w['head.kernel'], w['head.bias']).reshape(-1)
+    return fwd, w
+
+
+def _c5_oracle(named, dtype, layer, dims):
+    R, _ = _oracle()
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype).requires_grad_(True) for k, v in named.items()}
+    n_groups = len(layer.task_names[:layer.num_total_task])
+
+    def fwd(xc):          # (rows, 3) task logits
+        layers = []
+        for l in range(len(dims)):
+            entry = {'dnn': [], 'gate': []}
+            for gi in range(n_groups):
+                scope = 'PLE/ple_layer_%d/task_%s' % (l, layer.task_names[gi])
+                entry['dnn'].append([(w['ple.%s/%s/MultiDenseLayer_%d/kernel' % (scope, scope, i)], w['ple.%s/%s/MultiDenseLayer_%d/bias' % (scope, scope, i)])
+                                     for i in range(len(dims[l]))])
+                gk = 'ple.PLE/ple_gate_%d/task_%s/dense/kernel' % (l, layer.task_names[gi])
+                entry['gate'].append((w[gk], w[gk[:-6] + 'bias']) if gk in w else None)
+            layers.append(entry)
+        outs = R.ple_layer(xc, layers, layer.is_shared_tasks, activation='tanh')
+        return R.multi_dense_layer(torch.stack(list(outs)), w['head.kernel'], w['head.bias']).reshape(3, -1).t()
+    return fwd, w
+
+
+def _chunked_fwd(fwd, x, dtype, chunk):
+    xt = torch.from_numpy(x)
+    outs = []
+    with torch.no_grad():
+        for lo in range(0, x.shape[0], chunk):
+            outs.append(fwd(xt[lo:lo + chunk].to(dtype)).numpy())
+    return np.concatenate(outs, 0)
+
+
+def _chunked_bwd(fwd, x, dout, dtype, chunk):
+    xt = torch.from_numpy(x)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    g = torch.from_numpy(np.asarray(dout).astype(npdt))
+    dx = np.empty(x.shape, npdt)
+    for lo in range(0, x.shape[0], chunk):
+        xc = xt[lo:lo + chunk].to(dtype).clone().requires_grad_(True)
+        fwd(xc).backward(g[lo:lo + chunk])
+        dx[lo:lo + chunk] = xc.grad.numpy()
+    return dx
+
+
+def _listwise_fp(groups, labels, logits, dtype):
+    """The reference's dense (G, B) listwise stage on three task logits (+ the pointwise terms C5_AUX): (loss sum, valid lists, d sum / d logits)."""
+    R, _ = _oracle()
+    lt = torch.from_numpy(np.asarray(logits)).to(dtype).requires_grad_(True)
+    total, nv = 0.0, 0
+    for t in range(lt.shape[1]):
+        _, lab, lg = R.to_listwise_sample(torch.from_numpy(groups), torch.from_numpy(labels).to(dtype), lt[:, t])
+        total = total + R.listwise_loss_via_softmax_cross_entropy_with_logits(lab, lg, do_reduce=False).sum()
+        nv = int(lab.shape[0])
+    for t in range(lt.shape[1]):
+        total = total + C5_AUX[t] * lt[:, t].sum()
+    total.backward()
+    return float(total.item()), nv, lt.grad.numpy()
+
+
+def main_models(args, world, rank, dev, json_fd, use_dist):
+    """`bench.py --config c4 | c5`: the per-rank model step of BASELINE.json's configs[3] / configs[4] through dp.OverlappedGradientReducer (buckets
+    all-reduced from autograd's post-accumulate hooks, under the backward pass), the same JSON schema as the headline line, cross-rank fp64 gate."""
+    from rec_now_amd import _lib, dp
+    lib = _lib.load()
+    dp.FORCE_COLLECTIVES = bool(args.force_dist)
+    _lib.call('recnow_set_gemm_precision', 0)          # these models' products are the exact-fp32 kernels (no split form of CIN / PLE products)
+    cfg = MODEL_CONFIGS[args.config]
+    rows = args.rows if args.rows is not None else cfg['rows']
+    rng = np.random.default_rng(40 + 1000 * rank)
+    torch.manual_seed(5)
+    labels = (rng.random(rows) < 0.25).astype(np.float32)
+    if args.config == 'c4':
+        from rec_now_amd.layers.cin_layer import CINLayer
+        from rec_now_amd.layers.fm_layer import FMLayer
+        from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+        from rec_now_amd.rec_block.pairwise_loss_from_batch import pairwise_loss_fused
+        F, Dm, Hs = 64, 16, [128, 128, 128]
+        n_groups = max(rows // 8, 2)
+        x = rng.normal(0, 0.3, (rows, F * Dm)).astype(np.float32)
+        groups = (rng.integers(0, n_groups, rows) + rank * n_groups).astype(np.float32)
+        cin, fm, head = CINLayer(Hs), FMLayer(), MultiDenseLayer(1, 1)
+        xs = [torch.from_numpy(np.ascontiguousarray(x[:, f * Dm:(f + 1) * Dm])).to(dev).requires_grad_(True) for f in range(F)]
+        head(torch.cat([cin([v[:64] for v in xs]), fm([v[:64] for v in xs])], dim=1))          # lazy build
+        with torch.no_grad():
+            head.kernel.mul_(0.05)
+            head.bias.fill_(0.2)
+        named = {'cin.%d' % k: cin.idx2weight[k] for k in range(1, len(Hs) + 1)}
+        named['head.kernel'], named['head.bias'] = head.kernel, head.bias
+        denom = 'eps'
+    else:
+        from rec_now_amd.layers.multi_dense_layer import MultiDenseLayer
+        from rec_now_amd.layers.ple_layer import PLELayer
+        from rec_now_amd.rec_block.listwise_loss_from_batch import listwise_loss_from_batch
+        Din, dims, n_exp = 4096, [[512, 256], [256, 128]], 2
+        n_groups = max(rows // 64, 2)
+        x = (rng.normal(0, 0.3, (rows, Din))).astype(np.float32)
+        groups = (rng.integers(0, n_groups, rows) + rank * n_groups).astype(np.float32)
+        ple, head = PLELayer(3, dims, n_exp, 1, activation='tanh', name='PLE'), MultiDenseLayer(1, 3)
+        xs = [torch.from_numpy(x).to(dev).requires_grad_(True)]
+        head(torch.stack(list(ple(xs[0][:256]))))
+        g = torch.Generator(device='cpu').manual_seed(56)
+        with torch.no_grad():
+            for name, p in ple.named_weights().items():
+                if 'bias' in name:
+                    p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).mul_(0.1).to(p.device))
+            head.kernel.mul_(6.0)
+            head.bias.fill_(0.1)
+        named = {'ple.' + k: v for k, v in ple.named_weights().items()}
+        named['head.kernel'], named['head.bias'] = head.kernel, head.bias
+        denom = 'max1'
+    params = list(named.values())
+    yd, gd = torch.from_numpy(labels).to(dev), torch.from_numpy(groups).to(dev)
+    red = dp.OverlappedGradientReducer(params, denom=denom)
+    rank_rows = [rows]
+    if use_dist:
+        cnt_t = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=dev if args.backend == 'nccl' else 'cpu')
+        cnt_t[dist.get_rank()] = rows
+        dist.all_reduce(cnt_t, op=dist.ReduceOp.SUM)
+        rank_rows = [int(v) for v in cnt_t.tolist()]
+    total_rows = sum(rank_rows)
+    last = {}
+
+    def run_step():
+        for p in params:
+            p.grad = None
+        for v in xs:
+            v.grad = None
+        if args.config == 'c4':
+            scores = head(torch.cat([cin(xs), fm(xs)], dim=1)).reshape(-1)
+            local_sum, count = pairwise_loss_fused(scores, yd, gd, reduce_mean=False)
+            last['out'] = scores
+        else:
+            logits = head(torch.stack(list(ple(xs[0])))).reshape(3, -1)
+            local_sum, count = 0.0, None
+            for t in range(3):
+                lmean, nv = listwise_loss_from_batch(gd, yd, logits[t], return_num_list=True)
+                local_sum = local_sum + lmean * nv.detach()
+                count = nv.detach().to(torch.float32)
+            # + small pointwise terms on the task logits (as tests/test_northstar_gpu.py::test_config5_end_to_end..: the listwise gradient sums to zero inside
+            # every list, so bias gradients made of it alone are sums that cancel and a relative bound on them measures the conditioning of the sum)
+            local_sum = local_sum + C5_AUX[0] * logits[0].sum() + C5_AUX[1] * logits[1].sum() + C5_AUX[2] * logits[2].sum()
+            last['out'] = logits
+        red.prepare(local_sum, count)
+        local_sum.backward()
+        loss, cnt = red.finish()
+        last['count'] = cnt
+        return loss
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        run_step()
+    prof = not args.no_prof
+    if prof:
+        _lib.check(lib.recnow_prof_enable(512 * (args.steps + 1)), 'recnow_prof_enable')
+        _lib.check(lib.recnow_prof_sample_every(1), 'recnow_prof_sample_every')
+    import gc
+    gc.collect()
+    gc.disable()
+    for _ in range(2):
+        run_step()
+    if prof:
+        _c, _m, _f, _b = (ctypes.c_int * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
+        _lib.check(lib.recnow_prof_collect(_c, _m, _f, _b), 'recnow_prof_collect')
+        _lib.check(lib.recnow_prof_sample_every(1), 'recnow_prof_sample_every')
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = run_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    roofline = None
+    if prof:
+        cnt, ms, fl, by = (ctypes.c_int * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
+        _lib.check(lib.recnow_prof_collect(cnt, ms, fl, by), 'recnow_prof_collect')
+        lib.recnow_prof_enable(0)
+    account = step_account(lib, run_step, sync, steps=4) if prof else None
+    comm = None
+    if use_dist:
+        def timed_ms(n=6):
+            sync()
+            c0 = time.perf_counter()
+            for _ in range(n):
+                run_step()
+            sync()
+            tt = torch.tensor([(time.perf_counter() - c0) * 1e3 / n], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        with_ms = timed_ms()
+        dp._SKIP_COLLECTIVE = True
+        try:
+            without_ms = timed_ms()
+        finally:
+            dp._SKIP_COLLECTIVE = False
+        comm = {'with_collectives_ms': with_ms, 'without_collectives_ms': without_ms, 'comm_exposed_ms': with_ms - without_ms,
+                'buckets': [int(f.numel() * 4) for f in red._flat],
+                'what': 'ms per step over 6 untimed steps (max over the ranks) with and without the bucket all-reduces; buckets (bytes) in the order they '
+                        'are reduced, each from the autograd hook that completes it'}
+    if prof:
+        tag = max(GEMM_TAGS, key=lambda t: ms[t])
+        if account is not None:
+            excl = {t: account['by_tag'].get(t, 0.0) for t in GEMM_TAGS if cnt[t] > 0}
+            if excl:
+                tag = max(excl, key=lambda t: excl[t])
+        if cnt[tag] > 0 and ms[tag] > 0:
+            achieved = fl[tag] / (ms[tag] * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                        'traffic': None, 'kernel': GEMM_TAGS[tag], 'launches': cnt[tag], 'sampled': 'every hooked launch of the timed region',
+                        'avg_launch_us': ms[tag] * 1e3 / cnt[tag], 'algorithmic_flops_per_launch': fl[tag] / cnt[tag],
+                        'all_gemm': {GEMM_TAGS[t]: {'launches': cnt[t], 'ms': ms[t], 'tflops': (fl[t] / (ms[t] * 1e-3) / 1e12) if ms[t] > 0 else None}
+                                     for t in GEMM_TAGS if cnt[t] > 0},
+                        'whole_step_tflops': sum(fl[t] for t in GEMM_TAGS) / args.steps / (elapsed / args.steps) / 1e12}
+            if account is not None:
+                roofline['exclusive_ms_per_step'] = account['per_step_ms']
+                roofline['exclusive_covered_ms_per_step'] = account['covered_ms_per_step']
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        if args.backend != 'nccl':
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- the gate (untimed): one more step, every rank holds its rows to the fp64 oracle, the loss stage and the reduced gradients to the gathered batch
+    R, PO = _oracle()
+    loss_q = run_step()
+    torch.cuda.synchronize()
+    named_np = {k: v.detach().cpu().numpy() for k, v in named.items()}
+    out_gpu = last['out'].detach().cpu().numpy()
+    dx_gpu = (torch.cat([v.grad for v in xs], dim=1) if args.config == 'c4' else xs[0].grad).cpu().numpy()
+    count_glob = float(last['count'].item())
+    dx_gpu = dx_gpu / (np.float32(count_glob) + np.float32(1e-10) if denom == 'eps' else max(count_glob, 1.0))      # x is not a parameter: the loss SUM's gradient
+    full_gate = not args.no_cpu_baseline
+    world_n = dist.get_world_size() if use_dist else 1
+
+    def gather(a):
+        if not use_dist:
+            return np.ascontiguousarray(a)
+        a = np.ascontiguousarray(a)
+        tt = torch.from_numpy(a)
+        if args.backend == 'nccl':
+            tt = tt.to(dev)
+        parts = [torch.empty_like(tt) for _ in range(world_n)]
+        dist.all_gather(parts, tt)
+        return torch.cat(parts).cpu().numpy()
+
+    def allsum64(v):
+        tt = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
+        if use_dist:
+            if args.backend == 'nccl':
+                tt = tt.to(dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        return tt.cpu().numpy()
+    chunk = 512 if args.config == 'c4' else 2048
+    parity = {'tolerance': PARITY_TOL, 'loss': float(loss_q.item()), 'ranks': world_n}
+    worst = 0.0
+    if args.config == 'c4':
+        g_all, y_all, s_all = gather(groups), gather(labels), gather(out_gpu)
+        o_loss, _, o_pairs = PO.pairwise_bpr(g_all, y_all, s_all, grouped=True)
+        parity['gathered_batch_pairs_oracle'] = {'loss': rel_err(float(loss_q.item()), o_loss), 'pairs_gpu': int(count_glob), 'pairs_oracle': int(o_pairs)}
+        worst = parity['gathered_batch_pairs_oracle']['loss']
+        ok = int(count_glob) == int(o_pairs)
+        if full_gate:
+            fwd, wl = _c4_oracle(named_np, torch.float64, 64, 16, 3)
+            s64 = _chunked_fwd(fwd, x, torch.float64, chunk)
+            s64_all = gather(s64)
+            f_loss, ds_all, f_pairs = PO.pairwise_bpr(g_all, y_all, s64_all, grouped=True)
+            lo = sum(rank_rows[:rank])
+            dx64 = _chunked_bwd(fwd, x, ds_all[lo:lo + rows], torch.float64, chunk)
+    else:
+        if full_gate:
+            fwd, wl = _c5_oracle(named_np, torch.float64, ple, [[512, 256], [256, 128]])
+            l64 = _chunked_fwd(fwd, x, torch.float64, chunk)
+        else:
+            l64 = out_gpu.T.astype(np.float64)
+        # the listwise stage on the GPU's own logits (fp64, dense (G, B) form of the reference): lists live on one rank, so the global mean is sum / sum
+        lsum_g, nv_l, _ = _listwise_fp(groups, labels, out_gpu.T.astype(np.float64), torch.float64)
+        tot = allsum64(np.array([lsum_g, nv_l]))
+        parity['listwise_stage_oracle'] = {'loss': rel_err(float(loss_q.item()), tot[0] / max(tot[1], 1.0)), 'lists_gpu': int(count_glob), 'lists_oracle': int(tot[1])}
+        worst = parity['listwise_stage_oracle']['loss']
+        ok = int(count_glob) == int(tot[1])
+        if full_gate:
+            lsum64, nv64, dl64 = _listwise_fp(groups, labels, l64, torch.float64)
+            tot64 = allsum64(np.array([lsum64, nv64]))
+            f_loss = tot64[0] / max(tot64[1], 1.0)
+            dx64 = _chunked_bwd(fwd, x, dl64 / max(tot64[1], 1.0), torch.float64, chunk)
+            s64 = l64
+    if full_gate:
+        names = sorted(named)
+        flat = allsum64(np.concatenate([(wl[k].grad.numpy() if wl[k].grad is not None else np.zeros(tuple(wl[k].shape))).reshape(-1) for k in names]))
+        full = {'loss': rel_err(float(loss_q.item()), f_loss), 'outputs': rel_err(out_gpu if args.config == 'c4' else out_gpu.T, s64), 'dx': rel_err(dx_gpu, dx64)}
+        loc = torch.tensor([full['outputs'], full['dx']], dtype=torch.float64, device=dev)
+        if use_dist:
+            loc = loc if args.backend == 'nccl' else loc.cpu()
+            dist.all_reduce(loc, op=dist.ReduceOp.MAX)
+        full['outputs'], full['dx'] = float(loc[0].item()), float(loc[1].item())
+        off = 0
+        gsum = float(np.abs(ds_all).sum()) if args.config == 'c4' else None
+        for k in names:
+            n = named[k].numel()
+            ref = flat[off:off + n].reshape(tuple(named[k].shape))
+            off += n
+            # a gradient that is a sum cancelling to ~0 (the head bias under a pairwise loss): on the scale of its terms
+            full[k] = rel_err(named[k].grad.cpu().numpy(), ref, scale=gsum if (k == 'head.bias' and args.config == 'c4') else None)
+        parity['oracle_fp64_all_ranks'] = full
+        worst = max([worst] + list(full.values()))
+    parity['parity_max_rel'] = worst
+    parity['ok'] = bool(ok and worst <= PARITY_TOL)
+
+    # ---- CPU baseline (rank 0 at N = 1 only): the fp32 port on a bounded sample of the same workload
+    cpu = None
+    if full_gate and world == 1 and not use_dist:
+        n_s = min(rows, 2048 if args.config == 'c4' else 8192)
+        ids = np.unique(groups)
+        sel = np.nonzero(np.isin(groups, ids[:max(1, int(len(ids) * n_s / rows))]))[0]          # whole groups, ~n_s rows
+        xs_, gs_, ys_ = np.ascontiguousarray(x[sel]), groups[sel], labels[sel]
+        c0 = time.perf_counter()
+        if args.config == 'c4':
+            fwd32, _w = _c4_oracle(named_np, torch.float32, 64, 16, 3)
+            sc = _chunked_fwd(fwd32, xs_, torch.float32, chunk)
+            _, ds, _ = PO.pairwise_bpr(gs_, ys_, sc, grouped=True)
+            _chunked_bwd(fwd32, xs_, ds, torch.float32, chunk)
+        else:
+            fwd32, _w = _c5_oracle(named_np, torch.float32, ple, [[512, 256], [256, 128]])
+            lg = _chunked_fwd(fwd32, xs_, torch.float32, chunk)
+            _, nvs, dl = _listwise_fp(gs_, ys_, lg, torch.float32)
+            _chunked_bwd(fwd32, xs_, dl / max(nvs, 1), torch.float32, chunk)
+        c_sec = time.perf_counter() - c0
+        cpu = {'value': len(sel) / c_sec, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '1 step of fwd+bwd on %d rows of whole groups of the same batch (%.1f s): oracle/dense_ref.py layers in %d-row chunks on torch-CPU fp32 + '
+                         'the loss stage of the oracle; TF2 itself is not installable here' % (len(sel), c_sec, chunk)}
+
+    if rank == 0:
+        out = {'metric': 'samples/sec fwd+bwd, %s' % ('cin_layer + fm_layer + in-batch pairwise, data-parallel' if args.config == 'c4' else 'ple_layer 3-task + listwise_loss_from_batch, data-parallel'),
+               'value': total_rows * args.steps / elapsed, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': cfg['workload'] + '; this run: %d rows per GPU on %d GPU(s)' % (rows, world), 'rows_per_gpu': rows, 'rows_per_rank': rank_rows,
+                          'global_batch': total_rows, 'parallelism': 'dp%d' % world, 'input_grad': True,
+                          'route': 'drop-in layers through autograd; gradients all-reduced per bucket from post-accumulate hooks under the backward pass '
+                                   '(dp.OverlappedGradientReducer), loss statistics in the first bucket',
+                          'loss': float(loss.item())},
+               'roofline': roofline, 'parity': parity, 'parity_max_rel': parity['parity_max_rel']}
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+        if use_dist:
+            out['rccl_ranks'] = world_n
+            out['backend'] = args.backend
+            if comm is not None:
+                out['comm_exposed_ms'] = comm['comm_exposed_ms']
+                out['comm'] = comm
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--config', choices=['c3', 'c4', 'c5'], default='c3', help="c3 (default): BASELINE.json's metric (configs[2], the headline); c4 / c5: the "
+                    'data-parallel MODEL steps of configs[3] / configs[4] at their per-rank size (16 384 / 32 768 rows per GPU; --rows overrides), through dp.OverlappedGradientReducer')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -443,6 +832,8 @@ def main():
 
     # host legs (CPU baseline, fp64 gate): threads from the cgroup's CPU share, not from the 256 logical CPUs a GPU box shows
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, 2 * cpu_share()) // max(world, 1)))
+    if args.config != 'c3':
+        return main_models(args, world, rank, dev, json_fd, use_dist)
     from rec_now_amd import _lib, dp
     from rec_now_amd.rec_block.pairwise_loss_from_batch import group_rows, pairwise_loss_fused
     lib = _lib.load()

@@ -425,3 +425,123 @@ class LayerwiseReducer(object):
             main.wait_stream(self.comm)                 # the gradients are final for whatever the main stream does next
             result.record_stream(main)
         return result[0], result[1]
+
+
+class OverlappedGradientReducer(object):
+    """Gradient all-reduce UNDER an autograd backward pass, for models whose backward is not one library call (round 6: the configs[3] / configs[4]
+    model steps -- CIN || FM -> head -> pairwise, PLE -> heads -> listwise).  `GradientAllReducer` packs and reduces everything AFTER the backward
+    pass; here the parameters are bucketed in REVERSE registration order (the order their gradients become final: the head first, the first
+    layer last), every parameter carries a post-accumulate-grad hook that copies its gradient into its bucket's flat buffer, and the hook that
+    completes a bucket records an event and enqueues that bucket's all-reduce on the communication stream -- the backward of the layers below
+    runs on beside it.  The two loss statistics ride in the FIRST bucket to go (they are known before the backward pass starts: `prepare`).
+
+        reducer.prepare(local_loss_sum, local_count)      # before backward
+        local_loss_sum.backward()                         # hooks fire; collectives start while the pass runs
+        loss, count = reducer.finish()                    # waits, scales every gradient by 1 / denom(count_global), p.grad = bucket views
+
+    denom: 'eps' -> count + 1e-10 (the pairwise mean, rec_block/pairwise_loss_from_batch.py:279); 'max1' -> max(count, 1) (the listwise mean over
+    valid lists with NaN -> 0, rec_block/listwise_loss_from_batch.py:151-173).  Works without a process group (scaling only) and on CPU tensors
+    (gloo tests: the collectives run in the hooks, in order).  Set `p.grad = None` (or zero_grad(set_to_none=True)) before each step: a live
+    gradient would be accumulated into by autograd and reduced a second time."""
+
+    def __init__(self, params, bucket_bytes=24 << 20, denom='eps'):
+        if denom not in ('eps', 'max1'):
+            raise ValueError("denom: 'eps' or 'max1'")
+        self.denom = denom
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no parameter requires a gradient')
+        dev, dt = self.params[0].device, self.params[0].dtype
+        order = list(reversed(self.params))
+        groups, cur, cur_bytes = [], [], 0
+        for p in order:
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        self.buckets = groups
+        self._flat, self._slot = [], {}
+        for bi, bucket in enumerate(groups):
+            total = sum(-(-p.numel() // 4) * 4 for p in bucket) + (4 if bi == 0 else 0)      # 16-byte aligned slices; the statistics behind bucket 0
+            flat = torch.zeros(total, dtype=dt, device=dev)
+            off = 0
+            for p in bucket:
+                self._slot[id(p)] = (bi, flat[off:off + p.numel()])
+                off += -(-p.numel() // 4) * 4
+            self._flat.append(flat)
+        self.comm = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self._events = [torch.cuda.Event() for _ in groups] if self.comm is not None else None
+        self._arrived = [0] * len(groups)
+        self._works = []
+        self._armed = False
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def prepare(self, local_loss_sum, local_count):
+        torch.stack([local_loss_sum.detach().to(self._flat[0].dtype), local_count.detach().to(self._flat[0].dtype)], out=self._flat[0][-4:-2])
+        self._arrived = [0] * len(self.buckets)
+        self._works = []
+        self._armed = True
+
+    def _launch(self, bi):
+        flat = self._flat[bi]
+        if not is_dist() or _SKIP_COLLECTIVE:
+            return
+        if self.comm is None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            return
+        main = torch.cuda.current_stream()
+        self._events[bi].record(main)
+        self.comm.wait_event(self._events[bi])
+        torch.cuda.set_stream(self.comm)
+        try:
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        finally:
+            torch.cuda.set_stream(main)
+
+    def _on_grad(self, p):
+        if not self._armed or p.grad is None:
+            return
+        bi, view = self._slot[id(p)]
+        view.copy_(p.grad.reshape(-1))
+        self._arrived[bi] += 1
+        if self._arrived[bi] == len(self.buckets[bi]):
+            self._launch(bi)
+
+    def finish(self):
+        """After backward(): buckets whose parameters got no gradient on this rank are reduced now (zeros), every collective is waited for, the
+        gradients are scaled and `p.grad` becomes the parameter's slice of its bucket.  Returns (global mean loss, global count), 0-dim tensors."""
+        if not self._armed:
+            raise RuntimeError('finish() without prepare()')
+        self._armed = False
+        for bi, bucket in enumerate(self.buckets):
+            if self._arrived[bi] < len(bucket):
+                for p in bucket:
+                    if p.grad is None:
+                        self._slot[id(p)][1].zero_()
+                    elif self._arrived[bi] == 0 or p.grad.data_ptr() != self._slot[id(p)][1].data_ptr():
+                        self._slot[id(p)][1].copy_(p.grad.reshape(-1))
+                self._launch(bi)
+        if self.comm is not None:
+            for w in self._works:
+                w.wait()
+            torch.cuda.current_stream().wait_stream(self.comm)
+        self._works = []
+        stats = self._flat[0][-4:-2]
+        den = (stats[1] + SMALL_POSIVITE_FLOAT) if self.denom == 'eps' else torch.clamp(stats[1], min=1.0)
+        inv = 1.0 / den
+        result = torch.stack([stats[0] * inv, stats[1]])
+        for bi, flat in enumerate(self._flat):
+            n = flat.numel() - (4 if bi == 0 else 0)
+            flat[:n].mul_(inv)
+        for p in self.params:
+            p.grad = self._slot[id(p)][1].view(p.shape)
+        return result[0], result[1]

@@ -108,3 +108,31 @@ def test_two_ranks_share_one_gpu_over_gloo_and_verify_across_ranks(dev):
     full = par['oracle_fp64_all_ranks']
     assert full['pairs_equal'] and len([k for k in full if k.startswith('cross.')]) == 15
     assert par['ok'] and par['parity_max_rel'] <= 1e-5, par
+
+
+@pytest.mark.parametrize('config', ['c4', 'c5'])
+def test_model_configs_two_ranks_over_gloo_verify_across_ranks(dev, config):
+    """`bench.py --config c4 | c5` (VERDICT round 5, row e''): the data-parallel MODEL steps of BASELINE.json's configs[3] / configs[4] -- CIN || FM -> head ->
+    pairwise; PLE -> 3 heads -> listwise -- with two real ranks (two processes on GPU 0 over gloo), every rank its own whole groups / lists, the gradients
+    all-reduced bucket by bucket from autograd's post-accumulate hooks (dp.OverlappedGradientReducer).  The line's gate: the reduced loss against the
+    oracle's loss stage on the gathered batch, outputs and d loss / d x per rank and every all-reduced weight gradient against the sum of the ranks' fp64
+    oracles.  /root/reference/rec_now/layers/cin_layer.py:72-122, ple_layer.py:295-321, rec_block/listwise_loss_from_batch.py:89-173."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', config, '--gpus', '2', '--backend', 'gloo', '--oversubscribe',
+                          '--rows', '2048', '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=_clean_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+                'roofline', 'parity', 'comm_exposed_ms'):
+        assert key in line, key
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['config']['rows_per_rank'] == [2048, 2048] and line['scaling'] == 'weak'
+    assert ('configs[3]' if config == 'c4' else 'configs[4]') in line['config']['workload']
+    par = line['parity']
+    assert par['ok'] and par['parity_max_rel'] <= 1e-5, par
+    full = par['oracle_fp64_all_ranks']
+    if config == 'c4':
+        assert par['gathered_batch_pairs_oracle']['pairs_gpu'] == par['gathered_batch_pairs_oracle']['pairs_oracle'] > 0
+        assert {'cin.1', 'cin.2', 'cin.3', 'head.kernel', 'head.bias', 'outputs', 'dx', 'loss'} <= set(full)
+    else:
+        assert par['listwise_stage_oracle']['lists_gpu'] == par['listwise_stage_oracle']['lists_oracle'] > 0
+        assert len([k for k in full if k.startswith('ple.')]) >= 4 * 2 * 2 * 2 + 4 and 'head.kernel' in full
+    assert line['roofline']['bound'] == 'mfma' and len(line['comm']['buckets']) >= 1

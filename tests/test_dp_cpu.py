@@ -362,3 +362,83 @@ def test_in_place_reducer_protocol_equals_single_process(one_collective):
         assert pg == n_pair and abs(lv - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))
         assert np.abs(ga - wa.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wa.grad.numpy()).max())
         assert np.abs(gb - wb.grad.numpy()).max() <= 2e-6 * max(1.0, np.abs(wb.grad.numpy()).max())
+
+
+def _mlp_params(seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(6, 16, generator=g).mul_(0.3).requires_grad_(True), torch.zeros(16).requires_grad_(True),
+            torch.randn(16, 1, generator=g).mul_(0.3).requires_grad_(True), torch.zeros(1).requires_grad_(True),
+            torch.randn(3, 3, generator=g).requires_grad_(True)]          # the last one never gets a gradient: its bucket is reduced as zeros
+
+
+def _mlp_scores(params, x):
+    return (torch.tanh(x @ params[0] + params[1]) @ params[2] + params[3]).reshape(-1)
+
+
+def _overlap_worker(rank, world, port, out, kind):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rec_now_amd import dp
+    rng = np.random.default_rng(7)
+    B, G = 600, 31
+    g = rng.integers(0, G, B)
+    x = rng.normal(size=(B, 6)).astype(np.float32)
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    mine = dp.shard_rows_by_group(g, world).numpy() == rank
+    params = _mlp_params(5)
+    red = dp.OverlappedGradientReducer(params, bucket_bytes=100, denom='eps' if kind == 'pairwise' else 'max1')      # several small buckets
+    assert len(red.buckets) >= 3
+    for step in range(2):                 # twice: the buckets and hooks are reused, the second step must not see the first one's gradients
+        for p in params:
+            p.grad = None
+        sc = _mlp_scores(params, torch.from_numpy(x[mine]))
+        gl, yl = torch.from_numpy(g[mine].astype(np.float32)), torch.from_numpy(y[mine])
+        if kind == 'pairwise':
+            f = lambda p, n, wgt: R.bpr_loss_func(p, n, wgt, 1.0, reduce_mean=False)      # noqa: E731
+            local_sum, cnt = R.pairwise_loss(sc, yl, gl, f, return_num_pair=True)
+            cnt = torch.tensor(float(cnt))
+        else:
+            _, lab, lg = R.to_listwise_sample(gl, yl.double(), sc.double())
+            per_list = R.listwise_loss_via_softmax_cross_entropy_with_logits(lab, lg, do_reduce=False)
+            local_sum, cnt = per_list.sum().float(), torch.tensor(float(lab.shape[0]))
+        red.prepare(local_sum, cnt)
+        local_sum.backward()
+        loss, total = red.finish()
+    out[rank] = (float(loss), float(total), [p.grad.numpy().copy() for p in params])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['pairwise', 'listwise'])
+def test_overlapped_reducer_two_ranks_equal_single_process(kind):
+    """dp.OverlappedGradientReducer (round 6: the reducer of the configs[3] / configs[4] model steps): buckets in reverse registration order, every
+    bucket all-reduced from the post-accumulate-grad hook that completes it, the loss statistics in the first bucket, a parameter without a
+    gradient reduced as zeros -- two gloo ranks with whole groups per rank against the single-process loss and gradients, pairwise (1 / (P + 1e-10))
+    and listwise (1 / max(lists, 1)) normalisation."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, port, out, kind), nprocs=world, join=True)
+    rng = np.random.default_rng(7)
+    B, G = 600, 31
+    g = rng.integers(0, G, B)
+    x = rng.normal(size=(B, 6)).astype(np.float32)
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    params = _mlp_params(5)
+    sc = _mlp_scores(params, torch.from_numpy(x))
+    gt, yt = torch.from_numpy(g.astype(np.float32)), torch.from_numpy(y)
+    if kind == 'pairwise':
+        loss, cnt = R.pairwise_loss(sc, yt, gt, return_num_pair=True)
+    else:
+        _, lab, lg = R.to_listwise_sample(gt, yt.double(), sc.double())
+        loss, cnt = R.listwise_loss_via_softmax_cross_entropy_with_logits(lab, lg).float(), lab.shape[0]
+    loss.backward()
+    for r in range(world):
+        lv, total, grads = out[r]
+        assert total == float(cnt)
+        assert abs(lv - float(loss)) <= 2e-6 * max(1.0, abs(float(loss)))
+        for gp, p in zip(grads, params):
+            ref = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+            assert np.abs(gp - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
