@@ -65,6 +65,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 PEAK_BF16_MFMA_TFLOPS = 16 * 157.3     # same guide: the fp32 MFMA rate is 1/16 of the dense bf16 rate (~2.5 PFLOP/s)
 PEAK_HBM_GBS = 8000.0                 # same guide, "HBM3E peak BW" (spec; 6.29 TB/s is the measured copy ceiling)
 REWARM_STEPS, REWARM_SECONDS = 3, 0.06   # untimed steps between the host-side preparations of the timed region (gc, hook events) and its start: at least 3, and 60 ms of them
+N_TAGS = 32                           # host arrays of recnow_prof_collect: at least recnow_prof_tag_count() entries (checked in main)
 PROF_EVERY = 5                        # time every 5th hooked launch (24 per step: every launch position gets sampled)
 GEMM_TAGS = {1: 'k_gemm<128,128,2,2>', 2: 'k_gemm<128,160,4,1>', 3: 'k_gemm<256,64,4,1>', 4: 'k_gemm<256,32,4,1>',
              5: 'k_gemm_shortk', 8: 'k_gemm_split',         # the library's RN_TAG_*: one per GEMM kernel as rocprof names them
@@ -275,7 +276,7 @@ def step_account(lib, run_step, sync, steps=10):
     equally among the launches running at it -- a kernel family's EXCLUSIVE (shared) time per step.  Under one stream this is its plain
     kernel time; under the second stream of the backward pass two co-running products get half of their common time each instead of
     both being charged all of it.  Returns {'per_step_ms': {name: ms}, 'covered_ms_per_step': .., 'launches_per_step': {name: n}}."""
-    cap = 96 * steps
+    cap = 512 * steps          # (a product-route step under two streams with phase tags is ~60 records; the model steps of c4 / c5 up to ~200)
     if lib.recnow_prof_enable(cap) != 0 or lib.recnow_prof_sample_every(1) != 0:
         return None
     sync()
@@ -284,6 +285,7 @@ def step_account(lib, run_step, sync, steps=10):
     sync()
     tags, t0, t1 = (ctypes.c_int * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
     n = lib.recnow_prof_intervals(tags, t0, t1, cap)
+    dropped = lib.recnow_prof_dropped()          # records that found the pool full: the account would under-report
     lib.recnow_prof_enable(0)
     if n <= 0:
         return None
@@ -316,7 +318,7 @@ def step_account(lib, run_step, sync, steps=10):
         per[k] = per.get(k, 0.0) + share[i] / steps
         cnt[k] = cnt.get(k, 0) + 1
     return {'per_step_ms': dict(sorted(per.items(), key=lambda kv: -kv[1])), 'covered_ms_per_step': covered / steps,
-            'launches_per_step': {k: v / steps for k, v in cnt.items()}, 'by_tag': {t: sum(share[i] for i in range(n) if tags[i] == t) / steps for t in set(tags[:n])},
+            'launches_per_step': {k: v / steps for k, v in cnt.items()}, 'truncated_records': int(dropped), 'by_tag': {t: sum(share[i] for i in range(n) if tags[i] == t) / steps for t in set(tags[:n])},
             'what': 'exclusive time per kernel family: %d untimed steps with every hooked launch and phase recorded; an instant shared by k '
                     'running launches counts 1/k for each' % steps}
 
@@ -547,7 +549,7 @@ def main_models(args, world, rank, dev, json_fd, use_dist):
     for _ in range(2):
         run_step()
     if prof:
-        _c, _m, _f, _b = (ctypes.c_int * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
+        _c, _m, _f, _b = (ctypes.c_int * N_TAGS)(), (ctypes.c_double * N_TAGS)(), (ctypes.c_double * N_TAGS)(), (ctypes.c_double * N_TAGS)()
         _lib.check(lib.recnow_prof_collect(_c, _m, _f, _b), 'recnow_prof_collect')
         _lib.check(lib.recnow_prof_sample_every(1), 'recnow_prof_sample_every')
     sync()
@@ -559,7 +561,7 @@ def main_models(args, world, rank, dev, json_fd, use_dist):
     gc.enable()
     roofline = None
     if prof:
-        cnt, ms, fl, by = (ctypes.c_int * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
+        cnt, ms, fl, by = (ctypes.c_int * N_TAGS)(), (ctypes.c_double * N_TAGS)(), (ctypes.c_double * N_TAGS)(), (ctypes.c_double * N_TAGS)()
         _lib.check(lib.recnow_prof_collect(cnt, ms, fl, by), 'recnow_prof_collect')
         lib.recnow_prof_enable(0)
     account = step_account(lib, run_step, sync, steps=4) if prof else None
@@ -832,6 +834,8 @@ def main():
 
     # host legs (CPU baseline, fp64 gate): threads from the cgroup's CPU share, not from the 256 logical CPUs a GPU box shows
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, 2 * cpu_share()) // max(world, 1)))
+    from rec_now_amd import _lib as _l0
+    assert _l0.load().recnow_prof_tag_count() <= N_TAGS, 'recnow_prof_collect fills more tags than bench.py has room for'
     if args.config != 'c3':
         return main_models(args, world, rank, dev, json_fd, use_dist)
     from rec_now_amd import _lib, dp
@@ -996,7 +1000,7 @@ def main():
             for _ in range(10):
                 step()
             torch.cuda.synchronize()
-            hook_pre = tuple((ctypes.c_int * 16)() if i == 0 else (ctypes.c_double * 16)() for i in range(4))
+            hook_pre = tuple((ctypes.c_int * N_TAGS)() if i == 0 else (ctypes.c_double * N_TAGS)() for i in range(4))
             _lib.check(lib.recnow_prof_collect(*hook_pre), 'recnow_prof_collect')
             lib.recnow_prof_enable(0)
             mark('eager hook steps done')
@@ -1061,7 +1065,7 @@ def main():
     for _ in range(rewarm):
         run_step()
     if prof:
-        _c, _m, _f, _b = (ctypes.c_int * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)(), (ctypes.c_double * 16)()
+        _c, _m, _f, _b = (ctypes.c_int * N_TAGS)(), (ctypes.c_double * N_TAGS)(), (ctypes.c_double * N_TAGS)(), (ctypes.c_double * N_TAGS)()
         _lib.check(lib.recnow_prof_collect(_c, _m, _f, _b), 'recnow_prof_collect')      # (synchronises; rewinds the sample pool)
         _lib.check(lib.recnow_prof_sample_every(prof_every), 'recnow_prof_sample_every')
     sync()
@@ -1088,10 +1092,10 @@ def main():
         prof_note = 'every %dth hooked launch of 10 EAGER steps run before the graphs were captured (the timed steps replay HIP graphs)' % PROF_EVERY
         cnt, ms, fl, by = hook_pre
     if prof and not hook_done:               # collected and switched off HERE: the samples are launches of the timed steps only
-        cnt = (ctypes.c_int * 16)()          # the library fills RN_TAG_MAX (= 12) entries
-        ms = (ctypes.c_double * 16)()
-        fl = (ctypes.c_double * 16)()
-        by = (ctypes.c_double * 16)()
+        cnt = (ctypes.c_int * N_TAGS)()          # the library fills RN_TAG_MAX (= 12) entries
+        ms = (ctypes.c_double * N_TAGS)()
+        fl = (ctypes.c_double * N_TAGS)()
+        by = (ctypes.c_double * N_TAGS)()
         _lib.check(lib.recnow_prof_collect(cnt, ms, fl, by), 'recnow_prof_collect')
         lib.recnow_prof_enable(0)
     # diagnostic: host time to ENQUEUE a step (no synchronisation inside): well below ms_per_step = the step is GPU-bound
@@ -1178,6 +1182,7 @@ def main():
                 roofline['exclusive_ms_per_step'] = account['per_step_ms']
                 roofline['exclusive_covered_ms_per_step'] = account['covered_ms_per_step']
                 roofline['exclusive_note'] = account['what']
+                roofline['exclusive_truncated_records'] = account['truncated_records']
     # ---- the OTHER arithmetic, same run, same buffers (untimed by the headline): `exact_f32` beside a split-precision headline and vice versa
     other = None
     if pstep is not None and graph is None and not args.no_input_grad:

@@ -10,7 +10,8 @@
  * Conventions
  *   - plain pointers + sizes only; every pointer is DEVICE memory (hipMalloc'ed / torch CUDA tensor storage) unless
  *     the parameter name ends in _host.  The caller owns every buffer; the library never allocates or frees.
- *   - every entry point is asynchronous on `stream` (a hipStream_t passed as void*), stateless and re-entrant.
+ *   - every entry point is asynchronous on `stream` (a hipStream_t passed as void*), stateless and re-entrant -- with the three
+ *     process-wide settings and the one host-side note listed under "Library state" below.
  *   - return value: 0 = ok, negative = RECNOW_E*, positive = a forwarded hipError_t.  No C++ exception crosses.
  *   - scratch memory: `*_workspace_bytes(...)` is queried first, the caller passes `ws`/`ws_bytes`.
  *   - all matrices are row-major, fp32 unless stated; index outputs are int32, counts are int64.
@@ -391,6 +392,18 @@ int recnow_dcn_step_bwd(const float* x0, const float* xl, const float* w, const 
  * The two D-sized contractions per layer run on the exact-fp32 MFMA GEMM with the gate logits folded in as extra
  * columns and the gate-weighted bias folded in as extra K rows; `saved` keeps the small (B x ~(N*S+N)) activations
  * and the layer inputs for backward.
+ *
+ * Library state (the whole of it).
+ *   - Process-wide settings: recnow_set_gemm_precision, recnow_set_gemm_staging, recnow_prof_* (one launching thread per process is the model).
+ *   - One host-side NOTE per `saved` buffer of the DCN-v2 entries, keyed by the buffer's ADDRESS (a table of 256 entries under a mutex,
+ *     csrc/dcnmix.hip): which weight packs / piece planes the forward that filled it left there, because the route rule (batch size,
+ *     precision mode, RECNOW_TILE) is read per call and may differ between a forward and its backward.  Contract: every forward call
+ *     (recnow_dcn_mix_fwd / _score_fwd / the FORWARD phase of recnow_dcn_mix_step) RE-WRITES the note of its `saved` before any backward can read
+ *     it, so a recycled address -- another shape, another allocation -- never meets a stale note; a backward whose `saved` has no note (filled
+ *     by another copy of the library, or more than 256 distinct buffers ago) packs what its route needs itself: slower by one pack launch,
+ *     never wrong.  The note holds no device data and no pointer is dereferenced through it.
+ *   - Thread-local hand-offs between the phases of ONE recnow_dcn_mix_step call (packs written by the GROUP phase's front kernel, the piece
+ *     planes of the next product): consumed inside the call that set them.
  * ---------------------------------------------------------------------------------------------------------- */
 size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int L);
 size_t recnow_dcn_mix_workspace_bytes(int64_t B, int D, int S, int N, int L);
@@ -658,6 +671,10 @@ int recnow_prof_collect(int* count_host, double* ms_host, double* flops_host, do
  * the phase tags 13 (grouping), 14 (loss stage), 15 (packs, layer-end reductions): the timeline from which a caller tells overlapping
  * launches of two streams apart. */
 int recnow_prof_intervals(int* tag_host, double* t0_ms_host, double* t1_ms_host, int capacity);
+/* (ABI 6) Entries of the per-tag arrays recnow_prof_collect fills -- size the host arrays from this -- and the number of records that found the pool full
+ * since the last recnow_prof_enable / the last call (non-zero: the totals and intervals under-report; re-arm with a larger capacity). */
+int recnow_prof_tag_count(void);
+int recnow_prof_dropped(void);
 
 /* HIP events owned through the C ABI (timing disabled): the layer_events_host of recnow_dcn_mix_score_bwd.  A host framework
  * whose event type is created lazily (torch.cuda.Event) cannot hand a handle over before the first record. */

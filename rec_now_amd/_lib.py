@@ -105,6 +105,8 @@ SIGNATURES = {
     'recnow_prof_sample_every': (_I, [_I]),
     'recnow_prof_collect': (_I, [_P, _P, _P, _P]),
     'recnow_prof_intervals': (_I, [_P, _P, _P, _I]),
+    'recnow_prof_tag_count': (_I, []),
+    'recnow_prof_dropped': (_I, []),
     'recnow_event_create': (_I, [_P]),
     'recnow_event_destroy': (_I, [_P]),
     'recnow_event_record': (_I, [_P, _P]),
@@ -131,7 +133,7 @@ class GemmDesc(ctypes.Structure):
         ('E4', _P), ('E5', _P), ('E6', _P),
     ]
 
-ABI_VERSION = 5      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)
+ABI_VERSION = 6      # the recnow_abi_version() the SIGNATURES above were written for (csrc/abi.hip)
 
 class StepDesc(ctypes.Structure):
     """recnow_dcn_mix_step_desc of include/recnow.h."""

@@ -6,14 +6,17 @@ static std::vector<RnProfRecord> g_pool;
 static size_t g_used = 0;
 static int g_every = 1;          // time one launch in g_every (timing events serialise the stream around the launch)
 static unsigned g_seq = 0;
+static int g_dropped = 0;         // records wanted while the pool was full (since the last enable / collect)
 
 bool rn_prof_on() { return g_on; }
 
 RnProfRecord* rn_prof_begin(int tag, double flops, double bytes, hipStream_t st) {
-    if (!g_on || g_used >= g_pool.size()) return nullptr;
+    if (!g_on) return nullptr;
     if (tag >= RN_TAG_FIRST_PHASE && g_every != 1) return nullptr;      // phase tags: every-launch mode only (prof.hpp)
     if ((g_seq++ % (unsigned)g_every) != 0) return nullptr;
+    if (g_used >= g_pool.size()) { ++g_dropped; return nullptr; }
     RnProfRecord* r = &g_pool[g_used++];
+    r->closed = false;
     r->tag = tag;
     r->flops = flops;
     r->bytes = bytes;
@@ -21,7 +24,7 @@ RnProfRecord* rn_prof_begin(int tag, double flops, double bytes, hipStream_t st)
     return r;
 }
 void rn_prof_end(RnProfRecord* r, hipStream_t st) {
-    if (r) (void)hipEventRecord(r->e1, st);
+    if (r) { (void)hipEventRecord(r->e1, st); r->closed = true; }
 }
 
 // capacity > 0: (re)arm with that many launch slots; capacity == 0: disable and free.
@@ -32,6 +35,7 @@ extern "C" int recnow_prof_enable(int capacity) {
     }
     g_pool.clear();
     g_used = 0;
+    g_dropped = 0;
     g_on = false;
     if (capacity <= 0) return RECNOW_OK;
     g_pool.resize((size_t)capacity);
@@ -62,6 +66,7 @@ extern "C" int recnow_prof_collect(int* count_host, double* ms_host, double* flo
     }
     for (size_t i = 0; i < g_used; ++i) {
         RnProfRecord& r = g_pool[i];
+        if (!r.closed) continue;             // (an error return between begin and end: e1 was never recorded)
         RN_HIP(hipEventSynchronize(r.e1));
         float ms = 0.f;
         RN_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
@@ -76,6 +81,11 @@ extern "C" int recnow_prof_collect(int* count_host, double* ms_host, double* flo
     return RECNOW_OK;
 }
 
+// Entries of the per-tag arrays recnow_prof_collect fills (a caller sizes its host arrays from this instead of a literal), and the records that
+// found the pool full since the last recnow_prof_enable / the last call of this function (a non-zero value: the totals under-report).
+extern "C" int recnow_prof_tag_count(void) { return RN_TAG_MAX; }
+extern "C" int recnow_prof_dropped(void) { const int d = g_dropped; g_dropped = 0; return d; }
+
 
 // Synchronises and returns the recorded launches one by one: tag and [t0, t1] in milliseconds after the FIRST record's start (events of
 // different streams of one device share a clock).  With recnow_prof_sample_every(1) this is the timeline of every hooked launch and phase:
@@ -86,6 +96,7 @@ extern "C" int recnow_prof_intervals(int* tag_host, double* t0_ms_host, double* 
     int n = 0;
     for (size_t i = 0; i < g_used && n < capacity; ++i) {
         RnProfRecord& r = g_pool[i];
+        if (!r.closed) continue;
         if (hipEventSynchronize(r.e1) != hipSuccess) return RECNOW_EINVAL;
         float a = 0.f, b = 0.f;
         if (i > 0 && hipEventElapsedTime(&a, g_pool[0].e0, r.e0) != hipSuccess) return RECNOW_EINVAL;

@@ -8,6 +8,7 @@ struct RnProfRecord {
     double flops;       // algorithmic flops of the launch
     double bytes;       // algorithmic HBM bytes of the launch (operands read once + outputs written once)
     hipEvent_t e0, e1;
+    bool closed;        // rn_prof_end has recorded e1 (a launch path that returned an error in between leaves a half-open record: skipped by the readers)
 };
 #define RN_TAG_GEMM_128x128 1
 #define RN_TAG_GEMM_128x160 2

@@ -252,6 +252,8 @@ class LayerwiseReducer(object):
         # weight-gradient products: the stages' events then fire within ~40 us of each other at the end of the pass, so
         # three 1 MB ring all-reduces (latency-bound: ~3 x (2 (N-1) hops x ~2 us + 2 x 1.06 MB (N-1)/N / 153 GB/s) each) queue up behind the
         # step, where one 3.2 MB all-reduce pays the hop latency once.  Which wins is a property of the node: the switch makes it an A/B.
+        # Applies to the IN-PLACE protocol only (`stage_done` / `reduce_in_place`, what step.DCNMixPairwiseStep drives): the autograd-route `reduce()` keeps
+        # one collective per stage whatever this says.
         self.one_collective = (_os.environ.get('RECNOW_DP_ONE_BUCKET') == '1') if one_collective is None else bool(one_collective)
         self._flat, self._view = [], {}
         # the stages' buckets are slices of ONE allocation (each starting on a 16-byte boundary): per-stage collectives see their own
