@@ -785,6 +785,7 @@ def main():
                          "'auto' (default): whichever is faster at this shard size under that gate -- bf16x3 from 32 768 rows per GPU (product route), "
                          "f32 below (row-block kernels).  The other mode's step time is measured in the same run and reported beside the headline "
                          "(`exact_f32` / `split_precision` at the end of the JSON line)")
+    ap.add_argument('--no-other', action='store_true', help='do not time the other arithmetic of the products behind the headline (profiling runs: one kernel family per trace)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl', help="process-group backend: 'nccl' (= RCCL over xGMI, the product path); 'gloo' is a "
                     'diagnostic that lets several ranks share one GPU (with --oversubscribe), so that the N > 1 step, reducer and cross-rank gate run with real '
@@ -1185,7 +1186,7 @@ def main():
                 roofline['exclusive_truncated_records'] = account['truncated_records']
     # ---- the OTHER arithmetic, same run, same buffers (untimed by the headline): `exact_f32` beside a split-precision headline and vice versa
     other = None
-    if pstep is not None and graph is None and not args.no_input_grad:
+    if pstep is not None and graph is None and not args.no_input_grad and not args.no_other:
         other_mode = 'f32' if precision == 'bf16x3' else 'bf16x3'
         _lib.call('recnow_set_gemm_precision', 1 if other_mode == 'bf16x3' else 0)
         for _ in range(max(rewarm, 5)):

@@ -591,3 +591,29 @@ print('poisoned ok')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=root,
                          env=dict(os.environ, RECNOW_DEBUG_GROUP_TIMEOUT='1', PYTHONPATH=root))
     assert out.returncode == 0 and 'poisoned ok' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_cooperative_grouping_beside_a_cu_filling_kernel(dev):
+    """the single-launch grouping (k_group_mid: a plain launch whose grid barrier counts on its workgroups being co-resident, gated
+    on an occupancy query) started while ANOTHER stream keeps every CU busy with long fp32 products -- the situation of a grouping launched beside the
+    step's GEMMs or RCCL's persistent kernels.  Its workgroups then become resident as slots free up; the bounded barrier must not time out
+    (n_seg >= 0) and the segments must equal those of a quiet run.  65 536 rows, ~1024 groups."""
+    from rec_now_amd.rec_block.pairwise_loss_from_batch import group_rows
+    rng = np.random.default_rng(123)
+    B = 65536
+    g = torch.from_numpy(rng.integers(0, 1024, B).astype(np.float32)).to(dev)
+    quiet = group_rows(g)
+    torch.cuda.synchronize()
+    n_quiet = quiet.num_segments()
+    a = torch.randn(8192, 8192, device=dev)
+    busy, side = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(busy):
+        for _ in range(6):                 # ~50 ms of CU-filling work
+            a = (a @ a) * 1e-4
+    with torch.cuda.stream(side):
+        under = [group_rows(g) for _ in range(4)]
+    torch.cuda.synchronize()
+    for s in under:
+        assert s.num_segments() == n_quiet >= 1000          # raises on a barrier time-out (n_seg = -1)
+        assert torch.equal(s.order, quiet.order) and torch.equal(s.seg_id, quiet.seg_id) and torch.equal(s.seg_first[:n_quiet + 1], quiet.seg_first[:n_quiet + 1])

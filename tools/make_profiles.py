@@ -9,7 +9,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 
@@ -84,6 +84,8 @@ with open('profiles/%s_bench_pmc_hbm.csv' % tag, 'w') as fo:
         w.writerow([k, n, '%.1f' % fv, '%.1f' % wv, '%.0f' % b])
         m = re.match(r'void k_gemm<(\d+), (\d+), (\d+), (\d+),', k)
         other = [f for f in ('k_gemm_shortk', 'k_mix_mid_fwd', 'k_mix_mid_bwd', 'k_gemm_split') if k.startswith('void %s<' % f) or k.startswith('void %s_fast<' % f)]
+        if k.startswith('void k_gemm_s3<'):       # round 6: the lean form of the split long-K product: one family with k_gemm_split (bench.py tag 8)
+            other = ['k_gemm_split']
         if m or other:      # the persistent short-K kernel and the sub-space kernels are families of their own (bench.py *_TAGS)
             key = 'k_gemm<%s,%s,%s,%s>' % m.groups() if m else other[0]
             fam[key][0] += n
@@ -116,6 +118,18 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
     fo.write('**HBM traffic of one step (PMC, `%s_bench_pmc_hbm.csv`): %.2f GB** = the sum over every dispatch of the counter run of (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes, '
              'divided by its %d steps (algorithmic: 1.34 GB; round 4: 11.3 GB -- the input gradient is now written once by layer 0\'s product instead of as a '
              'read-modify-write in the product of every layer).\n\n' % (tag, traffic_step_gb, n_steps_pmc))
+    spl = [r for r in rows if r['Name'].startswith(('void k_gemm_s3<', 'void k_gemm_split<'))]
+    if spl:      # round 6: the headline step runs the six-term split products
+        savg = sum(r['TotalDurationNs'] for r in spl) / sum(r['Calls'] for r in spl) / 1e3
+        peak6 = 16 * 157.3 / 6
+        fo.write('**The long-K products of the headline step (`k_gemm_s3<..>` / `k_gemm_split<..>`: fp32 operands as three bf16 pieces, six bf16 MFMA terms per product)**: '
+                 'rocprofv3 average over their %d launches in this profiled run %.1f us = %.3f of %.1f TFLOP/s (dense bf16 peak / 6 terms; 17.45 GFLOP per launch)'
+                 % (sum(r['Calls'] for r in spl), savg, 17.448 / savg / peak6 * 1e3, peak6))
+        if hook and hook.get('roofline') and hook['roofline'].get('kernel') == 'k_gemm_split':
+            fo.write('; the library\'s own HIP-event hook inside the same profiled run %.1f us = %.3f (step %.3f ms)' % (hook['roofline']['avg_launch_us'], hook['roofline']['frac'], hook['ms_per_step']))
+        if clean and clean.get('roofline') and clean['roofline'].get('kernel') == 'k_gemm_split':
+            fo.write('; the hook in the UNPROFILED run (`%s_bench.json`) %.1f us = %.3f, step %.3f ms' % (tag, clean['roofline']['avg_launch_us'], clean['roofline']['frac'], clean['ms_per_step']))
+        fo.write('.  By instantiation: %s.\n\n' % '; '.join('`%s` %.1f us x %d' % (r['Name'][5:r['Name'].index('(')], float(r['AverageNs']) / 1e3, r['Calls']) for r in spl))
     gem = [r for r in rows if 'k_gemm<128, 128' in r['Name'] and ', 25>' not in r['Name']]      # (the ', 25>' instantiation: GEMM1 + sub-space forward, listed on its own)
     if gem:
         gavg = sum(r['TotalDurationNs'] for r in gem) / sum(r['Calls'] for r in gem) / 1e3
@@ -182,7 +196,11 @@ with open('profiles/%s_bench_summary.md' % tag, 'w') as fo:
         shutil.copy(pg, 'profiles/%s_bench_rows8192_graph.json' % tag)
         fo.write('\n8192 rows replayed from per-piece HIP graphs (`--graph`): %.3f ms/step, host %.3f ms.\n' % (d['ms_per_step'], d['config']['host_enqueue_ms_per_step']))
 shutil.copy('gpurun_out/%s_bench.json' % tag, 'profiles/%s_bench.json' % tag)
-for extra in ('bench_unfused', 'bench_autograd', 'bench_bf16x3', 'layer_bench'):
+try:      # the exact-fp32 step's own kernel trace
+    trace_stats(newest('gpurun_out/%s_stats_f32/*/*_kernel_trace.csv' % tag), 'profiles/%s_bench_f32_kernel_stats.csv' % tag)
+except (IndexError, StopIteration, ValueError):
+    pass
+for extra in ('bench_unfused', 'bench_autograd', 'bench_bf16x3', 'bench_f32', 'bench_c4', 'bench_c5', 'layer_bench'):
     for ext in ('json', 'txt'):
         src = 'gpurun_out/%s_%s.%s' % (tag, extra, ext)
         if os.path.exists(src):
