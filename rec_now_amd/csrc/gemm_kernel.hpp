@@ -534,6 +534,10 @@ k_gemm(const GemmK p) {
     // half the FMAs and half the LDS bytes of the weights; the side product costs 15 us of a 180 us launch in its four-wide form
     using SPV = std::conditional_t<(XF & 8) != 0, f32x2, f32x4>;
     SPV spn = SPV(0.f);
+    // sliced kernels: `spn` holds ONE k-tile's terms of the side product (fp32 FMAs); the running sum over the k-tiles is fp64 (`spd`, one v_cvt +
+    // one v_add_f64 per column and k-tile).  With fp32 running sums the layer-0 gate logits of the north-star step (512 sequential FMAs per thread,
+    // |logit| up to 39 on bench.py's parity inputs) were the largest single consumer of the 1e-5 parity budget (tools/micro/error_budget_cpu.py).
+    double spd[(XF & 8) != 0 ? 2 : 4] = {};
     float bxr[4] = {0.f, 0.f, 0.f, 0.f};
 
 #ifdef RN_GEMM_TRACE      // per-workgroup phase timestamps for tools/gemm_trace.py (build with RECNOW_TRACE=1)
@@ -852,6 +856,15 @@ k_gemm(const GemmK p) {
                 __builtin_amdgcn_sched_barrier(0);
                 sa0 = na0; sa1 = na1; sb0 = nb0; sb1 = nb1;
             }
+            if constexpr ((XF & 1) != 0) {      // this k-tile's terms join the fp64 running sums
+                spd[0] += (double)spn.x;
+                spd[1] += (double)spn.y;
+                if constexpr ((XF & 8) == 0) {
+                    spd[2] += (double)spn.z;
+                    spd[3] += (double)spn.w;
+                }
+                spn = SPV(0.f);
+            }
         } else
         for (int kk = 0; kk < kv; kk += 4) {
 #pragma unroll
@@ -908,8 +921,8 @@ k_gemm(const GemmK p) {
         for (int t = 0; t < ntile; ++t) ktile_body(t, t & 1);
     }
     if constexpr ((XF & 1) != 0 && SLICED) {
-        if constexpr ((XF & 8) != 0) spacc = mk4(spn.x, spn.y, 0.f, 0.f);
-        else spacc = spn;
+        if constexpr ((XF & 8) != 0) spacc = mk4((float)spd[0], (float)spd[1], 0.f, 0.f);
+        else spacc = mk4((float)spd[0], (float)spd[1], (float)spd[(XF & 8) != 0 ? 0 : 2], (float)spd[(XF & 8) != 0 ? 1 : 3]);
     }
     if constexpr ((XF & 1) != 0) {
         // combine the k-parts of a row through LDS (free now) and write the side columns

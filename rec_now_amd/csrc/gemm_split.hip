@@ -375,7 +375,11 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float sp0 = 0.f, sp1 = 0.f;
+    // side product (the gate logits of a cross layer when this is GEMM1): the 8 terms of a thread's unit are summed in fp32, the running sum over the
+    // k-tiles is kept in fp64 (2 v_cvt + 2 v_add_f64 per k-tile).  Why: with fp32 running sums (512 sequential FMAs per thread) the layer-0 logits of
+    // bench.py's parity inputs (|logit| up to 39) carried an absolute error of 3.5e-6 rms -- row-wide gate errors up to 5.7e-6, by themselves
+    // 1.2e-5 of max|d loss / d x| in the worst row of 65 536 (tools/micro/error_budget_cpu.py); this form leaves 2.5e-7 rms.
+    double sp0 = 0.0, sp1 = 0.0;
     float va[2][8], ya[A2K != RECNOW_OPMODE_NONE ? 2 : 1][8];
     u32x4 bpl[3], wq[3];
 
@@ -433,13 +437,18 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
         f32x4 q[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) q[e] = *reinterpret_cast<const f32x4*>(b + 4 * e);
+        float t0 = v[0] * q[0].x, t1 = v[0] * q[0].y;
+        t0 = fmaf(v[1], q[0].z, t0);
+        t1 = fmaf(v[1], q[0].w, t1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sp0 = fmaf(v[2 * e], q[e].x, sp0);
-            sp1 = fmaf(v[2 * e], q[e].y, sp1);
-            sp0 = fmaf(v[2 * e + 1], q[e].z, sp0);
-            sp1 = fmaf(v[2 * e + 1], q[e].w, sp1);
+        for (int e = 1; e < 4; ++e) {
+            t0 = fmaf(v[2 * e], q[e].x, t0);
+            t1 = fmaf(v[2 * e], q[e].y, t1);
+            t0 = fmaf(v[2 * e + 1], q[e].z, t0);
+            t1 = fmaf(v[2 * e + 1], q[e].w, t1);
         }
+        sp0 += (double)t0;
+        sp1 += (double)t1;
     };
     auto split_pairs = [&](const float (&v)[8], int e0) {
 #pragma unroll
@@ -558,14 +567,12 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
     if (A_KC) {
         sp0 += __shfl_xor(sp0, 1);
         sp1 += __shfl_xor(sp1, 1);
-        if ((tid & 1) == 0) side_out(m0 + a_row, sp0, sp1);
+        if ((tid & 1) == 0) side_out(m0 + a_row, (float)sp0, (float)sp1);
     } else {
-        if (tid >= 128) *reinterpret_cast<f32x2*>(smem + (tid - 128) * 2) = f32x2{sp0, sp1};
+        double* const dsm = reinterpret_cast<double*>(spl_smem);
+        if (tid >= 128) { dsm[(tid - 128) * 2] = sp0; dsm[(tid - 128) * 2 + 1] = sp1; }
         __syncthreads();
-        if (tid < 128) {
-            const f32x2 o = *reinterpret_cast<const f32x2*>(smem + tid * 2);
-            side_out(m0 + tid, sp0 + o.x, sp1 + o.y);
-        }
+        if (tid < 128) side_out(m0 + tid, (float)(sp0 + dsm[tid * 2]), (float)(sp1 + dsm[tid * 2 + 1]));
         __syncthreads();
     }
     gemm_lean_epilogue<2, 2, 0>(p, acc, smem, m0, 0, wm, wn, lane, wave, z, 0);
