@@ -1203,7 +1203,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         o_el = float(tt.item())
         other = {'gemm_precision': other_mode, 'ms_per_step': o_el * 1e3 / args.steps, 'value': total_rows * args.steps / o_el, 'unit': 'samples/s',
-                 'steps': args.steps, 'route': 'row-block persistent kernels' if pstep.tile_route() else 'one launch per product',
+                 'steps': args.steps, 'route': {1: 'row-block persistent kernels', 2: 'row-block persistent forward (k_mix_tile_fwd_s3) + one launch per product in the backward'}.get(pstep.route_code(), 'one launch per product'),
                  'note': 'the same step on the same buffers with the other arithmetic of the products, timed after the headline (its own warm-up, '
                          'barrier + synchronize on both sides, max over the ranks); parity of this mode: tests/test_step_gpu.py, tests/test_northstar_gpu.py'}
         _lib.call('recnow_set_gemm_precision', 1 if precision == 'bf16x3' else 0)
@@ -1371,7 +1371,9 @@ def main():
                        'rows_per_gpu': rows, 'rows_per_rank': rank_rows,
                        'global_batch': total_rows, 'input_grad': not args.no_input_grad, 'hip_graph': bool(use_graph), 'parallelism': 'dp%d' % world,
                        'route': ('whole-step entry recnow_dcn_mix_step (one C call per phase; cross layers: %s; grouping of the batch: %s)'
-                                 % ('row-block persistent kernels k_mix_tile_fwd / k_mix_tile_bwd' if pstep.tile_route() else 'one launch per product (k_gemm / k_gemm_shortk)',
+                                 % ({1: 'row-block persistent kernels k_mix_tile_fwd / k_mix_tile_bwd',
+                                     2: 'forward: ONE row-block persistent launch on the bf16 MFMA (k_mix_tile_fwd_s3); backward: one launch per product (k_gemm_s3 / k_gemm_split / k_gemm_shortk)'}
+                                    .get(pstep.route_code(), 'one launch per product (k_gemm / k_gemm_shortk)'),
                                     {'side': 'on a side stream under the forward pass', 'inline': 'on the main stream in front of the forward pass',
                                      'after': 'on the main stream behind the forward pass'}.get(getattr(pstep, 'group_mode', 'side'), '?'))
                                  + (', replayed from HIP graphs' if use_graph else '') + (', weight-gradient products on a second stream' if two_streams else '')

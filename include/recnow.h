@@ -435,7 +435,8 @@ int recnow_dcn_mix_score_supported(int64_t B, int D, int S, int N, int L);
 /* 1 when a step / score / layer call of this shape runs the row-block persistent kernels (csrc/dcnmix_tile.hip: two experts of 64,
  * D in {256, 512, 1024}, batches up to 16 384 rows; RECNOW_TILE=0 / =1 and the precision mode are read at every call): the ONE
  * statement of that rule -- callers that place other work around the cross layers (rec_now_amd/step.py: where the grouping of the
- * batch runs) ask here instead of restating it. */
+ * batch runs) ask here instead of restating it.  2 (round 6): split-precision mode with the FORWARD pass of all cross layers as one
+ * row-block launch on the bf16 MFMA (csrc/dcnmix_tile_split.hip; RECNOW_TILE_SPLIT=0 / =1) and the backward pass one launch per product. */
 int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L);
 int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_host, const float* const* V_host, const float* const* W_host,
                              const float* const* bias_host, const float* const* gate_host, const float* head_w, const float* head_b,

@@ -176,6 +176,9 @@ static inline size_t mix_plane_long(const MixDims& m) { return rn_gemm_split_pla
 static inline size_t mix_plane_short(const MixDims& m) { return rn_gemm_split_planes_bytes(m.KP, m.D); }
 static inline size_t mix_planes_bytes(const MixDims& m) { return mix_planes_shape(m) ? (size_t)m.L * 2 * (mix_plane_long(m) + mix_plane_short(m)) : 0; }
 static inline size_t mix_planes_off(const MixDims& m) { return mix_tile_pack_off(m) + mix_tile_pack_bytes(m); }
+// Round 6, second session: the fragment-ordered piece planes of the split-precision row-block forward (dcnmix_tile_split.hip), behind the planes above
+static inline size_t mix_tile_split_bytes(const MixDims& m) { return mix_tile_shape(m) ? rn_mix_tile_split_pack_bytes(m.D, m.S, m.N, m.L, m.LDT) : 0; }
+static inline size_t mix_tile_split_off(const MixDims& m) { return mix_planes_off(m) + mix_planes_bytes(m); }
 static inline char* mix_plane(const MixDims& m, const void* saved, int l, int which) {      // which: 0 = P1, 1 = P2, 2 = P3, 3 = P4
     char* base = (char*)saved + mix_planes_off(m) + (size_t)l * 2 * (mix_plane_long(m) + mix_plane_short(m));
     return base + (which == 0 ? 0 : which == 1 ? mix_plane_long(m) : which == 2 ? mix_plane_long(m) + mix_plane_short(m) : 2 * mix_plane_long(m) + mix_plane_short(m));
@@ -190,6 +193,18 @@ static bool mix_tile_on(const MixDims& m, bool maybe = false) {
     const int mode = e ? atoi(e) : -1;
     if (mode == 0 || !mix_tile_shape(m) || (!maybe && rn_gemm_precision() != 0)) return false;
     return mode == 1 || m.B <= MIX_TILE_MAX_B;
+}
+
+// Split-precision products (recnow_set_gemm_precision(1)): the FORWARD pass of all cross layers as one row-block launch on the bf16 MFMA
+// (k_mix_tile_fwd_s3), the backward pass stays on the launch-per-product route (which then finds the saved activations, O_l and x_{l+1} exactly where
+// the product-route forward leaves them).  RECNOW_TILE_SPLIT: 0 off, 1 every supported batch; default: see MIX_TILE_SPLIT_MIN_B.
+#define MIX_TILE_SPLIT_MIN_B (1ll << 62)
+static bool mix_tile_split_on(const MixDims& m) {
+    if (rn_gemm_precision() != 1 || !mix_tile_shape(m)) return false;
+    const char* e = getenv("RECNOW_TILE_SPLIT");          // read per call (tests switch the route inside one process)
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 0) return false;
+    return mode == 1 || m.B >= MIX_TILE_SPLIT_MIN_B;
 }
 
 // The row-block backward chain walks all its layers in one launch and leaves g_l of EVERY layer for the weight-gradient products behind it: the two
@@ -231,7 +246,7 @@ extern "C" size_t recnow_dcn_mix_saved_bytes(int64_t B, int D, int S, int N, int
     const MixDims m = mix_dims(B, D, S, N, L);
     // exact path: O_l = T2g_l [W; b] of every layer is kept next to x_{l+1} = x * O_l (second output of GEMM3), so the
     // backward forms dx = sum_l g_l * O_l inside kernels that stream g_l anyway instead of recomputing the products.
-    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + mix_pack_bytes(m) + mix_tile_pack_bytes(m) + mix_planes_bytes(m) + 256;
+    return (size_t)L * 3 * act_block(m) + (size_t)(L - 1) * xbuf(m) + (m.exact ? (size_t)L * xbuf(m) : 0) + mix_pack_bytes(m) + mix_tile_pack_bytes(m) + mix_planes_bytes(m) + mix_tile_split_bytes(m) + 256;
 }
 
 // Round 4: x_{l+1} = x0 * O_l is NOT materialised between the cross layers of the exact path (two experts).  The product that leaves layer l
@@ -577,7 +592,8 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
     mix_stamp_put(saved, (pack_product ? MIX_HAS_PRODUCT_PACKS : 0) | (tile_fwd ? MIX_HAS_TILE_PACKS : 0) | (planes_on ? MIX_HAS_SPLIT_PLANES | (head ? MIX_PLANES_HEAD : 0) : 0));
     const float* xl = x;
     const bool xless = mix_xless(m);
-    if (tile_fwd) {       // every layer (+ the scoring head) in one launch of row-block workgroups
+    const bool tile_split = !tile_fwd && mix_tile_split_on(m) && (y || head);
+    if (tile_fwd || tile_split) {       // every layer (+ the scoring head) in one launch of row-block workgroups
         RnTileFwd t;
         memset(&t, 0, sizeof(t));
         t.x = x; t.B = B; t.D = D; t.L = L; t.act_inner = act_inner; t.act_outer = act_outer;
@@ -593,6 +609,10 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
         if (head) { t.head_w = head->w; t.head_b = head->b; t.scores = head->scores; }
         t.packed = (tl_step_tile_packed != nullptr && tl_step_tile_packed == (const void*)saved) ? 1 : 0;
         tl_step_tile_packed = nullptr;
+        if (tile_split) {
+            t.splanes = sv + mix_tile_split_off(m);
+            return rn_mix_tile_fwd_split(t, st);
+        }
         return rn_mix_tile_fwd(t, st);
     }
     for (int l = 0; l < L; ++l) {
@@ -742,7 +762,8 @@ int rn_group_mid_raw(const void* group, int dtype, int64_t B, uint8_t* solo, int
 
 extern "C" int recnow_dcn_mix_tile_route(int64_t B, int D, int S, int N, int L) {
     if (B <= 0 || D < 1 || S < 1 || N < 1 || L < 1 || N > 64) return 0;
-    return mix_tile_on(mix_dims(B, D, S, N, L)) ? 1 : 0;
+    const MixDims m = mix_dims(B, D, S, N, L);
+    return mix_tile_on(m) ? 1 : mix_tile_split_on(m) ? 2 : 0;
 }
 
 extern "C" int recnow_dcn_mix_score_fwd(const float* x, const float* const* U_host, const float* const* V_host,

@@ -29,7 +29,15 @@ struct RnTileFwd {
     int64_t B;
     int D, L, act_inner, act_outer;
     int packed;                             // != 0: `packs` are already filled for these weights (the step's front kernel packed them beside the grouping)
+    char* splanes;                          // split-precision forward (dcnmix_tile_split.hip): rn_mix_tile_split_pack_bytes, or NULL
 };
+// split-precision forward: piece planes of the weights in fragment order (16-byte units of 8 bf16), per layer [P1s: 3 planes][P2s: 3 planes]
+#define TLS_P1_UNITS(D) ((D) * 16)          // per plane: D / 16 k-steps x 4 column blocks x 64 lanes
+#define TLS_P2_UNITS(D) ((D) * 18)          // per plane: 9 k-steps x D / 32 d-blocks x 64 lanes
+#define TLS_LAYER_BYTES(D) ((size_t)3 * (TLS_P1_UNITS(D) + TLS_P2_UNITS(D)) * 16)
+size_t rn_mix_tile_split_pack_bytes(int D, int S, int N, int L, int LDT);
+// packs the piece planes (one launch) and runs every layer of the forward pass in ONE launch on the bf16 MFMA (three pieces, six terms)
+int rn_mix_tile_fwd_split(const RnTileFwd& p, hipStream_t st);
 #ifdef __HIPCC__
 // P1_l[kg][col][i] = U_l[n = col / 64][d = 4 kg + i][s = col % 64]         (D / 4 x 128 float4)      forward GEMM1, B fragments
 // P2_l[g][h][d][i] = W_l[t = 8 g + 4 h + i][d],  W_l as (N S, D)            (16 x 2 x D float4)       forward output product, A fragments

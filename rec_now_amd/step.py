@@ -130,7 +130,12 @@ class DCNMixPairwiseStep(object):
     def tile_route(self):
         """Whether THIS call's cross layers run the row-block persistent kernels: the library's own rule (csrc/dcnmix.hip `mix_tile_on` through
         recnow_dcn_mix_tile_route: shape, batch, RECNOW_TILE and the precision mode, read per call) -- asked, not restated."""
-        return bool(_lib.load().recnow_dcn_mix_tile_route(*self._shape))
+        return _lib.load().recnow_dcn_mix_tile_route(*self._shape) == 1
+
+    def route_code(self):
+        """recnow_dcn_mix_tile_route of THIS call: 0 one launch per product, 1 row-block kernels in both directions, 2 split-precision row-block forward
+        (csrc/dcnmix_tile_split.hip) in front of the launch-per-product backward."""
+        return int(_lib.load().recnow_dcn_mix_tile_route(*self._shape))
 
     @staticmethod
     def stages_for(cross, head):

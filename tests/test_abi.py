@@ -78,8 +78,11 @@ def test_size_queries_cover_the_row_block_route():
     base_saved = L * 3 * act + (L - 1) * B * D * 4 + L * B * D * 4 + (2 * L + 1) * D * ldt * 4
     # round 6: + the split-precision piece planes of the packed weights (per layer two of D / 8 x 128 and two of 144 / 8 x D units of 16 B, three pieces each)
     planes = L * 2 * (D // 8 * 128 * 48 + 144 // 8 * D * 48)
-    assert sv >= base_saved + packs + planes
-    assert sv < base_saved + packs + planes + (1 << 20)             # alignment slack only
+    # round 6, second session: + the fragment-ordered piece planes of the split-precision row-block forward (csrc/dcnmix_tile_split.hip: per layer three
+    # pieces of D x 16 + D x 18 units of 16 B)
+    tile_planes = L * 3 * (D * 16 + D * 18) * 16
+    assert sv >= base_saved + packs + planes + tile_planes
+    assert sv < base_saved + packs + planes + tile_planes + (1 << 20)             # alignment slack only
     assert ws >= L * act + L * 256 * N * S * S * 4 + 3 * act + 2 * B * D * 4
     # a width without an instantiation (D = 1152: exact-128 path, leading dimension 144) and a batch off the exact path (B % 256 != 0: leading
     # dimension 160, no O_l, no packs at all): what the formulation itself keeps plus alignment slack -- the packs (7 MB / 6 MB) are not in there

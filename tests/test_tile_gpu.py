@@ -74,6 +74,40 @@ def test_tile_forward_vs_oracle_and_product_route(dev, B, D, L, ai, ao):
         close(mixed[k], w64[k].grad, what=k + ' (tile forward, product backward)')
 
 
+# 8448 rows: eight workgroups walk a second block (the weight ring of the next block is requested in the last steps of the block before)
+@pytest.mark.parametrize('B,D,L,ai,ao', [(512, 256, 2, 'tanh', 'tanh'), (1024, 512, 3, 'tanh', 'tanh'), (8448, 1024, 3, 'tanh', 'tanh'),
+                                          (768, 1024, 1, 'relu', 'sigmoid'), (512, 256, 4, None, 'tanh')])
+def test_split_precision_tile_forward_vs_oracle_and_split_product_route(dev, B, D, L, ai, ao):
+    """Split-precision mode with RECNOW_TILE_SPLIT=1: every cross layer + the folded head in ONE row-block launch on the bf16 MFMA (three pieces, six
+    terms: csrc/dcnmix_tile_split.hip), the launch-per-product backward behind it reads what that forward saved -- scores and EVERY gradient against
+    the fp64 oracle at the suite's 1e-5 bound, and against the split-precision product route (another summation order, not bit-identical)."""
+    from rec_now_amd import _lib
+    x, xd, cross, head, w, hk, hb = _build(dev, B, D, 64, 2, L, B + D + L + 1, ai, ao)
+    gs = np.random.default_rng(1).normal(size=B).astype(np.float32)
+    lib = _lib.load()
+    try:
+        _lib.call('recnow_set_gemm_precision', 1)
+        os.environ['RECNOW_TILE_SPLIT'] = '1'
+        assert lib.recnow_dcn_mix_tile_route(B, D, 64, 2, L) == 2
+        tile = _run_fused(dev, cross, head, xd, gs)
+        os.environ['RECNOW_TILE_SPLIT'] = '0'
+        assert lib.recnow_dcn_mix_tile_route(B, D, 64, 2, L) == 0
+        prod = _run_fused(dev, cross, head, xd, gs)
+    finally:
+        os.environ.pop('RECNOW_TILE_SPLIT', None)
+        _lib.call('recnow_set_gemm_precision', 0)
+    rs, x64, w64, hk64, hb64 = _oracle(x, w, hk, hb, L, gs, ai, ao)
+    close(tile['s'], rs, what='scores')
+    close(tile['dx'], x64.grad, what='dx')
+    for k in w:
+        close(tile[k], w64[k].grad, what=k)
+    close(tile['hk'], hk64.grad, what='head kernel')
+    close(tile['hb'], hb64.grad, what='head bias', scale=np.abs(gs).sum())
+    assert not torch.equal(tile['s'], prod['s'])          # two routes, not one route twice
+    for k in tile:
+        close(tile[k], prod[k], rtol=4e-6, what=k + ' split tile forward vs split product route', scale=(np.abs(gs).sum() if k == 'hb' else None))
+
+
 def test_tile_forward_of_the_layer_without_head_and_without_input_gradient(dev):
     """`DCNMixLayer.call` alone (recnow_dcn_mix_fwd: the layer output y leaves the last layer) with x as data: O_{L-1} is not kept."""
     B, D, L = 1536, 1024, 3
