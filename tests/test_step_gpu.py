@@ -201,8 +201,9 @@ def one_rank_rccl(dev):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('B,two_streams', [(8192, False), (8192, True), (16384, True), (32768, True)])
-def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B, two_streams):
+@pytest.mark.parametrize('B,two_streams,one_collective', [(8192, False, False), (8192, True, False), (8192, True, True), (16384, True, False), (32768, True, False),
+                                                          (32768, True, True)])
+def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B, two_streams, one_collective):
     """(8192, 1024), (16 384, 1024) and (32 768, 1024): the 8-, 4- and 2-GPU shards of the metric's batch, step route + LayerwiseReducer over a 1-rank
     RCCL group (every collective runs), eager and replayed from graphs, against the fp64 oracle: loss, pair count, scores,
     d loss / d x and all 17 weight gradients."""
@@ -212,7 +213,9 @@ def test_shard_sizes_through_reducer_vs_oracle(dev, one_rank_rccl, B, two_stream
     D, S, N, L = 1024, 64, 2, 3
     x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 100 + B)
     stages = DCNMixPairwiseStep.stages_for(cross, head)
-    reducer = dp.LayerwiseReducer(stages, [GpuEvent() for _ in stages], dev)
+    # one_collective (RECNOW_DP_ONE_BUCKET=1): ONE all-reduce over all stages behind the last one -- the device path of the switch (waits on every stage's
+    # event, both scale launches on the communication stream), same results as one collective per stage
+    reducer = dp.LayerwiseReducer(stages, [GpuEvent() for _ in stages], dev, one_collective=one_collective)
     # two_streams: the eager step walks all layers in one call, weight-gradient products on a second stream, the library records the
     # stages' events (what bench.py runs under a process group); the replayed graphs are single-stream pieces either way
     step = DCNMixPairwiseStep(cross, head, xd, yd, gd, reducer=reducer, two_streams=two_streams)
@@ -258,13 +261,22 @@ def test_step_route_at_the_metric_batch_vs_oracle(dev):
     rloss, rds, rP = PO.pairwise_bpr(groups, labels, rs.astype(np.float32), grouped=True)
     assert rP > B and abs(rloss - np.log(2.0)) > 1e-3
     _, rdx, rgrads = run_chunked(fwd, torch.from_numpy(x), torch.from_numpy(rds), w64, chunk=4096)
-    for prec in GEMM_PRECISIONS:            # the exact-fp32 products and the six-term split (bench.py's default at this size): one oracle, one bound
+    # the exact-fp32 products and the six-term split (bench.py's default at this size): one oracle, one bound; 'bf16x3 tile': the split-precision row-block
+    # forward (RECNOW_TILE_SPLIT=1, csrc/dcnmix_tile_split.hip) in front of the split products' backward
+    for prec in tuple(GEMM_PRECISIONS) + ('bf16x3 tile',):
         for f in step.grads:
             f.fill_(float('nan'))
         step.dx.fill_(float('nan'))
-        with gemm_precision(prec):
-            loss, n_pair = step.run()
-            torch.cuda.synchronize()
+        tile = prec.endswith(' tile')
+        if tile:
+            os.environ['RECNOW_TILE_SPLIT'] = '1'
+        try:
+            with gemm_precision(prec.split()[0]):
+                assert step.route_code() == (2 if tile else 0)
+                loss, n_pair = step.run()
+                torch.cuda.synchronize()
+        finally:
+            os.environ.pop('RECNOW_TILE_SPLIT', None)
         assert int(n_pair.item()) == rP
         close(step.scores, rs, what='scores ' + prec)
         close(loss, np.float64(rloss), what='loss ' + prec)
