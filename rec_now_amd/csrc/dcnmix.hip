@@ -221,7 +221,7 @@ static bool mix_tile_bwd_on(const MixDims& m) {
 // what it packed under the address of `saved` (host side: a stamp inside the device buffer could not be read back without a synchronisation); the
 // backward packs what is missing for the route it takes, and the lower pieces of a backward cut into layer ranges follow the top piece.  A buffer
 // this process has no record of (filled through another copy of the library, or 256 forwards ago) is "unknown": the backward then packs for itself.
-enum { MIX_HAS_PRODUCT_PACKS = 1, MIX_HAS_TILE_PACKS = 2, MIX_BWD_TILE = 4, MIX_HAS_SPLIT_PLANES = 8, MIX_PLANES_HEAD = 16 };      // (.._HEAD: the top layer's P3 holds W * w_head)
+enum { MIX_HAS_PRODUCT_PACKS = 1, MIX_HAS_TILE_PACKS = 2, MIX_BWD_TILE = 4, MIX_HAS_SPLIT_PLANES = 8, MIX_PLANES_HEAD = 16, MIX_XLESS = 32 };      // (.._XLESS: the forward did not materialise x_{l+1})      // (.._HEAD: the top layer's P3 holds W * w_head)
 struct MixStamp { const void* sv; int bits; };
 static std::mutex g_mix_stamp_mu;
 static MixStamp g_mix_stamps[256];
@@ -259,7 +259,16 @@ static bool mix_xless(const MixDims& m) {
     // measured (tools/ab_xless.sh, one box): 8192 rows 0.768 -> 0.758 ms, 16 384 rows 1.176 -> 1.156 ms per step; at 65 536 rows NEUTRAL (3.445 vs 3.450 ms:
     // the short-K launches lose 13 us on average, the nine long-K launches with a second operand stream gain 5 us each) -- so only below the batch at
     // which GEMM1 carries the sub-space forward in its epilogue (512 row blocks)
-    return on && m.exact && m.N <= 2 && m.L > 1 && m.B / 128 < 512;
+    // Round 6: with the split-precision products at every batch -- the launch that leaves a layer is HBM-bound there (842 -> 306 MB, 190 -> 108 us), the two
+    // consumers of x_{l+1} pay 34 + 16 us for their second operand stream: 65 536 rows 2.843 / 2.858 -> 2.825 / 2.811 ms per step (one box, alternating),
+    // 0.5 GB less HBM traffic per step.  RECNOW_XLESS=2 forces it for the exact products too, =1 keeps the round-4 rule (A/B).  The rule is read by the FORWARD;
+    // a backward follows what its forward did (the MIX_XLESS stamp of `saved`), whatever the precision switch says by then.
+    static const int mode = []() { const char* e = getenv("RECNOW_XLESS"); return e ? atoi(e) : -1; }();
+    return on && m.exact && m.N <= 2 && m.L > 1 && (mode == 2 || m.B / 128 < 512 || (mode != 1 && rn_gemm_precision() == 1));
+}
+static bool mix_xless_saved(const MixDims& m, const void* sv) {      // what the forward that filled `saved` did (unknown buffer: the rule)
+    const int have = mix_stamp_get(sv);
+    return have >= 0 ? (have & MIX_XLESS) != 0 : mix_xless(m);
 }
 
 static size_t mix_gemm_ws(const MixDims& m) {
@@ -589,9 +598,10 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
         rn_prof_end(pr_pl, st);
         if (rc) return rc;
     }
-    mix_stamp_put(saved, (pack_product ? MIX_HAS_PRODUCT_PACKS : 0) | (tile_fwd ? MIX_HAS_TILE_PACKS : 0) | (planes_on ? MIX_HAS_SPLIT_PLANES | (head ? MIX_PLANES_HEAD : 0) : 0));
-    const float* xl = x;
     const bool xless = mix_xless(m);
+    mix_stamp_put(saved, (pack_product ? MIX_HAS_PRODUCT_PACKS : 0) | (tile_fwd ? MIX_HAS_TILE_PACKS : 0) | (planes_on ? MIX_HAS_SPLIT_PLANES | (head ? MIX_PLANES_HEAD : 0) : 0) |
+                             (xless ? MIX_XLESS : 0));
+    const float* xl = x;
     const bool tile_split = !tile_fwd && mix_tile_split_on(m) && (y || head);
     if (tile_fwd || tile_split) {       // every layer (+ the scoring head) in one launch of row-block workgroups
         RnTileFwd t;
@@ -664,7 +674,7 @@ static int dcnmix_fwd_impl(const float* x, const float* const* U_host, const flo
                 d.sp_bx = gate_host[l]; d.sp_bx_ks = N; d.sp_bx_rs = 1; d.sp_cx = T1 + m.NS; d.sp_cx_ms = m.LDT; d.sp_cx_rs = 1; d.sp_r = N;
                 // a shard small enough for this product to be split over K: the sub-space kernel sums the slabs (and applies act_inner)
                 // on its way in -- no reduction launch
-                if (planes_on && !d.A2) rn_gemm_planes_hint(mix_plane(m, saved, l, 0));
+                if (planes_on) rn_gemm_planes_hint(mix_plane(m, saved, l, 0));
                 if (absorb) rc = rn_gemm_deferred(&d, gws, gws_bytes, st, &red1);
                 else rc = rn_gemm(&d, gws, gws_bytes, st);
                 if (rc) return rc;
@@ -960,7 +970,7 @@ static int dcnmix_bwd_tile(const MixDims& m, const float* x, const float* const*
         {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = xl; d.lda = D; d.a_trans = 1;
-            if (mix_xless(m) && l > 0) { d.A = x; d.A2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.a_mode = RECNOW_OPMODE_MUL; }      // x_l = x0 * O_{l-1} (not stored)
+            if (mix_xless_saved(m, sv) && l > 0) { d.A = x; d.A2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.a_mode = RECNOW_OPMODE_MUL; }      // x_l = x0 * O_{l-1} (not stored)
             d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
             d.C = dWc1; d.ldc = m.NS;
             d.M = D; d.N = m.NS; d.K = (int)B;
@@ -1207,7 +1217,7 @@ static int dcnmix_bwd_exact(const MixDims& m, const float* x, const float* const
         {   // dWc1 = x_l^T dT1[:, :NS] -> dU;  dgate[d][n] = x_l^T dlogits as the side product
             recnow_gemm_desc d = rn_gemm_desc_zero();
             d.A = xl; d.lda = D; d.a_trans = 1;
-            if (mix_xless(m) && l > 0) { d.A = x; d.A2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.a_mode = RECNOW_OPMODE_MUL; }      // x_l = x0 * O_{l-1} (not stored)
+            if (mix_xless_saved(m, sv) && l > 0) { d.A = x; d.A2 = omid + (size_t)(l - 1) * (xbuf(m) / sizeof(float)); d.a_mode = RECNOW_OPMODE_MUL; }      // x_l = x0 * O_{l-1} (not stored)
             d.B = dT1; d.ldb = m.LDT; d.b_trans = 0;
             d.C = dWc1; d.ldc = m.NS;
             d.M = D; d.N = m.NS; d.K = (int)B;

@@ -324,7 +324,7 @@ static int rn_gemm_impl(const recnow_gemm_desc* d, void* ws, size_t ws_bytes, hi
     static const bool split_longk = []() { const char* e = getenv("RECNOW_SPLIT_LONGK"); return !e || e[0] != '0'; }();      // A/B switch (diagnostics: which family an error comes from)
     const bool split_ok = g_gemm_precision == 1 && split_longk && xf == 1 && !d->as_out && !edge && !bk16 && c.BM == 128 && c.BN == 128 && d->b_mode == 0 &&
                           (d->a_mode == RECNOW_OPMODE_NONE || d->a_mode == RECNOW_OPMODE_MUL) &&
-                          ((a_kc && !b_kc && d->a_mode == 0) || (a_kc && b_kc) || (!a_kc && !b_kc));
+                          ((a_kc && !b_kc && (d->a_mode == 0 || planes_ready != nullptr)) || (a_kc && b_kc) || (!a_kc && !b_kc));      // (x0 * O_{l-1}) U: the lean kernel on the caller's planes only
     if (split_ok) tag = RN_TAG_GEMM_SPLIT;
     if (d->mid_V) tag = RN_TAG_GEMM_MIDF;      // a kernel of its own: the product's flops + the whole sub-space forward in one launch
     RnProfRecord* pr = nullptr;

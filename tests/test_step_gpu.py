@@ -285,6 +285,34 @@ def test_step_route_at_the_metric_batch_vs_oracle(dev):
             close(p.grad, rgrads[name], what=name + ' ' + prec, scale=np.abs(rds).sum() if name == 'head/bias' else None)
 
 
+def test_backward_follows_what_its_forward_saved_when_the_precision_flips(dev):
+    """B = 65 536: in split-precision mode the forward does not materialise x_{l+1} = x0 * O_l (csrc/dcnmix.hip `mix_xless`: the consumers form it in their
+    operand loads), in exact mode it does.  The rule is read by the FORWARD; a backward issued after the switch was flipped must follow what its forward
+    left in `saved` (the MIX_XLESS stamp), not the rule of the moment -- it would read a buffer nobody wrote.  Forward phases in one arithmetic, backward in
+    the other, both orders, every gradient against the fp64 oracle."""
+    from rec_now_amd.step import DCNMixPairwiseStep, _GROUP, _FORWARD, _LOSS, _BACKWARD
+    B, D, S, N, L = 65536, 1024, 64, 2, 3
+    x, groups, labels, xd, yd, gd, cross, head = _model(dev, B, D, S, N, L, 777)
+    step = DCNMixPairwiseStep(cross, head, xd, yd, gd)
+    rs, rloss, rds, rP, rdx, rgrads, named = _oracle_step(x, groups, labels, cross, head, L)
+    for fwd_prec, bwd_prec in (('bf16x3', 'f32'), ('f32', 'bf16x3')):
+        for f in step.grads:
+            f.fill_(float('nan'))
+        step.dx.fill_(float('nan'))
+        step._bind_grads()
+        with gemm_precision(fwd_prec):
+            step._call(_GROUP | _FORWARD | _LOSS)
+        with gemm_precision(bwd_prec):
+            step._call(_BACKWARD, L - 1, 0)
+        torch.cuda.synchronize()
+        what = fwd_prec + ' forward, ' + bwd_prec + ' backward'
+        assert int(step.n_pair.item()) == rP
+        close(step.scores, rs, what='scores, ' + what)
+        close(step.dx, rdx, what='dx, ' + what)
+        for name, p in named.items():
+            close(p.grad, rgrads[name], what=name + ', ' + what, scale=np.abs(rds).sum() if name == 'head/bias' else None)
+
+
 def _oracle_step(x, groups, labels, cross, head, L, grouped=True):
     """fp64 chunked oracle of the layers + the C pair oracle: (scores, loss, d loss / d score, pairs, dx, {name: grad}, named weights)."""
     named = dict(cross.named_weights())
