@@ -345,9 +345,14 @@ k_gemm_split(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_b
 // (row = tid & 127, octet = tid >> 7): eight dword loads, one per k row (a wave reads 256 contiguous bytes of each).
 #define S3_BX_MAXK 2048                                   // side weights staged per k-chunk: 2 floats per k
 #define S3_LDS(kchunk) (SPL_BX_OFF + (kchunk) * 8)
-template <bool A_KC, int A2K>
+// PAIR (round 6, second session; [row][k] operands, whole groups of four k-tiles): the A loads of k-tiles (2 j, 2 j + 1) are issued TOGETHER.  A wave load of a
+// k-contiguous operand covers 32 rows x 64 B -- half of each 128-byte line -- and the other half used to be asked for one k-tile (~1 us) later: with 32 CUs x 2
+// workgroups x 2 streams x 3 k-tiles in flight per XCD (6 MB against 4 MB of L2) the line was often gone by then and came from HBM a second time (PMC:
+// `k_gemm_s3<true, 1>` 738 MB per launch for 570 MB of operands).  Three register sets instead of two: E holds the even k-tiles, O1 / O2 the odd ones in turn.
+template <bool A_KC, int A2K, bool PAIR = false>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
 k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_bytes) {
+    static_assert(!PAIR || A_KC, "paired loads: k-contiguous A operands");
     extern __shared__ __attribute__((aligned(16))) char spl_smem[];
     int bx = blockIdx.x, z = blockIdx.z;
     if (p.xcd_remap == 1) {       // as k_gemm: the row tiles of one k-slab become consecutive workgroups of one XCD
@@ -380,7 +385,8 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
     // bench.py's parity inputs (|logit| up to 39) carried an absolute error of 3.5e-6 rms -- row-wide gate errors up to 5.7e-6, by themselves
     // 1.2e-5 of max|d loss / d x| in the worst row of 65 536 (tools/micro/error_budget_cpu.py); this form leaves 2.5e-7 rms.
     double sp0 = 0.0, sp1 = 0.0;
-    float va[2][8], ya[A2K != RECNOW_OPMODE_NONE ? 2 : 1][8];
+    constexpr int NSET = PAIR ? 3 : 2;
+    float va[NSET][8], ya[A2K != RECNOW_OPMODE_NONE ? NSET : 1][8];
     u32x4 bpl[3], wq[3];
 
     auto a_base = [&](int t) { return A_KC ? (int64_t)m0 * p.lda + k_begin + t * SPL_BK : (int64_t)(k_begin + t * SPL_BK) * p.lda + m0; };
@@ -472,9 +478,12 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
         *reinterpret_cast<f32x2*>(spl_smem + SPL_BX_OFF + i * 8) = w;
     }
     // prologue: k-tile 0 -> stage 0; A of k-tiles 1 (set 1) and 2 (set 0), B of k-tile 1 requested
+    // (PAIR: k-tiles 0 and 1 requested together into sets E = 0 and O1 = 1, then 2 and 3 into E and O2 = 2)
+    constexpr int Y1 = A2K != RECNOW_OPMODE_NONE ? 1 : 0, Y2 = A2K != RECNOW_OPMODE_NONE ? 2 : 0;
     a_issue(va[0], ya[0], 0);
+    if constexpr (PAIR) a_issue(va[1], ya[Y1], clampt(1));
     b_issue(0);
-    a_issue(va[1], ya[A2K != RECNOW_OPMODE_NONE ? 1 : 0], clampt(1));
+    if constexpr (!PAIR) a_issue(va[1], ya[Y1], clampt(1));
     __syncthreads();
     a_combine(va[0], ya[0]);
     a_side(va[0], 0);
@@ -483,6 +492,7 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
     a_store(spl_smem);
     b_store(spl_smem);
     a_issue(va[0], ya[0], clampt(2));
+    if constexpr (PAIR) a_issue(va[2], ya[Y2], clampt(3));
     b_issue(clampt(1));
     __syncthreads();
 
@@ -497,10 +507,12 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SA][i], bf[SB][j], acc[i][j], 0, 0, 0);
     // one k-tile: t = its index; SLOT holds A of k-tile t + 1; STG: stage k-tile t + 1 (false: the last k-tile, compute only)
-    auto ktile = [&](int t, auto slot_c, auto stage_c) {
+    // (PAIR: `issue_c` = the set that takes k-tile t + 4 beside SLOT's t + 3, or -1: this k-tile issues no A loads)
+    auto ktile = [&](int t, auto slot_c, auto stage_c, auto issue_c) {
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr int YS = A2K != RECNOW_OPMODE_NONE ? SLOT : 0;
         constexpr bool STG = decltype(stage_c)::value;
+        constexpr int ISS = decltype(issue_c)::value;
         const char* S = spl_smem + (t & 1) * SPL_STAGE;
         char* Sn = spl_smem + ((t & 1) ^ 1) * SPL_STAGE;
         bf16x8 af[3][2], bf[3][2];
@@ -529,7 +541,12 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
         __builtin_amdgcn_sched_barrier(0);
         S3_TERM(1, 1)
         if (STG) {
-            a_issue(va[SLOT], ya[YS], clampt(t + 3));
+            if constexpr (!PAIR) {
+                a_issue(va[SLOT], ya[YS], clampt(t + 3));
+            } else if constexpr (ISS >= 0) {
+                a_issue(va[SLOT], ya[YS], clampt(t + 3));
+                a_issue(va[ISS], ya[A2K != RECNOW_OPMODE_NONE ? ISS : 0], clampt(t + 4));
+            }
             b_store(Sn);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -541,15 +558,32 @@ k_gemm_s3(const GemmK p, const char* __restrict__ b_planes, int64_t b_plane_byte
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using IN = std::integral_constant<int, -1>;
     using BT = std::integral_constant<bool, true>;
     using BF = std::integral_constant<bool, false>;
     int t = 0;
-    for (; t + 2 < nt; t += 2) {
-        ktile(t, I1(), BT());
-        ktile(t + 1, I0(), BT());
+    if constexpr (!PAIR) {
+        for (; t + 2 < nt; t += 2) {
+            ktile(t, I1(), BT(), IN());
+            ktile(t + 1, I0(), BT(), IN());
+        }
+        ktile(t, I1(), BT(), IN());
+        ktile(t + 1, I0(), BF(), IN());
+    } else {
+        // k-tile t stages k-tile t + 1: an odd one from O1 / O2 (t = 0, 2 mod 4), an even one from E (t odd), which then takes k-tile t + 3 while the
+        // odd set that was emptied one k-tile before takes t + 4 -- the two halves of the same 128-byte lines, requested back to back
+        for (; t + 4 < nt; t += 4) {
+            ktile(t, I1(), BT(), IN());
+            ktile(t + 1, I0(), BT(), I1());
+            ktile(t + 2, I2(), BT(), IN());
+            ktile(t + 3, I0(), BT(), I2());
+        }
+        ktile(t, I1(), BT(), IN());
+        ktile(t + 1, I0(), BT(), IN());
+        ktile(t + 2, I2(), BT(), IN());
+        ktile(t + 3, I0(), BF(), IN());
     }
-    ktile(t, I1(), BT());
-    ktile(t + 1, I0(), BF());
 #undef S3_TERM
 
     // side product: the two threads of a row (its two k-octets): adjacent lanes (KC) or 128 threads apart (through LDS)
@@ -588,10 +622,23 @@ static bool s3_shape(const GemmK& k, int a2k) {
     return k.batch == 1 && k.N == 128 && k.sp_r >= 1 && k.sp_r <= 2 && k.kchunk % (2 * SPL_BK) == 0 && k.K % k.kchunk == 0 && k.kchunk <= S3_BX_MAXK &&
            (a2k == RECNOW_OPMODE_NONE || a2k == RECNOW_OPMODE_MUL) && !k.as_out;
 }
-static std::atomic<int> g_s3_lds_ready[4];      // dynamic-LDS attribute raised per instantiation (the default limit is 64 KB; a chunk of 2048 k needs 66 KB)
+static std::atomic<int> g_s3_lds_ready[8];      // dynamic-LDS attribute raised per instantiation (the default limit is 64 KB; a chunk of 2048 k needs 66 KB)
 template <bool A_KC, int A2K>
 static int s3_launch(const GemmK& k, const char* planes, int64_t pb, dim3 grid, hipStream_t st, int slot) {
     const size_t lds = S3_LDS(k.kchunk);
+    // paired A loads (see the kernel): k-contiguous operands, whole groups of four k-tiles, rows that start on a 128-byte line; RECNOW_S3_PAIR=0: A/B switch
+    static const bool pair_on = []() { const char* e = getenv("RECNOW_S3_PAIR"); return !e || e[0] != '0'; }();
+    if constexpr (A_KC) {
+        if (pair_on && k.kchunk % (4 * SPL_BK) == 0 && k.lda % 32 == 0 && ((uintptr_t)k.A & 127) == 0 && (A2K == RECNOW_OPMODE_NONE || ((uintptr_t)k.A2 & 127) == 0)) {
+            if (lds > 64 * 1024 && !g_s3_lds_ready[4 + slot].load(std::memory_order_acquire)) {
+                RN_HIP(hipFuncSetAttribute((const void*)k_gemm_s3<A_KC, A2K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS(S3_BX_MAXK)));
+                g_s3_lds_ready[4 + slot].store(1, std::memory_order_release);
+            }
+            hipLaunchKernelGGL((k_gemm_s3<A_KC, A2K, true>), grid, GEMM_THREADS, lds, st, k, planes, pb);
+            RN_LAUNCH_CHECK();
+            return RECNOW_OK;
+        }
+    }
     if (lds > 64 * 1024 && !g_s3_lds_ready[slot].load(std::memory_order_acquire)) {
         RN_HIP(hipFuncSetAttribute((const void*)k_gemm_s3<A_KC, A2K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS(S3_BX_MAXK)));
         g_s3_lds_ready[slot].store(1, std::memory_order_release);

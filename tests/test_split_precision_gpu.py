@@ -157,3 +157,36 @@ def test_lds_dma_staging_is_bit_identical_to_register_staging(dev, M, K):
         _lib.call('recnow_set_gemm_staging', 0)
     assert np.array_equal(C0, C1) and np.array_equal(Cx0, Cx1)
     assert np.abs(C1 - R).max() <= 1e-5 * np.abs(R).max() and np.abs(Cx1 - Rx).max() <= 1e-5 * np.abs(Rx).max()
+
+
+_PAIR_SNIPPET = r'''
+import hashlib, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from rec_now_amd import _lib
+from test_split_precision_gpu import _product
+_lib.call('recnow_set_gemm_precision', 1)
+dev = torch.device('cuda:0')
+h = hashlib.sha256()
+for mul in (0, 1):
+    C, Cx, _, _ = _product(dev, 2048, 128, 1024, 0, 1, mul, 31 + mul)
+    h.update(C.tobytes()); h.update(Cx.tobytes())
+print('SHA', h.hexdigest())
+'''
+
+
+def test_paired_a_loads_are_bit_identical_to_the_two_set_schedule(dev):
+    """k_gemm_s3's PAIR form (the A loads of k-tiles 2 j and 2 j + 1 requested together: whole 128-byte lines instead of two half-line requests a k-tile
+    apart; csrc/gemm_split.hip) changes WHEN operands are requested, not what is summed in which order: same bits as RECNOW_S3_PAIR=0 (read once per
+    process: two subprocesses), with and without the second A operand."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for v in ('1', '0'):
+        r = subprocess.run([sys.executable, '-c', _PAIR_SNIPPET % (root, os.path.join(root, 'tests'))], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, RECNOW_S3_PAIR=v), cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[v] = [line for line in r.stdout.splitlines() if line.startswith('SHA')][-1]
+    assert out['1'] == out['0']
