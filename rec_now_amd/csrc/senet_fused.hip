@@ -9,6 +9,7 @@
 //             its rows and added up in a fixed order afterwards (deterministic).
 // Limits: equal field widths D % 4 == 0 with D/4 a power of two, F*D/4 <= 256 (a row is one float4 per thread), F <= 64,
 // M <= 64, built-in activations.  Everything else takes the unfused kernels.
+#include <atomic>
 #include "common.hpp"
 #include "gemm.hpp"
 
@@ -123,6 +124,106 @@ k_senet_fused_fwd(const float* const* __restrict__ fields, SfDims dm, int64_t B,
 #pragma unroll
         for (int j = 0; j < SF_R; ++j)
             if (col && b0 + j < B) *reinterpret_cast<sf_f4*>(out + (b0 + j) * FD + t * 4) = v[j] * ws[j * F + f];
+    }
+}
+
+// ---- round 6: the same pass on 8-row tiles with the fields read as 512 contiguous bytes per half wave (D = 16, F % 8 == 0) -----------------------------------
+// The kernel above maps thread t to (field t / 4, chunk t % 4) of ONE row: its wave loads touch 16 field tensors x 64 B each (a quarter of the 256 B that the
+// four rows of a step hold per field), 4.1 TB/s.  Here a half wave reads (8 rows) x (64 B) of ONE field -- 512 contiguous bytes -- the rows change layout in an LDS
+// tile ([row][F D], row stride padded by 16 floats: the eight lanes of a ds_write_b128 group are two rows x four chunks, 16 banks apart) and leave as whole rows
+// (a wave stores 1 KiB of one output row).  Squeeze, excitation and the saved activations as above, per 8 rows.
+#define S8_R 8
+#define S8_LD 1040
+static inline bool sf8_ok(int F, int D, int M) { return D == 16 && F >= 8 && F <= 64 && F % 8 == 0 && M >= 1 && M <= 64; }
+static inline size_t sf8_lds_floats(int F, int M) { return (size_t)2 * F * M + M + F + (size_t)S8_R * (2 * F + M) + (size_t)S8_R * S8_LD; }
+
+__global__ void __launch_bounds__(256)
+k_senet_fused_fwd8(const float* const* __restrict__ fields, SfDims dm, int64_t B, const float* __restrict__ W1, const float* __restrict__ b1,
+                   const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out, float* __restrict__ sq_save,
+                   float* __restrict__ h_save, float* __restrict__ w_save) {
+    extern __shared__ __attribute__((aligned(16))) float sf_lds[];
+    const int F = dm.F, M = dm.M, QT = F * 4, NP = F / 8;
+    constexpr int D = 16;
+    float* w1s = sf_lds;
+    float* w2s = w1s + F * M;
+    float* b1s = w2s + F * M;
+    float* b2s = b1s + M;
+    float* sq = b2s + F;              // [8][F]
+    float* hs = sq + S8_R * F;        // [8][M]
+    float* ws = hs + S8_R * M;        // [8][F]
+    float* X = ws + S8_R * F;         // [8][S8_LD]
+    sf_load_weights(W1, b1, W2, b2, F, M, w1s, w2s, b1s, b2s);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, fi = lane >> 5, r = (lane >> 2) & 7, q = lane & 3;
+    // this thread's field of pass p: 8 p + 2 w + fi; the pointers are fetched once (a per-lane pointer load in front of every row load would be a dependent latency)
+    rn_gcf fp[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) fp[p] = (rn_gcf)fields[(p < NP ? 8 * p : 0) + 2 * w + fi] + 4 * q;
+    const int64_t FD = (int64_t)F * D;
+    int P = 1;
+    while (P < 8 && 2 * P * S8_R * M <= 256) P *= 2;
+    sf_f4 vn[8];
+    auto request = [&](int64_t r0) {
+        const int64_t row = r0 + r < B ? r0 + r : B - 1;
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            vn[p] = *reinterpret_cast<const RN_GLOBAL sf_f4*>(fp[p] + row * D);      // unconditional: passes beyond NP re-read the fields of pass 0
+    };
+    request((int64_t)blockIdx.x * S8_R);
+    for (int64_t b0 = (int64_t)blockIdx.x * S8_R; b0 < B; b0 += (int64_t)gridDim.x * S8_R) {
+        sf_f4 v[8];
+        const bool live = b0 + r < B;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v[p] = (p < NP && live) ? vn[p] : sf_f4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                   // the previous tile is done with X / ws (and the weights are loaded)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (p < NP) {
+                const int f = 8 * p + 2 * w + fi;
+                *reinterpret_cast<sf_f4*>(X + r * S8_LD + f * D + 4 * q) = v[p];
+                float s = (v[p].x + v[p].y) + (v[p].z + v[p].w);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 1, 64);
+                if (q == 0) sq[r * F + f] = s / (float)D;
+            }
+        }
+        {
+            const int64_t nb0 = b0 + (int64_t)gridDim.x * S8_R;
+            request(nb0 < B ? nb0 : b0);
+        }
+        __syncthreads();
+        for (int o = t / P; o < (S8_R * M + 256 / P - 1) / (256 / P) * (256 / P); o += 256 / P) {      // h = act1(sq W1 + b1)
+            const int part = t % P;
+            const bool act = o < S8_R * M;
+            const int j = act ? o / M : 0, m = act ? o - j * M : 0;
+            float a = 0.f;
+            if (act)
+                for (int k = part; k < F; k += P) a += sq[j * F + k] * w1s[k * M + m];
+            for (int x = P / 2; x > 0; x >>= 1) a += __shfl_xor(a, x, 64);
+            if (act && part == 0) {
+                a = rn_act(a + b1s[m], dm.act1);
+                hs[o] = a;
+                if (b0 + j < B) h_save[(b0 + j) * M + m] = a;
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < S8_R * F; i += 256) {          // w = act2(h W2 + b2)
+            const int j = i / F, k = i - j * F;
+            float a = b2s[k];
+            for (int m = 0; m < M; ++m) a += hs[j * M + m] * w2s[m * F + k];
+            a = rn_act(a, dm.act2);
+            ws[i] = a;
+            if (b0 + j < B) {
+                w_save[(b0 + j) * F + k] = a;
+                sq_save[(b0 + j) * F + k] = sq[i];
+            }
+        }
+        __syncthreads();
+        if (t < QT) {
+#pragma unroll
+            for (int j = 0; j < S8_R; ++j)
+                if (b0 + j < B)
+                    *reinterpret_cast<sf_f4*>(out + (b0 + j) * FD + t * 4) = *reinterpret_cast<const sf_f4*>(X + j * S8_LD + t * 4) * ws[j * F + (t >> 2)];
+        }
     }
 }
 
@@ -288,6 +389,24 @@ extern "C" int recnow_senet_fused_fwd(const float* const* fields, int F, int D, 
     if (B == 0) return RECNOW_OK;
     if (!fields || !W1 || !W2 || !out || !sq_save || !h_save || !w_save) return RECNOW_EINVAL;
     const SfDims dm = {F, D, M, act1, act2, (b1 || b2) ? 1 : 0};
+    static const bool tile8 = []() { const char* e = getenv("RECNOW_SENET_TILE8"); return !e || e[0] != '0'; }();      // A/B switch
+    if (tile8 && sf8_ok(F, D, M) && ((uintptr_t)out & 15) == 0) {
+        const size_t lds = sf8_lds_floats(F, M) * sizeof(float);
+        if (lds > 64 * 1024) {
+            static std::atomic<bool> raised[64];
+            int dev = 0;
+            RN_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
+                RN_HIP(hipFuncSetAttribute((const void*)k_senet_fused_fwd8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sf8_lds_floats(64, 64) * sizeof(float))));
+                if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
+            }
+        }
+        int64_t g = (B + S8_R - 1) / S8_R;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(k_senet_fused_fwd8, (int)g, 256, lds, (hipStream_t)stream, fields, dm, B, W1, b1, W2, b2, out, sq_save, h_save, w_save);
+        RN_LAUNCH_CHECK();
+        return RECNOW_OK;
+    }
     hipLaunchKernelGGL(k_senet_fused_fwd, sf_grid(B), 256, sf_lds_floats(F, M) * sizeof(float), (hipStream_t)stream, fields, dm, B, W1,
                        b1, W2, b2, out, sq_save, h_save, w_save);
     RN_LAUNCH_CHECK();
