@@ -190,3 +190,36 @@ def test_paired_a_loads_are_bit_identical_to_the_two_set_schedule(dev):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         out[v] = [line for line in r.stdout.splitlines() if line.startswith('SHA')][-1]
     assert out['1'] == out['0']
+
+
+@pytest.mark.parametrize('mul', [0, 1])
+def test_lean_split_kernel_with_operands_off_a_line_boundary(dev, split_mode, mul):
+    """The PAIR form of k_gemm_s3 needs rows that start on a 128-byte line (it asks for the two halves of a line back to back); an A operand that starts 64 bytes
+    into a line -- a column slice of a wider tensor -- takes the two-set schedule instead (csrc/gemm_split.hip `s3_launch`): same bound against fp64."""
+    from rec_now_amd import _lib
+    M, N, K, off = 1024, 128, 1024, 16
+    rng = np.random.default_rng(77 + mul)
+    wide = rng.standard_normal((M, K + 32)).astype(np.float32)
+    wide2 = rng.uniform(-1, 1, wide.shape).astype(np.float32)
+    Bm = rng.standard_normal((N, K)).astype(np.float32)             # [N][K]: the dT2g layout
+    Bx = rng.standard_normal((K, 2)).astype(np.float32)
+    Wd, W2d, Bd, Bxd = (torch.from_numpy(v).to(dev) for v in (wide, wide2, Bm, Bx))
+    C = torch.empty((M, N), device=dev)
+    Cx = torch.empty((M, 2), device=dev)
+    lib = _lib.load()
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.a_trans = Wd.data_ptr() + 4 * off, K + 32, 0
+    assert d.A % 128 == 64
+    if mul:
+        d.A2, d.a_mode = W2d.data_ptr() + 4 * off, 1
+    d.B, d.ldb, d.b_trans = Bd.data_ptr(), K, 1
+    d.C, d.ldc = C.data_ptr(), N
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    d.sp_bx, d.sp_cx, d.sp_bx_ks, d.sp_bx_rs, d.sp_cx_ms, d.sp_cx_rs, d.sp_r = Bxd.data_ptr(), Cx.data_ptr(), 2, 1, 2, 1, 2
+    ws = _lib.workspace(lib.recnow_gemm_workspace_bytes(ctypes.byref(d)), dev)
+    _lib.call('recnow_gemm', ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.stream())
+    torch.cuda.synchronize()
+    A64 = wide[:, off:off + K].astype(np.float64) * (wide2[:, off:off + K].astype(np.float64) if mul else 1.0)
+    R, Rx = A64 @ Bm.astype(np.float64).T, A64 @ Bx.astype(np.float64)
+    assert np.abs(C.cpu().numpy() - R).max() <= 1e-5 * np.abs(R).max()
+    assert np.abs(Cx.cpu().numpy() - Rx).max() <= 1e-5 * np.abs(Rx).max()
